@@ -1,0 +1,60 @@
+// glv_tables.h -- host-side generation of the constant tables the kernels consume.
+//
+// These are the only places libm's cos()/sin() are evaluated; they run on the host with the
+// same glibc the reference would use, so the tables carry the reference's exact bits:
+//   window    glava/render.c:660 (macro) as expanded at the call site :794
+//   twiddles  glava/render.c:817-836 (float recurrence seeded by double sin)
+//   weights   glava/render.c:661 (macro) as expanded at :766
+// Host compile flags must not contract or reassociate (-ffp-contract=off, no -ffast-math).
+#pragma once
+
+#include <math.h>
+#include <stddef.h>
+
+#include "glv_core.h"
+
+namespace glv {
+
+static const double kTwoPi = 6.28318530718;   // render.c:63 (TWOPI), deliberately not 2*M_PI
+
+// window(i, s->sz - 1) with the macro's unparenthesised `sz`:
+//   0.53836 - 0.46164 * cos(TWOPI * i / N - 1)
+inline void make_window(double* w, size_t n) {
+    for (size_t i = 0; i < n; ++i)
+        w[i] = 0.53836 - (0.46164 * cos(kTwoPi * (double) i / (double) n - 1));
+}
+
+// window_frame(f, avg_frames - 1), same macro quirk: 0.6 - 0.4 * cos(TWOPI * f / F - 1).
+// kind 1 = the GL twin's coefficients (shaders/glava/util/common.glsl:13).
+inline void make_frame_weights(double* w, size_t F, bool use_window, int kind) {
+    for (size_t f = 0; f < F; ++f) {
+        if (!use_window) w[f] = 1.0;
+        else if (kind == 0) w[f] = 0.6 - (0.4 * cos(kTwoPi * (double) f / (double) F - 1));
+        else w[f] = 0.53836 - (0.46164 * cos(kTwoPi * (double) f / (double) F - 1));
+    }
+}
+
+// All radix-2 stages of an nn-point transform: stage with half size L at [L-1, 2L-1).
+inline void make_twiddles(cf* table, size_t nn) {
+    for (size_t L = 1; L < nn; L <<= 1) {
+        const size_t mmax = 2 * L;
+        const float theta = (float) (-(2 * M_PI / (double) mmax));
+        const float wtemp = (float) sin(0.5 * (double) theta);
+        const float wpr = (float) (-2.0 * (double) wtemp * (double) wtemp);
+        const float wpi = (float) sin((double) theta);
+        float wr = 1.0f, wi = 0.0f;
+        cf* t = table + tw_offset((int) L);
+        for (size_t k = 0; k < L; ++k) {
+            t[k].x = wr; t[k].y = wi;
+            const float wt = wr;
+            const float a = wr * wpr, b = wi * wpi;
+            const float ab = a - b;
+            wr = wr + ab;
+            const float c = wi * wpr, d = wt * wpi;
+            const float cd = c + d;
+            wi = wi + cd;
+        }
+    }
+}
+
+}  // namespace glv

@@ -1,0 +1,162 @@
+/*
+ * glv_spectrum.h -- C ABI of the MI355X-native GLava audio-spectrum path.
+ *
+ * Drop-in boundary for GLava's  fifo/pulse_input -> window -> FFT -> magnitude ->
+ * gravity/average  pipeline.  Plain C: pointers, sizes, int status
+ * returns.  No exceptions, no exit(), no torch/HIP types (a HIP stream is passed as
+ * `void*`).  Every entry point names the reference interface it replaces; paths are
+ * relative to the jarcode-foss/glava tree.
+ *
+ * The library is libglvspectrum.so (glava_amd/csrc), hand-written HIP for gfx950.  There
+ * is NO CPU fallback: without a usable HIP device every compute entry point returns
+ * GLV_ERR_NO_DEVICE and glv_last_error() says why.
+ */
+#ifndef GLV_SPECTRUM_H
+#define GLV_SPECTRUM_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GLV_ABI_VERSION 1
+
+/* status codes (0 = ok).  The reference has no error channel: it prints and calls
+ * glava_abort() (glava/glava.h:17, glava/render.c passim); the in-tree shim maps any
+ * non-zero status to that. */
+enum {
+    GLV_OK = 0,
+    GLV_ERR_INVALID = 1,     /* bad argument (n not a power of two in [512,16384], NULL, ...) */
+    GLV_ERR_NO_DEVICE = 2,   /* no HIP device / kernels for gfx950 not loadable */
+    GLV_ERR_HIP = 3,         /* a HIP runtime call failed; see glv_last_error() */
+    GLV_ERR_NOMEM = 4,
+    GLV_ERR_STATE = 5        /* operator used on a batch/state that lacks the required buffers */
+};
+
+/* Operator selection for the batched calls (bit set).  The order of application is
+ * fixed and is the reference's: fft -> gravity -> average (glava/render.c:2140-2156). */
+enum {
+    GLV_OP_FFT      = 1u << 0,  /* window + FFT + abs/log/tilt   == transform_fft     render.c:783-847 */
+    GLV_OP_GRAVITY  = 1u << 1,  /*                               == transform_gravity render.c:720-736 */
+    GLV_OP_AVERAGE  = 1u << 2,  /*                               == transform_average render.c:738-771 */
+    GLV_OP_RAW      = 1u << 3,  /* testing aid: with GLV_OP_FFT, skip abs/log/tilt and emit the raw
+                                   interleaved (Re,Im) FFT output, which must be bit-identical to the
+                                   reference's data[] at render.c:840 */
+    GLV_OP_WRANGE   = 1u << 4,  /* (b+1)/2                       == transform_wrange  render.c:773-781;
+                                   exclusive with GLV_OP_FFT (the wave module requests window,wrange) */
+    GLV_OP_BARS     = 1u << 5   /* smooth_audio() bin averaging + bar lookup (shaders/glava/util/
+                                   smooth.glsl:13-64, radial/1.frag:58-70): emit `bars` values per
+                                   channel instead of n bins */
+};
+
+/* Mirrors the fields of the private `struct gl_data` that the path reads
+ * (glava/render.c:166-207) and of `struct audio_data` (glava/fifo.h:9-20). */
+typedef struct glv_params {
+    uint32_t n;             /* audio_buf_sz / bsz: real samples per channel; power of two in [512, 16384]
+                               (#request setbufsize, render.c:1176).  Complex FFT length is n/2 (render.c:786) */
+    uint32_t channels;      /* 2 = stereo, 1 = mirror/mono mix (fifo.c:98-102, setmirror render.c:1053) */
+    float fft_scale;        /* render.c:845, default 10.2 (render.c:930) */
+    float fft_cutoff;       /* render.c:845, default 0.3  (render.c:931) */
+    float gravity_step;     /* render.c:728, default 4.2  (render.c:911) */
+    float ur;               /* updates per second used by gravity (render.c:728); the reference measures it
+                               (render.c:2387); ideal value rate/(sample_sz/4) */
+    uint32_t avg_frames;    /* F, render.c:743; 1..GLV_MAX_AVG_FRAMES */
+    uint32_t avg_window;    /* bool, render.c:745/765 */
+    uint32_t avg_window_kind; /* 0: CPU twin 0.6/0.4, oldest-first (render.c:661,751-766)
+                                 1: GL twin 0.53836/0.46164, newest-first (common.glsl:13, average_pass.frag:19-45,
+                                    render.c:2247-2256) */
+    uint32_t log_mode;      /* 0: fp64 log (bit-faithful to the reference's libm call up to the last-ulp
+                                  behaviour of log()); 1: fast fp32-pair log, <= 2e-7 relative */
+    /* GLV_OP_BARS parameters (shaders/glava/smooth_parameters.glsl) */
+    uint32_t bars;          /* bars per channel (radial.glsl:9 NBARS 160 => 80) */
+    float smooth_factor;    /* SMOOTH_FACTOR, smooth_parameters.glsl:72, default 0.025 */
+} glv_params;
+
+#define GLV_MAX_AVG_FRAMES 16
+
+/* Fill `p` with the shipped defaults (shaders/glava/rc.glsl:181-211,
+ * shaders/glava/smooth_parameters.glsl:46-67): n=4096, stereo, 10.2/0.3, 4.2,
+ * ur = 22050/256, F=5 windowed. */
+void glv_params_default(glv_params* p);
+
+/* Version / diagnostics. */
+int         glv_abi_version(void);
+const char* glv_last_error(void);          /* thread-local, never NULL */
+int         glv_device_count(void);        /* 0 when no HIP device is usable */
+
+/* ------------------------------------------------------------------------------------
+ * 1. Single-stream drop-ins (host pointers, in place).  Same shape as the reference's
+ *    operator seam  void apply(struct gl_data*, void** udata, void* data)
+ *    (glava/render.c:106-118, table at :849-856).  `glv_state` replaces the `*udata`
+ *    slot (lazily calloc'd by the reference, render.c:662-666, and free()d by
+ *    rd_destroy, render.c:2463-2469); here it is created/destroyed explicitly.
+ * ------------------------------------------------------------------------------------ */
+typedef struct glv_state glv_state;   /* per (channel, stream) device-side gravity + history state */
+
+int glv_state_create(const glv_params* p, int device, glv_state** out);
+int glv_state_reset(glv_state* s);            /* zero gravity/history (== fresh calloc) */
+int glv_state_destroy(glv_state* s);
+
+/* == transform_fft(gl, _, &(struct gl_sampler_data){buf, p->n})   glava/render.c:783-847 */
+int glv_fft(const glv_params* p, glv_state* s, float* buf);
+/* == transform_gravity                                             glava/render.c:720-736 */
+int glv_gravity(const glv_params* p, glv_state* s, float* buf);
+/* == transform_average                                             glava/render.c:738-771 */
+int glv_average(const glv_params* p, glv_state* s, float* buf);
+/* == transform_wrange                                              glava/render.c:773-781 */
+int glv_wrange(const glv_params* p, glv_state* s, float* buf);
+/* fft -> gravity -> average in one launch (what handle_audio does per bind, render.c:2140-2156) */
+int glv_fft_gravity_average(const glv_params* p, glv_state* s, float* buf);
+
+/* == the unpack loop of the FIFO backend, glava/fifo.c:94-110 (and :67-79 when pcm == NULL):
+ * `frames` interleaved stereo s16 frames -> planar f32.  Runs on the device (the bit-exactness
+ * of int16 -> f32 /65535f is part of the parity contract). */
+int glv_unpack_s16(int device, const int16_t* pcm, size_t frames, int channels, float* l, float* r);
+
+/* ------------------------------------------------------------------------------------
+ * 2. Batched extension (device pointers, stream-ordered).  No reference counterpart:
+ *    B independent stereo streams, one update ("frame") of every stream per call.
+ *    Layouts (row-major):
+ *      d_pcm   int16 [streams][n][2]     interleaved LRLR, exactly the bytes a FIFO delivers
+ *      d_f32   float [streams][2][n]     planar, what glava.c:528-537 snapshots into lb/rb
+ *      d_spec  float [streams][2][n]     out; index 2k = |Re Z_k| path, 2k+1 = |Im Z_k| path
+ *      d_bars  float [streams][2][bars]  out when GLV_OP_BARS
+ *    State (gravity [streams][2][n], history ring [streams][2][F][n]) is owned by the
+ *    batch and allocated according to `ops_mask` given at creation.
+ * ------------------------------------------------------------------------------------ */
+typedef struct glv_batch glv_batch;
+
+int glv_batch_create(const glv_params* p, uint32_t streams, unsigned ops_mask, int device, glv_batch** out);
+int glv_batch_reset(glv_batch* b);
+int glv_batch_destroy(glv_batch* b);
+
+/* one update of every stream from s16 PCM already resident in HBM */
+int glv_batch_process_s16(glv_batch* b, const int16_t* d_pcm, float* d_out, unsigned ops, void* hip_stream);
+/* same from planar f32 (the lb/rb snapshot) */
+int glv_batch_process_f32(glv_batch* b, const float* d_f32, float* d_out, unsigned ops, void* hip_stream);
+
+/* FIFO ring mode (glava/fifo.c:91-112): the batch keeps an n-frame s16 ring per stream in
+ * HBM; each call appends `new_frames` (= sample_sz/4, fifo.c:38,91) stereo frames per
+ * stream (d_new int16 [streams][new_frames][2]; NULL => poll-timeout zero fill,
+ * fifo.c:67-79), then transforms the whole window. */
+int glv_batch_ring_update_s16(glv_batch* b, const int16_t* d_new, uint32_t new_frames, float* d_out,
+                              unsigned ops, void* hip_stream);
+
+/* Kernel-time accounting for the roofline report: HIP events recorded on the caller's
+ * stream around every launch between begin/end; returns accumulated milliseconds and the
+ * number of launches of the dominant (FFT) kernel. */
+int glv_batch_timing_begin(glv_batch* b);
+int glv_batch_timing_end(glv_batch* b, double* kernel_ms, uint64_t* launches);
+
+/* Algorithmic HBM bytes one process call moves for the given ops. */
+uint64_t glv_batch_algorithmic_bytes(const glv_batch* b, unsigned ops, int input_is_s16);
+
+/* Name of the kernel the last process call launched (for matching rocprofv3 rows). */
+const char* glv_batch_kernel_name(const glv_batch* b);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GLV_SPECTRUM_H */

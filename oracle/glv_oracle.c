@@ -1,0 +1,222 @@
+/*
+ * oracle/glv_oracle.c -- TEST INFRASTRUCTURE ONLY.
+ *
+ * CPU restatement (plain C, scalar, one thread) of the GLava audio-spectrum hot path.
+ * It exists so the HIP path can be checked where the reference itself cannot be
+ * linked (the GPU box has no /root/reference) and so intermediate values the
+ * reference never exposes (the FFT before abs/log) can be compared bit-for-bit.
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load it.
+ * The product library (glava_amd/csrc) never includes, links or calls anything here.
+ *
+ * Pinning: the reference's tests hold no golden vector for this path (SURVEY.md 4 /
+ * 8c), so this file is pinned against the *compiled reference itself*
+ * (oracle/_ref/libglvref.so, built from /root/reference by oracle/Makefile):
+ * tests/test_oracle_vs_ref.py demands bit equality on every function below, and the
+ * vectors in tests/golden/ were produced by the compiled reference
+ * (tests/golden/make_golden.py).
+ *
+ * Each function cites the reference lines it restates (paths relative to
+ * /root/reference).  The structure is deliberately different from the reference
+ * (Stockham autosort instead of bit-reversal + in-place Danielson-Lanczos, explicit
+ * twiddle tables, a ring instead of memmove) -- the *arithmetic per output bit* is
+ * what is being restated.  Build with -O2 -ffp-contract=off, no -march=native, no
+ * -ffast-math (meson.build:5 builds the reference at optimization=2 on baseline x86-64,
+ * which has no FMA).
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define GLVO_TWOPI 6.28318530718 /* glava/render.c:63 -- a truncated 2*pi, on purpose */
+
+/* ---- a2: s16 interleaved -> planar f32 (glava/fifo.c:94-110) -------------------------
+ * stereo: l = L/65535f, r = R/65535f.  mono (channels == 1): ((L + R) / 2) with C int
+ * arithmetic (truncation toward zero), then /65535f, written to both channels. */
+void glvo_unpack_s16(const int16_t* pcm, size_t frames, int channels, float* l, float* r) {
+    for (size_t n = 0; n < frames; ++n) {
+        int a = pcm[2 * n], b = pcm[2 * n + 1];
+        if (channels == 1) {
+            float s = (float) ((a + b) / 2) / (float) 65535;
+            l[n] = s; r[n] = s;
+        } else {
+            l[n] = (float) a / (float) 65535;
+            r[n] = (float) b / (float) 65535;
+        }
+    }
+}
+
+/* a3: f32 interleaved -> planar (glava/pulse_input.c:155-178); mono = (L+R)/2 in float */
+void glvo_unpack_f32(const float* pcm, size_t frames, int channels, float* l, float* r) {
+    for (size_t n = 0; n < frames; ++n) {
+        if (channels == 1) {
+            float s = (pcm[2 * n] + pcm[2 * n + 1]) / 2;
+            l[n] = s; r[n] = s;
+        } else { l[n] = pcm[2 * n]; r[n] = pcm[2 * n + 1]; }
+    }
+}
+
+/* a2: ring update (glava/fifo.c:91-92 shift, :94-110 append, :67-79 zero fill).
+ * `pcm == NULL` restates the poll-timeout branch. ring_l/ring_r hold fsz floats. */
+void glvo_ring_update_s16(float* ring_l, float* ring_r, size_t fsz, const int16_t* pcm,
+                          size_t new_frames, int channels) {
+    memmove(ring_l, ring_l + new_frames, (fsz - new_frames) * sizeof(float));
+    memmove(ring_r, ring_r + new_frames, (fsz - new_frames) * sizeof(float));
+    if (pcm) glvo_unpack_s16(pcm, new_frames, channels, ring_l + fsz - new_frames, ring_r + fsz - new_frames);
+    else {
+        memset(ring_l + fsz - new_frames, 0, new_frames * sizeof(float));
+        memset(ring_r + fsz - new_frames, 0, new_frames * sizeof(float));
+    }
+}
+
+/* ---- a7(i): the window (glava/render.c:660 macro, call site :794) ---------------------
+ * window(i, s->sz - 1) expands, because the macro does not parenthesise `sz`, to
+ *   0.53836 - 0.46164*cos(TWOPI*(double)i/(double)N - 1)
+ * i.e. Hamming coefficients, period N, shifted by one radian. */
+double glvo_window(size_t i, size_t n) {
+    return 0.53836 - (0.46164 * cos(GLVO_TWOPI * (double) i / (double) n - 1));
+}
+void glvo_window_table(double* w, size_t n) {
+    for (size_t i = 0; i < n; ++i) w[i] = glvo_window(i, n);
+}
+void glvo_apply_window(float* data, size_t n) {
+    for (size_t i = 0; i < n; ++i) data[i] = (float) ((double) data[i] * glvo_window(i, n));
+}
+
+/* ---- a7(iii): per-stage twiddles by the reference's float recurrence -------------------
+ * (glava/render.c:817-836).  Stage with complex half-size L (reference mmax = 2L).
+ * tw: L complex floats (re, im interleaved). */
+void glvo_twiddles(float* tw, size_t L) {
+    size_t mmax = 2 * L;
+    float theta = -(2 * M_PI / mmax);
+    float wtemp = sin(0.5 * theta);
+    float wpr   = -2.0 * wtemp * wtemp;
+    float wpi   = sin(theta);
+    float wr = 1.0, wi = 0.0;
+    for (size_t k = 0; k < L; ++k) {
+        tw[2 * k] = wr; tw[2 * k + 1] = wi;
+        float t = wr;
+        float a = wr * wpr, b = wi * wpi; wr = wr + (a - b);
+        float c = wi * wpr, d = t * wpi;  wi = wi + (c + d);
+    }
+}
+
+/* a7(ii)+(iii): Stockham radix-2 autosort restatement of bit-reversal + in-place DIT
+ * (glava/render.c:797-840).  Natural order in, natural order out; each butterfly does
+ * exactly the reference's six roundings (render.c:826-832).  In place on data[0..2nn). */
+void glvo_fft_core(float* data, size_t nn) {
+    float* x = malloc(sizeof(float) * 2 * nn);
+    float* y = malloc(sizeof(float) * 2 * nn);
+    float* tw = malloc(sizeof(float) * 2 * (nn > 1 ? nn / 2 : 1));
+    memcpy(x, data, sizeof(float) * 2 * nn);
+    for (size_t L = 1; L < nn; L <<= 1) {
+        glvo_twiddles(tw, L);
+        size_t m = nn / (2 * L);               /* x viewed as [2][m][L], y as [m][2][L] */
+        for (size_t j = 0; j < m; ++j)
+            for (size_t k = 0; k < L; ++k) {
+                float wr = tw[2 * k], wi = tw[2 * k + 1];
+                const float* a = x + 2 * (j * L + k);
+                const float* b = x + 2 * ((m + j) * L + k);
+                float p0 = wr * b[0], p1 = wi * b[1]; float tr = p0 - p1;
+                float p2 = wr * b[1], p3 = wi * b[0]; float ti = p2 + p3;
+                float* lo = y + 2 * ((2 * j) * L + k);
+                float* hi = y + 2 * ((2 * j + 1) * L + k);
+                hi[0] = a[0] - tr; hi[1] = a[1] - ti;
+                lo[0] = a[0] + tr; lo[1] = a[1] + ti;
+            }
+        float* t = x; x = y; y = t;
+    }
+    memcpy(data, x, sizeof(float) * 2 * nn);
+    free(x); free(y); free(tw);
+}
+
+/* a7(iv): per-float abs, log, tilt (glava/render.c:842-846). */
+float glvo_tilt(size_t n, size_t sz, float fft_scale, float fft_cutoff) {
+    float t = (((float) n / (float) sz) * fft_scale) + (1.0F - fft_cutoff);
+    return t > 1.0F ? t : 1.0F;
+}
+void glvo_magnitude(float* data, size_t sz, float fft_scale, float fft_cutoff) {
+    for (size_t n = 0; n < sz; ++n) {
+        float x = data[n];
+        if (x < 0.0F) x = -x;
+        x = (float) (log((double) (x + 1)) / 3);
+        x *= glvo_tilt(n, sz, fft_scale, fft_cutoff);
+        data[n] = x;
+    }
+}
+
+/* a7: the whole transform_fft (glava/render.c:783-847).  If raw_out != NULL the FFT
+ * output before abs/log/tilt is copied there (not observable in the reference). */
+void glvo_transform_fft(float* data, size_t sz, float fft_scale, float fft_cutoff, float* raw_out) {
+    glvo_apply_window(data, sz);
+    glvo_fft_core(data, sz / 2);
+    if (raw_out) memcpy(raw_out, data, sz * sizeof(float));
+    glvo_magnitude(data, sz, fft_scale, fft_cutoff);
+}
+
+/* ---- a8: gravity (glava/render.c:720-736).  state: sz floats, zero-initialised. */
+void glvo_gravity(float* b, float* applied, size_t sz, float gravity_step, float ur) {
+    float g = gravity_step * (1.0F / ur);
+    for (size_t t = 0; t < sz; ++t) {
+        if (b[t] >= applied[t]) applied[t] = b[t] - g;
+        else applied[t] -= g;
+        b[t] = applied[t];
+    }
+}
+
+/* ---- a9: F-frame (optionally windowed) average (glava/render.c:738-771).
+ * The reference shifts a [F][sz] history with memmove; here it is a ring:
+ * `hist` is [F][sz], `*head` is the slot that receives the current frame, and age
+ * order oldest..newest is head+1, head+2, ..., head (mod F).  window_frame(f, F-1)
+ * expands (macro at render.c:661, call at :766) to 0.6 - 0.4*cos(TWOPI*f/F - 1). */
+double glvo_frame_weight(size_t f, size_t F, int use_window) {
+    if (!use_window) return 1.0;
+    return 0.6 - (0.4 * cos(GLVO_TWOPI * (double) f / (double) F - 1));
+}
+void glvo_average(float* b, float* hist, size_t* head, size_t sz, size_t F, int use_window) {
+    memcpy(hist + (*head) * sz, b, sz * sizeof(float));
+    for (size_t t = 0; t < sz; ++t) {
+        float v = 0.0F;
+        for (size_t f = 0; f < F; ++f) {
+            size_t slot = (*head + 1 + f) % F;
+            if (use_window) v = (float) ((double) v + glvo_frame_weight(f, F, 1) * (double) hist[slot * sz + t]);
+            else            v = v + (float) 1 * hist[slot * sz + t];
+        }
+        b[t] = v / (float) F;
+    }
+    *head = (*head + 1) % F;
+}
+
+/* ---- a10: wrange (glava/render.c:773-781) */
+void glvo_wrange(float* b, size_t sz) {
+    for (size_t t = 0; t < sz; ++t) { float x = b[t] + 1.0F; b[t] = x / 2.0F; }
+}
+
+/* ---- whole stereo frame from PCM, the unit the batched GPU path processes --------------
+ * pcm: [n][2] s16; out: [2][n]; grav: [2][n] state or NULL; hist: [2][F][n] or NULL.
+ * Order of operators as handle_audio applies them (glava/render.c:2140-2156):
+ * fft -> gravity -> average, per channel. */
+void glvo_frame_s16(const int16_t* pcm, size_t n, int channels, float fft_scale, float fft_cutoff,
+                    float* out, float* raw_out,
+                    float* grav, float gravity_step, float ur,
+                    float* hist, size_t* heads, size_t F, int use_window) {
+    glvo_unpack_s16(pcm, n, channels, out, out + n);
+    for (int c = 0; c < 2; ++c) {
+        glvo_transform_fft(out + c * n, n, fft_scale, fft_cutoff, raw_out ? raw_out + c * n : NULL);
+        if (grav) glvo_gravity(out + c * n, grav + c * n, n, gravity_step, ur);
+        if (hist) glvo_average(out + c * n, hist + c * F * n, heads + c, n, F, use_window);
+    }
+}
+
+/* CPU-baseline helper for bench.py ("port" kind): process `frames` stereo frames of the
+ * same PCM layout the GPU sees; returns a checksum so the work cannot be elided. */
+double glvo_bench_frames(const int16_t* pcm, size_t frames, size_t n, float fft_scale, float fft_cutoff) {
+    float* out = malloc(sizeof(float) * 2 * n);
+    double acc = 0;
+    for (size_t f = 0; f < frames; ++f) {
+        glvo_frame_s16(pcm + f * 2 * n, n, 2, fft_scale, fft_cutoff, out, NULL, NULL, 0, 1, NULL, NULL, 0, 0);
+        acc += out[1] + out[n + 1];
+    }
+    free(out);
+    return acc;
+}

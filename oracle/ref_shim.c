@@ -1,0 +1,155 @@
+/*
+ * oracle/ref_shim.c -- TEST INFRASTRUCTURE ONLY (never linked into the product library).
+ *
+ * Thin C wrapper around the *unmodified* reference sources where they lie under
+ * /root/reference (nothing is copied into this repository).  `glava/render.c` is
+ * unity-included so that the private `struct gl_data` / `struct gl_sampler_data`
+ * (render.c:106-118, 166-207) and the non-static operators
+ *     transform_fft      render.c:783-847
+ *     transform_gravity  render.c:720-736
+ *     transform_average  render.c:738-771
+ *     transform_wrange   render.c:773-781
+ *     transform_smooth   render.c:694-718
+ * are visible.  `glava/fifo.c` is compiled as its own TU (see Makefile) and its
+ * `entry` (fifo.c:29-127) is reached through the `audio_impls[]` registry exactly as
+ * glava.c:469-479 does.
+ *
+ * Output: oracle/_ref/libglvref.so (git-ignored, travels to the GPU box prebuilt).
+ * The build is skipped when /root/reference is absent.
+ */
+#include "/root/reference/glava/render.c"
+
+#include <fcntl.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+/* Symbols that rd_new()/rd_update() reference but the audio transforms never call. */
+struct gl_wcb wcb_glx;
+void xwin_assign_icon_bmp(struct gl_wcb* a, void* b, const char* c) { (void) a; (void) b; (void) c; }
+unsigned int xwin_copyglbg(struct glava_renderer* r, unsigned int t) { (void) r; (void) t; return 0; }
+bool xwin_should_render(struct gl_wcb* a, void* b) { (void) a; (void) b; return true; }
+void xwin_wait_for_wm(void) {}
+
+typedef struct {
+    float fft_scale, fft_cutoff, gravity_step, ur, smooth_distance, smooth_ratio;
+    unsigned long avg_frames;
+    int avg_window;
+} glvref_params;
+
+static void fill(struct gl_data* gl, const glvref_params* p) {
+    memset(gl, 0, sizeof(*gl));
+    gl->fft_scale       = p->fft_scale;
+    gl->fft_cutoff      = p->fft_cutoff;
+    gl->gravity_step    = p->gravity_step;
+    gl->ur              = p->ur;
+    gl->avg_frames      = p->avg_frames;
+    gl->avg_window      = p->avg_window != 0;
+    gl->smooth_distance = p->smooth_distance;
+    gl->smooth_ratio    = p->smooth_ratio;
+}
+
+/* One persistent state slot per (channel, transform), calloc'd by the callee
+ * (ALLOC_ONCE, render.c:662-666); pass the address of a NULL-initialised pointer. */
+void glvref_fft(const glvref_params* p, float* buf, size_t n) {
+    struct gl_data gl; fill(&gl, p);
+    struct gl_sampler_data d = { .buf = buf, .sz = n };
+    void* slot = NULL;
+    transform_fft(&gl, &slot, &d);
+}
+void glvref_gravity(const glvref_params* p, void** slot, float* buf, size_t n) {
+    struct gl_data gl; fill(&gl, p);
+    struct gl_sampler_data d = { .buf = buf, .sz = n };
+    transform_gravity(&gl, slot, &d);
+}
+void glvref_average(const glvref_params* p, void** slot, float* buf, size_t n) {
+    struct gl_data gl; fill(&gl, p);
+    struct gl_sampler_data d = { .buf = buf, .sz = n };
+    transform_average(&gl, slot, &d);
+}
+void glvref_wrange(const glvref_params* p, float* buf, size_t n) {
+    struct gl_data gl; fill(&gl, p);
+    struct gl_sampler_data d = { .buf = buf, .sz = n };
+    void* slot = NULL;
+    transform_wrange(&gl, &slot, &d);
+}
+void glvref_smooth(const glvref_params* p, float* buf, size_t n) {
+    struct gl_data gl; fill(&gl, p);
+    struct gl_sampler_data d = { .buf = buf, .sz = n };
+    void* slot = NULL;
+    transform_smooth(&gl, &slot, &d);
+}
+void glvref_slot_free(void** slot) { free(*slot); *slot = NULL; }
+
+/* ---- FIFO backend driven through the plugin registry (fifo.h:22-44) ------------------ */
+#include "/root/reference/glava/fifo.h"
+
+/* Feeds `chunks` updates of `ssz` bytes each through a real named pipe into the
+ * reference's fifo `entry` thread and snapshots both rings after every *data* update.
+ * rings_out: [chunks][2][fsz] floats (L then R).  Poll-timeout zero-fills
+ * (fifo.c:67-79) that slip in while we are not writing are reported in *zero_fills
+ * and also applied by the caller's model.  Returns 0 on success. */
+int glvref_fifo_run(const char* fifo_path, const int16_t* pcm, size_t chunks, size_t ssz,
+                    size_t fsz, int channels, float* rings_out, unsigned char* was_zero_fill,
+                    size_t max_events, size_t* n_events) {
+    struct audio_impl* impl = NULL;
+    for (size_t t = 0; t < audio_impls_idx; ++t)
+        if (!strcmp(audio_impls[t]->name, "fifo")) impl = audio_impls[t];
+    if (!impl) return -1;
+
+    unlink(fifo_path);
+    if (mkfifo(fifo_path, 0600) != 0) return -2;
+
+    float* bl = calloc(fsz, sizeof(float));
+    float* br = calloc(fsz, sizeof(float));
+    struct audio_data audio = {
+        .audio_out_r = br, .audio_out_l = bl, .modified = false,
+        .audio_buf_sz = fsz, .sample_sz = ssz, .format = -1, .rate = 22050,
+        .source = strdup(fifo_path), .channels = channels, .terminate = 0,
+        .mutex = PTHREAD_MUTEX_INITIALIZER
+    };
+    pthread_t thr;
+    pthread_create(&thr, NULL, impl->entry, &audio);
+    int wfd = open(fifo_path, O_WRONLY);   /* blocks until the reader opened it */
+    if (wfd < 0) return -3;
+
+    size_t ev = 0, sent = 0;
+    int rc = 0;
+    while (sent < chunks && ev < max_events) {
+        if (write(wfd, (const char*) pcm + sent * ssz, ssz) != (ssize_t) ssz) { rc = -4; break; }
+        /* wait for this chunk to land; record any zero-fill that happened first */
+        bool landed = false;
+        while (!landed && ev < max_events) {
+            pthread_mutex_lock(&audio.mutex);
+            if (audio.modified) {
+                audio.modified = false;
+                /* a data update ends in our samples; a zero fill ends in ssz/4 zeros.
+                   Distinguish by asking whether the pipe is drained: the reader sets
+                   `modified` under the same mutex right after consuming the bytes. */
+                bool all_zero = true;
+                for (size_t q = fsz - ssz / 4; q < fsz; ++q)
+                    if (bl[q] != 0.0f || br[q] != 0.0f) { all_zero = false; break; }
+                bool input_zero = true;
+                for (size_t q = 0; q < ssz / 2; ++q)
+                    if (pcm[sent * (ssz / 2) + q] != 0) { input_zero = false; break; }
+                bool zf = all_zero && !input_zero;
+                memcpy(rings_out + (ev * 2 + 0) * fsz, bl, fsz * sizeof(float));
+                memcpy(rings_out + (ev * 2 + 1) * fsz, br, fsz * sizeof(float));
+                was_zero_fill[ev] = zf;
+                ++ev;
+                if (!zf) landed = true;
+            }
+            pthread_mutex_unlock(&audio.mutex);
+            if (!landed) usleep(200);
+        }
+        ++sent;
+    }
+    /* the thread notices `terminate` after its next event; with nothing written that
+       event is the poll timeout (fifo.c:63-79,119-122), a few ms away */
+    audio.terminate = 1;
+    pthread_join(thr, NULL);
+    close(wfd);
+    unlink(fifo_path);
+    free(audio.source); free(bl); free(br);
+    *n_events = ev;
+    return rc;
+}

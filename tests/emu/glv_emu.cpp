@@ -1,0 +1,120 @@
+// tests/emu/glv_emu.cpp -- host "kernel emulator" (test infrastructure).
+//
+// Runs the very same per-thread phase functions the gfx950 kernel runs (glava_amd/csrc/
+// glv_frame.h), but walks tid = 0..T-1 sequentially per phase where the kernel has T lanes
+// and a barrier, with a plain array standing in for LDS.  It exists so that the index
+// maps, the pass plan, the twiddle gathering and the epilogue state machine are checked
+// against the oracle on the CPU-only container; it is NOT a fallback and the product
+// library never links it.
+//
+// Build: g++ -O2 -std=c++17 -ffp-contract=off -shared -fPIC (tests/conftest.py does it).
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include "../../glava_amd/csrc/glv_frame.h"
+#include "../../glava_amd/csrc/glv_tables.h"
+
+using namespace glv;
+
+template <int LOG_NN, int LOG_MODE>
+struct Emu {
+    using FR = Frame<LOG_NN>;
+    static constexpr int T = FR::T, P = FR::P, NN = FR::NN, N = FR::N;
+
+    struct Thread { cf v[16]; };
+
+    template <int PASS>
+    static void run_pass(std::vector<Thread>& th, std::vector<cf>& lds, const cf* table) {
+        for (int tid = 0; tid < T; ++tid) {
+            if constexpr (PASS > 0) FR::template exchange_read<PASS>(th[tid].v, lds.data(), tid);
+        }
+        // (barrier) -- all reads done before the next exchange overwrites the region
+        for (int tid = 0; tid < T; ++tid) {
+            cf tw[FR::template PassInfo<PASS>::NTW];
+            FR::template gather_tw<PASS>(tw, table, tid);
+            FR::template compute<PASS>(th[tid].v, tw);
+            if constexpr (PASS < P - 1) FR::template exchange_write<PASS>(lds.data(), th[tid].v, tid);
+        }
+        // (barrier)
+        if constexpr (PASS < P - 1) run_pass<PASS + 1>(th, lds, table);
+    }
+
+    // one channel row given register-resident inputs -> out_row
+    static void finish(std::vector<Thread>& th, float* out_row, size_t row, const FrameArgs& a) {
+        for (int tid = 0; tid < T; ++tid) FR::template epilogue<LOG_MODE>(th[tid].v, out_row, row, tid, a);
+    }
+
+    static void frame_s16(const int16_t* frame, size_t unit, const FrameArgs& a) {
+        std::vector<Thread> th(T);
+        std::vector<cf> lds(NN);
+        std::vector<typename FR::Pcm> pcm(T);
+        for (int tid = 0; tid < T; ++tid) FR::load_pcm(pcm[tid], frame, tid);
+        for (int ch = 0; ch < 2; ++ch) {
+            for (int tid = 0; tid < T; ++tid) {
+                if (ch == 0) FR::template unpack_window<0>(th[tid].v, pcm[tid], a.win, tid, a.mono != 0);
+                else         FR::template unpack_window<1>(th[tid].v, pcm[tid], a.win, tid, a.mono != 0);
+            }
+            run_pass<0>(th, lds, a.tw);
+            const size_t row = unit * 2 + ch;
+            finish(th, a.out + row * N, row, a);
+        }
+    }
+    static void row_f32(const float* in_row, size_t row, const FrameArgs& a) {
+        std::vector<Thread> th(T);
+        std::vector<cf> lds(NN);
+        for (int tid = 0; tid < T; ++tid) FR::load_f32_window(th[tid].v, in_row, a.win, tid);
+        run_pass<0>(th, lds, a.tw);
+        finish(th, a.out + row * N, row, a);
+    }
+};
+
+template <int LOG_NN, int LOG_MODE>
+static void run_units(int in_mode, const FrameArgs& a) {
+    using EM = Emu<LOG_NN, LOG_MODE>;
+    for (uint32_t u = 0; u < a.units; ++u) {
+        if (in_mode == IN_S16_STEREO) EM::frame_s16((const int16_t*) a.in + (size_t) u * 2 * EM::N, u, a);
+        else EM::row_f32((const float*) a.in + (size_t) u * EM::N, u, a);
+    }
+}
+
+template <int LOG_MODE>
+static int dispatch(int log_nn, int in_mode, const FrameArgs& a) {
+    switch (log_nn) {
+        case 8:  run_units<8, LOG_MODE>(in_mode, a); return 0;
+        case 9:  run_units<9, LOG_MODE>(in_mode, a); return 0;
+        case 10: run_units<10, LOG_MODE>(in_mode, a); return 0;
+        case 11: run_units<11, LOG_MODE>(in_mode, a); return 0;
+        case 12: run_units<12, LOG_MODE>(in_mode, a); return 0;
+        case 13: run_units<13, LOG_MODE>(in_mode, a); return 0;
+    }
+    return 1;
+}
+
+extern "C" {
+
+// n: real samples per channel.  in: s16 [units][n][2] (in_mode 0) or f32 [units][n] (in_mode 1).
+// grav / hist may be NULL when the op is not requested.  Returns 0 on success.
+int glvemu_process(int n, int in_mode, const void* in, float* out, float* grav, float* hist,
+                   unsigned units, unsigned ops, unsigned F, unsigned head, int mono, int avg_window,
+                   int avg_kind, int log_mode, float fft_scale, float fft_cutoff, float gravity_step, float ur) {
+    int log_nn = 0;
+    while ((2 << log_nn) < n) ++log_nn;
+    if ((2 << log_nn) != n) return 2;
+    const int nn = n / 2;
+    std::vector<cf> tw(nn);
+    std::vector<double> win(n);
+    make_twiddles(tw.data(), nn);
+    make_window(win.data(), n);
+    FrameArgs a;
+    std::memset(&a, 0, sizeof(a));
+    a.in = in; a.out = out; a.grav = grav; a.hist = hist; a.tw = tw.data(); a.win = win.data();
+    a.units = units; a.ops = ops; a.F = F; a.head = head; a.mono = mono; a.avg_window = avg_window;
+    a.inv_n = 1.0f / (float) n; a.fft_scale = fft_scale; a.one_minus_cutoff = 1.0f - fft_cutoff;
+    a.g = gravity_step * (1.0f / ur); a.F_as_float = (float) F;
+    if (F > 16) return 3;
+    make_frame_weights(a.wts, F, avg_window != 0, avg_kind);
+    return log_mode == 0 ? dispatch<0>(log_nn, in_mode, a) : dispatch<1>(log_nn, in_mode, a);
+}
+
+}  // extern "C"

@@ -1,0 +1,182 @@
+#!/usr/bin/env python3
+"""bench.py -- BASELINE.json's metric on BASELINE.json's configuration.
+
+metric    stereo 4096-pt (setbufsize 4096) unpack+window+FFT+magnitude frames/s
+workload  configs[1]: 1 MI355X, 64K batched stereo streams, N=4096; per GPU for --gpus N
+          (configs[3]: 512K streams sharded 64K-per-GPU over 8 GPUs; weak scaling, no data-path
+          collective -- streams are independent; RCCL only gathers the per-rank stats record)
+step      one pass of the fused HIP kernel over every stream of the rank (65536 frames)
+
+Inputs are resident in HBM before the timed region.  One JSON line on rank 0.
+
+    python bench.py                       # N=1
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+           --master-port P bench.py --gpus N --steps K --warmup W
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import threading
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0     # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md (6.29 TB/s measured copy)
+
+
+def cpu_baseline(n: int, seconds: float = 10.0) -> dict | None:
+    """Time the reference's own transform_fft (oracle/_ref, kind "reference") -- or, if that
+    library is absent, the C restatement (kind "port") -- on every host core, on a bounded
+    sample of the same workload: stereo frames of uniform s16 noise, N real samples/channel."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    try:
+        import numpy as np
+        from oracle_lib import Oracle, Ref
+    except Exception as e:  # pragma: no cover
+        return {"value": None, "unit": "frames/s", "cores": 0, "kind": "port", "sample": f"unavailable: {e}"}
+    cores = os.cpu_count() or 1
+    frames_per_call = 256
+    rng = np.random.default_rng(12345)
+    bufs = [rng.integers(-32768, 32768, frames_per_call * 2 * n, dtype=np.int16) for _ in range(cores)]
+    use_ref = Ref.available()
+    if use_ref:
+        p = Ref.params()
+        fn = lambda buf: Ref.lib().glvref_bench_frames(C.byref(p), buf, frames_per_call, n, 0)  # noqa: E731
+    else:
+        fn = lambda buf: Oracle.lib().glvo_bench_frames(buf, frames_per_call, n, 10.2, 0.3)   # noqa: E731
+    fn(bufs[0])  # warm
+    counts = [0] * cores
+    stop_at = time.perf_counter() + seconds
+
+    def work(i):
+        while time.perf_counter() < stop_at:
+            fn(bufs[i])
+            counts[i] += frames_per_call
+
+    t0 = time.perf_counter()
+    th = [threading.Thread(target=work, args=(i,)) for i in range(cores)]
+    for t in th: t.start()
+    for t in th: t.join()
+    dt = time.perf_counter() - t0
+    total = sum(counts)
+    return {"value": total / dt, "unit": "frames/s", "cores": cores, "kind": "reference" if use_ref else "port",
+            "sample": f"{total} stereo frames N={n} (uniform s16 noise, {frames_per_call}-frame buffers looped) over "
+                      f"{cores} threads in {dt:.1f} s; reference transform_fft x2 ch + fifo.c unpack, gcc -O2"}
+
+
+def main() -> None:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--streams", type=int, default=65536, help="stereo streams per GPU (configs[1]: 64K)")
+    ap.add_argument("--n", type=int, default=4096, help="real samples per channel (setbufsize)")
+    ap.add_argument("--ops", default="fft", choices=["fft", "fft+gravity", "fft+gravity+average"])
+    ap.add_argument("--log-mode", type=int, default=0, help="0 strict fp64 log (default), 1 fast fp32 log")
+    ap.add_argument("--grid", type=int, default=0, help="workgroups of the persistent kernel (0 = auto)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=10.0)
+    a = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if a.gpus != world and world > 1:
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))   # nccl == RCCL on ROCm
+
+    from glava_amd import build as B
+    if rank == 0:
+        B.build()
+    if world > 1:
+        dist.barrier()
+    from glava_amd import spectrum as G
+    from glava_amd.sharding import shard_range, gather_stats
+
+    ops = G.OP_FFT
+    if "gravity" in a.ops: ops |= G.OP_GRAVITY
+    if "average" in a.ops: ops |= G.OP_AVERAGE
+    n, streams = a.n, a.streams
+    total_streams = streams * world                       # weak scaling: 64K streams per GPU
+    lo, hi = shard_range(total_streams, rank, world)      # contiguous shard, SURVEY.md 8e
+    assert hi - lo == streams
+
+    params = G.Params(n=n, log_mode=a.log_mode)
+    batch = G.Batch(params, streams, ops, device=local_rank)
+    if a.grid: batch.set_grid(a.grid)
+    gen = torch.Generator(device="cuda"); gen.manual_seed(12345 + rank)
+    d_pcm = torch.randint(-32768, 32768, (streams, n, 2), dtype=torch.int16, device="cuda", generator=gen)
+    d_out = torch.empty((streams, 2, n), dtype=torch.float32, device="cuda")
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def step():
+        batch.process_s16(d_pcm, d_out, ops, stream)
+
+    for _ in range(a.warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1: dist.barrier()
+    torch.cuda.synchronize()
+    batch.timing_begin()                                   # HIP events on the launch stream, per launch
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        step()
+    torch.cuda.synchronize()
+    if world > 1: dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    kernel_ms, launches = batch.timing_end()
+
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    frames_rank = streams * a.steps
+    stats = gather_stats({"frames": frames_rank, "seconds": elapsed, "kernel_ms": kernel_ms,
+                          "bytes": batch.algorithmic_bytes(ops) * launches}, world)
+
+    if rank == 0:
+        total_frames = sum(s["frames"] for s in stats)
+        value = total_frames / elapsed
+        alg_bytes = batch.algorithmic_bytes(ops)           # per launch (all streams of the rank)
+        avg_kernel_s = (kernel_ms / max(launches, 1)) * 1e-3
+        achieved = alg_bytes / avg_kernel_s / 1e9 if avg_kernel_s > 0 else 0.0
+        line = {
+            "metric": "stereo 4096-pt FFT+smooth frames/s", "value": value, "unit": "frames/s",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": elapsed / a.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{world} MI355X, {streams} batched stereo streams per GPU, N={n} "
+                                   f"{'Hann(-like) window+FFT+magnitude' if ops == G.OP_FFT else a.ops}",
+                       "streams_per_gpu": streams, "n": n, "ops": a.ops, "log_mode": a.log_mode,
+                       "input": "int16 [streams][n][2] resident in HBM", "kernel": batch.kernel_name()},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "algorithmic_bytes_per_launch": alg_bytes, "avg_kernel_ms": avg_kernel_s * 1e3,
+                         "kernel": batch.kernel_name()},
+        }
+        if world == 1 and not a.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(n, a.cpu_seconds)
+        else:
+            line["cpu_baseline"] = None
+        print(json.dumps(line), flush=True)
+    batch.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,85 @@
+"""Build the gfx950 shared objects in-tree (hipcc cross-compiles without a GPU).
+
+    python -m glava_amd.build            # libglvspectrum.so (product)
+    python -m glava_amd.build --tune     # + libglvtune.so (knob sweep used by tools/tune.py)
+
+Outputs live next to the sources (glava_amd/csrc/*.so, git-ignored, shipped to the GPU
+box by gpurun).  Objects are rebuilt only when a source/header is newer.
+"""
+from __future__ import annotations
+
+import argparse
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+OBJ = os.path.join(CSRC, "build")
+ARCH = "gfx950"
+# -ffp-contract=off: the bit-exactness contract forbids fusing the reference's separate
+# multiplies and adds (SURVEY.md 7 "hard parts"); explicit __builtin_fmaf calls are unaffected.
+HIPFLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC",
+            "-fno-fast-math", "-Wall", "-Wno-unused-function"]
+SIZES = (8, 9, 10, 11, 12, 13)
+HEADERS = ["glv_core.h", "glv_frame.h", "glv_kernel_tmpl.h", "glv_launch.h", "glv_tables.h",
+           os.path.join("..", "..", "include", "glv_spectrum.h")]
+
+
+def _newer(target: str, deps: list[str]) -> bool:
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def _hipcc() -> str:
+    for c in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", "hipcc"):
+        if c and (os.path.isabs(c) and os.path.exists(c) or not os.path.isabs(c)):
+            return c
+    return "hipcc"
+
+
+def _run(cmd: list[str]) -> None:
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        sys.stderr.write(" ".join(cmd) + "\n" + r.stdout + r.stderr)
+        raise RuntimeError("build step failed: " + os.path.basename(cmd[-1]))
+
+
+def _compile(src: str, obj: str, extra: list[str]) -> str:
+    deps = [os.path.join(CSRC, src)] + [os.path.join(CSRC, h) for h in HEADERS]
+    if _newer(obj, deps):
+        _run([_hipcc(), *HIPFLAGS, *extra, "-c", os.path.join(CSRC, src), "-o", obj])
+    return obj
+
+
+def build(tune: bool = False, verbose: bool = False) -> str:
+    os.makedirs(OBJ, exist_ok=True)
+    jobs = [("glv_inst.hip", os.path.join(OBJ, f"glv_inst_{k}.o"), [f"-DGLV_LOG_NN={k}"]) for k in SIZES]
+    jobs.append(("glv_misc.hip", os.path.join(OBJ, "glv_misc.o"), []))
+    jobs.append(("glv_api.cpp", os.path.join(OBJ, "glv_api.o"), ["-x", "hip"]))
+    if tune:
+        jobs.append(("glv_tune.hip", os.path.join(OBJ, "glv_tune.o"), []))
+    with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 2)) as ex:
+        objs = list(ex.map(lambda j: _compile(*j), jobs))
+    lib = os.path.join(CSRC, "libglvspectrum.so")
+    prod = [o for o in objs if not o.endswith("glv_tune.o")]
+    if _newer(lib, prod):
+        _run([_hipcc(), "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", lib, *prod])
+    if tune:
+        tlib = os.path.join(CSRC, "libglvtune.so")
+        tobj = os.path.join(OBJ, "glv_tune.o")
+        if _newer(tlib, [tobj]):
+            _run([_hipcc(), "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", tlib, tobj])
+    if verbose:
+        print("built", lib)
+    return lib
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--tune", action="store_true")
+    a = ap.parse_args()
+    build(tune=a.tune, verbose=True)

@@ -1,0 +1,459 @@
+// glv_api.cpp -- the C ABI of include/glv_spectrum.h on top of the gfx950 kernels.
+//
+// Host-side responsibilities only: argument validation, constant tables (window, twiddles,
+// frame weights -- glv_tables.h), device state (gravity buffers, history rings, PCM rings),
+// launch geometry, HIP-event timing.  All arithmetic on samples happens in the kernels;
+// there is no CPU compute path here and none is ever substituted.
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/glv_spectrum.h"
+#include "glv_frame.h"
+#include "glv_launch.h"
+#include "glv_tables.h"
+
+namespace {
+
+thread_local std::string g_err = "";
+
+int fail(int code, const char* fmt, ...) __attribute__((format(printf, 2, 3)));
+int fail(int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                              \
+    do {                                                                                           \
+        hipError_t e_ = (expr);                                                                    \
+        if (e_ != hipSuccess) return fail(GLV_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)); \
+    } while (0)
+
+int log2_exact(uint32_t v) {
+    int l = 0;
+    while ((1u << l) < v) ++l;
+    return (1u << l) == v ? l : -1;
+}
+
+int validate(const glv_params* p) {
+    if (!p) return fail(GLV_ERR_INVALID, "params is NULL");
+    const int l = log2_exact(p->n);
+    if (l < 9 || l > 14) return fail(GLV_ERR_INVALID, "n=%u: must be a power of two in [512, 16384]", p->n);
+    if (p->channels != 1 && p->channels != 2) return fail(GLV_ERR_INVALID, "channels=%u: must be 1 or 2", p->channels);
+    if (p->avg_frames < 1 || p->avg_frames > GLV_MAX_AVG_FRAMES)
+        return fail(GLV_ERR_INVALID, "avg_frames=%u: must be in [1, %d]", p->avg_frames, GLV_MAX_AVG_FRAMES);
+    if (p->avg_window_kind > 1) return fail(GLV_ERR_INVALID, "avg_window_kind=%u: must be 0 or 1", p->avg_window_kind);
+    if (p->log_mode > 1) return fail(GLV_ERR_INVALID, "log_mode=%u: must be 0 or 1", p->log_mode);
+    if (!(p->ur > 0.0f)) return fail(GLV_ERR_INVALID, "ur must be > 0");
+    return GLV_OK;
+}
+
+int ensure_device(int device) {
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count <= 0)
+        return fail(GLV_ERR_NO_DEVICE, "no usable HIP device (%s); this library has no CPU path",
+                    e == hipSuccess ? "device count is 0" : hipGetErrorString(e));
+    if (device < 0 || device >= count) return fail(GLV_ERR_INVALID, "device %d out of range [0, %d)", device, count);
+    HIP_TRY(hipSetDevice(device));
+    return GLV_OK;
+}
+
+// Device-resident constants of one transform size.
+struct Tables {
+    glv::cf* d_tw = nullptr;
+    double* d_win = nullptr;
+    int create(uint32_t n) {
+        const uint32_t nn = n / 2;
+        std::vector<glv::cf> tw(nn);
+        std::vector<double> win(n);
+        glv::make_twiddles(tw.data(), nn);
+        glv::make_window(win.data(), n);
+        HIP_TRY(hipMalloc(&d_tw, sizeof(glv::cf) * nn));
+        HIP_TRY(hipMalloc(&d_win, sizeof(double) * n));
+        HIP_TRY(hipMemcpy(d_tw, tw.data(), sizeof(glv::cf) * (nn - 1), hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(d_win, win.data(), sizeof(double) * n, hipMemcpyHostToDevice));
+        return GLV_OK;
+    }
+    void destroy() {
+        if (d_tw) (void) hipFree(d_tw);
+        if (d_win) (void) hipFree(d_win);
+        d_tw = nullptr; d_win = nullptr;
+    }
+};
+
+void fill_common(glv::FrameArgs& a, const glv_params& p, const Tables& t) {
+    std::memset(&a, 0, sizeof(a));
+    a.tw = t.d_tw; a.win = t.d_win;
+    a.F = p.avg_frames; a.mono = p.channels == 1; a.avg_window = p.avg_window != 0;
+    a.inv_n = 1.0f / (float) p.n;
+    a.fft_scale = p.fft_scale;
+    a.one_minus_cutoff = 1.0F - p.fft_cutoff;                  // render.c:845
+    a.g = p.gravity_step * (1.0F / p.ur);                      // render.c:728
+    a.F_as_float = (float) p.avg_frames;                       // render.c:761
+    glv::make_frame_weights(a.wts, p.avg_frames, p.avg_window != 0, (int) p.avg_window_kind);
+}
+
+}  // namespace
+
+// =====================================================================================================
+struct glv_batch {
+    glv_params p;
+    uint32_t streams = 0;
+    unsigned ops_mask = 0;
+    int device = 0;
+    int log_nn = 0;
+    int num_cus = 256;
+    Tables tab;
+    float* d_grav = nullptr;     // [streams*2][n]      gravity state (gravity without average)
+    float* d_hist = nullptr;     // [streams*2][F][n]   ring (average; doubles as gravity state)
+    int16_t* d_ring = nullptr;   // [streams][n][2]     FIFO ring mode
+    uint32_t head = 0;           // history slot receiving the next frame
+    uint32_t ring_pos = 0;       // next write position in the PCM ring, in frames
+    int grid_override = 0;
+    // timing
+    bool timing = false;
+    std::vector<hipEvent_t> ev;  // start/stop pairs
+    size_t ev_used = 0;
+    uint64_t launches = 0;
+    const char* kernel_name = "glv_frame_kernel";
+};
+
+struct glv_state {
+    glv_batch* b = nullptr;      // a one-row batch (one channel of one stream)
+    float* d_io = nullptr;       // n floats staging
+};
+
+namespace {
+
+int batch_alloc(glv_batch* b, uint32_t rows) {
+    const size_t n = b->p.n;
+    if ((b->ops_mask & GLV_OP_AVERAGE)) {
+        const size_t bytes = sizeof(float) * rows * (size_t) b->p.avg_frames * n;
+        HIP_TRY(hipMalloc(&b->d_hist, bytes));
+        HIP_TRY(hipMemset(b->d_hist, 0, bytes));
+    }
+    if ((b->ops_mask & GLV_OP_GRAVITY)) {
+        // kept even when the ring also exists: the single-op glv_gravity() drop-in owns its own
+        // `applied` buffer exactly like the reference's separate udata slot (render.c:724)
+        const size_t bytes = sizeof(float) * rows * n;
+        HIP_TRY(hipMalloc(&b->d_grav, bytes));
+        HIP_TRY(hipMemset(b->d_grav, 0, bytes));
+    }
+    return GLV_OK;
+}
+
+int frame_grid(const glv_batch* b, uint32_t units) {
+    if (b->grid_override > 0) return b->grid_override;
+    const int slots = glv::frame_slots(b->log_nn);
+    const uint32_t wgs = (units + slots - 1) / slots;
+    // persistent workgroups: enough to fill every CU several times over, never more than the work
+    const uint32_t cap = (uint32_t) b->num_cus * 8u;
+    return (int) (wgs < cap ? wgs : cap);
+}
+
+int timed_launch_begin(glv_batch* b, hipStream_t st) {
+    if (!b->timing) return GLV_OK;
+    if (b->ev_used + 2 > b->ev.size()) {
+        hipEvent_t e0, e1;
+        HIP_TRY(hipEventCreate(&e0));
+        HIP_TRY(hipEventCreate(&e1));
+        b->ev.push_back(e0); b->ev.push_back(e1);
+    }
+    HIP_TRY(hipEventRecord(b->ev[b->ev_used], st));
+    return GLV_OK;
+}
+int timed_launch_end(glv_batch* b, hipStream_t st) {
+    if (!b->timing) return GLV_OK;
+    HIP_TRY(hipEventRecord(b->ev[b->ev_used + 1], st));
+    b->ev_used += 2;
+    b->launches += 1;
+    return GLV_OK;
+}
+
+// One update of `units` units through the fused kernel (or the post kernel when no FFT is asked).
+int process(glv_batch* b, const void* d_in, int in_mode, float* d_out, unsigned ops, uint32_t units,
+            uint32_t rot, hipStream_t st) {
+    if (!d_in || !d_out) return fail(GLV_ERR_INVALID, "NULL device pointer");
+    const unsigned stateful = ops & (GLV_OP_GRAVITY | GLV_OP_AVERAGE);
+    if (stateful & ~b->ops_mask)
+        return fail(GLV_ERR_STATE, "ops 0x%x need state the batch was not created with (ops_mask 0x%x)", ops, b->ops_mask);
+    if ((ops & GLV_OP_WRANGE) && (ops & GLV_OP_FFT)) return fail(GLV_ERR_INVALID, "GLV_OP_WRANGE excludes GLV_OP_FFT");
+    if ((ops & GLV_OP_RAW) && !(ops & GLV_OP_FFT)) return fail(GLV_ERR_INVALID, "GLV_OP_RAW needs GLV_OP_FFT");
+    if (ops & GLV_OP_BARS) return fail(GLV_ERR_INVALID, "GLV_OP_BARS is not available in this build");
+    if (!(ops & (GLV_OP_FFT | GLV_OP_GRAVITY | GLV_OP_AVERAGE | GLV_OP_WRANGE))) return fail(GLV_ERR_INVALID, "empty ops");
+
+    glv::FrameArgs a;
+    fill_common(a, b->p, b->tab);
+    a.in = d_in; a.out = d_out; a.grav = b->d_grav; a.hist = b->d_hist;
+    a.units = units; a.ops = ops; a.head = b->head; a.rot = rot;
+
+    HIP_TRY(hipSetDevice(b->device));
+    if (int rc = timed_launch_begin(b, st)) return rc;
+    hipError_t e;
+    if (ops & GLV_OP_FFT) {
+        e = glv::launch_frame(b->log_nn, in_mode, (int) b->p.log_mode, a, frame_grid(b, units), st);
+        b->kernel_name = "glv_frame_kernel";
+    } else {
+        if (in_mode != glv::IN_F32_PLANAR) return fail(GLV_ERR_INVALID, "operators without GLV_OP_FFT take planar f32 input");
+        e = glv::launch_post(a, b->p.n, st);
+        b->kernel_name = "glv_post_kernel";
+    }
+    if (e != hipSuccess) return fail(GLV_ERR_HIP, "kernel launch failed: %s", hipGetErrorString(e));
+    if (int rc = timed_launch_end(b, st)) return rc;
+    if (ops & GLV_OP_AVERAGE) b->head = (b->head + 1) % b->p.avg_frames;
+    return GLV_OK;
+}
+
+int batch_create_rows(const glv_params* p, uint32_t streams, unsigned ops_mask, int device, bool single_row, glv_batch** out) {
+    if (!out) return fail(GLV_ERR_INVALID, "out is NULL");
+    *out = nullptr;
+    if (int rc = validate(p)) return rc;
+    if (streams == 0) return fail(GLV_ERR_INVALID, "streams must be > 0");
+    if (int rc = ensure_device(device)) return rc;
+    glv_batch* b = new (std::nothrow) glv_batch();
+    if (!b) return fail(GLV_ERR_NOMEM, "out of host memory");
+    b->p = *p; b->streams = streams; b->ops_mask = ops_mask; b->device = device;
+    b->log_nn = log2_exact(p->n) - 1;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess) b->num_cus = prop.multiProcessorCount;
+    int rc = b->tab.create(p->n);
+    if (rc == GLV_OK) rc = batch_alloc(b, single_row ? 1u : streams * 2u);
+    if (rc != GLV_OK) { glv_batch_destroy(b); return rc; }
+    *out = b;
+    return GLV_OK;
+}
+
+}  // namespace
+
+// =====================================================================================================
+extern "C" {
+
+void glv_params_default(glv_params* p) {
+    if (!p) return;
+    std::memset(p, 0, sizeof(*p));
+    p->n = 4096;                 // shaders/glava/rc.glsl:190
+    p->channels = 2;
+    p->fft_scale = 10.2F;        // smooth_parameters.glsl:46 / render.c:930
+    p->fft_cutoff = 0.3F;        // smooth_parameters.glsl:51 / render.c:931
+    p->gravity_step = 4.2F;      // smooth_parameters.glsl:67 / render.c:911
+    p->ur = 22050.0F / 256.0F;   // rate / (samplesize/4), rc.glsl:181,203; formula render.c:1674
+    p->avg_frames = 5;           // smooth_parameters.glsl:56
+    p->avg_window = 1;           // smooth_parameters.glsl:61
+    p->avg_window_kind = 0;
+    p->log_mode = 0;
+    p->bars = 80;                // radial.glsl:9 (NBARS 160, two channels)
+    p->smooth_factor = 0.025F;   // smooth_parameters.glsl:72
+}
+
+int glv_abi_version(void) { return GLV_ABI_VERSION; }
+const char* glv_last_error(void) { return g_err.c_str(); }
+int glv_device_count(void) {
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess) return 0;
+    return count;
+}
+
+// ---- batched -----------------------------------------------------------------------------------------
+int glv_batch_create(const glv_params* p, uint32_t streams, unsigned ops_mask, int device, glv_batch** out) {
+    return batch_create_rows(p, streams, ops_mask, device, false, out);
+}
+
+int glv_batch_reset(glv_batch* b) {
+    if (!b) return fail(GLV_ERR_INVALID, "batch is NULL");
+    HIP_TRY(hipSetDevice(b->device));
+    const size_t n = b->p.n;
+    size_t rows = (size_t) b->streams * 2;
+    if (b->d_hist) HIP_TRY(hipMemset(b->d_hist, 0, sizeof(float) * rows * b->p.avg_frames * n));
+    if (b->d_grav) HIP_TRY(hipMemset(b->d_grav, 0, sizeof(float) * rows * n));
+    if (b->d_ring) HIP_TRY(hipMemset(b->d_ring, 0, sizeof(int16_t) * 2 * n * b->streams));
+    b->head = 0; b->ring_pos = 0;
+    return GLV_OK;
+}
+
+int glv_batch_destroy(glv_batch* b) {
+    if (!b) return GLV_OK;
+    (void) hipSetDevice(b->device);
+    b->tab.destroy();
+    if (b->d_grav) (void) hipFree(b->d_grav);
+    if (b->d_hist) (void) hipFree(b->d_hist);
+    if (b->d_ring) (void) hipFree(b->d_ring);
+    for (hipEvent_t e : b->ev) (void) hipEventDestroy(e);
+    delete b;
+    return GLV_OK;
+}
+
+int glv_batch_process_s16(glv_batch* b, const int16_t* d_pcm, float* d_out, unsigned ops, void* hip_stream) {
+    if (!b) return fail(GLV_ERR_INVALID, "batch is NULL");
+    if (!(ops & GLV_OP_FFT)) return fail(GLV_ERR_INVALID, "s16 input requires GLV_OP_FFT");
+    return process(b, d_pcm, glv::IN_S16_STEREO, d_out, ops, b->streams, 0, (hipStream_t) hip_stream);
+}
+
+int glv_batch_process_f32(glv_batch* b, const float* d_f32, float* d_out, unsigned ops, void* hip_stream) {
+    if (!b) return fail(GLV_ERR_INVALID, "batch is NULL");
+    return process(b, d_f32, glv::IN_F32_PLANAR, d_out, ops, b->streams * 2, 0, (hipStream_t) hip_stream);
+}
+
+int glv_batch_ring_update_s16(glv_batch* b, const int16_t* d_new, uint32_t new_frames, float* d_out, unsigned ops,
+                              void* hip_stream) {
+    if (!b) return fail(GLV_ERR_INVALID, "batch is NULL");
+    if (!(ops & GLV_OP_FFT)) return fail(GLV_ERR_INVALID, "ring mode requires GLV_OP_FFT");
+    const uint32_t n = b->p.n;
+    if (new_frames == 0 || new_frames > n || (new_frames & 1u) || (n % new_frames) != 0)
+        return fail(GLV_ERR_INVALID, "new_frames=%u: must be even, divide n=%u (sample_sz/4 of fifo.c:38,91)", new_frames, n);
+    hipStream_t st = (hipStream_t) hip_stream;
+    HIP_TRY(hipSetDevice(b->device));
+    if (!b->d_ring) {
+        const size_t bytes = sizeof(int16_t) * 2 * (size_t) n * b->streams;
+        HIP_TRY(hipMalloc(&b->d_ring, bytes));
+        HIP_TRY(hipMemset(b->d_ring, 0, bytes));          // == the calloc'd rings of glava.c:487-494
+        b->ring_pos = 0;
+    }
+    // append at ring_pos (never wraps inside one update: new_frames divides n and ring_pos is a multiple of it)
+    char* dst = reinterpret_cast<char*>(b->d_ring) + (size_t) b->ring_pos * 4;
+    const size_t pitch = (size_t) n * 4, width = (size_t) new_frames * 4;
+    if (d_new) HIP_TRY(hipMemcpy2DAsync(dst, pitch, d_new, width, width, b->streams, hipMemcpyDeviceToDevice, st));
+    else       HIP_TRY(hipMemset2DAsync(dst, pitch, 0, width, b->streams, st));   // fifo.c:67-79
+    b->ring_pos = (b->ring_pos + new_frames) % n;
+    // oldest sample now sits at ring_pos; rotation in complex points (pairs of frames)
+    return process(b, b->d_ring, glv::IN_S16_STEREO, d_out, ops, b->streams, b->ring_pos / 2, st);
+}
+
+int glv_batch_timing_begin(glv_batch* b) {
+    if (!b) return fail(GLV_ERR_INVALID, "batch is NULL");
+    b->timing = true; b->ev_used = 0; b->launches = 0;
+    return GLV_OK;
+}
+
+int glv_batch_timing_end(glv_batch* b, double* kernel_ms, uint64_t* launches) {
+    if (!b) return fail(GLV_ERR_INVALID, "batch is NULL");
+    double total = 0.0;
+    for (size_t i = 0; i + 1 < b->ev_used; i += 2) {
+        HIP_TRY(hipEventSynchronize(b->ev[i + 1]));
+        float ms = 0.f;
+        HIP_TRY(hipEventElapsedTime(&ms, b->ev[i], b->ev[i + 1]));
+        total += ms;
+    }
+    if (kernel_ms) *kernel_ms = total;
+    if (launches) *launches = b->launches;
+    b->timing = false;
+    return GLV_OK;
+}
+
+uint64_t glv_batch_algorithmic_bytes(const glv_batch* b, unsigned ops, int input_is_s16) {
+    if (!b) return 0;
+    // SURVEY.md 8d, per stereo frame with N real samples per channel, F = avg_frames:
+    //   in: 4N (s16 x 2ch) or 8N (f32 x 2ch);  out: 8N
+    //   + gravity (no average): read 8N state, write 8N state
+    //   + average: read (F-1) ring slots 8N each, write the newest slot 8N (doubles as gravity state)
+    const uint64_t N = b->p.n, F = b->p.avg_frames;
+    uint64_t per = (input_is_s16 ? 4 * N : 8 * N) + 8 * N;
+    if (ops & GLV_OP_AVERAGE) per += 8 * N * (F - 1) + 8 * N;
+    else if (ops & GLV_OP_GRAVITY) per += 16 * N;
+    return per * b->streams;
+}
+
+const char* glv_batch_kernel_name(const glv_batch* b) { return b ? b->kernel_name : ""; }
+
+// tuning hook used by tools/tune.py and bench.py --grid (0 = automatic)
+int glv_batch_set_grid(glv_batch* b, int grid) {
+    if (!b) return fail(GLV_ERR_INVALID, "batch is NULL");
+    b->grid_override = grid;
+    return GLV_OK;
+}
+
+// ---- single-stream drop-ins -------------------------------------------------------------------------
+int glv_state_create(const glv_params* p, int device, glv_state** out) {
+    if (!out) return fail(GLV_ERR_INVALID, "out is NULL");
+    *out = nullptr;
+    glv_state* s = new (std::nothrow) glv_state();
+    if (!s) return fail(GLV_ERR_NOMEM, "out of host memory");
+    int rc = batch_create_rows(p, 1, GLV_OP_GRAVITY | GLV_OP_AVERAGE, device, true, &s->b);
+    if (rc == GLV_OK) {
+        hipError_t e = hipMalloc(&s->d_io, sizeof(float) * p->n);
+        if (e != hipSuccess) rc = fail(GLV_ERR_HIP, "hipMalloc failed: %s", hipGetErrorString(e));
+    }
+    if (rc != GLV_OK) { glv_state_destroy(s); return rc; }
+    *out = s;
+    return GLV_OK;
+}
+
+int glv_state_reset(glv_state* s) {
+    if (!s || !s->b) return fail(GLV_ERR_INVALID, "state is NULL");
+    glv_batch* b = s->b;
+    HIP_TRY(hipSetDevice(b->device));
+    const size_t n = b->p.n;
+    HIP_TRY(hipMemset(b->d_hist, 0, sizeof(float) * b->p.avg_frames * n));
+    HIP_TRY(hipMemset(b->d_grav, 0, sizeof(float) * n));
+    b->head = 0;
+    return GLV_OK;
+}
+
+int glv_state_destroy(glv_state* s) {
+    if (!s) return GLV_OK;
+    if (s->b) { (void) hipSetDevice(s->b->device); glv_batch_destroy(s->b); }
+    if (s->d_io) (void) hipFree(s->d_io);
+    delete s;
+    return GLV_OK;
+}
+
+static int single(const glv_params* p, glv_state* s, float* buf, unsigned ops) {
+    if (!s || !s->b) return fail(GLV_ERR_INVALID, "state is NULL");
+    if (!buf) return fail(GLV_ERR_INVALID, "buf is NULL");
+    if (int rc = validate(p)) return rc;
+    glv_batch* b = s->b;
+    if (p->n != b->p.n || p->avg_frames != b->p.avg_frames)
+        return fail(GLV_ERR_STATE, "params (n=%u, F=%u) do not match the state (n=%u, F=%u)", p->n, p->avg_frames, b->p.n, b->p.avg_frames);
+    b->p = *p;   // scalar knobs may change between calls, exactly like gl_data fields
+    HIP_TRY(hipSetDevice(b->device));
+    const size_t bytes = sizeof(float) * p->n;
+    HIP_TRY(hipMemcpyAsync(s->d_io, buf, bytes, hipMemcpyHostToDevice, nullptr));
+    if (int rc = process(b, s->d_io, glv::IN_F32_PLANAR, s->d_io, ops, 1, 0, nullptr)) return rc;
+    HIP_TRY(hipMemcpyAsync(buf, s->d_io, bytes, hipMemcpyDeviceToHost, nullptr));
+    HIP_TRY(hipStreamSynchronize(nullptr));
+    return GLV_OK;
+}
+
+int glv_fft(const glv_params* p, glv_state* s, float* buf) { return single(p, s, buf, GLV_OP_FFT); }
+int glv_gravity(const glv_params* p, glv_state* s, float* buf) { return single(p, s, buf, GLV_OP_GRAVITY); }
+int glv_average(const glv_params* p, glv_state* s, float* buf) { return single(p, s, buf, GLV_OP_AVERAGE); }
+int glv_wrange(const glv_params* p, glv_state* s, float* buf) { return single(p, s, buf, GLV_OP_WRANGE); }
+int glv_fft_gravity_average(const glv_params* p, glv_state* s, float* buf) {
+    return single(p, s, buf, GLV_OP_FFT | GLV_OP_GRAVITY | GLV_OP_AVERAGE);
+}
+
+int glv_unpack_s16(int device, const int16_t* pcm, size_t frames, int channels, float* l, float* r) {
+    if (!l || !r) return fail(GLV_ERR_INVALID, "NULL output");
+    if (channels != 1 && channels != 2) return fail(GLV_ERR_INVALID, "channels=%d: must be 1 or 2", channels);
+    if (frames == 0) return GLV_OK;
+    if (int rc = ensure_device(device)) return rc;
+    int16_t* d_pcm = nullptr; float* d_l = nullptr; float* d_r = nullptr;
+    int rc = GLV_OK;
+    auto cleanup = [&]() { if (d_pcm) (void) hipFree(d_pcm); if (d_l) (void) hipFree(d_l); if (d_r) (void) hipFree(d_r); };
+#define TRY_C(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { rc = fail(GLV_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)); cleanup(); return rc; } } while (0)
+    TRY_C(hipMalloc(&d_pcm, frames * 4));
+    TRY_C(hipMalloc(&d_l, frames * 4));
+    TRY_C(hipMalloc(&d_r, frames * 4));
+    if (pcm) TRY_C(hipMemcpy(d_pcm, pcm, frames * 4, hipMemcpyHostToDevice));
+    else     TRY_C(hipMemset(d_pcm, 0, frames * 4));            // fifo.c:67-79
+    TRY_C(glv::launch_unpack(d_pcm, frames, channels == 1, d_l, d_r, nullptr));
+    TRY_C(hipMemcpy(l, d_l, frames * 4, hipMemcpyDeviceToHost));
+    TRY_C(hipMemcpy(r, d_r, frames * 4, hipMemcpyDeviceToHost));
+#undef TRY_C
+    cleanup();
+    return GLV_OK;
+}
+
+}  // extern "C"

@@ -19,6 +19,7 @@
 namespace glv {
 
 enum InMode { IN_S16_STEREO = 0, IN_F32_PLANAR = 1 };
+enum Epi { EPI_RAW = 0, EPI_MAG = 1, EPI_MAG_STATE = 2, EPI_RAW_STATE = 3 };
 
 // ops bits as in include/glv_spectrum.h
 enum : uint32_t { OP_FFT = 1u, OP_GRAVITY = 2u, OP_AVERAGE = 4u, OP_RAW = 8u, OP_WRANGE = 16u, OP_BARS = 32u };
@@ -36,9 +37,52 @@ struct FrameArgs {
                            // head+1, ..., head+F-1, head  (mod F)
     uint32_t mono;         // fifo.c:98-102
     uint32_t avg_window;
+    uint32_t rot;          // s16 ring mode: rotation of the window start, in complex points (pairs of frames)
     float inv_n, fft_scale, one_minus_cutoff, g, F_as_float;
     double wts[16];        // window_frame weights, oldest first (render.c:661 as expanded at :766)
 };
+
+// ring slot of age f (0 = oldest .. F-1 = newest = head)
+GLV_HD uint32_t ring_slot(uint32_t head, uint32_t f, uint32_t F) {
+    uint32_t s = head + 1 + f;
+    return s >= F ? s - F : s;   // head < F, f < F  =>  s < 2F
+}
+
+// gravity (render.c:720-736) and average (render.c:738-771) for the float pair (n0, n0+1) of
+// channel row `row`; n = floats per row.  State traffic is 8 bytes per lane, lanes contiguous.
+// With both operators the newest ring slot doubles as the gravity state ("applied" of
+// render.c:724 is by construction the previous gravity output, i.e. the previous newest slot).
+GLV_HD cf apply_state(cf val, int n0, size_t row, uint32_t n, const FrameArgs& a) {
+    if (a.ops & OP_AVERAGE) {
+        float* h = a.hist + row * (size_t) a.F * n + n0;
+        const uint32_t F = a.F;
+        cf acc = { 0.0f, 0.0f }, prev = { 0.0f, 0.0f };
+        if (F == 1) prev = *reinterpret_cast<const cf*>(h + (size_t) a.head * n);
+        for (uint32_t f = 0; f + 1 < F; ++f) {                               // oldest .. second newest
+            prev = *reinterpret_cast<const cf*>(h + (size_t) ring_slot(a.head, f, F) * n);
+            if (a.avg_window) {                                              // render.c:759, double product
+                acc.x = (float) ((double) acc.x + a.wts[f] * (double) prev.x);
+                acc.y = (float) ((double) acc.y + a.wts[f] * (double) prev.y);
+            } else { acc.x = acc.x + prev.x; acc.y = acc.y + prev.y; }
+        }
+        if (a.ops & OP_GRAVITY) {
+            val.x = gravity(val.x, prev.x, a.g); val.y = gravity(val.y, prev.y, a.g);
+        }
+        *reinterpret_cast<cf*>(h + (size_t) a.head * n) = val;
+        if (a.avg_window) {
+            acc.x = (float) ((double) acc.x + a.wts[F - 1] * (double) val.x);
+            acc.y = (float) ((double) acc.y + a.wts[F - 1] * (double) val.y);
+        } else { acc.x = acc.x + val.x; acc.y = acc.y + val.y; }
+        val.x = acc.x / a.F_as_float;                                        // render.c:761
+        val.y = acc.y / a.F_as_float;
+    } else if (a.ops & OP_GRAVITY) {
+        cf* gs = reinterpret_cast<cf*>(a.grav + row * (size_t) n + n0);
+        const cf st = *gs;
+        val.x = gravity(val.x, st.x, a.g); val.y = gravity(val.y, st.y, a.g);
+        *gs = val;
+    }
+    return val;
+}
 
 template <int LOG_NN>
 struct Frame {
@@ -49,11 +93,13 @@ struct Frame {
     // s16: one 8-byte load holds complex point c of BOTH channels: (L[2c], R[2c], L[2c+1], R[2c+1]).
     struct Pcm { uint32_t lo[E], hi[E]; };   // lo = L[2c] | R[2c] << 16, hi = L[2c+1] | R[2c+1] << 16
 
-    GLV_HD static void load_pcm(Pcm& p, const int16_t* frame, int tid) {
+    // `rot` (complex points) rotates the read position for the FIFO ring mode (fifo.c:91-92 keeps
+    // the newest samples at the end of the buffer; the device ring is circular instead).
+    GLV_HD static void load_pcm(Pcm& p, const int16_t* frame, int tid, uint32_t rot) {
         const u32x2* src = reinterpret_cast<const u32x2*>(frame);
 #pragma unroll
         for (int i = 0; i < E; ++i) {
-            const u32x2 u = src[i * T + tid];
+            const u32x2 u = src[(uint32_t) (i * T + tid + rot) & (uint32_t) (NN - 1)];
             p.lo[i] = u.x; p.hi[i] = u.y;
         }
     }
@@ -157,55 +203,12 @@ struct Frame {
     }
 
     // ---- epilogue: registers of the last pass -> HBM ------------------------------------------------
-    // ring slot of age f (0 = oldest .. F-1 = newest = head)
-    GLV_HD static uint32_t ring_slot(uint32_t head, uint32_t f, uint32_t F) {
-        uint32_t s = head + 1 + f;
-        return s >= F ? s - F : s;   // head < F, f < F  =>  s < 2F
-    }
-
-    // One complex point = floats n0 (even) and n0+1 of channel row `row`.  All state traffic is
-    // 8 bytes per lane, lanes contiguous.
-    template <int LOG_MODE>
-    GLV_HD static cf finish_pair(cf x, int n0, size_t row, const FrameArgs& a) {
-        cf val = x;
-        if (!(a.ops & OP_RAW)) {
-            const float y0 = __builtin_fabsf(x.x) + 1.0f, y1 = __builtin_fabsf(x.y) + 1.0f;   // render.c:843-844
-            val.x = log_third<LOG_MODE>(y0) * tilt(n0, a.inv_n, a.fft_scale, a.one_minus_cutoff);      // :845
-            val.y = log_third<LOG_MODE>(y1) * tilt(n0 + 1, a.inv_n, a.fft_scale, a.one_minus_cutoff);
-        }
-        if (a.ops & OP_AVERAGE) {
-            float* h = a.hist + row * (size_t) a.F * N + n0;
-            const uint32_t F = a.F;
-            cf acc = { 0.0f, 0.0f }, prev = { 0.0f, 0.0f };
-            if (F == 1) prev = *reinterpret_cast<const cf*>(h + (size_t) a.head * N);
-            for (uint32_t f = 0; f + 1 < F; ++f) {                               // oldest .. second newest
-                prev = *reinterpret_cast<const cf*>(h + (size_t) ring_slot(a.head, f, F) * N);
-                if (a.avg_window) {
-                    acc.x = (float) ((double) acc.x + a.wts[f] * (double) prev.x);
-                    acc.y = (float) ((double) acc.y + a.wts[f] * (double) prev.y);
-                } else { acc.x = acc.x + prev.x; acc.y = acc.y + prev.y; }
-            }
-            if (a.ops & OP_GRAVITY) {                                            // state == previous newest slot
-                val.x = gravity(val.x, prev.x, a.g); val.y = gravity(val.y, prev.y, a.g);
-            }
-            *reinterpret_cast<cf*>(h + (size_t) a.head * N) = val;
-            if (a.avg_window) {
-                acc.x = (float) ((double) acc.x + a.wts[F - 1] * (double) val.x);
-                acc.y = (float) ((double) acc.y + a.wts[F - 1] * (double) val.y);
-            } else { acc.x = acc.x + val.x; acc.y = acc.y + val.y; }
-            val.x = acc.x / a.F_as_float;                                        // render.c:761
-            val.y = acc.y / a.F_as_float;
-        } else if (a.ops & OP_GRAVITY) {
-            cf* gs = reinterpret_cast<cf*>(a.grav + row * (size_t) N + n0);
-            const cf st = *gs;
-            val.x = gravity(val.x, st.x, a.g); val.y = gravity(val.y, st.y, a.g);
-            *gs = val;
-        }
-        return val;
-    }
-
-    // registers of the last pass -> out row (8-byte stores, lanes contiguous)
-    template <int LOG_MODE>
+    // One complex point = floats n0 (even) and n0+1 of channel row `row`; 8-byte stores, lanes
+    // contiguous.  EPI selects the operator chain at compile time (the kernel switches on a.ops
+    // once per frame, outside the unrolled element loop):
+    //   EPI_RAW  raw FFT output              EPI_MAG   abs/log/tilt
+    //   EPI_MAG_STATE  abs/log/tilt followed by gravity and/or average (apply_state)
+    template <int LOG_MODE, int EPI>
     GLV_HD static void epilogue(const cf (&v)[E], float* out_row, size_t row, int tid, const FrameArgs& a) {
         using PI = PassInfo<P - 1>;
 #pragma unroll
@@ -213,8 +216,15 @@ struct Frame {
 #pragma unroll
             for (int r = 0; r < PI::R; ++r) {
                 const int q = out_index<P - 1>(tid, gi, r);
-                const cf val = finish_pair<LOG_MODE>(v[gi * PI::R + r], 2 * q, row, a);
-                *reinterpret_cast<cf*>(out_row + 2 * q) = val;
+                const int n0 = 2 * q;
+                cf val = v[gi * PI::R + r];
+                if constexpr (EPI != EPI_RAW) {
+                    const float y0 = __builtin_fabsf(val.x) + 1.0f, y1 = __builtin_fabsf(val.y) + 1.0f;   // render.c:843-844
+                    val.x = log_third<LOG_MODE>(y0) * tilt(n0, a.inv_n, a.fft_scale, a.one_minus_cutoff);  // :845
+                    val.y = log_third<LOG_MODE>(y1) * tilt(n0 + 1, a.inv_n, a.fft_scale, a.one_minus_cutoff);
+                }
+                if constexpr (EPI == EPI_MAG_STATE || EPI == EPI_RAW_STATE) val = apply_state(val, n0, row, (uint32_t) N, a);
+                *reinterpret_cast<cf*>(out_row + n0) = val;
             }
     }
 };

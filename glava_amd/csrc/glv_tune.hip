@@ -1,0 +1,105 @@
+// glv_tune.hip -- knob sweep of glv_frame_kernel for ONE size (default N = 4096, -DGLV_TUNE_LOG_NN=k).
+// Built into its own shared object (libglvtune.so) that only tools/tune.py loads; the
+// product library does not contain these instantiations.
+#include <cstring>
+#include <vector>
+
+#include "glv_kernel_tmpl.h"
+#include "glv_tables.h"
+
+#ifndef GLV_TUNE_LOG_NN
+#define GLV_TUNE_LOG_NN 11
+#endif
+
+namespace glv {
+namespace {
+
+struct Variant {
+    const char* desc;
+    hipError_t (*launch)(int in_mode, int log_mode, const FrameArgs& a, int grid, hipStream_t st);
+    int slots;
+};
+
+template <int SLOTS, int NBUF, bool TWREG, bool WINLDS, int OCC>
+hipError_t launch_v(int in_mode, int log_mode, const FrameArgs& a, int grid, hipStream_t st) {
+    constexpr int K = GLV_TUNE_LOG_NN;
+    if (in_mode != IN_S16_STEREO) return hipErrorInvalidValue;
+    if (log_mode == 0) return launch_variant<K, IN_S16_STEREO, 0, SLOTS, NBUF, TWREG, WINLDS, OCC>(a, grid, st);
+    return launch_variant<K, IN_S16_STEREO, 1, SLOTS, NBUF, TWREG, WINLDS, OCC>(a, grid, st);
+}
+
+#define V(S, NB, TR, WL, OC) { "slots=" #S " nbuf=" #NB " twreg=" #TR " winlds=" #WL " occ=" #OC, launch_v<S, NB, TR, WL, OC>, S }
+const Variant kVariants[] = {
+#ifdef GLV_TUNE_VARIANTS
+    GLV_TUNE_VARIANTS
+#else
+    V(2, 1, true, true, 2),  V(2, 1, true, true, 3),  V(2, 1, true, true, 4),
+    V(2, 1, false, true, 2), V(2, 1, false, true, 3), V(2, 1, false, true, 4),
+    V(2, 2, true, true, 2),  V(2, 2, false, true, 3), V(2, 2, false, true, 4),
+    V(2, 1, true, false, 2), V(2, 1, false, false, 4),
+    V(4, 1, true, true, 2),  V(4, 1, false, true, 4), V(4, 2, false, false, 4),
+    V(1, 1, true, true, 2),  V(1, 1, false, true, 4),
+#endif
+};
+#undef V
+
+}  // namespace
+}  // namespace glv
+
+extern "C" {
+int glv_tune_count(void) { return (int) (sizeof(glv::kVariants) / sizeof(glv::kVariants[0])); }
+const char* glv_tune_describe(int i) { return glv::kVariants[i].desc; }
+int glv_tune_slots(int i) { return glv::kVariants[i].slots; }
+int glv_tune_log_nn(void) { return GLV_TUNE_LOG_NN; }
+int glv_tune_launch(int i, int in_mode, int log_mode, const glv::FrameArgs* a, int grid, void* stream) {
+    return (int) glv::kVariants[i].launch(in_mode, log_mode, *a, grid, (hipStream_t) stream);
+}
+
+// Self-contained timing of one variant: `iters` launches over `units` stereo frames of s16 PCM
+// already in HBM (FFT + magnitude only), HIP events around the whole run on `stream`.
+// Returns average milliseconds per launch in *ms.  Tables are created once per process.
+int glv_tune_run(int i, const void* d_pcm, float* d_out, unsigned units, int log_mode, int grid, int iters,
+                 void* stream, float* ms) {
+    using namespace glv;
+    static cf* d_tw = nullptr;
+    static double* d_win = nullptr;
+    constexpr int NN = 1 << GLV_TUNE_LOG_NN, N = 2 * NN;
+    if (!d_tw) {
+        std::vector<cf> tw(NN);
+        std::vector<double> win(N);
+        make_twiddles(tw.data(), NN);
+        make_window(win.data(), N);
+        if (hipMalloc(&d_tw, sizeof(cf) * NN) != hipSuccess) return -1;
+        if (hipMalloc(&d_win, sizeof(double) * N) != hipSuccess) return -1;
+        (void) hipMemcpy(d_tw, tw.data(), sizeof(cf) * (NN - 1), hipMemcpyHostToDevice);
+        (void) hipMemcpy(d_win, win.data(), sizeof(double) * N, hipMemcpyHostToDevice);
+    }
+    FrameArgs a;
+    std::memset(&a, 0, sizeof(a));
+    a.in = d_pcm; a.out = d_out; a.tw = d_tw; a.win = d_win; a.units = units; a.ops = OP_FFT;
+    a.F = 1; a.inv_n = 1.0f / (float) N; a.fft_scale = 10.2f; a.one_minus_cutoff = 1.0f - 0.3f;
+    a.g = 4.2f * (1.0f / 86.1328125f); a.F_as_float = 1.0f;
+    hipStream_t st = (hipStream_t) stream;
+    if (grid <= 0) {
+        const unsigned slots = (unsigned) kVariants[i].slots;
+        const unsigned wgs = (units + slots - 1) / slots;
+        grid = (int) (wgs < 2048u ? wgs : 2048u);
+    }
+    hipEvent_t e0, e1;
+    (void) hipEventCreate(&e0); (void) hipEventCreate(&e1);
+    hipError_t e = kVariants[i].launch(IN_S16_STEREO, log_mode, a, grid, st);   // warm-up + attribute setup
+    if (e != hipSuccess) return (int) e;
+    (void) hipEventRecord(e0, st);
+    for (int it = 0; it < iters; ++it) {
+        e = kVariants[i].launch(IN_S16_STEREO, log_mode, a, grid, st);
+        if (e != hipSuccess) return (int) e;
+    }
+    (void) hipEventRecord(e1, st);
+    if (hipEventSynchronize(e1) != hipSuccess) return -2;
+    float t = 0;
+    (void) hipEventElapsedTime(&t, e0, e1);
+    *ms = t / (float) iters;
+    (void) hipEventDestroy(e0); (void) hipEventDestroy(e1);
+    return 0;
+}
+}

@@ -1,0 +1,207 @@
+"""ctypes binding of the C ABI (include/glv_spectrum.h) -- plumbing, not the product.
+
+The product is libglvspectrum.so (hand-written HIP for gfx950, glava_amd/csrc).  This
+module only loads it, mirrors `glv_params`, and passes raw device pointers (from torch
+tensors or any other allocator) across.  There is no fallback of any kind: if the shared
+object is missing or the device is unusable, calls raise `GlvError`.
+
+Names follow the reference's operator table (glava/render.c:849-856): fft, gravity,
+avg(average), wrange.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from dataclasses import dataclass
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "csrc", "libglvspectrum.so")
+
+OP_FFT, OP_GRAVITY, OP_AVERAGE, OP_RAW, OP_WRANGE, OP_BARS = 1, 2, 4, 8, 16, 32
+OK, ERR_INVALID, ERR_NO_DEVICE, ERR_HIP, ERR_NOMEM, ERR_STATE = 0, 1, 2, 3, 4, 5
+
+
+class GlvError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"glv error {code}: {msg}")
+        self.code = code
+
+
+class CParams(C.Structure):
+    _fields_ = [("n", C.c_uint32), ("channels", C.c_uint32), ("fft_scale", C.c_float), ("fft_cutoff", C.c_float),
+                ("gravity_step", C.c_float), ("ur", C.c_float), ("avg_frames", C.c_uint32),
+                ("avg_window", C.c_uint32), ("avg_window_kind", C.c_uint32), ("log_mode", C.c_uint32),
+                ("bars", C.c_uint32), ("smooth_factor", C.c_float)]
+
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    """Load libglvspectrum.so (built in-tree by glava_amd.build); fail loudly if absent."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise GlvError(ERR_NO_DEVICE, f"{LIB_PATH} not built -- run `python -m glava_amd.build` "
+                                          "(there is no Python/CPU fallback)")
+        L = C.CDLL(LIB_PATH)
+        P = C.POINTER(CParams)
+        vp = C.c_void_p
+        L.glv_params_default.argtypes = [P]; L.glv_params_default.restype = None
+        L.glv_abi_version.restype = C.c_int
+        L.glv_last_error.restype = C.c_char_p
+        L.glv_device_count.restype = C.c_int
+        L.glv_state_create.argtypes = [P, C.c_int, C.POINTER(vp)]
+        L.glv_state_reset.argtypes = [vp]
+        L.glv_state_destroy.argtypes = [vp]
+        for name in ("glv_fft", "glv_gravity", "glv_average", "glv_wrange", "glv_fft_gravity_average"):
+            getattr(L, name).argtypes = [P, vp, vp]
+        L.glv_unpack_s16.argtypes = [C.c_int, vp, C.c_size_t, C.c_int, vp, vp]
+        L.glv_batch_create.argtypes = [P, C.c_uint32, C.c_uint, C.c_int, C.POINTER(vp)]
+        L.glv_batch_reset.argtypes = [vp]
+        L.glv_batch_destroy.argtypes = [vp]
+        L.glv_batch_process_s16.argtypes = [vp, vp, vp, C.c_uint, vp]
+        L.glv_batch_process_f32.argtypes = [vp, vp, vp, C.c_uint, vp]
+        L.glv_batch_ring_update_s16.argtypes = [vp, vp, C.c_uint32, vp, C.c_uint, vp]
+        L.glv_batch_timing_begin.argtypes = [vp]
+        L.glv_batch_timing_end.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]
+        L.glv_batch_algorithmic_bytes.argtypes = [vp, C.c_uint, C.c_int]
+        L.glv_batch_algorithmic_bytes.restype = C.c_uint64
+        L.glv_batch_kernel_name.argtypes = [vp]; L.glv_batch_kernel_name.restype = C.c_char_p
+        L.glv_batch_set_grid.argtypes = [vp, C.c_int]
+        _lib = L
+    return _lib
+
+
+def _check(rc: int) -> None:
+    if rc != OK:
+        raise GlvError(rc, lib().glv_last_error().decode())
+
+
+@dataclass
+class Params:
+    """Mirror of glv_params; defaults are the shipped GLava configuration."""
+    n: int = 4096
+    channels: int = 2
+    fft_scale: float = 10.2
+    fft_cutoff: float = 0.3
+    gravity_step: float = 4.2
+    ur: float = 22050.0 / 256.0
+    avg_frames: int = 5
+    avg_window: bool = True
+    avg_window_kind: int = 0
+    log_mode: int = 0
+    bars: int = 80
+    smooth_factor: float = 0.025
+
+    def c(self) -> CParams:
+        return CParams(self.n, self.channels, self.fft_scale, self.fft_cutoff, self.gravity_step, self.ur,
+                       self.avg_frames, int(self.avg_window), self.avg_window_kind, self.log_mode,
+                       self.bars, self.smooth_factor)
+
+
+def _ptr(x) -> C.c_void_p:
+    """Raw pointer of a torch tensor / numpy array / int / None."""
+    if x is None:
+        return C.c_void_p(None)
+    if isinstance(x, int):
+        return C.c_void_p(x)
+    if hasattr(x, "data_ptr"):
+        return C.c_void_p(x.data_ptr())
+    if hasattr(x, "ctypes"):
+        return C.c_void_p(x.ctypes.data)
+    raise TypeError(type(x))
+
+
+class Batch:
+    """B independent stereo streams on one GPU (glv_batch)."""
+
+    def __init__(self, params: Params, streams: int, ops_mask: int = OP_FFT, device: int = 0):
+        self.params, self.streams, self.ops_mask, self.device = params, streams, ops_mask, device
+        self._h = C.c_void_p(None)
+        cp = params.c()
+        _check(lib().glv_batch_create(C.byref(cp), streams, ops_mask, device, C.byref(self._h)))
+
+    def process_s16(self, d_pcm, d_out, ops: int = OP_FFT, stream: int | None = None) -> None:
+        _check(lib().glv_batch_process_s16(self._h, _ptr(d_pcm), _ptr(d_out), ops, _ptr(stream)))
+
+    def process_f32(self, d_in, d_out, ops: int = OP_FFT, stream: int | None = None) -> None:
+        _check(lib().glv_batch_process_f32(self._h, _ptr(d_in), _ptr(d_out), ops, _ptr(stream)))
+
+    def ring_update_s16(self, d_new, new_frames: int, d_out, ops: int = OP_FFT, stream: int | None = None) -> None:
+        _check(lib().glv_batch_ring_update_s16(self._h, _ptr(d_new), new_frames, _ptr(d_out), ops, _ptr(stream)))
+
+    def reset(self) -> None:
+        _check(lib().glv_batch_reset(self._h))
+
+    def timing_begin(self) -> None:
+        _check(lib().glv_batch_timing_begin(self._h))
+
+    def timing_end(self) -> tuple[float, int]:
+        ms, n = C.c_double(0), C.c_uint64(0)
+        _check(lib().glv_batch_timing_end(self._h, C.byref(ms), C.byref(n)))
+        return ms.value, n.value
+
+    def algorithmic_bytes(self, ops: int, input_is_s16: bool = True) -> int:
+        return int(lib().glv_batch_algorithmic_bytes(self._h, ops, int(input_is_s16)))
+
+    def kernel_name(self) -> str:
+        return lib().glv_batch_kernel_name(self._h).decode()
+
+    def set_grid(self, grid: int) -> None:
+        _check(lib().glv_batch_set_grid(self._h, grid))
+
+    def close(self) -> None:
+        if self._h:
+            lib().glv_batch_destroy(self._h)
+            self._h = C.c_void_p(None)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class State:
+    """Per-(stream, channel) state behind the single-buffer drop-ins (glv_state): the
+    replacement for the `*udata` slot of the reference's operator seam (render.c:106-118)."""
+
+    def __init__(self, params: Params, device: int = 0):
+        self.params = params
+        self._h = C.c_void_p(None)
+        cp = params.c()
+        _check(lib().glv_state_create(C.byref(cp), device, C.byref(self._h)))
+
+    def _call(self, name: str, buf) -> None:
+        cp = self.params.c()
+        _check(getattr(lib(), name)(C.byref(cp), self._h, _ptr(buf)))
+
+    def fft(self, buf) -> None: self._call("glv_fft", buf)                 # transform_fft
+    def gravity(self, buf) -> None: self._call("glv_gravity", buf)         # transform_gravity
+    def average(self, buf) -> None: self._call("glv_average", buf)         # transform_average
+    def wrange(self, buf) -> None: self._call("glv_wrange", buf)           # transform_wrange
+    def fft_gravity_average(self, buf) -> None: self._call("glv_fft_gravity_average", buf)
+
+    def reset(self) -> None:
+        _check(lib().glv_state_reset(self._h))
+
+    def close(self) -> None:
+        if self._h:
+            lib().glv_state_destroy(self._h)
+            self._h = C.c_void_p(None)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def unpack_s16(pcm, frames: int, channels, l, r, device: int = 0) -> None:
+    """fifo.c:94-110 on the device; host numpy buffers in/out."""
+    _check(lib().glv_unpack_s16(device, _ptr(pcm), frames, channels, _ptr(l), _ptr(r)))
+
+
+def device_count() -> int:
+    return int(lib().glv_device_count())

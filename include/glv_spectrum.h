@@ -153,6 +153,9 @@ int glv_batch_timing_end(glv_batch* b, double* kernel_ms, uint64_t* launches);
 /* Algorithmic HBM bytes one process call moves for the given ops. */
 uint64_t glv_batch_algorithmic_bytes(const glv_batch* b, unsigned ops, int input_is_s16);
 
+/* Launch-geometry override for tuning (workgroups of the persistent frame kernel; 0 = automatic). */
+int glv_batch_set_grid(glv_batch* b, int grid);
+
 /* Name of the kernel the last process call launched (for matching rocprofv3 rows). */
 const char* glv_batch_kernel_name(const glv_batch* b);
 

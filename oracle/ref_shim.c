@@ -153,3 +153,36 @@ int glvref_fifo_run(const char* fifo_path, const int16_t* pcm, size_t chunks, si
     *n_events = ev;
     return rc;
 }
+
+/* ---- CPU baseline ("reference" kind in bench.py) -----------------------------------------
+ * `frames` stereo frames of interleaved s16 PCM ([frames][n][2]) through the reference's own
+ * transform_fft (both channels), optionally followed by transform_gravity + transform_average
+ * with per-channel slots that persist across the frames of the call (one stream's history).
+ * The unpack loop is the 2-line body of fifo.c:105-106 (the surrounding `entry` is a static
+ * thread function bound to a file descriptor, exercised separately by glvref_fifo_run).
+ * Returns a checksum so the work cannot be optimised away. */
+double glvref_bench_frames(const glvref_params* p, const int16_t* pcm, size_t frames, size_t n, int with_state) {
+    struct gl_data gl; fill(&gl, p);
+    float* l = malloc(sizeof(float) * n);
+    float* r = malloc(sizeof(float) * n);
+    void* gs[2] = { NULL, NULL };
+    void* as[2] = { NULL, NULL };
+    double acc = 0;
+    for (size_t f = 0; f < frames; ++f) {
+        const int16_t* buf = pcm + f * 2 * n;
+        for (size_t q = 0, i = 0; q < 2 * n; q += 2, ++i) {
+            l[i] = buf[q] / (float) 65535;
+            r[i] = buf[q + 1] / (float) 65535;
+        }
+        struct gl_sampler_data dl = { .buf = l, .sz = n }, dr = { .buf = r, .sz = n };
+        transform_fft(&gl, NULL, &dl);
+        transform_fft(&gl, NULL, &dr);
+        if (with_state) {
+            transform_gravity(&gl, &gs[0], &dl); transform_average(&gl, &as[0], &dl);
+            transform_gravity(&gl, &gs[1], &dr); transform_average(&gl, &as[1], &dr);
+        }
+        acc += l[1] + r[1];
+    }
+    free(l); free(r); free(gs[0]); free(gs[1]); free(as[0]); free(as[1]);
+    return acc;
+}

@@ -42,14 +42,20 @@ struct Emu {
 
     // one channel row given register-resident inputs -> out_row
     static void finish(std::vector<Thread>& th, float* out_row, size_t row, const FrameArgs& a) {
-        for (int tid = 0; tid < T; ++tid) FR::template epilogue<LOG_MODE>(th[tid].v, out_row, row, tid, a);
+        const bool st = (a.ops & (OP_GRAVITY | OP_AVERAGE)) != 0, raw = (a.ops & OP_RAW) != 0;
+        for (int tid = 0; tid < T; ++tid) {
+            if (raw && st)       FR::template epilogue<LOG_MODE, EPI_RAW_STATE>(th[tid].v, out_row, row, tid, a);
+            else if (raw)        FR::template epilogue<LOG_MODE, EPI_RAW>(th[tid].v, out_row, row, tid, a);
+            else if (st)         FR::template epilogue<LOG_MODE, EPI_MAG_STATE>(th[tid].v, out_row, row, tid, a);
+            else                 FR::template epilogue<LOG_MODE, EPI_MAG>(th[tid].v, out_row, row, tid, a);
+        }
     }
 
     static void frame_s16(const int16_t* frame, size_t unit, const FrameArgs& a) {
         std::vector<Thread> th(T);
         std::vector<cf> lds(NN);
         std::vector<typename FR::Pcm> pcm(T);
-        for (int tid = 0; tid < T; ++tid) FR::load_pcm(pcm[tid], frame, tid);
+        for (int tid = 0; tid < T; ++tid) FR::load_pcm(pcm[tid], frame, tid, a.rot);
         for (int ch = 0; ch < 2; ++ch) {
             for (int tid = 0; tid < T; ++tid) {
                 if (ch == 0) FR::template unpack_window<0>(th[tid].v, pcm[tid], a.win, tid, a.mono != 0);

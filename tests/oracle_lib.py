@@ -198,6 +198,8 @@ class Ref:
             L.glvref_fifo_run.argtypes = [C.c_char_p, _i16p, C.c_size_t, C.c_size_t, C.c_size_t, C.c_int,
                                           _f32p, _u8p, C.c_size_t, C.POINTER(C.c_size_t)]
             L.glvref_fifo_run.restype = C.c_int
+            L.glvref_bench_frames.argtypes = [P, _i16p, C.c_size_t, C.c_size_t, C.c_int]
+            L.glvref_bench_frames.restype = C.c_double
             cls._lib = L
         return cls._lib
 

@@ -1,0 +1,300 @@
+"""GPU (MI355X): parity of the HIP path against the oracle, called through the C ABI only.
+
+Bars (BASELINE.json north_star):
+  * bit-exact for the s16 -> f32 unpack/index path and for everything up to and including the
+    FFT butterflies (GLV_OP_RAW exposes the pre-abs/log values), and for gravity/average applied
+    to those raw values;
+  * <= 1e-5 relative for the magnitudes after log/tilt (log_mode 0 is expected to be bit-identical
+    except for last-ulp differences between the device's and glibc's fp64 log).
+The oracle (oracle/liboracle.so) is the checker; it is pinned to the compiled reference by
+tests/test_oracle.py.  /root/reference is never touched here.
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from oracle_lib import Oracle, StreamOracle, lcg_pcm_fast
+
+pytestmark = pytest.mark.gpu
+
+REL = 1e-5   # north_star tolerance for magnitudes
+
+
+def bits(a):
+    return np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)
+
+
+def rel_err(got, want):
+    return np.abs(got.astype(np.float64) - want) / np.maximum(np.abs(want.astype(np.float64)), 1e-30)
+
+
+@pytest.fixture(scope="module")
+def G(glvlib):
+    import torch
+    assert torch.cuda.is_available(), "gpu-marked tests need a GPU"
+    assert glvlib.device_count() >= 1
+    return glvlib
+
+
+def run_batch(G, params, pcm_np, streams, ops, ops_mask=None, in_f32=False):
+    import torch
+    n = params.n
+    b = G.Batch(params, streams, ops if ops_mask is None else ops_mask)
+    d_in = torch.from_numpy(pcm_np).cuda()
+    d_out = torch.full((streams * 2, n), float("nan"), dtype=torch.float32, device="cuda")
+    (b.process_f32 if in_f32 else b.process_s16)(d_in, d_out, ops)
+    torch.cuda.synchronize()
+    out = d_out.cpu().numpy()
+    b.close()
+    return out
+
+
+# ---- unpack --------------------------------------------------------------------------------------
+def test_unpack_all_65536_inputs_bit_exact(G):
+    v = np.arange(-32768, 32768, dtype=np.int32).astype(np.int16)
+    pcm = np.ascontiguousarray(np.stack([v, v[::-1]], axis=1)).reshape(-1)
+    l = np.empty(65536, np.float32); r = np.empty(65536, np.float32)
+    G.unpack_s16(pcm, 65536, 2, l, r)
+    assert (bits(l) == bits(v.astype(np.float32) / np.float32(65535))).all()
+    assert (bits(r) == bits(v[::-1].astype(np.float32) / np.float32(65535))).all()
+    # mono mix: C integer (a+b)/2 truncating toward zero (fifo.c:99)
+    G.unpack_s16(pcm, 65536, 1, l, r)
+    wl, wr = Oracle.unpack_s16(pcm, channels=1)
+    assert (bits(l) == bits(wl)).all() and (bits(r) == bits(wr)).all()
+    # NULL pcm == poll-timeout zero fill (fifo.c:67-79)
+    G.unpack_s16(None, 16, 2, l[:16], r[:16])
+    assert not l[:16].any() and not r[:16].any()
+
+
+# ---- FFT core: bit exact, every size -----------------------------------------------------------------
+@pytest.mark.parametrize("n", [512, 1024, 2048, 4096, 8192, 16384])
+def test_fft_raw_bit_exact_and_magnitude_within_tol(G, n):
+    streams = 37                      # ragged: not a multiple of any slots-per-workgroup
+    pcm = lcg_pcm_fast(2000 + n, streams * 2 * n)
+    raw = run_batch(G, G.Params(n=n), pcm, streams, G.OP_FFT | G.OP_RAW)
+    mag = run_batch(G, G.Params(n=n), pcm, streams, G.OP_FFT)
+    fast = run_batch(G, G.Params(n=n, log_mode=1), pcm, streams, G.OP_FFT)
+    nbad = 0
+    for u in range(streams):
+        want, wraw = StreamOracle(n, gravity=False, average=False).frame(pcm[u * 2 * n:(u + 1) * 2 * n], want_raw=True)
+        assert (bits(wraw) == bits(raw[2 * u:2 * u + 2])).all(), f"raw FFT differs, stream {u}"
+        got = mag[2 * u:2 * u + 2]
+        assert rel_err(got, want).max() <= REL
+        nbad += int((bits(got) != bits(want)).sum())
+        # strict log mode: at most one float ulp away anywhere
+        assert np.abs(bits(got).astype(np.int64) - bits(want).astype(np.int64)).max() <= 1
+        assert rel_err(fast[2 * u:2 * u + 2], want).max() <= REL
+    # strict mode is bit-identical except for rare last-ulp fp64-log differences
+    assert nbad <= 1e-4 * streams * 2 * n, nbad
+
+
+def test_golden_vectors_through_gpu(G, golden):
+    """Committed outputs of the compiled reference (tests/golden) vs the f32-planar GPU path."""
+    for key, seed, n in (("fft_n512_seed12857", 12857, 512), ("fft_n1024_seed13369", 13369, 1024),
+                         ("fft_n4096_seed16441", 16441, 4096), ("fft_n16384_seed28729", 28729, 16384),
+                         ("fft_kat_survey", 12345, 4096)):
+        x = lcg_pcm_fast(seed, n).astype(np.float32) / np.float32(65535)
+        st = G.State(G.Params(n=n))
+        buf = x.copy()
+        st.fft(buf)
+        st.close()
+        assert rel_err(buf, golden[key]).max() <= REL, key
+        assert np.abs(bits(buf).astype(np.int64) - bits(golden[key]).astype(np.int64)).max() <= 1, key
+    # parameters and edge inputs
+    st = G.State(G.Params(n=1024, fft_scale=3.0, fft_cutoff=0.7))
+    buf = (lcg_pcm_fast(7, 1024).astype(np.float32) / np.float32(65535)); st.fft(buf)
+    assert rel_err(buf, golden["fft_n1024_scale3_cut0p7"]).max() <= REL
+    st.close()
+    st = G.State(G.Params(n=1024))
+    buf = np.zeros(1024, np.float32); st.fft(buf)
+    assert (bits(buf) == bits(golden["fft_n1024_zeros"])).all()
+    buf = np.full(1024, 32767 / 65535, np.float32); st.fft(buf)
+    assert rel_err(buf, golden["fft_n1024_dc"]).max() <= REL
+    st.close()
+
+
+# ---- stateful operators ----------------------------------------------------------------------------
+def oracle_raw_chain(n, F, win, gravity, average, frames_pcm, streams, gravity_step=4.2, ur=86.1328125):
+    """fft(raw) -> gravity -> average on the oracle, all float ops => bit-comparable with EPI_RAW_STATE."""
+    outs = []
+    grav = np.zeros((streams * 2, n), np.float32)
+    hist = np.zeros((streams * 2, F, n), np.float32)
+    heads = [C.c_size_t(0) for _ in range(streams * 2)]
+    for pcm in frames_pcm:
+        out = np.empty((streams * 2, n), np.float32)
+        for u in range(streams):
+            _, raw = StreamOracle(n, gravity=False, average=False).frame(pcm[u * 2 * n:(u + 1) * 2 * n], want_raw=True)
+            for c in range(2):
+                row = np.ascontiguousarray(raw[c])
+                if gravity: Oracle.gravity(row, grav[2 * u + c], gravity_step, ur)
+                if average: Oracle.average(row, hist[2 * u + c], heads[2 * u + c], F, win)
+                out[2 * u + c] = row
+        outs.append(out)
+    return outs
+
+
+@pytest.mark.parametrize("F,win,ops", [(5, True, 2 | 4), (6, False, 2 | 4), (1, True, 2 | 4), (3, True, 4), (5, True, 2)])
+def test_gravity_average_bit_exact_on_raw(G, F, win, ops):
+    import torch
+    n, streams, nframes = 1024, 5, 2 * F + 3
+    frames = [lcg_pcm_fast(3000 + 17 * F + fr, streams * 2 * n) for fr in range(nframes)]
+    want = oracle_raw_chain(n, F, win, bool(ops & 2), bool(ops & 4), frames, streams)
+    b = G.Batch(G.Params(n=n, avg_frames=F, avg_window=win), streams, G.OP_FFT | ops)
+    d_out = torch.empty((streams * 2, n), dtype=torch.float32, device="cuda")
+    for fr in range(nframes):
+        b.process_s16(torch.from_numpy(frames[fr]).cuda(), d_out, G.OP_FFT | G.OP_RAW | ops)
+        got = d_out.cpu().numpy()
+        assert (bits(got) == bits(want[fr])).all(), f"frame {fr}"
+    b.close()
+
+
+@pytest.mark.parametrize("n,F", [(512, 5), (4096, 5), (16384, 6)])
+def test_full_chain_magnitudes(G, n, F):
+    """fft -> gravity -> average with the log in between: tolerance 1e-5 relative (+ tiny absolute
+    floor because gravity subtracts and can land arbitrarily close to zero)."""
+    import torch
+    streams, nframes = 3, F + 3
+    sos = [StreamOracle(n, avg_frames=F) for _ in range(streams)]
+    b = G.Batch(G.Params(n=n, avg_frames=F), streams, G.OP_FFT | G.OP_GRAVITY | G.OP_AVERAGE)
+    d_out = torch.empty((streams * 2, n), dtype=torch.float32, device="cuda")
+    for fr in range(nframes):
+        pcm = lcg_pcm_fast(4000 + n + fr, streams * 2 * n)
+        b.process_s16(torch.from_numpy(pcm).cuda(), d_out, G.OP_FFT | G.OP_GRAVITY | G.OP_AVERAGE)
+        got = d_out.cpu().numpy()
+        for u in range(streams):
+            want = sos[u].frame(pcm[u * 2 * n:(u + 1) * 2 * n])
+            assert np.allclose(got[2 * u:2 * u + 2], want, rtol=REL, atol=2e-6), (fr, u)
+    b.close()
+
+
+def test_golden_chain_through_single_stream_dropins(G, golden):
+    """glv_fft / glv_gravity / glv_average used like the reference's operator table
+    (render.c:2140-2156), checked against the compiled reference's committed outputs."""
+    n = 1024
+    for tag, F, win in (("F5w", 5, True), ("F6u", 6, False), ("F1w", 1, True)):
+        want = golden[f"chain_n1024_{tag}"]
+        p = G.Params(n=n, avg_frames=F, avg_window=win, ur=86.1328125)
+        sl, sr = G.State(p), G.State(p)          # one state per channel, like the t_data[] slots
+        fl, fr_ = G.State(p), G.State(p)         # fused variant
+        for fr in range(9):
+            pcm = lcg_pcm_fast(500 + fr, 2 * n).reshape(n, 2)
+            for c, (st, fs) in enumerate(((sl, fl), (sr, fr_))):
+                x = pcm[:, c].astype(np.float32) / np.float32(65535)
+                buf = x.copy(); st.fft(buf); st.gravity(buf); st.average(buf)
+                assert np.allclose(buf, want[fr, c], rtol=REL, atol=2e-6), (tag, fr, c)
+                buf2 = x.copy(); fs.fft_gravity_average(buf2)
+                assert np.allclose(buf2, want[fr, c], rtol=REL, atol=2e-6), (tag, fr, c, "fused")
+        for s in (sl, sr, fl, fr_): s.close()
+
+
+def test_wrange_and_state_reset(G, golden):
+    p = G.Params(n=512)
+    st = G.State(p)
+    b = np.zeros(512, np.float32)
+    b[:256] = lcg_pcm_fast(31, 256).astype(np.float32) / np.float32(65535)
+    st.wrange(b)
+    assert (bits(b[:256]) == bits(golden["wrange_seed31"])).all()
+    # gravity state persists, reset clears it
+    x = np.full(512, 0.5, np.float32); st.gravity(x)
+    y = np.zeros(512, np.float32); st.gravity(y)
+    g = np.float32(4.2) * (np.float32(1.0) / np.float32(p.ur))
+    assert (x == np.float32(0.5) - g).all() and (y == (np.float32(0.5) - g) - g).all()
+    st.reset()
+    z = np.zeros(512, np.float32); st.gravity(z)
+    assert (z == np.float32(0.0) - g).all()
+    st.close()
+
+
+# ---- layouts / modes -----------------------------------------------------------------------------------
+def test_f32_planar_batch_and_mono(G):
+    n, streams = 2048, 9
+    x = (np.random.default_rng(3).standard_normal((streams * 2, n)) * 0.3).astype(np.float32)
+    raw = run_batch(G, G.Params(n=n), x, streams, G.OP_FFT | G.OP_RAW, in_f32=True)
+    for r in range(streams * 2):
+        _, wraw = Oracle.transform_fft(x[r], want_raw=True)
+        assert (bits(raw[r]) == bits(wraw)).all()
+    pcm = lcg_pcm_fast(88, streams * 2 * n)
+    got = run_batch(G, G.Params(n=n, channels=1), pcm, streams, G.OP_FFT | G.OP_RAW)
+    for u in range(streams):
+        _, wraw = StreamOracle(n, channels=1, gravity=False, average=False).frame(pcm[u * 2 * n:(u + 1) * 2 * n], want_raw=True)
+        assert (bits(got[2 * u:2 * u + 2]) == bits(wraw)).all()
+
+
+def test_fifo_ring_mode(G):
+    """glv_batch_ring_update_s16 == fifo.c:91-112 ring shift/append (+ :67-79 zero fill) followed by
+    the transform of the whole window."""
+    import torch
+    n, streams, nf = 1024, 4, 256
+    b = G.Batch(G.Params(n=n), streams, G.OP_FFT)
+    rl = np.zeros((streams, n), np.float32); rr = np.zeros((streams, n), np.float32)
+    d_out = torch.empty((streams * 2, n), dtype=torch.float32, device="cuda")
+    for step in range(7):
+        zero_fill = step == 3
+        new = lcg_pcm_fast(600 + step, streams * nf * 2).reshape(streams, nf * 2)
+        b.ring_update_s16(None if zero_fill else torch.from_numpy(new).cuda(), nf, d_out, G.OP_FFT | G.OP_RAW)
+        got = d_out.cpu().numpy()
+        for u in range(streams):
+            chunk = np.ascontiguousarray(new[u])
+            Oracle.lib().glvo_ring_update_s16(rl[u], rr[u], n, None if zero_fill else chunk.ctypes.data_as(C.c_void_p), nf, 2)
+            _, wl = Oracle.transform_fft(rl[u], want_raw=True)
+            _, wr = Oracle.transform_fft(rr[u], want_raw=True)
+            assert (bits(got[2 * u]) == bits(wl)).all() and (bits(got[2 * u + 1]) == bits(wr)).all(), (step, u)
+    b.close()
+
+
+def test_error_behaviour(G):
+    import torch
+    b = G.Batch(G.Params(n=512), 2, G.OP_FFT)
+    d = torch.zeros(2 * 2 * 512, dtype=torch.int16, device="cuda")
+    o = torch.zeros((4, 512), dtype=torch.float32, device="cuda")
+    with pytest.raises(G.GlvError) as ei:
+        b.process_s16(d, o, G.OP_FFT | G.OP_GRAVITY)      # state not allocated
+    assert ei.value.code == G.ERR_STATE
+    with pytest.raises(G.GlvError) as ei:
+        b.process_s16(None, o, G.OP_FFT)
+    assert ei.value.code == G.ERR_INVALID
+    with pytest.raises(G.GlvError) as ei:
+        b.ring_update_s16(d, 255, o, G.OP_FFT)            # odd / non-dividing update size
+    assert ei.value.code == G.ERR_INVALID
+    b.close()
+
+
+# ---- BASELINE.json full size: 64K streams x N=4096 --------------------------------------------------
+def test_full_size_64k_streams_properties(G):
+    """configs[1]: 65536 stereo streams, N=4096, window+FFT+magnitude.  Size-independent checks:
+    (a) a random subset of >= 1024 streams against the oracle (magnitudes <= 1e-5 rel);
+    (b) every stream that was given identical PCM produces identical output bits (indexing across
+        the whole batch, all workgroups/slots);
+    (c) no element left unwritten."""
+    import torch
+    n, streams = 4096, 65536
+    g = torch.Generator(device="cuda"); g.manual_seed(1234)
+    d_pcm = torch.randint(-32768, 32768, (streams, n * 2), dtype=torch.int16, device="cuda", generator=g)
+    # plant duplicates of stream 7 at scattered positions
+    dup = [7, 8, 1023, 4097, 32768, 65535, 40001]
+    for s in dup[1:]:
+        d_pcm[s] = d_pcm[7]
+    d_out = torch.full((streams * 2, n), float("nan"), dtype=torch.float32, device="cuda")
+    b = G.Batch(G.Params(n=n), streams, G.OP_FFT)
+    b.process_s16(d_pcm, d_out, G.OP_FFT)
+    torch.cuda.synchronize()
+    assert not torch.isnan(d_out).any().item()
+    ref7 = d_out[14:16]
+    for s in dup[1:]:
+        assert torch.equal(d_out[2 * s:2 * s + 2].view(torch.int32), ref7.view(torch.int32)), s
+    rng = np.random.default_rng(99)
+    subset = np.unique(np.concatenate([rng.integers(0, streams, 1040), [0, streams - 1]]))
+    assert subset.size >= 1024
+    idx = torch.from_numpy(subset).cuda()
+    pcm_sub = d_pcm[idx].cpu().numpy()
+    rows = torch.stack([2 * idx, 2 * idx + 1], dim=1).reshape(-1)
+    out_sub = d_out[rows].cpu().numpy().reshape(subset.size, 2, n)
+    worst, nbad = 0.0, 0
+    for i in range(subset.size):
+        want = StreamOracle(n, gravity=False, average=False).frame(pcm_sub[i])
+        worst = max(worst, rel_err(out_sub[i], want).max())
+        nbad += int((bits(out_sub[i]) != bits(want)).sum())
+    assert worst <= REL, worst
+    assert nbad <= 1e-4 * subset.size * 2 * n, nbad
+    b.close()

@@ -103,19 +103,27 @@ struct Frame {
             p.lo[i] = u.x; p.hi[i] = u.y;
         }
     }
+    // fifo.c:98-102 mono mix, applied once to the packed samples so that the per-channel unpack
+    // below stays branch free: both channels become ((L + R) / 2) (C int division).
+    GLV_HD static void mono_mix(Pcm& p) {
+#pragma unroll
+        for (int i = 0; i < E; ++i) {
+            const int m0 = ((int) (int16_t) (p.lo[i] & 0xffffu) + (int) (int16_t) (p.lo[i] >> 16)) / 2;
+            const int m1 = ((int) (int16_t) (p.hi[i] & 0xffffu) + (int) (int16_t) (p.hi[i] >> 16)) / 2;
+            p.lo[i] = ((uint32_t) m0 & 0xffffu) | ((uint32_t) m0 << 16);
+            p.hi[i] = ((uint32_t) m1 & 0xffffu) | ((uint32_t) m1 << 16);
+        }
+    }
     template <int CH>
-    GLV_HD static void unpack_window(cf (&v)[E], const Pcm& p, const double* win, int tid, bool mono) {
+    GLV_HD static void unpack_window(cf (&v)[E], const Pcm& p, const double* win, int tid) {
 #pragma unroll
         for (int i = 0; i < E; ++i) {
             const int c = i * T + tid;
-            const int l0 = (int16_t) (p.lo[i] & 0xffffu), r0 = (int16_t) (p.lo[i] >> 16);
-            const int l1 = (int16_t) (p.hi[i] & 0xffffu), r1 = (int16_t) (p.hi[i] >> 16);
-            float a, b;
-            if (mono) { a = unpack_s16_mono(l0, r0); b = unpack_s16_mono(l1, r1); }
-            else      { a = unpack_s16(CH == 0 ? l0 : r0); b = unpack_s16(CH == 0 ? l1 : r1); }
+            const int s0 = CH == 0 ? (int) (int16_t) (p.lo[i] & 0xffffu) : (int) (int16_t) (p.lo[i] >> 16);
+            const int s1 = CH == 0 ? (int) (int16_t) (p.hi[i] & 0xffffu) : (int) (int16_t) (p.hi[i] >> 16);
             const d2 w = reinterpret_cast<const d2*>(win)[c];
-            v[i].x = apply_window(a, w.x);
-            v[i].y = apply_window(b, w.y);
+            v[i].x = apply_window(unpack_s16(s0), w.x);
+            v[i].y = apply_window(unpack_s16(s1), w.y);
         }
     }
     GLV_HD static void load_f32_window(cf (&v)[E], const float* row, const double* win, int tid) {
@@ -218,7 +226,7 @@ struct Frame {
                 const int q = out_index<P - 1>(tid, gi, r);
                 const int n0 = 2 * q;
                 cf val = v[gi * PI::R + r];
-                if constexpr (EPI != EPI_RAW) {
+                if constexpr (EPI == EPI_MAG || EPI == EPI_MAG_STATE) {
                     const float y0 = __builtin_fabsf(val.x) + 1.0f, y1 = __builtin_fabsf(val.y) + 1.0f;   // render.c:843-844
                     val.x = log_third<LOG_MODE>(y0) * tilt(n0, a.inv_n, a.fft_scale, a.one_minus_cutoff);  // :845
                     val.y = log_third<LOG_MODE>(y1) * tilt(n0 + 1, a.inv_n, a.fft_scale, a.one_minus_cutoff);

@@ -121,11 +121,12 @@ glv_frame_kernel(const FrameArgs a) {
         if constexpr (IN_MODE == IN_S16_STEREO) {
             typename FR::Pcm pcm;
             FR::load_pcm(pcm, static_cast<const int16_t*>(a.in) + (size_t) u * 2 * N, tid, a.rot);
+            if (a.mono) FR::mono_mix(pcm);
             // channel 0 (left), then channel 1 (right), from the same 8-byte loads
-            FR::template unpack_window<0>(v, pcm, win, tid, a.mono != 0);
+            FR::template unpack_window<0>(v, pcm, win, tid);
             BD::template run<0>(v, tw_all, a.tw, xslot, tid, xcount);
             if (active) finish(v, (size_t) u * 2);
-            FR::template unpack_window<1>(v, pcm, win, tid, a.mono != 0);
+            FR::template unpack_window<1>(v, pcm, win, tid);
             BD::template run<0>(v, tw_all, a.tw, xslot, tid, xcount);
             if (active) finish(v, (size_t) u * 2 + 1);
         } else {

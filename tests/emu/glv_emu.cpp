@@ -55,11 +55,14 @@ struct Emu {
         std::vector<Thread> th(T);
         std::vector<cf> lds(NN);
         std::vector<typename FR::Pcm> pcm(T);
-        for (int tid = 0; tid < T; ++tid) FR::load_pcm(pcm[tid], frame, tid, a.rot);
+        for (int tid = 0; tid < T; ++tid) {
+            FR::load_pcm(pcm[tid], frame, tid, a.rot);
+            if (a.mono) FR::mono_mix(pcm[tid]);
+        }
         for (int ch = 0; ch < 2; ++ch) {
             for (int tid = 0; tid < T; ++tid) {
-                if (ch == 0) FR::template unpack_window<0>(th[tid].v, pcm[tid], a.win, tid, a.mono != 0);
-                else         FR::template unpack_window<1>(th[tid].v, pcm[tid], a.win, tid, a.mono != 0);
+                if (ch == 0) FR::template unpack_window<0>(th[tid].v, pcm[tid], a.win, tid);
+                else         FR::template unpack_window<1>(th[tid].v, pcm[tid], a.win, tid);
             }
             run_pass<0>(th, lds, a.tw);
             const size_t row = unit * 2 + ch;

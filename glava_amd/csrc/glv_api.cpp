@@ -55,7 +55,7 @@ int validate(const glv_params* p) {
     if (p->avg_frames < 1 || p->avg_frames > GLV_MAX_AVG_FRAMES)
         return fail(GLV_ERR_INVALID, "avg_frames=%u: must be in [1, %d]", p->avg_frames, GLV_MAX_AVG_FRAMES);
     if (p->avg_window_kind > 1) return fail(GLV_ERR_INVALID, "avg_window_kind=%u: must be 0 or 1", p->avg_window_kind);
-    if (p->log_mode > 1) return fail(GLV_ERR_INVALID, "log_mode=%u: must be 0 or 1", p->log_mode);
+    if (p->log_mode > 2) return fail(GLV_ERR_INVALID, "log_mode=%u: must be 0, 1 or 2", p->log_mode);
     if (!(p->ur > 0.0f)) return fail(GLV_ERR_INVALID, "ur must be > 0");
     return GLV_OK;
 }
@@ -75,6 +75,7 @@ int ensure_device(int device) {
 struct Tables {
     glv::cf* d_tw = nullptr;
     double* d_win = nullptr;
+    glv::LogEntry* d_log = nullptr;
     int create(uint32_t n) {
         const uint32_t nn = n / 2;
         std::vector<glv::cf> tw(nn);
@@ -85,18 +86,23 @@ struct Tables {
         HIP_TRY(hipMalloc(&d_win, sizeof(double) * n));
         HIP_TRY(hipMemcpy(d_tw, tw.data(), sizeof(glv::cf) * (nn - 1), hipMemcpyHostToDevice));
         HIP_TRY(hipMemcpy(d_win, win.data(), sizeof(double) * n, hipMemcpyHostToDevice));
+        glv::LogEntry lt[64];
+        glv::make_log_table(lt);
+        HIP_TRY(hipMalloc(&d_log, sizeof(lt)));
+        HIP_TRY(hipMemcpy(d_log, lt, sizeof(lt), hipMemcpyHostToDevice));
         return GLV_OK;
     }
     void destroy() {
         if (d_tw) (void) hipFree(d_tw);
         if (d_win) (void) hipFree(d_win);
-        d_tw = nullptr; d_win = nullptr;
+        if (d_log) (void) hipFree(d_log);
+        d_tw = nullptr; d_win = nullptr; d_log = nullptr;
     }
 };
 
 void fill_common(glv::FrameArgs& a, const glv_params& p, const Tables& t) {
     std::memset(&a, 0, sizeof(a));
-    a.tw = t.d_tw; a.win = t.d_win;
+    a.tw = t.d_tw; a.win = t.d_win; a.logtab = t.d_log;
     a.F = p.avg_frames; a.mono = p.channels == 1; a.avg_window = p.avg_window != 0;
     a.inv_n = 1.0f / (float) p.n;
     a.fft_scale = p.fft_scale;
@@ -183,7 +189,7 @@ int timed_launch_end(glv_batch* b, hipStream_t st) {
     return GLV_OK;
 }
 
-// One update of `units` units through the fused kernel (or the post kernel when no FFT is asked).
+// One update of `units` channel rows through the fused kernel (or the post kernel when no FFT is asked).
 int process(glv_batch* b, const void* d_in, int in_mode, float* d_out, unsigned ops, uint32_t units,
             uint32_t rot, hipStream_t st) {
     if (!d_in || !d_out) return fail(GLV_ERR_INVALID, "NULL device pointer");
@@ -298,7 +304,7 @@ int glv_batch_destroy(glv_batch* b) {
 int glv_batch_process_s16(glv_batch* b, const int16_t* d_pcm, float* d_out, unsigned ops, void* hip_stream) {
     if (!b) return fail(GLV_ERR_INVALID, "batch is NULL");
     if (!(ops & GLV_OP_FFT)) return fail(GLV_ERR_INVALID, "s16 input requires GLV_OP_FFT");
-    return process(b, d_pcm, glv::IN_S16_STEREO, d_out, ops, b->streams, 0, (hipStream_t) hip_stream);
+    return process(b, d_pcm, glv::IN_S16_STEREO, d_out, ops, b->streams * 2, 0, (hipStream_t) hip_stream);
 }
 
 int glv_batch_process_f32(glv_batch* b, const float* d_f32, float* d_out, unsigned ops, void* hip_stream) {
@@ -328,7 +334,7 @@ int glv_batch_ring_update_s16(glv_batch* b, const int16_t* d_new, uint32_t new_f
     else       HIP_TRY(hipMemset2DAsync(dst, pitch, 0, width, b->streams, st));   // fifo.c:67-79
     b->ring_pos = (b->ring_pos + new_frames) % n;
     // oldest sample now sits at ring_pos; rotation in complex points (pairs of frames)
-    return process(b, b->d_ring, glv::IN_S16_STEREO, d_out, ops, b->streams, b->ring_pos / 2, st);
+    return process(b, b->d_ring, glv::IN_S16_RING, d_out, ops, b->streams * 2, b->ring_pos / 2, st);
 }
 
 int glv_batch_timing_begin(glv_batch* b) {

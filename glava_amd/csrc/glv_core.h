@@ -27,6 +27,14 @@
 #define GLV_HD inline
 #endif
 
+// Scheduling fence: nothing is moved across it by the backend's instruction scheduler.  Used to
+// bound how many table loads the compiler clusters (each in-flight window pair costs 4 VGPRs).
+#if defined(__HIP_DEVICE_COMPILE__)
+#define GLV_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+#else
+#define GLV_SCHED_FENCE() ((void) 0)
+#endif
+
 namespace glv {
 
 struct alignas(8) cf { float x, y; };        // one complex point == two consecutive floats of the reference's data[]
@@ -109,10 +117,12 @@ struct Plan {
 
 // LDS address (in complex units, within one FFT's exchange region) of element index q for the
 // exchange that follows pass `pass`.  Only the first pass writes with a lane stride of 16
-// elements (q = 16*tid + e); XOR-ing the low four bits with the next four makes both that
-// write (16-lane ds_write_b64 groups) and the following contiguous read (32-lane ds_read_b64
-// groups) bank-conflict free without padding.  Later exchanges are conflict free as is.
-GLV_HD constexpr int lds_index(int pass, int q) { return pass == 0 ? (q ^ ((q >> 4) & 15)) : q; }
+// elements (q = 16*tid + e); padding one element per 16 turns that into a stride of 17 -- conflict
+// free for the 16-lane ds_write_b64 groups -- and keeps every access of a phase at
+// `lane base + compile-time constant` (an XOR swizzle would need a separate address VGPR per
+// element).  The following read (q = i*nn/R + tid) sees one 2-way conflict per 32-lane group
+// (+1 LDS cycle); later exchanges are contiguous per 16 lanes and conflict free as they are.
+GLV_HD constexpr int lds_index(int pass, int q) { return pass == 0 ? q + (q >> 4) : q; }
 
 // ---- scalar pieces ----------------------------------------------------------------------------
 // fifo.c:105-106: (float) s16 / (float) 65535, IEEE single division.
@@ -146,10 +156,54 @@ GLV_HD float gravity(float b, float applied, float g) {
 }
 
 // render.c:844: (float)(log((double)y) / 3) with y = |x| + 1.0f already rounded to float (y >= 1).
-//   mode 0  "strict": fp64 log + fp64 divide, the reference's expression verbatim
-//   mode 1  "fast":   fp32 log, <= ~3e-7 relative (the parity bar is 1e-5)
-template <int LOG_MODE> GLV_HD float log_third(float y);
-template <> GLV_HD float log_third<0>(float y) { return (float) (::log((double) y) / 3); }
-template <> GLV_HD float log_third<1>(float y) { return ::logf(y) * (1.0f / 3.0f); }
+//   mode 0  fp64: table-driven double-precision log (relative error ~2^-50) times 1/3, rounded to
+//           float once -- equals the reference's float result except when the double value sits
+//           within ~1e-15 relative of a float rounding boundary (probability ~1e-8 per value)
+//   mode 1  fast: the hardware log2 (v_log_f32, 1 ulp) times ln2/3; <= ~2e-7 relative, the
+//           parity bar for magnitudes is 1e-5
+//   mode 2  audit: the device libm's fp64 log and a true fp64 division, the reference's
+//           expression verbatim (slow; for cross-checking mode 0)
+struct LogEntry;
+template <int LOG_MODE> GLV_HD float log_third(float y, const LogEntry* tab);
+
+#if defined(__HIP_DEVICE_COMPILE__)
+#define GLV_LOG2F(x) __builtin_amdgcn_logf(x)
+#else
+#define GLV_LOG2F(x) ::log2f(x)
+#endif
+
+// log table: for j = 0..63, c_j = 1 + j/64 (the value of the top six mantissa bits),
+// kLogTab[j] = { 1/c_j rounded to double, log(c_j) rounded to double }.  Generated on the host
+// by glv::make_log_table (glv_tables.h) and passed to the kernel in constant/global memory.
+struct alignas(16) LogEntry { double inv_c, log_c; };
+
+// y >= 1 finite.  y = 2^e * m, m in [1,2); c = m truncated to 6 mantissa bits; r = (m - c)/c in
+// [0, 2^-6); log y = e*ln2 + log c + log1p(r), log1p by a degree-7 polynomial (|error| < 2^-52).
+GLV_HD float log_third_table(float y, const LogEntry* tab) {
+    union { float f; uint32_t u; } in = { y };
+    const int e = (int) (in.u >> 23) - 127;
+    const uint32_t j = (in.u >> 17) & 63u;
+    union { uint32_t u; float f; } mm = { (in.u & 0x007fffffu) | 0x3f800000u };          // m
+    union { uint32_t u; float f; } cc = { (in.u & 0x007e0000u) | 0x3f800000u };          // c_j
+    const LogEntry t = tab[j];
+    const double d = (double) (mm.f - cc.f);             // exact in float: both in [1,2), same top bits
+    const double r = d * t.inv_c;
+    // log1p(r) = r - r^2/2 + r^3/3 - ... - r^8/8 ; explicit fma: these are OUR arithmetic, not the reference's
+    double p = -1.0 / 8.0;
+    p = __builtin_fma(p, r, 1.0 / 7.0);
+    p = __builtin_fma(p, r, -1.0 / 6.0);
+    p = __builtin_fma(p, r, 1.0 / 5.0);
+    p = __builtin_fma(p, r, -1.0 / 4.0);
+    p = __builtin_fma(p, r, 1.0 / 3.0);
+    p = __builtin_fma(p, r, -1.0 / 2.0);
+    p = __builtin_fma(p, r, 1.0);
+    const double l1p = p * r;
+    const double hi = __builtin_fma((double) e, 0.6931471805599453094, t.log_c);
+    return (float) ((hi + l1p) * (1.0 / 3.0));
+}
+
+template <> GLV_HD float log_third<0>(float y, const LogEntry* tab) { return log_third_table(y, tab); }
+template <> GLV_HD float log_third<1>(float y, const LogEntry*) { return GLV_LOG2F(y) * (0.69314718055994530942f / 3.0f); }
+template <> GLV_HD float log_third<2>(float y, const LogEntry*) { return (float) (::log((double) y) / 3); }
 
 }  // namespace glv

@@ -18,29 +18,42 @@
 
 namespace glv {
 
-enum InMode { IN_S16_STEREO = 0, IN_F32_PLANAR = 1 };
+enum InMode { IN_S16_STEREO = 0, IN_F32_PLANAR = 1, IN_S16_RING = 2 };
 enum Epi { EPI_RAW = 0, EPI_MAG = 1, EPI_MAG_STATE = 2, EPI_RAW_STATE = 3 };
 
 // ops bits as in include/glv_spectrum.h
 enum : uint32_t { OP_FFT = 1u, OP_GRAVITY = 2u, OP_AVERAGE = 4u, OP_RAW = 8u, OP_WRANGE = 16u, OP_BARS = 32u };
 
 struct FrameArgs {
-    const void* in;        // IN_S16_STEREO: int16 [units][n][2];  IN_F32_PLANAR: float [units][n]
-    float* out;            // [rows][n], rows = units*2 (s16) or units (f32)
+    const void* in;        // s16: int16 [units/2][n][2] (a unit is one channel row of a frame);  f32: float [units][n]
+    float* out;            // [units][n]
     float* grav;           // [rows][n] gravity state (only when gravity without average)
     float* hist;           // [rows][F][n] history ring (average); doubles as gravity state
     const cf* tw;          // nn-1 twiddles, layout glv::tw_offset
     const double* win;     // n window values (render.c:660 as expanded at :794)
-    uint32_t units;        // stereo frames (s16) or channel rows (f32) to process
+    const LogEntry* logtab; // 64 entries, log_mode 0 (glv_core.h)
+    uint32_t units;        // channel rows to process (2 per stereo frame)
     uint32_t ops;
     uint32_t F, head;      // ring: `head` receives the current frame; ages oldest..newest are
                            // head+1, ..., head+F-1, head  (mod F)
     uint32_t mono;         // fifo.c:98-102
     uint32_t avg_window;
-    uint32_t rot;          // s16 ring mode: rotation of the window start, in complex points (pairs of frames)
+    uint32_t rot;          // s16 ring mode (RING kernels): rotation of the window start, in complex points
     float inv_n, fft_scale, one_minus_cutoff, g, F_as_float;
     double wts[16];        // window_frame weights, oldest first (render.c:661 as expanded at :766)
 };
+
+// ---- addressing -------------------------------------------------------------------------------
+// Every HBM/LDS access of a phase is `uniform base + 32-bit byte offset`, the offsets of the 16
+// accesses differing only by compile-time constants.  That is the shape the gfx950 backend turns
+// into  global_load ... v_off, s[base:base+1] offset:imm  /  ds_read ... v_off offset:imm  -- one
+// offset VGPR per phase instead of sixteen 64-bit addresses kept alive across the frame loop.
+template <typename V> GLV_HD V ld(const void* base, uint32_t byte_off) {
+    return *reinterpret_cast<const V*>(static_cast<const char*>(base) + byte_off);
+}
+template <typename V> GLV_HD void st(void* base, uint32_t byte_off, const V& v) {
+    *reinterpret_cast<V*>(static_cast<char*>(base) + byte_off) = v;
+}
 
 // ring slot of age f (0 = oldest .. F-1 = newest = head)
 GLV_HD uint32_t ring_slot(uint32_t head, uint32_t f, uint32_t F) {
@@ -48,18 +61,18 @@ GLV_HD uint32_t ring_slot(uint32_t head, uint32_t f, uint32_t F) {
     return s >= F ? s - F : s;   // head < F, f < F  =>  s < 2F
 }
 
-// gravity (render.c:720-736) and average (render.c:738-771) for the float pair (n0, n0+1) of
-// channel row `row`; n = floats per row.  State traffic is 8 bytes per lane, lanes contiguous.
-// With both operators the newest ring slot doubles as the gravity state ("applied" of
-// render.c:724 is by construction the previous gravity output, i.e. the previous newest slot).
-GLV_HD cf apply_state(cf val, int n0, size_t row, uint32_t n, const FrameArgs& a) {
+// gravity (render.c:720-736) and average (render.c:738-771) for the float pair at byte offset
+// `off` of channel row `row`; n = floats per row.  State traffic is 8 bytes per lane, lanes
+// contiguous.  With both operators the newest ring slot doubles as the gravity state ("applied"
+// of render.c:724 is by construction the previous gravity output, i.e. the previous newest slot).
+GLV_HD cf apply_state(cf val, uint32_t off, size_t row, uint32_t n, const FrameArgs& a) {
     if (a.ops & OP_AVERAGE) {
-        float* h = a.hist + row * (size_t) a.F * n + n0;
+        float* h = a.hist + row * (size_t) a.F * n;                          // uniform
         const uint32_t F = a.F;
         cf acc = { 0.0f, 0.0f }, prev = { 0.0f, 0.0f };
-        if (F == 1) prev = *reinterpret_cast<const cf*>(h + (size_t) a.head * n);
+        if (F == 1) prev = ld<cf>(h + (size_t) a.head * n, off);
         for (uint32_t f = 0; f + 1 < F; ++f) {                               // oldest .. second newest
-            prev = *reinterpret_cast<const cf*>(h + (size_t) ring_slot(a.head, f, F) * n);
+            prev = ld<cf>(h + (size_t) ring_slot(a.head, f, F) * n, off);
             if (a.avg_window) {                                              // render.c:759, double product
                 acc.x = (float) ((double) acc.x + a.wts[f] * (double) prev.x);
                 acc.y = (float) ((double) acc.y + a.wts[f] * (double) prev.y);
@@ -68,7 +81,7 @@ GLV_HD cf apply_state(cf val, int n0, size_t row, uint32_t n, const FrameArgs& a
         if (a.ops & OP_GRAVITY) {
             val.x = gravity(val.x, prev.x, a.g); val.y = gravity(val.y, prev.y, a.g);
         }
-        *reinterpret_cast<cf*>(h + (size_t) a.head * n) = val;
+        st<cf>(h + (size_t) a.head * n, off, val);
         if (a.avg_window) {
             acc.x = (float) ((double) acc.x + a.wts[F - 1] * (double) val.x);
             acc.y = (float) ((double) acc.y + a.wts[F - 1] * (double) val.y);
@@ -76,10 +89,10 @@ GLV_HD cf apply_state(cf val, int n0, size_t row, uint32_t n, const FrameArgs& a
         val.x = acc.x / a.F_as_float;                                        // render.c:761
         val.y = acc.y / a.F_as_float;
     } else if (a.ops & OP_GRAVITY) {
-        cf* gs = reinterpret_cast<cf*>(a.grav + row * (size_t) n + n0);
-        const cf st = *gs;
-        val.x = gravity(val.x, st.x, a.g); val.y = gravity(val.y, st.y, a.g);
-        *gs = val;
+        float* gs = a.grav + row * (size_t) n;                               // uniform
+        const cf st0 = ld<cf>(gs, off);
+        val.x = gravity(val.x, st0.x, a.g); val.y = gravity(val.y, st0.y, a.g);
+        st<cf>(gs, off, val);
     }
     return val;
 }
@@ -88,51 +101,71 @@ template <int LOG_NN>
 struct Frame {
     using PL = Plan<LOG_NN>;
     static constexpr int NN = PL::NN, N = 2 * NN, T = PL::T, P = PL::P, E = 16;
+    // complex points of one LDS exchange region: the pass-0 exchange is padded by one point per 16
+    static constexpr int XREGION = NN + NN / 16;
 
     // ---- input: v[i] <- windowed sample pair (complex point) c = i*T + tid ---------------------
     // s16: one 8-byte load holds complex point c of BOTH channels: (L[2c], R[2c], L[2c+1], R[2c+1]).
-    struct Pcm { uint32_t lo[E], hi[E]; };   // lo = L[2c] | R[2c] << 16, hi = L[2c+1] | R[2c+1] << 16
+    // A slot transforms ONE channel row per iteration; the two channels of a frame are handled by
+    // neighbouring slots of the same workgroup at the same time, so the second reader of a frame's
+    // PCM hits the CU's L1 / the XCD's L2 and HBM still sees every PCM byte once -- while no lane has
+    // to park the other channel's samples in registers across a whole transform.
+    struct Raw { uint32_t x[E], y[E]; };     // x = L[2c] | R[2c] << 16,  y = L[2c+1] | R[2c+1] << 16
 
-    // `rot` (complex points) rotates the read position for the FIFO ring mode (fifo.c:91-92 keeps
-    // the newest samples at the end of the buffer; the device ring is circular instead).
-    GLV_HD static void load_pcm(Pcm& p, const int16_t* frame, int tid, uint32_t rot) {
-        const u32x2* src = reinterpret_cast<const u32x2*>(frame);
+    // RING: rotate the read position (complex points) for the FIFO ring mode -- fifo.c:91-92 keeps
+    // the newest samples at the end of the buffer by memmove; the device ring is circular instead.
+    template <bool RING>
+    GLV_HD static void load_pcm(Raw& p, const void* frame, int tid, uint32_t rot) {
 #pragma unroll
         for (int i = 0; i < E; ++i) {
-            const u32x2 u = src[(uint32_t) (i * T + tid + rot) & (uint32_t) (NN - 1)];
-            p.lo[i] = u.x; p.hi[i] = u.y;
+            uint32_t off;
+            if constexpr (RING) off = ((uint32_t) (i * T + tid + rot) & (uint32_t) (NN - 1)) * 8u;
+            else off = (uint32_t) tid * 8u + (uint32_t) (i * T) * 8u;
+            const u32x2 u = ld<u32x2>(frame, off);
+            p.x[i] = u.x; p.y[i] = u.y;
         }
     }
-    // fifo.c:98-102 mono mix, applied once to the packed samples so that the per-channel unpack
-    // below stays branch free: both channels become ((L + R) / 2) (C int division).
-    GLV_HD static void mono_mix(Pcm& p) {
+    // one sample of channel `ch` (0 = left/low half, 1 = right/high half) -- fifo.c:105-106;
+    // mono: fifo.c:98-102, ((L + R) / 2) with C int division, for both channels.
+    GLV_HD static float sample(uint32_t packed, uint32_t ch_shift, bool mono) {
+        if (mono) return unpack_s16(((int) (int16_t) (packed & 0xffffu) + (int) (int16_t) (packed >> 16)) / 2);
+        return unpack_s16((int) (int16_t) ((packed >> ch_shift) & 0xffffu));
+    }
+    // WCHUNK window pairs are fetched per scheduling fence: two chunks in flight hide the L2/LDS
+    // latency of the table while keeping the transient footprint at 2*WCHUNK*4 VGPRs.
+    static constexpr int WCHUNK = 4;
+    template <bool MONO>
+    GLV_HD static void unpack_window_impl(cf (&v)[E], const Raw& p, const void* win, int tid, uint32_t ch_shift) {
+        d2 w[2][WCHUNK];
 #pragma unroll
-        for (int i = 0; i < E; ++i) {
-            const int m0 = ((int) (int16_t) (p.lo[i] & 0xffffu) + (int) (int16_t) (p.lo[i] >> 16)) / 2;
-            const int m1 = ((int) (int16_t) (p.hi[i] & 0xffffu) + (int) (int16_t) (p.hi[i] >> 16)) / 2;
-            p.lo[i] = ((uint32_t) m0 & 0xffffu) | ((uint32_t) m0 << 16);
-            p.hi[i] = ((uint32_t) m1 & 0xffffu) | ((uint32_t) m1 << 16);
+        for (int j = 0; j < WCHUNK; ++j) w[0][j] = ld<d2>(win, (uint32_t) tid * 16u + (uint32_t) (j * T) * 16u);
+#pragma unroll
+        for (int c0 = 0; c0 < E; c0 += WCHUNK) {
+            const int cur = (c0 / WCHUNK) & 1;
+            if (c0 + WCHUNK < E) {
+#pragma unroll
+                for (int j = 0; j < WCHUNK; ++j)
+                    w[cur ^ 1][j] = ld<d2>(win, (uint32_t) tid * 16u + (uint32_t) ((c0 + WCHUNK + j) * T) * 16u);
+            }
+            GLV_SCHED_FENCE();
+#pragma unroll
+            for (int j = 0; j < WCHUNK; ++j) {
+                const int i = c0 + j;
+                v[i].x = apply_window(sample(p.x[i], ch_shift, MONO), w[cur][j].x);   // render.c:794
+                v[i].y = apply_window(sample(p.y[i], ch_shift, MONO), w[cur][j].y);
+            }
+            GLV_SCHED_FENCE();
         }
     }
-    template <int CH>
-    GLV_HD static void unpack_window(cf (&v)[E], const Pcm& p, const double* win, int tid) {
-#pragma unroll
-        for (int i = 0; i < E; ++i) {
-            const int c = i * T + tid;
-            const int s0 = CH == 0 ? (int) (int16_t) (p.lo[i] & 0xffffu) : (int) (int16_t) (p.lo[i] >> 16);
-            const int s1 = CH == 0 ? (int) (int16_t) (p.hi[i] & 0xffffu) : (int) (int16_t) (p.hi[i] >> 16);
-            const d2 w = reinterpret_cast<const d2*>(win)[c];
-            v[i].x = apply_window(unpack_s16(s0), w.x);
-            v[i].y = apply_window(unpack_s16(s1), w.y);
-        }
+    GLV_HD static void unpack_window(cf (&v)[E], const Raw& p, const void* win, int tid, uint32_t ch, bool mono) {
+        if (mono) unpack_window_impl<true>(v, p, win, tid, 0);
+        else unpack_window_impl<false>(v, p, win, tid, ch * 16u);
     }
-    GLV_HD static void load_f32_window(cf (&v)[E], const float* row, const double* win, int tid) {
-        const cf* src = reinterpret_cast<const cf*>(row);
+    GLV_HD static void load_f32_window(cf (&v)[E], const void* row, const void* win, int tid) {
 #pragma unroll
         for (int i = 0; i < E; ++i) {
-            const int c = i * T + tid;
-            const cf u = src[c];
-            const d2 w = reinterpret_cast<const d2*>(win)[c];
+            const cf u = ld<cf>(row, (uint32_t) tid * 8u + (uint32_t) (i * T) * 8u);
+            const d2 w = ld<d2>(win, (uint32_t) tid * 16u + (uint32_t) (i * T) * 16u);
             v[i].x = apply_window(u.x, w.x);
             v[i].y = apply_window(u.y, w.y);
         }
@@ -179,6 +212,7 @@ struct Frame {
     GLV_HD static constexpr int out_index(int tid, int gi, int r) {
         using PI = PassInfo<PASS>;
         const int G = gi * T + tid;
+        if (PASS == P - 1) return bitrev(r, PI::RB) * PI::L0 + G;        // R*L0 == nn: jt == 0, k0 == G
         const int k0 = G & (PI::L0 - 1);
         const int jt = G >> PI::LOG_L0;
         return jt * (PI::R * PI::L0) + bitrev(r, PI::RB) * PI::L0 + k0;
@@ -190,24 +224,25 @@ struct Frame {
         return i * (NN / PI::R) + gi * T + tid;
     }
 
+    // LDS byte offset of element q in the exchange after pass PASS (see glv::lds_index)
     template <int PASS>
-    GLV_HD static void exchange_write(cf* xbuf, const cf (&v)[E], int tid) {
+    GLV_HD static void exchange_write(void* xbuf, const cf (&v)[E], int tid) {
         using PI = PassInfo<PASS>;
 #pragma unroll
         for (int gi = 0; gi < PI::NG; ++gi)
 #pragma unroll
             for (int r = 0; r < PI::R; ++r)
-                xbuf[lds_index(PASS, out_index<PASS>(tid, gi, r))] = v[gi * PI::R + r];
+                st<cf>(xbuf, (uint32_t) lds_index(PASS, out_index<PASS>(tid, gi, r)) * 8u, v[gi * PI::R + r]);
     }
     // read the inputs of pass PASS from the exchange written after pass PASS-1
     template <int PASS>
-    GLV_HD static void exchange_read(cf (&v)[E], const cf* xbuf, int tid) {
+    GLV_HD static void exchange_read(cf (&v)[E], const void* xbuf, int tid) {
         using PI = PassInfo<PASS>;
 #pragma unroll
         for (int gi = 0; gi < PI::NG; ++gi)
 #pragma unroll
             for (int i = 0; i < PI::R; ++i)
-                v[gi * PI::R + i] = xbuf[lds_index(PASS - 1, in_index<PASS>(tid, gi, i))];
+                v[gi * PI::R + i] = ld<cf>(xbuf, (uint32_t) lds_index(PASS - 1, in_index<PASS>(tid, gi, i)) * 8u);
     }
 
     // ---- epilogue: registers of the last pass -> HBM ------------------------------------------------
@@ -223,16 +258,16 @@ struct Frame {
         for (int gi = 0; gi < PI::NG; ++gi)
 #pragma unroll
             for (int r = 0; r < PI::R; ++r) {
-                const int q = out_index<P - 1>(tid, gi, r);
+                const int q = out_index<P - 1>(tid, gi, r);     // = tid + compile-time constant
                 const int n0 = 2 * q;
                 cf val = v[gi * PI::R + r];
                 if constexpr (EPI == EPI_MAG || EPI == EPI_MAG_STATE) {
                     const float y0 = __builtin_fabsf(val.x) + 1.0f, y1 = __builtin_fabsf(val.y) + 1.0f;   // render.c:843-844
-                    val.x = log_third<LOG_MODE>(y0) * tilt(n0, a.inv_n, a.fft_scale, a.one_minus_cutoff);  // :845
-                    val.y = log_third<LOG_MODE>(y1) * tilt(n0 + 1, a.inv_n, a.fft_scale, a.one_minus_cutoff);
+                    val.x = log_third<LOG_MODE>(y0, a.logtab) * tilt(n0, a.inv_n, a.fft_scale, a.one_minus_cutoff);  // :845
+                    val.y = log_third<LOG_MODE>(y1, a.logtab) * tilt(n0 + 1, a.inv_n, a.fft_scale, a.one_minus_cutoff);
                 }
-                if constexpr (EPI == EPI_MAG_STATE || EPI == EPI_RAW_STATE) val = apply_state(val, n0, row, (uint32_t) N, a);
-                *reinterpret_cast<cf*>(out_row + n0) = val;
+                if constexpr (EPI == EPI_MAG_STATE || EPI == EPI_RAW_STATE) val = apply_state(val, (uint32_t) q * 8u, row, (uint32_t) N, a);
+                st<cf>(out_row, (uint32_t) q * 8u, val);
             }
     }
 };

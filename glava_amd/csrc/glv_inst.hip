@@ -12,28 +12,42 @@
 namespace glv {
 
 template <int LOG_NN> struct Tuned;
-//                                      SLOTS NBUF TWREG WINLDS OCC
-template <> struct Tuned<8>  { static constexpr int slots = 16, nbuf = 2; static constexpr bool twreg = true, winlds = true; static constexpr int occ = 2; };
-template <> struct Tuned<9>  { static constexpr int slots = 8,  nbuf = 2; static constexpr bool twreg = true, winlds = true; static constexpr int occ = 2; };
-template <> struct Tuned<10> { static constexpr int slots = 4,  nbuf = 2; static constexpr bool twreg = true, winlds = true; static constexpr int occ = 2; };
-template <> struct Tuned<11> { static constexpr int slots = 2,  nbuf = 1; static constexpr bool twreg = true, winlds = true; static constexpr int occ = 2; };
-template <> struct Tuned<12> { static constexpr int slots = 1,  nbuf = 1; static constexpr bool twreg = true, winlds = false; static constexpr int occ = 2; };
-template <> struct Tuned<13> { static constexpr int slots = 1,  nbuf = 1; static constexpr bool twreg = true, winlds = false; static constexpr int occ = 2; };
+//                                                  SLOTS          NBUF                 TWREG              WINLDS           OCC
+template <> struct Tuned<8>  { static constexpr int slots = 16, nbuf = 1; static constexpr bool twreg = false, winlds = false; static constexpr int occ = 2; };
+template <> struct Tuned<9>  { static constexpr int slots = 8,  nbuf = 1; static constexpr bool twreg = false, winlds = false; static constexpr int occ = 2; };
+template <> struct Tuned<10> { static constexpr int slots = 4,  nbuf = 1; static constexpr bool twreg = false, winlds = false; static constexpr int occ = 2; };
+template <> struct Tuned<11> { static constexpr int slots = 2,  nbuf = 1; static constexpr bool twreg = true,  winlds = false; static constexpr int occ = 2; };
+template <> struct Tuned<12> { static constexpr int slots = 1,  nbuf = 1; static constexpr bool twreg = false, winlds = false; static constexpr int occ = 2; };
+template <> struct Tuned<13> { static constexpr int slots = 1,  nbuf = 1; static constexpr bool twreg = false, winlds = false; static constexpr int occ = 2; };
 
 #define GLV_CAT2(a, b) a##b
 #define GLV_CAT(a, b) GLV_CAT2(a, b)
 
-hipError_t GLV_CAT(launch_frame_, GLV_LOG_NN)(int in_mode, int log_mode, const FrameArgs& a, int grid, hipStream_t st) {
+template <int IN_MODE, int LOG_MODE>
+static hipError_t launch_one(const FrameArgs& a, int grid, hipStream_t st) {
     using TU = Tuned<GLV_LOG_NN>;
-    constexpr int K = GLV_LOG_NN;
-    if (in_mode == IN_S16_STEREO) {
-        if (log_mode == 0) return launch_variant<K, IN_S16_STEREO, 0, TU::slots, TU::nbuf, TU::twreg, TU::winlds, TU::occ>(a, grid, st);
-        return launch_variant<K, IN_S16_STEREO, 1, TU::slots, TU::nbuf, TU::twreg, TU::winlds, TU::occ>(a, grid, st);
-    }
-    if (log_mode == 0) return launch_variant<K, IN_F32_PLANAR, 0, TU::slots, TU::nbuf, TU::twreg, TU::winlds, TU::occ>(a, grid, st);
-    return launch_variant<K, IN_F32_PLANAR, 1, TU::slots, TU::nbuf, TU::twreg, TU::winlds, TU::occ>(a, grid, st);
+    return launch_variant<GLV_LOG_NN, IN_MODE, LOG_MODE, TU::slots, TU::nbuf, TU::twreg, TU::winlds, TU::occ>(a, grid, st);
 }
 
-int GLV_CAT(frame_slots_, GLV_LOG_NN)() { return Tuned<GLV_LOG_NN>::slots; }
+template <int IN_MODE>
+static hipError_t launch_log(int log_mode, const FrameArgs& a, int grid, hipStream_t st) {
+    switch (log_mode) {
+        case 0: return launch_one<IN_MODE, 0>(a, grid, st);
+        case 1: return launch_one<IN_MODE, 1>(a, grid, st);
+        case 2: return launch_one<IN_MODE, 2>(a, grid, st);
+    }
+    return hipErrorInvalidValue;
+}
+
+hipError_t GLV_CAT(launch_frame_, GLV_LOG_NN)(int in_mode, int log_mode, const FrameArgs& a, int grid, hipStream_t st) {
+    switch (in_mode) {
+        case IN_S16_STEREO: return launch_log<IN_S16_STEREO>(log_mode, a, grid, st);
+        case IN_S16_RING:   return launch_log<IN_S16_RING>(log_mode, a, grid, st);
+        case IN_F32_PLANAR: return launch_log<IN_F32_PLANAR>(log_mode, a, grid, st);
+    }
+    return hipErrorInvalidValue;
+}
+
+int GLV_CAT(frame_slots_, GLV_LOG_NN)() { return Tuned<GLV_LOG_NN>::slots == 1 ? 2 : Tuned<GLV_LOG_NN>::slots; }
 
 }  // namespace glv

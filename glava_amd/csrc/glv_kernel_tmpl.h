@@ -55,43 +55,59 @@ struct Body {
     }
 
     // passes PASS..P-1 on the 16 register-resident points; `xcount` counts exchanges so the
-    // ping-pong region alternates consistently across channels and frames.
+    // ping-pong region alternates consistently across channels and frames.  Scheduling fences
+    // pin the phase order  compute | LDS write + next twiddle gather | barrier | LDS read | compute
+    // so that the backend cannot pull the table loads of later passes (30 VGPRs each) up front.
     template <int PASS>
     static __device__ __forceinline__ void run(cf (&v)[16], cf* tw_all, const cf* __restrict__ table,
-                                               cf* xslot, int tid, unsigned& xcount) {
+                                               char* xslot, int tid, unsigned& xcount) {
         // pass 0's twiddles are the same for every lane (k0 = 0): compile-time table offsets,
         // scalar loads; they are (re)gathered here so they never occupy VGPRs across frames.
-        if constexpr (!TWREG || PASS == 0) FR::template gather_tw<PASS>(tw_ref<PASS>(tw_all), table, tid);
+        if constexpr (PASS == 0) FR::template gather_tw<0>(tw_ref<0>(tw_all), table, tid);
         FR::template compute<PASS>(v, tw_ref<PASS>(tw_all));
         if constexpr (PASS + 1 < P) {
-            cf* xb = xslot + (NBUF == 2 ? (xcount & 1u) * NN : 0);
+            char* xb = xslot + (NBUF == 2 ? (size_t) (xcount & 1u) * FR::XREGION * sizeof(cf) : 0);
+            GLV_SCHED_FENCE();
             if constexpr (NBUF == 1) __syncthreads();   // previous readers of the region are done
             FR::template exchange_write<PASS>(xb, v, tid);
+            // the next pass's per-lane twiddles travel from L2 while the exchange settles
+            if constexpr (!TWREG) FR::template gather_tw<PASS + 1>(tw_ref<PASS + 1>(tw_all), table, tid);
             __syncthreads();
             FR::template exchange_read<PASS + 1>(v, xb, tid);
+            GLV_SCHED_FENCE();
             ++xcount;
             run<PASS + 1>(v, tw_all, table, xslot, tid, xcount);
         }
     }
 };
 
+// wave-uniform value -> SGPR (valid when all lanes of the wave hold the same value)
+template <bool UNIFORM>
+static __device__ __forceinline__ uint32_t maybe_scalar(uint32_t v) {
+    if constexpr (UNIFORM) return (uint32_t) __builtin_amdgcn_readfirstlane((int) v);
+    else return v;
+}
+
 template <int LOG_NN, int IN_MODE, int LOG_MODE, int SLOTS, int NBUF, bool TWREG, bool WINLDS, int OCC>
 __global__ void __launch_bounds__(Frame<LOG_NN>::T * SLOTS, OCC)
 glv_frame_kernel(const FrameArgs a) {
     using FR = Frame<LOG_NN>;
     using BD = Body<LOG_NN, NBUF, TWREG>;
-    constexpr int T = FR::T, N = FR::N, NN = FR::NN;
+    constexpr int T = FR::T, N = FR::N;
+    constexpr bool RING = IN_MODE == IN_S16_RING;
+    constexpr bool S16 = IN_MODE == IN_S16_STEREO || RING;
+    constexpr bool WAVE_SLOT = (T % 64) == 0;      // a wave never straddles two slots
+    constexpr size_t XBYTES = (size_t) FR::XREGION * sizeof(cf);
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int slot = threadIdx.x / T;
+    const uint32_t slot = maybe_scalar<WAVE_SLOT>(threadIdx.x / T);
     const int tid = threadIdx.x % T;
-    cf* xslot = reinterpret_cast<cf*>(smem) + (size_t) slot * NBUF * NN;
+    char* xslot = smem + (size_t) slot * NBUF * XBYTES;
 
-    const double* win = a.win;
+    const void* win = a.win;
     if constexpr (WINLDS) {
-        double* lwin = reinterpret_cast<double*>(smem + (size_t) SLOTS * NBUF * NN * sizeof(cf));
-        for (int i = threadIdx.x; i < N / 2; i += T * SLOTS)
-            reinterpret_cast<d2*>(lwin)[i] = reinterpret_cast<const d2*>(a.win)[i];
+        char* lwin = smem + (size_t) SLOTS * NBUF * XBYTES;
+        for (int i = threadIdx.x; i < N / 2; i += T * SLOTS) st<d2>(lwin, (uint32_t) i * 16u, ld<d2>(a.win, (uint32_t) i * 16u));
         __syncthreads();
         win = lwin;
     }
@@ -102,7 +118,7 @@ glv_frame_kernel(const FrameArgs a) {
     // operator chain, uniform for the launch
     const int epi = (a.ops & (OP_GRAVITY | OP_AVERAGE)) ? ((a.ops & OP_RAW) ? EPI_RAW_STATE : EPI_MAG_STATE)
                                                         : ((a.ops & OP_RAW) ? EPI_RAW : EPI_MAG);
-    auto finish = [&](const cf (&v)[16], size_t row) {
+    auto finish = [&](const cf (&v)[16], size_t row, int tid) {
         float* out_row = a.out + row * N;
         switch (epi) {
             case EPI_MAG:       FR::template epilogue<LOG_MODE, EPI_MAG>(v, out_row, row, tid, a); break;
@@ -111,35 +127,46 @@ glv_frame_kernel(const FrameArgs a) {
             default:            FR::template epilogue<LOG_MODE, EPI_RAW_STATE>(v, out_row, row, tid, a); break;
         }
     };
+    // row handled by this slot in the iteration that starts at `base` (idle slots clamp to the last
+    // row and still take part in the barriers; they just do not store).  For s16 input row r is
+    // channel r&1 of frame r>>1: the two channels of a frame sit in neighbouring slots.
+    auto row_of = [&](uint32_t base) -> uint32_t {
+        const uint32_t r = base + slot;
+        return r < a.units ? r : a.units - 1;
+    };
 
     unsigned xcount = 0;
-    for (uint32_t base = blockIdx.x * SLOTS; base < a.units; base += gridDim.x * SLOTS) {
-        const uint32_t unit = base + slot;
-        const bool active = unit < a.units;      // idle slots still take part in the barriers
-        const uint32_t u = active ? unit : a.units - 1;
+    // A workgroup with a single slot takes both channel rows of a frame back to back (SEQ = 2), so
+    // the frame's PCM is still fetched from HBM once and re-read from this CU's L1/L2.
+    constexpr uint32_t SEQ = SLOTS == 1 ? 2 : 1, RPI = SLOTS * SEQ;      // rows per workgroup iteration
+    const uint32_t stride = gridDim.x * RPI;
+    const int tid_outer = tid;
+    for (uint32_t base0 = blockIdx.x * RPI; base0 < a.units; base0 += stride)
+    for (uint32_t base = base0; base < base0 + RPI && base < a.units; base += SLOTS) {
+        // Re-define the lane id opaquely every iteration: window / twiddle table reads are loop
+        // invariant, and LLVM would otherwise hoist ~120 VGPRs worth of them out of the frame loop
+        // (and then spill them).  TWREG is the explicit, budgeted way to keep twiddles resident.
+        int tid = tid_outer;
+        asm volatile("" : "+v"(tid));
+        const bool active = base + slot < a.units;
+        const uint32_t row = row_of(base);
         cf v[16];
-        if constexpr (IN_MODE == IN_S16_STEREO) {
-            typename FR::Pcm pcm;
-            FR::load_pcm(pcm, static_cast<const int16_t*>(a.in) + (size_t) u * 2 * N, tid, a.rot);
-            if (a.mono) FR::mono_mix(pcm);
-            // channel 0 (left), then channel 1 (right), from the same 8-byte loads
-            FR::template unpack_window<0>(v, pcm, win, tid);
-            BD::template run<0>(v, tw_all, a.tw, xslot, tid, xcount);
-            if (active) finish(v, (size_t) u * 2);
-            FR::template unpack_window<1>(v, pcm, win, tid);
-            BD::template run<0>(v, tw_all, a.tw, xslot, tid, xcount);
-            if (active) finish(v, (size_t) u * 2 + 1);
+        if constexpr (S16) {
+            typename FR::Raw raw;
+            FR::template load_pcm<RING>(raw, static_cast<const char*>(a.in) + (size_t) (row >> 1) * ((size_t) N * 4), tid, a.rot);
+            GLV_SCHED_FENCE();
+            FR::unpack_window(v, raw, win, tid, row & 1u, a.mono != 0);
         } else {
-            FR::load_f32_window(v, static_cast<const float*>(a.in) + (size_t) u * N, win, tid);
-            BD::template run<0>(v, tw_all, a.tw, xslot, tid, xcount);
-            if (active) finish(v, (size_t) u);
+            FR::load_f32_window(v, static_cast<const char*>(a.in) + (size_t) row * ((size_t) N * 4), win, tid);
         }
+        BD::template run<0>(v, tw_all, a.tw, xslot, tid, xcount);
+        if (active) finish(v, (size_t) row, tid);
     }
 }
 
 template <int LOG_NN, int SLOTS, int NBUF, bool WINLDS>
 constexpr size_t frame_lds_bytes() {
-    return (size_t) SLOTS * NBUF * Frame<LOG_NN>::NN * sizeof(cf) + (WINLDS ? (size_t) Frame<LOG_NN>::N * sizeof(double) : 0);
+    return (size_t) SLOTS * NBUF * Frame<LOG_NN>::XREGION * sizeof(cf) + (WINLDS ? (size_t) Frame<LOG_NN>::N * sizeof(double) : 0);
 }
 
 template <int LOG_NN, int IN_MODE, int LOG_MODE, int SLOTS, int NBUF, bool TWREG, bool WINLDS, int OCC>

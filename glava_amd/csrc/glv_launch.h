@@ -16,7 +16,7 @@ GLV_DECL_INST(8) GLV_DECL_INST(9) GLV_DECL_INST(10) GLV_DECL_INST(11) GLV_DECL_I
 
 // glv_misc.hip
 hipError_t launch_frame(int log_nn, int in_mode, int log_mode, const FrameArgs& a, int grid, hipStream_t st);
-int frame_slots(int log_nn);      // FFT slots (frames in flight) per workgroup for that size
+int frame_slots(int log_nn);      // channel rows one workgroup takes per iteration of its persistent loop
 hipError_t launch_post(const FrameArgs& a, uint32_t n, hipStream_t st);
 hipError_t launch_unpack(const int16_t* pcm, size_t frames, int mono, float* l, float* r, hipStream_t st);
 

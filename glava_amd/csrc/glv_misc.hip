@@ -17,14 +17,14 @@ __global__ void __launch_bounds__(256) glv_post_kernel(const FrameArgs a, const 
     const size_t total = (size_t) a.units * pairs_per_row;
     for (size_t i = (size_t) blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t) gridDim.x * blockDim.x) {
         const size_t row = i / pairs_per_row;
-        const int n0 = (int) (i % pairs_per_row) * 2;
-        cf val = *reinterpret_cast<const cf*>(static_cast<const float*>(a.in) + row * n + n0);
+        const uint32_t off = (uint32_t) (i % pairs_per_row) * 8u;     // byte offset of the pair in its row
+        cf val = ld<cf>(static_cast<const float*>(a.in) + row * n, off);
         if (a.ops & OP_WRANGE) {                                                  // render.c:777-779
             const float p = val.x + 1.0f, q = val.y + 1.0f;
             val.x = p / 2.0f; val.y = q / 2.0f;
         }
-        val = apply_state(val, n0, row, n, a);
-        *reinterpret_cast<cf*>(a.out + row * n + n0) = val;
+        val = apply_state(val, off, row, n, a);
+        st<cf>(a.out + row * n, off, val);
     }
 }
 

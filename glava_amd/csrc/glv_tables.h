@@ -57,4 +57,13 @@ inline void make_twiddles(cf* table, size_t nn) {
     }
 }
 
+// log_mode 0 table (glv_core.h log_third_table): c_j = 1 + j/64.
+inline void make_log_table(LogEntry* t) {
+    for (int j = 0; j < 64; ++j) {
+        const double c = 1.0 + (double) j / 64.0;
+        t[j].inv_c = 1.0 / c;
+        t[j].log_c = log(c);
+    }
+}
+
 }  // namespace glv

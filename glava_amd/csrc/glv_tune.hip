@@ -33,12 +33,11 @@ const Variant kVariants[] = {
 #ifdef GLV_TUNE_VARIANTS
     GLV_TUNE_VARIANTS
 #else
-    V(2, 1, true, true, 2),  V(2, 1, true, true, 3),  V(2, 1, true, true, 4),
-    V(2, 1, false, true, 2), V(2, 1, false, true, 3), V(2, 1, false, true, 4),
-    V(2, 2, true, true, 2),  V(2, 2, false, true, 3), V(2, 2, false, true, 4),
-    V(2, 1, true, false, 2), V(2, 1, false, false, 4),
-    V(4, 1, true, true, 2),  V(4, 1, false, true, 4), V(4, 2, false, false, 4),
-    V(1, 1, true, true, 2),  V(1, 1, false, true, 4),
+    V(2, 1, false, false, 2), V(2, 1, false, false, 3), V(2, 1, false, false, 4),
+    V(2, 1, false, true, 2),  V(2, 1, false, true, 4),
+    V(2, 1, true, false, 2),  V(2, 1, true, false, 3),
+    V(4, 1, false, false, 3), V(4, 1, false, false, 4), V(4, 1, false, true, 4),
+    V(2, 2, false, false, 4), V(4, 2, false, false, 4),
 #endif
 };
 #undef V
@@ -63,6 +62,7 @@ int glv_tune_run(int i, const void* d_pcm, float* d_out, unsigned units, int log
     using namespace glv;
     static cf* d_tw = nullptr;
     static double* d_win = nullptr;
+    static LogEntry* d_log = nullptr;
     constexpr int NN = 1 << GLV_TUNE_LOG_NN, N = 2 * NN;
     if (!d_tw) {
         std::vector<cf> tw(NN);
@@ -73,16 +73,20 @@ int glv_tune_run(int i, const void* d_pcm, float* d_out, unsigned units, int log
         if (hipMalloc(&d_win, sizeof(double) * N) != hipSuccess) return -1;
         (void) hipMemcpy(d_tw, tw.data(), sizeof(cf) * (NN - 1), hipMemcpyHostToDevice);
         (void) hipMemcpy(d_win, win.data(), sizeof(double) * N, hipMemcpyHostToDevice);
+        LogEntry lt[64];
+        make_log_table(lt);
+        if (hipMalloc(&d_log, sizeof(lt)) != hipSuccess) return -1;
+        (void) hipMemcpy(d_log, lt, sizeof(lt), hipMemcpyHostToDevice);
     }
     FrameArgs a;
     std::memset(&a, 0, sizeof(a));
-    a.in = d_pcm; a.out = d_out; a.tw = d_tw; a.win = d_win; a.units = units; a.ops = OP_FFT;
+    a.in = d_pcm; a.out = d_out; a.tw = d_tw; a.win = d_win; a.logtab = d_log; a.units = units * 2; a.ops = OP_FFT;
     a.F = 1; a.inv_n = 1.0f / (float) N; a.fft_scale = 10.2f; a.one_minus_cutoff = 1.0f - 0.3f;
     a.g = 4.2f * (1.0f / 86.1328125f); a.F_as_float = 1.0f;
     hipStream_t st = (hipStream_t) stream;
     if (grid <= 0) {
-        const unsigned slots = (unsigned) kVariants[i].slots;
-        const unsigned wgs = (units + slots - 1) / slots;
+        const unsigned slots = (unsigned) (kVariants[i].slots == 1 ? 2 : kVariants[i].slots);
+        const unsigned wgs = (units * 2 + slots - 1) / slots;
         grid = (int) (wgs < 2048u ? wgs : 2048u);
     }
     hipEvent_t e0, e1;

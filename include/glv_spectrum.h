@@ -67,8 +67,11 @@ typedef struct glv_params {
     uint32_t avg_window_kind; /* 0: CPU twin 0.6/0.4, oldest-first (render.c:661,751-766)
                                  1: GL twin 0.53836/0.46164, newest-first (common.glsl:13, average_pass.frag:19-45,
                                     render.c:2247-2256) */
-    uint32_t log_mode;      /* 0: fp64 log (bit-faithful to the reference's libm call up to the last-ulp
-                                  behaviour of log()); 1: fast fp32-pair log, <= 2e-7 relative */
+    uint32_t log_mode;      /* render.c:844 evaluates log() in fp64 and divides by 3 in fp64:
+                               0: fp64 table-driven log (rel. error ~2^-50) * (1/3): the reference's float
+                                  result except on ~1e-8 of values (last-ulp ties); default
+                               1: fast: hardware log2 (1 ulp) * ln2/3 in fp32, <= ~2e-7 relative
+                               2: audit: device libm fp64 log + true fp64 division (slow) */
     /* GLV_OP_BARS parameters (shaders/glava/smooth_parameters.glsl) */
     uint32_t bars;          /* bars per channel (radial.glsl:9 NBARS 160 => 80) */
     float smooth_factor;    /* SMOOTH_FACTOR, smooth_parameters.glsl:72, default 0.025 */

@@ -51,27 +51,22 @@ struct Emu {
         }
     }
 
-    static void frame_s16(const int16_t* frame, size_t unit, const FrameArgs& a) {
+    // one channel row of an s16 frame (row = 2*frame + channel), exactly what one kernel slot does
+    static void row_s16(const int16_t* frame, size_t row, const FrameArgs& a) {
         std::vector<Thread> th(T);
-        std::vector<cf> lds(NN);
-        std::vector<typename FR::Pcm> pcm(T);
+        std::vector<cf> lds(FR::XREGION);
         for (int tid = 0; tid < T; ++tid) {
-            FR::load_pcm(pcm[tid], frame, tid, a.rot);
-            if (a.mono) FR::mono_mix(pcm[tid]);
+            typename FR::Raw raw;
+            if (a.rot) FR::template load_pcm<true>(raw, frame, tid, a.rot);
+            else       FR::template load_pcm<false>(raw, frame, tid, 0);
+            FR::unpack_window(th[tid].v, raw, a.win, tid, (uint32_t) (row & 1), a.mono != 0);
         }
-        for (int ch = 0; ch < 2; ++ch) {
-            for (int tid = 0; tid < T; ++tid) {
-                if (ch == 0) FR::template unpack_window<0>(th[tid].v, pcm[tid], a.win, tid);
-                else         FR::template unpack_window<1>(th[tid].v, pcm[tid], a.win, tid);
-            }
-            run_pass<0>(th, lds, a.tw);
-            const size_t row = unit * 2 + ch;
-            finish(th, a.out + row * N, row, a);
-        }
+        run_pass<0>(th, lds, a.tw);
+        finish(th, a.out + row * N, row, a);
     }
     static void row_f32(const float* in_row, size_t row, const FrameArgs& a) {
         std::vector<Thread> th(T);
-        std::vector<cf> lds(NN);
+        std::vector<cf> lds(FR::XREGION);
         for (int tid = 0; tid < T; ++tid) FR::load_f32_window(th[tid].v, in_row, a.win, tid);
         run_pass<0>(th, lds, a.tw);
         finish(th, a.out + row * N, row, a);
@@ -82,7 +77,7 @@ template <int LOG_NN, int LOG_MODE>
 static void run_units(int in_mode, const FrameArgs& a) {
     using EM = Emu<LOG_NN, LOG_MODE>;
     for (uint32_t u = 0; u < a.units; ++u) {
-        if (in_mode == IN_S16_STEREO) EM::frame_s16((const int16_t*) a.in + (size_t) u * 2 * EM::N, u, a);
+        if (in_mode == IN_S16_STEREO) EM::row_s16((const int16_t*) a.in + (size_t) (u >> 1) * 2 * EM::N, u, a);
         else EM::row_f32((const float*) a.in + (size_t) u * EM::N, u, a);
     }
 }
@@ -102,11 +97,13 @@ static int dispatch(int log_nn, int in_mode, const FrameArgs& a) {
 
 extern "C" {
 
-// n: real samples per channel.  in: s16 [units][n][2] (in_mode 0) or f32 [units][n] (in_mode 1).
+// n: real samples per channel.  in: s16 [units/2][n][2] (in_mode 0) or f32 [units][n] (in_mode 1);
+// units = channel rows.
 // grav / hist may be NULL when the op is not requested.  Returns 0 on success.
 int glvemu_process(int n, int in_mode, const void* in, float* out, float* grav, float* hist,
                    unsigned units, unsigned ops, unsigned F, unsigned head, int mono, int avg_window,
-                   int avg_kind, int log_mode, float fft_scale, float fft_cutoff, float gravity_step, float ur) {
+                   int avg_kind, int log_mode, float fft_scale, float fft_cutoff, float gravity_step, float ur,
+                   unsigned rot) {
     int log_nn = 0;
     while ((2 << log_nn) < n) ++log_nn;
     if ((2 << log_nn) != n) return 2;
@@ -115,15 +112,17 @@ int glvemu_process(int n, int in_mode, const void* in, float* out, float* grav, 
     std::vector<double> win(n);
     make_twiddles(tw.data(), nn);
     make_window(win.data(), n);
+    LogEntry lt[64];
+    make_log_table(lt);
     FrameArgs a;
     std::memset(&a, 0, sizeof(a));
-    a.in = in; a.out = out; a.grav = grav; a.hist = hist; a.tw = tw.data(); a.win = win.data();
-    a.units = units; a.ops = ops; a.F = F; a.head = head; a.mono = mono; a.avg_window = avg_window;
+    a.in = in; a.out = out; a.grav = grav; a.hist = hist; a.tw = tw.data(); a.win = win.data(); a.logtab = lt;
+    a.units = units; a.ops = ops; a.F = F; a.head = head; a.mono = mono; a.avg_window = avg_window; a.rot = rot;
     a.inv_n = 1.0f / (float) n; a.fft_scale = fft_scale; a.one_minus_cutoff = 1.0f - fft_cutoff;
     a.g = gravity_step * (1.0f / ur); a.F_as_float = (float) F;
     if (F > 16) return 3;
     make_frame_weights(a.wts, F, avg_window != 0, avg_kind);
-    return log_mode == 0 ? dispatch<0>(log_nn, in_mode, a) : dispatch<1>(log_nn, in_mode, a);
+    return log_mode == 0 ? dispatch<0>(log_nn, in_mode, a) : log_mode == 1 ? dispatch<1>(log_nn, in_mode, a) : dispatch<2>(log_nn, in_mode, a);
 }
 
 }  // extern "C"

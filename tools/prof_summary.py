@@ -1,0 +1,44 @@
+#!/usr/bin/env python3
+"""Summarise a tools/profile.sh output directory: kernel stats + per-dispatch PMC averages for the
+frame kernel.  Prints plain text (committed under profiles/)."""
+import csv
+import glob
+import os
+import sys
+from collections import defaultdict
+
+
+def main(out):
+    for f in glob.glob(os.path.join(out, "stats", "**", "*kernel_stats.csv"), recursive=True):
+        print("== kernel stats:", os.path.relpath(f, out))
+        for row in csv.DictReader(open(f)):
+            name = row.get("Name", "")[:90]
+            print(f"  {name:90s} calls={row.get('Calls')} avg_ns={row.get('AverageNs')} total_ns={row.get('TotalDurationNs')} pct={row.get('Percentage')}")
+    bj = os.path.join(out, "bench_stats.json")
+    if os.path.exists(bj):
+        print("== bench line under --kernel-trace:", open(bj).read().strip()[:1500])
+    agg = defaultdict(lambda: defaultdict(list))
+    for f in glob.glob(os.path.join(out, "pmc*", "**", "*counter_collection.csv"), recursive=True):
+        for row in csv.DictReader(open(f)):
+            k = row.get("Kernel_Name", "")
+            if "glv_" not in k:
+                continue
+            agg[k.split("(")[0][:60]][row.get("Counter_Name")].append(float(row.get("Counter_Value", 0)))
+    for k, cs in agg.items():
+        print("== PMC (mean per dispatch):", k)
+        for c, v in sorted(cs.items()):
+            print(f"  {c:28s} {sum(v) / len(v):18.1f}   (n={len(v)})")
+        g = lambda n: (sum(cs[n]) / len(cs[n])) if n in cs else None  # noqa: E731
+        if g("SQ_WAVE_CYCLES"):
+            wc = g("SQ_WAVE_CYCLES")
+            for n in ("SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "SQ_ACTIVE_INST_VALU"):
+                if g(n) is not None:
+                    print(f"  {n}/SQ_WAVE_CYCLES = {g(n) / wc:.3f}")
+        if g("FETCH_SIZE") is not None:
+            print(f"  FETCH_SIZE KB={g('FETCH_SIZE'):.0f} (x2 gfx950 correction for wide streams => {2 * g('FETCH_SIZE') * 1024 / 1e9:.3f} GB)")
+        if g("WRITE_SIZE") is not None:
+            print(f"  WRITE_SIZE KB={g('WRITE_SIZE'):.0f} => {g('WRITE_SIZE') * 1024 / 1e9:.3f} GB")
+
+
+if __name__ == "__main__":
+    main(sys.argv[1])

@@ -55,6 +55,20 @@ def _compile(src: str, obj: str, extra: list[str]) -> str:
     return obj
 
 
+def build_tune_variant(name: str, extra_flags: list[str], variants: str | None = None) -> str:
+    """Experimental knob-sweep library glava_amd/csrc/libglvtune_<name>.so compiled with extra
+    flags (and optionally a custom variant list) -- used by tools/tune.py --lib for A/B tests."""
+    os.makedirs(OBJ, exist_ok=True)
+    obj = os.path.join(OBJ, f"glv_tune_{name}.o")
+    flags = list(extra_flags)
+    if variants:
+        flags.append("-DGLV_TUNE_VARIANTS=" + variants)
+    _run([_hipcc(), *HIPFLAGS, *flags, "-c", os.path.join(CSRC, "glv_tune.hip"), "-o", obj])
+    lib = os.path.join(CSRC, f"libglvtune_{name}.so")
+    _run([_hipcc(), "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", lib, obj])
+    return lib
+
+
 def build(tune: bool = False, verbose: bool = False) -> str:
     os.makedirs(OBJ, exist_ok=True)
     jobs = [("glv_inst.hip", os.path.join(OBJ, f"glv_inst_{k}.o"), [f"-DGLV_LOG_NN={k}"]) for k in SIZES]

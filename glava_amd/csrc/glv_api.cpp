@@ -76,7 +76,21 @@ struct Tables {
     glv::cf* d_tw = nullptr;
     double* d_win = nullptr;
     glv::LogEntry* d_log = nullptr;
+    float* d_tilt = nullptr;
+    float tilt_scale = 0.f, tilt_cutoff = 0.f;
+    uint32_t n_ = 0;
+    // (re)generate the tilt factors when fft_scale / fft_cutoff change (render.c:845)
+    int set_tilt(float fft_scale, float fft_cutoff) {
+        if (d_tilt && fft_scale == tilt_scale && fft_cutoff == tilt_cutoff) return GLV_OK;
+        std::vector<float> t(n_);
+        glv::make_tilt(t.data(), n_, fft_scale, fft_cutoff);
+        if (!d_tilt) HIP_TRY(hipMalloc(&d_tilt, sizeof(float) * n_));
+        HIP_TRY(hipMemcpy(d_tilt, t.data(), sizeof(float) * n_, hipMemcpyHostToDevice));
+        tilt_scale = fft_scale; tilt_cutoff = fft_cutoff;
+        return GLV_OK;
+    }
     int create(uint32_t n) {
+        n_ = n;
         const uint32_t nn = n / 2;
         std::vector<glv::cf> tw(nn);
         std::vector<double> win(n);
@@ -96,13 +110,14 @@ struct Tables {
         if (d_tw) (void) hipFree(d_tw);
         if (d_win) (void) hipFree(d_win);
         if (d_log) (void) hipFree(d_log);
-        d_tw = nullptr; d_win = nullptr; d_log = nullptr;
+        if (d_tilt) (void) hipFree(d_tilt);
+        d_tw = nullptr; d_win = nullptr; d_log = nullptr; d_tilt = nullptr;
     }
 };
 
 void fill_common(glv::FrameArgs& a, const glv_params& p, const Tables& t) {
     std::memset(&a, 0, sizeof(a));
-    a.tw = t.d_tw; a.win = t.d_win; a.logtab = t.d_log;
+    a.tw = t.d_tw; a.win = t.d_win; a.logtab = t.d_log; a.tilt = t.d_tilt;
     a.F = p.avg_frames; a.mono = p.channels == 1; a.avg_window = p.avg_window != 0;
     a.inv_n = 1.0f / (float) p.n;
     a.fft_scale = p.fft_scale;
@@ -201,12 +216,13 @@ int process(glv_batch* b, const void* d_in, int in_mode, float* d_out, unsigned 
     if (ops & GLV_OP_BARS) return fail(GLV_ERR_INVALID, "GLV_OP_BARS is not available in this build");
     if (!(ops & (GLV_OP_FFT | GLV_OP_GRAVITY | GLV_OP_AVERAGE | GLV_OP_WRANGE))) return fail(GLV_ERR_INVALID, "empty ops");
 
+    HIP_TRY(hipSetDevice(b->device));
+    if (int rc = b->tab.set_tilt(b->p.fft_scale, b->p.fft_cutoff)) return rc;
     glv::FrameArgs a;
     fill_common(a, b->p, b->tab);
     a.in = d_in; a.out = d_out; a.grav = b->d_grav; a.hist = b->d_hist;
     a.units = units; a.ops = ops; a.head = b->head; a.rot = rot;
 
-    HIP_TRY(hipSetDevice(b->device));
     if (int rc = timed_launch_begin(b, st)) return rc;
     hipError_t e;
     if (ops & GLV_OP_FFT) {

@@ -48,7 +48,50 @@ struct alignas(16) d2 { double x, y; };      // two consecutive window values
 GLV_HD constexpr int tw_offset(int L) { return L - 1; }
 
 // The reference's six-rounding butterfly (render.c:826-832):  t = w*b;  b = a - t;  a = a + t.
+//   tr = wr*b.re - wi*b.im;  ti = wr*b.im + wi*b.re     (four products, two sums, each rounded)
+// On gfx950 a complex point lives in an aligned VGPR pair and the whole butterfly is five packed
+// IEEE f32 instructions whose op_sel / neg modifiers do the broadcast, swap and sign work, so
+// no operand ever has to be moved into place:
+//   p02 = (wr*b.re, wr*b.im)      v_pk_mul_f32  W.lo broadcast
+//   p13 = (wi*b.im, wi*b.re)      v_pk_mul_f32  W.hi broadcast, B halves swapped
+//   t   = (p0 - p1, p2 + p3)      v_pk_add_f32  neg_lo on the second source
+//   hi  = a - t ; lo = a + t      v_pk_add_f32  (neg_lo+neg_hi) / plain
+// The host (emulator) build performs the same ten IEEE operations one by one.
+#if defined(__HIP_DEVICE_COMPILE__)
+typedef float glv_f2 __attribute__((ext_vector_type(2)));
+// The three dependent steps of one butterfly, separately callable so that a group of independent
+// butterflies can be issued step by step (4-8 independent packed ops between dependent ones:
+// no forwarding stalls / hazard nops from back-to-back dependent v_pk instructions).
+template <bool SCALAR_W>
+__device__ __forceinline__ void bf_mul(glv_f2& p02, glv_f2& p13, const cf& b, const cf& w) {
+    const glv_f2 B = { b.x, b.y }, W = { w.x, w.y };
+    if constexpr (SCALAR_W) {
+        asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[0,1]" : "=v"(p02) : "s"(W), "v"(B));
+        asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[1,0]" : "=v"(p13) : "s"(W), "v"(B));
+    } else {
+        asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[0,1]" : "=v"(p02) : "v"(W), "v"(B));
+        asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[1,0]" : "=v"(p13) : "v"(W), "v"(B));
+    }
+}
+__device__ __forceinline__ void bf_t(glv_f2& t, const glv_f2& p02, const glv_f2& p13) {
+    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1]" : "=v"(t) : "v"(p02), "v"(p13));
+}
+__device__ __forceinline__ void bf_out(cf& a, cf& b, const glv_f2& t) {
+    const glv_f2 A = { a.x, a.y };
+    glv_f2 hi, lo;
+    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(hi) : "v"(A), "v"(t));
+    asm("v_pk_add_f32 %0, %1, %2" : "=v"(lo) : "v"(A), "v"(t));
+    a.x = lo.x; a.y = lo.y; b.x = hi.x; b.y = hi.y;
+}
+#endif
+template <bool SCALAR_W = false>
 GLV_HD void butterfly(cf& a, cf& b, const cf w) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    glv_f2 p02, p13, t;
+    bf_mul<SCALAR_W>(p02, p13, b, w);
+    bf_t(t, p02, p13);
+    bf_out(a, b, t);
+#else
     const float p0 = w.x * b.x, p1 = w.y * b.y;
     const float p2 = w.x * b.y, p3 = w.y * b.x;
     const float tr = p0 - p1;
@@ -56,6 +99,28 @@ GLV_HD void butterfly(cf& a, cf& b, const cf w) {
     const cf hi = { a.x - tr, a.y - ti };
     const cf lo = { a.x + tr, a.y + ti };
     a = lo; b = hi;
+#endif
+}
+
+// Twiddle exactly (1, +0) -- the k = 0 column of every stage (render.c:821-822 start values).
+//   tr = 1*b.re - (+0)*b.im = b.re,  ti = 1*b.im + (+0)*b.re = b.im   bit for bit, PROVIDED b holds
+// no -0.0 (then (-0) - (-0) would give +0) and no Inf/NaN.  That holds for every value this
+// path produces: PCM samples and window factors are finite, v/65535 and x*w (w > 0.07) are never
+// -0, and a +- t under round-to-nearest yields -0 only from (-0) operands (induction over the
+// stages).  Planar f32 input containing -0.0f or non-finite samples is the one case where the
+// sign of an exact zero in GLV_OP_RAW output may differ from the reference; magnitudes never do.
+GLV_HD void butterfly_unit(cf& a, cf& b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const glv_f2 A = { a.x, a.y }, B = { b.x, b.y };
+    glv_f2 hi, lo;
+    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(hi) : "v"(A), "v"(B));
+    asm("v_pk_add_f32 %0, %1, %2" : "=v"(lo) : "v"(A), "v"(B));
+    a.x = lo.x; a.y = lo.y; b.x = hi.x; b.y = hi.y;
+#else
+    const cf hi = { a.x - b.x, a.y - b.y };
+    const cf lo = { a.x + b.x, a.y + b.y };
+    a = lo; b = hi;
+#endif
 }
 
 GLV_HD constexpr int bitrev(int v, int bits) {
@@ -84,17 +149,48 @@ struct SubPass {
         return k;
     }
 
+    // FIRST: the sub-pass starts at L0 = 1, so k0 = 0 for every lane: the twiddles are wave-uniform
+    // (scalar registers) and the ksub = 0 twiddle of each stage is exactly (1, +0).
+    template <bool FIRST>
     GLV_HD static void run(cf (&v)[R], const cf (&tw)[R > 1 ? R - 1 : 1]) {
 #pragma unroll
         for (int s = 0; s < RB; ++s) {
             const int bit = 1 << (RB - 1 - s);
+#if defined(__HIP_DEVICE_COMPILE__)
+            // the R/2 butterflies of a stage are independent: issue them step-wise in groups of GRP
+            constexpr int NB = R / 2, GRP = NB < 4 ? NB : 4;
+#pragma unroll
+            for (int g0 = 0; g0 < NB; g0 += GRP) {
+                glv_f2 p02[GRP], p13[GRP], t[GRP];
+#pragma unroll
+                for (int j = 0; j < GRP; ++j) {
+                    const int r0 = lo_slot(g0 + j, bit);
+                    if (!(FIRST && ksub_of(r0, s) == 0)) bf_mul<FIRST>(p02[j], p13[j], v[r0 | bit], tw[(1 << s) - 1 + ksub_of(r0, s)]);
+                }
+#pragma unroll
+                for (int j = 0; j < GRP; ++j) {
+                    const int r0 = lo_slot(g0 + j, bit);
+                    if (!(FIRST && ksub_of(r0, s) == 0)) bf_t(t[j], p02[j], p13[j]);
+                }
+#pragma unroll
+                for (int j = 0; j < GRP; ++j) {
+                    const int r0 = lo_slot(g0 + j, bit);
+                    if (FIRST && ksub_of(r0, s) == 0) butterfly_unit(v[r0], v[r0 | bit]);
+                    else bf_out(v[r0], v[r0 | bit], t[j]);
+                }
+            }
+#else
 #pragma unroll
             for (int r0 = 0; r0 < R; ++r0) {
                 if (r0 & bit) continue;
-                butterfly(v[r0], v[r0 | bit], tw[(1 << s) - 1 + ksub_of(r0, s)]);
+                if (FIRST && ksub_of(r0, s) == 0) butterfly_unit(v[r0], v[r0 | bit]);
+                else butterfly<FIRST>(v[r0], v[r0 | bit], tw[(1 << s) - 1 + ksub_of(r0, s)]);
             }
+#endif
         }
     }
+    // the idx-th slot (in increasing order) whose `bit` is clear
+    GLV_HD static constexpr int lo_slot(int idx, int bit) { return ((idx & ~(bit - 1)) << 1) | (idx & (bit - 1)); }
 
     // index into the size-nn twiddle table of the (s, ksub) twiddle for group constant k0
     GLV_HD static constexpr int tw_index(int L0, int k0, int s, int ksub) {

@@ -32,6 +32,7 @@ struct FrameArgs {
     const cf* tw;          // nn-1 twiddles, layout glv::tw_offset
     const double* win;     // n window values (render.c:660 as expanded at :794)
     const LogEntry* logtab; // 64 entries, log_mode 0 (glv_core.h)
+    const float* tilt;     // n tilt factors max(n/N*fft_scale + (1 - fft_cutoff), 1) (render.c:845), host-generated
     uint32_t units;        // channel rows to process (2 per stereo frame)
     uint32_t ops;
     uint32_t F, head;      // ring: `head` receives the current frame; ages oldest..newest are
@@ -203,7 +204,7 @@ struct Frame {
             cf(&vg)[PI::R] = *reinterpret_cast<cf(*)[PI::R]>(&v[gi * PI::R]);
             const cf(&tg)[PI::R > 1 ? PI::R - 1 : 1] =
                 *reinterpret_cast<const cf(*)[PI::R > 1 ? PI::R - 1 : 1]>(&tw[gi * (PI::R - 1)]);
-            SubPass<PI::RB>::run(vg, tg);
+            SubPass<PI::RB>::template run<PASS == 0>(vg, tg);
         }
     }
 
@@ -252,19 +253,20 @@ struct Frame {
     //   EPI_RAW  raw FFT output              EPI_MAG   abs/log/tilt
     //   EPI_MAG_STATE  abs/log/tilt followed by gravity and/or average (apply_state)
     template <int LOG_MODE, int EPI>
-    GLV_HD static void epilogue(const cf (&v)[E], float* out_row, size_t row, int tid, const FrameArgs& a) {
+    GLV_HD static void epilogue(const cf (&v)[E], float* out_row, size_t row, int tid, const FrameArgs& a,
+                                const LogEntry* logtab) {
         using PI = PassInfo<P - 1>;
 #pragma unroll
         for (int gi = 0; gi < PI::NG; ++gi)
 #pragma unroll
             for (int r = 0; r < PI::R; ++r) {
                 const int q = out_index<P - 1>(tid, gi, r);     // = tid + compile-time constant
-                const int n0 = 2 * q;
                 cf val = v[gi * PI::R + r];
                 if constexpr (EPI == EPI_MAG || EPI == EPI_MAG_STATE) {
                     const float y0 = __builtin_fabsf(val.x) + 1.0f, y1 = __builtin_fabsf(val.y) + 1.0f;   // render.c:843-844
-                    val.x = log_third<LOG_MODE>(y0, a.logtab) * tilt(n0, a.inv_n, a.fft_scale, a.one_minus_cutoff);  // :845
-                    val.y = log_third<LOG_MODE>(y1, a.logtab) * tilt(n0 + 1, a.inv_n, a.fft_scale, a.one_minus_cutoff);
+                    const cf tl = ld<cf>(a.tilt, (uint32_t) q * 8u);                                       // :845 factors
+                    val.x = log_third<LOG_MODE>(y0, logtab) * tl.x;
+                    val.y = log_third<LOG_MODE>(y1, logtab) * tl.y;
                 }
                 if constexpr (EPI == EPI_MAG_STATE || EPI == EPI_RAW_STATE) val = apply_state(val, (uint32_t) q * 8u, row, (uint32_t) N, a);
                 st<cf>(out_row, (uint32_t) q * 8u, val);

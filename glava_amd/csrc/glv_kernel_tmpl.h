@@ -23,6 +23,8 @@
 //           false: gathered from the (L2-resident) table at every pass
 //   WINLDS  true: window table staged once per workgroup into LDS; false: read through L1/L2
 //   OCC     __launch_bounds__ minimum waves per SIMD (caps the VGPR budget: 512 / OCC)
+//   PREFETCH  s16 input: the PCM of the slot's NEXT row is loaded (32 VGPRs) before the current row is
+//           transformed, taking the HBM latency off the per-row critical path
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -88,7 +90,7 @@ static __device__ __forceinline__ uint32_t maybe_scalar(uint32_t v) {
     else return v;
 }
 
-template <int LOG_NN, int IN_MODE, int LOG_MODE, int SLOTS, int NBUF, bool TWREG, bool WINLDS, int OCC>
+template <int LOG_NN, int IN_MODE, int LOG_MODE, int SLOTS, int NBUF, bool TWREG, bool WINLDS, int OCC, bool PREFETCH>
 __global__ void __launch_bounds__(Frame<LOG_NN>::T * SLOTS, OCC)
 glv_frame_kernel(const FrameArgs a) {
     using FR = Frame<LOG_NN>;
@@ -112,6 +114,16 @@ glv_frame_kernel(const FrameArgs a) {
         win = lwin;
     }
 
+    // log_mode 0: the 64-entry (1/c, log c) table is gathered per value; LDS serves such random
+    // 16-byte reads without touching the vector-memory path the PCM/spectrum streams use.
+    const LogEntry* logtab = a.logtab;
+    if constexpr (LOG_MODE == 0) {
+        char* llog = smem + (size_t) SLOTS * NBUF * XBYTES + (WINLDS ? (size_t) N * sizeof(double) : 0);
+        if (threadIdx.x < 64) st<d2>(llog, threadIdx.x * 16u, ld<d2>(a.logtab, threadIdx.x * 16u));
+        __syncthreads();
+        logtab = reinterpret_cast<const LogEntry*>(llog);
+    }
+
     cf tw_all[BD::TW_TOTAL];
     if constexpr (TWREG && FR::P > 1) BD::template gather_from<1>(tw_all, a.tw, tid);
 
@@ -121,10 +133,10 @@ glv_frame_kernel(const FrameArgs a) {
     auto finish = [&](const cf (&v)[16], size_t row, int tid) {
         float* out_row = a.out + row * N;
         switch (epi) {
-            case EPI_MAG:       FR::template epilogue<LOG_MODE, EPI_MAG>(v, out_row, row, tid, a); break;
-            case EPI_MAG_STATE: FR::template epilogue<LOG_MODE, EPI_MAG_STATE>(v, out_row, row, tid, a); break;
-            case EPI_RAW:       FR::template epilogue<LOG_MODE, EPI_RAW>(v, out_row, row, tid, a); break;
-            default:            FR::template epilogue<LOG_MODE, EPI_RAW_STATE>(v, out_row, row, tid, a); break;
+            case EPI_MAG:       FR::template epilogue<LOG_MODE, EPI_MAG>(v, out_row, row, tid, a, logtab); break;
+            case EPI_MAG_STATE: FR::template epilogue<LOG_MODE, EPI_MAG_STATE>(v, out_row, row, tid, a, logtab); break;
+            case EPI_RAW:       FR::template epilogue<LOG_MODE, EPI_RAW>(v, out_row, row, tid, a, logtab); break;
+            default:            FR::template epilogue<LOG_MODE, EPI_RAW_STATE>(v, out_row, row, tid, a, logtab); break;
         }
     };
     // row handled by this slot in the iteration that starts at `base` (idle slots clamp to the last
@@ -140,9 +152,21 @@ glv_frame_kernel(const FrameArgs a) {
     // the frame's PCM is still fetched from HBM once and re-read from this CU's L1/L2.
     constexpr uint32_t SEQ = SLOTS == 1 ? 2 : 1, RPI = SLOTS * SEQ;      // rows per workgroup iteration
     const uint32_t stride = gridDim.x * RPI;
+    const uint32_t nsteps = a.units == 0 ? 0 : ((a.units - 1) / RPI / gridDim.x + 1) * SEQ;   // upper bound, uniform
+    auto step_base = [&](uint32_t step) -> uint32_t {            // first row of the workgroup's step-th row group
+        return blockIdx.x * RPI + (step / SEQ) * stride + (step % SEQ) * SLOTS;
+    };
+    auto pcm_ptr = [&](uint32_t row) -> const void* {
+        return static_cast<const char*>(a.in) + (size_t) (row >> 1) * ((size_t) N * 4);
+    };
     const int tid_outer = tid;
-    for (uint32_t base0 = blockIdx.x * RPI; base0 < a.units; base0 += stride)
-    for (uint32_t base = base0; base < base0 + RPI && base < a.units; base += SLOTS) {
+    typename FR::Raw raw_next;
+    if constexpr (S16 && PREFETCH) {
+        if (step_base(0) < a.units) FR::template load_pcm<RING>(raw_next, pcm_ptr(row_of(step_base(0))), tid, a.rot);
+    }
+    for (uint32_t step = 0; step < nsteps; ++step) {
+        const uint32_t base = step_base(step);
+        if (base >= a.units) break;                              // uniform for the workgroup
         // Re-define the lane id opaquely every iteration: window / twiddle table reads are loop
         // invariant, and LLVM would otherwise hoist ~120 VGPRs worth of them out of the frame loop
         // (and then spill them).  TWREG is the explicit, budgeted way to keep twiddles resident.
@@ -153,7 +177,13 @@ glv_frame_kernel(const FrameArgs a) {
         cf v[16];
         if constexpr (S16) {
             typename FR::Raw raw;
-            FR::template load_pcm<RING>(raw, static_cast<const char*>(a.in) + (size_t) (row >> 1) * ((size_t) N * 4), tid, a.rot);
+            if constexpr (PREFETCH) {
+                raw = raw_next;
+                const uint32_t nb = step_base(step + 1);
+                if (step + 1 < nsteps && nb < a.units) FR::template load_pcm<RING>(raw_next, pcm_ptr(row_of(nb)), tid, a.rot);
+            } else {
+                FR::template load_pcm<RING>(raw, pcm_ptr(row), tid, a.rot);
+            }
             GLV_SCHED_FENCE();
             FR::unpack_window(v, raw, win, tid, row & 1u, a.mono != 0);
         } else {
@@ -166,13 +196,14 @@ glv_frame_kernel(const FrameArgs a) {
 
 template <int LOG_NN, int SLOTS, int NBUF, bool WINLDS>
 constexpr size_t frame_lds_bytes() {
-    return (size_t) SLOTS * NBUF * Frame<LOG_NN>::XREGION * sizeof(cf) + (WINLDS ? (size_t) Frame<LOG_NN>::N * sizeof(double) : 0);
+    return (size_t) SLOTS * NBUF * Frame<LOG_NN>::XREGION * sizeof(cf) + (WINLDS ? (size_t) Frame<LOG_NN>::N * sizeof(double) : 0)
+           + 64 * sizeof(LogEntry);
 }
 
-template <int LOG_NN, int IN_MODE, int LOG_MODE, int SLOTS, int NBUF, bool TWREG, bool WINLDS, int OCC>
+template <int LOG_NN, int IN_MODE, int LOG_MODE, int SLOTS, int NBUF, bool TWREG, bool WINLDS, int OCC, bool PREFETCH>
 hipError_t launch_variant(const FrameArgs& a, int grid, hipStream_t st) {
     using FR = Frame<LOG_NN>;
-    auto k = glv_frame_kernel<LOG_NN, IN_MODE, LOG_MODE, SLOTS, NBUF, TWREG, WINLDS, OCC>;
+    auto k = glv_frame_kernel<LOG_NN, IN_MODE, LOG_MODE, SLOTS, NBUF, TWREG, WINLDS, OCC, PREFETCH>;
     constexpr size_t lds = frame_lds_bytes<LOG_NN, SLOTS, NBUF, WINLDS>();
     static_assert(lds <= 160 * 1024, "exchange regions + window exceed the 160 KiB LDS of a gfx950 CU");
     if (lds > 64 * 1024) {

@@ -57,6 +57,13 @@ inline void make_twiddles(cf* table, size_t nn) {
     }
 }
 
+// render.c:845 per-bin tilt factors, evaluated with the reference's float operations.
+inline void make_tilt(float* t, size_t n, float fft_scale, float fft_cutoff) {
+    const float inv_n = 1.0f / (float) n;              // n is a power of two: exact
+    const float omc = 1.0F - fft_cutoff;
+    for (size_t i = 0; i < n; ++i) t[i] = tilt((int) i, inv_n, fft_scale, omc);
+}
+
 // log_mode 0 table (glv_core.h log_third_table): c_j = 1 + j/64.
 inline void make_log_table(LogEntry* t) {
     for (int j = 0; j < 64; ++j) {

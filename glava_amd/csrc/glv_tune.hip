@@ -20,15 +20,16 @@ struct Variant {
     int slots;
 };
 
-template <int SLOTS, int NBUF, bool TWREG, bool WINLDS, int OCC>
+template <int SLOTS, int NBUF, bool TWREG, bool WINLDS, int OCC, bool PF = false>
 hipError_t launch_v(int in_mode, int log_mode, const FrameArgs& a, int grid, hipStream_t st) {
     constexpr int K = GLV_TUNE_LOG_NN;
     if (in_mode != IN_S16_STEREO) return hipErrorInvalidValue;
-    if (log_mode == 0) return launch_variant<K, IN_S16_STEREO, 0, SLOTS, NBUF, TWREG, WINLDS, OCC>(a, grid, st);
-    return launch_variant<K, IN_S16_STEREO, 1, SLOTS, NBUF, TWREG, WINLDS, OCC>(a, grid, st);
+    if (log_mode == 0) return launch_variant<K, IN_S16_STEREO, 0, SLOTS, NBUF, TWREG, WINLDS, OCC, PF>(a, grid, st);
+    return launch_variant<K, IN_S16_STEREO, 1, SLOTS, NBUF, TWREG, WINLDS, OCC, PF>(a, grid, st);
 }
 
 #define V(S, NB, TR, WL, OC) { "slots=" #S " nbuf=" #NB " twreg=" #TR " winlds=" #WL " occ=" #OC, launch_v<S, NB, TR, WL, OC>, S }
+#define VP(S, NB, TR, WL, OC) { "slots=" #S " nbuf=" #NB " twreg=" #TR " winlds=" #WL " occ=" #OC " prefetch", launch_v<S, NB, TR, WL, OC, true>, S }
 const Variant kVariants[] = {
 #ifdef GLV_TUNE_VARIANTS
     GLV_TUNE_VARIANTS
@@ -41,6 +42,7 @@ const Variant kVariants[] = {
 #endif
 };
 #undef V
+#undef VP
 
 }  // namespace
 }  // namespace glv
@@ -63,6 +65,7 @@ int glv_tune_run(int i, const void* d_pcm, float* d_out, unsigned units, int log
     static cf* d_tw = nullptr;
     static double* d_win = nullptr;
     static LogEntry* d_log = nullptr;
+    static float* d_tilt = nullptr;
     constexpr int NN = 1 << GLV_TUNE_LOG_NN, N = 2 * NN;
     if (!d_tw) {
         std::vector<cf> tw(NN);
@@ -77,10 +80,14 @@ int glv_tune_run(int i, const void* d_pcm, float* d_out, unsigned units, int log
         make_log_table(lt);
         if (hipMalloc(&d_log, sizeof(lt)) != hipSuccess) return -1;
         (void) hipMemcpy(d_log, lt, sizeof(lt), hipMemcpyHostToDevice);
+        std::vector<float> tl(N);
+        make_tilt(tl.data(), N, 10.2f, 0.3f);
+        if (hipMalloc(&d_tilt, sizeof(float) * N) != hipSuccess) return -1;
+        (void) hipMemcpy(d_tilt, tl.data(), sizeof(float) * N, hipMemcpyHostToDevice);
     }
     FrameArgs a;
     std::memset(&a, 0, sizeof(a));
-    a.in = d_pcm; a.out = d_out; a.tw = d_tw; a.win = d_win; a.logtab = d_log; a.units = units * 2; a.ops = OP_FFT;
+    a.in = d_pcm; a.out = d_out; a.tw = d_tw; a.win = d_win; a.logtab = d_log; a.tilt = d_tilt; a.units = units * 2; a.ops = OP_FFT;
     a.F = 1; a.inv_n = 1.0f / (float) N; a.fft_scale = 10.2f; a.one_minus_cutoff = 1.0f - 0.3f;
     a.g = 4.2f * (1.0f / 86.1328125f); a.F_as_float = 1.0f;
     hipStream_t st = (hipStream_t) stream;

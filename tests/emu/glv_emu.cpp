@@ -44,10 +44,10 @@ struct Emu {
     static void finish(std::vector<Thread>& th, float* out_row, size_t row, const FrameArgs& a) {
         const bool st = (a.ops & (OP_GRAVITY | OP_AVERAGE)) != 0, raw = (a.ops & OP_RAW) != 0;
         for (int tid = 0; tid < T; ++tid) {
-            if (raw && st)       FR::template epilogue<LOG_MODE, EPI_RAW_STATE>(th[tid].v, out_row, row, tid, a);
-            else if (raw)        FR::template epilogue<LOG_MODE, EPI_RAW>(th[tid].v, out_row, row, tid, a);
-            else if (st)         FR::template epilogue<LOG_MODE, EPI_MAG_STATE>(th[tid].v, out_row, row, tid, a);
-            else                 FR::template epilogue<LOG_MODE, EPI_MAG>(th[tid].v, out_row, row, tid, a);
+            if (raw && st)       FR::template epilogue<LOG_MODE, EPI_RAW_STATE>(th[tid].v, out_row, row, tid, a, a.logtab);
+            else if (raw)        FR::template epilogue<LOG_MODE, EPI_RAW>(th[tid].v, out_row, row, tid, a, a.logtab);
+            else if (st)         FR::template epilogue<LOG_MODE, EPI_MAG_STATE>(th[tid].v, out_row, row, tid, a, a.logtab);
+            else                 FR::template epilogue<LOG_MODE, EPI_MAG>(th[tid].v, out_row, row, tid, a, a.logtab);
         }
     }
 
@@ -114,9 +114,11 @@ int glvemu_process(int n, int in_mode, const void* in, float* out, float* grav, 
     make_window(win.data(), n);
     LogEntry lt[64];
     make_log_table(lt);
+    std::vector<float> tl(n);
+    make_tilt(tl.data(), n, fft_scale, fft_cutoff);
     FrameArgs a;
     std::memset(&a, 0, sizeof(a));
-    a.in = in; a.out = out; a.grav = grav; a.hist = hist; a.tw = tw.data(); a.win = win.data(); a.logtab = lt;
+    a.in = in; a.out = out; a.grav = grav; a.hist = hist; a.tw = tw.data(); a.win = win.data(); a.logtab = lt; a.tilt = tl.data();
     a.units = units; a.ops = ops; a.F = F; a.head = head; a.mono = mono; a.avg_window = avg_window; a.rot = rot;
     a.inv_n = 1.0f / (float) n; a.fft_scale = fft_scale; a.one_minus_cutoff = 1.0f - fft_cutoff;
     a.g = gravity_step * (1.0f / ur); a.F_as_float = (float) F;

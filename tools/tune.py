@@ -21,14 +21,16 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--streams", type=int, default=65536)
     ap.add_argument("--iters", type=int, default=5)
+    ap.add_argument("--reps", type=int, default=5)
     ap.add_argument("--grids", default="0", help="comma list of grid sizes (0 = auto)")
     ap.add_argument("--log-modes", default="0,1")
     ap.add_argument("--out", default="")
+    ap.add_argument("--lib", default="", help="alternative libglvtune_*.so (A/B experiments)")
     a = ap.parse_args()
     import torch
     from glava_amd import build as B, spectrum as G
-    B.build(tune=True)
-    T = C.CDLL(os.path.join(ROOT, "glava_amd", "csrc", "libglvtune.so"))
+    B.build(tune=not a.lib)
+    T = C.CDLL(a.lib if a.lib else os.path.join(ROOT, "glava_amd", "csrc", "libglvtune.so"))
     T.glv_tune_describe.restype = C.c_char_p
     T.glv_tune_run.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_uint, C.c_int, C.c_int, C.c_int, C.c_void_p,
                                C.POINTER(C.c_float)]
@@ -39,26 +41,38 @@ def main():
     d_ref = torch.empty((streams, 2, n), dtype=torch.float32, device="cuda")
     d_out = torch.empty_like(d_ref)
     lines = []
+    import statistics
+    grids = [int(x) for x in a.grids.split(",")]
     for lm in [int(x) for x in a.log_modes.split(",")]:
         b = G.Batch(G.Params(n=n, log_mode=lm), streams, G.OP_FFT)
         b.process_s16(d_pcm, d_ref, G.OP_FFT)
         torch.cuda.synchronize()
         b.close()
-        for grid in [int(x) for x in a.grids.split(",")]:
-            for i in range(T.glv_tune_count()):
+        cases = [(grid, i) for grid in grids for i in range(T.glv_tune_count())]
+        times = {c: [] for c in cases}
+        same = {}
+        # round-robin over the variants, `reps` times, so clock/thermal drift hits all of them alike
+        for rep in range(a.reps):
+            for (grid, i) in cases:
                 ms = C.c_float(0)
-                d_out.fill_(float("nan"))
+                if rep == 0:
+                    d_out.fill_(float("nan"))
                 rc = T.glv_tune_run(i, d_pcm.data_ptr(), d_out.data_ptr(), streams, lm, grid, a.iters, None, C.byref(ms))
                 torch.cuda.synchronize()
                 if rc != 0:
-                    lines.append(f"log={lm} grid={grid} {T.glv_tune_describe(i).decode():48s} FAILED rc={rc}")
+                    times[(grid, i)].append(float("inf"))
                     continue
-                same = bool(torch.equal(d_out.view(torch.int32), d_ref.view(torch.int32)))
-                fps = streams / (ms.value * 1e-3)
-                frac = fps * 12 * n / 8e12
-                lines.append(f"log={lm} grid={grid:5d} {T.glv_tune_describe(i).decode():48s} {ms.value:9.3f} ms  "
-                             f"{fps / 1e6:8.2f} Mframes/s  {100 * frac:5.1f}% of 8TB/s  bits_equal_prod={same}")
-                print(lines[-1], flush=True)
+                times[(grid, i)].append(ms.value)
+                if rep == 0:
+                    same[(grid, i)] = bool(torch.equal(d_out.view(torch.int32), d_ref.view(torch.int32)))
+        for (grid, i) in cases:
+            t = times[(grid, i)]
+            med, best = statistics.median(t), min(t)
+            fps = streams / (med * 1e-3)
+            frac = fps * 12 * n / 8e12
+            lines.append(f"log={lm} grid={grid:5d} {T.glv_tune_describe(i).decode():44s} median {med:7.3f} ms (min {best:7.3f})  "
+                         f"{fps / 1e6:7.2f} Mframes/s  {100 * frac:5.1f}% of 8TB/s  bits_equal_prod={same.get((grid, i))}")
+            print(lines[-1], flush=True)
     if a.out:
         os.makedirs(os.path.dirname(a.out) or ".", exist_ok=True)
         open(a.out, "w").write("\n".join(lines) + "\n")

@@ -40,6 +40,7 @@ namespace glv {
 struct alignas(8) cf { float x, y; };        // one complex point == two consecutive floats of the reference's data[]
 struct alignas(8) u32x2 { uint32_t x, y; };  // four interleaved s16 samples (L,R,L,R)
 struct alignas(16) d2 { double x, y; };      // two consecutive window values
+struct alignas(16) cf2 { cf a, b; };         // two consecutive complex points (one 16-byte access)
 
 // ---- twiddle table layout ------------------------------------------------------------------
 // One table per FFT size: stage with complex half-size L (L = 1,2,4,...,nn/2; reference

@@ -122,7 +122,11 @@ struct Frame {
             uint32_t off;
             if constexpr (RING) off = ((uint32_t) (i * T + tid + rot) & (uint32_t) (NN - 1)) * 8u;
             else off = (uint32_t) tid * 8u + (uint32_t) (i * T) * 8u;
+#if defined(GLV_EXP_NOLOAD)    /* tools/tune.py experiment: fake PCM, no HBM read */
+            const u32x2 u = { off * 2654435761u, off * 40503u + 977u };
+#else
             const u32x2 u = ld<u32x2>(frame, off);
+#endif
             p.x[i] = u.x; p.y[i] = u.y;
         }
     }
@@ -180,12 +184,22 @@ struct Frame {
         static constexpr int NTW = NG * (R - 1);
     };
 
+    // Which of the nn/R radix-R groups of pass PASS does lane `tid` take as its gi-th group?
+    // Intermediate passes: G = gi*T + tid (lanes contiguous: conflict-free LDS, one base address).
+    // Last pass: G = tid*NG + gi -- the lane's groups are ADJACENT, so its outputs come in runs of NG
+    // consecutive complex points: 16-byte ds_read_b128 / global_store_dwordx4 instead of 8-byte ones
+    // (the spectrum store is issue-bound, not bandwidth-bound: half the instructions, half the time).
+    template <int PASS>
+    GLV_HD static constexpr int group_of(int tid, int gi) {
+        return PASS == P - 1 ? tid * PassInfo<PASS>::NG + gi : gi * T + tid;
+    }
+
     template <int PASS>
     GLV_HD static void gather_tw(cf (&tw)[PassInfo<PASS>::NTW], const cf* table, int tid) {
         using PI = PassInfo<PASS>;
 #pragma unroll
         for (int gi = 0; gi < PI::NG; ++gi) {
-            const int G = gi * T + tid;
+            const int G = group_of<PASS>(tid, gi);
             const int k0 = G & (PI::L0 - 1);
 #pragma unroll
             for (int s = 0; s < PI::RB; ++s)
@@ -212,7 +226,7 @@ struct Frame {
     template <int PASS>
     GLV_HD static constexpr int out_index(int tid, int gi, int r) {
         using PI = PassInfo<PASS>;
-        const int G = gi * T + tid;
+        const int G = group_of<PASS>(tid, gi);
         if (PASS == P - 1) return bitrev(r, PI::RB) * PI::L0 + G;        // R*L0 == nn: jt == 0, k0 == G
         const int k0 = G & (PI::L0 - 1);
         const int jt = G >> PI::LOG_L0;
@@ -222,7 +236,7 @@ struct Frame {
     template <int PASS>
     GLV_HD static constexpr int in_index(int tid, int gi, int i) {
         using PI = PassInfo<PASS>;
-        return i * (NN / PI::R) + gi * T + tid;
+        return i * (NN / PI::R) + group_of<PASS>(tid, gi);
     }
 
     // LDS byte offset of element q in the exchange after pass PASS (see glv::lds_index)
@@ -235,15 +249,27 @@ struct Frame {
             for (int r = 0; r < PI::R; ++r)
                 st<cf>(xbuf, (uint32_t) lds_index(PASS, out_index<PASS>(tid, gi, r)) * 8u, v[gi * PI::R + r]);
     }
-    // read the inputs of pass PASS from the exchange written after pass PASS-1
+    // read the inputs of pass PASS from the exchange written after pass PASS-1; in the last pass a
+    // lane's groups are adjacent (group_of), so two points come with one 16-byte read
     template <int PASS>
     GLV_HD static void exchange_read(cf (&v)[E], const void* xbuf, int tid) {
         using PI = PassInfo<PASS>;
-#pragma unroll
-        for (int gi = 0; gi < PI::NG; ++gi)
+        if constexpr (PASS == P - 1 && PI::NG >= 2 && PASS - 1 != 0) {
 #pragma unroll
             for (int i = 0; i < PI::R; ++i)
-                v[gi * PI::R + i] = ld<cf>(xbuf, (uint32_t) lds_index(PASS - 1, in_index<PASS>(tid, gi, i)) * 8u);
+#pragma unroll
+                for (int gi = 0; gi < PI::NG; gi += 2) {
+                    const cf2 two = ld<cf2>(xbuf, (uint32_t) in_index<PASS>(tid, gi, i) * 8u);
+                    v[gi * PI::R + i] = two.a;
+                    v[(gi + 1) * PI::R + i] = two.b;
+                }
+        } else {
+#pragma unroll
+            for (int gi = 0; gi < PI::NG; ++gi)
+#pragma unroll
+                for (int i = 0; i < PI::R; ++i)
+                    v[gi * PI::R + i] = ld<cf>(xbuf, (uint32_t) lds_index(PASS - 1, in_index<PASS>(tid, gi, i)) * 8u);
+        }
     }
 
     // ---- epilogue: registers of the last pass -> HBM ------------------------------------------------
@@ -252,25 +278,54 @@ struct Frame {
     // once per frame, outside the unrolled element loop):
     //   EPI_RAW  raw FFT output              EPI_MAG   abs/log/tilt
     //   EPI_MAG_STATE  abs/log/tilt followed by gravity and/or average (apply_state)
-    template <int LOG_MODE, int EPI>
-    GLV_HD static void epilogue(const cf (&v)[E], float* out_row, size_t row, int tid, const FrameArgs& a,
-                                const LogEntry* logtab) {
+    // per-lane tilt factors of the E output points (loop invariant: a slot always owns the same bins)
+    GLV_HD static void gather_tilt(cf (&tl)[E], const float* tilt, int tid) {
         using PI = PassInfo<P - 1>;
 #pragma unroll
         for (int gi = 0; gi < PI::NG; ++gi)
 #pragma unroll
-            for (int r = 0; r < PI::R; ++r) {
-                const int q = out_index<P - 1>(tid, gi, r);     // = tid + compile-time constant
-                cf val = v[gi * PI::R + r];
-                if constexpr (EPI == EPI_MAG || EPI == EPI_MAG_STATE) {
-                    const float y0 = __builtin_fabsf(val.x) + 1.0f, y1 = __builtin_fabsf(val.y) + 1.0f;   // render.c:843-844
-                    const cf tl = ld<cf>(a.tilt, (uint32_t) q * 8u);                                       // :845 factors
-                    val.x = log_third<LOG_MODE>(y0, logtab) * tl.x;
-                    val.y = log_third<LOG_MODE>(y1, logtab) * tl.y;
-                }
-                if constexpr (EPI == EPI_MAG_STATE || EPI == EPI_RAW_STATE) val = apply_state(val, (uint32_t) q * 8u, row, (uint32_t) N, a);
-                st<cf>(out_row, (uint32_t) q * 8u, val);
+            for (int r = 0; r < PI::R; ++r)
+                tl[gi * PI::R + r] = ld<cf>(tilt, (uint32_t) out_index<P - 1>(tid, gi, r) * 8u);
+    }
+
+    // TILTREG: tilt factors come from `tl` (registers, gathered once per kernel) instead of the table
+    template <int LOG_MODE, int EPI, bool TILTREG = false>
+    GLV_HD static void epilogue(const cf (&v)[E], float* out_row, size_t row, int tid, const FrameArgs& a,
+                                const LogEntry* logtab, const cf* tl_reg = nullptr) {
+        using PI = PassInfo<P - 1>;
+        auto value = [&](int gi, int r) -> cf {
+            const int q = out_index<P - 1>(tid, gi, r);     // = tid*NG + compile-time constant
+            cf val = v[gi * PI::R + r];
+            if constexpr (EPI == EPI_MAG || EPI == EPI_MAG_STATE) {
+                const float y0 = __builtin_fabsf(val.x) + 1.0f, y1 = __builtin_fabsf(val.y) + 1.0f;   // render.c:843-844
+                const cf tl = TILTREG ? tl_reg[gi * PI::R + r] : ld<cf>(a.tilt, (uint32_t) q * 8u);        // :845 factors
+                val.x = log_third<LOG_MODE>(y0, logtab) * tl.x;
+                val.y = log_third<LOG_MODE>(y1, logtab) * tl.y;
             }
+            if constexpr (EPI == EPI_MAG_STATE || EPI == EPI_RAW_STATE) val = apply_state(val, (uint32_t) q * 8u, row, (uint32_t) N, a);
+            return val;
+        };
+#pragma unroll
+        for (int r = 0; r < PI::R; ++r) {
+            if constexpr (PI::NG >= 2) {
+                // the lane's NG groups are adjacent points: 16-byte stores
+#pragma unroll
+                for (int gi = 0; gi < PI::NG; gi += 2) {
+                    cf2 two;
+                    two.a = value(gi, r);
+                    two.b = value(gi + 1, r);
+#if defined(GLV_EXP_NOSTORE)   /* tools/tune.py experiment: keep 1 store in 16 (never in product builds) */
+                    if (r == 0 && gi == 0)
+#endif
+                    st<cf2>(out_row, (uint32_t) out_index<P - 1>(tid, gi, r) * 8u, two);
+                }
+            } else {
+#if defined(GLV_EXP_NOSTORE)
+                if (r == 0)
+#endif
+                st<cf>(out_row, (uint32_t) out_index<P - 1>(tid, 0, r) * 8u, value(0, r));
+            }
+        }
     }
 };
 

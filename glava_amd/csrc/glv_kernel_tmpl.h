@@ -23,8 +23,10 @@
 //           false: gathered from the (L2-resident) table at every pass
 //   WINLDS  true: window table staged once per workgroup into LDS; false: read through L1/L2
 //   OCC     __launch_bounds__ minimum waves per SIMD (caps the VGPR budget: 512 / OCC)
-//   PREFETCH  s16 input: the PCM of the slot's NEXT row is loaded (32 VGPRs) before the current row is
-//           transformed, taking the HBM latency off the per-row critical path
+//   TILTREG   the 32 per-lane tilt factors stay in VGPRs across rows instead of being re-read per row
+//   PREFETCH  s16 input: rows are software-pipelined -- the next row's PCM is loaded before and
+//           unpacked after the current row's passes, so neither HBM reads nor spectrum stores sit on
+//           a row's critical path (costs a second 32-VGPR point set)
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -50,6 +52,17 @@ struct Body {
         return *reinterpret_cast<cf(*)[FR::template PassInfo<PASS>::NTW]>(all + tw_off<PASS>());
     }
 
+    // pass-0 twiddles: wave-uniform by construction; readfirstlane pins them into SGPRs
+    static __device__ __forceinline__ void gather_uniform_tw0(cf* all, const cf* __restrict__ table) {
+        cf (&t0)[FR::template PassInfo<0>::NTW] = tw_ref<0>(all);
+        FR::template gather_tw<0>(t0, table, 0);
+#pragma unroll
+        for (int i = 0; i < FR::template PassInfo<0>::NTW; ++i) {
+            t0[i].x = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, t0[i].x)));
+            t0[i].y = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, t0[i].y)));
+        }
+    }
+
     template <int PASS>
     static __device__ __forceinline__ void gather_from(cf* all, const cf* __restrict__ table, int tid) {
         FR::template gather_tw<PASS>(tw_ref<PASS>(all), table, tid);
@@ -63,9 +76,9 @@ struct Body {
     template <int PASS>
     static __device__ __forceinline__ void run(cf (&v)[16], cf* tw_all, const cf* __restrict__ table,
                                                char* xslot, int tid, unsigned& xcount) {
-        // pass 0's twiddles are the same for every lane (k0 = 0): compile-time table offsets,
-        // scalar loads; they are (re)gathered here so they never occupy VGPRs across frames.
-        if constexpr (PASS == 0) FR::template gather_tw<0>(tw_ref<0>(tw_all), table, tid);
+        // pass 0's twiddles are the same for every lane (k0 = 0); the kernel gathers them once, before
+        // the row loop, into scalar registers (gather_uniform_tw0) -- a vector load here would sit in
+        // front of every row's first butterfly AND, vmcnt being in-order, behind the PCM prefetch.
         FR::template compute<PASS>(v, tw_ref<PASS>(tw_all));
         if constexpr (PASS + 1 < P) {
             char* xb = xslot + (NBUF == 2 ? (size_t) (xcount & 1u) * FR::XREGION * sizeof(cf) : 0);
@@ -90,7 +103,7 @@ static __device__ __forceinline__ uint32_t maybe_scalar(uint32_t v) {
     else return v;
 }
 
-template <int LOG_NN, int IN_MODE, int LOG_MODE, int SLOTS, int NBUF, bool TWREG, bool WINLDS, int OCC, bool PREFETCH>
+template <int LOG_NN, int IN_MODE, int LOG_MODE, int SLOTS, int NBUF, bool TWREG, bool WINLDS, int OCC, bool PREFETCH, bool TILTREG>
 __global__ void __launch_bounds__(Frame<LOG_NN>::T * SLOTS, OCC)
 glv_frame_kernel(const FrameArgs a) {
     using FR = Frame<LOG_NN>;
@@ -125,7 +138,10 @@ glv_frame_kernel(const FrameArgs a) {
     }
 
     cf tw_all[BD::TW_TOTAL];
+    BD::gather_uniform_tw0(tw_all, a.tw);
     if constexpr (TWREG && FR::P > 1) BD::template gather_from<1>(tw_all, a.tw, tid);
+    cf tilt_reg[TILTREG ? 16 : 1];
+    if constexpr (TILTREG) FR::gather_tilt(tilt_reg, a.tilt, tid);
 
     // operator chain, uniform for the launch
     const int epi = (a.ops & (OP_GRAVITY | OP_AVERAGE)) ? ((a.ops & OP_RAW) ? EPI_RAW_STATE : EPI_MAG_STATE)
@@ -133,8 +149,8 @@ glv_frame_kernel(const FrameArgs a) {
     auto finish = [&](const cf (&v)[16], size_t row, int tid) {
         float* out_row = a.out + row * N;
         switch (epi) {
-            case EPI_MAG:       FR::template epilogue<LOG_MODE, EPI_MAG>(v, out_row, row, tid, a, logtab); break;
-            case EPI_MAG_STATE: FR::template epilogue<LOG_MODE, EPI_MAG_STATE>(v, out_row, row, tid, a, logtab); break;
+            case EPI_MAG:       FR::template epilogue<LOG_MODE, EPI_MAG, TILTREG>(v, out_row, row, tid, a, logtab, tilt_reg); break;
+            case EPI_MAG_STATE: FR::template epilogue<LOG_MODE, EPI_MAG_STATE, TILTREG>(v, out_row, row, tid, a, logtab, tilt_reg); break;
             case EPI_RAW:       FR::template epilogue<LOG_MODE, EPI_RAW>(v, out_row, row, tid, a, logtab); break;
             default:            FR::template epilogue<LOG_MODE, EPI_RAW_STATE>(v, out_row, row, tid, a, logtab); break;
         }
@@ -160,9 +176,54 @@ glv_frame_kernel(const FrameArgs a) {
         return static_cast<const char*>(a.in) + (size_t) (row >> 1) * ((size_t) N * 4);
     };
     const int tid_outer = tid;
-    typename FR::Raw raw_next;
     if constexpr (S16 && PREFETCH) {
-        if (step_base(0) < a.units) FR::template load_pcm<RING>(raw_next, pcm_ptr(row_of(step_base(0))), tid, a.rot);
+        // Software pipeline over rows (one iteration = one row k of this slot):
+        //   A  issue the PCM loads of row k+1                (HBM latency starts here)
+        //   B  all FFT passes of row k                       (registers/LDS only: ~2 us of cover)
+        //   C  unpack + window row k+1 into a second register set (first use of A's data)
+        //   D  epilogue of row k: log/tilt/state + spectrum stores
+        // The only vector-memory wait (C) finds A's loads AND the previous iteration's stores a
+        // full transform old.  gfx9-class targets count loads and stores on one counter (vmcnt),
+        // and a wait with both kinds pending drains everything -- so a row must never need fresh
+        // load data right after its predecessor's stores were issued.
+        cf v[16], vn[16];
+        typename FR::Raw raw;
+        if (step_base(0) < a.units) {
+            int tid = tid_outer;
+            asm volatile("" : "+v"(tid));
+            const uint32_t row0 = row_of(step_base(0));
+            FR::template load_pcm<RING>(raw, pcm_ptr(row0), tid, a.rot);
+            FR::unpack_window(v, raw, win, tid, row0 & 1u, a.mono != 0);
+        }
+        // Every load issued so far (resident twiddles, tilt factors, first row) must have landed
+        // before the loop: otherwise the backend's wait-count model carries "N loads may still be
+        // pending behind this register" around the back edge and, vmcnt being one in-order
+        // counter, turns the first use of each resident register into a partial drain of the PCM
+        // prefetch in the middle of a row.  (s_waitcnt vmcnt(0); expcnt/lgkmcnt untouched.)
+        __builtin_amdgcn_s_waitcnt(0x0F70);
+        for (uint32_t step = 0; step < nsteps; ++step) {
+            const uint32_t base = step_base(step);
+            if (base >= a.units) break;                          // uniform for the workgroup
+            int tid = tid_outer;
+            asm volatile("" : "+v"(tid));                        // see the note on LICM below
+            const bool active = base + slot < a.units;
+            const uint32_t row = row_of(base);
+            const uint32_t nb = step_base(step + 1);
+            const bool has_next = step + 1 < nsteps && nb < a.units;
+            const uint32_t row_n = row_of(has_next ? nb : base);
+            // A and C run unconditionally (the last iteration re-reads its own row and discards it): a
+            // branch here would make "were A's loads consumed?" path dependent for the wait-count pass
+            FR::template load_pcm<RING>(raw, pcm_ptr(row_n), tid, a.rot);                        // A
+            GLV_SCHED_FENCE();
+            BD::template run<0>(v, tw_all, a.tw, xslot, tid, xcount);                            // B
+            GLV_SCHED_FENCE();
+            FR::unpack_window(vn, raw, win, tid, row_n & 1u, a.mono != 0);                       // C
+            GLV_SCHED_FENCE();
+            if (active) finish(v, (size_t) row, tid);                                            // D
+#pragma unroll
+            for (int i = 0; i < 16; ++i) v[i] = vn[i];
+        }
+        return;
     }
     for (uint32_t step = 0; step < nsteps; ++step) {
         const uint32_t base = step_base(step);
@@ -177,13 +238,7 @@ glv_frame_kernel(const FrameArgs a) {
         cf v[16];
         if constexpr (S16) {
             typename FR::Raw raw;
-            if constexpr (PREFETCH) {
-                raw = raw_next;
-                const uint32_t nb = step_base(step + 1);
-                if (step + 1 < nsteps && nb < a.units) FR::template load_pcm<RING>(raw_next, pcm_ptr(row_of(nb)), tid, a.rot);
-            } else {
-                FR::template load_pcm<RING>(raw, pcm_ptr(row), tid, a.rot);
-            }
+            FR::template load_pcm<RING>(raw, pcm_ptr(row), tid, a.rot);
             GLV_SCHED_FENCE();
             FR::unpack_window(v, raw, win, tid, row & 1u, a.mono != 0);
         } else {
@@ -200,10 +255,10 @@ constexpr size_t frame_lds_bytes() {
            + 64 * sizeof(LogEntry);
 }
 
-template <int LOG_NN, int IN_MODE, int LOG_MODE, int SLOTS, int NBUF, bool TWREG, bool WINLDS, int OCC, bool PREFETCH>
+template <int LOG_NN, int IN_MODE, int LOG_MODE, int SLOTS, int NBUF, bool TWREG, bool WINLDS, int OCC, bool PREFETCH, bool TILTREG>
 hipError_t launch_variant(const FrameArgs& a, int grid, hipStream_t st) {
     using FR = Frame<LOG_NN>;
-    auto k = glv_frame_kernel<LOG_NN, IN_MODE, LOG_MODE, SLOTS, NBUF, TWREG, WINLDS, OCC, PREFETCH>;
+    auto k = glv_frame_kernel<LOG_NN, IN_MODE, LOG_MODE, SLOTS, NBUF, TWREG, WINLDS, OCC, PREFETCH, TILTREG>;
     constexpr size_t lds = frame_lds_bytes<LOG_NN, SLOTS, NBUF, WINLDS>();
     static_assert(lds <= 160 * 1024, "exchange regions + window exceed the 160 KiB LDS of a gfx950 CU");
     if (lds > 64 * 1024) {

@@ -20,15 +20,16 @@ struct Variant {
     int slots;
 };
 
-template <int SLOTS, int NBUF, bool TWREG, bool WINLDS, int OCC, bool PF = false>
+template <int SLOTS, int NBUF, bool TWREG, bool WINLDS, int OCC, bool PF = false, bool TL = false>
 hipError_t launch_v(int in_mode, int log_mode, const FrameArgs& a, int grid, hipStream_t st) {
     constexpr int K = GLV_TUNE_LOG_NN;
     if (in_mode != IN_S16_STEREO) return hipErrorInvalidValue;
-    if (log_mode == 0) return launch_variant<K, IN_S16_STEREO, 0, SLOTS, NBUF, TWREG, WINLDS, OCC, PF>(a, grid, st);
-    return launch_variant<K, IN_S16_STEREO, 1, SLOTS, NBUF, TWREG, WINLDS, OCC, PF>(a, grid, st);
+    if (log_mode == 0) return launch_variant<K, IN_S16_STEREO, 0, SLOTS, NBUF, TWREG, WINLDS, OCC, PF, TL>(a, grid, st);
+    return launch_variant<K, IN_S16_STEREO, 1, SLOTS, NBUF, TWREG, WINLDS, OCC, PF, TL>(a, grid, st);
 }
 
 #define V(S, NB, TR, WL, OC) { "slots=" #S " nbuf=" #NB " twreg=" #TR " winlds=" #WL " occ=" #OC, launch_v<S, NB, TR, WL, OC>, S }
+#define VX(S, NB, TR, WL, OC, PF, TL) { "slots=" #S " nbuf=" #NB " twreg=" #TR " winlds=" #WL " occ=" #OC " pf=" #PF " tiltreg=" #TL, launch_v<S, NB, TR, WL, OC, PF, TL>, S }
 #define VP(S, NB, TR, WL, OC) { "slots=" #S " nbuf=" #NB " twreg=" #TR " winlds=" #WL " occ=" #OC " prefetch", launch_v<S, NB, TR, WL, OC, true>, S }
 const Variant kVariants[] = {
 #ifdef GLV_TUNE_VARIANTS
@@ -43,6 +44,7 @@ const Variant kVariants[] = {
 };
 #undef V
 #undef VP
+#undef VX
 
 }  // namespace
 }  // namespace glv

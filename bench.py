@@ -69,6 +69,20 @@ def cpu_baseline(n: int, seconds: float = 10.0) -> dict | None:
                       f"{cores} threads in {dt:.1f} s; reference transform_fft x2 ch + fifo.c unpack, gcc -O2"}
 
 
+def measured_traffic(n: int, streams: int, ops: str):
+    """HBM bytes per launch from the PMC passes of tools/profile.sh (FETCH_SIZE x2 gfx950 correction
+    + WRITE_SIZE, separate rocprofv3 --pmc runs), committed as profiles/hbm_traffic.json; None when
+    no measurement for this exact workload is on file."""
+    try:
+        rec = json.load(open(os.path.join(ROOT, "profiles", "hbm_traffic.json")))
+        for r in rec:
+            if r["n"] == n and r["streams"] == streams and r["ops"] == ops:
+                return r["bytes_per_launch"]
+    except Exception:
+        pass
+    return None
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -80,6 +94,7 @@ def main() -> None:
     ap.add_argument("--log-mode", type=int, default=0, help="0 strict fp64 log (default), 1 fast fp32 log")
     ap.add_argument("--grid", type=int, default=0, help="workgroups of the persistent kernel (0 = auto)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-alt", action="store_true", help="skip the secondary fast-log measurement")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
     a = ap.parse_args()
 
@@ -117,33 +132,40 @@ def main() -> None:
     params = G.Params(n=n, log_mode=a.log_mode)
     batch = G.Batch(params, streams, ops, device=local_rank)
     if a.grid: batch.set_grid(a.grid)
+    alt_batch = None
+    if a.log_mode == 0 and not a.no_alt:       # secondary measurement: the fast-log variant of the same pass
+        alt_batch = G.Batch(G.Params(n=n, log_mode=1), streams, ops, device=local_rank)
+        if a.grid: alt_batch.set_grid(a.grid)
     gen = torch.Generator(device="cuda"); gen.manual_seed(12345 + rank)
     d_pcm = torch.randint(-32768, 32768, (streams, n, 2), dtype=torch.int16, device="cuda", generator=gen)
     d_out = torch.empty((streams, 2, n), dtype=torch.float32, device="cuda")
     stream = torch.cuda.current_stream().cuda_stream
 
-    def step():
-        batch.process_s16(d_pcm, d_out, ops, stream)
+    def timed(b):
+        """W warm-up steps, then exactly K steps bracketed by barrier + synchronize on both sides."""
+        for _ in range(a.warmup):
+            b.process_s16(d_pcm, d_out, ops, stream)
+        torch.cuda.synchronize()
+        if world > 1: dist.barrier()
+        torch.cuda.synchronize()
+        b.timing_begin()                                   # HIP events on the launch stream, per launch
+        t0 = time.perf_counter()
+        for _ in range(a.steps):
+            b.process_s16(d_pcm, d_out, ops, stream)
+        torch.cuda.synchronize()
+        if world > 1: dist.barrier()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        kms, nl = b.timing_end()
+        if world > 1:
+            t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt, kms, nl
 
-    for _ in range(a.warmup):
-        step()
-    torch.cuda.synchronize()
-    if world > 1: dist.barrier()
-    torch.cuda.synchronize()
-    batch.timing_begin()                                   # HIP events on the launch stream, per launch
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        step()
-    torch.cuda.synchronize()
-    if world > 1: dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    kernel_ms, launches = batch.timing_end()
+    elapsed, kernel_ms, launches = timed(batch)
+    alt = timed(alt_batch) if alt_batch is not None else None
 
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
     frames_rank = streams * a.steps
     stats = gather_stats({"frames": frames_rank, "seconds": elapsed, "kernel_ms": kernel_ms,
                           "bytes": batch.algorithmic_bytes(ops) * launches}, world)
@@ -164,16 +186,24 @@ def main() -> None:
                        "streams_per_gpu": streams, "n": n, "ops": a.ops, "log_mode": a.log_mode,
                        "input": "int16 [streams][n][2] resident in HBM", "kernel": batch.kernel_name()},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(n, streams, a.ops),
                          "algorithmic_bytes_per_launch": alg_bytes, "avg_kernel_ms": avg_kernel_s * 1e3,
                          "kernel": batch.kernel_name()},
         }
+        if alt is not None:
+            a_el, a_kms, a_nl = alt
+            a_k = (a_kms / max(a_nl, 1)) * 1e-3
+            line["fast_log"] = {"note": "same pass with log_mode 1 (hardware log2, <= 2e-7 relative; the parity bar is 1e-5)",
+                                "value": streams * world * a.steps / a_el, "unit": "frames/s",
+                                "ms_per_step": a_el / a.steps * 1e3, "avg_kernel_ms": a_k * 1e3,
+                                "roofline_frac": (alg_bytes / a_k / 1e9) / HBM_PEAK_GBS if a_k > 0 else 0.0}
         if world == 1 and not a.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(n, a.cpu_seconds)
         else:
             line["cpu_baseline"] = None
         print(json.dumps(line), flush=True)
     batch.close()
+    if alt_batch is not None: alt_batch.close()
     if world > 1:
         dist.destroy_process_group()
 

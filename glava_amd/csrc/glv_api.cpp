@@ -100,7 +100,7 @@ struct Tables {
         HIP_TRY(hipMalloc(&d_win, sizeof(double) * n));
         HIP_TRY(hipMemcpy(d_tw, tw.data(), sizeof(glv::cf) * (nn - 1), hipMemcpyHostToDevice));
         HIP_TRY(hipMemcpy(d_win, win.data(), sizeof(double) * n, hipMemcpyHostToDevice));
-        glv::LogEntry lt[64];
+        glv::LogEntry lt[glv::kLogTabSize];
         glv::make_log_table(lt);
         HIP_TRY(hipMalloc(&d_log, sizeof(lt)));
         HIP_TRY(hipMemcpy(d_log, lt, sizeof(lt), hipMemcpyHostToDevice));

@@ -221,6 +221,14 @@ struct Plan {
 // (+1 LDS cycle); later exchanges are contiguous per 16 lanes and conflict free as they are.
 GLV_HD constexpr int lds_index(int pass, int q) { return pass == 0 ? q + (q >> 4) : q; }
 
+// `uniform base + 32-bit byte offset` access (see glv_frame.h "addressing")
+template <typename V> GLV_HD V ld(const void* base, uint32_t byte_off) {
+    return *reinterpret_cast<const V*>(static_cast<const char*>(base) + byte_off);
+}
+template <typename V> GLV_HD void st(void* base, uint32_t byte_off, const V& v) {
+    *reinterpret_cast<V*>(static_cast<char*>(base) + byte_off) = v;
+}
+
 // ---- scalar pieces ----------------------------------------------------------------------------
 // fifo.c:105-106: (float) s16 / (float) 65535, IEEE single division.
 // Evaluated as one correctly-rounded-by-construction sequence: q0 = v*rcp; r = fma(-q0, 65535, v);
@@ -269,34 +277,46 @@ template <int LOG_MODE> GLV_HD float log_third(float y, const LogEntry* tab);
 #define GLV_LOG2F(x) ::log2f(x)
 #endif
 
-// log table: for j = 0..63, c_j = 1 + j/64 (the value of the top six mantissa bits),
-// kLogTab[j] = { 1/c_j rounded to double, log(c_j) rounded to double }.  Generated on the host
-// by glv::make_log_table (glv_tables.h) and passed to the kernel in constant/global memory.
-struct alignas(16) LogEntry { double inv_c, log_c; };
+// log table: for j = 0..255, c_j = 1 + j/256 (the value of the top eight mantissa bits),
+// tab[j] = { 1/c_j, log(c_j)/3 } rounded to double.  Generated on the host by glv::make_log_table
+// (glv_tables.h); the kernel stages it into LDS (random 16-byte gathers are what LDS is good at).
+constexpr int kLogTabSize = 256;
+struct alignas(16) LogEntry { double inv_c, log_c3; };
 
-// y >= 1 finite.  y = 2^e * m, m in [1,2); c = m truncated to 6 mantissa bits; r = (m - c)/c in
-// [0, 2^-6); log y = e*ln2 + log c + log1p(r), log1p by a degree-7 polynomial (|error| < 2^-52).
+#if defined(__HIP_DEVICE_COMPILE__)
+// d = fma(a, b, c) with c in scalar registers: VOP3 form, so the constant is not clobbered and
+// need not be re-materialised into a VGPR pair before every use (what v_fmac_f64 would force).
+__device__ __forceinline__ double fma_sc(double a, double b, double c_uniform) {
+    double d;
+    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "s"(c_uniform));
+    return d;
+}
+#define GLV_FMA_SC(a, b, c) fma_sc(a, b, c)
+#else
+#define GLV_FMA_SC(a, b, c) __builtin_fma(a, b, c)
+#endif
+
+// y >= 1 finite.  y = 2^e * m, m in [1,2); c = m truncated to 8 mantissa bits; r = (m - c)/c in
+// [0, 2^-8).  log(y)/3 = e*(ln2/3) + log(c)/3 + r*P(r),
+//   P(r) = (1 - r/2 + r^2/3 - r^3/4 + r^4/5 - r^5/6)/3      (truncation r^6/7 < 2^-50 relative)
+// All polynomial arithmetic is ours (fused): only the final float matters, and it equals the
+// reference's (float)(log(y)/3) unless the exact value lies within ~2^-49 (relative) of a float
+// rounding boundary.
 GLV_HD float log_third_table(float y, const LogEntry* tab) {
-    union { float f; uint32_t u; } in = { y };
-    const int e = (int) (in.u >> 23) - 127;
-    const uint32_t j = (in.u >> 17) & 63u;
-    union { uint32_t u; float f; } mm = { (in.u & 0x007fffffu) | 0x3f800000u };          // m
-    union { uint32_t u; float f; } cc = { (in.u & 0x007e0000u) | 0x3f800000u };          // c_j
-    const LogEntry t = tab[j];
-    const double d = (double) (mm.f - cc.f);             // exact in float: both in [1,2), same top bits
-    const double r = d * t.inv_c;
-    // log1p(r) = r - r^2/2 + r^3/3 - ... - r^8/8 ; explicit fma: these are OUR arithmetic, not the reference's
-    double p = -1.0 / 8.0;
-    p = __builtin_fma(p, r, 1.0 / 7.0);
-    p = __builtin_fma(p, r, -1.0 / 6.0);
-    p = __builtin_fma(p, r, 1.0 / 5.0);
-    p = __builtin_fma(p, r, -1.0 / 4.0);
-    p = __builtin_fma(p, r, 1.0 / 3.0);
-    p = __builtin_fma(p, r, -1.0 / 2.0);
-    p = __builtin_fma(p, r, 1.0);
-    const double l1p = p * r;
-    const double hi = __builtin_fma((double) e, 0.6931471805599453094, t.log_c);
-    return (float) ((hi + l1p) * (1.0 / 3.0));
+    const uint32_t u = __builtin_bit_cast(uint32_t, y);
+    const int e = (int) (u >> 23) - 127;
+    const LogEntry t = ld<LogEntry>(tab, (u >> 11) & 0xff0u);                       // j * 16 bytes
+    const float m = __builtin_bit_cast(float, (u & 0x007fffffu) | 0x3f800000u);
+    const float c = __builtin_bit_cast(float, (u & 0x007f8000u) | 0x3f800000u);
+    const double r = (double) (m - c) * t.inv_c;       // m - c is exact (same exponent, c <= m)
+    double p = -1.0 / 18.0;
+    p = GLV_FMA_SC(p, r, 1.0 / 15.0);
+    p = GLV_FMA_SC(p, r, -1.0 / 12.0);
+    p = GLV_FMA_SC(p, r, 1.0 / 9.0);
+    p = GLV_FMA_SC(p, r, -1.0 / 6.0);
+    p = GLV_FMA_SC(p, r, 1.0 / 3.0);
+    const double hi = __builtin_fma((double) e, 0.6931471805599453094 / 3.0, t.log_c3);
+    return (float) __builtin_fma(r, p, hi);
 }
 
 template <> GLV_HD float log_third<0>(float y, const LogEntry* tab) { return log_third_table(y, tab); }

@@ -49,12 +49,7 @@ struct FrameArgs {
 // accesses differing only by compile-time constants.  That is the shape the gfx950 backend turns
 // into  global_load ... v_off, s[base:base+1] offset:imm  /  ds_read ... v_off offset:imm  -- one
 // offset VGPR per phase instead of sixteen 64-bit addresses kept alive across the frame loop.
-template <typename V> GLV_HD V ld(const void* base, uint32_t byte_off) {
-    return *reinterpret_cast<const V*>(static_cast<const char*>(base) + byte_off);
-}
-template <typename V> GLV_HD void st(void* base, uint32_t byte_off, const V& v) {
-    *reinterpret_cast<V*>(static_cast<char*>(base) + byte_off) = v;
-}
+// (ld<V>(base, byte_off) / st<V>(base, byte_off, v) live in glv_core.h)
 
 // ring slot of age f (0 = oldest .. F-1 = newest = head)
 GLV_HD uint32_t ring_slot(uint32_t head, uint32_t f, uint32_t F) {

@@ -127,12 +127,12 @@ glv_frame_kernel(const FrameArgs a) {
         win = lwin;
     }
 
-    // log_mode 0: the 64-entry (1/c, log c) table is gathered per value; LDS serves such random
+    // log_mode 0: the 256-entry (1/c, log(c)/3) table is gathered per value; LDS serves such random
     // 16-byte reads without touching the vector-memory path the PCM/spectrum streams use.
     const LogEntry* logtab = a.logtab;
     if constexpr (LOG_MODE == 0) {
         char* llog = smem + (size_t) SLOTS * NBUF * XBYTES + (WINLDS ? (size_t) N * sizeof(double) : 0);
-        if (threadIdx.x < 64) st<d2>(llog, threadIdx.x * 16u, ld<d2>(a.logtab, threadIdx.x * 16u));
+        for (int i = threadIdx.x; i < kLogTabSize; i += T * SLOTS) st<d2>(llog, (uint32_t) i * 16u, ld<d2>(a.logtab, (uint32_t) i * 16u));
         __syncthreads();
         logtab = reinterpret_cast<const LogEntry*>(llog);
     }
@@ -252,7 +252,7 @@ glv_frame_kernel(const FrameArgs a) {
 template <int LOG_NN, int SLOTS, int NBUF, bool WINLDS>
 constexpr size_t frame_lds_bytes() {
     return (size_t) SLOTS * NBUF * Frame<LOG_NN>::XREGION * sizeof(cf) + (WINLDS ? (size_t) Frame<LOG_NN>::N * sizeof(double) : 0)
-           + 64 * sizeof(LogEntry);
+           + kLogTabSize * sizeof(LogEntry);
 }
 
 template <int LOG_NN, int IN_MODE, int LOG_MODE, int SLOTS, int NBUF, bool TWREG, bool WINLDS, int OCC, bool PREFETCH, bool TILTREG>

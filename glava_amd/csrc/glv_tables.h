@@ -64,12 +64,12 @@ inline void make_tilt(float* t, size_t n, float fft_scale, float fft_cutoff) {
     for (size_t i = 0; i < n; ++i) t[i] = tilt((int) i, inv_n, fft_scale, omc);
 }
 
-// log_mode 0 table (glv_core.h log_third_table): c_j = 1 + j/64.
+// log_mode 0 table (glv_core.h log_third_table): c_j = 1 + j/256, { 1/c_j, log(c_j)/3 }.
 inline void make_log_table(LogEntry* t) {
-    for (int j = 0; j < 64; ++j) {
-        const double c = 1.0 + (double) j / 64.0;
+    for (int j = 0; j < kLogTabSize; ++j) {
+        const double c = 1.0 + (double) j / (double) kLogTabSize;
         t[j].inv_c = 1.0 / c;
-        t[j].log_c = log(c);
+        t[j].log_c3 = log(c) / 3.0;
     }
 }
 

@@ -78,7 +78,7 @@ int glv_tune_run(int i, const void* d_pcm, float* d_out, unsigned units, int log
         if (hipMalloc(&d_win, sizeof(double) * N) != hipSuccess) return -1;
         (void) hipMemcpy(d_tw, tw.data(), sizeof(cf) * (NN - 1), hipMemcpyHostToDevice);
         (void) hipMemcpy(d_win, win.data(), sizeof(double) * N, hipMemcpyHostToDevice);
-        LogEntry lt[64];
+        LogEntry lt[kLogTabSize];
         make_log_table(lt);
         if (hipMalloc(&d_log, sizeof(lt)) != hipSuccess) return -1;
         (void) hipMemcpy(d_log, lt, sizeof(lt), hipMemcpyHostToDevice);

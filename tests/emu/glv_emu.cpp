@@ -112,7 +112,7 @@ int glvemu_process(int n, int in_mode, const void* in, float* out, float* grav, 
     std::vector<double> win(n);
     make_twiddles(tw.data(), nn);
     make_window(win.data(), n);
-    LogEntry lt[64];
+    LogEntry lt[kLogTabSize];
     make_log_table(lt);
     std::vector<float> tl(n);
     make_tilt(tl.data(), n, fft_scale, fft_cutoff);

@@ -38,6 +38,9 @@ def main(out):
             print(f"  FETCH_SIZE KB={g('FETCH_SIZE'):.0f} (x2 gfx950 correction for wide streams => {2 * g('FETCH_SIZE') * 1024 / 1e9:.3f} GB)")
         if g("WRITE_SIZE") is not None:
             print(f"  WRITE_SIZE KB={g('WRITE_SIZE'):.0f} => {g('WRITE_SIZE') * 1024 / 1e9:.3f} GB")
+        if g("FETCH_SIZE") is not None and g("WRITE_SIZE") is not None:
+            tot = (2 * g("FETCH_SIZE") + g("WRITE_SIZE")) * 1024
+            print(f"  HBM traffic per launch (2*FETCH_SIZE + WRITE_SIZE) = {tot:.0f} bytes")
 
 
 if __name__ == "__main__":

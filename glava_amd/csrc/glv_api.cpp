@@ -144,6 +144,11 @@ struct glv_batch {
     uint32_t head = 0;           // history slot receiving the next frame
     uint32_t ring_pos = 0;       // next write position in the PCM ring, in frames
     int grid_override = 0;
+    float* d_scratch = nullptr;  // [streams*2][n] spectra feeding GLV_OP_BARS
+    int* d_smin = nullptr;       // transform_smooth window bounds (host generated)
+    int* d_smax = nullptr;
+    uint32_t smooth_asz = 0;
+    float smooth_d = -1.f, smooth_r = -1.f;
     // timing
     bool timing = false;
     std::vector<hipEvent_t> ev;  // start/stop pairs
@@ -204,6 +209,19 @@ int timed_launch_end(glv_batch* b, hipStream_t st) {
     return GLV_OK;
 }
 
+int ensure_smooth_tables(glv_batch* b) {
+    if (b->d_smin && b->smooth_d == b->p.smooth_distance && b->smooth_r == b->p.smooth_ratio) return GLV_OK;
+    if (!(b->p.smooth_ratio >= 1.0f)) return fail(GLV_ERR_INVALID, "smooth_ratio must be >= 1");
+    const size_t n = b->p.n;
+    std::vector<int> lo(n), hi(n);
+    const size_t asz = glv::make_smooth_bounds(lo.data(), hi.data(), n, b->p.smooth_distance, b->p.smooth_ratio);
+    if (!b->d_smin) { HIP_TRY(hipMalloc(&b->d_smin, sizeof(int) * n)); HIP_TRY(hipMalloc(&b->d_smax, sizeof(int) * n)); }
+    HIP_TRY(hipMemcpy(b->d_smin, lo.data(), sizeof(int) * asz, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(b->d_smax, hi.data(), sizeof(int) * asz, hipMemcpyHostToDevice));
+    b->smooth_asz = (uint32_t) asz; b->smooth_d = b->p.smooth_distance; b->smooth_r = b->p.smooth_ratio;
+    return GLV_OK;
+}
+
 // One update of `units` channel rows through the fused kernel (or the post kernel when no FFT is asked).
 int process(glv_batch* b, const void* d_in, int in_mode, float* d_out, unsigned ops, uint32_t units,
             uint32_t rot, hipStream_t st) {
@@ -213,10 +231,15 @@ int process(glv_batch* b, const void* d_in, int in_mode, float* d_out, unsigned 
         return fail(GLV_ERR_STATE, "ops 0x%x need state the batch was not created with (ops_mask 0x%x)", ops, b->ops_mask);
     if ((ops & GLV_OP_WRANGE) && (ops & GLV_OP_FFT)) return fail(GLV_ERR_INVALID, "GLV_OP_WRANGE excludes GLV_OP_FFT");
     if ((ops & GLV_OP_RAW) && !(ops & GLV_OP_FFT)) return fail(GLV_ERR_INVALID, "GLV_OP_RAW needs GLV_OP_FFT");
-    if (ops & GLV_OP_BARS) return fail(GLV_ERR_INVALID, "GLV_OP_BARS is not available in this build");
-    if (!(ops & (GLV_OP_FFT | GLV_OP_GRAVITY | GLV_OP_AVERAGE | GLV_OP_WRANGE))) return fail(GLV_ERR_INVALID, "empty ops");
-
+    if (!(ops & (GLV_OP_FFT | GLV_OP_GRAVITY | GLV_OP_AVERAGE | GLV_OP_WRANGE | GLV_OP_SMOOTH))) return fail(GLV_ERR_INVALID, "empty ops");
+    if ((ops & GLV_OP_BARS) && (b->p.bars == 0 || b->p.bars > b->p.n)) return fail(GLV_ERR_INVALID, "bars=%u out of range", b->p.bars);
+    float* d_final = d_out;
     HIP_TRY(hipSetDevice(b->device));
+    if (ops & GLV_OP_BARS) {                       // spectra go to an internal buffer, d_out receives the bars
+        if (!b->d_scratch) HIP_TRY(hipMalloc(&b->d_scratch, sizeof(float) * (size_t) b->streams * 2 * b->p.n));
+        d_out = b->d_scratch;
+    }
+
     if (int rc = b->tab.set_tilt(b->p.fft_scale, b->p.fft_cutoff)) return rc;
     glv::FrameArgs a;
     fill_common(a, b->p, b->tab);
@@ -225,7 +248,13 @@ int process(glv_batch* b, const void* d_in, int in_mode, float* d_out, unsigned 
 
     if (int rc = timed_launch_begin(b, st)) return rc;
     hipError_t e;
-    if (ops & GLV_OP_FFT) {
+    const unsigned core = ops & (GLV_OP_FFT | GLV_OP_GRAVITY | GLV_OP_AVERAGE | GLV_OP_WRANGE);
+    if (!core) {                                   // smooth / bars only: operate on a copy of the input rows
+        if (in_mode != glv::IN_F32_PLANAR) return fail(GLV_ERR_INVALID, "operators without GLV_OP_FFT take planar f32 input");
+        e = (const void*) d_out == d_in ? hipSuccess
+            : hipMemcpyAsync(d_out, d_in, sizeof(float) * (size_t) units * b->p.n, hipMemcpyDeviceToDevice, st);
+        b->kernel_name = "glv_smooth_kernel";
+    } else if (ops & GLV_OP_FFT) {
         e = glv::launch_frame(b->log_nn, in_mode, (int) b->p.log_mode, a, frame_grid(b, units), st);
         b->kernel_name = "glv_frame_kernel";
     } else {
@@ -236,6 +265,15 @@ int process(glv_batch* b, const void* d_in, int in_mode, float* d_out, unsigned 
     if (e != hipSuccess) return fail(GLV_ERR_HIP, "kernel launch failed: %s", hipGetErrorString(e));
     if (int rc = timed_launch_end(b, st)) return rc;
     if (ops & GLV_OP_AVERAGE) b->head = (b->head + 1) % b->p.avg_frames;
+    if (ops & GLV_OP_SMOOTH) {                     // render.c:694-718, in place on the finished rows
+        if (int rc = ensure_smooth_tables(b)) return rc;
+        e = glv::launch_smooth(d_out, units, b->p.n, b->d_smin, b->d_smax, b->smooth_asz, st);
+        if (e != hipSuccess) return fail(GLV_ERR_HIP, "smooth launch failed: %s", hipGetErrorString(e));
+    }
+    if (ops & GLV_OP_BARS) {
+        e = glv::launch_bars(d_out, d_final, units, b->p.n, b->p.bars, b->p.smooth_factor, st);
+        if (e != hipSuccess) return fail(GLV_ERR_HIP, "bars launch failed: %s", hipGetErrorString(e));
+    }
     return GLV_OK;
 }
 
@@ -278,6 +316,8 @@ void glv_params_default(glv_params* p) {
     p->log_mode = 0;
     p->bars = 80;                // radial.glsl:9 (NBARS 160, two channels)
     p->smooth_factor = 0.025F;   // smooth_parameters.glsl:72
+    p->smooth_distance = 0.01F;  // render.c:917
+    p->smooth_ratio = 4.0F;      // render.c:918
 }
 
 int glv_abi_version(void) { return GLV_ABI_VERSION; }
@@ -312,6 +352,9 @@ int glv_batch_destroy(glv_batch* b) {
     if (b->d_grav) (void) hipFree(b->d_grav);
     if (b->d_hist) (void) hipFree(b->d_hist);
     if (b->d_ring) (void) hipFree(b->d_ring);
+    if (b->d_scratch) (void) hipFree(b->d_scratch);
+    if (b->d_smin) (void) hipFree(b->d_smin);
+    if (b->d_smax) (void) hipFree(b->d_smax);
     for (hipEvent_t e : b->ev) (void) hipEventDestroy(e);
     delete b;
     return GLV_OK;
@@ -326,6 +369,12 @@ int glv_batch_process_s16(glv_batch* b, const int16_t* d_pcm, float* d_out, unsi
 int glv_batch_process_f32(glv_batch* b, const float* d_f32, float* d_out, unsigned ops, void* hip_stream) {
     if (!b) return fail(GLV_ERR_INVALID, "batch is NULL");
     return process(b, d_f32, glv::IN_F32_PLANAR, d_out, ops, b->streams * 2, 0, (hipStream_t) hip_stream);
+}
+
+int glv_batch_process_f32_stereo(glv_batch* b, const float* d_pcm, float* d_out, unsigned ops, void* hip_stream) {
+    if (!b) return fail(GLV_ERR_INVALID, "batch is NULL");
+    if (!(ops & GLV_OP_FFT)) return fail(GLV_ERR_INVALID, "interleaved input requires GLV_OP_FFT");
+    return process(b, d_pcm, glv::IN_F32_STEREO, d_out, ops, b->streams * 2, 0, (hipStream_t) hip_stream);
 }
 
 int glv_batch_ring_update_s16(glv_batch* b, const int16_t* d_new, uint32_t new_frames, float* d_out, unsigned ops,
@@ -351,6 +400,36 @@ int glv_batch_ring_update_s16(glv_batch* b, const int16_t* d_new, uint32_t new_f
     b->ring_pos = (b->ring_pos + new_frames) % n;
     // oldest sample now sits at ring_pos; rotation in complex points (pairs of frames)
     return process(b, b->d_ring, glv::IN_S16_RING, d_out, ops, b->streams * 2, b->ring_pos / 2, st);
+}
+
+int glv_batch_bars(glv_batch* b, const float* d_spec, float* d_bars, void* hip_stream) {
+    if (!b) return fail(GLV_ERR_INVALID, "batch is NULL");
+    if (!d_spec || !d_bars) return fail(GLV_ERR_INVALID, "NULL device pointer");
+    if (b->p.bars == 0 || b->p.bars > b->p.n) return fail(GLV_ERR_INVALID, "bars=%u out of range", b->p.bars);
+    HIP_TRY(hipSetDevice(b->device));
+    hipError_t e = glv::launch_bars(d_spec, d_bars, (size_t) b->streams * 2, b->p.n, b->p.bars, b->p.smooth_factor, (hipStream_t) hip_stream);
+    if (e != hipSuccess) return fail(GLV_ERR_HIP, "bars launch failed: %s", hipGetErrorString(e));
+    return GLV_OK;
+}
+
+int glv_prelude_bufscale(int device, const float* d_in, float* d_out, size_t rows, uint32_t n_out, uint32_t k, void* hip_stream) {
+    if (!d_in || !d_out) return fail(GLV_ERR_INVALID, "NULL device pointer");
+    if (k == 0 || n_out == 0) return fail(GLV_ERR_INVALID, "bufscale k and n_out must be > 0");
+    if (int rc = ensure_device(device)) return rc;
+    hipError_t e = glv::launch_bufscale(d_in, d_out, rows * n_out, k, (hipStream_t) hip_stream);
+    if (e != hipSuccess) return fail(GLV_ERR_HIP, "bufscale launch failed: %s", hipGetErrorString(e));
+    return GLV_OK;
+}
+
+int glv_prelude_lerp(int device, const float* d_start, const float* d_end, float* d_out, size_t count, float uratio,
+                     int kcounter, void* hip_stream) {
+    if (!d_start || !d_end || !d_out) return fail(GLV_ERR_INVALID, "NULL device pointer");
+    if (int rc = ensure_device(device)) return rc;
+    float mod = uratio * (float) kcounter;               // render.c:1804-1805
+    if (mod > 1.0F) mod = 1.0F;
+    hipError_t e = glv::launch_lerp(d_start, d_end, d_out, count, mod, (hipStream_t) hip_stream);
+    if (e != hipSuccess) return fail(GLV_ERR_HIP, "lerp launch failed: %s", hipGetErrorString(e));
+    return GLV_OK;
 }
 
 int glv_batch_timing_begin(glv_batch* b) {
@@ -452,6 +531,7 @@ int glv_fft(const glv_params* p, glv_state* s, float* buf) { return single(p, s,
 int glv_gravity(const glv_params* p, glv_state* s, float* buf) { return single(p, s, buf, GLV_OP_GRAVITY); }
 int glv_average(const glv_params* p, glv_state* s, float* buf) { return single(p, s, buf, GLV_OP_AVERAGE); }
 int glv_wrange(const glv_params* p, glv_state* s, float* buf) { return single(p, s, buf, GLV_OP_WRANGE); }
+int glv_smooth(const glv_params* p, glv_state* s, float* buf) { return single(p, s, buf, GLV_OP_SMOOTH); }
 int glv_fft_gravity_average(const glv_params* p, glv_state* s, float* buf) {
     return single(p, s, buf, GLV_OP_FFT | GLV_OP_GRAVITY | GLV_OP_AVERAGE);
 }

@@ -18,14 +18,15 @@
 
 namespace glv {
 
-enum InMode { IN_S16_STEREO = 0, IN_F32_PLANAR = 1, IN_S16_RING = 2 };
+enum InMode { IN_S16_STEREO = 0, IN_F32_PLANAR = 1, IN_S16_RING = 2, IN_F32_STEREO = 3 };
 enum Epi { EPI_RAW = 0, EPI_MAG = 1, EPI_MAG_STATE = 2, EPI_RAW_STATE = 3 };
 
 // ops bits as in include/glv_spectrum.h
 enum : uint32_t { OP_FFT = 1u, OP_GRAVITY = 2u, OP_AVERAGE = 4u, OP_RAW = 8u, OP_WRANGE = 16u, OP_BARS = 32u };
 
 struct FrameArgs {
-    const void* in;        // s16: int16 [units/2][n][2] (a unit is one channel row of a frame);  f32: float [units][n]
+    const void* in;        // s16: int16 [units/2][n][2] (a unit is one channel row of a frame);  f32 planar: float [units][n];
+                           // f32 stereo (PulseAudio layout, pulse_input.c:155-178): float [units/2][n][2]
     float* out;            // [units][n]
     float* grav;           // [rows][n] gravity state (only when gravity without average)
     float* hist;           // [rows][F][n] history ring (average); doubles as gravity state
@@ -168,6 +169,22 @@ struct Frame {
             const d2 w = ld<d2>(win, (uint32_t) tid * 16u + (uint32_t) (i * T) * 16u);
             v[i].x = apply_window(u.x, w.x);
             v[i].y = apply_window(u.y, w.y);
+        }
+    }
+
+    // interleaved stereo f32 (pulse_input.c:159-176): one 16-byte load = complex point c of both
+    // channels (L[2c], R[2c], L[2c+1], R[2c+1]); mono = (L + R) / 2 in float (pulse_input.c:167)
+    struct alignas(16) f4 { float a, b, c, d; };
+    GLV_HD static void load_f32_stereo_window(cf (&v)[E], const void* frame, const void* win, int tid, uint32_t ch, bool mono) {
+#pragma unroll
+        for (int i = 0; i < E; ++i) {
+            const f4 u = ld<f4>(frame, (uint32_t) tid * 16u + (uint32_t) (i * T) * 16u);
+            const d2 w = ld<d2>(win, (uint32_t) tid * 16u + (uint32_t) (i * T) * 16u);
+            float s0, s1;
+            if (mono) { s0 = (u.a + u.b) / 2; s1 = (u.c + u.d) / 2; }
+            else { s0 = ch ? u.b : u.a; s1 = ch ? u.d : u.c; }
+            v[i].x = apply_window(s0, w.x);
+            v[i].y = apply_window(s1, w.y);
         }
     }
 

@@ -241,6 +241,9 @@ glv_frame_kernel(const FrameArgs a) {
             FR::template load_pcm<RING>(raw, pcm_ptr(row), tid, a.rot);
             GLV_SCHED_FENCE();
             FR::unpack_window(v, raw, win, tid, row & 1u, a.mono != 0);
+        } else if constexpr (IN_MODE == IN_F32_STEREO) {
+            FR::load_f32_stereo_window(v, static_cast<const char*>(a.in) + (size_t) (row >> 1) * ((size_t) N * 8), win, tid,
+                                       row & 1u, a.mono != 0);
         } else {
             FR::load_f32_window(v, static_cast<const char*>(a.in) + (size_t) row * ((size_t) N * 4), win, tid);
         }

@@ -38,6 +38,80 @@ __global__ void __launch_bounds__(256) glv_unpack_kernel(const int16_t* __restri
     }
 }
 
+// ---- rd_update prelude (glava/render.c:1765-1809) ------------------------------------------------
+// bufscale: mean of k consecutive samples, float accumulation in index order, one float division
+__global__ void __launch_bounds__(256) glv_bufscale_kernel(const float* __restrict__ in, float* __restrict__ out,
+                                                           size_t total_out, uint32_t k) {
+    const float fk = (float) k;
+    for (size_t i = (size_t) blockIdx.x * blockDim.x + threadIdx.x; i < total_out; i += (size_t) gridDim.x * blockDim.x) {
+        float accum = 0.0f;
+        for (uint32_t a = 0; a < k; ++a) accum = accum + in[i * k + a];     // rows are n_out*k long: i*k stays inside the row
+        out[i] = accum / fk;
+    }
+}
+// keyframe interpolation: s + (e - s) * mod, mod = min(uratio * kcounter, 1) computed on the host
+__global__ void __launch_bounds__(256) glv_lerp_kernel(const float* __restrict__ s0, const float* __restrict__ e0,
+                                                       float* __restrict__ out, size_t total, float mod) {
+    for (size_t i = (size_t) blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t) gridDim.x * blockDim.x) {
+        const float d = e0[i] - s0[i];
+        const float p = d * mod;
+        out[i] = s0[i] + p;
+    }
+}
+
+// ---- CPU-path transform_smooth (glava/render.c:694-718) --------------------------------------------
+// In place and sequentially dependent inside a row (output t reads inputs that earlier outputs already
+// replaced), so one lane walks one row; rows are independent.  smin/smax depend only on t and come from
+// the host (powf/log/floor/ceil of the reference's libm, glv_tables.h).
+__global__ void __launch_bounds__(64) glv_smooth_kernel(float* __restrict__ rows, size_t nrows, uint32_t n,
+                                                        const int* __restrict__ smin, const int* __restrict__ smax, uint32_t asz) {
+    const size_t r = (size_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= nrows) return;
+    float* b = rows + r * n;
+    for (uint32_t t = 0; t < asz; ++t) {
+        float avg = 0.0f;
+        int count = 0;
+        for (int q = smin[t]; q <= smax[t]; ++q) {
+            const float x = b[q];
+            if (x != 0.0f) { avg = avg + x; ++count; }     // `if (b[s])`: NaN counts, +-0 does not
+        }
+        b[t] = avg / (float) count;                        // 0/0 = NaN at t = 0, as in the reference
+    }
+}
+
+// ---- smooth_audio() bar sampling (shaders/glava/util/smooth.glsl:13-40, radial/1.frag:58-70) --------
+// One wave per (row, bar); lanes stride over the taps s = smin, smin+1, ... <= smax and the two sums are
+// reduced across the wave.  SAMPLE_MODE average, ROUND_FORMULA sinusoidal, SAMPLE_SCALE 8, SAMPLE_RANGE 0.9.
+__device__ __forceinline__ float glv_scale_audio(float idx) { return -logf((-0.9f * idx) + 1.0f) / 8.0f; }
+__device__ __forceinline__ float glv_clamp01(float x) { return x < 0.0f ? 0.0f : (x > 1.0f ? 1.0f : x); }
+__global__ void __launch_bounds__(256) glv_bars_kernel(const float* __restrict__ spec, float* __restrict__ bars_out,
+                                                       size_t nrows, uint32_t n, uint32_t bars, float smooth_factor) {
+    const size_t wave = ((size_t) blockIdx.x * blockDim.x + threadIdx.x) / 64;
+    const int lane = threadIdx.x & 63;
+    if (wave >= nrows * bars) return;
+    const size_t row = wave / bars;
+    const uint32_t k = (uint32_t) (wave % bars);
+    const float* tex = spec + row * n;
+    const float idx = (float) k / (float) bars;
+    const float smin = glv_scale_audio(glv_clamp01(idx - smooth_factor)) * (float) n;
+    const float smax = glv_scale_audio(glv_clamp01(idx + smooth_factor)) * (float) n;
+    const float m = (smax - smin) / 2.0f, rm = smin + m;
+    float avg = 0.0f, weight = 0.0f;
+    for (int j = lane;; j += 64) {
+        const float sx = smin + (float) j;
+        if (!(sx <= smax)) break;
+        const float w = (0.5f * sinf((3.14159265359f * glv_clamp01((m - fabsf(rm - sx)) / m)) - (3.14159265359f / 2.0f))) + 0.5f;
+        weight += w;
+        avg += glv_clamp01(tex[(int) roundf(sx)]) * w;      // GL_R16 textures clamp to [0,1] (render.c:523)
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        avg += __shfl_xor(avg, o);
+        weight += __shfl_xor(weight, o);
+    }
+    if (lane == 0) bars_out[row * bars + k] = avg / weight;
+}
+
 static int capped_grid(size_t items, int block) {
     size_t g = (items + block - 1) / block;
     if (g > 256 * 8) g = 256 * 8;     // 256 CUs x 8 resident 256-thread blocks, grid-stride beyond
@@ -52,6 +126,24 @@ hipError_t launch_post(const FrameArgs& a, uint32_t n, hipStream_t st) {
 
 hipError_t launch_unpack(const int16_t* pcm, size_t frames, int mono, float* l, float* r, hipStream_t st) {
     hipLaunchKernelGGL(glv_unpack_kernel, dim3(capped_grid(frames, 256)), dim3(256), 0, st, pcm, frames, mono, l, r);
+    return hipGetLastError();
+}
+
+hipError_t launch_bufscale(const float* in, float* out, size_t total_out, uint32_t k, hipStream_t st) {
+    hipLaunchKernelGGL(glv_bufscale_kernel, dim3(capped_grid(total_out, 256)), dim3(256), 0, st, in, out, total_out, k);
+    return hipGetLastError();
+}
+hipError_t launch_lerp(const float* s0, const float* e0, float* out, size_t total, float mod, hipStream_t st) {
+    hipLaunchKernelGGL(glv_lerp_kernel, dim3(capped_grid(total, 256)), dim3(256), 0, st, s0, e0, out, total, mod);
+    return hipGetLastError();
+}
+hipError_t launch_smooth(float* rows, size_t nrows, uint32_t n, const int* smin, const int* smax, uint32_t asz, hipStream_t st) {
+    hipLaunchKernelGGL(glv_smooth_kernel, dim3((unsigned) ((nrows + 63) / 64)), dim3(64), 0, st, rows, nrows, n, smin, smax, asz);
+    return hipGetLastError();
+}
+hipError_t launch_bars(const float* spec, float* bars_out, size_t nrows, uint32_t n, uint32_t bars, float smooth_factor, hipStream_t st) {
+    const size_t waves = nrows * bars;
+    hipLaunchKernelGGL(glv_bars_kernel, dim3((unsigned) ((waves + 3) / 4)), dim3(256), 0, st, spec, bars_out, nrows, n, bars, smooth_factor);
     return hipGetLastError();
 }
 

@@ -24,13 +24,17 @@ inline void make_window(double* w, size_t n) {
         w[i] = 0.53836 - (0.46164 * cos(kTwoPi * (double) i / (double) n - 1));
 }
 
-// window_frame(f, avg_frames - 1), same macro quirk: 0.6 - 0.4 * cos(TWOPI * f / F - 1).
-// kind 1 = the GL twin's coefficients (shaders/glava/util/common.glsl:13).
+// Average weights by AGE f (0 = oldest frame ... F-1 = newest), as apply_state consumes them.
+//   kind 0, CPU twin (render.c:751-766): window_frame(f, avg_frames - 1) with the macro's unparenthesised
+//           `sz`: 0.6 - 0.4*cos(TWOPI*f/F - 1); f = 0 is the oldest frame.
+//   kind 1, GL twin (average_pass.frag:19-45, common.glsl:13): window(I, _AVG_FRAMES - 1) -- same macro quirk,
+//           Hamming coefficients -- with I = 0 the MOST RECENT frame (render.c:2247-2256), i.e. I = F-1-f;
+//           no window at all when F == 2 (average_pass.frag:27-29).
 inline void make_frame_weights(double* w, size_t F, bool use_window, int kind) {
     for (size_t f = 0; f < F; ++f) {
-        if (!use_window) w[f] = 1.0;
+        if (!use_window || (kind == 1 && F == 2)) w[f] = 1.0;
         else if (kind == 0) w[f] = 0.6 - (0.4 * cos(kTwoPi * (double) f / (double) F - 1));
-        else w[f] = 0.53836 - (0.46164 * cos(kTwoPi * (double) f / (double) F - 1));
+        else w[f] = 0.53836 - (0.46164 * cos(kTwoPi * (double) (F - 1 - f) / (double) F - 1));
     }
 }
 
@@ -62,6 +66,22 @@ inline void make_tilt(float* t, size_t n, float fft_scale, float fft_cutoff) {
     const float inv_n = 1.0f / (float) n;              // n is a power of two: exact
     const float omc = 1.0F - fft_cutoff;
     for (size_t i = 0; i < n; ++i) t[i] = tilt((int) i, inv_n, fft_scale, omc);
+}
+
+// transform_smooth window bounds (render.c:699-707): they depend only on the output index t.
+//   asz = ceil(sz / smooth_ratio); smin = floor(e^max(log t - d, 0)); smax = min(ceil(e^(log t + d)), sz - 1)
+inline size_t make_smooth_bounds(int* smin, int* smax, size_t sz, float smooth_distance, float smooth_ratio) {
+    const double kE = 2.7182818284590452353;           // render.c:692
+    const size_t asz = (size_t) ceil(sz / smooth_ratio);
+    for (size_t t = 0; t < asz; ++t) {
+        const float db = (float) log((double) (int) t);
+        float lo = db - smooth_distance;
+        if (!(lo > 0)) lo = 0;
+        smin[t] = (int) floor(powf((float) kE, lo));
+        const int hi = (int) ceil(powf((float) kE, db + smooth_distance));
+        smax[t] = hi < (int) sz - 1 ? hi : (int) sz - 1;
+    }
+    return asz;
 }
 
 // log_mode 0 table (glv_core.h log_third_table): c_j = 1 + j/256, { 1/c_j, log(c_j)/3 }.

@@ -17,7 +17,7 @@ from dataclasses import dataclass
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "csrc", "libglvspectrum.so")
 
-OP_FFT, OP_GRAVITY, OP_AVERAGE, OP_RAW, OP_WRANGE, OP_BARS = 1, 2, 4, 8, 16, 32
+OP_FFT, OP_GRAVITY, OP_AVERAGE, OP_RAW, OP_WRANGE, OP_BARS, OP_SMOOTH = 1, 2, 4, 8, 16, 32, 64
 OK, ERR_INVALID, ERR_NO_DEVICE, ERR_HIP, ERR_NOMEM, ERR_STATE = 0, 1, 2, 3, 4, 5
 
 
@@ -31,7 +31,8 @@ class CParams(C.Structure):
     _fields_ = [("n", C.c_uint32), ("channels", C.c_uint32), ("fft_scale", C.c_float), ("fft_cutoff", C.c_float),
                 ("gravity_step", C.c_float), ("ur", C.c_float), ("avg_frames", C.c_uint32),
                 ("avg_window", C.c_uint32), ("avg_window_kind", C.c_uint32), ("log_mode", C.c_uint32),
-                ("bars", C.c_uint32), ("smooth_factor", C.c_float)]
+                ("bars", C.c_uint32), ("smooth_factor", C.c_float),
+                ("smooth_distance", C.c_float), ("smooth_ratio", C.c_float)]
 
 
 _lib = None
@@ -54,7 +55,7 @@ def lib() -> C.CDLL:
         L.glv_state_create.argtypes = [P, C.c_int, C.POINTER(vp)]
         L.glv_state_reset.argtypes = [vp]
         L.glv_state_destroy.argtypes = [vp]
-        for name in ("glv_fft", "glv_gravity", "glv_average", "glv_wrange", "glv_fft_gravity_average"):
+        for name in ("glv_fft", "glv_gravity", "glv_average", "glv_wrange", "glv_smooth", "glv_fft_gravity_average"):
             getattr(L, name).argtypes = [P, vp, vp]
         L.glv_unpack_s16.argtypes = [C.c_int, vp, C.c_size_t, C.c_int, vp, vp]
         L.glv_batch_create.argtypes = [P, C.c_uint32, C.c_uint, C.c_int, C.POINTER(vp)]
@@ -62,7 +63,11 @@ def lib() -> C.CDLL:
         L.glv_batch_destroy.argtypes = [vp]
         L.glv_batch_process_s16.argtypes = [vp, vp, vp, C.c_uint, vp]
         L.glv_batch_process_f32.argtypes = [vp, vp, vp, C.c_uint, vp]
+        L.glv_batch_process_f32_stereo.argtypes = [vp, vp, vp, C.c_uint, vp]
         L.glv_batch_ring_update_s16.argtypes = [vp, vp, C.c_uint32, vp, C.c_uint, vp]
+        L.glv_batch_bars.argtypes = [vp, vp, vp, vp]
+        L.glv_prelude_bufscale.argtypes = [C.c_int, vp, vp, C.c_size_t, C.c_uint32, C.c_uint32, vp]
+        L.glv_prelude_lerp.argtypes = [C.c_int, vp, vp, vp, C.c_size_t, C.c_float, C.c_int, vp]
         L.glv_batch_timing_begin.argtypes = [vp]
         L.glv_batch_timing_end.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]
         L.glv_batch_algorithmic_bytes.argtypes = [vp, C.c_uint, C.c_int]
@@ -93,11 +98,13 @@ class Params:
     log_mode: int = 0
     bars: int = 80
     smooth_factor: float = 0.025
+    smooth_distance: float = 0.01
+    smooth_ratio: float = 4.0
 
     def c(self) -> CParams:
         return CParams(self.n, self.channels, self.fft_scale, self.fft_cutoff, self.gravity_step, self.ur,
                        self.avg_frames, int(self.avg_window), self.avg_window_kind, self.log_mode,
-                       self.bars, self.smooth_factor)
+                       self.bars, self.smooth_factor, self.smooth_distance, self.smooth_ratio)
 
 
 def _ptr(x) -> C.c_void_p:
@@ -128,8 +135,14 @@ class Batch:
     def process_f32(self, d_in, d_out, ops: int = OP_FFT, stream: int | None = None) -> None:
         _check(lib().glv_batch_process_f32(self._h, _ptr(d_in), _ptr(d_out), ops, _ptr(stream)))
 
+    def process_f32_stereo(self, d_in, d_out, ops: int = OP_FFT, stream: int | None = None) -> None:
+        _check(lib().glv_batch_process_f32_stereo(self._h, _ptr(d_in), _ptr(d_out), ops, _ptr(stream)))
+
     def ring_update_s16(self, d_new, new_frames: int, d_out, ops: int = OP_FFT, stream: int | None = None) -> None:
         _check(lib().glv_batch_ring_update_s16(self._h, _ptr(d_new), new_frames, _ptr(d_out), ops, _ptr(stream)))
+
+    def bars(self, d_spec, d_bars, stream: int | None = None) -> None:
+        _check(lib().glv_batch_bars(self._h, _ptr(d_spec), _ptr(d_bars), _ptr(stream)))
 
     def reset(self) -> None:
         _check(lib().glv_batch_reset(self._h))
@@ -181,6 +194,7 @@ class State:
     def gravity(self, buf) -> None: self._call("glv_gravity", buf)         # transform_gravity
     def average(self, buf) -> None: self._call("glv_average", buf)         # transform_average
     def wrange(self, buf) -> None: self._call("glv_wrange", buf)           # transform_wrange
+    def smooth(self, buf) -> None: self._call("glv_smooth", buf)           # transform_smooth
     def fft_gravity_average(self, buf) -> None: self._call("glv_fft_gravity_average", buf)
 
     def reset(self) -> None:
@@ -201,6 +215,17 @@ class State:
 def unpack_s16(pcm, frames: int, channels, l, r, device: int = 0) -> None:
     """fifo.c:94-110 on the device; host numpy buffers in/out."""
     _check(lib().glv_unpack_s16(device, _ptr(pcm), frames, channels, _ptr(l), _ptr(r)))
+
+
+def prelude_bufscale(d_in, d_out, rows: int, n_out: int, k: int, device: int = 0, stream: int | None = None) -> None:
+    """render.c:1768-1781 box decimation on device buffers."""
+    _check(lib().glv_prelude_bufscale(device, _ptr(d_in), _ptr(d_out), rows, n_out, k, _ptr(stream)))
+
+
+def prelude_lerp(d_start, d_end, d_out, count: int, uratio: float, kcounter: int, device: int = 0,
+                 stream: int | None = None) -> None:
+    """render.c:1794-1809 keyframe interpolation on device buffers."""
+    _check(lib().glv_prelude_lerp(device, _ptr(d_start), _ptr(d_end), _ptr(d_out), count, uratio, kcounter, _ptr(stream)))
 
 
 def device_count() -> int:

@@ -46,9 +46,11 @@ enum {
                                    reference's data[] at render.c:840 */
     GLV_OP_WRANGE   = 1u << 4,  /* (b+1)/2                       == transform_wrange  render.c:773-781;
                                    exclusive with GLV_OP_FFT (the wave module requests window,wrange) */
-    GLV_OP_BARS     = 1u << 5   /* smooth_audio() bin averaging + bar lookup (shaders/glava/util/
+    GLV_OP_BARS     = 1u << 5,  /* smooth_audio() bin averaging + bar lookup (shaders/glava/util/
                                    smooth.glsl:13-64, radial/1.frag:58-70): emit `bars` values per
-                                   channel instead of n bins */
+                                   channel instead of n bins; d_out is float [streams][2][bars] */
+    GLV_OP_SMOOTH   = 1u << 6   /* CPU-path log-window mean  == transform_smooth   render.c:694-718;
+                                   applied last, in place on each row (after fft/gravity/average) */
 };
 
 /* Mirrors the fields of the private `struct gl_data` that the path reads
@@ -75,6 +77,9 @@ typedef struct glv_params {
     /* GLV_OP_BARS parameters (shaders/glava/smooth_parameters.glsl) */
     uint32_t bars;          /* bars per channel (radial.glsl:9 NBARS 160 => 80) */
     float smooth_factor;    /* SMOOTH_FACTOR, smooth_parameters.glsl:72, default 0.025 */
+    /* GLV_OP_SMOOTH parameters (render.c:917-918, #request setsmooth / setsmoothratio render.c:1201-1206) */
+    float smooth_distance;  /* default 0.01 */
+    float smooth_ratio;     /* default 4 */
 } glv_params;
 
 #define GLV_MAX_AVG_FRAMES 16
@@ -110,6 +115,8 @@ int glv_gravity(const glv_params* p, glv_state* s, float* buf);
 int glv_average(const glv_params* p, glv_state* s, float* buf);
 /* == transform_wrange                                              glava/render.c:773-781 */
 int glv_wrange(const glv_params* p, glv_state* s, float* buf);
+/* == transform_smooth                                              glava/render.c:694-718 */
+int glv_smooth(const glv_params* p, glv_state* s, float* buf);
 /* fft -> gravity -> average in one launch (what handle_audio does per bind, render.c:2140-2156) */
 int glv_fft_gravity_average(const glv_params* p, glv_state* s, float* buf);
 
@@ -117,6 +124,13 @@ int glv_fft_gravity_average(const glv_params* p, glv_state* s, float* buf);
  * `frames` interleaved stereo s16 frames -> planar f32.  Runs on the device (the bit-exactness
  * of int16 -> f32 /65535f is part of the parity contract). */
 int glv_unpack_s16(int device, const int16_t* pcm, size_t frames, int channels, float* l, float* r);
+
+/* rd_update prelude on device buffers (glava/render.c:1765-1809); stream-ordered, no state:
+ *   bufscale  d_out[r][t] = mean(d_in[r][t*k .. t*k+k-1]), float accumulation (render.c:1768-1781)
+ *   lerp      d_out = d_start + (d_end - d_start) * min(uratio * kcounter, 1)   (render.c:1794-1809) */
+int glv_prelude_bufscale(int device, const float* d_in, float* d_out, size_t rows, uint32_t n_out, uint32_t k, void* hip_stream);
+int glv_prelude_lerp(int device, const float* d_start, const float* d_end, float* d_out, size_t count,
+                     float uratio, int kcounter, void* hip_stream);
 
 /* ------------------------------------------------------------------------------------
  * 2. Batched extension (device pointers, stream-ordered).  No reference counterpart:
@@ -140,12 +154,20 @@ int glv_batch_process_s16(glv_batch* b, const int16_t* d_pcm, float* d_out, unsi
 /* same from planar f32 (the lb/rb snapshot) */
 int glv_batch_process_f32(glv_batch* b, const float* d_f32, float* d_out, unsigned ops, void* hip_stream);
 
+/* same from interleaved stereo f32 frames, float [streams][n][2] -- the layout the PulseAudio backend
+ * receives (glava/pulse_input.c:155-178); channels == 1 mixes (L + R) / 2 in float (pulse_input.c:167) */
+int glv_batch_process_f32_stereo(glv_batch* b, const float* d_pcm, float* d_out, unsigned ops, void* hip_stream);
+
 /* FIFO ring mode (glava/fifo.c:91-112): the batch keeps an n-frame s16 ring per stream in
  * HBM; each call appends `new_frames` (= sample_sz/4, fifo.c:38,91) stereo frames per
  * stream (d_new int16 [streams][new_frames][2]; NULL => poll-timeout zero fill,
  * fifo.c:67-79), then transforms the whole window. */
 int glv_batch_ring_update_s16(glv_batch* b, const int16_t* d_new, uint32_t new_frames, float* d_out,
                               unsigned ops, void* hip_stream);
+
+/* smooth_audio() bar sampling of spectra already in HBM (d_spec float [streams][2][n]) into
+ * d_bars float [streams][2][bars]; what GLV_OP_BARS runs after the transform. */
+int glv_batch_bars(glv_batch* b, const float* d_spec, float* d_bars, void* hip_stream);
 
 /* Kernel-time accounting for the roofline report: HIP events recorded on the caller's
  * stream around every launch between begin/end; returns accumulated milliseconds and the

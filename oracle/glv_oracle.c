@@ -11,7 +11,9 @@
  * Pinning: the reference's tests hold no golden vector for this path (SURVEY.md 4 /
  * 8c), so this file is pinned against the *compiled reference itself*
  * (oracle/_ref/libglvref.so, built from /root/reference by oracle/Makefile):
- * tests/test_oracle_vs_ref.py demands bit equality on every function below, and the
+ * tests/test_oracle.py demands bit equality on every function below that the
+ * reference can execute without a GL context (the rd_update prelude and the GLSL twins at the
+ * end of this file are restatements only and say so), and the
  * vectors in tests/golden/ were produced by the compiled reference
  * (tests/golden/make_golden.py).
  *
@@ -219,4 +221,101 @@ double glvo_bench_frames(const int16_t* pcm, size_t frames, size_t n, float fft_
     }
     free(out);
     return acc;
+}
+
+/* ---- a5: rd_update prelude (glava/render.c:1765-1809).  These run inside rd_update, which needs
+ * a GL context, so they cannot be driven through oracle/_ref: restated only ("parity unpinned" for
+ * these two functions; they are four lines of float arithmetic each). --------------------------- */
+/* bufscale box decimation (render.c:1768-1781): mean of `k` consecutive samples, float accumulate
+ * in index order, then one float division. */
+void glvo_bufscale(const float* in, float* out, size_t n_out, size_t k) {
+    for (size_t t = 0; t < n_out; ++t) {
+        float accum = 0.0F;
+        for (size_t a = 0; a < k; ++a) accum += in[t * k + a];
+        accum /= (float) k;
+        out[t] = accum;
+    }
+}
+/* keyframe interpolation (render.c:1794-1809): s + (e - s) * min(uratio * kcounter, 1) */
+void glvo_lerp(const float* start, const float* end, float* out, size_t n, float uratio, int kcounter) {
+    float mod = uratio * kcounter;
+    if (mod > 1.0F) mod = 1.0F;
+    for (size_t t = 0; t < n; ++t) out[t] = start[t] + ((end[t] - start[t]) * mod);
+}
+
+/* ---- CPU transform_smooth (glava/render.c:694-718): in place, sequentially dependent (later
+ * outputs read earlier, already replaced inputs).  Pinned against the compiled reference
+ * (glvref_smooth).  The window bounds depend only on t: smin/smax tables (what the device consumes,
+ * generated on the host with the same libm) are exposed separately. */
+#define GLVO_E 2.7182818284590452353 /* render.c:692 */
+void glvo_smooth_bounds(int* smin, int* smax, size_t sz, float smooth_distance, float smooth_ratio, size_t* asz_out) {
+    size_t asz = (size_t) ceil(sz / smooth_ratio);
+    for (size_t t = 0; t < asz; ++t) {
+        float db = log((int) t);
+        float lo = db - smooth_distance; if (!(lo > 0)) lo = 0;      /* max(db - d, 0) with the macro's `_a > _b ? _a : _b` */
+        smin[t] = (int) floor(powf(GLVO_E, lo));
+        int hi = (int) ceil(powf(GLVO_E, db + smooth_distance));
+        smax[t] = hi < (int) sz - 1 ? hi : (int) sz - 1;
+    }
+    *asz_out = asz;
+}
+void glvo_smooth(float* b, size_t sz, float smooth_distance, float smooth_ratio) {
+    size_t asz = (size_t) ceil(sz / smooth_ratio);
+    for (int t = 0; t < (int) asz; ++t) {
+        float db = log(t), avg = 0;
+        float lo = db - smooth_distance; if (!(lo > 0)) lo = 0;
+        int smin = (int) floor(powf(GLVO_E, lo));
+        int hi = (int) ceil(powf(GLVO_E, db + smooth_distance));
+        int smax = hi < (int) sz - 1 ? hi : (int) sz - 1;
+        int count = 0;
+        for (int s = smin; s <= smax; ++s)
+            if (b[s]) { avg += b[s]; count++; }
+        avg /= count;
+        b[t] = avg;
+    }
+}
+
+/* ---- a12: the GL "accel" twins (semantics only; GLSL float, cannot be executed here: no GL
+ * context, so this part of the oracle is UNPINNED and tolerances in the tests are loose). ---------- */
+/* average_pass.frag:19-45 with window() of common.glsl:13 as expanded at average_pass.frag:41:
+ *   r = sum_I (0.53836 - 0.46164*cos(TWOPI*I/F - 1)) * t_I / F,  t_0 = most recent (render.c:2247-2256);
+ * no window when F == 2 (average_pass.frag:27-29). Weight for age f (0 = oldest): I = F-1-f. */
+double glvo_gl_frame_weight(size_t f, size_t F, int use_window) {
+    if (!use_window || F == 2) return 1.0;
+    size_t I = F - 1 - f;
+    return 0.53836 - (0.46164 * cos(GLVO_TWOPI * (double) I / (double) F - 1));
+}
+void glvo_average_gl(float* b, float* hist, size_t* head, size_t sz, size_t F, int use_window) {
+    memcpy(hist + (*head) * sz, b, sz * sizeof(float));
+    for (size_t t = 0; t < sz; ++t) {
+        float v = 0.0F;
+        for (size_t f = 0; f < F; ++f) {
+            size_t slot = (*head + 1 + f) % F;
+            v = (float) ((double) v + glvo_gl_frame_weight(f, F, use_window) * (double) hist[slot * sz + t]);
+        }
+        b[t] = v / (float) F;
+    }
+    *head = (*head + 1) % F;
+}
+/* smooth_audio() (shaders/glava/util/smooth.glsl:13-40, SAMPLE_MODE average, ROUND_FORMULA sinusoidal,
+ * SAMPLE_SCALE 8, SAMPLE_RANGE 0.9 -- smooth_parameters.glsl) sampled at the bar positions the radial
+ * module uses (radial/1.frag:58-70: pos = k / bars, k = 0..bars-1).  tex[] is clamped to [0,1] as the
+ * GL_R16 texture would (render.c:523). */
+static float glvo_scale_audio(float idx) { return -logf((-0.9F * idx) + 1) / 8.0F; }
+static float glvo_clamp01(float x) { return x < 0 ? 0 : (x > 1 ? 1 : x); }
+static float glvo_sinusoidal(float x) { return (0.5F * sinf((3.14159265359F * x) - (3.14159265359F / 2))) + 0.5F; }
+void glvo_bars(const float* tex, size_t sz, float* bars_out, size_t bars, float smooth_factor) {
+    for (size_t k = 0; k < bars; ++k) {
+        float idx = (float) k / (float) bars;
+        float smin = glvo_scale_audio(glvo_clamp01(idx - smooth_factor)) * sz;
+        float smax = glvo_scale_audio(glvo_clamp01(idx + smooth_factor)) * sz;
+        float m = (smax - smin) / 2.0F, rm = smin + m;
+        float avg = 0, weight = 0;
+        for (float s = smin; s <= smax; s += 1.0F) {
+            float w = glvo_sinusoidal(glvo_clamp01((m - fabsf(rm - s)) / m));
+            weight += w;
+            avg += glvo_clamp01(tex[(int) roundf(s)]) * w;
+        }
+        bars_out[k] = avg / weight;
+    }
 }

@@ -64,6 +64,14 @@ struct Emu {
         run_pass<0>(th, lds, a.tw);
         finish(th, a.out + row * N, row, a);
     }
+    static void row_f32_stereo(const float* frame, size_t row, const FrameArgs& a) {
+        std::vector<Thread> th(T);
+        std::vector<cf> lds(FR::XREGION);
+        for (int tid = 0; tid < T; ++tid)
+            FR::load_f32_stereo_window(th[tid].v, frame, a.win, tid, (uint32_t) (row & 1), a.mono != 0);
+        run_pass<0>(th, lds, a.tw);
+        finish(th, a.out + row * N, row, a);
+    }
     static void row_f32(const float* in_row, size_t row, const FrameArgs& a) {
         std::vector<Thread> th(T);
         std::vector<cf> lds(FR::XREGION);
@@ -78,6 +86,7 @@ static void run_units(int in_mode, const FrameArgs& a) {
     using EM = Emu<LOG_NN, LOG_MODE>;
     for (uint32_t u = 0; u < a.units; ++u) {
         if (in_mode == IN_S16_STEREO) EM::row_s16((const int16_t*) a.in + (size_t) (u >> 1) * 2 * EM::N, u, a);
+        else if (in_mode == IN_F32_STEREO) EM::row_f32_stereo((const float*) a.in + (size_t) (u >> 1) * 2 * EM::N, u, a);
         else EM::row_f32((const float*) a.in + (size_t) u * EM::N, u, a);
     }
 }

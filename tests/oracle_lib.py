@@ -96,6 +96,11 @@ class Oracle:
                                          C.c_void_p, C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
             L.glvo_bench_frames.argtypes = [_i16p, C.c_size_t, C.c_size_t, C.c_float, C.c_float]
             L.glvo_bench_frames.restype = C.c_double
+            L.glvo_bufscale.argtypes = [_f32p, _f32p, C.c_size_t, C.c_size_t]
+            L.glvo_lerp.argtypes = [_f32p, _f32p, _f32p, C.c_size_t, C.c_float, C.c_int]
+            L.glvo_smooth.argtypes = [_f32p, C.c_size_t, C.c_float, C.c_float]
+            L.glvo_average_gl.argtypes = [_f32p, _f32p, C.POINTER(C.c_size_t), C.c_size_t, C.c_size_t, C.c_int]
+            L.glvo_bars.argtypes = [_f32p, C.c_size_t, _f32p, C.c_size_t, C.c_float]
             cls._lib = L
         return cls._lib
 

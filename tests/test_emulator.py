@@ -87,6 +87,26 @@ def test_fast_log_mode_within_tolerance(emu, oracle):
     assert rel.max() <= 1e-5, rel.max()
 
 
+def test_f32_interleaved_pulse_layout(emu, oracle):
+    """pulse_input.c:155-178: interleaved f32 frames, stereo and mono ((L+R)/2 in float)."""
+    n = 1024
+    x = (np.random.default_rng(9).standard_normal((2, n, 2)) * 0.3).astype(np.float32)    # [frames][n][2]
+    out = emu_process(emu, n, x, 2, OP_FFT | OP_RAW, in_mode=3)
+    for fr in range(2):
+        l, r = oracle.lib().glvo_unpack_f32, None
+        pl = np.empty(n, np.float32); pr = np.empty(n, np.float32)
+        oracle.lib().glvo_unpack_f32(np.ascontiguousarray(x[fr].reshape(-1)), n, 2, pl, pr)
+        for c, ch in enumerate((pl, pr)):
+            _, want = oracle.transform_fft(ch, want_raw=True)
+            assert (bits(out[2 * fr + c]) == bits(want)).all()
+    mono = emu_process(emu, n, x, 2, OP_FFT | OP_RAW, in_mode=3, mono=1)
+    for fr in range(2):
+        pl = np.empty(n, np.float32); pr = np.empty(n, np.float32)
+        oracle.lib().glvo_unpack_f32(np.ascontiguousarray(x[fr].reshape(-1)), n, 1, pl, pr)
+        _, want = oracle.transform_fft(pl, want_raw=True)
+        assert (bits(mono[2 * fr]) == bits(want)).all() and (bits(mono[2 * fr + 1]) == bits(want)).all()
+
+
 def test_raw_state_chain_bit_exact(emu, oracle):
     """GLV_OP_RAW with gravity/average: the state machine on raw FFT values, all-float => bit-exact."""
     import ctypes as C

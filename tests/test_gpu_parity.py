@@ -221,6 +221,98 @@ def test_f32_planar_batch_and_mono(G):
         assert (bits(got[2 * u:2 * u + 2]) == bits(wraw)).all()
 
 
+def test_pulse_f32_interleaved_input(G):
+    """pulse_input.c:155-178 layout: float [streams][n][2]; stereo and (L+R)/2 mono; raw FFT bit-exact."""
+    import torch
+    n, streams = 2048, 7
+    x = (np.random.default_rng(11).standard_normal((streams, n, 2)) * 0.3).astype(np.float32)
+    for ch in (2, 1):
+        b = G.Batch(G.Params(n=n, channels=ch), streams, G.OP_FFT)
+        d_out = torch.empty((streams * 2, n), dtype=torch.float32, device="cuda")
+        b.process_f32_stereo(torch.from_numpy(x).cuda(), d_out, G.OP_FFT | G.OP_RAW)
+        got = d_out.cpu().numpy()
+        b.close()
+        for u in range(streams):
+            pl = np.empty(n, np.float32); pr = np.empty(n, np.float32)
+            Oracle.lib().glvo_unpack_f32(np.ascontiguousarray(x[u].reshape(-1)), n, ch, pl, pr)
+            for c, row in enumerate((pl, pr)):
+                _, want = Oracle.transform_fft(row, want_raw=True)
+                assert (bits(got[2 * u + c]) == bits(want)).all(), (ch, u, c)
+
+
+def test_prelude_bufscale_and_lerp(G):
+    """rd_update prelude (render.c:1765-1809) on device buffers, bit-exact vs the restatement."""
+    import torch
+    rows, n_out = 6, 1024
+    for k in (2, 4, 3):
+        x = np.random.default_rng(k).standard_normal((rows, n_out * k)).astype(np.float32)
+        d_out = torch.empty((rows, n_out), dtype=torch.float32, device="cuda")
+        G.prelude_bufscale(torch.from_numpy(x).cuda(), d_out, rows, n_out, k)
+        got = d_out.cpu().numpy()
+        for r in range(rows):
+            want = np.empty(n_out, np.float32)
+            Oracle.lib().glvo_bufscale(np.ascontiguousarray(x[r]), want, n_out, k)
+            assert (bits(got[r]) == bits(want)).all()
+    s0 = np.random.default_rng(1).standard_normal(5000).astype(np.float32)
+    e0 = np.random.default_rng(2).standard_normal(5000).astype(np.float32)
+    for uratio, kc in ((0.3, 1), (0.3, 2), (0.6, 3)):      # the last one saturates at 1
+        d_out = torch.empty(5000, dtype=torch.float32, device="cuda")
+        G.prelude_lerp(torch.from_numpy(s0).cuda(), torch.from_numpy(e0).cuda(), d_out, 5000, uratio, kc)
+        want = np.empty(5000, np.float32)
+        Oracle.lib().glvo_lerp(s0, e0, want, 5000, uratio, kc)
+        assert (bits(d_out.cpu().numpy()) == bits(want)).all()
+
+
+def test_cpu_smooth_operator(G):
+    """transform_smooth (render.c:694-718): bit-exact incl. the NaN the reference produces at t = 0."""
+    for n, dist, ratio in ((512, 0.01, 4.0), (4096, 0.01, 4.0), (1024, 0.05, 2.0)):
+        x = np.abs(np.random.default_rng(n).standard_normal(n)).astype(np.float32)
+        x[::7] = 0
+        want = x.copy(); Oracle.lib().glvo_smooth(want, n, dist, ratio)
+        st = G.State(G.Params(n=n, smooth_distance=dist, smooth_ratio=ratio))
+        got = x.copy(); st.smooth(got)
+        st.close()
+        assert ((bits(got) == bits(want)) | (np.isnan(got) & np.isnan(want))).all()
+
+
+def test_gl_twin_average_and_bars(G):
+    """a12 semantics (GL accel passes): Hamming-weighted newest-first average (average_pass.frag) and
+    smooth_audio() bar sampling (smooth.glsl, radial/1.frag).  GLSL cannot run here, so both sides are
+    restatements; tolerance reflects float summation order only."""
+    import torch
+    n, streams, F, bars = 16384, 3, 5, 80
+    p = G.Params(n=n, avg_frames=F, avg_window_kind=1, bars=bars)
+    b = G.Batch(p, streams, G.OP_FFT | G.OP_GRAVITY | G.OP_AVERAGE)
+    d_bars = torch.empty((streams * 2, bars), dtype=torch.float32, device="cuda")
+    d_spec = torch.empty((streams * 2, n), dtype=torch.float32, device="cuda")
+    grav = np.zeros((streams * 2, n), np.float32)
+    hist = np.zeros((streams * 2, F, n), np.float32)
+    heads = [C.c_size_t(0) for _ in range(streams * 2)]
+    for fr in range(F + 2):
+        pcm = (lcg_pcm_fast(7000 + fr, streams * 2 * n) // 64).astype(np.int16)      # keep magnitudes inside [0,1]-ish
+        d_pcm = torch.from_numpy(pcm).cuda()
+        b.process_s16(d_pcm, d_bars, G.OP_FFT | G.OP_GRAVITY | G.OP_AVERAGE | G.OP_BARS)
+        got_bars = d_bars.cpu().numpy()
+        for u in range(streams):
+            out = StreamOracle(n, gravity=False, average=False).frame(pcm[u * 2 * n:(u + 1) * 2 * n])
+            for c in range(2):
+                row = np.ascontiguousarray(out[c])
+                Oracle.gravity(row, grav[2 * u + c])
+                Oracle.lib().glvo_average_gl(row, hist[2 * u + c], C.byref(heads[2 * u + c]), n, F, 1)
+                want = np.empty(bars, np.float32)
+                Oracle.lib().glvo_bars(row, n, want, bars, 0.025)
+                assert np.allclose(got_bars[2 * u + c], want, rtol=2e-4, atol=2e-6), (fr, u, c)
+    # bars of spectra already in HBM (glv_batch_bars)
+    spec = np.abs(np.random.default_rng(5).standard_normal((streams * 2, n))).astype(np.float32) * 0.4
+    b.bars(torch.from_numpy(spec).cuda(), d_bars)
+    got = d_bars.cpu().numpy()
+    for r in range(streams * 2):
+        want = np.empty(bars, np.float32)
+        Oracle.lib().glvo_bars(np.ascontiguousarray(spec[r]), n, want, bars, 0.025)
+        assert np.allclose(got[r], want, rtol=2e-4, atol=2e-6)
+    b.close()
+
+
 def test_fifo_ring_mode(G):
     """glv_batch_ring_update_s16 == fifo.c:91-112 ring shift/append (+ :67-79 zero fill) followed by
     the transform of the whole window."""

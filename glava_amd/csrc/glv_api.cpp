@@ -78,12 +78,14 @@ struct Tables {
     glv::LogEntry* d_log = nullptr;
     float* d_tilt = nullptr;
     float tilt_scale = 0.f, tilt_cutoff = 0.f;
+    bool tilt_fold = false;
     uint32_t n_ = 0;
-    // (re)generate the tilt factors when fft_scale / fft_cutoff change (render.c:845)
-    int set_tilt(float fft_scale, float fft_cutoff) {
-        if (d_tilt && fft_scale == tilt_scale && fft_cutoff == tilt_cutoff) return GLV_OK;
+    // (re)generate the tilt factors when fft_scale / fft_cutoff / log mode change (render.c:845)
+    int set_tilt(float fft_scale, float fft_cutoff, bool fold) {
+        if (d_tilt && fft_scale == tilt_scale && fft_cutoff == tilt_cutoff && fold == tilt_fold) return GLV_OK;
         std::vector<float> t(n_);
-        glv::make_tilt(t.data(), n_, fft_scale, fft_cutoff);
+        glv::make_tilt(t.data(), n_, fft_scale, fft_cutoff, fold);
+        tilt_fold = fold;
         if (!d_tilt) HIP_TRY(hipMalloc(&d_tilt, sizeof(float) * n_));
         HIP_TRY(hipMemcpy(d_tilt, t.data(), sizeof(float) * n_, hipMemcpyHostToDevice));
         tilt_scale = fft_scale; tilt_cutoff = fft_cutoff;
@@ -240,7 +242,7 @@ int process(glv_batch* b, const void* d_in, int in_mode, float* d_out, unsigned 
         d_out = b->d_scratch;
     }
 
-    if (int rc = b->tab.set_tilt(b->p.fft_scale, b->p.fft_cutoff)) return rc;
+    if (int rc = b->tab.set_tilt(b->p.fft_scale, b->p.fft_cutoff, b->p.log_mode == 1)) return rc;
     glv::FrameArgs a;
     fill_common(a, b->p, b->tab);
     a.in = d_in; a.out = d_out; a.grav = b->d_grav; a.hist = b->d_hist;

@@ -199,27 +199,29 @@ struct SubPass {
     }
 };
 
-// ---- pass plan: log2(nn) bits split into sub-passes of at most 4 bits --------------------------
-// E = 16 elements per thread, T = nn/16 threads cooperate on one FFT.  Passes 0..P-2 are
-// radix 16; the last takes the remaining bits (1..4) and handles 16 >> RB groups per thread.
-template <int LOG_NN>
+// ---- pass plan: log2(nn) bits split into sub-passes of at most LOG_E bits ------------------------
+// E = 2^LOG_E points per lane (16 or 8), T = nn/E lanes cooperate on one FFT.  Passes 0..P-2 are
+// radix E; the last takes the remaining bits and handles E >> RB groups per lane.  E = 16 means
+// fewer LDS exchanges (N=4096: 4+4+3), E = 8 half the registers per lane and twice the waves per
+// row (3+3+3+2) -- which one wins is a per-size tuning decision (glv_inst.hip).
+template <int LOG_NN, int LOG_E = 4>
 struct Plan {
     static constexpr int NN = 1 << LOG_NN;
-    static constexpr int E = 16;
+    static constexpr int E = 1 << LOG_E;
     static constexpr int T = NN / E;
-    static constexpr int P = (LOG_NN + 3) / 4;
-    GLV_HD static constexpr int rb(int pass) { return pass < P - 1 ? 4 : LOG_NN - 4 * (P - 1); }
-    GLV_HD static constexpr int log_l0(int pass) { return 4 * pass; }
+    static constexpr int P = (LOG_NN + LOG_E - 1) / LOG_E;
+    GLV_HD static constexpr int rb(int pass) { return pass < P - 1 ? LOG_E : LOG_NN - LOG_E * (P - 1); }
+    GLV_HD static constexpr int log_l0(int pass) { return LOG_E * pass; }
 };
 
 // LDS address (in complex units, within one FFT's exchange region) of element index q for the
-// exchange that follows pass `pass`.  Only the first pass writes with a lane stride of 16
-// elements (q = 16*tid + e); padding one element per 16 turns that into a stride of 17 -- conflict
+// exchange that follows pass `pass`.  Only the first pass writes with a lane stride of E
+// elements (q = E*tid + e); padding one element per E turns that into a stride of E+1 -- conflict
 // free for the 16-lane ds_write_b64 groups -- and keeps every access of a phase at
 // `lane base + compile-time constant` (an XOR swizzle would need a separate address VGPR per
-// element).  The following read (q = i*nn/R + tid) sees one 2-way conflict per 32-lane group
+// element).  The following read (q = i*nn/R + tid) sees a few 2-way conflicts per 32-lane group
 // (+1 LDS cycle); later exchanges are contiguous per 16 lanes and conflict free as they are.
-GLV_HD constexpr int lds_index(int pass, int q) { return pass == 0 ? q + (q >> 4) : q; }
+GLV_HD constexpr int lds_index(int pass, int q, int log_e = 4) { return pass == 0 ? q + (q >> log_e) : q; }
 
 // `uniform base + 32-bit byte offset` access (see glv_frame.h "addressing")
 template <typename V> GLV_HD V ld(const void* base, uint32_t byte_off) {
@@ -264,8 +266,8 @@ GLV_HD float gravity(float b, float applied, float g) {
 //   mode 0  fp64: table-driven double-precision log (relative error ~2^-50) times 1/3, rounded to
 //           float once -- equals the reference's float result except when the double value sits
 //           within ~1e-15 relative of a float rounding boundary (probability ~1e-8 per value)
-//   mode 1  fast: the hardware log2 (v_log_f32, 1 ulp) times ln2/3; <= ~2e-7 relative, the
-//           parity bar for magnitudes is 1e-5
+//   mode 1  fast: the hardware log2 (v_log_f32, 1 ulp) times (ln2/3 * tilt) in one multiply;
+//           <= ~3e-7 relative, the parity bar for magnitudes is 1e-5
 //   mode 2  audit: the device libm's fp64 log and a true fp64 division, the reference's
 //           expression verbatim (slow; for cross-checking mode 0)
 struct LogEntry;
@@ -320,7 +322,9 @@ GLV_HD float log_third_table(float y, const LogEntry* tab) {
 }
 
 template <> GLV_HD float log_third<0>(float y, const LogEntry* tab) { return log_third_table(y, tab); }
-template <> GLV_HD float log_third<1>(float y, const LogEntry*) { return GLV_LOG2F(y) * (0.69314718055994530942f / 3.0f); }
+// mode 1 returns log2(y); the ln2/3 factor is folded into the tilt table the kernel multiplies with
+// (glv_tables.h make_tilt with fold_ln2_3), one multiply less per value
+template <> GLV_HD float log_third<1>(float y, const LogEntry*) { return GLV_LOG2F(y); }
 template <> GLV_HD float log_third<2>(float y, const LogEntry*) { return (float) (::log((double) y) / 3); }
 
 }  // namespace glv

@@ -94,12 +94,12 @@ GLV_HD cf apply_state(cf val, uint32_t off, size_t row, uint32_t n, const FrameA
     return val;
 }
 
-template <int LOG_NN>
+template <int LOG_NN, int LOG_E = 4>
 struct Frame {
-    using PL = Plan<LOG_NN>;
-    static constexpr int NN = PL::NN, N = 2 * NN, T = PL::T, P = PL::P, E = 16;
-    // complex points of one LDS exchange region: the pass-0 exchange is padded by one point per 16
-    static constexpr int XREGION = NN + NN / 16;
+    using PL = Plan<LOG_NN, LOG_E>;
+    static constexpr int NN = PL::NN, N = 2 * NN, T = PL::T, P = PL::P, E = PL::E;
+    // complex points of one LDS exchange region: the pass-0 exchange is padded by one point per E
+    static constexpr int XREGION = NN + NN / E;
 
     // ---- input: v[i] <- windowed sample pair (complex point) c = i*T + tid ---------------------
     // s16: one 8-byte load holds complex point c of BOTH channels: (L[2c], R[2c], L[2c+1], R[2c+1]).
@@ -134,7 +134,7 @@ struct Frame {
     }
     // WCHUNK window pairs are fetched per scheduling fence: two chunks in flight hide the L2/LDS
     // latency of the table while keeping the transient footprint at 2*WCHUNK*4 VGPRs.
-    static constexpr int WCHUNK = 4;
+    static constexpr int WCHUNK = E < 4 ? E : 4;
     template <bool MONO>
     GLV_HD static void unpack_window_impl(cf (&v)[E], const Raw& p, const void* win, int tid, uint32_t ch_shift) {
         d2 w[2][WCHUNK];
@@ -259,7 +259,7 @@ struct Frame {
         for (int gi = 0; gi < PI::NG; ++gi)
 #pragma unroll
             for (int r = 0; r < PI::R; ++r)
-                st<cf>(xbuf, (uint32_t) lds_index(PASS, out_index<PASS>(tid, gi, r)) * 8u, v[gi * PI::R + r]);
+                st<cf>(xbuf, (uint32_t) lds_index(PASS, out_index<PASS>(tid, gi, r), LOG_E) * 8u, v[gi * PI::R + r]);
     }
     // read the inputs of pass PASS from the exchange written after pass PASS-1; in the last pass a
     // lane's groups are adjacent (group_of), so two points come with one 16-byte read
@@ -280,7 +280,7 @@ struct Frame {
             for (int gi = 0; gi < PI::NG; ++gi)
 #pragma unroll
                 for (int i = 0; i < PI::R; ++i)
-                    v[gi * PI::R + i] = ld<cf>(xbuf, (uint32_t) lds_index(PASS - 1, in_index<PASS>(tid, gi, i)) * 8u);
+                    v[gi * PI::R + i] = ld<cf>(xbuf, (uint32_t) lds_index(PASS - 1, in_index<PASS>(tid, gi, i), LOG_E) * 8u);
         }
     }
 

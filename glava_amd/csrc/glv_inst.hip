@@ -12,17 +12,17 @@
 namespace glv {
 
 template <int LOG_NN> struct Tuned;
-#define GLV_TUNED(K, S, NB, TR, WL, OC, PF, TL) \
-    template <> struct Tuned<K> { static constexpr int slots = S, nbuf = NB, occ = OC; \
+#define GLV_TUNED(K, LE, S, NB, TR, WL, OC, PF, TL) \
+    template <> struct Tuned<K> { static constexpr int log_e = LE, slots = S, nbuf = NB, occ = OC; \
                                   static constexpr bool twreg = TR, winlds = WL, prefetch = PF, tiltreg = TL; };
 // measured best of tools/tune.py on MI355X (profiles/tune_r01.txt), equal bytes per size class:
-//         log2(nn) SLOTS NBUF TWREG  WINLDS OCC PREFETCH TILTREG
-GLV_TUNED(8,        16,   1,   true,  true,  2,  true,    true)    // N=512
-GLV_TUNED(9,        8,    1,   true,  true,  2,  true,    true)    // N=1024
-GLV_TUNED(10,       4,    1,   true,  true,  2,  true,    true)    // N=2048
-GLV_TUNED(11,       2,    1,   true,  true,  2,  true,    true)    // N=4096
-GLV_TUNED(12,       1,    1,   true,  false, 2,  true,    true)    // N=8192  (window 64 KiB: read through L2)
-GLV_TUNED(13,       1,    1,   true,  false, 2,  true,    true)    // N=16384 (70 KiB exchange region per slot)
+//         log2(nn) LOG_E SLOTS NBUF TWREG  WINLDS OCC PREFETCH TILTREG
+GLV_TUNED(8,        3,    16,   1,   true,  true,  4,  true,    true)    // N=512    E=8: 3+3+2
+GLV_TUNED(9,        3,    4,    1,   true,  true,  4,  false,   true)    // N=1024   E=8: 3+3+3
+GLV_TUNED(10,       3,    2,    1,   true,  true,  4,  false,   true)    // N=2048   E=8: 3+3+3+1
+GLV_TUNED(11,       4,    2,    1,   true,  true,  2,  true,    true)    // N=4096   E=16: 4+4+3
+GLV_TUNED(12,       4,    1,    1,   true,  false, 2,  true,    true)    // N=8192   E=16: 4+4+4 (window 64 KiB: via L2)
+GLV_TUNED(13,       4,    1,    1,   true,  false, 2,  true,    true)    // N=16384  E=16: 4+4+4+1 (70 KiB exchange region)
 #undef GLV_TUNED
 
 #define GLV_CAT2(a, b) a##b
@@ -31,7 +31,7 @@ GLV_TUNED(13,       1,    1,   true,  false, 2,  true,    true)    // N=16384 (7
 template <int IN_MODE, int LOG_MODE>
 static hipError_t launch_one(const FrameArgs& a, int grid, hipStream_t st) {
     using TU = Tuned<GLV_LOG_NN>;
-    return launch_variant<GLV_LOG_NN, IN_MODE, LOG_MODE, TU::slots, TU::nbuf, TU::twreg, TU::winlds, TU::occ, TU::prefetch, TU::tiltreg>(a, grid, st);
+    return launch_variant<GLV_LOG_NN, IN_MODE, LOG_MODE, TU::slots, TU::nbuf, TU::twreg, TU::winlds, TU::occ, TU::prefetch, TU::tiltreg, TU::log_e>(a, grid, st);
 }
 
 template <int IN_MODE>

@@ -16,6 +16,7 @@
 //
 // Tuning knobs (template parameters; production picks one set per size in glv_inst.hip,
 // tools/tune.py sweeps them through glv_tune.hip):
+//   LOG_E   log2 of the points a lane owns (4: E=16, T=nn/16 lanes per row; 3: E=8, T=nn/8)
 //   SLOTS   FFT slots per workgroup
 //   NBUF    1: one LDS exchange region per slot, two barriers per exchange
 //           2: ping-pong regions, one barrier per exchange
@@ -35,9 +36,9 @@
 
 namespace glv {
 
-template <int LOG_NN, int NBUF, bool TWREG>
+template <int LOG_NN, int LOG_E, int NBUF, bool TWREG>
 struct Body {
-    using FR = Frame<LOG_NN>;
+    using FR = Frame<LOG_NN, LOG_E>;
     static constexpr int P = FR::P, NN = FR::NN, N = FR::N, T = FR::T;
 
     template <int PASS>
@@ -74,7 +75,7 @@ struct Body {
     // pin the phase order  compute | LDS write + next twiddle gather | barrier | LDS read | compute
     // so that the backend cannot pull the table loads of later passes (30 VGPRs each) up front.
     template <int PASS>
-    static __device__ __forceinline__ void run(cf (&v)[16], cf* tw_all, const cf* __restrict__ table,
+    static __device__ __forceinline__ void run(cf (&v)[FR::E], cf* tw_all, const cf* __restrict__ table,
                                                char* xslot, int tid, unsigned& xcount) {
         // pass 0's twiddles are the same for every lane (k0 = 0); the kernel gathers them once, before
         // the row loop, into scalar registers (gather_uniform_tw0) -- a vector load here would sit in
@@ -103,11 +104,13 @@ static __device__ __forceinline__ uint32_t maybe_scalar(uint32_t v) {
     else return v;
 }
 
-template <int LOG_NN, int IN_MODE, int LOG_MODE, int SLOTS, int NBUF, bool TWREG, bool WINLDS, int OCC, bool PREFETCH, bool TILTREG>
-__global__ void __launch_bounds__(Frame<LOG_NN>::T * SLOTS, OCC)
+template <int LOG_NN, int IN_MODE, int LOG_MODE, int SLOTS, int NBUF, bool TWREG, bool WINLDS, int OCC, bool PREFETCH, bool TILTREG,
+          int LOG_E>
+__global__ void __launch_bounds__((Frame<LOG_NN, LOG_E>::T * SLOTS), OCC)
 glv_frame_kernel(const FrameArgs a) {
-    using FR = Frame<LOG_NN>;
-    using BD = Body<LOG_NN, NBUF, TWREG>;
+    using FR = Frame<LOG_NN, LOG_E>;
+    using BD = Body<LOG_NN, LOG_E, NBUF, TWREG>;
+    constexpr int E = FR::E;
     constexpr int T = FR::T, N = FR::N;
     constexpr bool RING = IN_MODE == IN_S16_RING;
     constexpr bool S16 = IN_MODE == IN_S16_STEREO || RING;
@@ -140,13 +143,13 @@ glv_frame_kernel(const FrameArgs a) {
     cf tw_all[BD::TW_TOTAL];
     BD::gather_uniform_tw0(tw_all, a.tw);
     if constexpr (TWREG && FR::P > 1) BD::template gather_from<1>(tw_all, a.tw, tid);
-    cf tilt_reg[TILTREG ? 16 : 1];
+    cf tilt_reg[TILTREG ? E : 1];
     if constexpr (TILTREG) FR::gather_tilt(tilt_reg, a.tilt, tid);
 
     // operator chain, uniform for the launch
     const int epi = (a.ops & (OP_GRAVITY | OP_AVERAGE)) ? ((a.ops & OP_RAW) ? EPI_RAW_STATE : EPI_MAG_STATE)
                                                         : ((a.ops & OP_RAW) ? EPI_RAW : EPI_MAG);
-    auto finish = [&](const cf (&v)[16], size_t row, int tid) {
+    auto finish = [&](const cf (&v)[E], size_t row, int tid) {
         float* out_row = a.out + row * N;
         switch (epi) {
             case EPI_MAG:       FR::template epilogue<LOG_MODE, EPI_MAG, TILTREG>(v, out_row, row, tid, a, logtab, tilt_reg); break;
@@ -186,7 +189,7 @@ glv_frame_kernel(const FrameArgs a) {
         // full transform old.  gfx9-class targets count loads and stores on one counter (vmcnt),
         // and a wait with both kinds pending drains everything -- so a row must never need fresh
         // load data right after its predecessor's stores were issued.
-        cf v[16], vn[16];
+        cf v[E], vn[E];
         typename FR::Raw raw;
         if (step_base(0) < a.units) {
             int tid = tid_outer;
@@ -220,8 +223,10 @@ glv_frame_kernel(const FrameArgs a) {
             FR::unpack_window(vn, raw, win, tid, row_n & 1u, a.mono != 0);                       // C
             GLV_SCHED_FENCE();
             if (active) finish(v, (size_t) row, tid);                                            // D
+            // (swapping the roles of v/vn by unrolling twice doubles the loop body and pushed the fp64-log
+            //  variant into heavy spilling; 32 v_mov per row are the cheaper price)
 #pragma unroll
-            for (int i = 0; i < 16; ++i) v[i] = vn[i];
+            for (int i = 0; i < E; ++i) v[i] = vn[i];
         }
         return;
     }
@@ -235,7 +240,7 @@ glv_frame_kernel(const FrameArgs a) {
         asm volatile("" : "+v"(tid));
         const bool active = base + slot < a.units;
         const uint32_t row = row_of(base);
-        cf v[16];
+        cf v[E];
         if constexpr (S16) {
             typename FR::Raw raw;
             FR::template load_pcm<RING>(raw, pcm_ptr(row), tid, a.rot);
@@ -252,17 +257,18 @@ glv_frame_kernel(const FrameArgs a) {
     }
 }
 
-template <int LOG_NN, int SLOTS, int NBUF, bool WINLDS>
+template <int LOG_NN, int LOG_E, int SLOTS, int NBUF, bool WINLDS>
 constexpr size_t frame_lds_bytes() {
-    return (size_t) SLOTS * NBUF * Frame<LOG_NN>::XREGION * sizeof(cf) + (WINLDS ? (size_t) Frame<LOG_NN>::N * sizeof(double) : 0)
+    return (size_t) SLOTS * NBUF * Frame<LOG_NN, LOG_E>::XREGION * sizeof(cf) + (WINLDS ? (size_t) Frame<LOG_NN, LOG_E>::N * sizeof(double) : 0)
            + kLogTabSize * sizeof(LogEntry);
 }
 
-template <int LOG_NN, int IN_MODE, int LOG_MODE, int SLOTS, int NBUF, bool TWREG, bool WINLDS, int OCC, bool PREFETCH, bool TILTREG>
+template <int LOG_NN, int IN_MODE, int LOG_MODE, int SLOTS, int NBUF, bool TWREG, bool WINLDS, int OCC, bool PREFETCH, bool TILTREG,
+          int LOG_E = 4>
 hipError_t launch_variant(const FrameArgs& a, int grid, hipStream_t st) {
-    using FR = Frame<LOG_NN>;
-    auto k = glv_frame_kernel<LOG_NN, IN_MODE, LOG_MODE, SLOTS, NBUF, TWREG, WINLDS, OCC, PREFETCH, TILTREG>;
-    constexpr size_t lds = frame_lds_bytes<LOG_NN, SLOTS, NBUF, WINLDS>();
+    using FR = Frame<LOG_NN, LOG_E>;
+    auto k = glv_frame_kernel<LOG_NN, IN_MODE, LOG_MODE, SLOTS, NBUF, TWREG, WINLDS, OCC, PREFETCH, TILTREG, LOG_E>;
+    constexpr size_t lds = frame_lds_bytes<LOG_NN, LOG_E, SLOTS, NBUF, WINLDS>();
     static_assert(lds <= 160 * 1024, "exchange regions + window exceed the 160 KiB LDS of a gfx950 CU");
     if (lds > 64 * 1024) {
         static bool attr_done = false;   // per instantiation

@@ -62,10 +62,14 @@ inline void make_twiddles(cf* table, size_t nn) {
 }
 
 // render.c:845 per-bin tilt factors, evaluated with the reference's float operations.
-inline void make_tilt(float* t, size_t n, float fft_scale, float fft_cutoff) {
+// fold_ln2_3: log_mode 1 only -- the table carries tilt * (ln2/3) so the kernel multiplies log2(y) once.
+inline void make_tilt(float* t, size_t n, float fft_scale, float fft_cutoff, bool fold_ln2_3 = false) {
     const float inv_n = 1.0f / (float) n;              // n is a power of two: exact
     const float omc = 1.0F - fft_cutoff;
-    for (size_t i = 0; i < n; ++i) t[i] = tilt((int) i, inv_n, fft_scale, omc);
+    for (size_t i = 0; i < n; ++i) {
+        const float tl = tilt((int) i, inv_n, fft_scale, omc);
+        t[i] = fold_ln2_3 ? (float) ((double) tl * (0.69314718055994530942 / 3.0)) : tl;
+    }
 }
 
 // transform_smooth window bounds (render.c:699-707): they depend only on the output index t.

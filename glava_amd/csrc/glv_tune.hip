@@ -20,16 +20,17 @@ struct Variant {
     int slots;
 };
 
-template <int SLOTS, int NBUF, bool TWREG, bool WINLDS, int OCC, bool PF = false, bool TL = false>
+template <int SLOTS, int NBUF, bool TWREG, bool WINLDS, int OCC, bool PF = false, bool TL = false, int LE = 4>
 hipError_t launch_v(int in_mode, int log_mode, const FrameArgs& a, int grid, hipStream_t st) {
     constexpr int K = GLV_TUNE_LOG_NN;
     if (in_mode != IN_S16_STEREO) return hipErrorInvalidValue;
-    if (log_mode == 0) return launch_variant<K, IN_S16_STEREO, 0, SLOTS, NBUF, TWREG, WINLDS, OCC, PF, TL>(a, grid, st);
-    return launch_variant<K, IN_S16_STEREO, 1, SLOTS, NBUF, TWREG, WINLDS, OCC, PF, TL>(a, grid, st);
+    if (log_mode == 0) return launch_variant<K, IN_S16_STEREO, 0, SLOTS, NBUF, TWREG, WINLDS, OCC, PF, TL, LE>(a, grid, st);
+    return launch_variant<K, IN_S16_STEREO, 1, SLOTS, NBUF, TWREG, WINLDS, OCC, PF, TL, LE>(a, grid, st);
 }
 
 #define V(S, NB, TR, WL, OC) { "slots=" #S " nbuf=" #NB " twreg=" #TR " winlds=" #WL " occ=" #OC, launch_v<S, NB, TR, WL, OC>, S }
 #define VX(S, NB, TR, WL, OC, PF, TL) { "slots=" #S " nbuf=" #NB " twreg=" #TR " winlds=" #WL " occ=" #OC " pf=" #PF " tiltreg=" #TL, launch_v<S, NB, TR, WL, OC, PF, TL>, S }
+#define VE(S, NB, TR, WL, OC, PF, TL, LE) { "slots=" #S " nbuf=" #NB " twreg=" #TR " winlds=" #WL " occ=" #OC " pf=" #PF " tiltreg=" #TL " log_e=" #LE, launch_v<S, NB, TR, WL, OC, PF, TL, LE>, S }
 #define VP(S, NB, TR, WL, OC) { "slots=" #S " nbuf=" #NB " twreg=" #TR " winlds=" #WL " occ=" #OC " prefetch", launch_v<S, NB, TR, WL, OC, true>, S }
 const Variant kVariants[] = {
 #ifdef GLV_TUNE_VARIANTS
@@ -45,6 +46,7 @@ const Variant kVariants[] = {
 #undef V
 #undef VP
 #undef VX
+#undef VE
 
 }  // namespace
 }  // namespace glv
@@ -68,6 +70,7 @@ int glv_tune_run(int i, const void* d_pcm, float* d_out, unsigned units, int log
     static double* d_win = nullptr;
     static LogEntry* d_log = nullptr;
     static float* d_tilt = nullptr;
+    static float* d_tilt_fast = nullptr;
     constexpr int NN = 1 << GLV_TUNE_LOG_NN, N = 2 * NN;
     if (!d_tw) {
         std::vector<cf> tw(NN);
@@ -86,10 +89,13 @@ int glv_tune_run(int i, const void* d_pcm, float* d_out, unsigned units, int log
         make_tilt(tl.data(), N, 10.2f, 0.3f);
         if (hipMalloc(&d_tilt, sizeof(float) * N) != hipSuccess) return -1;
         (void) hipMemcpy(d_tilt, tl.data(), sizeof(float) * N, hipMemcpyHostToDevice);
+        make_tilt(tl.data(), N, 10.2f, 0.3f, true);
+        if (hipMalloc(&d_tilt_fast, sizeof(float) * N) != hipSuccess) return -1;
+        (void) hipMemcpy(d_tilt_fast, tl.data(), sizeof(float) * N, hipMemcpyHostToDevice);
     }
     FrameArgs a;
     std::memset(&a, 0, sizeof(a));
-    a.in = d_pcm; a.out = d_out; a.tw = d_tw; a.win = d_win; a.logtab = d_log; a.tilt = d_tilt; a.units = units * 2; a.ops = OP_FFT;
+    a.in = d_pcm; a.out = d_out; a.tw = d_tw; a.win = d_win; a.logtab = d_log; a.tilt = log_mode == 1 ? d_tilt_fast : d_tilt; a.units = units * 2; a.ops = OP_FFT;
     a.F = 1; a.inv_n = 1.0f / (float) N; a.fft_scale = 10.2f; a.one_minus_cutoff = 1.0f - 0.3f;
     a.g = 4.2f * (1.0f / 86.1328125f); a.F_as_float = 1.0f;
     hipStream_t st = (hipStream_t) stream;

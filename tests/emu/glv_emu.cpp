@@ -17,12 +17,12 @@
 
 using namespace glv;
 
-template <int LOG_NN, int LOG_MODE>
+template <int LOG_NN, int LOG_MODE, int LOG_E>
 struct Emu {
-    using FR = Frame<LOG_NN>;
+    using FR = Frame<LOG_NN, LOG_E>;
     static constexpr int T = FR::T, P = FR::P, NN = FR::NN, N = FR::N;
 
-    struct Thread { cf v[16]; };
+    struct Thread { cf v[FR::E]; };
 
     template <int PASS>
     static void run_pass(std::vector<Thread>& th, std::vector<cf>& lds, const cf* table) {
@@ -81,9 +81,9 @@ struct Emu {
     }
 };
 
-template <int LOG_NN, int LOG_MODE>
+template <int LOG_NN, int LOG_MODE, int LOG_E>
 static void run_units(int in_mode, const FrameArgs& a) {
-    using EM = Emu<LOG_NN, LOG_MODE>;
+    using EM = Emu<LOG_NN, LOG_MODE, LOG_E>;
     for (uint32_t u = 0; u < a.units; ++u) {
         if (in_mode == IN_S16_STEREO) EM::row_s16((const int16_t*) a.in + (size_t) (u >> 1) * 2 * EM::N, u, a);
         else if (in_mode == IN_F32_STEREO) EM::row_f32_stereo((const float*) a.in + (size_t) (u >> 1) * 2 * EM::N, u, a);
@@ -91,15 +91,15 @@ static void run_units(int in_mode, const FrameArgs& a) {
     }
 }
 
-template <int LOG_MODE>
+template <int LOG_MODE, int LOG_E>
 static int dispatch(int log_nn, int in_mode, const FrameArgs& a) {
     switch (log_nn) {
-        case 8:  run_units<8, LOG_MODE>(in_mode, a); return 0;
-        case 9:  run_units<9, LOG_MODE>(in_mode, a); return 0;
-        case 10: run_units<10, LOG_MODE>(in_mode, a); return 0;
-        case 11: run_units<11, LOG_MODE>(in_mode, a); return 0;
-        case 12: run_units<12, LOG_MODE>(in_mode, a); return 0;
-        case 13: run_units<13, LOG_MODE>(in_mode, a); return 0;
+        case 8:  run_units<8, LOG_MODE, LOG_E>(in_mode, a); return 0;
+        case 9:  run_units<9, LOG_MODE, LOG_E>(in_mode, a); return 0;
+        case 10: run_units<10, LOG_MODE, LOG_E>(in_mode, a); return 0;
+        case 11: run_units<11, LOG_MODE, LOG_E>(in_mode, a); return 0;
+        case 12: run_units<12, LOG_MODE, LOG_E>(in_mode, a); return 0;
+        case 13: run_units<13, LOG_MODE, LOG_E>(in_mode, a); return 0;
     }
     return 1;
 }
@@ -112,7 +112,7 @@ extern "C" {
 int glvemu_process(int n, int in_mode, const void* in, float* out, float* grav, float* hist,
                    unsigned units, unsigned ops, unsigned F, unsigned head, int mono, int avg_window,
                    int avg_kind, int log_mode, float fft_scale, float fft_cutoff, float gravity_step, float ur,
-                   unsigned rot) {
+                   unsigned rot, int log_e) {
     int log_nn = 0;
     while ((2 << log_nn) < n) ++log_nn;
     if ((2 << log_nn) != n) return 2;
@@ -124,7 +124,7 @@ int glvemu_process(int n, int in_mode, const void* in, float* out, float* grav, 
     LogEntry lt[kLogTabSize];
     make_log_table(lt);
     std::vector<float> tl(n);
-    make_tilt(tl.data(), n, fft_scale, fft_cutoff);
+    make_tilt(tl.data(), n, fft_scale, fft_cutoff, log_mode == 1);
     FrameArgs a;
     std::memset(&a, 0, sizeof(a));
     a.in = in; a.out = out; a.grav = grav; a.hist = hist; a.tw = tw.data(); a.win = win.data(); a.logtab = lt; a.tilt = tl.data();
@@ -133,7 +133,8 @@ int glvemu_process(int n, int in_mode, const void* in, float* out, float* grav, 
     a.g = gravity_step * (1.0f / ur); a.F_as_float = (float) F;
     if (F > 16) return 3;
     make_frame_weights(a.wts, F, avg_window != 0, avg_kind);
-    return log_mode == 0 ? dispatch<0>(log_nn, in_mode, a) : log_mode == 1 ? dispatch<1>(log_nn, in_mode, a) : dispatch<2>(log_nn, in_mode, a);
+    if (log_e == 3) return log_mode == 0 ? dispatch<0, 3>(log_nn, in_mode, a) : log_mode == 1 ? dispatch<1, 3>(log_nn, in_mode, a) : dispatch<2, 3>(log_nn, in_mode, a);
+    return log_mode == 0 ? dispatch<0, 4>(log_nn, in_mode, a) : log_mode == 1 ? dispatch<1, 4>(log_nn, in_mode, a) : dispatch<2, 4>(log_nn, in_mode, a);
 }
 
 }  // extern "C"

@@ -6,12 +6,12 @@ import numpy as np
 
 def emu_process(L, n, data, units, ops, grav=None, hist=None, F=5, head=0, mono=0, avg_window=1,
                 avg_kind=0, log_mode=0, in_mode=0, fft_scale=10.2, fft_cutoff=0.3, gravity_step=4.2,
-                ur=86.1328125, rot=0):
+                ur=86.1328125, rot=0, log_e=4):
     rows = units * (2 if in_mode in (0, 3) else 1)      # `units` = stereo frames (s16 / f32 interleaved) or rows (f32 planar)
     out = np.zeros((rows, n), np.float32)
     vp = lambda a: a.ctypes.data_as(C.c_void_p) if a is not None else None  # noqa: E731
     rc = L.glvemu_process(n, in_mode, vp(data), vp(out), vp(grav), vp(hist), rows, ops, F, head, mono,
                           avg_window, avg_kind, log_mode, C.c_float(fft_scale), C.c_float(fft_cutoff),
-                          C.c_float(gravity_step), C.c_float(ur), rot)
+                          C.c_float(gravity_step), C.c_float(ur), rot, log_e)
     assert rc == 0, rc
     return out

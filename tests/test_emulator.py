@@ -15,12 +15,14 @@ def bits(a):
     return np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)
 
 
+@pytest.mark.parametrize("log_e", [4, 3])
 @pytest.mark.parametrize("n", [512, 1024, 2048, 4096, 8192, 16384])
-def test_fft_raw_and_magnitude_bit_exact(emu, oracle, n):
+def test_fft_raw_and_magnitude_bit_exact(emu, oracle, n, log_e):
+    """every size, both lane footprints (E = 16 and E = 8 points per lane: different pass plans)"""
     units = 2
     pcm = lcg_pcm_fast(1000 + n, units * 2 * n)
-    raw = emu_process(emu, n, pcm, units, OP_FFT | OP_RAW)
-    mag = emu_process(emu, n, pcm, units, OP_FFT)
+    raw = emu_process(emu, n, pcm, units, OP_FFT | OP_RAW, log_e=log_e)
+    mag = emu_process(emu, n, pcm, units, OP_FFT, log_e=log_e)
     for u in range(units):
         o, r = StreamOracle(n, gravity=False, average=False).frame(pcm[u * 2 * n:(u + 1) * 2 * n], want_raw=True)
         assert (bits(r) == bits(raw[2 * u:2 * u + 2])).all()

@@ -96,6 +96,7 @@ def main() -> None:
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-alt", action="store_true", help="skip the secondary fast-log measurement")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
+    ap.add_argument("--spinup-s", type=float, default=0.3, help="untimed clock spin-up before the W warm-up steps")
     a = ap.parse_args()
 
     import torch
@@ -108,10 +109,17 @@ def main() -> None:
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
-    torch.cuda.set_device(local_rank)
+    ndev = torch.cuda.device_count()
+    device = local_rank % ndev          # one rank per GPU in production; the modulo only matters for the
+    torch.cuda.set_device(device)       # single-GPU rehearsal of the N>1 code path (GLV_BENCH_BACKEND=gloo)
+    backend = os.environ.get("GLV_BENCH_BACKEND", "nccl")      # "nccl" is RCCL over xGMI on ROCm
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))   # nccl == RCCL on ROCm
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", device))
+        else:
+            dist.init_process_group(backend)
+    coll_dev = torch.device("cuda", device) if backend == "nccl" else torch.device("cpu")
 
     from glava_amd import build as B
     if rank == 0:
@@ -130,11 +138,11 @@ def main() -> None:
     assert hi - lo == streams
 
     params = G.Params(n=n, log_mode=a.log_mode)
-    batch = G.Batch(params, streams, ops, device=local_rank)
+    batch = G.Batch(params, streams, ops, device=device)
     if a.grid: batch.set_grid(a.grid)
     alt_batch = None
     if a.log_mode == 0 and not a.no_alt:       # secondary measurement: the fast-log variant of the same pass
-        alt_batch = G.Batch(G.Params(n=n, log_mode=1), streams, ops, device=local_rank)
+        alt_batch = G.Batch(G.Params(n=n, log_mode=1), streams, ops, device=device)
         if a.grid: alt_batch.set_grid(a.grid)
     gen = torch.Generator(device="cuda"); gen.manual_seed(12345 + rank)
     d_pcm = torch.randint(-32768, 32768, (streams, n, 2), dtype=torch.int16, device="cuda", generator=gen)
@@ -142,7 +150,16 @@ def main() -> None:
     stream = torch.cuda.current_stream().cuda_stream
 
     def timed(b):
-        """W warm-up steps, then exactly K steps bracketed by barrier + synchronize on both sides."""
+        """Spin-up, W warm-up steps, then exactly K steps bracketed by barrier + synchronize on both sides.
+
+        The spin-up (same launches, untimed, `--spinup-s` seconds of wall clock) brings the GPU to its
+        sustained clock/power state: the first few dozen launches after idle run ~20 % slower on MI355X
+        (ms/step 1.27 at K=3 vs 1.04 at K=50 without it), which would make `value` depend on K."""
+        t_end = time.perf_counter() + a.spinup_s
+        while time.perf_counter() < t_end:
+            for _ in range(8):
+                b.process_s16(d_pcm, d_out, ops, stream)
+            torch.cuda.synchronize()
         for _ in range(a.warmup):
             b.process_s16(d_pcm, d_out, ops, stream)
         torch.cuda.synchronize()
@@ -158,7 +175,7 @@ def main() -> None:
         dt = time.perf_counter() - t0
         kms, nl = b.timing_end()
         if world > 1:
-            t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+            t = torch.tensor([dt], dtype=torch.float64, device=coll_dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t.item())
         return dt, kms, nl
@@ -183,7 +200,7 @@ def main() -> None:
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{world} MI355X, {streams} batched stereo streams per GPU, N={n} "
                                    f"{'Hann(-like) window+FFT+magnitude' if ops == G.OP_FFT else a.ops}",
-                       "streams_per_gpu": streams, "n": n, "ops": a.ops, "log_mode": a.log_mode,
+                       "streams_per_gpu": streams, "n": n, "ops": a.ops, "log_mode": a.log_mode, "spinup_s": a.spinup_s,
                        "input": "int16 [streams][n][2] resident in HBM", "kernel": batch.kernel_name()},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(n, streams, a.ops),

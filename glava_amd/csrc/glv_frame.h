@@ -308,12 +308,14 @@ struct Frame {
         auto value = [&](int gi, int r) -> cf {
             const int q = out_index<P - 1>(tid, gi, r);     // = tid*NG + compile-time constant
             cf val = v[gi * PI::R + r];
+#if !defined(GLV_EXP_NOCOMPUTE)
             if constexpr (EPI == EPI_MAG || EPI == EPI_MAG_STATE) {
                 const float y0 = __builtin_fabsf(val.x) + 1.0f, y1 = __builtin_fabsf(val.y) + 1.0f;   // render.c:843-844
                 const cf tl = TILTREG ? tl_reg[gi * PI::R + r] : ld<cf>(a.tilt, (uint32_t) q * 8u);        // :845 factors
                 val.x = log_third<LOG_MODE>(y0, logtab) * tl.x;
                 val.y = log_third<LOG_MODE>(y1, logtab) * tl.y;
             }
+#endif
             if constexpr (EPI == EPI_MAG_STATE || EPI == EPI_RAW_STATE) val = apply_state(val, (uint32_t) q * 8u, row, (uint32_t) N, a);
             return val;
         };

@@ -54,6 +54,11 @@ hipError_t GLV_CAT(launch_frame_, GLV_LOG_NN)(int in_mode, int log_mode, const F
     return hipErrorInvalidValue;
 }
 
-int GLV_CAT(frame_slots_, GLV_LOG_NN)() { return Tuned<GLV_LOG_NN>::slots == 1 ? 2 : Tuned<GLV_LOG_NN>::slots; }
+// channel rows one workgroup takes per trip of its persistent loop (grid sizing): a pipelined s16 slot
+// takes a whole frame (2 rows), a single-slot workgroup takes both rows of its frame in sequence
+int GLV_CAT(frame_slots_, GLV_LOG_NN)() {
+    using TU = Tuned<GLV_LOG_NN>;
+    return (TU::prefetch || TU::slots == 1) ? 2 * TU::slots : TU::slots;
+}
 
 }  // namespace glv

@@ -80,15 +80,22 @@ struct Body {
         // pass 0's twiddles are the same for every lane (k0 = 0); the kernel gathers them once, before
         // the row loop, into scalar registers (gather_uniform_tw0) -- a vector load here would sit in
         // front of every row's first butterfly AND, vmcnt being in-order, behind the PCM prefetch.
+#if defined(GLV_EXP_NOCOMPUTE)        /* tools/tune.py timing experiment only: memory traffic without the transform */
+        return;
+#endif
         FR::template compute<PASS>(v, tw_ref<PASS>(tw_all));
         if constexpr (PASS + 1 < P) {
             char* xb = xslot + (NBUF == 2 ? (size_t) (xcount & 1u) * FR::XREGION * sizeof(cf) : 0);
             GLV_SCHED_FENCE();
+#if !defined(GLV_EXP_NOBARRIER)      /* tools/tune.py timing experiment only: wrong results without the barriers */
             if constexpr (NBUF == 1) __syncthreads();   // previous readers of the region are done
+#endif
             FR::template exchange_write<PASS>(xb, v, tid);
             // the next pass's per-lane twiddles travel from L2 while the exchange settles
             if constexpr (!TWREG) FR::template gather_tw<PASS + 1>(tw_ref<PASS + 1>(tw_all), table, tid);
+#if !defined(GLV_EXP_NOBARRIER)
             __syncthreads();
+#endif
             FR::template exchange_read<PASS + 1>(v, xb, tid);
             GLV_SCHED_FENCE();
             ++xcount;
@@ -180,49 +187,56 @@ glv_frame_kernel(const FrameArgs a) {
     };
     const int tid_outer = tid;
     if constexpr (S16 && PREFETCH) {
-        // Software pipeline over rows (one iteration = one row k of this slot):
-        //   A  issue the PCM loads of row k+1                (HBM latency starts here)
-        //   B  all FFT passes of row k                       (registers/LDS only: ~2 us of cover)
-        //   C  unpack + window row k+1 into a second register set (first use of A's data)
-        //   D  epilogue of row k: log/tilt/state + spectrum stores
-        // The only vector-memory wait (C) finds A's loads AND the previous iteration's stores a
-        // full transform old.  gfx9-class targets count loads and stores on one counter (vmcnt),
-        // and a wait with both kinds pending drains everything -- so a row must never need fresh
-        // load data right after its predecessor's stores were issued.
+        // Software pipeline, one slot = one FRAME at a time, its two channel rows back to back:
+        //   iteration r = 2*m + ch   (m-th frame of this slot, channel ch)
+        //   A  ch == 1 only: issue the PCM loads of the slot's NEXT frame (the current frame's
+        //      samples were fully consumed by the previous iteration's C)     <- HBM latency starts here
+        //   B  all FFT passes of row r                         (registers/LDS only: ~2 us of cover)
+        //   C  unpack + window row r+1 into a second register set (ch == 0: right channel of the same
+        //      frame, still in `raw`; ch == 1: left channel of the next frame = first use of A's data)
+        //   D  epilogue of row r: log/tilt/state + spectrum stores
+        // Every frame's PCM is loaded exactly once by exactly one slot (16 x 8 B per lane per FRAME).
+        // The only vector-memory wait (C) finds A's loads AND the previous iteration's stores a full
+        // transform old.  gfx9-class targets count loads and stores on one counter (vmcnt), and a
+        // wait with both kinds pending drains everything -- so a row must never need fresh load
+        // data right after its predecessor's stores were issued.
+        const uint32_t nframes = a.units / 2;
+        const uint32_t fstride = gridDim.x * SLOTS;
+        const uint32_t nfs = nframes == 0 ? 0 : (nframes - 1) / fstride + 1;           // frame steps, uniform upper bound
+        auto frame_of = [&](uint32_t m) -> uint32_t {                                   // clamped: idle slots redo the last frame
+            const uint32_t f = blockIdx.x * SLOTS + m * fstride + slot;
+            return f < nframes ? f : nframes - 1;
+        };
+        auto frame_ptr = [&](uint32_t f) -> const void* { return static_cast<const char*>(a.in) + (size_t) f * ((size_t) N * 4); };
         cf v[E], vn[E];
         typename FR::Raw raw;
-        if (step_base(0) < a.units) {
+        if (blockIdx.x * SLOTS < nframes) {
             int tid = tid_outer;
             asm volatile("" : "+v"(tid));
-            const uint32_t row0 = row_of(step_base(0));
-            FR::template load_pcm<RING>(raw, pcm_ptr(row0), tid, a.rot);
-            FR::unpack_window(v, raw, win, tid, row0 & 1u, a.mono != 0);
+            FR::template load_pcm<RING>(raw, frame_ptr(frame_of(0)), tid, a.rot);
+            FR::unpack_window(v, raw, win, tid, 0u, a.mono != 0);
         }
-        // Every load issued so far (resident twiddles, tilt factors, first row) must have landed
+        // Every load issued so far (resident twiddles, tilt factors, first frame) must have landed
         // before the loop: otherwise the backend's wait-count model carries "N loads may still be
         // pending behind this register" around the back edge and, vmcnt being one in-order
         // counter, turns the first use of each resident register into a partial drain of the PCM
         // prefetch in the middle of a row.  (s_waitcnt vmcnt(0); expcnt/lgkmcnt untouched.)
         __builtin_amdgcn_s_waitcnt(0x0F70);
-        for (uint32_t step = 0; step < nsteps; ++step) {
-            const uint32_t base = step_base(step);
-            if (base >= a.units) break;                          // uniform for the workgroup
+        for (uint32_t r = 0; r < 2 * nfs; ++r) {
+            const uint32_t m = r >> 1, ch = r & 1u;
+            if (blockIdx.x * SLOTS + m * fstride >= nframes) break;                     // uniform for the workgroup
             int tid = tid_outer;
             asm volatile("" : "+v"(tid));                        // see the note on LICM below
-            const bool active = base + slot < a.units;
-            const uint32_t row = row_of(base);
-            const uint32_t nb = step_base(step + 1);
-            const bool has_next = step + 1 < nsteps && nb < a.units;
-            const uint32_t row_n = row_of(has_next ? nb : base);
-            // A and C run unconditionally (the last iteration re-reads its own row and discards it): a
-            // branch here would make "were A's loads consumed?" path dependent for the wait-count pass
-            FR::template load_pcm<RING>(raw, pcm_ptr(row_n), tid, a.rot);                        // A
+            const uint32_t fraw = blockIdx.x * SLOTS + m * fstride + slot;
+            const bool active = fraw < nframes;
+            const uint32_t f = frame_of(m);
+            if (ch) FR::template load_pcm<RING>(raw, frame_ptr(frame_of(m + 1)), tid, a.rot);   // A (clamped past the end)
             GLV_SCHED_FENCE();
             BD::template run<0>(v, tw_all, a.tw, xslot, tid, xcount);                            // B
             GLV_SCHED_FENCE();
-            FR::unpack_window(vn, raw, win, tid, row_n & 1u, a.mono != 0);                       // C
+            FR::unpack_window(vn, raw, win, tid, ch ^ 1u, a.mono != 0);                          // C
             GLV_SCHED_FENCE();
-            if (active) finish(v, (size_t) row, tid);                                            // D
+            if (active) finish(v, (size_t) f * 2 + ch, tid);                                     // D
             // (swapping the roles of v/vn by unrolling twice doubles the loop body and pushed the fp64-log
             //  variant into heavy spilling; 32 v_mov per row are the cheaper price)
 #pragma unroll

@@ -100,8 +100,8 @@ int glv_tune_run(int i, const void* d_pcm, float* d_out, unsigned units, int log
     a.g = 4.2f * (1.0f / 86.1328125f); a.F_as_float = 1.0f;
     hipStream_t st = (hipStream_t) stream;
     if (grid <= 0) {
-        const unsigned slots = (unsigned) (kVariants[i].slots == 1 ? 2 : kVariants[i].slots);
-        const unsigned wgs = (units * 2 + slots - 1) / slots;
+        const unsigned slots = (unsigned) kVariants[i].slots;          // >= one frame per slot per trip
+        const unsigned wgs = (units + slots - 1) / slots;
         grid = (int) (wgs < 2048u ? wgs : 2048u);
     }
     hipEvent_t e0, e1;

@@ -14,15 +14,15 @@ namespace glv {
 template <int LOG_NN> struct Tuned;
 #define GLV_TUNED(K, LE, S, NB, TR, WL, OC, PF, TL) \
     template <> struct Tuned<K> { static constexpr int log_e = LE, slots = S, nbuf = NB, occ = OC; \
-                                  static constexpr bool twreg = TR, winlds = WL, prefetch = PF, tiltreg = TL; };
+                                  static constexpr bool twreg = TR, winlds = WL, tiltreg = TL; static constexpr int prefetch = PF; };
 // measured best of tools/tune.py on MI355X (profiles/tune_r01.txt), equal bytes per size class:
-//         log2(nn) LOG_E SLOTS NBUF TWREG  WINLDS OCC PREFETCH TILTREG
-GLV_TUNED(8,        3,    16,   1,   true,  true,  4,  true,    true)    // N=512    E=8: 3+3+2
-GLV_TUNED(9,        3,    4,    1,   true,  true,  4,  false,   true)    // N=1024   E=8: 3+3+3
-GLV_TUNED(10,       3,    2,    1,   true,  true,  4,  false,   true)    // N=2048   E=8: 3+3+3+1
-GLV_TUNED(11,       4,    2,    1,   true,  true,  2,  true,    true)    // N=4096   E=16: 4+4+3
-GLV_TUNED(12,       4,    1,    1,   true,  false, 2,  true,    true)    // N=8192   E=16: 4+4+4 (window 64 KiB: via L2)
-GLV_TUNED(13,       4,    1,    1,   true,  false, 2,  true,    true)    // N=16384  E=16: 4+4+4+1 (70 KiB exchange region)
+//         log2(nn) LOG_E SLOTS NBUF TWREG  WINLDS OCC PREFETCH TILTREG      (PREFETCH 1 = frame pipeline, 2 = row pipeline)
+GLV_TUNED(8,        4,    16,   1,   true,  true,  2,  1,       true)    // N=512    E=16: 4+4
+GLV_TUNED(9,        3,    4,    1,   true,  true,  4,  0,       true)    // N=1024   E=8:  3+3+3
+GLV_TUNED(10,       3,    2,    1,   true,  true,  4,  0,       true)    // N=2048   E=8:  3+3+3+1
+GLV_TUNED(11,       4,    2,    1,   true,  true,  2,  1,       true)    // N=4096   E=16: 4+4+3
+GLV_TUNED(12,       4,    1,    1,   true,  false, 2,  2,       true)    // N=8192   E=16: 4+4+4 (window 64 KiB: via L2)
+GLV_TUNED(13,       4,    1,    1,   true,  false, 2,  2,       true)    // N=16384  E=16: 4+4+4+1 (70 KiB exchange region)
 #undef GLV_TUNED
 
 #define GLV_CAT2(a, b) a##b
@@ -54,11 +54,12 @@ hipError_t GLV_CAT(launch_frame_, GLV_LOG_NN)(int in_mode, int log_mode, const F
     return hipErrorInvalidValue;
 }
 
-// channel rows one workgroup takes per trip of its persistent loop (grid sizing): a pipelined s16 slot
-// takes a whole frame (2 rows), a single-slot workgroup takes both rows of its frame in sequence
+// channel rows one workgroup takes per trip of its persistent loop (grid sizing): a pipelined s16
+// slot takes a whole frame (2 rows), a single-slot workgroup both rows of its frame in sequence; for
+// other inputs the figure only makes the grid slightly smaller than strictly necessary.
 int GLV_CAT(frame_slots_, GLV_LOG_NN)() {
     using TU = Tuned<GLV_LOG_NN>;
-    return (TU::prefetch || TU::slots == 1) ? 2 * TU::slots : TU::slots;
+    return (TU::prefetch == 1 || TU::slots == 1) ? 2 * TU::slots : TU::slots;
 }
 
 }  // namespace glv

@@ -25,7 +25,7 @@
 //   WINLDS  true: window table staged once per workgroup into LDS; false: read through L1/L2
 //   OCC     __launch_bounds__ minimum waves per SIMD (caps the VGPR budget: 512 / OCC)
 //   TILTREG   the 32 per-lane tilt factors stay in VGPRs across rows instead of being re-read per row
-//   PREFETCH  s16 input: rows are software-pipelined -- the next row's PCM is loaded before and
+//   PREFETCH  s16 input, 0 off / 1 frame pipeline / 2 row pipeline: rows are software-pipelined -- the next row's PCM is loaded before and
 //           unpacked after the current row's passes, so neither HBM reads nor spectrum stores sit on
 //           a row's critical path (costs a second 32-VGPR point set)
 #pragma once
@@ -111,7 +111,7 @@ static __device__ __forceinline__ uint32_t maybe_scalar(uint32_t v) {
     else return v;
 }
 
-template <int LOG_NN, int IN_MODE, int LOG_MODE, int SLOTS, int NBUF, bool TWREG, bool WINLDS, int OCC, bool PREFETCH, bool TILTREG,
+template <int LOG_NN, int IN_MODE, int LOG_MODE, int SLOTS, int NBUF, bool TWREG, bool WINLDS, int OCC, int PREFETCH, bool TILTREG,
           int LOG_E>
 __global__ void __launch_bounds__((Frame<LOG_NN, LOG_E>::T * SLOTS), OCC)
 glv_frame_kernel(const FrameArgs a) {
@@ -182,11 +182,8 @@ glv_frame_kernel(const FrameArgs a) {
     auto step_base = [&](uint32_t step) -> uint32_t {            // first row of the workgroup's step-th row group
         return blockIdx.x * RPI + (step / SEQ) * stride + (step % SEQ) * SLOTS;
     };
-    auto pcm_ptr = [&](uint32_t row) -> const void* {
-        return static_cast<const char*>(a.in) + (size_t) (row >> 1) * ((size_t) N * 4);
-    };
     const int tid_outer = tid;
-    if constexpr (S16 && PREFETCH) {
+    if constexpr (S16 && PREFETCH == 1) {
         // Software pipeline, one slot = one FRAME at a time, its two channel rows back to back:
         //   iteration r = 2*m + ch   (m-th frame of this slot, channel ch)
         //   A  ch == 1 only: issue the PCM loads of the slot's NEXT frame (the current frame's
@@ -244,6 +241,46 @@ glv_frame_kernel(const FrameArgs a) {
         }
         return;
     }
+    if constexpr (S16 && PREFETCH == 2) {
+        // Software pipeline over ROWS (one slot = one channel row; neighbouring slots share a frame):
+        // like the frame pipeline above, but every row issues the 16 loads of its successor row, so a
+        // frame's PCM is requested twice (second time from L1/L2).  Measured faster than the frame
+        // pipeline for the single-slot workgroups of N >= 8192.
+        auto pcm_ptr = [&](uint32_t row) -> const void* {
+            return static_cast<const char*>(a.in) + (size_t) (row >> 1) * ((size_t) N * 4);
+        };
+        cf v[E], vn[E];
+        typename FR::Raw raw;
+        if (step_base(0) < a.units) {
+            int tid = tid_outer;
+            asm volatile("" : "+v"(tid));
+            const uint32_t row0 = row_of(step_base(0));
+            FR::template load_pcm<RING>(raw, pcm_ptr(row0), tid, a.rot);
+            FR::unpack_window(v, raw, win, tid, row0 & 1u, a.mono != 0);
+        }
+        __builtin_amdgcn_s_waitcnt(0x0F70);                      // vmcnt(0): see the frame pipeline
+        for (uint32_t step = 0; step < nsteps; ++step) {
+            const uint32_t base = step_base(step);
+            if (base >= a.units) break;                          // uniform for the workgroup
+            int tid = tid_outer;
+            asm volatile("" : "+v"(tid));
+            const bool active = base + slot < a.units;
+            const uint32_t row = row_of(base);
+            const uint32_t nb = step_base(step + 1);
+            const bool has_next = step + 1 < nsteps && nb < a.units;
+            const uint32_t row_n = row_of(has_next ? nb : base);
+            FR::template load_pcm<RING>(raw, pcm_ptr(row_n), tid, a.rot);                        // A (unconditional)
+            GLV_SCHED_FENCE();
+            BD::template run<0>(v, tw_all, a.tw, xslot, tid, xcount);                            // B
+            GLV_SCHED_FENCE();
+            FR::unpack_window(vn, raw, win, tid, row_n & 1u, a.mono != 0);                       // C
+            GLV_SCHED_FENCE();
+            if (active) finish(v, (size_t) row, tid);                                            // D
+#pragma unroll
+            for (int i = 0; i < E; ++i) v[i] = vn[i];
+        }
+        return;
+    }
     for (uint32_t step = 0; step < nsteps; ++step) {
         const uint32_t base = step_base(step);
         if (base >= a.units) break;                              // uniform for the workgroup
@@ -256,8 +293,11 @@ glv_frame_kernel(const FrameArgs a) {
         const uint32_t row = row_of(base);
         cf v[E];
         if constexpr (S16) {
+            // not pipelined: one slot = one channel row; the two channels of a frame sit in neighbouring
+            // slots (the second reader of the frame's PCM hits L1/L2).  Measured faster than keeping the
+            // samples in registers across two sequential rows of one slot.
             typename FR::Raw raw;
-            FR::template load_pcm<RING>(raw, pcm_ptr(row), tid, a.rot);
+            FR::template load_pcm<RING>(raw, static_cast<const char*>(a.in) + (size_t) (row >> 1) * ((size_t) N * 4), tid, a.rot);
             GLV_SCHED_FENCE();
             FR::unpack_window(v, raw, win, tid, row & 1u, a.mono != 0);
         } else if constexpr (IN_MODE == IN_F32_STEREO) {
@@ -277,7 +317,7 @@ constexpr size_t frame_lds_bytes() {
            + kLogTabSize * sizeof(LogEntry);
 }
 
-template <int LOG_NN, int IN_MODE, int LOG_MODE, int SLOTS, int NBUF, bool TWREG, bool WINLDS, int OCC, bool PREFETCH, bool TILTREG,
+template <int LOG_NN, int IN_MODE, int LOG_MODE, int SLOTS, int NBUF, bool TWREG, bool WINLDS, int OCC, int PREFETCH, bool TILTREG,
           int LOG_E = 4>
 hipError_t launch_variant(const FrameArgs& a, int grid, hipStream_t st) {
     using FR = Frame<LOG_NN, LOG_E>;

@@ -20,7 +20,7 @@ struct Variant {
     int slots;
 };
 
-template <int SLOTS, int NBUF, bool TWREG, bool WINLDS, int OCC, bool PF = false, bool TL = false, int LE = 4>
+template <int SLOTS, int NBUF, bool TWREG, bool WINLDS, int OCC, int PF = 0, bool TL = false, int LE = 4>
 hipError_t launch_v(int in_mode, int log_mode, const FrameArgs& a, int grid, hipStream_t st) {
     constexpr int K = GLV_TUNE_LOG_NN;
     if (in_mode != IN_S16_STEREO) return hipErrorInvalidValue;
@@ -100,8 +100,8 @@ int glv_tune_run(int i, const void* d_pcm, float* d_out, unsigned units, int log
     a.g = 4.2f * (1.0f / 86.1328125f); a.F_as_float = 1.0f;
     hipStream_t st = (hipStream_t) stream;
     if (grid <= 0) {
-        const unsigned slots = (unsigned) kVariants[i].slots;          // >= one frame per slot per trip
-        const unsigned wgs = (units + slots - 1) / slots;
+        const unsigned slots = (unsigned) kVariants[i].slots;          // at most one frame per slot per trip
+        const unsigned wgs = (units * 2 + slots - 1) / slots;
         grid = (int) (wgs < 2048u ? wgs : 2048u);
     }
     hipEvent_t e0, e1;

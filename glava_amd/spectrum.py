@@ -45,6 +45,14 @@ def lib() -> C.CDLL:
         if not os.path.exists(LIB_PATH):
             raise GlvError(ERR_NO_DEVICE, f"{LIB_PATH} not built -- run `python -m glava_amd.build` "
                                           "(there is no Python/CPU fallback)")
+        # One HIP runtime per process: PyTorch bundles its own libamdhip64 with the same soname as
+        # /opt/rocm's.  Whichever is loaded first wins for everybody, and torch.cuda only comes up on
+        # its own copy -- so make sure torch (when installed) is imported before our library pulls in
+        # the system one.  This is process plumbing, not a dependency: the C ABI itself is torch-free.
+        try:
+            import torch  # noqa: F401
+        except Exception:
+            pass
         L = C.CDLL(LIB_PATH)
         P = C.POINTER(CParams)
         vp = C.c_void_p

@@ -182,6 +182,22 @@ def main() -> None:
 
     elapsed, kernel_ms, launches = timed(batch)
     alt = timed(alt_batch) if alt_batch is not None else None
+    # tertiary measurement (N=1 only): the chain GLava's spectrum modules actually request --
+    # window,fft,gravity,avg (bars/1.frag:12-24) -- i.e. the same pass + gravity + F=5 windowed average
+    chain = None
+    if world == 1 and ops == G.OP_FFT and not a.no_alt:
+        if alt_batch is not None: alt_batch.close(); alt_batch = None
+        cops = G.OP_FFT | G.OP_GRAVITY | G.OP_AVERAGE
+        cb = G.Batch(params, streams, cops, device=device)
+        ops_saved, ops = ops, cops
+        c_el, c_kms, c_nl = timed(cb)
+        ops = ops_saved
+        c_k = (c_kms / max(c_nl, 1)) * 1e-3
+        c_bytes = cb.algorithmic_bytes(cops)
+        chain = {"note": "fft -> gravity -> average(F=5, windowed), fp64 log; algorithmic bytes 52*N per frame (SURVEY 8d row C)",
+                 "value": streams * a.steps / c_el, "unit": "frames/s", "ms_per_step": c_el / a.steps * 1e3,
+                 "avg_kernel_ms": c_k * 1e3, "roofline_frac": (c_bytes / c_k / 1e9) / HBM_PEAK_GBS if c_k > 0 else 0.0}
+        cb.close()
 
     frames_rank = streams * a.steps
     stats = gather_stats({"frames": frames_rank, "seconds": elapsed, "kernel_ms": kernel_ms,
@@ -214,6 +230,8 @@ def main() -> None:
                                 "value": streams * world * a.steps / a_el, "unit": "frames/s",
                                 "ms_per_step": a_el / a.steps * 1e3, "avg_kernel_ms": a_k * 1e3,
                                 "roofline_frac": (alg_bytes / a_k / 1e9) / HBM_PEAK_GBS if a_k > 0 else 0.0}
+        if chain is not None:
+            line["smooth_chain"] = chain
         if world == 1 and not a.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(n, a.cpu_seconds)
         else:

@@ -459,12 +459,13 @@ uint64_t glv_batch_algorithmic_bytes(const glv_batch* b, unsigned ops, int input
     if (!b) return 0;
     // SURVEY.md 8d, per stereo frame with N real samples per channel, F = avg_frames:
     //   in: 4N (s16 x 2ch) or 8N (f32 x 2ch);  out: 8N
-    //   + gravity (no average): read 8N state, write 8N state
+    //   + gravity (no average): 20N in SURVEY 8d row B, which lets the output double as the state; this
+    //     implementation keeps a separate state buffer (one more 8N write) but reports the survey's figure
     //   + average: read (F-1) ring slots 8N each, write the newest slot 8N (doubles as gravity state)
     const uint64_t N = b->p.n, F = b->p.avg_frames;
     uint64_t per = (input_is_s16 ? 4 * N : 8 * N) + 8 * N;
     if (ops & GLV_OP_AVERAGE) per += 8 * N * (F - 1) + 8 * N;
-    else if (ops & GLV_OP_GRAVITY) per += 16 * N;
+    else if (ops & GLV_OP_GRAVITY) per += 8 * N;
     return per * b->streams;
 }
 

@@ -94,6 +94,60 @@ GLV_HD cf apply_state(cf val, uint32_t off, size_t row, uint32_t n, const FrameA
     return val;
 }
 
+// The same state machine for NV values of one lane at once, loads first: for every history slot the
+// NV loads are issued back to back before any of them is consumed, so a lane keeps NV (not 1) HBM
+// requests in flight.  (The one-value form above is load -> wait -> use per slot and per value: fine
+// for glv_post_kernel's one-pair-per-lane grid, latency-bound inside the frame kernel's epilogue.)
+template <int NV>
+GLV_HD void apply_state_block(cf (&val)[NV], const uint32_t (&off)[NV], size_t row, uint32_t n, const FrameArgs& a) {
+    if (a.ops & OP_AVERAGE) {
+        float* h = a.hist + row * (size_t) a.F * n;                          // uniform
+        const uint32_t F = a.F;
+        cf acc[NV], prev[NV];
+#pragma unroll
+        for (int e = 0; e < NV; ++e) { acc[e].x = 0.0f; acc[e].y = 0.0f; prev[e].x = 0.0f; prev[e].y = 0.0f; }
+        if (F == 1) {
+#pragma unroll
+            for (int e = 0; e < NV; ++e) prev[e] = ld<cf>(h + (size_t) a.head * n, off[e]);
+        }
+        for (uint32_t f = 0; f + 1 < F; ++f) {                               // oldest .. second newest
+            const float* hs = h + (size_t) ring_slot(a.head, f, F) * n;      // uniform
+#pragma unroll
+            for (int e = 0; e < NV; ++e) prev[e] = ld<cf>(hs, off[e]);
+            const double w = a.wts[f];
+#pragma unroll
+            for (int e = 0; e < NV; ++e) {
+                if (a.avg_window) {                                          // render.c:759, double product
+                    acc[e].x = (float) ((double) acc[e].x + w * (double) prev[e].x);
+                    acc[e].y = (float) ((double) acc[e].y + w * (double) prev[e].y);
+                } else { acc[e].x = acc[e].x + prev[e].x; acc[e].y = acc[e].y + prev[e].y; }
+            }
+        }
+        const double wl = a.wts[F - 1];
+#pragma unroll
+        for (int e = 0; e < NV; ++e) {
+            if (a.ops & OP_GRAVITY) { val[e].x = gravity(val[e].x, prev[e].x, a.g); val[e].y = gravity(val[e].y, prev[e].y, a.g); }
+            st<cf>(h + (size_t) a.head * n, off[e], val[e]);
+            if (a.avg_window) {
+                acc[e].x = (float) ((double) acc[e].x + wl * (double) val[e].x);
+                acc[e].y = (float) ((double) acc[e].y + wl * (double) val[e].y);
+            } else { acc[e].x = acc[e].x + val[e].x; acc[e].y = acc[e].y + val[e].y; }
+            val[e].x = acc[e].x / a.F_as_float;                              // render.c:761
+            val[e].y = acc[e].y / a.F_as_float;
+        }
+    } else if (a.ops & OP_GRAVITY) {
+        float* gs = a.grav + row * (size_t) n;                               // uniform
+        cf st0[NV];
+#pragma unroll
+        for (int e = 0; e < NV; ++e) st0[e] = ld<cf>(gs, off[e]);
+#pragma unroll
+        for (int e = 0; e < NV; ++e) {
+            val[e].x = gravity(val[e].x, st0[e].x, a.g); val[e].y = gravity(val[e].y, st0[e].y, a.g);
+            st<cf>(gs, off[e], val[e]);
+        }
+    }
+}
+
 template <int LOG_NN, int LOG_E = 4>
 struct Frame {
     using PL = Plan<LOG_NN, LOG_E>;
@@ -305,39 +359,68 @@ struct Frame {
     GLV_HD static void epilogue(const cf (&v)[E], float* out_row, size_t row, int tid, const FrameArgs& a,
                                 const LogEntry* logtab, const cf* tl_reg = nullptr) {
         using PI = PassInfo<P - 1>;
+        constexpr bool STATE = EPI == EPI_MAG_STATE || EPI == EPI_RAW_STATE;
+        // magnitude of register slot (gi, r): abs/log/tilt, or the raw value
         auto value = [&](int gi, int r) -> cf {
-            const int q = out_index<P - 1>(tid, gi, r);     // = tid*NG + compile-time constant
             cf val = v[gi * PI::R + r];
 #if !defined(GLV_EXP_NOCOMPUTE)
             if constexpr (EPI == EPI_MAG || EPI == EPI_MAG_STATE) {
+                const int q = out_index<P - 1>(tid, gi, r);     // = tid*NG + compile-time constant
                 const float y0 = __builtin_fabsf(val.x) + 1.0f, y1 = __builtin_fabsf(val.y) + 1.0f;   // render.c:843-844
                 const cf tl = TILTREG ? tl_reg[gi * PI::R + r] : ld<cf>(a.tilt, (uint32_t) q * 8u);        // :845 factors
                 val.x = log_third<LOG_MODE>(y0, logtab) * tl.x;
                 val.y = log_third<LOG_MODE>(y1, logtab) * tl.y;
             }
 #endif
-            if constexpr (EPI == EPI_MAG_STATE || EPI == EPI_RAW_STATE) val = apply_state(val, (uint32_t) q * 8u, row, (uint32_t) N, a);
             return val;
         };
+        if constexpr (!STATE) {
+            // stateless: value -> store, pair by pair (nothing but the pair in flight)
 #pragma unroll
-        for (int r = 0; r < PI::R; ++r) {
-            if constexpr (PI::NG >= 2) {
-                // the lane's NG groups are adjacent points: 16-byte stores
+            for (int r = 0; r < PI::R; ++r) {
+                if constexpr (PI::NG >= 2) {
 #pragma unroll
-                for (int gi = 0; gi < PI::NG; gi += 2) {
-                    cf2 two;
-                    two.a = value(gi, r);
-                    two.b = value(gi + 1, r);
+                    for (int gi = 0; gi < PI::NG; gi += 2) {             // adjacent groups: 16-byte stores
+                        cf2 two;
+                        two.a = value(gi, r);
+                        two.b = value(gi + 1, r);
 #if defined(GLV_EXP_NOSTORE)   /* tools/tune.py experiment: keep 1 store in 16 (never in product builds) */
-                    if (r == 0 && gi == 0)
+                        if (r == 0 && gi == 0)
 #endif
-                    st<cf2>(out_row, (uint32_t) out_index<P - 1>(tid, gi, r) * 8u, two);
-                }
-            } else {
+                        st<cf2>(out_row, (uint32_t) out_index<P - 1>(tid, gi, r) * 8u, two);
+                    }
+                } else {
 #if defined(GLV_EXP_NOSTORE)
-                if (r == 0)
+                    if (r == 0)
 #endif
-                st<cf>(out_row, (uint32_t) out_index<P - 1>(tid, 0, r) * 8u, value(0, r));
+                    st<cf>(out_row, (uint32_t) out_index<P - 1>(tid, 0, r) * 8u, value(0, r));
+                }
+            }
+        } else {
+            // stateful: the lane's E points in blocks of BLK, loads of a block issued together
+            // (apply_state_block); BLK bounds the registers the history loads need
+            constexpr int BLK = E / 2 > 0 ? E / 2 : 1;
+#pragma unroll
+            for (int h0 = 0; h0 < E; h0 += BLK) {
+                cf val[BLK];
+                uint32_t off[BLK];
+                // enumeration order: r outer, gi inner => adjacent groups sit next to each other in val[]
+#pragma unroll
+                for (int j = 0; j < BLK; ++j) {
+                    const int idx = h0 + j, r = idx / PI::NG, gi = idx % PI::NG;
+                    val[j] = value(gi, r);
+                    off[j] = (uint32_t) out_index<P - 1>(tid, gi, r) * 8u;
+                }
+                apply_state_block<BLK>(val, off, row, (uint32_t) N, a);
+#pragma unroll
+                for (int j = 0; j < BLK; ++j) {
+                    const int gi = (h0 + j) % PI::NG;
+                    if constexpr (PI::NG >= 2) {
+                        if (gi % 2 == 0) { cf2 two; two.a = val[j]; two.b = val[j + 1]; st<cf2>(out_row, off[j], two); }
+                    } else {
+                        st<cf>(out_row, off[j], val[j]);
+                    }
+                }
             }
         }
     }

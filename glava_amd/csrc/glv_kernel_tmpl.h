@@ -112,7 +112,7 @@ static __device__ __forceinline__ uint32_t maybe_scalar(uint32_t v) {
 }
 
 template <int LOG_NN, int IN_MODE, int LOG_MODE, int SLOTS, int NBUF, bool TWREG, bool WINLDS, int OCC, int PREFETCH, bool TILTREG,
-          int LOG_E>
+          int LOG_E, bool STATEFUL>
 __global__ void __launch_bounds__((Frame<LOG_NN, LOG_E>::T * SLOTS), OCC)
 glv_frame_kernel(const FrameArgs a) {
     using FR = Frame<LOG_NN, LOG_E>;
@@ -153,16 +153,19 @@ glv_frame_kernel(const FrameArgs a) {
     cf tilt_reg[TILTREG ? E : 1];
     if constexpr (TILTREG) FR::gather_tilt(tilt_reg, a.tilt, tid);
 
-    // operator chain, uniform for the launch
-    const int epi = (a.ops & (OP_GRAVITY | OP_AVERAGE)) ? ((a.ops & OP_RAW) ? EPI_RAW_STATE : EPI_MAG_STATE)
-                                                        : ((a.ops & OP_RAW) ? EPI_RAW : EPI_MAG);
+    // operator chain, uniform for the launch.  Stateless and stateful chains are separate kernels
+    // (STATEFUL): the history loads of gravity/average need ~60 more VGPRs in the epilogue, and having
+    // them in the same kernel costs the plain FFT+magnitude pass 15-30 % (register allocation is per
+    // kernel, not per path).
+    const bool raw_out = (a.ops & OP_RAW) != 0;
     auto finish = [&](const cf (&v)[E], size_t row, int tid) {
         float* out_row = a.out + row * N;
-        switch (epi) {
-            case EPI_MAG:       FR::template epilogue<LOG_MODE, EPI_MAG, TILTREG>(v, out_row, row, tid, a, logtab, tilt_reg); break;
-            case EPI_MAG_STATE: FR::template epilogue<LOG_MODE, EPI_MAG_STATE, TILTREG>(v, out_row, row, tid, a, logtab, tilt_reg); break;
-            case EPI_RAW:       FR::template epilogue<LOG_MODE, EPI_RAW>(v, out_row, row, tid, a, logtab); break;
-            default:            FR::template epilogue<LOG_MODE, EPI_RAW_STATE>(v, out_row, row, tid, a, logtab); break;
+        if constexpr (STATEFUL) {
+            if (raw_out) FR::template epilogue<LOG_MODE, EPI_RAW_STATE>(v, out_row, row, tid, a, logtab);
+            else FR::template epilogue<LOG_MODE, EPI_MAG_STATE, TILTREG>(v, out_row, row, tid, a, logtab, tilt_reg);
+        } else {
+            if (raw_out) FR::template epilogue<LOG_MODE, EPI_RAW>(v, out_row, row, tid, a, logtab);
+            else FR::template epilogue<LOG_MODE, EPI_MAG, TILTREG>(v, out_row, row, tid, a, logtab, tilt_reg);
         }
     };
     // row handled by this slot in the iteration that starts at `base` (idle slots clamp to the last
@@ -321,20 +324,22 @@ template <int LOG_NN, int IN_MODE, int LOG_MODE, int SLOTS, int NBUF, bool TWREG
           int LOG_E = 4>
 hipError_t launch_variant(const FrameArgs& a, int grid, hipStream_t st) {
     using FR = Frame<LOG_NN, LOG_E>;
-    auto k = glv_frame_kernel<LOG_NN, IN_MODE, LOG_MODE, SLOTS, NBUF, TWREG, WINLDS, OCC, PREFETCH, TILTREG, LOG_E>;
     constexpr size_t lds = frame_lds_bytes<LOG_NN, LOG_E, SLOTS, NBUF, WINLDS>();
     static_assert(lds <= 160 * 1024, "exchange regions + window exceed the 160 KiB LDS of a gfx950 CU");
-    if (lds > 64 * 1024) {
-        static bool attr_done = false;   // per instantiation
-        if (!attr_done) {
+    auto launch = [&](auto k, bool& attr_done) -> hipError_t {
+        if (lds > 64 * 1024 && !attr_done) {
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
             if (e != hipSuccess) return e;
             attr_done = true;
         }
-    }
-    hipLaunchKernelGGL(k, dim3(grid), dim3(FR::T * SLOTS), lds, st, a);
-    return hipGetLastError();
+        hipLaunchKernelGGL(k, dim3(grid), dim3(FR::T * SLOTS), lds, st, a);
+        return hipGetLastError();
+    };
+    static bool done_plain = false, done_state = false;   // per instantiation
+    if (a.ops & (OP_GRAVITY | OP_AVERAGE))
+        return launch(glv_frame_kernel<LOG_NN, IN_MODE, LOG_MODE, SLOTS, NBUF, TWREG, WINLDS, OCC, PREFETCH, TILTREG, LOG_E, true>, done_state);
+    return launch(glv_frame_kernel<LOG_NN, IN_MODE, LOG_MODE, SLOTS, NBUF, TWREG, WINLDS, OCC, PREFETCH, TILTREG, LOG_E, false>, done_plain);
 }
 
 }  // namespace glv

@@ -151,6 +151,9 @@ struct glv_batch {
     int* d_smax = nullptr;
     uint32_t smooth_asz = 0;
     float smooth_d = -1.f, smooth_r = -1.f;
+    glv::BarDesc* d_bar_desc = nullptr;   // GLV_OP_BARS tap tables (host generated)
+    float* d_bar_w = nullptr;
+    uint32_t bar_count = 0; float bar_factor = -1.f;
     // timing
     bool timing = false;
     std::vector<hipEvent_t> ev;  // start/stop pairs
@@ -224,6 +227,22 @@ int ensure_smooth_tables(glv_batch* b) {
     return GLV_OK;
 }
 
+int ensure_bar_tables(glv_batch* b) {
+    if (b->d_bar_desc && b->bar_count == b->p.bars && b->bar_factor == b->p.smooth_factor) return GLV_OK;
+    if (b->p.bars == 0 || b->p.bars > b->p.n) return fail(GLV_ERR_INVALID, "bars=%u out of range", b->p.bars);
+    std::vector<glv::BarDesc> desc;
+    std::vector<float> w;
+    glv::make_bar_taps(desc, w, b->p.n, b->p.bars, b->p.smooth_factor);
+    if (b->d_bar_desc) { (void) hipFree(b->d_bar_desc); b->d_bar_desc = nullptr; }
+    if (b->d_bar_w) { (void) hipFree(b->d_bar_w); b->d_bar_w = nullptr; }
+    HIP_TRY(hipMalloc(&b->d_bar_desc, sizeof(glv::BarDesc) * desc.size()));
+    HIP_TRY(hipMalloc(&b->d_bar_w, sizeof(float) * (w.size() + 1)));
+    HIP_TRY(hipMemcpy(b->d_bar_desc, desc.data(), sizeof(glv::BarDesc) * desc.size(), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(b->d_bar_w, w.data(), sizeof(float) * w.size(), hipMemcpyHostToDevice));
+    b->bar_count = b->p.bars; b->bar_factor = b->p.smooth_factor;
+    return GLV_OK;
+}
+
 // One update of `units` channel rows through the fused kernel (or the post kernel when no FFT is asked).
 int process(glv_batch* b, const void* d_in, int in_mode, float* d_out, unsigned ops, uint32_t units,
             uint32_t rot, hipStream_t st) {
@@ -273,7 +292,8 @@ int process(glv_batch* b, const void* d_in, int in_mode, float* d_out, unsigned 
         if (e != hipSuccess) return fail(GLV_ERR_HIP, "smooth launch failed: %s", hipGetErrorString(e));
     }
     if (ops & GLV_OP_BARS) {
-        e = glv::launch_bars(d_out, d_final, units, b->p.n, b->p.bars, b->p.smooth_factor, st);
+        if (int rc = ensure_bar_tables(b)) return rc;
+        e = glv::launch_bars(d_out, d_final, units, b->p.n, b->p.bars, b->d_bar_desc, b->d_bar_w, st);
         if (e != hipSuccess) return fail(GLV_ERR_HIP, "bars launch failed: %s", hipGetErrorString(e));
     }
     return GLV_OK;
@@ -357,6 +377,8 @@ int glv_batch_destroy(glv_batch* b) {
     if (b->d_scratch) (void) hipFree(b->d_scratch);
     if (b->d_smin) (void) hipFree(b->d_smin);
     if (b->d_smax) (void) hipFree(b->d_smax);
+    if (b->d_bar_desc) (void) hipFree(b->d_bar_desc);
+    if (b->d_bar_w) (void) hipFree(b->d_bar_w);
     for (hipEvent_t e : b->ev) (void) hipEventDestroy(e);
     delete b;
     return GLV_OK;
@@ -409,7 +431,8 @@ int glv_batch_bars(glv_batch* b, const float* d_spec, float* d_bars, void* hip_s
     if (!d_spec || !d_bars) return fail(GLV_ERR_INVALID, "NULL device pointer");
     if (b->p.bars == 0 || b->p.bars > b->p.n) return fail(GLV_ERR_INVALID, "bars=%u out of range", b->p.bars);
     HIP_TRY(hipSetDevice(b->device));
-    hipError_t e = glv::launch_bars(d_spec, d_bars, (size_t) b->streams * 2, b->p.n, b->p.bars, b->p.smooth_factor, (hipStream_t) hip_stream);
+    if (int rc = ensure_bar_tables(b)) return rc;
+    hipError_t e = glv::launch_bars(d_spec, d_bars, (size_t) b->streams * 2, b->p.n, b->p.bars, b->d_bar_desc, b->d_bar_w, (hipStream_t) hip_stream);
     if (e != hipSuccess) return fail(GLV_ERR_HIP, "bars launch failed: %s", hipGetErrorString(e));
     return GLV_OK;
 }

@@ -24,6 +24,10 @@ enum Epi { EPI_RAW = 0, EPI_MAG = 1, EPI_MAG_STATE = 2, EPI_RAW_STATE = 3 };
 // ops bits as in include/glv_spectrum.h
 enum : uint32_t { OP_FFT = 1u, OP_GRAVITY = 2u, OP_AVERAGE = 4u, OP_RAW = 8u, OP_WRANGE = 16u, OP_BARS = 32u };
 
+// one output bar of GLV_OP_BARS: taps are consecutive bins [first_bin, first_bin + count) with weights
+// tap_w[tap_offset ...]; weight_sum = float sum of the weights in tap order (smooth.glsl:31-36)
+struct BarDesc { uint32_t first_bin, count, tap_offset; float weight_sum; };
+
 struct FrameArgs {
     const void* in;        // s16: int16 [units/2][n][2] (a unit is one channel row of a frame);  f32 planar: float [units][n];
                            // f32 stereo (PulseAudio layout, pulse_input.c:155-178): float [units/2][n][2]

@@ -80,36 +80,32 @@ __global__ void __launch_bounds__(64) glv_smooth_kernel(float* __restrict__ rows
 }
 
 // ---- smooth_audio() bar sampling (shaders/glava/util/smooth.glsl:13-40, radial/1.frag:58-70) --------
-// One wave per (row, bar); lanes stride over the taps s = smin, smin+1, ... <= smax and the two sums are
-// reduced across the wave.  SAMPLE_MODE average, ROUND_FORMULA sinusoidal, SAMPLE_SCALE 8, SAMPLE_RANGE 0.9.
-__device__ __forceinline__ float glv_scale_audio(float idx) { return -logf((-0.9f * idx) + 1.0f) / 8.0f; }
-__device__ __forceinline__ float glv_clamp01(float x) { return x < 0.0f ? 0.0f : (x > 1.0f ? 1.0f : x); }
+// The tap positions and weights of a bar depend only on (bar, n, smooth_factor) -- not on the data -- so
+// they are generated once per batch on the host (glv_tables.h make_bar_taps: SAMPLE_MODE average,
+// ROUND_FORMULA sinusoidal, SAMPLE_SCALE 8, SAMPLE_RANGE 0.9).  One wave per (row, bar): lanes stride the
+// bar's taps (consecutive bins => coalesced), sum(tex * w) is reduced across the wave and divided by the
+// bar's weight sum.  tex is clamped to [0,1] like the GL_R16 texture the shader samples (render.c:523).
 __global__ void __launch_bounds__(256) glv_bars_kernel(const float* __restrict__ spec, float* __restrict__ bars_out,
-                                                       size_t nrows, uint32_t n, uint32_t bars, float smooth_factor) {
-    const size_t wave = ((size_t) blockIdx.x * blockDim.x + threadIdx.x) / 64;
+                                                       size_t nrows, uint32_t n, uint32_t bars,
+                                                       const BarDesc* __restrict__ desc, const float* __restrict__ tap_w) {
+    const size_t nwaves = (size_t) gridDim.x * blockDim.x / 64;
     const int lane = threadIdx.x & 63;
-    if (wave >= nrows * bars) return;
-    const size_t row = wave / bars;
-    const uint32_t k = (uint32_t) (wave % bars);
-    const float* tex = spec + row * n;
-    const float idx = (float) k / (float) bars;
-    const float smin = glv_scale_audio(glv_clamp01(idx - smooth_factor)) * (float) n;
-    const float smax = glv_scale_audio(glv_clamp01(idx + smooth_factor)) * (float) n;
-    const float m = (smax - smin) / 2.0f, rm = smin + m;
-    float avg = 0.0f, weight = 0.0f;
-    for (int j = lane;; j += 64) {
-        const float sx = smin + (float) j;
-        if (!(sx <= smax)) break;
-        const float w = (0.5f * sinf((3.14159265359f * glv_clamp01((m - fabsf(rm - sx)) / m)) - (3.14159265359f / 2.0f))) + 0.5f;
-        weight += w;
-        avg += glv_clamp01(tex[(int) roundf(sx)]) * w;      // GL_R16 textures clamp to [0,1] (render.c:523)
-    }
+    for (size_t item = ((size_t) blockIdx.x * blockDim.x + threadIdx.x) / 64; item < nrows * bars; item += nwaves) {
+        const size_t row = item / bars;
+        const uint32_t k = (uint32_t) (item % bars);
+        const BarDesc d = desc[k];
+        const float* tex = spec + row * n + d.first_bin;
+        const float* w = tap_w + d.tap_offset;
+        float avg = 0.0f;
+        for (uint32_t j = lane; j < d.count; j += 64) {
+            float t = tex[j];
+            t = t < 0.0f ? 0.0f : (t > 1.0f ? 1.0f : t);
+            avg += t * w[j];
+        }
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        avg += __shfl_xor(avg, o);
-        weight += __shfl_xor(weight, o);
+        for (int o = 32; o > 0; o >>= 1) avg += __shfl_xor(avg, o);
+        if (lane == 0) bars_out[row * bars + k] = avg / d.weight_sum;
     }
-    if (lane == 0) bars_out[row * bars + k] = avg / weight;
 }
 
 static int capped_grid(size_t items, int block) {
@@ -141,9 +137,10 @@ hipError_t launch_smooth(float* rows, size_t nrows, uint32_t n, const int* smin,
     hipLaunchKernelGGL(glv_smooth_kernel, dim3((unsigned) ((nrows + 63) / 64)), dim3(64), 0, st, rows, nrows, n, smin, smax, asz);
     return hipGetLastError();
 }
-hipError_t launch_bars(const float* spec, float* bars_out, size_t nrows, uint32_t n, uint32_t bars, float smooth_factor, hipStream_t st) {
-    const size_t waves = nrows * bars;
-    hipLaunchKernelGGL(glv_bars_kernel, dim3((unsigned) ((waves + 3) / 4)), dim3(256), 0, st, spec, bars_out, nrows, n, bars, smooth_factor);
+hipError_t launch_bars(const float* spec, float* bars_out, size_t nrows, uint32_t n, uint32_t bars, const BarDesc* desc,
+                       const float* tap_w, hipStream_t st) {
+    const size_t waves = nrows * bars;                 // one wave per (row, bar) item, grid-stride beyond 256 CUs x 8 x 4 waves
+    hipLaunchKernelGGL(glv_bars_kernel, dim3(capped_grid(waves, 4)), dim3(256), 0, st, spec, bars_out, nrows, n, bars, desc, tap_w);
     return hipGetLastError();
 }
 

@@ -11,7 +11,10 @@
 #include <math.h>
 #include <stddef.h>
 
+#include <vector>
+
 #include "glv_core.h"
+#include "glv_frame.h"
 
 namespace glv {
 
@@ -86,6 +89,42 @@ inline size_t make_smooth_bounds(int* smin, int* smax, size_t sz, float smooth_d
         smax[t] = hi < (int) sz - 1 ? hi : (int) sz - 1;
     }
     return asz;
+}
+
+// smooth_audio() taps of every bar (shaders/glava/util/smooth.glsl:13-40 in float, as the GLSL would):
+//   idx = k / bars;  smin/smax = scale_audio(clamp(idx -/+ factor)) * n,  scale_audio(u) = -log(1 - 0.9u)/8
+//   m = (smax - smin)/2, rm = smin + m;  for s = smin; s <= smax; s += 1:  w = sinusoidal(clamp((m - |rm - s|)/m))
+//   sample bin int(round(s)).  Consecutive s round to consecutive bins, so a bar is a contiguous bin range.
+inline void make_bar_taps(std::vector<BarDesc>& desc, std::vector<float>& tap_w, uint32_t n, uint32_t bars, float smooth_factor) {
+    auto scale = [](float u) { return -logf((-0.9f * u) + 1.0f) / 8.0f; };
+    auto clamp01 = [](float x) { return x < 0.0f ? 0.0f : (x > 1.0f ? 1.0f : x); };
+    desc.resize(bars);
+    tap_w.clear();
+    for (uint32_t k = 0; k < bars; ++k) {
+        const float idx = (float) k / (float) bars;
+        const float smin = scale(clamp01(idx - smooth_factor)) * (float) n;
+        const float smax = scale(clamp01(idx + smooth_factor)) * (float) n;
+        const float m = (smax - smin) / 2.0f, rm = smin + m;
+        BarDesc d{};
+        d.tap_offset = (uint32_t) tap_w.size();
+        float weight = 0.0f;
+        bool first = true;
+        uint32_t prev_bin = 0;
+        for (float sx = smin; sx <= smax; sx += 1.0f) {
+            const float w = (0.5f * sinf((3.14159265359f * clamp01((m - fabsf(rm - sx)) / m)) - (3.14159265359f / 2.0f))) + 0.5f;
+            const uint32_t bin = (uint32_t) (int) roundf(sx);
+            if (first) { d.first_bin = bin; first = false; }
+            else if (bin != prev_bin + 1) {          // (never for step 1.0; keep the range contiguous regardless)
+                for (uint32_t g = prev_bin + 1; g < bin; ++g) tap_w.push_back(0.0f);
+            }
+            prev_bin = bin;
+            weight += w;
+            tap_w.push_back(w);
+        }
+        d.count = (uint32_t) tap_w.size() - d.tap_offset;
+        d.weight_sum = weight;
+        desc[k] = d;
+    }
 }
 
 // log_mode 0 table (glv_core.h log_third_table): c_j = 1 + j/256, { 1/c_j, log(c_j)/3 }.

@@ -390,3 +390,50 @@ def test_full_size_64k_streams_properties(G):
     assert worst <= REL, worst
     assert nbad <= 1e-4 * subset.size * 2 * n, nbad
     b.close()
+
+
+def test_full_size_stateful_chain_subset(G):
+    """configs[1] size with the chain GLava's modules request (fft -> gravity -> average, F=5): three
+    updates of 65536 streams, a random subset of streams against the stateful oracle every update."""
+    import torch
+    n, streams, F = 4096, 65536, 5
+    ops = G.OP_FFT | G.OP_GRAVITY | G.OP_AVERAGE
+    b = G.Batch(G.Params(n=n, avg_frames=F), streams, ops)
+    d_out = torch.empty((streams * 2, n), dtype=torch.float32, device="cuda")
+    rng = np.random.default_rng(7)
+    subset = np.unique(np.concatenate([rng.integers(0, streams, 96), [0, 1, streams - 1]]))
+    idx = torch.from_numpy(subset).cuda()
+    rows = torch.stack([2 * idx, 2 * idx + 1], dim=1).reshape(-1)
+    sos = {int(s): StreamOracle(n, avg_frames=F) for s in subset}
+    g = torch.Generator(device="cuda")
+    for fr in range(3):
+        g.manual_seed(100 + fr)
+        d_pcm = torch.randint(-32768, 32768, (streams, n * 2), dtype=torch.int16, device="cuda", generator=g)
+        b.process_s16(d_pcm, d_out, ops)
+        torch.cuda.synchronize()
+        pcm_sub = d_pcm[idx].cpu().numpy()
+        got = d_out[rows].cpu().numpy().reshape(subset.size, 2, n)
+        for i, s in enumerate(subset):
+            want = sos[int(s)].frame(pcm_sub[i])
+            assert np.allclose(got[i], want, rtol=REL, atol=2e-6), (fr, int(s))
+    assert not torch.isnan(d_out).any().item()
+    b.close()
+
+
+def test_single_stream_dropin_latency(G):
+    """The host-pointer drop-ins must comfortably hold GLava's real-time rate (86 updates/s => 11.6 ms
+    per update for both channels; render.c:1674): fused fft+gravity+average per channel buffer."""
+    import time
+    p = G.Params(n=4096)
+    st = [G.State(p), G.State(p)]
+    buf = [(lcg_pcm_fast(1 + c, 4096).astype(np.float32) / np.float32(65535)) for c in range(2)]
+    for _ in range(5):
+        for c in range(2): st[c].fft_gravity_average(buf[c].copy())
+    t0 = time.perf_counter()
+    reps = 50
+    for _ in range(reps):
+        for c in range(2): st[c].fft_gravity_average(buf[c].copy())
+    per_update = (time.perf_counter() - t0) / reps
+    for s in st: s.close()
+    print(f"single-stream stereo update through the host-pointer drop-ins: {per_update * 1e6:.0f} us")
+    assert per_update < 11.6e-3 / 4

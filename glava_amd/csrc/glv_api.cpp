@@ -252,7 +252,8 @@ int process(glv_batch* b, const void* d_in, int in_mode, float* d_out, unsigned 
         return fail(GLV_ERR_STATE, "ops 0x%x need state the batch was not created with (ops_mask 0x%x)", ops, b->ops_mask);
     if ((ops & GLV_OP_WRANGE) && (ops & GLV_OP_FFT)) return fail(GLV_ERR_INVALID, "GLV_OP_WRANGE excludes GLV_OP_FFT");
     if ((ops & GLV_OP_RAW) && !(ops & GLV_OP_FFT)) return fail(GLV_ERR_INVALID, "GLV_OP_RAW needs GLV_OP_FFT");
-    if (!(ops & (GLV_OP_FFT | GLV_OP_GRAVITY | GLV_OP_AVERAGE | GLV_OP_WRANGE | GLV_OP_SMOOTH))) return fail(GLV_ERR_INVALID, "empty ops");
+    if ((ops & GLV_OP_MAGNITUDE) && (ops & (GLV_OP_FFT | GLV_OP_WRANGE))) return fail(GLV_ERR_INVALID, "GLV_OP_MAGNITUDE excludes GLV_OP_FFT and GLV_OP_WRANGE");
+    if (!(ops & (GLV_OP_FFT | GLV_OP_GRAVITY | GLV_OP_AVERAGE | GLV_OP_WRANGE | GLV_OP_SMOOTH | GLV_OP_MAGNITUDE))) return fail(GLV_ERR_INVALID, "empty ops");
     if ((ops & GLV_OP_BARS) && (b->p.bars == 0 || b->p.bars > b->p.n)) return fail(GLV_ERR_INVALID, "bars=%u out of range", b->p.bars);
     float* d_final = d_out;
     HIP_TRY(hipSetDevice(b->device));
@@ -265,11 +266,11 @@ int process(glv_batch* b, const void* d_in, int in_mode, float* d_out, unsigned 
     glv::FrameArgs a;
     fill_common(a, b->p, b->tab);
     a.in = d_in; a.out = d_out; a.grav = b->d_grav; a.hist = b->d_hist;
-    a.units = units; a.ops = ops; a.head = b->head; a.rot = rot;
+    a.units = units; a.ops = ops; a.head = b->head; a.rot = rot; a.log_mode = b->p.log_mode;
 
     if (int rc = timed_launch_begin(b, st)) return rc;
     hipError_t e;
-    const unsigned core = ops & (GLV_OP_FFT | GLV_OP_GRAVITY | GLV_OP_AVERAGE | GLV_OP_WRANGE);
+    const unsigned core = ops & (GLV_OP_FFT | GLV_OP_GRAVITY | GLV_OP_AVERAGE | GLV_OP_WRANGE | GLV_OP_MAGNITUDE);
     if (!core) {                                   // smooth / bars only: operate on a copy of the input rows
         if (in_mode != glv::IN_F32_PLANAR) return fail(GLV_ERR_INVALID, "operators without GLV_OP_FFT take planar f32 input");
         e = (const void*) d_out == d_in ? hipSuccess
@@ -335,7 +336,7 @@ void glv_params_default(glv_params* p) {
     p->avg_frames = 5;           // smooth_parameters.glsl:56
     p->avg_window = 1;           // smooth_parameters.glsl:61
     p->avg_window_kind = 0;
-    p->log_mode = 0;
+    p->log_mode = 1;             // hardware log2: <= 1.8e-7 relative on every float (bar 1e-5); 0 = bit-faithful fp64
     p->bars = 80;                // radial.glsl:9 (NBARS 160, two channels)
     p->smooth_factor = 0.025F;   // smooth_parameters.glsl:72
     p->smooth_distance = 0.01F;  // render.c:917
@@ -558,6 +559,7 @@ int glv_gravity(const glv_params* p, glv_state* s, float* buf) { return single(p
 int glv_average(const glv_params* p, glv_state* s, float* buf) { return single(p, s, buf, GLV_OP_AVERAGE); }
 int glv_wrange(const glv_params* p, glv_state* s, float* buf) { return single(p, s, buf, GLV_OP_WRANGE); }
 int glv_smooth(const glv_params* p, glv_state* s, float* buf) { return single(p, s, buf, GLV_OP_SMOOTH); }
+int glv_magnitude(const glv_params* p, glv_state* s, float* buf) { return single(p, s, buf, GLV_OP_MAGNITUDE); }
 int glv_fft_gravity_average(const glv_params* p, glv_state* s, float* buf) {
     return single(p, s, buf, GLV_OP_FFT | GLV_OP_GRAVITY | GLV_OP_AVERAGE);
 }

@@ -22,7 +22,7 @@ enum InMode { IN_S16_STEREO = 0, IN_F32_PLANAR = 1, IN_S16_RING = 2, IN_F32_STER
 enum Epi { EPI_RAW = 0, EPI_MAG = 1, EPI_MAG_STATE = 2, EPI_RAW_STATE = 3 };
 
 // ops bits as in include/glv_spectrum.h
-enum : uint32_t { OP_FFT = 1u, OP_GRAVITY = 2u, OP_AVERAGE = 4u, OP_RAW = 8u, OP_WRANGE = 16u, OP_BARS = 32u };
+enum : uint32_t { OP_FFT = 1u, OP_GRAVITY = 2u, OP_AVERAGE = 4u, OP_RAW = 8u, OP_WRANGE = 16u, OP_BARS = 32u, OP_SMOOTH = 64u, OP_MAGNITUDE = 128u };
 
 // one output bar of GLV_OP_BARS: taps are consecutive bins [first_bin, first_bin + count) with weights
 // tap_w[tap_offset ...]; weight_sum = float sum of the weights in tap order (smooth.glsl:31-36)
@@ -44,6 +44,7 @@ struct FrameArgs {
                            // head+1, ..., head+F-1, head  (mod F)
     uint32_t mono;         // fifo.c:98-102
     uint32_t avg_window;
+    uint32_t log_mode;     // glv_post_kernel's OP_MAGNITUDE (the frame kernels take it as a template parameter)
     uint32_t rot;          // s16 ring mode (RING kernels): rotation of the window start, in complex points
     float inv_n, fft_scale, one_minus_cutoff, g, F_as_float;
     double wts[16];        // window_frame weights, oldest first (render.c:661 as expanded at :766)

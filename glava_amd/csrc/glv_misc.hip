@@ -1,7 +1,8 @@
 // glv_misc.hip -- the small kernels and the size dispatch.
 //
 //   glv_post_kernel    gravity / average / wrange on spectra already in HBM (the single-op
-//                      drop-ins glv_gravity, glv_average, glv_wrange; glava/render.c:720-781)
+//                      drop-ins glv_gravity, glv_average, glv_wrange; glava/render.c:720-781) and
+//                      the magnitude stage alone (glv_magnitude; render.c:842-846)
 //   glv_unpack_kernel  s16 interleaved -> planar f32 (glv_unpack_s16; glava/fifo.c:94-110)
 #include <hip/hip_runtime.h>
 
@@ -19,6 +20,13 @@ __global__ void __launch_bounds__(256) glv_post_kernel(const FrameArgs a, const 
         const size_t row = i / pairs_per_row;
         const uint32_t off = (uint32_t) (i % pairs_per_row) * 8u;     // byte offset of the pair in its row
         cf val = ld<cf>(static_cast<const float*>(a.in) + row * n, off);
+        if (a.ops & OP_MAGNITUDE) {                                               // render.c:842-846
+            const float y0 = __builtin_fabsf(val.x) + 1.0f, y1 = __builtin_fabsf(val.y) + 1.0f;
+            const cf tl = ld<cf>(a.tilt, off);
+            if (a.log_mode == 0)      { val.x = log_third<0>(y0, a.logtab) * tl.x; val.y = log_third<0>(y1, a.logtab) * tl.y; }
+            else if (a.log_mode == 1) { val.x = log_third<1>(y0, a.logtab) * tl.x; val.y = log_third<1>(y1, a.logtab) * tl.y; }
+            else                      { val.x = log_third<2>(y0, a.logtab) * tl.x; val.y = log_third<2>(y1, a.logtab) * tl.y; }
+        }
         if (a.ops & OP_WRANGE) {                                                  // render.c:777-779
             const float p = val.x + 1.0f, q = val.y + 1.0f;
             val.x = p / 2.0f; val.y = q / 2.0f;

@@ -17,7 +17,7 @@ from dataclasses import dataclass
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "csrc", "libglvspectrum.so")
 
-OP_FFT, OP_GRAVITY, OP_AVERAGE, OP_RAW, OP_WRANGE, OP_BARS, OP_SMOOTH = 1, 2, 4, 8, 16, 32, 64
+OP_FFT, OP_GRAVITY, OP_AVERAGE, OP_RAW, OP_WRANGE, OP_BARS, OP_SMOOTH, OP_MAGNITUDE = 1, 2, 4, 8, 16, 32, 64, 128
 OK, ERR_INVALID, ERR_NO_DEVICE, ERR_HIP, ERR_NOMEM, ERR_STATE = 0, 1, 2, 3, 4, 5
 
 
@@ -63,7 +63,7 @@ def lib() -> C.CDLL:
         L.glv_state_create.argtypes = [P, C.c_int, C.POINTER(vp)]
         L.glv_state_reset.argtypes = [vp]
         L.glv_state_destroy.argtypes = [vp]
-        for name in ("glv_fft", "glv_gravity", "glv_average", "glv_wrange", "glv_smooth", "glv_fft_gravity_average"):
+        for name in ("glv_fft", "glv_gravity", "glv_average", "glv_wrange", "glv_smooth", "glv_magnitude", "glv_fft_gravity_average"):
             getattr(L, name).argtypes = [P, vp, vp]
         L.glv_unpack_s16.argtypes = [C.c_int, vp, C.c_size_t, C.c_int, vp, vp]
         L.glv_batch_create.argtypes = [P, C.c_uint32, C.c_uint, C.c_int, C.POINTER(vp)]
@@ -103,7 +103,7 @@ class Params:
     avg_frames: int = 5
     avg_window: bool = True
     avg_window_kind: int = 0
-    log_mode: int = 0
+    log_mode: int = 1
     bars: int = 80
     smooth_factor: float = 0.025
     smooth_distance: float = 0.01
@@ -203,6 +203,7 @@ class State:
     def average(self, buf) -> None: self._call("glv_average", buf)         # transform_average
     def wrange(self, buf) -> None: self._call("glv_wrange", buf)           # transform_wrange
     def smooth(self, buf) -> None: self._call("glv_smooth", buf)           # transform_smooth
+    def magnitude(self, buf) -> None: self._call("glv_magnitude", buf)     # tail of transform_fft
     def fft_gravity_average(self, buf) -> None: self._call("glv_fft_gravity_average", buf)
 
     def reset(self) -> None:

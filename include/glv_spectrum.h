@@ -49,8 +49,12 @@ enum {
     GLV_OP_BARS     = 1u << 5,  /* smooth_audio() bin averaging + bar lookup (shaders/glava/util/
                                    smooth.glsl:13-64, radial/1.frag:58-70): emit `bars` values per
                                    channel instead of n bins; d_out is float [streams][2][bars] */
-    GLV_OP_SMOOTH   = 1u << 6   /* CPU-path log-window mean  == transform_smooth   render.c:694-718;
+    GLV_OP_SMOOTH   = 1u << 6,  /* CPU-path log-window mean  == transform_smooth   render.c:694-718;
                                    applied last, in place on each row (after fft/gravity/average) */
+    GLV_OP_MAGNITUDE = 1u << 7  /* the magnitude stage alone: b = (float)(log(|b| + 1.0f) / 3) * tilt(i),
+                                   the tail of transform_fft (render.c:842-846) on planar f32 rows that
+                                   already hold FFT output; exclusive with GLV_OP_FFT (which includes it);
+                                   runs before gravity/average when combined with them */
 };
 
 /* Mirrors the fields of the private `struct gl_data` that the path reads
@@ -69,10 +73,12 @@ typedef struct glv_params {
     uint32_t avg_window_kind; /* 0: CPU twin 0.6/0.4, oldest-first (render.c:661,751-766)
                                  1: GL twin 0.53836/0.46164, newest-first (common.glsl:13, average_pass.frag:19-45,
                                     render.c:2247-2256) */
-    uint32_t log_mode;      /* render.c:844 evaluates log() in fp64 and divides by 3 in fp64:
-                               0: fp64 table-driven log (rel. error ~2^-50) * (1/3): the reference's float
-                                  result except on ~1e-8 of values (last-ulp ties); default
-                               1: fast: hardware log2 (1 ulp) * ln2/3 in fp32, <= ~2e-7 relative
+    uint32_t log_mode;      /* render.c:844 evaluates log() in fp64 and divides by 3 in fp64, then rounds to float:
+                               1: (default) hardware log2 * (ln2/3 * tilt) in fp32: <= 1.8e-7 relative error
+                                  against the reference's float on EVERY float input of the stage (exhaustive
+                                  test, tests/test_gpu_parity.py::test_magnitude_stage_every_float; bar 1e-5)
+                               0: bit-faithful: fp64 table-driven log (rel. error ~2^-50) and fp64 /3 -- the
+                                  reference's float result on every input of the same exhaustive test
                                2: audit: device libm fp64 log + true fp64 division (slow) */
     /* GLV_OP_BARS parameters (shaders/glava/smooth_parameters.glsl) */
     uint32_t bars;          /* bars per channel (radial.glsl:9 NBARS 160 => 80) */
@@ -117,6 +123,8 @@ int glv_average(const glv_params* p, glv_state* s, float* buf);
 int glv_wrange(const glv_params* p, glv_state* s, float* buf);
 /* == transform_smooth                                              glava/render.c:694-718 */
 int glv_smooth(const glv_params* p, glv_state* s, float* buf);
+/* == the magnitude tail of transform_fft alone (abs, +1, log/3, tilt) glava/render.c:842-846 */
+int glv_magnitude(const glv_params* p, glv_state* s, float* buf);
 /* fft -> gravity -> average in one launch (what handle_audio does per bind, render.c:2140-2156) */
 int glv_fft_gravity_average(const glv_params* p, glv_state* s, float* buf);
 

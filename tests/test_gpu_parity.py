@@ -73,7 +73,7 @@ def test_fft_raw_bit_exact_and_magnitude_within_tol(G, n):
     streams = 37                      # ragged: not a multiple of any slots-per-workgroup
     pcm = lcg_pcm_fast(2000 + n, streams * 2 * n)
     raw = run_batch(G, G.Params(n=n), pcm, streams, G.OP_FFT | G.OP_RAW)
-    mag = run_batch(G, G.Params(n=n), pcm, streams, G.OP_FFT)
+    mag = run_batch(G, G.Params(n=n, log_mode=0), pcm, streams, G.OP_FFT)
     fast = run_batch(G, G.Params(n=n, log_mode=1), pcm, streams, G.OP_FFT)
     nbad = 0
     for u in range(streams):
@@ -89,24 +89,27 @@ def test_fft_raw_bit_exact_and_magnitude_within_tol(G, n):
     assert nbad <= 1e-4 * streams * 2 * n, nbad
 
 
-def test_golden_vectors_through_gpu(G, golden):
-    """Committed outputs of the compiled reference (tests/golden) vs the f32-planar GPU path."""
+@pytest.mark.parametrize("log_mode", [0, 1])
+def test_golden_vectors_through_gpu(G, golden, log_mode):
+    """Committed outputs of the compiled reference (tests/golden) vs the f32-planar GPU path, in the
+    strict log mode (<= 1 float ulp) and the default hardware-log mode (<= 1e-5 relative)."""
     for key, seed, n in (("fft_n512_seed12857", 12857, 512), ("fft_n1024_seed13369", 13369, 1024),
                          ("fft_n4096_seed16441", 16441, 4096), ("fft_n16384_seed28729", 28729, 16384),
                          ("fft_kat_survey", 12345, 4096)):
         x = lcg_pcm_fast(seed, n).astype(np.float32) / np.float32(65535)
-        st = G.State(G.Params(n=n))
+        st = G.State(G.Params(n=n, log_mode=log_mode))
         buf = x.copy()
         st.fft(buf)
         st.close()
         assert rel_err(buf, golden[key]).max() <= REL, key
-        assert np.abs(bits(buf).astype(np.int64) - bits(golden[key]).astype(np.int64)).max() <= 1, key
+        if log_mode == 0:
+            assert np.abs(bits(buf).astype(np.int64) - bits(golden[key]).astype(np.int64)).max() <= 1, key
     # parameters and edge inputs
-    st = G.State(G.Params(n=1024, fft_scale=3.0, fft_cutoff=0.7))
+    st = G.State(G.Params(n=1024, fft_scale=3.0, fft_cutoff=0.7, log_mode=log_mode))
     buf = (lcg_pcm_fast(7, 1024).astype(np.float32) / np.float32(65535)); st.fft(buf)
     assert rel_err(buf, golden["fft_n1024_scale3_cut0p7"]).max() <= REL
     st.close()
-    st = G.State(G.Params(n=1024))
+    st = G.State(G.Params(n=1024, log_mode=log_mode))
     buf = np.zeros(1024, np.float32); st.fft(buf)
     assert (bits(buf) == bits(golden["fft_n1024_zeros"])).all()
     buf = np.full(1024, 32767 / 65535, np.float32); st.fft(buf)
@@ -353,8 +356,10 @@ def test_error_behaviour(G):
 
 
 # ---- BASELINE.json full size: 64K streams x N=4096 --------------------------------------------------
-def test_full_size_64k_streams_properties(G):
-    """configs[1]: 65536 stereo streams, N=4096, window+FFT+magnitude.  Size-independent checks:
+@pytest.mark.parametrize("log_mode", [1, 0])
+def test_full_size_64k_streams_properties(G, log_mode):
+    """configs[1]: 65536 stereo streams, N=4096, window+FFT+magnitude, in the default (hardware log) and
+    the strict log mode.  Size-independent checks:
     (a) a random subset of >= 1024 streams against the oracle (magnitudes <= 1e-5 rel);
     (b) every stream that was given identical PCM produces identical output bits (indexing across
         the whole batch, all workgroups/slots);
@@ -368,7 +373,7 @@ def test_full_size_64k_streams_properties(G):
     for s in dup[1:]:
         d_pcm[s] = d_pcm[7]
     d_out = torch.full((streams * 2, n), float("nan"), dtype=torch.float32, device="cuda")
-    b = G.Batch(G.Params(n=n), streams, G.OP_FFT)
+    b = G.Batch(G.Params(n=n, log_mode=log_mode), streams, G.OP_FFT)
     b.process_s16(d_pcm, d_out, G.OP_FFT)
     torch.cuda.synchronize()
     assert not torch.isnan(d_out).any().item()
@@ -388,7 +393,8 @@ def test_full_size_64k_streams_properties(G):
         worst = max(worst, rel_err(out_sub[i], want).max())
         nbad += int((bits(out_sub[i]) != bits(want)).sum())
     assert worst <= REL, worst
-    assert nbad <= 1e-4 * subset.size * 2 * n, nbad
+    if log_mode == 0:                    # strict: bit-identical but for rare fp64 last-ulp ties
+        assert nbad <= 1e-4 * subset.size * 2 * n, nbad
     b.close()
 
 
@@ -437,3 +443,38 @@ def test_single_stream_dropin_latency(G):
     for s in st: s.close()
     print(f"single-stream stereo update through the host-pointer drop-ins: {per_update * 1e6:.0f} us")
     assert per_update < 11.6e-3 / 4
+
+
+@pytest.mark.parametrize("log_mode,bar", [(0, 0.0), (1, 1e-6)])
+def test_magnitude_stage_every_float(G, log_mode, bar):
+    """The magnitude stage alone (GLV_OP_MAGNITUDE, render.c:842-846) over EVERY float y = |b| + 1 in
+    [1, 2^14) -- all the stage can see for n <= 16384 (|b| <= n/2 * 0.5 * max window).  log_mode 0 must be
+    within one float ulp of (float)(log(y)/3) everywhere (and almost always equal); log_mode 1 (hardware
+    log2) within 1e-6 relative, ten times inside the 1e-5 bar, including right above y = 1 where
+    log(y) -> 0 makes a relative bound hardest."""
+    import torch
+    n, streams = 16384, 256                      # 2^23 values per call = one binade
+    b = G.Batch(G.Params(n=n, fft_scale=0.0, fft_cutoff=0.0, log_mode=log_mode), streams, G.OP_FFT)
+    d_out = torch.empty((streams * 2, n), dtype=torch.float32, device="cuda")
+    k = np.arange(1 << 23, dtype=np.uint32)
+    worst, nbad, total = 0.0, 0, 0
+    for e in range(14):
+        y = (np.uint32(0x3f800000 + (e << 23)) + k).view(np.float32)
+        x = y - np.float32(1)                    # exact; x + 1.0f == y on the device
+        assert (x + np.float32(1) == y).all()
+        x[1::2] *= np.float32(-1)                # abs
+        b.process_f32(torch.from_numpy(x.reshape(streams * 2, n)).cuda(), d_out, G.OP_MAGNITUDE)
+        got = d_out.cpu().numpy().reshape(-1)
+        want = (np.log(y.astype(np.float64)) / 3).astype(np.float32)      # tilt == 1 with fft_scale = cutoff = 0
+        ulps = np.abs(bits(got).astype(np.int64) - bits(want).astype(np.int64))
+        if log_mode == 0:
+            assert ulps.max() <= 1, (e, int(ulps.max()))
+            nbad += int((ulps != 0).sum())
+        nz = want != 0
+        worst = max(worst, float(np.abs((got[nz].astype(np.float64) - want[nz]) / want[nz]).max()))
+        assert (got[~nz] == 0).all()
+        total += y.size
+    print(f"log_mode {log_mode}: max relative error over {total} floats {worst:.3e}; values differing from the reference float: {nbad}")
+    assert worst <= (bar if log_mode else 1.3e-7)
+    if log_mode == 0: assert nbad <= 1e-4 * total
+    b.close()

@@ -18,11 +18,11 @@ template <int LOG_NN> struct Tuned;
 // measured best of tools/tune.py on MI355X (profiles/tune_r01.txt), equal bytes per size class:
 //         log2(nn) LOG_E SLOTS NBUF TWREG  WINLDS OCC PREFETCH TILTREG      (PREFETCH 1 = frame pipeline, 2 = row pipeline)
 GLV_TUNED(8,        4,    16,   1,   true,  true,  2,  1,       true)    // N=512    E=16: 4+4
-GLV_TUNED(9,        3,    4,    1,   true,  true,  4,  0,       true)    // N=1024   E=8:  3+3+3
-GLV_TUNED(10,       3,    2,    1,   true,  true,  4,  0,       true)    // N=2048   E=8:  3+3+3+1
-GLV_TUNED(11,       4,    2,    1,   true,  true,  2,  1,       true)    // N=4096   E=16: 4+4+3
-GLV_TUNED(12,       4,    1,    1,   true,  false, 2,  2,       true)    // N=8192   E=16: 4+4+4 (window 64 KiB: via L2)
-GLV_TUNED(13,       4,    1,    1,   true,  false, 2,  2,       true)    // N=16384  E=16: 4+4+4+1 (70 KiB exchange region)
+GLV_TUNED(9,        3,    4,    1,   true,  true,  4,  3,       true)    // N=1024   E=8:  3+3+3
+GLV_TUNED(10,       4,    2,    1,   true,  true,  2,  3,       true)    // N=2048   E=16: 4+4+2
+GLV_TUNED(11,       4,    2,    1,   true,  true,  2,  3,       true)    // N=4096   E=16: 4+4+3
+GLV_TUNED(12,       4,    1,    1,   true,  false, 2,  3,       true)    // N=8192   E=16: 4+4+4 (window 64 KiB: via L2)
+GLV_TUNED(13,       4,    1,    1,   true,  false, 2,  3,       true)    // N=16384  E=16: 4+4+4+1 (70 KiB exchange region)
 #undef GLV_TUNED
 
 #define GLV_CAT2(a, b) a##b

@@ -25,7 +25,7 @@
 //   WINLDS  true: window table staged once per workgroup into LDS; false: read through L1/L2
 //   OCC     __launch_bounds__ minimum waves per SIMD (caps the VGPR budget: 512 / OCC)
 //   TILTREG   the 32 per-lane tilt factors stay in VGPRs across rows instead of being re-read per row
-//   PREFETCH  s16 input, 0 off / 1 frame pipeline / 2 row pipeline: rows are software-pipelined -- the next row's PCM is loaded before and
+//   PREFETCH  s16 input, 0 off / 1 frame pipeline / 2 row pipeline / 3 in-place frame pipeline (no second point set): rows are software-pipelined -- the next row's PCM is loaded before and
 //           unpacked after the current row's passes, so neither HBM reads nor spectrum stores sit on
 //           a row's critical path (costs a second 32-VGPR point set)
 #pragma once
@@ -241,6 +241,54 @@ glv_frame_kernel(const FrameArgs a) {
             //  variant into heavy spilling; 32 v_mov per row are the cheaper price)
 #pragma unroll
             for (int i = 0; i < E; ++i) v[i] = vn[i];
+        }
+        return;
+    }
+    if constexpr (S16 && PREFETCH == 3) {
+        // In-place frame pipeline: like PREFETCH == 1 (one slot = one FRAME, channel rows back to back,
+        // PCM loaded exactly once), but without the second point set.  Per row r = 2*m + ch:
+        //   A  ch == 1 only: issue the PCM loads of the slot's next frame into `raw` (both channels of
+        //      the current frame were unpacked out of it already)
+        //   B  all FFT passes of row r
+        //   W  s_waitcnt vmcnt(0): A's loads are a whole transform old, the previous row's stores older
+        //   D  epilogue of row r: log/tilt/state + spectrum stores
+        //   C  unpack + window row r+1 from `raw` straight into v (register-only: no vector-memory
+        //      wait can land behind D's stores, W retired every load)
+        // 32 VGPRs less than PREFETCH == 1 and no per-row register copy; the price is that C cannot
+        // overlap D's store issue.
+        const uint32_t nframes = a.units / 2;
+        const uint32_t fstride = gridDim.x * SLOTS;
+        const uint32_t nfs = nframes == 0 ? 0 : (nframes - 1) / fstride + 1;
+        auto frame_of = [&](uint32_t m) -> uint32_t {
+            const uint32_t f = blockIdx.x * SLOTS + m * fstride + slot;
+            return f < nframes ? f : nframes - 1;
+        };
+        auto frame_ptr = [&](uint32_t f) -> const void* { return static_cast<const char*>(a.in) + (size_t) f * ((size_t) N * 4); };
+        cf v[E];
+        typename FR::Raw raw;
+        if (blockIdx.x * SLOTS < nframes) {
+            int tid = tid_outer;
+            asm volatile("" : "+v"(tid));
+            FR::template load_pcm<RING>(raw, frame_ptr(frame_of(0)), tid, a.rot);
+            FR::unpack_window(v, raw, win, tid, 0u, a.mono != 0);
+        }
+        __builtin_amdgcn_s_waitcnt(0x0F70);
+        for (uint32_t r = 0; r < 2 * nfs; ++r) {
+            const uint32_t m = r >> 1, ch = r & 1u;
+            if (blockIdx.x * SLOTS + m * fstride >= nframes) break;                     // uniform for the workgroup
+            int tid = tid_outer;
+            asm volatile("" : "+v"(tid));
+            const uint32_t fraw = blockIdx.x * SLOTS + m * fstride + slot;
+            const bool active = fraw < nframes;
+            const uint32_t f = frame_of(m);
+            if (ch) FR::template load_pcm<RING>(raw, frame_ptr(frame_of(m + 1)), tid, a.rot);   // A
+            GLV_SCHED_FENCE();
+            BD::template run<0>(v, tw_all, a.tw, xslot, tid, xcount);                            // B
+            GLV_SCHED_FENCE();
+            __builtin_amdgcn_s_waitcnt(0x0F70);                                                  // W
+            if (active) finish(v, (size_t) f * 2 + ch, tid);                                     // D
+            GLV_SCHED_FENCE();
+            FR::unpack_window(v, raw, win, tid, ch ^ 1u, a.mono != 0);                           // C
         }
         return;
     }

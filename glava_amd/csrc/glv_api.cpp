@@ -246,7 +246,12 @@ int ensure_bar_tables(glv_batch* b) {
 // One update of `units` channel rows through the fused kernel (or the post kernel when no FFT is asked).
 int process(glv_batch* b, const void* d_in, int in_mode, float* d_out, unsigned ops, uint32_t units,
             uint32_t rot, hipStream_t st) {
-    if (!d_in || !d_out) return fail(GLV_ERR_INVALID, "NULL device pointer");
+    if (!d_in) return fail(GLV_ERR_INVALID, "NULL device pointer");
+    // gravity's output IS its new state (render.c:733-734): a chain that ends in gravity can leave the
+    // spectra in the state buffer (glv_batch_gravity_state) instead of writing them a second time
+    const bool state_is_output = (ops & GLV_OP_GRAVITY) && !(ops & (GLV_OP_AVERAGE | GLV_OP_SMOOTH | GLV_OP_RAW));
+    if (!d_out && !(state_is_output && !(ops & GLV_OP_BARS)))
+        return fail(GLV_ERR_INVALID, "NULL output pointer (allowed only for chains ending in gravity, see glv_batch_gravity_state)");
     const unsigned stateful = ops & (GLV_OP_GRAVITY | GLV_OP_AVERAGE);
     if (stateful & ~b->ops_mask)
         return fail(GLV_ERR_STATE, "ops 0x%x need state the batch was not created with (ops_mask 0x%x)", ops, b->ops_mask);
@@ -257,9 +262,12 @@ int process(glv_batch* b, const void* d_in, int in_mode, float* d_out, unsigned 
     if ((ops & GLV_OP_BARS) && (b->p.bars == 0 || b->p.bars > b->p.n)) return fail(GLV_ERR_INVALID, "bars=%u out of range", b->p.bars);
     float* d_final = d_out;
     HIP_TRY(hipSetDevice(b->device));
-    if (ops & GLV_OP_BARS) {                       // spectra go to an internal buffer, d_out receives the bars
-        if (!b->d_scratch) HIP_TRY(hipMalloc(&b->d_scratch, sizeof(float) * (size_t) b->streams * 2 * b->p.n));
-        d_out = b->d_scratch;
+    if (ops & GLV_OP_BARS) {                       // d_out receives the bars; the spectra stay internal:
+        if (state_is_output) d_out = nullptr;      //   in the gravity state when the chain ends in gravity,
+        else {                                     //   in a scratch buffer otherwise
+            if (!b->d_scratch) HIP_TRY(hipMalloc(&b->d_scratch, sizeof(float) * (size_t) b->streams * 2 * b->p.n));
+            d_out = b->d_scratch;
+        }
     }
 
     if (int rc = b->tab.set_tilt(b->p.fft_scale, b->p.fft_cutoff, b->p.log_mode == 1)) return rc;
@@ -294,7 +302,7 @@ int process(glv_batch* b, const void* d_in, int in_mode, float* d_out, unsigned 
     }
     if (ops & GLV_OP_BARS) {
         if (int rc = ensure_bar_tables(b)) return rc;
-        e = glv::launch_bars(d_out, d_final, units, b->p.n, b->p.bars, b->d_bar_desc, b->d_bar_w, st);
+        e = glv::launch_bars(d_out ? d_out : b->d_grav, d_final, units, b->p.n, b->p.bars, b->d_bar_desc, b->d_bar_w, st);
         if (e != hipSuccess) return fail(GLV_ERR_HIP, "bars launch failed: %s", hipGetErrorString(e));
     }
     return GLV_OK;
@@ -425,6 +433,13 @@ int glv_batch_ring_update_s16(glv_batch* b, const int16_t* d_new, uint32_t new_f
     b->ring_pos = (b->ring_pos + new_frames) % n;
     // oldest sample now sits at ring_pos; rotation in complex points (pairs of frames)
     return process(b, b->d_ring, glv::IN_S16_RING, d_out, ops, b->streams * 2, b->ring_pos / 2, st);
+}
+
+int glv_batch_gravity_state(glv_batch* b, const float** d_state) {
+    if (!b || !d_state) return fail(GLV_ERR_INVALID, "NULL argument");
+    if (!b->d_grav) return fail(GLV_ERR_STATE, "the batch was created without GLV_OP_GRAVITY");
+    *d_state = b->d_grav;
+    return GLV_OK;
 }
 
 int glv_batch_bars(glv_batch* b, const float* d_spec, float* d_bars, void* hip_stream) {

@@ -417,6 +417,7 @@ struct Frame {
                     off[j] = (uint32_t) out_index<P - 1>(tid, gi, r) * 8u;
                 }
                 apply_state_block<BLK>(val, off, row, (uint32_t) N, a);
+                if (out_row == nullptr) continue;                     // uniform: output aliased to the gravity state
 #pragma unroll
                 for (int j = 0; j < BLK; ++j) {
                     const int gi = (h0 + j) % PI::NG;

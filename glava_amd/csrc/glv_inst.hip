@@ -22,7 +22,7 @@ GLV_TUNED(9,        3,    4,    1,   true,  true,  4,  3,       true)    // N=10
 GLV_TUNED(10,       4,    2,    1,   true,  true,  2,  3,       true)    // N=2048   E=16: 4+4+2
 GLV_TUNED(11,       4,    2,    1,   true,  true,  2,  3,       true)    // N=4096   E=16: 4+4+3
 GLV_TUNED(12,       4,    1,    1,   true,  false, 2,  3,       true)    // N=8192   E=16: 4+4+4 (window 64 KiB: via L2)
-GLV_TUNED(13,       4,    1,    1,   true,  false, 2,  3,       true)    // N=16384  E=16: 4+4+4+1 (70 KiB exchange region)
+GLV_TUNED(13,       5,    1,    1,   false, false, 2,  3,       false)   // N=16384  E=32: 5+5+3 (68 KiB exchange region, 2 rows per CU in flight)
 #undef GLV_TUNED
 
 #define GLV_CAT2(a, b) a##b

@@ -159,7 +159,9 @@ glv_frame_kernel(const FrameArgs a) {
     // kernel, not per path).
     const bool raw_out = (a.ops & OP_RAW) != 0;
     auto finish = [&](const cf (&v)[E], size_t row, int tid) {
-        float* out_row = a.out + row * N;
+        // a.out == nullptr (gravity without average only): the spectra ARE the gravity state
+        // (render.c:733-734 stores the same value to both), so the second copy is not written
+        float* out_row = STATEFUL && a.out == nullptr ? nullptr : a.out + row * N;
         if constexpr (STATEFUL) {
             if (raw_out) FR::template epilogue<LOG_MODE, EPI_RAW_STATE>(v, out_row, row, tid, a, logtab);
             else FR::template epilogue<LOG_MODE, EPI_MAG_STATE, TILTREG>(v, out_row, row, tid, a, logtab, tilt_reg);

@@ -32,7 +32,7 @@ __global__ void __launch_bounds__(256) glv_post_kernel(const FrameArgs a, const 
             val.x = p / 2.0f; val.y = q / 2.0f;
         }
         val = apply_state(val, off, row, n, a);
-        st<cf>(a.out + row * n, off, val);
+        if (a.out) st<cf>(a.out + row * n, off, val);
     }
 }
 

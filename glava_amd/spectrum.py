@@ -74,6 +74,7 @@ def lib() -> C.CDLL:
         L.glv_batch_process_f32_stereo.argtypes = [vp, vp, vp, C.c_uint, vp]
         L.glv_batch_ring_update_s16.argtypes = [vp, vp, C.c_uint32, vp, C.c_uint, vp]
         L.glv_batch_bars.argtypes = [vp, vp, vp, vp]
+        L.glv_batch_gravity_state.argtypes = [vp, C.POINTER(C.c_void_p)]
         L.glv_prelude_bufscale.argtypes = [C.c_int, vp, vp, C.c_size_t, C.c_uint32, C.c_uint32, vp]
         L.glv_prelude_lerp.argtypes = [C.c_int, vp, vp, vp, C.c_size_t, C.c_float, C.c_int, vp]
         L.glv_batch_timing_begin.argtypes = [vp]
@@ -148,6 +149,12 @@ class Batch:
 
     def ring_update_s16(self, d_new, new_frames: int, d_out, ops: int = OP_FFT, stream: int | None = None) -> None:
         _check(lib().glv_batch_ring_update_s16(self._h, _ptr(d_new), new_frames, _ptr(d_out), ops, _ptr(stream)))
+
+    def gravity_state(self) -> int:
+        """device address of the gravity state float [streams][2][n] (the spectra when d_out is None)"""
+        p = C.c_void_p()
+        _check(lib().glv_batch_gravity_state(self._h, C.byref(p)))
+        return int(p.value)
 
     def bars(self, d_spec, d_bars, stream: int | None = None) -> None:
         _check(lib().glv_batch_bars(self._h, _ptr(d_spec), _ptr(d_bars), _ptr(stream)))

@@ -157,8 +157,15 @@ int glv_batch_create(const glv_params* p, uint32_t streams, unsigned ops_mask, i
 int glv_batch_reset(glv_batch* b);
 int glv_batch_destroy(glv_batch* b);
 
-/* one update of every stream from s16 PCM already resident in HBM */
+/* one update of every stream from s16 PCM already resident in HBM.
+ * d_out may be NULL for a chain that ends in gravity (GLV_OP_GRAVITY without AVERAGE / SMOOTH / RAW /
+ * BARS): transform_gravity's output is its new state (render.c:733-734), so the spectra are then left
+ * in the state buffer only -- read them through glv_batch_gravity_state -- and 8*n bytes per frame of
+ * HBM writes are saved.  (With GLV_OP_BARS such a chain does this internally.) */
 int glv_batch_process_s16(glv_batch* b, const int16_t* d_pcm, float* d_out, unsigned ops, void* hip_stream);
+/* device pointer to the gravity state float [streams][2][n] (== the latest gravity output); valid
+ * until the batch is destroyed.  GLV_ERR_STATE if the batch was created without GLV_OP_GRAVITY. */
+int glv_batch_gravity_state(glv_batch* b, const float** d_state);
 /* same from planar f32 (the lb/rb snapshot) */
 int glv_batch_process_f32(glv_batch* b, const float* d_f32, float* d_out, unsigned ops, void* hip_stream);
 

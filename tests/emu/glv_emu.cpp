@@ -133,6 +133,7 @@ int glvemu_process(int n, int in_mode, const void* in, float* out, float* grav, 
     a.g = gravity_step * (1.0f / ur); a.F_as_float = (float) F;
     if (F > 16) return 3;
     make_frame_weights(a.wts, F, avg_window != 0, avg_kind);
+    if (log_e == 5) return log_mode == 0 ? dispatch<0, 5>(log_nn, in_mode, a) : log_mode == 1 ? dispatch<1, 5>(log_nn, in_mode, a) : dispatch<2, 5>(log_nn, in_mode, a);
     if (log_e == 3) return log_mode == 0 ? dispatch<0, 3>(log_nn, in_mode, a) : log_mode == 1 ? dispatch<1, 3>(log_nn, in_mode, a) : dispatch<2, 3>(log_nn, in_mode, a);
     return log_mode == 0 ? dispatch<0, 4>(log_nn, in_mode, a) : log_mode == 1 ? dispatch<1, 4>(log_nn, in_mode, a) : dispatch<2, 4>(log_nn, in_mode, a);
 }

@@ -15,7 +15,7 @@ def bits(a):
     return np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)
 
 
-@pytest.mark.parametrize("log_e", [4, 3])
+@pytest.mark.parametrize("log_e", [4, 3, 5])
 @pytest.mark.parametrize("n", [512, 1024, 2048, 4096, 8192, 16384])
 def test_fft_raw_and_magnitude_bit_exact(emu, oracle, n, log_e):
     """every size, both lane footprints (E = 16 and E = 8 points per lane: different pass plans)"""

@@ -478,3 +478,36 @@ def test_magnitude_stage_every_float(G, log_mode, bar):
     assert worst <= (bar if log_mode else 1.3e-7)
     if log_mode == 0: assert nbad <= 1e-4 * total
     b.close()
+
+
+def test_gravity_state_as_output(G):
+    """A chain ending in gravity may leave its spectra in the state buffer only (d_out = NULL,
+    render.c:733-734 stores the same value to both): identical bits to the explicit output, also for the
+    bars computed from it."""
+    import torch
+    n, streams, bars = 2048, 11, 80
+    ops = G.OP_FFT | G.OP_GRAVITY
+    a = G.Batch(G.Params(n=n, bars=bars), streams, ops)
+    b = G.Batch(G.Params(n=n, bars=bars), streams, ops)
+    c = G.Batch(G.Params(n=n, bars=bars), streams, ops)
+    d_out = torch.empty((streams * 2, n), dtype=torch.float32, device="cuda")
+    d_bars = torch.empty((streams * 2, bars), dtype=torch.float32, device="cuda")
+    d_bars2 = torch.empty_like(d_bars)
+    import ctypes
+    for fr in range(4):
+        d_pcm = torch.from_numpy(lcg_pcm_fast(900 + fr, streams * 2 * n)).cuda()
+        a.process_s16(d_pcm, d_out, ops)
+        b.process_s16(d_pcm, None, ops)
+        torch.cuda.synchronize()
+        # read the state buffer through torch: wrap the raw pointer
+        st = torch.empty_like(d_out)
+        hip = ctypes.CDLL("libamdhip64.so")
+        assert hip.hipMemcpy(ctypes.c_void_p(st.data_ptr()), ctypes.c_void_p(b.gravity_state()), ctypes.c_size_t(st.numel() * 4), 3) == 0
+        assert torch.equal(st.view(torch.int32), d_out.view(torch.int32)), fr
+        c.process_s16(d_pcm, d_bars, ops | G.OP_BARS)            # spectra stay in c's state buffer
+        a.bars(d_out, d_bars2)
+        torch.cuda.synchronize()
+        assert torch.equal(d_bars.view(torch.int32), d_bars2.view(torch.int32)), fr
+    with pytest.raises(G.GlvError):
+        a.process_s16(d_pcm, None, G.OP_FFT)                     # no state to hold the output
+    for x in (a, b, c): x.close()

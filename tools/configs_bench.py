@@ -87,11 +87,14 @@ def main():
     ops = G.OP_FFT | G.OP_GRAVITY
     dt = timed(lambda: b.process_s16(pcm, spec, ops), sync)
     lines.append(f"config[2a] N=16384 x {streams} streams, FFT+gravity (full spectra out): {streams / dt / 1e6:6.2f} M frames/s, "
-                 f"{streams / dt * 20 * n / 8e12 * 100:5.1f} % of 8 TB/s (20N B/frame)")
+                 f"{streams / dt * 20 * n / 8e12 * 100:5.1f} % of 8 TB/s (20N B/frame algorithmic, 28N moved: state and output are both written)")
+    dt = timed(lambda: b.process_s16(pcm, None, ops), sync)
+    lines.append(f"config[2a'] same, spectra left in the gravity state (d_out = NULL, output == state): {streams / dt / 1e6:6.2f} M frames/s, "
+                 f"{streams / dt * 20 * n / 8e12 * 100:5.1f} % of 8 TB/s (20N B/frame, the traffic actually moved)")
     dt = timed(lambda: b.process_s16(pcm, dbars, ops | G.OP_BARS), sync)
     lines.append(f"config[2b] N=16384 x {streams} streams, FFT+gravity+radial bin averaging -> {bars} bars/channel: "
                  f"{streams / dt / 1e6:6.2f} M frames/s, {streams / dt * (20 * n + 640) / 8e12 * 100:5.1f} % of 8 TB/s "
-                 f"(20N+640 B/frame algorithmic; bars are computed from spectra in HBM, not fused)")
+                 f"(20N+640 B/frame algorithmic; the bars kernel re-reads the spectra from the gravity state: 28N moved)")
     b.close()
     del pcm, dbars, spec
 

@@ -257,6 +257,15 @@ GLV_HD float tilt(int n, float inv_n, float fft_scale, float one_minus_cutoff) {
     return t > 1.0f ? t : 1.0f;
 }
 
+// tilt as the kernels multiply it: log_mode 1 folds ln2/3 in (log2 -> log/3) with ONE float multiply,
+// the same expression on the host (glv_tables.h make_tilt) and on the device
+constexpr float kLn2Third = (float) (0.69314718055994530942 / 3.0);
+template <bool FOLD_LN2_3>
+GLV_HD float tilt_factor(int n, float inv_n, float fft_scale, float one_minus_cutoff) {
+    const float t = tilt(n, inv_n, fft_scale, one_minus_cutoff);
+    return FOLD_LN2_3 ? t * kLn2Third : t;
+}
+
 // render.c:730-734
 GLV_HD float gravity(float b, float applied, float g) {
     return (b >= applied ? b : applied) - g;

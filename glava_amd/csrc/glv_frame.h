@@ -265,7 +265,8 @@ struct Frame {
         return PASS == P - 1 ? tid * PassInfo<PASS>::NG + gi : gi * T + tid;
     }
 
-    template <int PASS>
+    // BIAS: `table` points at entry BIAS of the twiddle table (the LDS copy of the middle passes' range)
+    template <int PASS, int BIAS = 0>
     GLV_HD static void gather_tw(cf (&tw)[PassInfo<PASS>::NTW], const cf* table, int tid) {
         using PI = PassInfo<PASS>;
 #pragma unroll
@@ -276,7 +277,7 @@ struct Frame {
             for (int s = 0; s < PI::RB; ++s)
 #pragma unroll
                 for (int ks = 0; ks < (1 << s); ++ks)
-                    tw[gi * (PI::R - 1) + (1 << s) - 1 + ks] = table[SubPass<PI::RB>::tw_index(PI::L0, k0, s, ks)];
+                    tw[gi * (PI::R - 1) + (1 << s) - 1 + ks] = table[SubPass<PI::RB>::tw_index(PI::L0, k0, s, ks) - BIAS];
         }
     }
 
@@ -359,8 +360,9 @@ struct Frame {
                 tl[gi * PI::R + r] = ld<cf>(tilt, (uint32_t) out_index<P - 1>(tid, gi, r) * 8u);
     }
 
-    // TILTREG: tilt factors come from `tl` (registers, gathered once per kernel) instead of the table
-    template <int LOG_MODE, int EPI, bool TILTREG = false>
+    // TILTREG 0: tilt factors read from the table per row; 1: from `tl_reg` (registers, gathered once per
+    // kernel); 2: evaluated in registers with the reference's float operations (no memory at all)
+    template <int LOG_MODE, int EPI, int TILTREG = 0>
     GLV_HD static void epilogue(const cf (&v)[E], float* out_row, size_t row, int tid, const FrameArgs& a,
                                 const LogEntry* logtab, const cf* tl_reg = nullptr) {
         using PI = PassInfo<P - 1>;
@@ -372,7 +374,12 @@ struct Frame {
             if constexpr (EPI == EPI_MAG || EPI == EPI_MAG_STATE) {
                 const int q = out_index<P - 1>(tid, gi, r);     // = tid*NG + compile-time constant
                 const float y0 = __builtin_fabsf(val.x) + 1.0f, y1 = __builtin_fabsf(val.y) + 1.0f;   // render.c:843-844
-                const cf tl = TILTREG ? tl_reg[gi * PI::R + r] : ld<cf>(a.tilt, (uint32_t) q * 8u);        // :845 factors
+                cf tl;                                                                                      // :845 factors
+                if constexpr (TILTREG == 1) tl = tl_reg[gi * PI::R + r];
+                else if constexpr (TILTREG == 2) {
+                    tl.x = tilt_factor<LOG_MODE == 1>(2 * q, a.inv_n, a.fft_scale, a.one_minus_cutoff);
+                    tl.y = tilt_factor<LOG_MODE == 1>(2 * q + 1, a.inv_n, a.fft_scale, a.one_minus_cutoff);
+                } else tl = ld<cf>(a.tilt, (uint32_t) q * 8u);
                 val.x = log_third<LOG_MODE>(y0, logtab) * tl.x;
                 val.y = log_third<LOG_MODE>(y1, logtab) * tl.y;
             }

@@ -14,15 +14,15 @@ namespace glv {
 template <int LOG_NN> struct Tuned;
 #define GLV_TUNED(K, LE, S, NB, TR, WL, OC, PF, TL) \
     template <> struct Tuned<K> { static constexpr int log_e = LE, slots = S, nbuf = NB, occ = OC; \
-                                  static constexpr bool twreg = TR, winlds = WL, tiltreg = TL; static constexpr int prefetch = PF; };
+                                  static constexpr bool winlds = WL; static constexpr int twreg = TR, tiltreg = TL, prefetch = PF; };
 // measured best of tools/tune.py on MI355X (profiles/tune_r01.txt), equal bytes per size class:
-//         log2(nn) LOG_E SLOTS NBUF TWREG  WINLDS OCC PREFETCH TILTREG      (PREFETCH 1 = frame pipeline, 2 = row pipeline)
+//         log2(nn) LOG_E SLOTS NBUF TWREG  WINLDS OCC PREFETCH TILTREG      (knob values: glv_kernel_tmpl.h)
 GLV_TUNED(8,        4,    16,   1,   true,  true,  2,  1,       true)    // N=512    E=16: 4+4
 GLV_TUNED(9,        3,    4,    1,   true,  true,  4,  3,       true)    // N=1024   E=8:  3+3+3
 GLV_TUNED(10,       4,    2,    1,   true,  true,  2,  3,       true)    // N=2048   E=16: 4+4+2
 GLV_TUNED(11,       4,    2,    1,   true,  true,  2,  3,       true)    // N=4096   E=16: 4+4+3
 GLV_TUNED(12,       4,    1,    1,   true,  false, 2,  3,       true)    // N=8192   E=16: 4+4+4 (window 64 KiB: via L2)
-GLV_TUNED(13,       5,    1,    1,   false, false, 2,  3,       false)   // N=16384  E=32: 5+5+3 (68 KiB exchange region, 2 rows per CU in flight)
+GLV_TUNED(13,       5,    1,    1,   3,     false, 2,  3,       2)       // N=16384  E=32: 5+5+3; pass-1 twiddles from an 8 KiB LDS table, tilt computed
 #undef GLV_TUNED
 
 #define GLV_CAT2(a, b) a##b

@@ -20,8 +20,11 @@
 //   SLOTS   FFT slots per workgroup
 //   NBUF    1: one LDS exchange region per slot, two barriers per exchange
 //           2: ping-pong regions, one barrier per exchange
-//   TWREG   true: passes >= 1 keep their per-lane twiddles in VGPRs across frames
-//           false: gathered from the (L2-resident) table at every pass
+//   TWREG   1 (true): passes >= 1 keep their per-lane twiddles in VGPRs across frames
+//           0 (false): gathered from the (L2-resident) table at every pass
+//           2: middle passes gather from an LDS copy of their table range (entries E-1 .. L0_last-2: 8 KiB
+//              for N=16384 at 32 points per lane), the last pass from the L2-resident table
+//           3: middle passes from LDS, the last pass resident in VGPRs
 //   WINLDS  true: window table staged once per workgroup into LDS; false: read through L1/L2
 //   OCC     __launch_bounds__ minimum waves per SIMD (caps the VGPR budget: 512 / OCC)
 //   TILTREG   the 32 per-lane tilt factors stay in VGPRs across rows instead of being re-read per row
@@ -36,10 +39,19 @@
 
 namespace glv {
 
-template <int LOG_NN, int LOG_E, int NBUF, bool TWREG>
+template <int LOG_NN, int LOG_E, int NBUF, int TWREG>
 struct Body {
     using FR = Frame<LOG_NN, LOG_E>;
     static constexpr int P = FR::P, NN = FR::NN, N = FR::N, T = FR::T;
+
+    // where the per-lane twiddles of pass Q (>= 1) come from
+    static constexpr bool TW_LDS_MODE = TWREG >= 2 && P >= 3;
+    static constexpr bool is_mid(int q) { return q >= 1 && q < P - 1; }
+    static constexpr bool from_lds(int q) { return TW_LDS_MODE && is_mid(q); }
+    static constexpr bool resident(int q) { return q >= 1 && (TWREG == 1 || (TWREG >= 2 && !TW_LDS_MODE) || (TWREG == 3 && q == P - 1)); }
+    // LDS copy: table entries [LDS_BIAS, LDS_BIAS + LDS_ENTRIES) = the stages of passes 1..P-2
+    static constexpr int LDS_BIAS = FR::E - 1;
+    static constexpr int LDS_ENTRIES = TW_LDS_MODE ? (1 << FR::PL::log_l0(P - 1)) - FR::E : 0;
 
     template <int PASS>
     static constexpr int tw_off() {
@@ -64,10 +76,17 @@ struct Body {
         }
     }
 
+    // once per kernel: the passes whose twiddles stay in VGPRs
     template <int PASS>
-    static __device__ __forceinline__ void gather_from(cf* all, const cf* __restrict__ table, int tid) {
-        FR::template gather_tw<PASS>(tw_ref<PASS>(all), table, tid);
-        if constexpr (PASS + 1 < P) gather_from<PASS + 1>(all, table, tid);
+    static __device__ __forceinline__ void gather_resident(cf* all, const cf* __restrict__ table, int tid) {
+        if constexpr (resident(PASS)) FR::template gather_tw<PASS>(tw_ref<PASS>(all), table, tid);
+        if constexpr (PASS + 1 < P) gather_resident<PASS + 1>(all, table, tid);
+    }
+    // per row: the twiddles of a non-resident pass, from the LDS copy or the L2-resident table
+    template <int PASS>
+    static __device__ __forceinline__ void gather_transient(cf* all, const cf* __restrict__ table, const cf* lds_tw, int tid) {
+        if constexpr (from_lds(PASS)) FR::template gather_tw<PASS, LDS_BIAS>(tw_ref<PASS>(all), lds_tw, tid);
+        else if constexpr (!resident(PASS)) FR::template gather_tw<PASS>(tw_ref<PASS>(all), table, tid);
     }
 
     // passes PASS..P-1 on the 16 register-resident points; `xcount` counts exchanges so the
@@ -76,7 +95,7 @@ struct Body {
     // so that the backend cannot pull the table loads of later passes (30 VGPRs each) up front.
     template <int PASS>
     static __device__ __forceinline__ void run(cf (&v)[FR::E], cf* tw_all, const cf* __restrict__ table,
-                                               char* xslot, int tid, unsigned& xcount) {
+                                               char* xslot, int tid, unsigned& xcount, const cf* lds_tw = nullptr) {
         // pass 0's twiddles are the same for every lane (k0 = 0); the kernel gathers them once, before
         // the row loop, into scalar registers (gather_uniform_tw0) -- a vector load here would sit in
         // front of every row's first butterfly AND, vmcnt being in-order, behind the PCM prefetch.
@@ -92,14 +111,14 @@ struct Body {
 #endif
             FR::template exchange_write<PASS>(xb, v, tid);
             // the next pass's per-lane twiddles travel from L2 while the exchange settles
-            if constexpr (!TWREG) FR::template gather_tw<PASS + 1>(tw_ref<PASS + 1>(tw_all), table, tid);
+            gather_transient<PASS + 1>(tw_all, table, lds_tw, tid);
 #if !defined(GLV_EXP_NOBARRIER)
             __syncthreads();
 #endif
             FR::template exchange_read<PASS + 1>(v, xb, tid);
             GLV_SCHED_FENCE();
             ++xcount;
-            run<PASS + 1>(v, tw_all, table, xslot, tid, xcount);
+            run<PASS + 1>(v, tw_all, table, xslot, tid, xcount, lds_tw);
         }
     }
 };
@@ -111,7 +130,7 @@ static __device__ __forceinline__ uint32_t maybe_scalar(uint32_t v) {
     else return v;
 }
 
-template <int LOG_NN, int IN_MODE, int LOG_MODE, int SLOTS, int NBUF, bool TWREG, bool WINLDS, int OCC, int PREFETCH, bool TILTREG,
+template <int LOG_NN, int IN_MODE, int LOG_MODE, int SLOTS, int NBUF, int TWREG, bool WINLDS, int OCC, int PREFETCH, int TILTREG,
           int LOG_E, bool STATEFUL>
 __global__ void __launch_bounds__((Frame<LOG_NN, LOG_E>::T * SLOTS), OCC)
 glv_frame_kernel(const FrameArgs a) {
@@ -147,11 +166,20 @@ glv_frame_kernel(const FrameArgs a) {
         logtab = reinterpret_cast<const LogEntry*>(llog);
     }
 
+    // TWREG >= 2: the twiddle table range of the middle passes is staged into LDS once per workgroup
+    const cf* lds_tw = nullptr;
+    if constexpr (BD::TW_LDS_MODE) {
+        char* ltw = smem + (size_t) SLOTS * NBUF * XBYTES + (WINLDS ? (size_t) N * sizeof(double) : 0) + kLogTabSize * sizeof(LogEntry);
+        for (int i = threadIdx.x; i < BD::LDS_ENTRIES; i += T * SLOTS) st<cf>(ltw, (uint32_t) i * 8u, ld<cf>(a.tw, (uint32_t) (BD::LDS_BIAS + i) * 8u));
+        __syncthreads();
+        lds_tw = reinterpret_cast<const cf*>(ltw);
+    }
+
     cf tw_all[BD::TW_TOTAL];
     BD::gather_uniform_tw0(tw_all, a.tw);
-    if constexpr (TWREG && FR::P > 1) BD::template gather_from<1>(tw_all, a.tw, tid);
-    cf tilt_reg[TILTREG ? E : 1];
-    if constexpr (TILTREG) FR::gather_tilt(tilt_reg, a.tilt, tid);
+    if constexpr (FR::P > 1) BD::template gather_resident<1>(tw_all, a.tw, tid);
+    cf tilt_reg[TILTREG == 1 ? E : 1];
+    if constexpr (TILTREG == 1) FR::gather_tilt(tilt_reg, a.tilt, tid);
 
     // operator chain, uniform for the launch.  Stateless and stateful chains are separate kernels
     // (STATEFUL): the history loads of gravity/average need ~60 more VGPRs in the epilogue, and having
@@ -234,7 +262,7 @@ glv_frame_kernel(const FrameArgs a) {
             const uint32_t f = frame_of(m);
             if (ch) FR::template load_pcm<RING>(raw, frame_ptr(frame_of(m + 1)), tid, a.rot);   // A (clamped past the end)
             GLV_SCHED_FENCE();
-            BD::template run<0>(v, tw_all, a.tw, xslot, tid, xcount);                            // B
+            BD::template run<0>(v, tw_all, a.tw, xslot, tid, xcount, lds_tw);                            // B
             GLV_SCHED_FENCE();
             FR::unpack_window(vn, raw, win, tid, ch ^ 1u, a.mono != 0);                          // C
             GLV_SCHED_FENCE();
@@ -285,7 +313,7 @@ glv_frame_kernel(const FrameArgs a) {
             const uint32_t f = frame_of(m);
             if (ch) FR::template load_pcm<RING>(raw, frame_ptr(frame_of(m + 1)), tid, a.rot);   // A
             GLV_SCHED_FENCE();
-            BD::template run<0>(v, tw_all, a.tw, xslot, tid, xcount);                            // B
+            BD::template run<0>(v, tw_all, a.tw, xslot, tid, xcount, lds_tw);                            // B
             GLV_SCHED_FENCE();
             __builtin_amdgcn_s_waitcnt(0x0F70);                                                  // W
             if (active) finish(v, (size_t) f * 2 + ch, tid);                                     // D
@@ -324,7 +352,7 @@ glv_frame_kernel(const FrameArgs a) {
             const uint32_t row_n = row_of(has_next ? nb : base);
             FR::template load_pcm<RING>(raw, pcm_ptr(row_n), tid, a.rot);                        // A (unconditional)
             GLV_SCHED_FENCE();
-            BD::template run<0>(v, tw_all, a.tw, xslot, tid, xcount);                            // B
+            BD::template run<0>(v, tw_all, a.tw, xslot, tid, xcount, lds_tw);                            // B
             GLV_SCHED_FENCE();
             FR::unpack_window(vn, raw, win, tid, row_n & 1u, a.mono != 0);                       // C
             GLV_SCHED_FENCE();
@@ -359,22 +387,22 @@ glv_frame_kernel(const FrameArgs a) {
         } else {
             FR::load_f32_window(v, static_cast<const char*>(a.in) + (size_t) row * ((size_t) N * 4), win, tid);
         }
-        BD::template run<0>(v, tw_all, a.tw, xslot, tid, xcount);
+        BD::template run<0>(v, tw_all, a.tw, xslot, tid, xcount, lds_tw);
         if (active) finish(v, (size_t) row, tid);
     }
 }
 
-template <int LOG_NN, int LOG_E, int SLOTS, int NBUF, bool WINLDS>
+template <int LOG_NN, int LOG_E, int SLOTS, int NBUF, bool WINLDS, int TWREG = 0>
 constexpr size_t frame_lds_bytes() {
     return (size_t) SLOTS * NBUF * Frame<LOG_NN, LOG_E>::XREGION * sizeof(cf) + (WINLDS ? (size_t) Frame<LOG_NN, LOG_E>::N * sizeof(double) : 0)
-           + kLogTabSize * sizeof(LogEntry);
+           + kLogTabSize * sizeof(LogEntry) + (size_t) Body<LOG_NN, LOG_E, NBUF, TWREG>::LDS_ENTRIES * sizeof(cf);
 }
 
-template <int LOG_NN, int IN_MODE, int LOG_MODE, int SLOTS, int NBUF, bool TWREG, bool WINLDS, int OCC, int PREFETCH, bool TILTREG,
+template <int LOG_NN, int IN_MODE, int LOG_MODE, int SLOTS, int NBUF, int TWREG, bool WINLDS, int OCC, int PREFETCH, int TILTREG,
           int LOG_E = 4>
 hipError_t launch_variant(const FrameArgs& a, int grid, hipStream_t st) {
     using FR = Frame<LOG_NN, LOG_E>;
-    constexpr size_t lds = frame_lds_bytes<LOG_NN, LOG_E, SLOTS, NBUF, WINLDS>();
+    constexpr size_t lds = frame_lds_bytes<LOG_NN, LOG_E, SLOTS, NBUF, WINLDS, TWREG>();
     static_assert(lds <= 160 * 1024, "exchange regions + window exceed the 160 KiB LDS of a gfx950 CU");
     auto launch = [&](auto k, bool& attr_done) -> hipError_t {
         if (lds > 64 * 1024 && !attr_done) {
@@ -387,8 +415,10 @@ hipError_t launch_variant(const FrameArgs& a, int grid, hipStream_t st) {
         return hipGetLastError();
     };
     static bool done_plain = false, done_state = false;   // per instantiation
+    // the stateful epilogue needs the registers a resident last pass (TWREG 3) would occupy
+    constexpr int TW_STATEFUL = TWREG == 3 ? 2 : TWREG;
     if (a.ops & (OP_GRAVITY | OP_AVERAGE))
-        return launch(glv_frame_kernel<LOG_NN, IN_MODE, LOG_MODE, SLOTS, NBUF, TWREG, WINLDS, OCC, PREFETCH, TILTREG, LOG_E, true>, done_state);
+        return launch(glv_frame_kernel<LOG_NN, IN_MODE, LOG_MODE, SLOTS, NBUF, TW_STATEFUL, WINLDS, OCC, PREFETCH, TILTREG, LOG_E, true>, done_state);
     return launch(glv_frame_kernel<LOG_NN, IN_MODE, LOG_MODE, SLOTS, NBUF, TWREG, WINLDS, OCC, PREFETCH, TILTREG, LOG_E, false>, done_plain);
 }
 

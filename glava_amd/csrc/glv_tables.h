@@ -70,8 +70,7 @@ inline void make_tilt(float* t, size_t n, float fft_scale, float fft_cutoff, boo
     const float inv_n = 1.0f / (float) n;              // n is a power of two: exact
     const float omc = 1.0F - fft_cutoff;
     for (size_t i = 0; i < n; ++i) {
-        const float tl = tilt((int) i, inv_n, fft_scale, omc);
-        t[i] = fold_ln2_3 ? (float) ((double) tl * (0.69314718055994530942 / 3.0)) : tl;
+        t[i] = fold_ln2_3 ? tilt_factor<true>((int) i, inv_n, fft_scale, omc) : tilt_factor<false>((int) i, inv_n, fft_scale, omc);
     }
 }
 

@@ -20,7 +20,7 @@ struct Variant {
     int slots;
 };
 
-template <int SLOTS, int NBUF, bool TWREG, bool WINLDS, int OCC, int PF = 0, bool TL = false, int LE = 4>
+template <int SLOTS, int NBUF, int TWREG, bool WINLDS, int OCC, int PF = 0, int TL = 0, int LE = 4>
 hipError_t launch_v(int in_mode, int log_mode, const FrameArgs& a, int grid, hipStream_t st) {
     constexpr int K = GLV_TUNE_LOG_NN;
     if (in_mode != IN_S16_STEREO) return hipErrorInvalidValue;

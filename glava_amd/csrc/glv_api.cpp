@@ -153,6 +153,9 @@ struct glv_batch {
     float smooth_d = -1.f, smooth_r = -1.f;
     glv::BarDesc* d_bar_desc = nullptr;   // GLV_OP_BARS tap tables (host generated)
     float* d_bar_w = nullptr;
+    glv::BarItem* d_bar_items = nullptr;    // work lists for glv_bars_kernel (16 groups per row)
+    glv::BarItem* d_bar_fitems = nullptr;   // work lists for the fused epilogue (lanes/16 groups per row)
+    uint32_t bar_nsteps = 0, bar_fnsteps = 0; bool bar_fusable = false;
     uint32_t bar_count = 0; float bar_factor = -1.f;
     // timing
     bool timing = false;
@@ -236,7 +239,25 @@ int ensure_bar_tables(glv_batch* b) {
     if (b->d_bar_desc) { (void) hipFree(b->d_bar_desc); b->d_bar_desc = nullptr; }
     if (b->d_bar_w) { (void) hipFree(b->d_bar_w); b->d_bar_w = nullptr; }
     HIP_TRY(hipMalloc(&b->d_bar_desc, sizeof(glv::BarDesc) * desc.size()));
-    HIP_TRY(hipMalloc(&b->d_bar_w, sizeof(float) * (w.size() + 1)));
+    // work lists: 16 groups per row for glv_bars_kernel; T/16 groups for the frame kernel of this size
+    // (fused bars: whole waves per row, one bar per lane of the row at most).  kBarChunk zero weights
+    // appended for padding items.
+    const uint32_t zero_off = (uint32_t) w.size();
+    w.resize(w.size() + glv::kBarChunk, 0.0f);
+    const int lanes = glv::frame_lanes(b->log_nn);
+    std::vector<glv::BarItem> items, fitems;
+    b->bar_nsteps = glv::make_bar_items(items, desc, 16, zero_off);
+    b->bar_fusable = lanes % 64 == 0 && b->p.bars <= (uint32_t) lanes;
+    if (b->bar_fusable) b->bar_fnsteps = glv::make_bar_items(fitems, desc, (uint32_t) lanes / 16, zero_off);
+    if (b->d_bar_items) { (void) hipFree(b->d_bar_items); b->d_bar_items = nullptr; }
+    if (b->d_bar_fitems) { (void) hipFree(b->d_bar_fitems); b->d_bar_fitems = nullptr; }
+    HIP_TRY(hipMalloc(&b->d_bar_items, sizeof(glv::BarItem) * items.size()));
+    HIP_TRY(hipMemcpy(b->d_bar_items, items.data(), sizeof(glv::BarItem) * items.size(), hipMemcpyHostToDevice));
+    if (b->bar_fusable) {
+        HIP_TRY(hipMalloc(&b->d_bar_fitems, sizeof(glv::BarItem) * fitems.size()));
+        HIP_TRY(hipMemcpy(b->d_bar_fitems, fitems.data(), sizeof(glv::BarItem) * fitems.size(), hipMemcpyHostToDevice));
+    }
+    HIP_TRY(hipMalloc(&b->d_bar_w, sizeof(float) * w.size()));
     HIP_TRY(hipMemcpy(b->d_bar_desc, desc.data(), sizeof(glv::BarDesc) * desc.size(), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(b->d_bar_w, w.data(), sizeof(float) * w.size(), hipMemcpyHostToDevice));
     b->bar_count = b->p.bars; b->bar_factor = b->p.smooth_factor;
@@ -262,9 +283,19 @@ int process(glv_batch* b, const void* d_in, int in_mode, float* d_out, unsigned 
     if ((ops & GLV_OP_BARS) && (b->p.bars == 0 || b->p.bars > b->p.n)) return fail(GLV_ERR_INVALID, "bars=%u out of range", b->p.bars);
     float* d_final = d_out;
     HIP_TRY(hipSetDevice(b->device));
-    if (ops & GLV_OP_BARS) {                       // d_out receives the bars; the spectra stay internal:
-        if (state_is_output) d_out = nullptr;      //   in the gravity state when the chain ends in gravity,
-        else {                                     //   in a scratch buffer otherwise
+    // GLV_OP_BARS: d_out receives the bars.  Stateful FFT chains whose rows are owned by whole waves compute
+    // them inside the frame kernel from the finished row in LDS (the spectra never reach HBM, apart from
+    // the state the operators keep anyway); otherwise the spectra stay internal -- in the gravity state
+    // when the chain ends in gravity, in a scratch buffer else -- and glv_bars_kernel runs after.
+    bool fused_bars = (ops & GLV_OP_BARS) && (ops & GLV_OP_FFT) && (ops & (GLV_OP_GRAVITY | GLV_OP_AVERAGE)) && !(ops & GLV_OP_SMOOTH);
+    if (fused_bars) {
+        if (int rc = ensure_bar_tables(b)) return rc;
+        fused_bars = b->bar_fusable                // whole waves per row, at most one bar per lane of the row
+                     && !std::getenv("GLV_UNFUSED_BARS");   // diagnostics: force the two-kernel path
+    }
+    if (ops & GLV_OP_BARS) {
+        if (fused_bars || state_is_output) d_out = nullptr;
+        else {
             if (!b->d_scratch) HIP_TRY(hipMalloc(&b->d_scratch, sizeof(float) * (size_t) b->streams * 2 * b->p.n));
             d_out = b->d_scratch;
         }
@@ -275,6 +306,10 @@ int process(glv_batch* b, const void* d_in, int in_mode, float* d_out, unsigned 
     fill_common(a, b->p, b->tab);
     a.in = d_in; a.out = d_out; a.grav = b->d_grav; a.hist = b->d_hist;
     a.units = units; a.ops = ops; a.head = b->head; a.rot = rot; a.log_mode = b->p.log_mode;
+    if (fused_bars) {
+        a.bar_desc = b->d_bar_desc; a.bar_items = b->d_bar_fitems; a.bar_nsteps = b->bar_fnsteps; a.bar_w = b->d_bar_w;
+        a.bars = b->p.bars; a.bars_out = d_final;
+    }
 
     if (int rc = timed_launch_begin(b, st)) return rc;
     hipError_t e;
@@ -300,9 +335,9 @@ int process(glv_batch* b, const void* d_in, int in_mode, float* d_out, unsigned 
         e = glv::launch_smooth(d_out, units, b->p.n, b->d_smin, b->d_smax, b->smooth_asz, st);
         if (e != hipSuccess) return fail(GLV_ERR_HIP, "smooth launch failed: %s", hipGetErrorString(e));
     }
-    if (ops & GLV_OP_BARS) {
+    if ((ops & GLV_OP_BARS) && !fused_bars) {
         if (int rc = ensure_bar_tables(b)) return rc;
-        e = glv::launch_bars(d_out ? d_out : b->d_grav, d_final, units, b->p.n, b->p.bars, b->d_bar_desc, b->d_bar_w, st);
+        e = glv::launch_bars(d_out ? d_out : b->d_grav, d_final, units, b->p.n, b->p.bars, b->bar_nsteps, b->d_bar_items, b->d_bar_desc, b->d_bar_w, st);
         if (e != hipSuccess) return fail(GLV_ERR_HIP, "bars launch failed: %s", hipGetErrorString(e));
     }
     return GLV_OK;
@@ -388,6 +423,8 @@ int glv_batch_destroy(glv_batch* b) {
     if (b->d_smax) (void) hipFree(b->d_smax);
     if (b->d_bar_desc) (void) hipFree(b->d_bar_desc);
     if (b->d_bar_w) (void) hipFree(b->d_bar_w);
+    if (b->d_bar_items) (void) hipFree(b->d_bar_items);
+    if (b->d_bar_fitems) (void) hipFree(b->d_bar_fitems);
     for (hipEvent_t e : b->ev) (void) hipEventDestroy(e);
     delete b;
     return GLV_OK;
@@ -448,7 +485,8 @@ int glv_batch_bars(glv_batch* b, const float* d_spec, float* d_bars, void* hip_s
     if (b->p.bars == 0 || b->p.bars > b->p.n) return fail(GLV_ERR_INVALID, "bars=%u out of range", b->p.bars);
     HIP_TRY(hipSetDevice(b->device));
     if (int rc = ensure_bar_tables(b)) return rc;
-    hipError_t e = glv::launch_bars(d_spec, d_bars, (size_t) b->streams * 2, b->p.n, b->p.bars, b->d_bar_desc, b->d_bar_w, (hipStream_t) hip_stream);
+    hipError_t e = glv::launch_bars(d_spec, d_bars, (size_t) b->streams * 2, b->p.n, b->p.bars, b->bar_nsteps, b->d_bar_items, b->d_bar_desc, b->d_bar_w,
+                                    (hipStream_t) hip_stream);
     if (e != hipSuccess) return fail(GLV_ERR_HIP, "bars launch failed: %s", hipGetErrorString(e));
     return GLV_OK;
 }

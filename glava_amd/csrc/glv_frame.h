@@ -27,6 +27,11 @@ enum : uint32_t { OP_FFT = 1u, OP_GRAVITY = 2u, OP_AVERAGE = 4u, OP_RAW = 8u, OP
 // one output bar of GLV_OP_BARS: taps are consecutive bins [first_bin, first_bin + count) with weights
 // tap_w[tap_offset ...]; weight_sum = float sum of the weights in tap order (smooth.glsl:31-36)
 struct BarDesc { uint32_t first_bin, count, tap_offset; float weight_sum; };
+// One work item of GLV_OP_BARS: a chunk of kBarChunk = 64 consecutive taps of one bar, taken by one group of
+// 16 lanes.  pack = index of the chunk's first tap in the row | bar index << 15 | (bar ends here) << 30;
+// w_off = offset of the chunk's 64 weights (zero-padded by make_bar_taps; an all-zero block for padding
+// items, which therefore add exactly 0).
+struct BarItem { uint32_t w_off, pack; };
 
 struct FrameArgs {
     const void* in;        // s16: int16 [units/2][n][2] (a unit is one channel row of a frame);  f32 planar: float [units][n];
@@ -48,7 +53,69 @@ struct FrameArgs {
     uint32_t rot;          // s16 ring mode (RING kernels): rotation of the window start, in complex points
     float inv_n, fft_scale, one_minus_cutoff, g, F_as_float;
     double wts[16];        // window_frame weights, oldest first (render.c:661 as expanded at :766)
+    // fused GLV_OP_BARS (stateful kernels, lanes-per-row a multiple of 64): the finished row goes to the
+    // slot's LDS region instead of HBM and only the bars leave the chip
+    const BarDesc* bar_desc;
+    const BarItem* bar_items;   // [bar_nsteps + kBarBatch][groups] work lists (glv_tables.h make_bar_items), groups = T/16
+    const float* bar_w;
+    float* bars_out;            // [units][bars], nullptr = not fused
+    uint32_t bars;
+    uint32_t bar_nsteps;        // multiple of kBarBatch
 };
+
+// ---- GLV_OP_BARS arithmetic (smooth.glsl:25-40; tex clamped to [0,1] like the GL_R16 texture the
+// shader samples, render.c:523) ---------------------------------------------------------------------
+// A bar's taps are cut into chunks of 64; a chunk is summed by a group of 16 lanes: lane l takes taps
+// l, l+16, l+32, l+48, adds its four products in that order, the group adds the 16 lane sums with a fixed
+// DPP pattern (quads, halves of 8, the two halves), and the chunk totals of a bar are added in chunk
+// order.  Which group of which wave takes a chunk does not enter the arithmetic, so the fused epilogue
+// (row in LDS, T/16 groups per row) and glv_bars_kernel (row in HBM, 16 groups per row) give the same
+// bits.  Small bars dominate (N=4096: 80 bars, 4591 taps, no bar above 191): one WAVE per bar, as in the
+// first version, spent ~100 instructions per bar on mostly idle lanes -- more than the transform itself.
+constexpr uint32_t kBarChunk = 64;
+constexpr int kBarBatch = 4;           // work-list steps whose loads are issued together
+struct BarTaps { float t[4], w[4]; };
+GLV_HD uint32_t bar_item_tex(const BarItem& it) { return it.pack & 0x7fffu; }
+GLV_HD uint32_t bar_item_bar(const BarItem& it) { return (it.pack >> 15) & 0x7fffu; }
+GLV_HD bool bar_item_last(const BarItem& it) { return ((it.pack >> 30) & 1u) != 0; }
+// sub = lane index within the group (0..15); n = floats per row (reads past the row are clamped into it:
+// their weights are zero)
+GLV_HD BarTaps bar_item_load(const float* tex_row, uint32_t n, const float* tap_w, const BarItem& it, int sub) {
+    BarTaps s;
+    const float* w = tap_w + it.w_off;
+    const uint32_t base = bar_item_tex(it);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const uint32_t idx = (uint32_t) sub + 16u * (uint32_t) i;
+        s.w[i] = w[idx];
+        const uint32_t q = base + idx;
+        s.t[i] = tex_row[q < n ? q : n - 1];
+    }
+    return s;
+}
+GLV_HD float bar_item_lane_sum(const BarTaps& s) {
+    float acc = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const float t = __builtin_fminf(__builtin_fmaxf(s.t[i], 0.0f), 1.0f);     // NaN -> 0 (v_max/v_min)
+        acc += t * s.w[i];
+    }
+    return acc;
+}
+#if defined(__HIPCC__)
+// sum over each group of 16 lanes (a DPP row), result in every lane of the group: VALU-speed cross-lane
+// adds (a ds_bpermute shuffle is an LDS round trip each)
+template <int CTRL> __device__ __forceinline__ float dpp_move(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, false));
+}
+__device__ __forceinline__ float group16_sum(float v) {
+    v = v + dpp_move<0xB1>(v);       // quad_perm [1,0,3,2]
+    v = v + dpp_move<0x4E>(v);       // quad_perm [2,3,0,1]
+    v = v + dpp_move<0x141>(v);      // row_half_mirror: the other quad of each 8
+    v = v + dpp_move<0x140>(v);      // row_mirror: the other half of the 16
+    return v;
+}
+#endif
 
 // ---- addressing -------------------------------------------------------------------------------
 // Every HBM/LDS access of a phase is `uniform base + 32-bit byte offset`, the offsets of the 16

@@ -57,6 +57,9 @@ hipError_t GLV_CAT(launch_frame_, GLV_LOG_NN)(int in_mode, int log_mode, const F
 // channel rows one workgroup takes per trip of its persistent loop (grid sizing): a pipelined s16
 // slot takes a whole frame (2 rows), a single-slot workgroup both rows of its frame in sequence; for
 // other inputs the figure only makes the grid slightly smaller than strictly necessary.
+// lanes that cooperate on one row (fused bars need whole waves per row)
+int GLV_CAT(frame_lanes_, GLV_LOG_NN)() { return Frame<GLV_LOG_NN, Tuned<GLV_LOG_NN>::log_e>::T; }
+
 int GLV_CAT(frame_slots_, GLV_LOG_NN)() {
     using TU = Tuned<GLV_LOG_NN>;
     return (TU::prefetch == 1 || TU::slots == 1) ? 2 * TU::slots : TU::slots;

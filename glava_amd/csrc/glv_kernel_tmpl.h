@@ -131,7 +131,7 @@ static __device__ __forceinline__ uint32_t maybe_scalar(uint32_t v) {
 }
 
 template <int LOG_NN, int IN_MODE, int LOG_MODE, int SLOTS, int NBUF, int TWREG, bool WINLDS, int OCC, int PREFETCH, int TILTREG,
-          int LOG_E, bool STATEFUL>
+          int LOG_E, int STATEFUL>
 __global__ void __launch_bounds__((Frame<LOG_NN, LOG_E>::T * SLOTS), OCC)
 glv_frame_kernel(const FrameArgs a) {
     using FR = Frame<LOG_NN, LOG_E>;
@@ -186,16 +186,74 @@ glv_frame_kernel(const FrameArgs a) {
     // them in the same kernel costs the plain FFT+magnitude pass 15-30 % (register allocation is per
     // kernel, not per path).
     const bool raw_out = (a.ops & OP_RAW) != 0;
+    // STATEFUL 0: no state (FFT + magnitude only)   1: gravity / average   2: gravity / average with the
+    // bars computed in the kernel (fused GLV_OP_BARS): the finished row is written to the slot's LDS
+    // exchange region (idle between a row's last exchange and the next row's first) instead of HBM.
+    constexpr bool FUSED_BARS = STATEFUL == 2;
+    static_assert(!FUSED_BARS || WAVE_SLOT, "fused bars need whole waves per row");
+    static_assert(!FUSED_BARS || NBUF == 1, "fused bars reuse exchange region 0: needs the two-barrier exchange");
     auto finish = [&](const cf (&v)[E], size_t row, int tid) {
         // a.out == nullptr (gravity without average only): the spectra ARE the gravity state
         // (render.c:733-734 stores the same value to both), so the second copy is not written
-        float* out_row = STATEFUL && a.out == nullptr ? nullptr : a.out + row * N;
-        if constexpr (STATEFUL) {
+        float* out_row = FUSED_BARS ? reinterpret_cast<float*>(xslot)
+                                    : (STATEFUL && a.out == nullptr ? nullptr : a.out + row * N);
+        if constexpr (STATEFUL != 0) {
             if (raw_out) FR::template epilogue<LOG_MODE, EPI_RAW_STATE>(v, out_row, row, tid, a, logtab);
             else FR::template epilogue<LOG_MODE, EPI_MAG_STATE, TILTREG>(v, out_row, row, tid, a, logtab, tilt_reg);
         } else {
             if (raw_out) FR::template epilogue<LOG_MODE, EPI_RAW>(v, out_row, row, tid, a, logtab);
             else FR::template epilogue<LOG_MODE, EPI_MAG, TILTREG>(v, out_row, row, tid, a, logtab, tilt_reg);
+        }
+    };
+    // FUSED_BARS: lane k of a slot stores bar k (bars <= T): its weight sum stays in a register
+    float bar_wsum = 1.0f;
+    if constexpr (FUSED_BARS) { if ((uint32_t) tid < a.bars) bar_wsum = a.bar_desc[tid].weight_sum; }
+    // the epilogue of one row; every lane of the workgroup calls it (barriers inside when FUSED_BARS)
+    auto finish_row = [&](const cf (&v)[E], size_t row, int tid, bool active) {
+        if constexpr (FUSED_BARS) {
+            __syncthreads();                               // every reader of the row's last exchange is done
+            if (active) finish(v, row, tid);               // finished row -> LDS, natural order
+            __syncthreads();
+            // T/16 groups of 16 lanes work through the row's bar chunks (glv_frame.h "GLV_OP_BARS
+            // arithmetic"; work lists from make_bar_items).  kBarBatch steps at a time: their loads (LDS
+            // row + L2-resident weights) are issued together and the next batch's items are fetched
+            // while the current one is reduced.  No global store inside the loop (vmcnt is one in-order
+            // counter): bar totals collect in the slack behind the row; after a barrier the slot's lanes
+            // divide by the weight sums and store the bars coalesced.
+            constexpr uint32_t G = T / 16;
+            float* lrow = reinterpret_cast<float*>(xslot);
+            float* lres = lrow + N;                                       // XREGION has NN/E points (2T floats) of slack
+            if (active) {
+                const int sub = tid & 15;
+                const uint32_t g = (uint32_t) tid >> 4;
+                const BarItem* items = a.bar_items + g;
+                BarItem it[kBarBatch];
+#pragma unroll
+                for (int b = 0; b < kBarBatch; ++b) it[b] = items[(size_t) b * G];
+                float total = 0.0f;
+                for (uint32_t s0 = 0; s0 < a.bar_nsteps; s0 += kBarBatch) {
+                    BarTaps tp[kBarBatch];
+                    BarItem nx[kBarBatch];
+#pragma unroll
+                    for (int b = 0; b < kBarBatch; ++b) tp[b] = bar_item_load(lrow, (uint32_t) N, a.bar_w, it[b], sub);
+#pragma unroll
+                    for (int b = 0; b < kBarBatch; ++b) nx[b] = items[(size_t) (s0 + kBarBatch + b) * G];   // table has one batch of padding
+#pragma unroll
+                    for (int b = 0; b < kBarBatch; ++b) {
+                        total += group16_sum(bar_item_lane_sum(tp[b]));
+                        const bool last = bar_item_last(it[b]);
+                        if (last && sub == 0) lres[bar_item_bar(it[b])] = total;
+                        total = last ? 0.0f : total;
+                    }
+#pragma unroll
+                    for (int b = 0; b < kBarBatch; ++b) it[b] = nx[b];
+                }
+            }
+            __syncthreads();
+            if (active && (uint32_t) tid < a.bars) a.bars_out[row * a.bars + (uint32_t) tid] = lres[tid] / bar_wsum;
+            // the next row's first exchange write is preceded by a barrier (NBUF == 1): the bars readers are safe
+        } else {
+            if (active) finish(v, row, tid);
         }
     };
     // row handled by this slot in the iteration that starts at `base` (idle slots clamp to the last
@@ -266,7 +324,7 @@ glv_frame_kernel(const FrameArgs a) {
             GLV_SCHED_FENCE();
             FR::unpack_window(vn, raw, win, tid, ch ^ 1u, a.mono != 0);                          // C
             GLV_SCHED_FENCE();
-            if (active) finish(v, (size_t) f * 2 + ch, tid);                                     // D
+            finish_row(v, (size_t) f * 2 + ch, tid, active);                                     // D
             // (swapping the roles of v/vn by unrolling twice doubles the loop body and pushed the fp64-log
             //  variant into heavy spilling; 32 v_mov per row are the cheaper price)
 #pragma unroll
@@ -316,7 +374,7 @@ glv_frame_kernel(const FrameArgs a) {
             BD::template run<0>(v, tw_all, a.tw, xslot, tid, xcount, lds_tw);                            // B
             GLV_SCHED_FENCE();
             __builtin_amdgcn_s_waitcnt(0x0F70);                                                  // W
-            if (active) finish(v, (size_t) f * 2 + ch, tid);                                     // D
+            finish_row(v, (size_t) f * 2 + ch, tid, active);                                     // D
             GLV_SCHED_FENCE();
             FR::unpack_window(v, raw, win, tid, ch ^ 1u, a.mono != 0);                           // C
         }
@@ -356,7 +414,7 @@ glv_frame_kernel(const FrameArgs a) {
             GLV_SCHED_FENCE();
             FR::unpack_window(vn, raw, win, tid, row_n & 1u, a.mono != 0);                       // C
             GLV_SCHED_FENCE();
-            if (active) finish(v, (size_t) row, tid);                                            // D
+            finish_row(v, (size_t) row, tid, active);                                            // D
 #pragma unroll
             for (int i = 0; i < E; ++i) v[i] = vn[i];
         }
@@ -388,7 +446,7 @@ glv_frame_kernel(const FrameArgs a) {
             FR::load_f32_window(v, static_cast<const char*>(a.in) + (size_t) row * ((size_t) N * 4), win, tid);
         }
         BD::template run<0>(v, tw_all, a.tw, xslot, tid, xcount, lds_tw);
-        if (active) finish(v, (size_t) row, tid);
+        finish_row(v, (size_t) row, tid, active);
     }
 }
 
@@ -417,9 +475,16 @@ hipError_t launch_variant(const FrameArgs& a, int grid, hipStream_t st) {
     static bool done_plain = false, done_state = false;   // per instantiation
     // the stateful epilogue needs the registers a resident last pass (TWREG 3) would occupy
     constexpr int TW_STATEFUL = TWREG == 3 ? 2 : TWREG;
+    if (a.bars_out != nullptr) {
+        if constexpr (FR::T % 64 == 0) {
+            static bool done_bars = false;
+            if (!(a.ops & (OP_GRAVITY | OP_AVERAGE))) return hipErrorInvalidValue;
+            return launch(glv_frame_kernel<LOG_NN, IN_MODE, LOG_MODE, SLOTS, NBUF, TW_STATEFUL, WINLDS, OCC, PREFETCH, TILTREG, LOG_E, 2>, done_bars);
+        } else return hipErrorInvalidValue;
+    }
     if (a.ops & (OP_GRAVITY | OP_AVERAGE))
-        return launch(glv_frame_kernel<LOG_NN, IN_MODE, LOG_MODE, SLOTS, NBUF, TW_STATEFUL, WINLDS, OCC, PREFETCH, TILTREG, LOG_E, true>, done_state);
-    return launch(glv_frame_kernel<LOG_NN, IN_MODE, LOG_MODE, SLOTS, NBUF, TWREG, WINLDS, OCC, PREFETCH, TILTREG, LOG_E, false>, done_plain);
+        return launch(glv_frame_kernel<LOG_NN, IN_MODE, LOG_MODE, SLOTS, NBUF, TW_STATEFUL, WINLDS, OCC, PREFETCH, TILTREG, LOG_E, 1>, done_state);
+    return launch(glv_frame_kernel<LOG_NN, IN_MODE, LOG_MODE, SLOTS, NBUF, TWREG, WINLDS, OCC, PREFETCH, TILTREG, LOG_E, 0>, done_plain);
 }
 
 }  // namespace glv

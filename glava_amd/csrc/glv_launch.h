@@ -10,19 +10,21 @@ namespace glv {
 // per-size production launchers, one translation unit each (glv_inst.hip -DGLV_LOG_NN=k)
 #define GLV_DECL_INST(K) \
     hipError_t launch_frame_##K(int in_mode, int log_mode, const FrameArgs& a, int grid, hipStream_t st); \
-    int frame_slots_##K();
+    int frame_slots_##K(); \
+    int frame_lanes_##K();
 GLV_DECL_INST(8) GLV_DECL_INST(9) GLV_DECL_INST(10) GLV_DECL_INST(11) GLV_DECL_INST(12) GLV_DECL_INST(13)
 #undef GLV_DECL_INST
 
 // glv_misc.hip
 hipError_t launch_frame(int log_nn, int in_mode, int log_mode, const FrameArgs& a, int grid, hipStream_t st);
 int frame_slots(int log_nn);      // channel rows one workgroup takes per iteration of its persistent loop
+int frame_lanes(int log_nn);      // lanes cooperating on one row
 hipError_t launch_post(const FrameArgs& a, uint32_t n, hipStream_t st);
 hipError_t launch_bufscale(const float* in, float* out, size_t total_out, uint32_t k, hipStream_t st);
 hipError_t launch_lerp(const float* s0, const float* e0, float* out, size_t total, float mod, hipStream_t st);
 hipError_t launch_smooth(float* rows, size_t nrows, uint32_t n, const int* smin, const int* smax, uint32_t asz, hipStream_t st);
-hipError_t launch_bars(const float* spec, float* bars_out, size_t nrows, uint32_t n, uint32_t bars, const BarDesc* desc,
-                       const float* tap_w, hipStream_t st);
+hipError_t launch_bars(const float* spec, float* bars_out, size_t nrows, uint32_t n, uint32_t bars, uint32_t nsteps,
+                       const BarItem* items, const BarDesc* desc, const float* tap_w, hipStream_t st);
 hipError_t launch_unpack(const int16_t* pcm, size_t frames, int mono, float* l, float* r, hipStream_t st);
 
 }  // namespace glv

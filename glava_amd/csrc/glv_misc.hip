@@ -90,29 +90,35 @@ __global__ void __launch_bounds__(64) glv_smooth_kernel(float* __restrict__ rows
 // ---- smooth_audio() bar sampling (shaders/glava/util/smooth.glsl:13-40, radial/1.frag:58-70) --------
 // The tap positions and weights of a bar depend only on (bar, n, smooth_factor) -- not on the data -- so
 // they are generated once per batch on the host (glv_tables.h make_bar_taps: SAMPLE_MODE average,
-// ROUND_FORMULA sinusoidal, SAMPLE_SCALE 8, SAMPLE_RANGE 0.9).  One wave per (row, bar): lanes stride the
-// bar's taps (consecutive bins => coalesced), sum(tex * w) is reduced across the wave and divided by the
-// bar's weight sum.  tex is clamped to [0,1] like the GL_R16 texture the shader samples (render.c:523).
+// ROUND_FORMULA sinusoidal, SAMPLE_SCALE 8, SAMPLE_RANGE 0.9) together with the work lists
+// (make_bar_items).  One 256-thread workgroup = 16 groups of 16 lanes per row; arithmetic: glv_frame.h.
 __global__ void __launch_bounds__(256) glv_bars_kernel(const float* __restrict__ spec, float* __restrict__ bars_out,
-                                                       size_t nrows, uint32_t n, uint32_t bars,
-                                                       const BarDesc* __restrict__ desc, const float* __restrict__ tap_w) {
-    const size_t nwaves = (size_t) gridDim.x * blockDim.x / 64;
-    const int lane = threadIdx.x & 63;
-    for (size_t item = ((size_t) blockIdx.x * blockDim.x + threadIdx.x) / 64; item < nrows * bars; item += nwaves) {
-        const size_t row = item / bars;
-        const uint32_t k = (uint32_t) (item % bars);
-        const BarDesc d = desc[k];
-        const float* tex = spec + row * n + d.first_bin;
-        const float* w = tap_w + d.tap_offset;
-        float avg = 0.0f;
-        for (uint32_t j = lane; j < d.count; j += 64) {
-            float t = tex[j];
-            t = t < 0.0f ? 0.0f : (t > 1.0f ? 1.0f : t);
-            avg += t * w[j];
-        }
+                                                       size_t nrows, uint32_t n, uint32_t bars, uint32_t nsteps,
+                                                       const BarItem* __restrict__ items, const BarDesc* __restrict__ desc,
+                                                       const float* __restrict__ tap_w) {
+    constexpr uint32_t G = 16;
+    const int sub = threadIdx.x & 15;
+    const uint32_t g = threadIdx.x >> 4;
+    for (size_t row = blockIdx.x; row < nrows; row += gridDim.x) {
+        const float* tex = spec + row * n;
+        float total = 0.0f;
+        for (uint32_t s0 = 0; s0 < nsteps; s0 += kBarBatch) {
+            BarItem it[kBarBatch];
+            BarTaps tp[kBarBatch];
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) avg += __shfl_xor(avg, o);
-        if (lane == 0) bars_out[row * bars + k] = avg / d.weight_sum;
+            for (int b = 0; b < kBarBatch; ++b) it[b] = items[(size_t) (s0 + b) * G + g];
+#pragma unroll
+            for (int b = 0; b < kBarBatch; ++b) tp[b] = bar_item_load(tex, n, tap_w, it[b], sub);
+#pragma unroll
+            for (int b = 0; b < kBarBatch; ++b) {
+                total += group16_sum(bar_item_lane_sum(tp[b]));
+                if (bar_item_last(it[b])) {
+                    const uint32_t k = bar_item_bar(it[b]);
+                    if (sub == 0) bars_out[row * bars + k] = total / desc[k].weight_sum;
+                    total = 0.0f;
+                }
+            }
+        }
     }
 }
 
@@ -145,10 +151,10 @@ hipError_t launch_smooth(float* rows, size_t nrows, uint32_t n, const int* smin,
     hipLaunchKernelGGL(glv_smooth_kernel, dim3((unsigned) ((nrows + 63) / 64)), dim3(64), 0, st, rows, nrows, n, smin, smax, asz);
     return hipGetLastError();
 }
-hipError_t launch_bars(const float* spec, float* bars_out, size_t nrows, uint32_t n, uint32_t bars, const BarDesc* desc,
-                       const float* tap_w, hipStream_t st) {
-    const size_t waves = nrows * bars;                 // one wave per (row, bar) item, grid-stride beyond 256 CUs x 8 x 4 waves
-    hipLaunchKernelGGL(glv_bars_kernel, dim3(capped_grid(waves, 4)), dim3(256), 0, st, spec, bars_out, nrows, n, bars, desc, tap_w);
+hipError_t launch_bars(const float* spec, float* bars_out, size_t nrows, uint32_t n, uint32_t bars, uint32_t nsteps,
+                       const BarItem* items, const BarDesc* desc, const float* tap_w, hipStream_t st) {
+    const size_t g = nrows < 256 * 8 ? nrows : 256 * 8;     // one row per workgroup trip, grid-stride beyond
+    hipLaunchKernelGGL(glv_bars_kernel, dim3((unsigned) (g ? g : 1)), dim3(256), 0, st, spec, bars_out, nrows, n, bars, nsteps, items, desc, tap_w);
     return hipGetLastError();
 }
 
@@ -168,6 +174,14 @@ int frame_slots(int log_nn) {
     switch (log_nn) {
         case 8: return frame_slots_8(); case 9: return frame_slots_9(); case 10: return frame_slots_10();
         case 11: return frame_slots_11(); case 12: return frame_slots_12(); case 13: return frame_slots_13();
+    }
+    return 1;
+}
+
+int frame_lanes(int log_nn) {
+    switch (log_nn) {
+        case 8: return frame_lanes_8(); case 9: return frame_lanes_9(); case 10: return frame_lanes_10();
+        case 11: return frame_lanes_11(); case 12: return frame_lanes_12(); case 13: return frame_lanes_13();
     }
     return 1;
 }

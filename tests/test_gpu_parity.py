@@ -511,3 +511,26 @@ def test_gravity_state_as_output(G):
     with pytest.raises(G.GlvError):
         a.process_s16(d_pcm, None, G.OP_FFT)                     # no state to hold the output
     for x in (a, b, c): x.close()
+
+
+@pytest.mark.parametrize("n,F", [(16384, 0), (4096, 5), (512, 5)])
+def test_fused_bars_equal_unfused(G, n, F):
+    """GLV_OP_BARS inside the frame kernel (row in LDS, sizes whose rows are owned by whole waves) must
+    give the bits of glv_batch_bars on the same spectra; N=512 exercises the unfused fallback."""
+    import torch
+    streams, bars = 5, 80
+    ops = G.OP_FFT | G.OP_GRAVITY | (G.OP_AVERAGE if F else 0)
+    p = G.Params(n=n, bars=bars, avg_frames=max(F, 1), avg_window_kind=1)
+    a, b = G.Batch(p, streams, ops), G.Batch(p, streams, ops)
+    d_spec = torch.empty((streams * 2, n), dtype=torch.float32, device="cuda")
+    d_b1 = torch.empty((streams * 2, bars), dtype=torch.float32, device="cuda")
+    d_b2 = torch.full_like(d_b1, float("nan"))
+    for fr in range(max(F, 1) + 2):
+        d_pcm = torch.from_numpy((lcg_pcm_fast(77 + fr, streams * 2 * n) // 32).astype(np.int16)).cuda()
+        a.process_s16(d_pcm, d_spec, ops)
+        a.bars(d_spec, d_b1)
+        b.process_s16(d_pcm, d_b2, ops | G.OP_BARS)
+        torch.cuda.synchronize()
+        assert torch.equal(d_b1.view(torch.int32), d_b2.view(torch.int32)), fr
+    assert float(d_b1.abs().max()) > 0
+    a.close(); b.close()

@@ -94,7 +94,7 @@ def main():
     dt = timed(lambda: b.process_s16(pcm, dbars, ops | G.OP_BARS), sync)
     lines.append(f"config[2b] N=16384 x {streams} streams, FFT+gravity+radial bin averaging -> {bars} bars/channel: "
                  f"{streams / dt / 1e6:6.2f} M frames/s, {streams / dt * (20 * n + 640) / 8e12 * 100:5.1f} % of 8 TB/s "
-                 f"(20N+640 B/frame algorithmic; the bars kernel re-reads the spectra from the gravity state: 28N moved)")
+                 f"(20N+640 B/frame, the traffic actually moved: bars are computed in the frame kernel from the row in LDS)")
     b.close()
     del pcm, dbars, spec
 

@@ -246,3 +246,17 @@ class RefStream:
     def close(self):
         for s in self.gslot + self.aslot:
             Ref.lib().glvref_slot_free(C.byref(s))
+
+
+def tones_pcm(stream: int, n: int, frame: int = 0) -> np.ndarray:
+    """SURVEY.md 8d "tones" generator: interleaved stereo s16 frame `frame` (n samples per channel) of
+    stream `stream`: 8000 sin(2 pi f1 t/22050) + 4000 sin(2 pi f2 t/22050 + c), f1 = 110 * 2^((b mod 48)/12),
+    f2 = 3 f1, channel phase c in {0, 1}, plus LCG noise >> 6."""
+    t = np.arange(frame * n, (frame + 1) * n, dtype=np.float64)
+    f1 = 110.0 * 2.0 ** ((stream % 48) / 12.0)
+    noise = (lcg_pcm_fast(12345 + stream + 7919 * frame, 2 * n).astype(np.int32) >> 6).reshape(n, 2)
+    out = np.empty((n, 2), np.int32)
+    for c in range(2):
+        x = 8000.0 * np.sin(2 * np.pi * f1 * t / 22050.0) + 4000.0 * np.sin(2 * np.pi * 3 * f1 * t / 22050.0 + c)
+        out[:, c] = np.rint(x).astype(np.int32) + noise[:, c]
+    return np.clip(out, -32768, 32767).astype(np.int16).reshape(-1)

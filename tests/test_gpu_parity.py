@@ -534,3 +534,116 @@ def test_fused_bars_equal_unfused(G, n, F):
         assert torch.equal(d_b1.view(torch.int32), d_b2.view(torch.int32)), fr
     assert float(d_b1.abs().max()) > 0
     a.close(); b.close()
+
+
+# ---- more inputs / modes ------------------------------------------------------------------------------
+from oracle_lib import tones_pcm  # noqa: E402
+
+
+@pytest.mark.parametrize("n", [4096, 16384])
+def test_tones_chain_parity(G, n):
+    """SURVEY 8d "tones" PCM (harmonic, strongly peaked spectra -- the opposite of the noise worst case) through
+    fft -> gravity -> average, consecutive frames of continuous signals, every stream against the oracle."""
+    import torch
+    streams, F, nframes = 6, 5, 7
+    ops = G.OP_FFT | G.OP_GRAVITY | G.OP_AVERAGE
+    b = G.Batch(G.Params(n=n, avg_frames=F), streams, ops)
+    raw_b = G.Batch(G.Params(n=n), streams, G.OP_FFT)
+    sos = [StreamOracle(n, avg_frames=F) for _ in range(streams)]
+    d_out = torch.empty((streams * 2, n), dtype=torch.float32, device="cuda")
+    for fr in range(nframes):
+        pcm = np.concatenate([tones_pcm(40 * s + 3, n, fr) for s in range(streams)])
+        d_pcm = torch.from_numpy(pcm).cuda()
+        raw_b.process_s16(d_pcm, d_out, G.OP_FFT | G.OP_RAW)
+        raw = d_out.cpu().numpy()
+        b.process_s16(d_pcm, d_out, ops)
+        got = d_out.cpu().numpy()
+        for u in range(streams):
+            _, wraw = StreamOracle(n, gravity=False, average=False).frame(pcm[u * 2 * n:(u + 1) * 2 * n], want_raw=True)
+            assert (bits(raw[2 * u:2 * u + 2]) == bits(wraw)).all(), (fr, u)
+            want = sos[u].frame(pcm[u * 2 * n:(u + 1) * 2 * n])
+            assert np.allclose(got[2 * u:2 * u + 2], want, rtol=REL, atol=2e-6), (fr, u)
+    b.close(); raw_b.close()
+
+
+@pytest.mark.parametrize("n", [512, 1024, 2048, 4096, 8192, 16384])
+def test_single_stream_mono_and_extreme_inputs(G, n):
+    """streams = 1 (one workgroup, idle slots), mono mix (fifo.c:98-102), and edge PCM: silence (exact zeros out),
+    full-scale alternating +-32768/32767 (largest magnitudes the stage can see), DC."""
+    for ch in (2, 1):
+        for kind in ("noise", "zeros", "alt", "dc"):
+            if kind == "noise": pcm = lcg_pcm_fast(5 + n, 2 * n)
+            elif kind == "zeros": pcm = np.zeros(2 * n, np.int16)
+            elif kind == "alt": pcm = np.tile(np.array([-32768, 32767, 32767, -32768], np.int16), n // 2)
+            else: pcm = np.full(2 * n, -32768, np.int16)
+            raw = run_batch(G, G.Params(n=n, channels=ch), pcm, 1, G.OP_FFT | G.OP_RAW)
+            mag = run_batch(G, G.Params(n=n, channels=ch, log_mode=0), pcm, 1, G.OP_FFT)
+            fast = run_batch(G, G.Params(n=n, channels=ch), pcm, 1, G.OP_FFT)
+            want, wraw = StreamOracle(n, channels=ch, gravity=False, average=False).frame(pcm, want_raw=True)
+            assert (bits(raw) == bits(wraw)).all(), (ch, kind)
+            assert np.abs(bits(mag).astype(np.int64) - bits(want).astype(np.int64)).max() <= 1, (ch, kind)
+            assert rel_err(fast, want).max() <= REL, (ch, kind)
+            assert np.isfinite(fast).all()
+            if kind == "zeros": assert (bits(fast) == 0).all() and (bits(mag) == 0).all()
+
+
+def test_ring_mode_full_window_equals_frame_mode(G):
+    """A ring update that replaces the whole window (new_frames == n) must equal process_s16 on the same PCM,
+    through the stateful chain with fused bars as well."""
+    import torch
+    n, streams, bars = 4096, 5, 80
+    ops = G.OP_FFT | G.OP_GRAVITY | G.OP_AVERAGE
+    p = G.Params(n=n, bars=bars)
+    a, b = G.Batch(p, streams, ops), G.Batch(p, streams, ops)
+    oa = torch.empty((streams * 2, n), dtype=torch.float32, device="cuda"); ob = torch.empty_like(oa)
+    ba = torch.empty((streams * 2, bars), dtype=torch.float32, device="cuda"); bb = torch.empty_like(ba)
+    for fr in range(4):
+        d_pcm = torch.from_numpy(lcg_pcm_fast(321 + fr, streams * 2 * n) // 16).cuda()
+        if fr % 2 == 0:
+            a.process_s16(d_pcm, oa, ops); b.ring_update_s16(d_pcm, n, ob, ops)
+            torch.cuda.synchronize()
+            assert torch.equal(oa.view(torch.int32), ob.view(torch.int32)), fr
+        else:
+            a.process_s16(d_pcm, ba, ops | G.OP_BARS); b.ring_update_s16(d_pcm, n, bb, ops | G.OP_BARS)
+            torch.cuda.synchronize()
+            assert torch.equal(ba.view(torch.int32), bb.view(torch.int32)), fr
+    a.close(); b.close()
+
+
+def test_config2_full_size_gravity_bars_subset(G):
+    """configs[2]: N=16384, 8192 streams, fft + gravity + radial bin averaging (80 bars/channel), fused in the frame
+    kernel.  Two updates; a random subset of streams against the oracle chain (spectra via d_out=NULL state, bars
+    via the restatement of smooth.glsl); every bar written."""
+    import torch, ctypes
+    n, streams, bars = 16384, 8192, 80
+    ops = G.OP_FFT | G.OP_GRAVITY
+    b = G.Batch(G.Params(n=n, bars=bars), streams, ops)
+    d_bars = torch.full((streams * 2, bars), float("nan"), dtype=torch.float32, device="cuda")
+    rng = np.random.default_rng(3)
+    subset = np.unique(np.concatenate([rng.integers(0, streams, 24), [0, streams - 1]]))
+    idx = torch.from_numpy(subset).cuda()
+    grav = {int(s): np.zeros((2, n), np.float32) for s in subset}
+    hip = ctypes.CDLL("libamdhip64.so")
+    g = torch.Generator(device="cuda")
+    for fr in range(2):
+        g.manual_seed(500 + fr)
+        d_pcm = (torch.randint(-32768, 32768, (streams, n * 2), dtype=torch.int16, device="cuda", generator=g) // 64).to(torch.int16)
+        b.process_s16(d_pcm, d_bars, ops | G.OP_BARS)
+        torch.cuda.synchronize()
+        assert not torch.isnan(d_bars).any().item()
+        state = torch.empty((streams * 2, n), dtype=torch.float32, device="cuda")
+        assert hip.hipMemcpy(ctypes.c_void_p(state.data_ptr()), ctypes.c_void_p(b.gravity_state()), ctypes.c_size_t(state.numel() * 4), 3) == 0
+        pcm_sub = d_pcm[idx].cpu().numpy()
+        rows = torch.stack([2 * idx, 2 * idx + 1], dim=1).reshape(-1)
+        got_bars = d_bars[rows].cpu().numpy().reshape(subset.size, 2, bars)
+        got_spec = state[rows].cpu().numpy().reshape(subset.size, 2, n)
+        for i, s in enumerate(subset):
+            out = StreamOracle(n, gravity=False, average=False).frame(pcm_sub[i])
+            for c in range(2):
+                row = np.ascontiguousarray(out[c])
+                Oracle.gravity(row, grav[int(s)][c])
+                assert np.allclose(got_spec[i, c], row, rtol=REL, atol=2e-6), (fr, int(s), c)
+                want = np.empty(bars, np.float32)
+                Oracle.lib().glvo_bars(row, n, want, bars, 0.025)
+                assert np.allclose(got_bars[i, c], want, rtol=2e-4, atol=2e-6), (fr, int(s), c)
+    b.close()

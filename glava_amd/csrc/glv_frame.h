@@ -298,6 +298,42 @@ struct Frame {
         }
     }
 
+    // ---- pipelined f32 inputs: samples are fetched into registers one row / frame ahead (kernel
+    // PREFETCH 3) and windowed from there
+    struct RawF { cf p[E]; };                                   // planar: complex point i*T + tid of the row
+    GLV_HD static void load_f32_raw(RawF& r, const void* row, int tid) {
+#pragma unroll
+        for (int i = 0; i < E; ++i) r.p[i] = ld<cf>(row, (uint32_t) tid * 8u + (uint32_t) (i * T) * 8u);
+    }
+    // window table reads in chunks of WCHUNK like unpack_window_impl
+    template <typename GET>
+    GLV_HD static void window_points(cf (&v)[E], const void* win, int tid, GET get) {
+        d2 w[2][WCHUNK];
+#pragma unroll
+        for (int j = 0; j < WCHUNK; ++j) w[0][j] = ld<d2>(win, (uint32_t) tid * 16u + (uint32_t) (j * T) * 16u);
+#pragma unroll
+        for (int c0 = 0; c0 < E; c0 += WCHUNK) {
+            const int cur = (c0 / WCHUNK) & 1;
+            if (c0 + WCHUNK < E) {
+#pragma unroll
+                for (int j = 0; j < WCHUNK; ++j)
+                    w[cur ^ 1][j] = ld<d2>(win, (uint32_t) tid * 16u + (uint32_t) ((c0 + WCHUNK + j) * T) * 16u);
+            }
+            GLV_SCHED_FENCE();
+#pragma unroll
+            for (int j = 0; j < WCHUNK; ++j) {
+                const int i = c0 + j;
+                const cf u = get(i);
+                v[i].x = apply_window(u.x, w[cur][j].x);
+                v[i].y = apply_window(u.y, w[cur][j].y);
+            }
+            GLV_SCHED_FENCE();
+        }
+    }
+    GLV_HD static void window_f32_raw(cf (&v)[E], const RawF& r, const void* win, int tid) {
+        window_points(v, win, tid, [&](int i) { return r.p[i]; });
+    }
+
     // interleaved stereo f32 (pulse_input.c:159-176): one 16-byte load = complex point c of both
     // channels (L[2c], R[2c], L[2c+1], R[2c+1]); mono = (L + R) / 2 in float (pulse_input.c:167)
     struct alignas(16) f4 { float a, b, c, d; };
@@ -311,6 +347,19 @@ struct Frame {
             else { s0 = ch ? u.b : u.a; s1 = ch ? u.d : u.c; }
             v[i].x = apply_window(s0, w.x);
             v[i].y = apply_window(s1, w.y);
+        }
+    }
+
+    // interleaved stereo f32, one channel of complex point i*T + tid: floats 4c + ch and 4c + 2 + ch of the
+    // frame.  Two dword loads per point keep the footprint at E registers pairs (a 16-byte load would park
+    // the other channel in registers across a whole transform: 64 VGPRs more than the kernel has); the
+    // other halves of the same cache lines are read by the channel's sibling row one transform later.
+    GLV_HD static void load_f32s_raw(RawF& r, const void* frame, int tid, uint32_t ch) {
+        const char* base = static_cast<const char*>(frame) + ch * 4u;
+#pragma unroll
+        for (int i = 0; i < E; ++i) {
+            r.p[i].x = ld<float>(base, (uint32_t) tid * 16u + (uint32_t) (i * T) * 16u);
+            r.p[i].y = ld<float>(base, (uint32_t) tid * 16u + (uint32_t) (i * T) * 16u + 8u);
         }
     }
 

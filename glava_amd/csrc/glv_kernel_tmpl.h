@@ -420,6 +420,80 @@ glv_frame_kernel(const FrameArgs a) {
         }
         return;
     }
+    if constexpr (IN_MODE == IN_F32_PLANAR && PREFETCH == 3 && LOG_E <= 4) {
+        // planar f32 rows (the lb/rb snapshot): the in-place pipeline over ROWS -- A issue the loads of the
+        // slot's next row, B transform, W, D epilogue, C window the fetched samples into the point registers
+        auto row_ptr = [&](uint32_t row) -> const void* { return static_cast<const char*>(a.in) + (size_t) row * ((size_t) N * 4); };
+        cf v[E];
+        typename FR::RawF raw;
+        if (step_base(0) < a.units) {
+            int tid = tid_outer;
+            asm volatile("" : "+v"(tid));
+            FR::load_f32_raw(raw, row_ptr(row_of(step_base(0))), tid);
+            FR::window_f32_raw(v, raw, win, tid);
+        }
+        __builtin_amdgcn_s_waitcnt(0x0F70);
+        for (uint32_t step = 0; step < nsteps; ++step) {
+            const uint32_t base = step_base(step);
+            if (base >= a.units) break;                          // uniform for the workgroup
+            int tid = tid_outer;
+            asm volatile("" : "+v"(tid));
+            const bool active = base + slot < a.units;
+            const uint32_t row = row_of(base);
+            const uint32_t nb = step_base(step + 1);
+            const bool has_next = step + 1 < nsteps && nb < a.units;
+            FR::load_f32_raw(raw, row_ptr(row_of(has_next ? nb : base)), tid);                   // A (unconditional)
+            GLV_SCHED_FENCE();
+            BD::template run<0>(v, tw_all, a.tw, xslot, tid, xcount, lds_tw);                    // B
+            GLV_SCHED_FENCE();
+            __builtin_amdgcn_s_waitcnt(0x0F70);                                                  // W
+            finish_row(v, (size_t) row, tid, active);                                            // D
+            GLV_SCHED_FENCE();
+            FR::window_f32_raw(v, raw, win, tid);                                                // C
+        }
+        return;
+    }
+    if constexpr (IN_MODE == IN_F32_STEREO && PREFETCH == 3 && LOG_E <= 4) {
+        // interleaved stereo f32 (PulseAudio), stereo only (the rare mono mix takes the generic loop below): one
+        // slot = one frame, rows back to back, every row fetches its successor row's channel -- the sibling
+        // channel of the same frame, then channel 0 of the slot's next frame
+        if (a.mono == 0) {
+            const uint32_t nframes = a.units / 2;
+            const uint32_t fstride = gridDim.x * SLOTS;
+            const uint32_t nfs = nframes == 0 ? 0 : (nframes - 1) / fstride + 1;
+            auto frame_of = [&](uint32_t m) -> uint32_t {
+                const uint32_t f = blockIdx.x * SLOTS + m * fstride + slot;
+                return f < nframes ? f : nframes - 1;
+            };
+            auto frame_ptr = [&](uint32_t f) -> const void* { return static_cast<const char*>(a.in) + (size_t) f * ((size_t) N * 8); };
+            cf v[E];
+            typename FR::RawF raw;
+            if (blockIdx.x * SLOTS < nframes) {
+                int tid = tid_outer;
+                asm volatile("" : "+v"(tid));
+                FR::load_f32s_raw(raw, frame_ptr(frame_of(0)), tid, 0u);
+                FR::window_f32_raw(v, raw, win, tid);
+            }
+            __builtin_amdgcn_s_waitcnt(0x0F70);
+            for (uint32_t r = 0; r < 2 * nfs; ++r) {
+                const uint32_t m = r >> 1, ch = r & 1u;
+                if (blockIdx.x * SLOTS + m * fstride >= nframes) break;                 // uniform for the workgroup
+                int tid = tid_outer;
+                asm volatile("" : "+v"(tid));
+                const bool active = blockIdx.x * SLOTS + m * fstride + slot < nframes;
+                const uint32_t f = frame_of(m);
+                FR::load_f32s_raw(raw, frame_ptr(frame_of(m + ch)), tid, ch ^ 1u);               // A (unconditional)
+                GLV_SCHED_FENCE();
+                BD::template run<0>(v, tw_all, a.tw, xslot, tid, xcount, lds_tw);                // B
+                GLV_SCHED_FENCE();
+                __builtin_amdgcn_s_waitcnt(0x0F70);                                              // W
+                finish_row(v, (size_t) f * 2 + ch, tid, active);                                 // D
+                GLV_SCHED_FENCE();
+                FR::window_f32_raw(v, raw, win, tid);                                            // C
+            }
+            return;
+        }
+    }
     for (uint32_t step = 0; step < nsteps; ++step) {
         const uint32_t base = step_base(step);
         if (base >= a.units) break;                              // uniform for the workgroup

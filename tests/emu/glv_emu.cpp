@@ -139,3 +139,82 @@ int glvemu_process(int n, int in_mode, const void* in, float* out, float* grav, 
 }
 
 }  // extern "C"
+
+// ---- GLV_OP_BARS on the host: the same tables, work lists and chunk arithmetic as the kernels; the
+// 16-lane DPP sum (glv_frame.h group16_sum) is restated as the data movement its four steps perform.
+namespace {
+float group16_sum_host(const float (&lane)[16]) {
+    float v[16], t[16];
+    for (int i = 0; i < 16; ++i) v[i] = lane[i];
+    auto step = [&](auto src) { for (int i = 0; i < 16; ++i) t[i] = v[i] + v[src(i)]; for (int i = 0; i < 16; ++i) v[i] = t[i]; };
+    step([](int i) { return i ^ 1; });                       // quad_perm [1,0,3,2]
+    step([](int i) { return i ^ 2; });                       // quad_perm [2,3,0,1]
+    step([](int i) { return (i & 8) | (7 - (i & 7)); });     // row_half_mirror
+    step([](int i) { return 15 - i; });                      // row_mirror
+    return v[0];
+}
+}  // namespace
+
+extern "C" {
+// bars of `nrows` rows of n floats through work lists for `groups` 16-lane groups.  steps_out (may be NULL)
+// receives the step count; returns 0 on success.
+int glvemu_bars(const float* spec, size_t nrows, int n, int bars, float smooth_factor, int groups, float* out, unsigned* steps_out) {
+    using namespace glv;
+    std::vector<BarDesc> desc;
+    std::vector<float> w;
+    make_bar_taps(desc, w, (uint32_t) n, (uint32_t) bars, smooth_factor);
+    const uint32_t zero_off = (uint32_t) w.size();
+    w.resize(w.size() + kBarChunk, 0.0f);
+    std::vector<BarItem> items;
+    const uint32_t nsteps = make_bar_items(items, desc, (uint32_t) groups, zero_off);
+    if (steps_out) *steps_out = nsteps;
+    for (size_t row = 0; row < nrows; ++row) {
+        const float* tex = spec + row * (size_t) n;
+        for (int g = 0; g < groups; ++g) {
+            float total = 0.0f;
+            for (uint32_t s = 0; s < nsteps; ++s) {
+                const BarItem it = items[(size_t) s * groups + g];
+                float lane[16];
+                for (int sub = 0; sub < 16; ++sub) lane[sub] = bar_item_lane_sum(bar_item_load(tex, (uint32_t) n, w.data(), it, sub));
+                total += group16_sum_host(lane);
+                if (bar_item_last(it)) { out[row * bars + bar_item_bar(it)] = total / desc[bar_item_bar(it)].weight_sum; total = 0.0f; }
+            }
+        }
+    }
+    return 0;
+}
+
+// work-list invariants for the tests: returns 0 when every chunk of every bar appears exactly once, a bar's
+// chunks sit in ONE group's list in increasing order, the last chunk (only) carries the end flag, padding
+// items point at zero weights, and the step count is a multiple of kBarBatch with one batch of padding rows.
+int glvemu_bar_items_check(int n, int bars, float smooth_factor, int groups) {
+    using namespace glv;
+    std::vector<BarDesc> desc;
+    std::vector<float> w;
+    make_bar_taps(desc, w, (uint32_t) n, (uint32_t) bars, smooth_factor);
+    for (const BarDesc& d : desc) { if (d.count == 0 || d.first_bin + d.count > (uint32_t) n || d.tap_offset % kBarChunk) return 1; }
+    const uint32_t zero_off = (uint32_t) w.size();
+    w.resize(w.size() + kBarChunk, 0.0f);
+    std::vector<BarItem> items;
+    const uint32_t nsteps = make_bar_items(items, desc, (uint32_t) groups, zero_off);
+    if (nsteps % kBarBatch || items.size() != (size_t) (nsteps + kBarBatch) * groups) return 2;
+    std::vector<int> owner(desc.size(), -1);
+    std::vector<uint32_t> next_chunk(desc.size(), 0);
+    for (int g = 0; g < groups; ++g)
+        for (uint32_t s = 0; s < nsteps + kBarBatch; ++s) {
+            const BarItem it = items[(size_t) s * groups + g];
+            if (it.w_off == zero_off) { if (it.pack != 0) return 3; continue; }
+            if (s >= nsteps) return 4;
+            const uint32_t k = bar_item_bar(it);
+            if (k >= desc.size()) return 5;
+            if (owner[k] == -1) owner[k] = g; else if (owner[k] != g) return 6;
+            const uint32_t i0 = next_chunk[k];
+            if (it.w_off != desc[k].tap_offset + i0 || bar_item_tex(it) != desc[k].first_bin + i0) return 7;
+            if (bar_item_last(it) != (i0 + kBarChunk >= desc[k].count)) return 8;
+            for (uint32_t j = 0; j < kBarChunk; ++j) if (i0 + j >= desc[k].count && w[it.w_off + j] != 0.0f) return 9;
+            next_chunk[k] = i0 + kBarChunk;
+        }
+    for (size_t k = 0; k < desc.size(); ++k) if (next_chunk[k] < desc[k].count) return 10;
+    return 0;
+}
+}  // extern "C"

@@ -166,3 +166,35 @@ def test_lds_padding_is_injective_and_conflict_free():
                 lanes = list(range(g0, min(g0 + 32, T)))
                 banks = [(2 * pad(i * (nn // R) + t)) % 64 for t in lanes]
                 assert len(lanes) - len(set(banks)) <= 1, (log_nn, i, g0)
+
+
+# ---- GLV_OP_BARS host logic: tap tables, work lists, chunk arithmetic -------------------------------------
+import ctypes as C  # noqa: E402
+from emu_lib import emu_bars  # noqa: E402
+
+
+@pytest.mark.parametrize("n,bars", [(512, 80), (4096, 80), (16384, 80), (4096, 31), (16384, 256)])
+def test_bar_work_lists(emu, n, bars):
+    """every chunk of every bar exactly once, a bar's chunks in one group in order, zero-weight padding --
+    for every group count the kernels use (T/16 of each size, 16 for glv_bars_kernel)"""
+    for groups in (1, 4, 8, 16, 32):
+        assert emu.glvemu_bar_items_check(n, bars, C.c_float(0.025), groups) == 0, groups
+    assert emu.glvemu_bar_items_check(n, bars, C.c_float(0.1), 16) == 0
+
+
+@pytest.mark.parametrize("n", [512, 4096, 16384])
+def test_bars_emulator_vs_restatement(emu, oracle, n):
+    """chunked 16-lane arithmetic vs the straight restatement of smooth.glsl (summation order differs)
+    and: the result does not depend on how many groups share the work"""
+    bars = 80
+    spec = np.abs(np.random.default_rng(n).standard_normal((3, n))).astype(np.float32) * 0.4
+    spec[1, ::7] = 1.7          # exercise the [0,1] clamp
+    got16, steps = emu_bars(emu, spec, n, bars, groups=16)
+    assert steps % 4 == 0 and steps > 0
+    for r in range(3):
+        want = np.empty(bars, np.float32)
+        oracle.lib().glvo_bars(np.ascontiguousarray(spec[r]), n, want, bars, 0.025)
+        assert np.allclose(got16[r], want, rtol=2e-4, atol=2e-6)
+    for groups in (1, 4, 8, 32):
+        got, _ = emu_bars(emu, spec, n, bars, groups=groups)
+        assert (bits(got) == bits(got16)).all(), groups

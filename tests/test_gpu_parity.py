@@ -647,3 +647,20 @@ def test_config2_full_size_gravity_bars_subset(G):
                 Oracle.lib().glvo_bars(row, n, want, bars, 0.025)
                 assert np.allclose(got_bars[i, c], want, rtol=2e-4, atol=2e-6), (fr, int(s), c)
     b.close()
+
+
+def test_bars_bits_equal_host_emulation(G, emu):
+    """glv_bars_kernel (and through test_fused_bars_equal_unfused the fused epilogue) produce exactly the bits
+    of the host emulation of the chunk arithmetic -- i.e. the DPP reduction adds in the documented order."""
+    import torch
+    from emu_lib import emu_bars
+    for n in (512, 4096, 16384):
+        bars, streams = 80, 3
+        spec = np.abs(np.random.default_rng(n + 1).standard_normal((streams * 2, n))).astype(np.float32) * 0.5
+        b = G.Batch(G.Params(n=n, bars=bars), streams, G.OP_FFT)
+        d_bars = torch.empty((streams * 2, bars), dtype=torch.float32, device="cuda")
+        b.bars(torch.from_numpy(spec).cuda(), d_bars)
+        got = d_bars.cpu().numpy()
+        want, _ = emu_bars(emu, spec, n, bars, groups=16)
+        assert (bits(got) == bits(want)).all(), n
+        b.close()

@@ -299,7 +299,7 @@ struct Frame {
     }
 
     // ---- pipelined f32 inputs: samples are fetched into registers one row / frame ahead (kernel
-    // PREFETCH 3) and windowed from there
+    // PREFETCH 1) and windowed from there
     struct RawF { cf p[E]; };                                   // planar: complex point i*T + tid of the row
     GLV_HD static void load_f32_raw(RawF& r, const void* row, int tid) {
 #pragma unroll

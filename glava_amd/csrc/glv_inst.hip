@@ -17,12 +17,12 @@ template <int LOG_NN> struct Tuned;
                                   static constexpr bool winlds = WL; static constexpr int twreg = TR, tiltreg = TL, prefetch = PF; };
 // measured best of tools/tune.py on MI355X (profiles/tune_r01.txt), equal bytes per size class:
 //         log2(nn) LOG_E SLOTS NBUF TWREG  WINLDS OCC PREFETCH TILTREG      (knob values: glv_kernel_tmpl.h)
-GLV_TUNED(8,        4,    16,   1,   true,  true,  2,  1,       true)    // N=512    E=16: 4+4
-GLV_TUNED(9,        3,    4,    1,   true,  true,  4,  3,       true)    // N=1024   E=8:  3+3+3
-GLV_TUNED(10,       4,    2,    1,   true,  true,  2,  3,       true)    // N=2048   E=16: 4+4+2
-GLV_TUNED(11,       4,    2,    1,   true,  true,  2,  3,       true)    // N=4096   E=16: 4+4+3
-GLV_TUNED(12,       4,    1,    1,   true,  false, 2,  3,       true)    // N=8192   E=16: 4+4+4 (window 64 KiB: via L2)
-GLV_TUNED(13,       5,    1,    1,   3,     false, 2,  3,       2)       // N=16384  E=32: 5+5+3; pass-1 twiddles from an 8 KiB LDS table, tilt computed
+GLV_TUNED(8,       4,    16,   1,   true,  true,  2,  1,       true)    // N=512    E=16: 4+4
+GLV_TUNED(9,       3,    4,    1,   true,  true,  4,  1,       true)    // N=1024   E=8:  3+3+3
+GLV_TUNED(10,      4,    2,    1,   true,  true,  2,  1,       true)    // N=2048   E=16: 4+4+2
+GLV_TUNED(11,      4,    2,    1,   true,  true,  2,  1,       true)    // N=4096   E=16: 4+4+3
+GLV_TUNED(12,      4,    1,    1,   true,  false, 2,  1,       true)    // N=8192   E=16: 4+4+4 (window 64 KiB: via L2)
+GLV_TUNED(13,      5,    1,    1,   3,     false, 2,  1,       2)       // N=16384  E=32: 5+5+3; pass-1 twiddles from an 8 KiB LDS table, tilt computed
 #undef GLV_TUNED
 
 #define GLV_CAT2(a, b) a##b
@@ -54,12 +54,12 @@ hipError_t GLV_CAT(launch_frame_, GLV_LOG_NN)(int in_mode, int log_mode, const F
     return hipErrorInvalidValue;
 }
 
-// channel rows one workgroup takes per trip of its persistent loop (grid sizing): a pipelined s16
-// slot takes a whole frame (2 rows), a single-slot workgroup both rows of its frame in sequence; for
-// other inputs the figure only makes the grid slightly smaller than strictly necessary.
 // lanes that cooperate on one row (fused bars need whole waves per row)
 int GLV_CAT(frame_lanes_, GLV_LOG_NN)() { return Frame<GLV_LOG_NN, Tuned<GLV_LOG_NN>::log_e>::T; }
 
+// channel rows one workgroup takes per trip of its persistent loop (grid sizing): a pipelined s16
+// slot takes a whole frame (2 rows), a single-slot workgroup both rows of its frame in sequence; for
+// other inputs the figure only makes the grid slightly smaller than strictly necessary.
 int GLV_CAT(frame_slots_, GLV_LOG_NN)() {
     using TU = Tuned<GLV_LOG_NN>;
     return (TU::prefetch == 1 || TU::slots == 1) ? 2 * TU::slots : TU::slots;

@@ -28,9 +28,12 @@
 //   WINLDS  true: window table staged once per workgroup into LDS; false: read through L1/L2
 //   OCC     __launch_bounds__ minimum waves per SIMD (caps the VGPR budget: 512 / OCC)
 //   TILTREG   the 32 per-lane tilt factors stay in VGPRs across rows instead of being re-read per row
-//   PREFETCH  s16 input, 0 off / 1 frame pipeline / 2 row pipeline / 3 in-place frame pipeline (no second point set): rows are software-pipelined -- the next row's PCM is loaded before and
-//           unpacked after the current row's passes, so neither HBM reads nor spectrum stores sit on
-//           a row's critical path (costs a second 32-VGPR point set)
+//   PREFETCH  0: no software pipeline (load, transform, store per row)
+//           1: in-place pipeline -- the next frame's (s16, interleaved f32) or row's (planar f32) samples
+//              are requested before the current row's passes and unpacked/windowed after its epilogue,
+//              straight into the point registers.  (Earlier variants that unpacked into a second point
+//              set before the epilogue, per frame or per row, measured slower at every size and are gone;
+//              profiles/tune_r01.txt still lists them as pf=1 / pf=2, this one as pf=3.)
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -275,75 +278,18 @@ glv_frame_kernel(const FrameArgs a) {
     };
     const int tid_outer = tid;
     if constexpr (S16 && PREFETCH == 1) {
-        // Software pipeline, one slot = one FRAME at a time, its two channel rows back to back:
-        //   iteration r = 2*m + ch   (m-th frame of this slot, channel ch)
-        //   A  ch == 1 only: issue the PCM loads of the slot's NEXT frame (the current frame's
-        //      samples were fully consumed by the previous iteration's C)     <- HBM latency starts here
-        //   B  all FFT passes of row r                         (registers/LDS only: ~2 us of cover)
-        //   C  unpack + window row r+1 into a second register set (ch == 0: right channel of the same
-        //      frame, still in `raw`; ch == 1: left channel of the next frame = first use of A's data)
-        //   D  epilogue of row r: log/tilt/state + spectrum stores
-        // Every frame's PCM is loaded exactly once by exactly one slot (16 x 8 B per lane per FRAME).
-        // The only vector-memory wait (C) finds A's loads AND the previous iteration's stores a full
-        // transform old.  gfx9-class targets count loads and stores on one counter (vmcnt), and a
-        // wait with both kinds pending drains everything -- so a row must never need fresh load
-        // data right after its predecessor's stores were issued.
-        const uint32_t nframes = a.units / 2;
-        const uint32_t fstride = gridDim.x * SLOTS;
-        const uint32_t nfs = nframes == 0 ? 0 : (nframes - 1) / fstride + 1;           // frame steps, uniform upper bound
-        auto frame_of = [&](uint32_t m) -> uint32_t {                                   // clamped: idle slots redo the last frame
-            const uint32_t f = blockIdx.x * SLOTS + m * fstride + slot;
-            return f < nframes ? f : nframes - 1;
-        };
-        auto frame_ptr = [&](uint32_t f) -> const void* { return static_cast<const char*>(a.in) + (size_t) f * ((size_t) N * 4); };
-        cf v[E], vn[E];
-        typename FR::Raw raw;
-        if (blockIdx.x * SLOTS < nframes) {
-            int tid = tid_outer;
-            asm volatile("" : "+v"(tid));
-            FR::template load_pcm<RING>(raw, frame_ptr(frame_of(0)), tid, a.rot);
-            FR::unpack_window(v, raw, win, tid, 0u, a.mono != 0);
-        }
-        // Every load issued so far (resident twiddles, tilt factors, first frame) must have landed
-        // before the loop: otherwise the backend's wait-count model carries "N loads may still be
-        // pending behind this register" around the back edge and, vmcnt being one in-order
-        // counter, turns the first use of each resident register into a partial drain of the PCM
-        // prefetch in the middle of a row.  (s_waitcnt vmcnt(0); expcnt/lgkmcnt untouched.)
-        __builtin_amdgcn_s_waitcnt(0x0F70);
-        for (uint32_t r = 0; r < 2 * nfs; ++r) {
-            const uint32_t m = r >> 1, ch = r & 1u;
-            if (blockIdx.x * SLOTS + m * fstride >= nframes) break;                     // uniform for the workgroup
-            int tid = tid_outer;
-            asm volatile("" : "+v"(tid));                        // see the note on LICM below
-            const uint32_t fraw = blockIdx.x * SLOTS + m * fstride + slot;
-            const bool active = fraw < nframes;
-            const uint32_t f = frame_of(m);
-            if (ch) FR::template load_pcm<RING>(raw, frame_ptr(frame_of(m + 1)), tid, a.rot);   // A (clamped past the end)
-            GLV_SCHED_FENCE();
-            BD::template run<0>(v, tw_all, a.tw, xslot, tid, xcount, lds_tw);                            // B
-            GLV_SCHED_FENCE();
-            FR::unpack_window(vn, raw, win, tid, ch ^ 1u, a.mono != 0);                          // C
-            GLV_SCHED_FENCE();
-            finish_row(v, (size_t) f * 2 + ch, tid, active);                                     // D
-            // (swapping the roles of v/vn by unrolling twice doubles the loop body and pushed the fp64-log
-            //  variant into heavy spilling; 32 v_mov per row are the cheaper price)
-#pragma unroll
-            for (int i = 0; i < E; ++i) v[i] = vn[i];
-        }
-        return;
-    }
-    if constexpr (S16 && PREFETCH == 3) {
-        // In-place frame pipeline: like PREFETCH == 1 (one slot = one FRAME, channel rows back to back,
-        // PCM loaded exactly once), but without the second point set.  Per row r = 2*m + ch:
+        // In-place frame pipeline: one slot = one FRAME at a time, its two channel rows back to back, so
+        // every frame's PCM is loaded exactly once by exactly one slot.  Per row r = 2*m + ch:
         //   A  ch == 1 only: issue the PCM loads of the slot's next frame into `raw` (both channels of
-        //      the current frame were unpacked out of it already)
-        //   B  all FFT passes of row r
+        //      the current frame were unpacked out of it already)        <- HBM latency starts here
+        //   B  all FFT passes of row r                     (registers/LDS only: ~2 us of cover)
         //   W  s_waitcnt vmcnt(0): A's loads are a whole transform old, the previous row's stores older
         //   D  epilogue of row r: log/tilt/state + spectrum stores
         //   C  unpack + window row r+1 from `raw` straight into v (register-only: no vector-memory
         //      wait can land behind D's stores, W retired every load)
-        // 32 VGPRs less than PREFETCH == 1 and no per-row register copy; the price is that C cannot
-        // overlap D's store issue.
+        // gfx9-class targets count loads and stores on one in-order counter (vmcnt) and a wait with
+        // both kinds pending drains everything -- so a row must never need fresh load data right
+        // after its predecessor's stores were issued; hence W before D and nothing but registers in C.
         const uint32_t nframes = a.units / 2;
         const uint32_t fstride = gridDim.x * SLOTS;
         const uint32_t nfs = nframes == 0 ? 0 : (nframes - 1) / fstride + 1;
@@ -380,47 +326,7 @@ glv_frame_kernel(const FrameArgs a) {
         }
         return;
     }
-    if constexpr (S16 && PREFETCH == 2) {
-        // Software pipeline over ROWS (one slot = one channel row; neighbouring slots share a frame):
-        // like the frame pipeline above, but every row issues the 16 loads of its successor row, so a
-        // frame's PCM is requested twice (second time from L1/L2).  Measured faster than the frame
-        // pipeline for the single-slot workgroups of N >= 8192.
-        auto pcm_ptr = [&](uint32_t row) -> const void* {
-            return static_cast<const char*>(a.in) + (size_t) (row >> 1) * ((size_t) N * 4);
-        };
-        cf v[E], vn[E];
-        typename FR::Raw raw;
-        if (step_base(0) < a.units) {
-            int tid = tid_outer;
-            asm volatile("" : "+v"(tid));
-            const uint32_t row0 = row_of(step_base(0));
-            FR::template load_pcm<RING>(raw, pcm_ptr(row0), tid, a.rot);
-            FR::unpack_window(v, raw, win, tid, row0 & 1u, a.mono != 0);
-        }
-        __builtin_amdgcn_s_waitcnt(0x0F70);                      // vmcnt(0): see the frame pipeline
-        for (uint32_t step = 0; step < nsteps; ++step) {
-            const uint32_t base = step_base(step);
-            if (base >= a.units) break;                          // uniform for the workgroup
-            int tid = tid_outer;
-            asm volatile("" : "+v"(tid));
-            const bool active = base + slot < a.units;
-            const uint32_t row = row_of(base);
-            const uint32_t nb = step_base(step + 1);
-            const bool has_next = step + 1 < nsteps && nb < a.units;
-            const uint32_t row_n = row_of(has_next ? nb : base);
-            FR::template load_pcm<RING>(raw, pcm_ptr(row_n), tid, a.rot);                        // A (unconditional)
-            GLV_SCHED_FENCE();
-            BD::template run<0>(v, tw_all, a.tw, xslot, tid, xcount, lds_tw);                            // B
-            GLV_SCHED_FENCE();
-            FR::unpack_window(vn, raw, win, tid, row_n & 1u, a.mono != 0);                       // C
-            GLV_SCHED_FENCE();
-            finish_row(v, (size_t) row, tid, active);                                            // D
-#pragma unroll
-            for (int i = 0; i < E; ++i) v[i] = vn[i];
-        }
-        return;
-    }
-    if constexpr (IN_MODE == IN_F32_PLANAR && PREFETCH == 3 && LOG_E <= 4) {
+    if constexpr (IN_MODE == IN_F32_PLANAR && PREFETCH == 1 && LOG_E <= 4) {
         // planar f32 rows (the lb/rb snapshot): the in-place pipeline over ROWS -- A issue the loads of the
         // slot's next row, B transform, W, D epilogue, C window the fetched samples into the point registers
         auto row_ptr = [&](uint32_t row) -> const void* { return static_cast<const char*>(a.in) + (size_t) row * ((size_t) N * 4); };
@@ -453,7 +359,7 @@ glv_frame_kernel(const FrameArgs a) {
         }
         return;
     }
-    if constexpr (IN_MODE == IN_F32_STEREO && PREFETCH == 3 && LOG_E <= 4) {
+    if constexpr (IN_MODE == IN_F32_STEREO && PREFETCH == 1 && LOG_E <= 4) {
         // interleaved stereo f32 (PulseAudio), stereo only (the rare mono mix takes the generic loop below): one
         // slot = one frame, rows back to back, every row fetches its successor row's channel -- the sibling
         // channel of the same frame, then channel 0 of the slot's next frame

@@ -19,7 +19,7 @@ template <int LOG_NN> struct Tuned;
 //         log2(nn) LOG_E SLOTS NBUF TWREG  WINLDS OCC PREFETCH TILTREG      (knob values: glv_kernel_tmpl.h)
 GLV_TUNED(8,       4,    16,   1,   true,  true,  2,  1,       true)    // N=512    E=16: 4+4
 GLV_TUNED(9,       3,    4,    1,   true,  true,  4,  1,       true)    // N=1024   E=8:  3+3+3
-GLV_TUNED(10,      4,    2,    1,   true,  true,  2,  1,       true)    // N=2048   E=16: 4+4+2
+GLV_TUNED(10,      3,    2,    1,   true,  true,  4,  1,       true)    // N=2048   E=8:  3+3+3+1
 GLV_TUNED(11,      4,    2,    1,   true,  true,  2,  1,       true)    // N=4096   E=16: 4+4+3
 GLV_TUNED(12,      4,    1,    1,   true,  false, 2,  1,       true)    // N=8192   E=16: 4+4+4 (window 64 KiB: via L2)
 GLV_TUNED(13,      5,    1,    1,   3,     false, 2,  1,       2)       // N=16384  E=32: 5+5+3; pass-1 twiddles from an 8 KiB LDS table, tilt computed

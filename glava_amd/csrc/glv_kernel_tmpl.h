@@ -42,6 +42,46 @@
 
 namespace glv {
 
+// ---- slot-scoped synchronisation --------------------------------------------------------------------
+// The slots of a workgroup transform independent rows; nothing but the read-only tables is shared between
+// them, so an exchange only has to order the waves of ONE slot:
+//   * T <= 64: the slot lives inside one wave and LDS executes a wave's instructions in order -- no
+//     hardware barrier at all, only a compiler fence;
+//   * one slot per workgroup: s_barrier is already slot-scoped;
+//   * otherwise (N=4096: two waves per slot, two slots): a counter in LDS per slot.  Lane 0 of every wave
+//     adds 1 (ordered behind the wave's own LDS writes), then the wave polls until all T/64 waves of the
+//     slot arrived.  A workgroup-wide s_barrier here would keep the two slots in lockstep -- the same
+//     coupling that makes 4 slots per workgroup slower than 2.
+// GLV_EXP_WGBARRIER (tools/tune.py experiments) restores the workgroup-wide barrier everywhere.
+template <int T, int SLOTS>
+struct SlotSync {
+#if defined(GLV_EXP_WGBARRIER)
+    static constexpr bool WAVE_LOCAL = false, WORKGROUP = true;
+#else
+    static constexpr bool WAVE_LOCAL = T <= 64 && (64 % T) == 0;
+    static constexpr bool WORKGROUP = !WAVE_LOCAL && SLOTS == 1;
+#endif
+    static constexpr bool COUNTER = !WAVE_LOCAL && !WORKGROUP;
+    static constexpr uint32_t WAVES = T / 64 > 0 ? T / 64 : 1;
+    uint32_t* counter = nullptr;     // LDS, one per slot (COUNTER mode)
+    uint32_t expected = 0;
+
+    __device__ __forceinline__ void sync() {
+        if constexpr (WAVE_LOCAL) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        } else if constexpr (WORKGROUP) {
+            __syncthreads();
+        } else {
+            expected += WAVES;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            if ((threadIdx.x & 63) == 0) __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < expected) __builtin_amdgcn_s_sleep(1);
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        }
+    }
+};
+
 template <int LOG_NN, int LOG_E, int NBUF, int TWREG>
 struct Body {
     using FR = Frame<LOG_NN, LOG_E>;
@@ -96,9 +136,9 @@ struct Body {
     // ping-pong region alternates consistently across channels and frames.  Scheduling fences
     // pin the phase order  compute | LDS write + next twiddle gather | barrier | LDS read | compute
     // so that the backend cannot pull the table loads of later passes (30 VGPRs each) up front.
-    template <int PASS>
+    template <int PASS, typename SYNC>
     static __device__ __forceinline__ void run(cf (&v)[FR::E], cf* tw_all, const cf* __restrict__ table,
-                                               char* xslot, int tid, unsigned& xcount, const cf* lds_tw = nullptr) {
+                                               char* xslot, int tid, unsigned& xcount, const cf* lds_tw, SYNC& sy) {
         // pass 0's twiddles are the same for every lane (k0 = 0); the kernel gathers them once, before
         // the row loop, into scalar registers (gather_uniform_tw0) -- a vector load here would sit in
         // front of every row's first butterfly AND, vmcnt being in-order, behind the PCM prefetch.
@@ -110,21 +150,29 @@ struct Body {
             char* xb = xslot + (NBUF == 2 ? (size_t) (xcount & 1u) * FR::XREGION * sizeof(cf) : 0);
             GLV_SCHED_FENCE();
 #if !defined(GLV_EXP_NOBARRIER)      /* tools/tune.py timing experiment only: wrong results without the barriers */
-            if constexpr (NBUF == 1) __syncthreads();   // previous readers of the region are done
+            if constexpr (NBUF == 1) sy.sync();         // previous readers of the region are done
 #endif
             FR::template exchange_write<PASS>(xb, v, tid);
             // the next pass's per-lane twiddles travel from L2 while the exchange settles
             gather_transient<PASS + 1>(tw_all, table, lds_tw, tid);
 #if !defined(GLV_EXP_NOBARRIER)
-            __syncthreads();
+            sy.sync();
 #endif
             FR::template exchange_read<PASS + 1>(v, xb, tid);
             GLV_SCHED_FENCE();
             ++xcount;
-            run<PASS + 1>(v, tw_all, table, xslot, tid, xcount, lds_tw);
+            run<PASS + 1>(v, tw_all, table, xslot, tid, xcount, lds_tw, sy);
         }
     }
 };
+
+// dynamic LDS of one workgroup: exchange regions | window (WINLDS) | log table | middle-pass twiddles (TWREG >= 2) |
+// one 16-byte cell per slot for the slot barrier counter
+template <int LOG_NN, int LOG_E, int SLOTS, int NBUF, bool WINLDS, int TWREG = 0>
+constexpr size_t frame_lds_bytes() {
+    return (size_t) SLOTS * NBUF * Frame<LOG_NN, LOG_E>::XREGION * sizeof(cf) + (WINLDS ? (size_t) Frame<LOG_NN, LOG_E>::N * sizeof(double) : 0)
+           + kLogTabSize * sizeof(LogEntry) + (size_t) Body<LOG_NN, LOG_E, NBUF, TWREG>::LDS_ENTRIES * sizeof(cf) + (size_t) 16 * SLOTS;
+}
 
 // wave-uniform value -> SGPR (valid when all lanes of the wave hold the same value)
 template <bool UNIFORM>
@@ -178,6 +226,15 @@ glv_frame_kernel(const FrameArgs a) {
         lds_tw = reinterpret_cast<const cf*>(ltw);
     }
 
+    // slot-scoped synchronisation state (a counter per slot at the end of the LDS allocation)
+    SlotSync<T, SLOTS> sy;
+    if constexpr (SlotSync<T, SLOTS>::COUNTER) {
+        uint32_t* ctr = reinterpret_cast<uint32_t*>(smem + frame_lds_bytes<LOG_NN, LOG_E, SLOTS, NBUF, WINLDS, TWREG>() - 16 * SLOTS) + 4 * slot;
+        if (tid == 0) *ctr = 0;
+        __syncthreads();
+        sy.counter = ctr;
+    }
+
     cf tw_all[BD::TW_TOTAL];
     BD::gather_uniform_tw0(tw_all, a.tw);
     if constexpr (FR::P > 1) BD::template gather_resident<1>(tw_all, a.tw, tid);
@@ -214,9 +271,9 @@ glv_frame_kernel(const FrameArgs a) {
     // the epilogue of one row; every lane of the workgroup calls it (barriers inside when FUSED_BARS)
     auto finish_row = [&](const cf (&v)[E], size_t row, int tid, bool active) {
         if constexpr (FUSED_BARS) {
-            __syncthreads();                               // every reader of the row's last exchange is done
+            sy.sync();                                     // every reader of the row's last exchange is done
             if (active) finish(v, row, tid);               // finished row -> LDS, natural order
-            __syncthreads();
+            sy.sync();
             // T/16 groups of 16 lanes work through the row's bar chunks (glv_frame.h "GLV_OP_BARS
             // arithmetic"; work lists from make_bar_items).  kBarBatch steps at a time: their loads (LDS
             // row + L2-resident weights) are issued together and the next batch's items are fetched
@@ -252,7 +309,7 @@ glv_frame_kernel(const FrameArgs a) {
                     for (int b = 0; b < kBarBatch; ++b) it[b] = nx[b];
                 }
             }
-            __syncthreads();
+            sy.sync();
             if (active && (uint32_t) tid < a.bars) a.bars_out[row * a.bars + (uint32_t) tid] = lres[tid] / bar_wsum;
             // the next row's first exchange write is preceded by a barrier (NBUF == 1): the bars readers are safe
         } else {
@@ -317,7 +374,7 @@ glv_frame_kernel(const FrameArgs a) {
             const uint32_t f = frame_of(m);
             if (ch) FR::template load_pcm<RING>(raw, frame_ptr(frame_of(m + 1)), tid, a.rot);   // A
             GLV_SCHED_FENCE();
-            BD::template run<0>(v, tw_all, a.tw, xslot, tid, xcount, lds_tw);                            // B
+            BD::template run<0>(v, tw_all, a.tw, xslot, tid, xcount, lds_tw, sy);                            // B
             GLV_SCHED_FENCE();
             __builtin_amdgcn_s_waitcnt(0x0F70);                                                  // W
             finish_row(v, (size_t) f * 2 + ch, tid, active);                                     // D
@@ -350,7 +407,7 @@ glv_frame_kernel(const FrameArgs a) {
             const bool has_next = step + 1 < nsteps && nb < a.units;
             FR::load_f32_raw(raw, row_ptr(row_of(has_next ? nb : base)), tid);                   // A (unconditional)
             GLV_SCHED_FENCE();
-            BD::template run<0>(v, tw_all, a.tw, xslot, tid, xcount, lds_tw);                    // B
+            BD::template run<0>(v, tw_all, a.tw, xslot, tid, xcount, lds_tw, sy);                    // B
             GLV_SCHED_FENCE();
             __builtin_amdgcn_s_waitcnt(0x0F70);                                                  // W
             finish_row(v, (size_t) row, tid, active);                                            // D
@@ -390,7 +447,7 @@ glv_frame_kernel(const FrameArgs a) {
                 const uint32_t f = frame_of(m);
                 FR::load_f32s_raw(raw, frame_ptr(frame_of(m + ch)), tid, ch ^ 1u);               // A (unconditional)
                 GLV_SCHED_FENCE();
-                BD::template run<0>(v, tw_all, a.tw, xslot, tid, xcount, lds_tw);                // B
+                BD::template run<0>(v, tw_all, a.tw, xslot, tid, xcount, lds_tw, sy);                // B
                 GLV_SCHED_FENCE();
                 __builtin_amdgcn_s_waitcnt(0x0F70);                                              // W
                 finish_row(v, (size_t) f * 2 + ch, tid, active);                                 // D
@@ -425,16 +482,12 @@ glv_frame_kernel(const FrameArgs a) {
         } else {
             FR::load_f32_window(v, static_cast<const char*>(a.in) + (size_t) row * ((size_t) N * 4), win, tid);
         }
-        BD::template run<0>(v, tw_all, a.tw, xslot, tid, xcount, lds_tw);
+        BD::template run<0>(v, tw_all, a.tw, xslot, tid, xcount, lds_tw, sy);
         finish_row(v, (size_t) row, tid, active);
     }
 }
 
-template <int LOG_NN, int LOG_E, int SLOTS, int NBUF, bool WINLDS, int TWREG = 0>
-constexpr size_t frame_lds_bytes() {
-    return (size_t) SLOTS * NBUF * Frame<LOG_NN, LOG_E>::XREGION * sizeof(cf) + (WINLDS ? (size_t) Frame<LOG_NN, LOG_E>::N * sizeof(double) : 0)
-           + kLogTabSize * sizeof(LogEntry) + (size_t) Body<LOG_NN, LOG_E, NBUF, TWREG>::LDS_ENTRIES * sizeof(cf);
-}
+
 
 template <int LOG_NN, int IN_MODE, int LOG_MODE, int SLOTS, int NBUF, int TWREG, bool WINLDS, int OCC, int PREFETCH, int TILTREG,
           int LOG_E = 4>

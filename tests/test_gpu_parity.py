@@ -10,6 +10,7 @@ The oracle (oracle/liboracle.so) is the checker; it is pinned to the compiled re
 tests/test_oracle.py.  /root/reference is never touched here.
 """
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
@@ -664,3 +665,33 @@ def test_bars_bits_equal_host_emulation(G, emu):
         want, _ = emu_bars(emu, spec, n, bars, groups=16)
         assert (bits(got) == bits(want)).all(), n
         b.close()
+
+
+def test_reference_host_through_shim(G):
+    """The drop-in at the operator seam, on the reference's own types: oracle/_ref/libglvshim.so is the UNMODIFIED
+    glava/render.c with integration/glava_hip_shim.c compiled into it.  handle_audio's
+    CPU-path sequence fft -> gravity -> average with persistent t_data[] slots (render.c:2149-2153) runs once
+    on the reference's operators and once on the *_hip operators (three launches, and the fused one)."""
+    import ctypes
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "_ref", "libglvshim.so")
+    if not os.path.exists(path):
+        pytest.skip("oracle/_ref/libglvshim.so not built (needs /root/reference at build time)")
+    S = ctypes.CDLL(path)
+
+    class P(ctypes.Structure):
+        _fields_ = [("fft_scale", ctypes.c_float), ("fft_cutoff", ctypes.c_float), ("gravity_step", ctypes.c_float),
+                    ("ur", ctypes.c_float), ("avg_frames", ctypes.c_ulong), ("avg_window", ctypes.c_int)]
+    S.glvshim_run.argtypes = [ctypes.POINTER(P), ctypes.c_int, ctypes.c_uint, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
+    for n, F, win in ((4096, 5, 1), (1024, 6, 0)):
+        p = P(10.2, 0.3, 4.2, 86.1328125, F, win)
+        nframes = F + 3
+        pcm = lcg_pcm_fast(4242 + n, nframes * 2 * n).reshape(nframes, n, 2)
+        x = (pcm.astype(np.float32) / np.float32(65535)).transpose(0, 2, 1).copy()      # [frame][ch][n], fifo.c:105-106
+        ref = x.copy()
+        assert S.glvshim_run(ctypes.byref(p), 0, 0, ref.ctypes.data_as(ctypes.c_void_p), n, nframes) == 0
+        for mode in (1, 2):
+            for log_mode in (0, 1):
+                got = x.copy()
+                assert S.glvshim_run(ctypes.byref(p), mode, log_mode, got.ctypes.data_as(ctypes.c_void_p), n, nframes) == 0
+                assert np.allclose(got, ref, rtol=REL, atol=2e-6), (n, mode, log_mode)
+                assert np.isfinite(got).all()

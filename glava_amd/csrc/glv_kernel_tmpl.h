@@ -25,6 +25,8 @@
 //           2: middle passes gather from an LDS copy of their table range (entries E-1 .. L0_last-2: 8 KiB
 //              for N=16384 at 32 points per lane), the last pass from the L2-resident table
 //           3: middle passes from LDS, the last pass resident in VGPRs
+//           4: every pass >= 1 from an LDS copy of the table (nn - E entries: 16 KiB at N=4096) -- no twiddle
+//              VGPRs; allows 3 waves/SIMD at N=4096 (6 slots), measured slower than 2 (tools/tune.py)
 //   WINLDS  true: window table staged once per workgroup into LDS; false: read through L1/L2
 //   OCC     __launch_bounds__ minimum waves per SIMD (caps the VGPR budget: 512 / OCC)
 //   TILTREG   the 32 per-lane tilt factors stay in VGPRs across rows instead of being re-read per row
@@ -88,13 +90,14 @@ struct Body {
     static constexpr int P = FR::P, NN = FR::NN, N = FR::N, T = FR::T;
 
     // where the per-lane twiddles of pass Q (>= 1) come from
-    static constexpr bool TW_LDS_MODE = TWREG >= 2 && P >= 3;
+    static constexpr bool TW_LDS_MODE = (TWREG == 4 && P >= 2) || (TWREG >= 2 && P >= 3);
     static constexpr bool is_mid(int q) { return q >= 1 && q < P - 1; }
-    static constexpr bool from_lds(int q) { return TW_LDS_MODE && is_mid(q); }
+    static constexpr bool from_lds(int q) { return TW_LDS_MODE && (is_mid(q) || (TWREG == 4 && q >= 1)); }
     static constexpr bool resident(int q) { return q >= 1 && (TWREG == 1 || (TWREG >= 2 && !TW_LDS_MODE) || (TWREG == 3 && q == P - 1)); }
-    // LDS copy: table entries [LDS_BIAS, LDS_BIAS + LDS_ENTRIES) = the stages of passes 1..P-2
+    // LDS copy: table entries [LDS_BIAS, LDS_BIAS + LDS_ENTRIES) = the stages of passes 1..P-2 (TWREG 2, 3)
+    // or of every pass >= 1 (TWREG 4: the whole table but pass 0's E-1 entries)
     static constexpr int LDS_BIAS = FR::E - 1;
-    static constexpr int LDS_ENTRIES = TW_LDS_MODE ? (1 << FR::PL::log_l0(P - 1)) - FR::E : 0;
+    static constexpr int LDS_ENTRIES = !TW_LDS_MODE ? 0 : TWREG == 4 ? NN - FR::E : (1 << FR::PL::log_l0(P - 1)) - FR::E;
 
     template <int PASS>
     static constexpr int tw_off() {

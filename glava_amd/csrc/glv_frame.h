@@ -284,9 +284,12 @@ struct Frame {
             GLV_SCHED_FENCE();
         }
     }
+    // three code versions (mono, left, right): with a compile-time shift the channel select becomes the
+    // operand selector of the conversion (v_cvt_f32_i32_sdwa WORD_0 / WORD_1) instead of a shift per sample
     GLV_HD static void unpack_window(cf (&v)[E], const Raw& p, const void* win, int tid, uint32_t ch, bool mono) {
         if (mono) unpack_window_impl<true>(v, p, win, tid, 0);
-        else unpack_window_impl<false>(v, p, win, tid, ch * 16u);
+        else if (ch) unpack_window_impl<false>(v, p, win, tid, 16u);
+        else unpack_window_impl<false>(v, p, win, tid, 0u);
     }
     GLV_HD static void load_f32_window(cf (&v)[E], const void* row, const void* win, int tid) {
 #pragma unroll
@@ -451,6 +454,17 @@ struct Frame {
                     v[gi * PI::R + i] = two.a;
                     v[(gi + 1) * PI::R + i] = two.b;
                 }
+        } else if constexpr (PASS - 1 == 0 && (NN / PI::R) % E == 0) {
+            // reading the padded pass-0 layout: pad(q) = q + q/E is additive when one term is a multiple
+            // of E, and i * nn/R is -- so the address is pad(group) + a compile-time constant (written as
+            // pad(i * nn/R + group) the backend re-derives the padding with three integer ops per point)
+#pragma unroll
+            for (int gi = 0; gi < PI::NG; ++gi) {
+                const uint32_t base = (uint32_t) lds_index(0, group_of<PASS>(tid, gi), LOG_E) * 8u;
+#pragma unroll
+                for (int i = 0; i < PI::R; ++i)
+                    v[gi * PI::R + i] = ld<cf>(xbuf, base + (uint32_t) lds_index(0, i * (NN / PI::R), LOG_E) * 8u);
+            }
         } else {
 #pragma unroll
             for (int gi = 0; gi < PI::NG; ++gi)

@@ -21,8 +21,8 @@ GLV_TUNED(8,       4,    16,   1,   true,  true,  2,  1,       true)    // N=512
 GLV_TUNED(9,       3,    4,    1,   true,  true,  4,  1,       true)    // N=1024   E=8:  3+3+3
 GLV_TUNED(10,      3,    2,    1,   true,  true,  4,  1,       true)    // N=2048   E=8:  3+3+3+1
 GLV_TUNED(11,      4,    2,    1,   true,  true,  2,  1,       true)    // N=4096   E=16: 4+4+3
-GLV_TUNED(12,      4,    1,    1,   true,  false, 2,  1,       true)    // N=8192   E=16: 4+4+4 (window 64 KiB: via L2)
-GLV_TUNED(13,      5,    1,    1,   3,     false, 2,  1,       2)       // N=16384  E=32: 5+5+3; pass-1 twiddles from an 8 KiB LDS table, tilt computed
+GLV_TUNED(12,      4,    2,    1,   true,  true,  2,  1,       true)    // N=8192   E=16: 4+4+4; two slots share the 64 KiB LDS window
+GLV_TUNED(13,      5,    1,    1,   2,     false, 2,  1,       2)       // N=16384  E=32: 5+5+3; pass-1 twiddles from an 8 KiB LDS table, tilt computed
 #undef GLV_TUNED
 
 #define GLV_CAT2(a, b) a##b
@@ -56,6 +56,18 @@ hipError_t GLV_CAT(launch_frame_, GLV_LOG_NN)(int in_mode, int log_mode, const F
 
 // lanes that cooperate on one row (fused bars need whole waves per row)
 int GLV_CAT(frame_lanes_, GLV_LOG_NN)() { return Frame<GLV_LOG_NN, Tuned<GLV_LOG_NN>::log_e>::T; }
+
+// workgroups of this size's production kernel that fit one CU (LDS and the launch-bounds wave budget)
+int GLV_CAT(frame_resident_, GLV_LOG_NN)() {
+    using TU = Tuned<GLV_LOG_NN>;
+    using FR = Frame<GLV_LOG_NN, TU::log_e>;
+    constexpr size_t lds = frame_lds_bytes<GLV_LOG_NN, TU::log_e, TU::slots, TU::nbuf, TU::winlds, TU::twreg>();
+    constexpr int by_lds = (int) (160 * 1024 / lds);
+    constexpr int waves = FR::T * TU::slots / 64 > 0 ? FR::T * TU::slots / 64 : 1;
+    constexpr int by_waves = TU::occ * 4 / waves;
+    constexpr int r = by_lds < by_waves ? by_lds : by_waves;
+    return r > 0 ? r : 1;
+}
 
 // channel rows one workgroup takes per trip of its persistent loop (grid sizing): a pipelined s16
 // slot takes a whole frame (2 rows), a single-slot workgroup both rows of its frame in sequence; for

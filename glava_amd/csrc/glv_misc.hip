@@ -186,4 +186,12 @@ int frame_lanes(int log_nn) {
     return 1;
 }
 
+int frame_resident(int log_nn) {
+    switch (log_nn) {
+        case 8: return frame_resident_8(); case 9: return frame_resident_9(); case 10: return frame_resident_10();
+        case 11: return frame_resident_11(); case 12: return frame_resident_12(); case 13: return frame_resident_13();
+    }
+    return 1;
+}
+
 }  // namespace glv

@@ -83,6 +83,18 @@ def measured_traffic(n: int, streams: int, ops: str):
     return None
 
 
+def streaming_ceiling(n: int, ops: str):
+    """Second, honest denominator: what a do-nothing streaming kernel reaches on MI355X for
+    this pass's read/write mix (tools/membench.hip, committed as profiles/stream_ceiling.json).  Only on file
+    for the FFT+magnitude pass of s16 input (1 byte read : 2 written)."""
+    if ops != "fft":
+        return None
+    try:
+        return float(json.load(open(os.path.join(ROOT, "profiles", "stream_ceiling.json")))["gbs"])
+    except Exception:
+        return None
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -225,6 +237,10 @@ def main() -> None:
                          "algorithmic_bytes_per_launch": alg_bytes, "avg_kernel_ms": avg_kernel_s * 1e3,
                          "kernel": batch.kernel_name()},
         }
+        ceil = streaming_ceiling(n, a.ops)
+        if ceil:
+            line["roofline"]["streaming_ceiling"] = {"value": ceil, "unit": "GB/s", "frac": achieved / ceil,
+                                                     "note": "best do-nothing kernel for the same 1:2 read/write mix, tools/membench.hip"}
         if alt is not None:
             a_el, a_kms, a_nl = alt
             a_k = (a_kms / max(a_nl, 1)) * 1e-3

@@ -147,6 +147,8 @@ struct glv_batch {
     uint32_t ring_pos = 0;       // next write position in the PCM ring, in frames
     int grid_override = 0;
     float* d_scratch = nullptr;  // [streams*2][n] spectra feeding GLV_OP_BARS
+    float* d_ring_f32 = nullptr; // [streams][n][2] interleaved f32 ring (glv_batch_ring_update_f32)
+    uint32_t ring_pos_f32 = 0;
     int* d_smin = nullptr;       // transform_smooth window bounds (host generated)
     int* d_smax = nullptr;
     uint32_t smooth_asz = 0;
@@ -423,6 +425,7 @@ int glv_batch_destroy(glv_batch* b) {
     if (b->d_hist) (void) hipFree(b->d_hist);
     if (b->d_ring) (void) hipFree(b->d_ring);
     if (b->d_scratch) (void) hipFree(b->d_scratch);
+    if (b->d_ring_f32) (void) hipFree(b->d_ring_f32);
     if (b->d_smin) (void) hipFree(b->d_smin);
     if (b->d_smax) (void) hipFree(b->d_smax);
     if (b->d_bar_desc) (void) hipFree(b->d_bar_desc);
@@ -474,6 +477,28 @@ int glv_batch_ring_update_s16(glv_batch* b, const int16_t* d_new, uint32_t new_f
     b->ring_pos = (b->ring_pos + new_frames) % n;
     // oldest sample now sits at ring_pos; rotation in complex points (pairs of frames)
     return process(b, b->d_ring, glv::IN_S16_RING, d_out, ops, b->streams * 2, b->ring_pos / 2, st);
+}
+
+int glv_batch_ring_update_f32(glv_batch* b, const float* d_new, uint32_t new_frames, float* d_out, unsigned ops, void* hip_stream) {
+    if (!b) return fail(GLV_ERR_INVALID, "batch is NULL");
+    if (!(ops & GLV_OP_FFT)) return fail(GLV_ERR_INVALID, "ring mode requires GLV_OP_FFT");
+    if (!d_new) return fail(GLV_ERR_INVALID, "d_new is NULL (the PulseAudio backend has no zero-fill path)");
+    const uint32_t n = b->p.n;
+    if (new_frames == 0 || new_frames > n || (new_frames & 1u) || (n % new_frames) != 0)
+        return fail(GLV_ERR_INVALID, "new_frames=%u: must be even, divide n=%u (sample_sz/4 of pulse_input.c:155-178)", new_frames, n);
+    hipStream_t st = (hipStream_t) hip_stream;
+    HIP_TRY(hipSetDevice(b->device));
+    if (!b->d_ring_f32) {
+        const size_t bytes = sizeof(float) * 2 * (size_t) n * b->streams;
+        HIP_TRY(hipMalloc(&b->d_ring_f32, bytes));
+        HIP_TRY(hipMemset(b->d_ring_f32, 0, bytes));      // == the calloc'd rings of glava.c:487-494
+        b->ring_pos_f32 = 0;
+    }
+    char* dst = reinterpret_cast<char*>(b->d_ring_f32) + (size_t) b->ring_pos_f32 * 8;
+    const size_t pitch = (size_t) n * 8, width = (size_t) new_frames * 8;
+    HIP_TRY(hipMemcpy2DAsync(dst, pitch, d_new, width, width, b->streams, hipMemcpyDeviceToDevice, st));
+    b->ring_pos_f32 = (b->ring_pos_f32 + new_frames) % n;
+    return process(b, b->d_ring_f32, glv::IN_F32_RING, d_out, ops, b->streams * 2, b->ring_pos_f32 / 2, st);
 }
 
 int glv_batch_gravity_state(glv_batch* b, const float** d_state) {

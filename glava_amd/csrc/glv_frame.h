@@ -18,7 +18,7 @@
 
 namespace glv {
 
-enum InMode { IN_S16_STEREO = 0, IN_F32_PLANAR = 1, IN_S16_RING = 2, IN_F32_STEREO = 3 };
+enum InMode { IN_S16_STEREO = 0, IN_F32_PLANAR = 1, IN_S16_RING = 2, IN_F32_STEREO = 3, IN_F32_RING = 4 };
 enum Epi { EPI_RAW = 0, EPI_MAG = 1, EPI_MAG_STATE = 2, EPI_RAW_STATE = 3 };
 
 // ops bits as in include/glv_spectrum.h
@@ -340,10 +340,15 @@ struct Frame {
     // interleaved stereo f32 (pulse_input.c:159-176): one 16-byte load = complex point c of both
     // channels (L[2c], R[2c], L[2c+1], R[2c+1]); mono = (L + R) / 2 in float (pulse_input.c:167)
     struct alignas(16) f4 { float a, b, c, d; };
-    GLV_HD static void load_f32_stereo_window(cf (&v)[E], const void* frame, const void* win, int tid, uint32_t ch, bool mono) {
+    // RING: the frame is a circular buffer whose oldest complex point sits at `rot` (glv_batch_ring_update_f32)
+    template <bool RING = false>
+    GLV_HD static void load_f32_stereo_window(cf (&v)[E], const void* frame, const void* win, int tid, uint32_t ch, bool mono,
+                                              uint32_t rot = 0) {
 #pragma unroll
         for (int i = 0; i < E; ++i) {
-            const f4 u = ld<f4>(frame, (uint32_t) tid * 16u + (uint32_t) (i * T) * 16u);
+            const uint32_t poff = RING ? ((uint32_t) (i * T + tid + rot) & (uint32_t) (NN - 1)) * 16u
+                                       : (uint32_t) tid * 16u + (uint32_t) (i * T) * 16u;
+            const f4 u = ld<f4>(frame, poff);
             const d2 w = ld<d2>(win, (uint32_t) tid * 16u + (uint32_t) (i * T) * 16u);
             float s0, s1;
             if (mono) { s0 = (u.a + u.b) / 2; s1 = (u.c + u.d) / 2; }
@@ -357,12 +362,15 @@ struct Frame {
     // frame.  Two dword loads per point keep the footprint at E registers pairs (a 16-byte load would park
     // the other channel in registers across a whole transform: 64 VGPRs more than the kernel has); the
     // other halves of the same cache lines are read by the channel's sibling row one transform later.
-    GLV_HD static void load_f32s_raw(RawF& r, const void* frame, int tid, uint32_t ch) {
+    template <bool RING = false>
+    GLV_HD static void load_f32s_raw(RawF& r, const void* frame, int tid, uint32_t ch, uint32_t rot = 0) {
         const char* base = static_cast<const char*>(frame) + ch * 4u;
 #pragma unroll
         for (int i = 0; i < E; ++i) {
-            r.p[i].x = ld<float>(base, (uint32_t) tid * 16u + (uint32_t) (i * T) * 16u);
-            r.p[i].y = ld<float>(base, (uint32_t) tid * 16u + (uint32_t) (i * T) * 16u + 8u);
+            const uint32_t poff = RING ? ((uint32_t) (i * T + tid + rot) & (uint32_t) (NN - 1)) * 16u
+                                       : (uint32_t) tid * 16u + (uint32_t) (i * T) * 16u;
+            r.p[i].x = ld<float>(base, poff);
+            r.p[i].y = ld<float>(base, poff + 8u);
         }
     }
 

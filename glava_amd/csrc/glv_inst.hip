@@ -50,6 +50,7 @@ hipError_t GLV_CAT(launch_frame_, GLV_LOG_NN)(int in_mode, int log_mode, const F
         case IN_S16_RING:   return launch_log<IN_S16_RING>(log_mode, a, grid, st);
         case IN_F32_PLANAR: return launch_log<IN_F32_PLANAR>(log_mode, a, grid, st);
         case IN_F32_STEREO: return launch_log<IN_F32_STEREO>(log_mode, a, grid, st);
+        case IN_F32_RING:   return launch_log<IN_F32_RING>(log_mode, a, grid, st);
     }
     return hipErrorInvalidValue;
 }

@@ -419,7 +419,9 @@ glv_frame_kernel(const FrameArgs a) {
         }
         return;
     }
-    if constexpr (IN_MODE == IN_F32_STEREO && PREFETCH == 1 && LOG_E <= 4) {
+    constexpr bool F32S = IN_MODE == IN_F32_STEREO || IN_MODE == IN_F32_RING;
+    constexpr bool RINGF = IN_MODE == IN_F32_RING;
+    if constexpr (F32S && PREFETCH == 1 && LOG_E <= 4) {
         // interleaved stereo f32 (PulseAudio), stereo only (the rare mono mix takes the generic loop below): one
         // slot = one frame, rows back to back, every row fetches its successor row's channel -- the sibling
         // channel of the same frame, then channel 0 of the slot's next frame
@@ -437,7 +439,7 @@ glv_frame_kernel(const FrameArgs a) {
             if (blockIdx.x * SLOTS < nframes) {
                 int tid = tid_outer;
                 asm volatile("" : "+v"(tid));
-                FR::load_f32s_raw(raw, frame_ptr(frame_of(0)), tid, 0u);
+                FR::template load_f32s_raw<RINGF>(raw, frame_ptr(frame_of(0)), tid, 0u, a.rot);
                 FR::window_f32_raw(v, raw, win, tid);
             }
             __builtin_amdgcn_s_waitcnt(0x0F70);
@@ -448,7 +450,7 @@ glv_frame_kernel(const FrameArgs a) {
                 asm volatile("" : "+v"(tid));
                 const bool active = blockIdx.x * SLOTS + m * fstride + slot < nframes;
                 const uint32_t f = frame_of(m);
-                FR::load_f32s_raw(raw, frame_ptr(frame_of(m + ch)), tid, ch ^ 1u);               // A (unconditional)
+                FR::template load_f32s_raw<RINGF>(raw, frame_ptr(frame_of(m + ch)), tid, ch ^ 1u, a.rot);   // A (unconditional)
                 GLV_SCHED_FENCE();
                 BD::template run<0>(v, tw_all, a.tw, xslot, tid, xcount, lds_tw, sy);                // B
                 GLV_SCHED_FENCE();
@@ -479,9 +481,9 @@ glv_frame_kernel(const FrameArgs a) {
             FR::template load_pcm<RING>(raw, static_cast<const char*>(a.in) + (size_t) (row >> 1) * ((size_t) N * 4), tid, a.rot);
             GLV_SCHED_FENCE();
             FR::unpack_window(v, raw, win, tid, row & 1u, a.mono != 0);
-        } else if constexpr (IN_MODE == IN_F32_STEREO) {
-            FR::load_f32_stereo_window(v, static_cast<const char*>(a.in) + (size_t) (row >> 1) * ((size_t) N * 8), win, tid,
-                                       row & 1u, a.mono != 0);
+        } else if constexpr (F32S) {
+            FR::template load_f32_stereo_window<RINGF>(v, static_cast<const char*>(a.in) + (size_t) (row >> 1) * ((size_t) N * 8), win, tid,
+                                                       row & 1u, a.mono != 0, a.rot);
         } else {
             FR::load_f32_window(v, static_cast<const char*>(a.in) + (size_t) row * ((size_t) N * 4), win, tid);
         }

@@ -73,6 +73,7 @@ def lib() -> C.CDLL:
         L.glv_batch_process_f32.argtypes = [vp, vp, vp, C.c_uint, vp]
         L.glv_batch_process_f32_stereo.argtypes = [vp, vp, vp, C.c_uint, vp]
         L.glv_batch_ring_update_s16.argtypes = [vp, vp, C.c_uint32, vp, C.c_uint, vp]
+        L.glv_batch_ring_update_f32.argtypes = [vp, vp, C.c_uint32, vp, C.c_uint, vp]
         L.glv_batch_bars.argtypes = [vp, vp, vp, vp]
         L.glv_batch_gravity_state.argtypes = [vp, C.POINTER(C.c_void_p)]
         L.glv_prelude_bufscale.argtypes = [C.c_int, vp, vp, C.c_size_t, C.c_uint32, C.c_uint32, vp]
@@ -155,6 +156,9 @@ class Batch:
         p = C.c_void_p()
         _check(lib().glv_batch_gravity_state(self._h, C.byref(p)))
         return int(p.value)
+
+    def ring_update_f32(self, d_new, new_frames: int, d_out, ops: int = OP_FFT, stream: int | None = None) -> None:
+        _check(lib().glv_batch_ring_update_f32(self._h, _ptr(d_new), new_frames, _ptr(d_out), ops, _ptr(stream)))
 
     def bars(self, d_spec, d_bars, stream: int | None = None) -> None:
         _check(lib().glv_batch_bars(self._h, _ptr(d_spec), _ptr(d_bars), _ptr(stream)))

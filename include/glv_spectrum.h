@@ -179,6 +179,11 @@ int glv_batch_process_f32_stereo(glv_batch* b, const float* d_pcm, float* d_out,
  * fifo.c:67-79), then transforms the whole window. */
 int glv_batch_ring_update_s16(glv_batch* b, const int16_t* d_new, uint32_t new_frames, float* d_out,
                               unsigned ops, void* hip_stream);
+/* the same ring kept in interleaved f32 frames -- the PulseAudio backend's update (glava/pulse_input.c:
+ * 155-178: shift both rings left by sample_sz/4, append sample_sz/4 stereo f32 frames; channels == 1 mixes
+ * (L + R) / 2 in float).  d_new: float [streams][new_frames][2]; no zero-fill path (pa_simple_read blocks). */
+int glv_batch_ring_update_f32(glv_batch* b, const float* d_new, uint32_t new_frames, float* d_out, unsigned ops,
+                              void* hip_stream);
 
 /* smooth_audio() bar sampling of spectra already in HBM (d_spec float [streams][2][n]) into
  * d_bars float [streams][2][bars]; what GLV_OP_BARS runs after the transform. */

@@ -695,3 +695,29 @@ def test_reference_host_through_shim(G):
                 assert S.glvshim_run(ctypes.byref(p), mode, log_mode, got.ctypes.data_as(ctypes.c_void_p), n, nframes) == 0
                 assert np.allclose(got, ref, rtol=REL, atol=2e-6), (n, mode, log_mode)
                 assert np.isfinite(got).all()
+
+
+@pytest.mark.parametrize("ch", [2, 1])
+def test_pulse_ring_mode(G, ch):
+    """glv_batch_ring_update_f32 == pulse_input.c:155-178: both rings shift left by new_frames, the new interleaved
+    f32 frames are appended (channels == 1: (L + R) / 2 in float), then the whole window is transformed."""
+    import torch
+    n, streams, nf = 2048, 4, 256
+    b = G.Batch(G.Params(n=n, channels=ch), streams, G.OP_FFT)
+    rl = np.zeros((streams, n), np.float32); rr = np.zeros((streams, n), np.float32)
+    d_out = torch.empty((streams * 2, n), dtype=torch.float32, device="cuda")
+    rng = np.random.default_rng(17)
+    for step in range(n // nf + 3):                      # wraps the device ring more than once
+        new = (rng.standard_normal((streams, nf, 2)) * 0.3).astype(np.float32)
+        b.ring_update_f32(torch.from_numpy(new).cuda(), nf, d_out, G.OP_FFT | G.OP_RAW)
+        got = d_out.cpu().numpy()
+        for u in range(streams):
+            pl = np.empty(nf, np.float32); pr = np.empty(nf, np.float32)
+            Oracle.lib().glvo_unpack_f32(np.ascontiguousarray(new[u].reshape(-1)), nf, ch, pl, pr)
+            rl[u] = np.concatenate([rl[u][nf:], pl]); rr[u] = np.concatenate([rr[u][nf:], pr])
+            _, wl = Oracle.transform_fft(rl[u], want_raw=True)
+            _, wr = Oracle.transform_fft(rr[u], want_raw=True)
+            assert (bits(got[2 * u]) == bits(wl)).all() and (bits(got[2 * u + 1]) == bits(wr)).all(), (step, u)
+    with pytest.raises(G.GlvError):
+        b.ring_update_f32(None, nf, d_out, G.OP_FFT)
+    b.close()

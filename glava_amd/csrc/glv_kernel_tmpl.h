@@ -500,22 +500,29 @@ hipError_t launch_variant(const FrameArgs& a, int grid, hipStream_t st) {
     using FR = Frame<LOG_NN, LOG_E>;
     constexpr size_t lds = frame_lds_bytes<LOG_NN, LOG_E, SLOTS, NBUF, WINLDS, TWREG>();
     static_assert(lds <= 160 * 1024, "exchange regions + window exceed the 160 KiB LDS of a gfx950 CU");
-    auto launch = [&](auto k, bool& attr_done) -> hipError_t {
-        if (lds > 64 * 1024 && !attr_done) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
-            if (e != hipSuccess) return e;
-            attr_done = true;
+    // the >64 KiB dynamic-LDS opt-in is a per-device function attribute: remember it per device
+    // (one process per GPU is the deployment, but a host that drives several devices must work too)
+    struct AttrDone { bool dev[64] = {}; };
+    auto launch = [&](auto k, AttrDone& done) -> hipError_t {
+        if (lds > 64 * 1024) {
+            int dev = 0;
+            (void) hipGetDevice(&dev);
+            if (dev < 0 || dev >= 64 || !done.dev[dev]) {
+                hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k),
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
+                if (e != hipSuccess) return e;
+                if (dev >= 0 && dev < 64) done.dev[dev] = true;
+            }
         }
         hipLaunchKernelGGL(k, dim3(grid), dim3(FR::T * SLOTS), lds, st, a);
         return hipGetLastError();
     };
-    static bool done_plain = false, done_state = false;   // per instantiation
+    static AttrDone done_plain, done_state;   // per instantiation
     // the stateful epilogue needs the registers a resident last pass (TWREG 3) would occupy
     constexpr int TW_STATEFUL = TWREG == 3 ? 2 : TWREG;
     if (a.bars_out != nullptr) {
         if constexpr (FR::T % 64 == 0) {
-            static bool done_bars = false;
+            static AttrDone done_bars;
             if (!(a.ops & (OP_GRAVITY | OP_AVERAGE))) return hipErrorInvalidValue;
             return launch(glv_frame_kernel<LOG_NN, IN_MODE, LOG_MODE, SLOTS, NBUF, TW_STATEFUL, WINLDS, OCC, PREFETCH, TILTREG, LOG_E, 2>, done_bars);
         } else return hipErrorInvalidValue;

@@ -721,3 +721,40 @@ def test_pulse_ring_mode(G, ch):
     with pytest.raises(G.GlvError):
         b.ring_update_f32(None, nf, d_out, G.OP_FFT)
     b.close()
+
+
+def test_randomized_parameter_sweep(G):
+    """Random operator parameters (fft_scale, fft_cutoff, gravity_step, ur, F in 1..16, window on/off, mono) at
+    random sizes and ragged stream counts, several consecutive frames each, against the stateful oracle:
+    raw FFT bit-exact, bit-faithful log mode within one float ulp before the state machines, chain <= 1e-5."""
+    import torch
+    rng = np.random.default_rng(20260923)
+    for trial in range(24):
+        n = int(rng.choice([512, 1024, 2048, 4096, 8192, 16384]))
+        streams = int(rng.integers(1, 7))
+        F = int(rng.integers(1, 17))
+        win = bool(rng.integers(0, 2))
+        ch = 1 if trial % 6 == 5 else 2
+        kw = dict(fft_scale=float(np.float32(rng.uniform(0.0, 20.0))), fft_cutoff=float(np.float32(rng.uniform(0.0, 1.0))),
+                  gravity_step=float(np.float32(rng.uniform(0.1, 9.0))), ur=float(np.float32(rng.uniform(20.0, 200.0))))
+        ops = G.OP_FFT | (G.OP_GRAVITY if trial % 3 != 2 else 0) | (G.OP_AVERAGE if trial % 4 != 3 else 0)
+        p = G.Params(n=n, channels=ch, avg_frames=F, avg_window=win, **kw)
+        b = G.Batch(p, streams, ops)
+        b0 = G.Batch(G.Params(n=n, channels=ch, log_mode=0, **kw), streams, G.OP_FFT)
+        sos = [StreamOracle(n, channels=ch, avg_frames=F, avg_window=win, gravity=bool(ops & G.OP_GRAVITY),
+                            average=bool(ops & G.OP_AVERAGE), **kw) for _ in range(streams)]
+        d_out = torch.empty((streams * 2, n), dtype=torch.float32, device="cuda")
+        for fr in range(min(F, 4) + 2):
+            pcm = lcg_pcm_fast(int(rng.integers(1, 1 << 30)), streams * 2 * n)
+            d_pcm = torch.from_numpy(pcm).cuda()
+            b0.process_s16(d_pcm, d_out, G.OP_FFT)
+            strict = d_out.cpu().numpy()
+            b.process_s16(d_pcm, d_out, ops)
+            got = d_out.cpu().numpy()
+            for u in range(streams):
+                seg = pcm[u * 2 * n:(u + 1) * 2 * n]
+                mag = StreamOracle(n, channels=ch, gravity=False, average=False, **kw).frame(seg)
+                assert np.abs(bits(strict[2 * u:2 * u + 2]).astype(np.int64) - bits(mag).astype(np.int64)).max() <= 1, (trial, fr, u)
+                want = sos[u].frame(seg)
+                assert np.allclose(got[2 * u:2 * u + 2], want, rtol=REL, atol=2e-6), (trial, n, F, win, ch, hex(ops), fr, u)
+        b.close(); b0.close()

@@ -646,6 +646,37 @@ int glv_fft_gravity_average(const glv_params* p, glv_state* s, float* buf) {
     return single(p, s, buf, GLV_OP_FFT | GLV_OP_GRAVITY | GLV_OP_AVERAGE);
 }
 
+int glv_device_malloc(int device, size_t bytes, void** d_ptr) {
+    if (!d_ptr) return fail(GLV_ERR_INVALID, "d_ptr is NULL");
+    *d_ptr = nullptr;
+    if (int rc = ensure_device(device)) return rc;
+    if (hipMalloc(d_ptr, bytes ? bytes : 1) != hipSuccess) return fail(GLV_ERR_NOMEM, "hipMalloc(%zu) failed", bytes);
+    return GLV_OK;
+}
+int glv_device_free(int device, void* d_ptr) {
+    if (!d_ptr) return GLV_OK;
+    if (int rc = ensure_device(device)) return rc;
+    HIP_TRY(hipFree(d_ptr));
+    return GLV_OK;
+}
+int glv_device_upload(int device, void* d_dst, const void* h_src, size_t bytes, void* hip_stream) {
+    if (!d_dst || !h_src) return fail(GLV_ERR_INVALID, "NULL pointer");
+    if (int rc = ensure_device(device)) return rc;
+    HIP_TRY(hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, (hipStream_t) hip_stream));
+    return GLV_OK;
+}
+int glv_device_download(int device, void* h_dst, const void* d_src, size_t bytes, void* hip_stream) {
+    if (!h_dst || !d_src) return fail(GLV_ERR_INVALID, "NULL pointer");
+    if (int rc = ensure_device(device)) return rc;
+    HIP_TRY(hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, (hipStream_t) hip_stream));
+    return GLV_OK;
+}
+int glv_device_sync(int device, void* hip_stream) {
+    if (int rc = ensure_device(device)) return rc;
+    HIP_TRY(hipStreamSynchronize((hipStream_t) hip_stream));
+    return GLV_OK;
+}
+
 int glv_unpack_s16(int device, const int16_t* pcm, size_t frames, int channels, float* l, float* r) {
     if (!l || !r) return fail(GLV_ERR_INVALID, "NULL output");
     if (channels != 1 && channels != 2) return fail(GLV_ERR_INVALID, "channels=%d: must be 1 or 2", channels);

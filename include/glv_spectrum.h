@@ -151,6 +151,15 @@ int glv_prelude_lerp(int device, const float* d_start, const float* d_end, float
  *    State (gravity [streams][2][n], history ring [streams][2][F][n]) is owned by the
  *    batch and allocated according to `ops_mask` given at creation.
  * ------------------------------------------------------------------------------------ */
+/* device memory for C hosts that do not want the HIP headers (the audio backend of INTEGRATION.md section 2):
+ * thin wrappers over hipMalloc / hipFree / hipMemcpyAsync on `device`; copies are ordered on hip_stream
+ * (NULL = the default stream) and glv_device_sync waits for it. */
+int glv_device_malloc(int device, size_t bytes, void** d_ptr);
+int glv_device_free(int device, void* d_ptr);
+int glv_device_upload(int device, void* d_dst, const void* h_src, size_t bytes, void* hip_stream);
+int glv_device_download(int device, void* h_dst, const void* d_src, size_t bytes, void* hip_stream);
+int glv_device_sync(int device, void* hip_stream);
+
 typedef struct glv_batch glv_batch;
 
 int glv_batch_create(const glv_params* p, uint32_t streams, unsigned ops_mask, int device, glv_batch** out);

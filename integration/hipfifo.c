@@ -1,0 +1,105 @@
+/*
+ * integration/hipfifo.c -- an `audio_impl` backend for GLava's plugin seam (glava/fifo.h:22-44), as real
+ * code: INTEGRATION.md section 2.
+ *
+ * Same source as the reference's "fifo" backend -- `sample_sz` bytes of interleaved s16 per update from a
+ * named pipe, poll timeout => an update of zeros (fifo.c:63-79) -- but the N-sample rings live on the MI355X
+ * (glv_batch_ring_update_s16: append sample_sz/4 frames, transform the whole window) and what the backend
+ * publishes in audio_out_l / audio_out_r under the mutex are the finished SPECTRA (window, FFT, magnitude of
+ * render.c:783-847), so a module that requests no further "fft" transform renders them as they are.
+ * Everything device-side goes through the C ABI of include/glv_spectrum.h; no HIP headers here.
+ *
+ * Meant to be compiled next to glava/fifo.c (it self-registers with AUDIO_ATTACH like every backend and is
+ * selected with --audio=hipfifo, glava.c:469-479).  integration/shim_harness.c builds it against the
+ * unmodified reference headers; tests/test_gpu_parity.py::test_hipfifo_backend_through_the_registry runs it.
+ */
+#include <errno.h>
+#include <fcntl.h>
+#include <poll.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+#include <unistd.h>
+
+#include <glv_spectrum.h>
+
+#include "fifo.h"
+
+/* observable by tests: how many updates were poll-timeout zero fills (timing dependent) */
+volatile unsigned long glv_hipfifo_zero_fills = 0;
+/* knobs the host would take from its config (rc.glsl): magnitude parameters of the transform */
+float glv_hipfifo_fft_scale = 10.2f, glv_hipfifo_fft_cutoff = 0.3f;
+
+static void glv_hipfifo_die(const char* what) {
+    fprintf(stderr, "hipfifo backend: %s: %s\n", what, glv_last_error());
+    exit(EXIT_FAILURE);                       /* the reference backends' error convention (fifo.c:47-50) */
+}
+
+static void init(struct audio_data* audio) {
+    if (!audio->source) audio->source = strdup("/tmp/mpd.fifo");      /* fifo.c:23-27 */
+}
+
+static void* entry(void* data) {
+    struct audio_data* audio = data;
+    const size_t n = audio->audio_buf_sz, ssz = audio->sample_sz;
+    const uint32_t frames = (uint32_t) (ssz / 4);                      /* stereo frames per update */
+
+    glv_params p;
+    glv_params_default(&p);
+    p.n = (uint32_t) n;
+    p.channels = (uint32_t) audio->channels;                           /* 1 = mirror/mono mix, fifo.c:98-102 */
+    p.fft_scale = glv_hipfifo_fft_scale;
+    p.fft_cutoff = glv_hipfifo_fft_cutoff;
+    glv_batch* batch = NULL;
+    void *d_new = NULL, *d_spec = NULL;
+    if (glv_batch_create(&p, 1, GLV_OP_FFT, 0, &batch) != GLV_OK) glv_hipfifo_die("glv_batch_create");
+    if (glv_device_malloc(0, ssz, &d_new) != GLV_OK || glv_device_malloc(0, 2 * n * sizeof(float), &d_spec) != GLV_OK)
+        glv_hipfifo_die("glv_device_malloc");
+
+    int fd = open(audio->source, O_RDONLY);
+    if (fd == -1) {
+        fprintf(stderr, "hipfifo backend: cannot open \"%s\": %s\n", audio->source, strerror(errno));
+        exit(EXIT_FAILURE);
+    }
+    struct pollfd pfd = { .fd = fd, .events = POLLIN };
+    int16_t* buf = malloc(ssz);
+    float* spec = malloc(2 * n * sizeof(float));
+    const int timeout_ms = 50;                                         /* initial value of fifo.c:39 */
+
+    for (;;) {
+        int rc, ready = poll(&pfd, 1, timeout_ms);
+        if (ready < 0) { fprintf(stderr, "hipfifo backend: poll: %s\n", strerror(errno)); exit(EXIT_FAILURE); }
+        if (ready == 0) {                                              /* nothing arrived: an update of zeros */
+            rc = glv_batch_ring_update_s16(batch, NULL, frames, d_spec, GLV_OP_FFT, NULL);
+        } else {
+            size_t have = 0;                                           /* a full update, like read(fd, buf, ssz) */
+            while (have < ssz) {
+                ssize_t r = read(fd, (char*) buf + have, ssz - have);
+                if (r <= 0) break;
+                have += (size_t) r;
+            }
+            if (have < ssz) memset((char*) buf + have, 0, ssz - have);
+            rc = glv_device_upload(0, d_new, buf, ssz, NULL);
+            if (rc == GLV_OK) rc = glv_batch_ring_update_s16(batch, d_new, frames, d_spec, GLV_OP_FFT, NULL);
+        }
+        if (rc == GLV_OK) rc = glv_device_download(0, spec, d_spec, 2 * n * sizeof(float), NULL);
+        if (rc == GLV_OK) rc = glv_device_sync(0, NULL);
+        if (rc != GLV_OK) glv_hipfifo_die("update");
+
+        pthread_mutex_lock(&audio->mutex);
+        memcpy((void*) audio->audio_out_l, spec, n * sizeof(float));
+        memcpy((void*) audio->audio_out_r, spec + n, n * sizeof(float));
+        if (ready == 0) ++glv_hipfifo_zero_fills;
+        audio->modified = true;
+        pthread_mutex_unlock(&audio->mutex);
+
+        if (audio->terminate == 1) break;                              /* fifo.c:119-122 */
+    }
+    close(fd);
+    free(buf); free(spec);
+    glv_device_free(0, d_new); glv_device_free(0, d_spec);
+    glv_batch_destroy(batch);
+    return NULL;
+}
+
+AUDIO_ATTACH(hipfifo);

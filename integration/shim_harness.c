@@ -55,3 +55,68 @@ int glvshim_run(const glvshim_params* sp, int mode, unsigned log_mode, float* fr
     }
     return 0;
 }
+
+/* ---- audio backend seam (glava/fifo.h): run a registered backend against a named pipe -------------------------
+ * Like glava.c:469-520: look the backend up by name in audio_impls[], start its `entry` on a thread, then feed
+ * `chunks` updates of `ssz` bytes and snapshot audio_out_l/r (fsz floats each) after every update the backend
+ * publishes.  zero_fill[e] = 1 when update e was a poll-timeout update of zeros (timing dependent; the test
+ * replays whatever happened).  Works for the reference's "fifo" backend (snapshots are the sample rings) and for
+ * "hipfifo" (snapshots are spectra).  Returns the number of events, or a negative error. */
+#include <sys/stat.h>
+#include "fifo.h"
+extern volatile unsigned long glv_hipfifo_zero_fills;
+
+long glvshim_backend_run(const char* name, const char* fifo_path, const int16_t* pcm, size_t chunks, size_t ssz, size_t fsz,
+                         int channels, float* snapshots /* [max_events][2][fsz] */, unsigned char* zero_fill, size_t max_events) {
+    struct audio_impl* impl = NULL;
+    for (size_t t = 0; t < audio_impls_idx; ++t)
+        if (!strcmp(audio_impls[t]->name, name)) impl = audio_impls[t];
+    if (!impl) return -1;
+    const bool hip = !strcmp(name, "hipfifo");
+    unlink(fifo_path);
+    if (mkfifo(fifo_path, 0600) != 0) return -2;
+    float* bl = calloc(fsz, sizeof(float));
+    float* br = calloc(fsz, sizeof(float));
+    struct audio_data audio = {
+        .audio_out_r = br, .audio_out_l = bl, .modified = false, .audio_buf_sz = fsz, .sample_sz = ssz,
+        .format = -1, .rate = 22050, .source = strdup(fifo_path), .channels = channels, .terminate = 0,
+        .mutex = PTHREAD_MUTEX_INITIALIZER
+    };
+    pthread_t thr;
+    pthread_create(&thr, NULL, impl->entry, &audio);
+    int wfd = open(fifo_path, O_WRONLY);                  /* blocks until the backend opened its end */
+    if (wfd < 0) return -3;
+    size_t ev = 0;
+    unsigned long zf_seen = hip ? glv_hipfifo_zero_fills : 0;
+    long rc = 0;
+    for (size_t sent = 0; sent < chunks && ev < max_events; ++sent) {
+        if (write(wfd, (const char*) pcm + sent * ssz, ssz) != (ssize_t) ssz) { rc = -4; break; }
+        bool landed = false;
+        while (!landed && ev < max_events) {
+            pthread_mutex_lock(&audio.mutex);
+            if (audio.modified) {
+                audio.modified = false;
+                bool zf;
+                if (hip) { zf = glv_hipfifo_zero_fills != zf_seen; zf_seen = glv_hipfifo_zero_fills; }
+                else {
+                    bool tail_zero = true, input_zero = true;
+                    for (size_t q = fsz - ssz / 4; q < fsz; ++q) if (bl[q] != 0.0f || br[q] != 0.0f) { tail_zero = false; break; }
+                    for (size_t q = 0; q < ssz / 2; ++q) if (pcm[sent * (ssz / 2) + q] != 0) { input_zero = false; break; }
+                    zf = tail_zero && !input_zero;
+                }
+                memcpy(snapshots + (ev * 2 + 0) * fsz, bl, fsz * sizeof(float));
+                memcpy(snapshots + (ev * 2 + 1) * fsz, br, fsz * sizeof(float));
+                zero_fill[ev++] = zf;
+                if (!zf) landed = true;
+            }
+            pthread_mutex_unlock(&audio.mutex);
+            if (!landed) usleep(200);
+        }
+    }
+    audio.terminate = 1;                                   /* noticed after the backend's next event (a timeout) */
+    pthread_join(thr, NULL);
+    close(wfd);
+    unlink(fifo_path);
+    free(bl); free(br); free(audio.source);
+    return rc < 0 ? rc : (long) ev;
+}

@@ -758,3 +758,44 @@ def test_randomized_parameter_sweep(G):
                 want = sos[u].frame(seg)
                 assert np.allclose(got[2 * u:2 * u + 2], want, rtol=REL, atol=2e-6), (trial, n, F, win, ch, hex(ops), fr, u)
         b.close(); b0.close()
+
+
+@pytest.mark.parametrize("channels", [2, 1])
+def test_hipfifo_backend_through_the_registry(G, channels, tmp_path):
+    """The audio-backend seam (glava/fifo.h:22-44) on real code: integration/hipfifo.c self-registers next to the
+    reference's own "fifo" backend in audio_impls[] (both compiled into oracle/_ref/libglvshim.so against the
+    unmodified reference headers); it is looked up by name and run on a thread against a named pipe exactly like
+    glava.c:469-520 does.  Every update it publishes (spectra of the device-resident ring) is checked against a
+    replay on the oracle: fifo.c ring shift/append or zero fill, then transform_fft of both rings."""
+    import ctypes
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "_ref", "libglvshim.so")
+    if not os.path.exists(path):
+        pytest.skip("oracle/_ref/libglvshim.so not built (needs /root/reference at build time)")
+    S = ctypes.CDLL(path)
+    S.glvshim_backend_run.restype = ctypes.c_long
+    S.glvshim_backend_run.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_size_t,
+                                      ctypes.c_size_t, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t]
+    n, ssz, chunks, max_events = 1024, 1024, 9, 64
+    nf = ssz // 4
+    pcm = lcg_pcm_fast(777 + channels, chunks * ssz // 2)
+    snaps = np.zeros((max_events, 2, n), np.float32)
+    zf = np.zeros(max_events, np.uint8)
+    fifo = str(tmp_path / "glv_hipfifo_test.fifo").encode()
+    ev = S.glvshim_backend_run(b"hipfifo", fifo, pcm.ctypes.data_as(ctypes.c_void_p), chunks, ssz, n, channels,
+                               snaps.ctypes.data_as(ctypes.c_void_p), zf.ctypes.data_as(ctypes.c_void_p), max_events)
+    assert ev >= chunks, ev
+    rl = np.zeros(n, np.float32); rr = np.zeros(n, np.float32)
+    sent = 0
+    for e in range(ev):
+        if zf[e]:
+            Oracle.lib().glvo_ring_update_s16(rl, rr, n, None, nf, channels)
+        else:
+            chunk = np.ascontiguousarray(pcm[sent * (ssz // 2):(sent + 1) * (ssz // 2)]); sent += 1
+            Oracle.lib().glvo_ring_update_s16(rl, rr, n, chunk.ctypes.data_as(C.c_void_p), nf, channels)
+        wl = Oracle.transform_fft(rl.copy()); wr = Oracle.transform_fft(rr.copy())
+        assert np.allclose(snaps[e, 0], wl, rtol=REL, atol=1e-7) and np.allclose(snaps[e, 1], wr, rtol=REL, atol=1e-7), e
+    assert sent == chunks
+    # the reference's own backend is in the same registry and runs through the same driver (rings, not spectra)
+    ev2 = S.glvshim_backend_run(b"fifo", fifo, pcm.ctypes.data_as(ctypes.c_void_p), 3, ssz, n, channels,
+                                snaps.ctypes.data_as(ctypes.c_void_p), zf.ctypes.data_as(ctypes.c_void_p), max_events)
+    assert ev2 >= 3

@@ -1,7 +1,7 @@
 // glv_core.h -- per-thread arithmetic and index maps of the spectrum kernels.
 //
 // Everything here is `GLV_HD` so the *same* code is compiled (a) by hipcc into the gfx950
-// kernels in glv_kernels.hip and (b) by g++ into tests/emu (a host "kernel emulator" that
+// kernels (glv_kernel_tmpl.h via glv_inst.hip, glv_misc.hip) and (b) by g++ into tests/emu (a host "kernel emulator" that
 // walks the phases thread by thread) -- index maps and butterflies get exercised against
 // the oracle on the CPU before a GPU is ever touched.
 //
@@ -12,9 +12,9 @@
 //   glava/render.c:842-846   abs / log / tilt
 //   glava/render.c:720-771   gravity, average
 // The *schedule* is new: a Stockham autosort decomposition into in-register radix-2^RB
-// sub-passes (RB <= 4) whose every radix-2 butterfly performs exactly the reference's six
+// sub-passes (RB <= 5) whose every radix-2 butterfly performs exactly the reference's six
 // individually rounded float operations with the reference's recurrence-generated twiddle,
-// so results are bit-identical while the data moves through LDS only ceil(log2(nn)/4)-1
+// so results are bit-identical while the data moves through LDS only ceil(log2(nn)/log2(E))-1
 // times.  Compile with -ffp-contract=off (no FMA contraction anywhere in this file).
 #pragma once
 

@@ -1,17 +1,20 @@
-// glv_frame.h -- the phases one FFT "slot" (T = nn/16 cooperating threads) runs per frame.
+// glv_frame.h -- the phases one FFT "slot" (T = nn/E cooperating lanes, E = 8, 16 or 32 points per lane) runs
+// per channel row, and the arithmetic of the operators that follow the transform.
 //
-// Shared between the gfx950 kernels (glv_kernels.hip) and the host emulator (tests/emu):
-// every function takes the thread id explicitly and touches memory only through the
-// pointers it is given, so the emulator can call the same phase for tid = 0..T-1 in turn
-// where the kernel has T lanes and an s_barrier.
+// Shared between the gfx950 kernels (glv_kernel_tmpl.h, glv_misc.hip) and the host emulator (tests/emu):
+// every function takes the lane id explicitly and touches memory only through the pointers it is given,
+// so the emulator can call the same phase for tid = 0..T-1 in turn where the kernel has T lanes and a
+// slot-scoped synchronisation.
 //
-// Data flow for one channel of one frame (nn = N/2 complex points, P = ceil(log2(nn)/4) passes):
-//   load_inputs      HBM -> registers, fused unpack (fifo.c:94-110) + window (render.c:792-795)
-//   pass<0>          four radix-2 stages in registers (twiddles uniform: scalar loads)
-//   exchange_write / barrier / exchange_read        through LDS (XOR-swizzled after pass 0)
-//   pass<1> ... pass<P-1>
-//   epilogue         abs/log/tilt (render.c:842-846) + gravity (720-736) + average (738-771),
-//                    registers -> HBM
+// Data flow for one channel row (nn = N/2 complex points, P = ceil(log2(nn)/log2(E)) passes):
+//   load_pcm / load_f32*_raw     HBM -> registers (one frame / row ahead of its use)
+//   unpack_window / window_*     fused unpack (fifo.c:94-110) + window (render.c:792-795)
+//   compute<0>                   log2(E) radix-2 stages in registers (twiddles uniform: SGPRs)
+//   exchange_write / sync / exchange_read     through LDS (padded by one point per E after pass 0)
+//   compute<1> ... compute<P-1>
+//   epilogue                     abs/log/tilt (render.c:842-846) + gravity (720-736) + average (738-771),
+//                                registers -> HBM (or -> LDS when the bars are computed in the kernel)
+//   bar_item_*                   smooth_audio() bin averaging (smooth.glsl:13-40) in 64-tap chunks
 #pragma once
 
 #include "glv_core.h"

@@ -5,18 +5,18 @@
 //                      between stages.  Replaces transform_fft/gravity/average
 //                      (glava/render.c:720-847) and the unpack loop of glava/fifo.c:94-110.
 //
-// Execution shape: T = nn/16 lanes cooperate on one FFT ("slot"), SLOTS slots per
-// workgroup; every lane owns 16 complex points and performs up to four radix-2 stages on them
-// in registers between LDS exchanges (ds_write_b64 / ds_read_b64, XOR swizzle after the first
-// pass).  HBM traffic is the algorithmic minimum: PCM in (8 B per lane per load, lanes
-// contiguous), spectra out (8 B per lane, lanes contiguous), state in/out.  Workgroups are
-// persistent over a grid-stride list of frames so per-lane twiddles can stay in VGPRs.
+// Execution shape: T = nn/E lanes cooperate on one FFT ("slot"), SLOTS slots per workgroup;
+// every lane owns E = 8/16/32 complex points and performs up to log2(E) radix-2 stages on them in registers
+// between LDS exchanges (ds_write2_b64 / ds_read2_b64 / ds_read_b128; the pass-0 layout is padded by one
+// point per E).  HBM traffic is the algorithmic minimum: PCM in (8 B per lane per load, lanes contiguous),
+// spectra out (16 B per lane, lanes contiguous), state in/out.  Workgroups are persistent over a
+// grid-stride list of frames so per-lane twiddles and tilt factors can stay in VGPRs.
 //
 // No MFMA: the path is a bandwidth/LDS/VALU problem, not a dense contraction.
 //
 // Tuning knobs (template parameters; production picks one set per size in glv_inst.hip,
 // tools/tune.py sweeps them through glv_tune.hip):
-//   LOG_E   log2 of the points a lane owns (4: E=16, T=nn/16 lanes per row; 3: E=8, T=nn/8)
+//   LOG_E   log2 of the points a lane owns (4: E=16, T=nn/16 lanes per row; 3: E=8, T=nn/8; 5: E=32, T=nn/32)
 //   SLOTS   FFT slots per workgroup
 //   NBUF    1: one LDS exchange region per slot, two barriers per exchange
 //           2: ping-pong regions, one barrier per exchange
@@ -29,7 +29,8 @@
 //              VGPRs; allows 3 waves/SIMD at N=4096 (6 slots), measured slower than 2 (tools/tune.py)
 //   WINLDS  true: window table staged once per workgroup into LDS; false: read through L1/L2
 //   OCC     __launch_bounds__ minimum waves per SIMD (caps the VGPR budget: 512 / OCC)
-//   TILTREG   the 32 per-lane tilt factors stay in VGPRs across rows instead of being re-read per row
+//   TILTREG   0: tilt factors re-read from the table per row; 1: the 2E per-lane factors stay in VGPRs across
+//             rows; 2: evaluated in registers with the reference's float operations (no memory, no registers)
 //   PREFETCH  0: no software pipeline (load, transform, store per row)
 //           1: in-place pipeline -- the next frame's (s16, interleaved f32) or row's (planar f32) samples
 //              are requested before the current row's passes and unpacked/windowed after its epilogue,

@@ -1,7 +1,7 @@
 // glv_inst.hip -- production instantiations of glv_frame_kernel for ONE transform size.
 // Compiled once per size with -DGLV_LOG_NN=k (k = log2(nn) = log2(N) - 1, 8..13) so the six
 // sizes build in parallel.  The knob set per size is the measured best of tools/tune.py
-// (profiles/tune_r01.txt); see DESIGN.md "Kernel configuration".
+// (profiles/tune_r01_final.txt, earlier sweeps in profiles/tune_r01.txt); see DESIGN.md "Kernel configuration".
 #include "glv_kernel_tmpl.h"
 #include "glv_launch.h"
 
@@ -15,9 +15,9 @@ template <int LOG_NN> struct Tuned;
 #define GLV_TUNED(K, LE, S, NB, TR, WL, OC, PF, TL) \
     template <> struct Tuned<K> { static constexpr int log_e = LE, slots = S, nbuf = NB, occ = OC; \
                                   static constexpr bool winlds = WL; static constexpr int twreg = TR, tiltreg = TL, prefetch = PF; };
-// measured best of tools/tune.py on MI355X (profiles/tune_r01.txt), equal bytes per size class:
+// measured best of tools/tune.py on MI355X (profiles/tune_r01_final.txt), equal bytes per size class:
 //         log2(nn) LOG_E SLOTS NBUF TWREG  WINLDS OCC PREFETCH TILTREG      (knob values: glv_kernel_tmpl.h)
-GLV_TUNED(8,       4,    16,   1,   true,  true,  2,  1,       true)    // N=512    E=16: 4+4
+GLV_TUNED(8,       3,    16,   1,   true,  true,  4,  1,       true)    // N=512    E=8:  3+3+2
 GLV_TUNED(9,       3,    4,    1,   true,  true,  4,  1,       true)    // N=1024   E=8:  3+3+3
 GLV_TUNED(10,      3,    2,    1,   true,  true,  4,  1,       true)    // N=2048   E=8:  3+3+3+1
 GLV_TUNED(11,      4,    2,    1,   true,  true,  2,  1,       true)    // N=4096   E=16: 4+4+3

@@ -93,3 +93,21 @@ def test_product_does_not_reference_the_oracle():
     out = subprocess.run(["ldd", os.path.join(ROOT, "glava_amd", "csrc", "libglvspectrum.so")],
                          capture_output=True, text=True).stdout
     assert "oracle" not in out and "glvref" not in out and "glvemu" not in out
+
+
+def test_integration_shim_library_links_the_abi():
+    """oracle/_ref/libglvshim.so (the reference's render.c / fifo.c with integration/*.c compiled in) is built
+    whenever /root/reference is present: it must export the harness entry points and the hipfifo backend's
+    constructor, and import (not define) the C ABI it forwards to."""
+    import subprocess
+    path = os.path.join(ROOT, "oracle", "_ref", "libglvshim.so")
+    if not os.path.exists(path):
+        pytest.skip("oracle/_ref/libglvshim.so not built (needs /root/reference at build time)")
+    out = subprocess.run(["nm", "-D", path], capture_output=True, text=True, check=True).stdout
+    defined = {l.split()[-1] for l in out.splitlines() if " T " in l or " D " in l or " B " in l}
+    undefined = {l.split()[-1] for l in out.splitlines() if " U " in l}
+    for sym in ("glvshim_run", "glvshim_backend_run", "_hipfifo_construct", "transform_fft_hip", "transform_fga_hip", "glv_hip_release"):
+        assert sym in defined, sym
+    for sym in ("glv_fft", "glv_gravity", "glv_average", "glv_fft_gravity_average", "glv_state_create",
+                "glv_batch_ring_update_s16", "glv_device_upload", "glv_device_download"):
+        assert sym in undefined, sym

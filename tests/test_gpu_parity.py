@@ -799,3 +799,44 @@ def test_hipfifo_backend_through_the_registry(G, channels, tmp_path):
     ev2 = S.glvshim_backend_run(b"fifo", fifo, pcm.ctypes.data_as(ctypes.c_void_p), 3, ssz, n, channels,
                                 snaps.ctypes.data_as(ctypes.c_void_p), zf.ctypes.data_as(ctypes.c_void_p), max_events)
     assert ev2 >= 3
+
+
+def test_f32_inputs_through_stateful_and_fused_paths(G):
+    """The pipelined f32 input paths (planar rows, interleaved stereo, the PulseAudio ring) through the stateful
+    kernel and the fused bars: same bits as the s16-free reference chain built from the stateless pass + the
+    standalone operators (glv_post_kernel, glv_bars_kernel)."""
+    import torch
+    n, streams, bars, F = 4096, 6, 80, 3
+    ops = G.OP_FFT | G.OP_GRAVITY | G.OP_AVERAGE
+    p = G.Params(n=n, bars=bars, avg_frames=F)
+    rng = np.random.default_rng(5150)
+    chain = {k: G.Batch(p, streams, ops) for k in ("planar", "stereo", "ring", "planar_bars", "stereo_bars")}
+    ref_fft = G.Batch(p, streams, ops)                    # stateless pass, then the operators one by one
+    d_spec = torch.empty((streams * 2, n), dtype=torch.float32, device="cuda")
+    d_ref = torch.empty_like(d_spec)
+    d_bars = torch.empty((streams * 2, bars), dtype=torch.float32, device="cuda")
+    d_bars_ref = torch.empty_like(d_bars)
+    for fr in range(F + 2):
+        x = (rng.standard_normal((streams, n, 2)) * 0.01).astype(np.float32)             # interleaved frames
+        d_st = torch.from_numpy(x).cuda()
+        d_pl = torch.from_numpy(np.ascontiguousarray(x.transpose(0, 2, 1))).cuda()        # planar [streams][2][n]
+        # reference: fft+magnitude (stateless kernel), then gravity+average on rows in HBM, then bars from HBM
+        ref_fft.process_f32(d_pl, d_ref, G.OP_FFT)
+        ref_fft.process_f32(d_ref, d_ref, G.OP_GRAVITY | G.OP_AVERAGE)
+        ref_fft.bars(d_ref, d_bars_ref)
+        chain["planar"].process_f32(d_pl, d_spec, ops)
+        torch.cuda.synchronize()
+        assert torch.equal(d_spec.view(torch.int32), d_ref.view(torch.int32)), ("planar", fr)
+        chain["stereo"].process_f32_stereo(d_st, d_spec, ops)
+        torch.cuda.synchronize()
+        assert torch.equal(d_spec.view(torch.int32), d_ref.view(torch.int32)), ("stereo", fr)
+        chain["ring"].ring_update_f32(d_st, n, d_spec, ops)                                # whole-window update
+        torch.cuda.synchronize()
+        assert torch.equal(d_spec.view(torch.int32), d_ref.view(torch.int32)), ("ring", fr)
+        chain["planar_bars"].process_f32(d_pl, d_bars, ops | G.OP_BARS)
+        torch.cuda.synchronize()
+        assert torch.equal(d_bars.view(torch.int32), d_bars_ref.view(torch.int32)), ("planar bars", fr)
+        chain["stereo_bars"].process_f32_stereo(d_st, d_bars, ops | G.OP_BARS)
+        torch.cuda.synchronize()
+        assert torch.equal(d_bars.view(torch.int32), d_bars_ref.view(torch.int32)), ("stereo bars", fr)
+    for b in list(chain.values()) + [ref_fft]: b.close()

@@ -553,7 +553,7 @@ struct Frame {
             // gravity without average: ONE state value per point, so all of the row's state can be requested
             // up front (2E registers) and its latency hides behind the log/tilt arithmetic -- in blocks, as below,
             // every block's loads were a separate exposed round trip (N=4096 fft+gravity: 0.72 -> ms)
-            if (!(a.ops & OP_AVERAGE) && (a.ops & OP_GRAVITY) && E <= 16) {
+            if (!(a.ops & OP_AVERAGE) && (a.ops & OP_GRAVITY) && E <= 32) {
                 float* gs = a.grav + row * (size_t) N;
                 cf st0[E];
 #pragma unroll

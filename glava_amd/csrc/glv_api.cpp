@@ -354,6 +354,7 @@ int batch_create_rows(const glv_params* p, uint32_t streams, unsigned ops_mask, 
     *out = nullptr;
     if (int rc = validate(p)) return rc;
     if (streams == 0) return fail(GLV_ERR_INVALID, "streams must be > 0");
+    if (streams > (1u << 30)) return fail(GLV_ERR_INVALID, "streams=%u: at most 2^30 (row indices are 32-bit)", streams);
     if (int rc = ensure_device(device)) return rc;
     glv_batch* b = new (std::nothrow) glv_batch();
     if (!b) return fail(GLV_ERR_NOMEM, "out of host memory");
@@ -413,7 +414,8 @@ int glv_batch_reset(glv_batch* b) {
     if (b->d_hist) HIP_TRY(hipMemset(b->d_hist, 0, sizeof(float) * rows * b->p.avg_frames * n));
     if (b->d_grav) HIP_TRY(hipMemset(b->d_grav, 0, sizeof(float) * rows * n));
     if (b->d_ring) HIP_TRY(hipMemset(b->d_ring, 0, sizeof(int16_t) * 2 * n * b->streams));
-    b->head = 0; b->ring_pos = 0;
+    if (b->d_ring_f32) HIP_TRY(hipMemset(b->d_ring_f32, 0, sizeof(float) * 2 * n * b->streams));
+    b->head = 0; b->ring_pos = 0; b->ring_pos_f32 = 0;
     return GLV_OK;
 }
 

@@ -85,6 +85,28 @@ struct SlotSync {
     }
 };
 
+// ---- poor man's phase trace (GLV_EXP_PHASETIME, tools/tune.py builds only) -----------------------------------
+// wave 0 of workgroup 0 adds the s_memtime cycles it spends in each phase of the row loop to g_phase[]:
+//   0 A (issue PCM loads)  1..P compute of pass 0..P-1  P+1.. exchange after pass 0.. (write, sync, gather, sync, read)
+//   14 W (vmcnt wait)  15 D (epilogue)  16 C (unpack + window)  17 rows
+#if defined(GLV_EXP_PHASETIME)
+__device__ unsigned long long g_phase[32];
+struct PhaseClock {
+    unsigned long long t;
+    bool on;
+    __device__ __forceinline__ void start() { on = blockIdx.x == 0 && threadIdx.x == 0; t = __builtin_readcyclecounter(); }
+    __device__ __forceinline__ void lap(int slot) {
+        const unsigned long long n = __builtin_readcyclecounter();
+        if (on) g_phase[slot] += n - t;
+        t = n;
+    }
+};
+#define GLV_PHASE(clk, slot) (clk).lap(slot)
+#else
+struct PhaseClock { __device__ __forceinline__ void start() {} };
+#define GLV_PHASE(clk, slot) ((void) 0)
+#endif
+
 template <int LOG_NN, int LOG_E, int NBUF, int TWREG>
 struct Body {
     using FR = Frame<LOG_NN, LOG_E>;
@@ -142,7 +164,7 @@ struct Body {
     // so that the backend cannot pull the table loads of later passes (30 VGPRs each) up front.
     template <int PASS, typename SYNC>
     static __device__ __forceinline__ void run(cf (&v)[FR::E], cf* tw_all, const cf* __restrict__ table,
-                                               char* xslot, int tid, unsigned& xcount, const cf* lds_tw, SYNC& sy) {
+                                               char* xslot, int tid, unsigned& xcount, const cf* lds_tw, SYNC& sy, PhaseClock& clk) {
         // pass 0's twiddles are the same for every lane (k0 = 0); the kernel gathers them once, before
         // the row loop, into scalar registers (gather_uniform_tw0) -- a vector load here would sit in
         // front of every row's first butterfly AND, vmcnt being in-order, behind the PCM prefetch.
@@ -150,6 +172,7 @@ struct Body {
         return;
 #endif
         FR::template compute<PASS>(v, tw_ref<PASS>(tw_all));
+        GLV_PHASE(clk, 1 + PASS);
         if constexpr (PASS + 1 < P) {
             char* xb = xslot + (NBUF == 2 ? (size_t) (xcount & 1u) * FR::XREGION * sizeof(cf) : 0);
             GLV_SCHED_FENCE();
@@ -164,8 +187,12 @@ struct Body {
 #endif
             FR::template exchange_read<PASS + 1>(v, xb, tid);
             GLV_SCHED_FENCE();
+#if defined(GLV_EXP_PHASETIME)
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#endif
+            GLV_PHASE(clk, 1 + P + PASS);
             ++xcount;
-            run<PASS + 1>(v, tw_all, table, xslot, tid, xcount, lds_tw, sy);
+            run<PASS + 1>(v, tw_all, table, xslot, tid, xcount, lds_tw, sy, clk);
         }
     }
 };
@@ -239,6 +266,8 @@ glv_frame_kernel(const FrameArgs a) {
         sy.counter = ctr;
     }
 
+    PhaseClock clk;
+    clk.start();
     cf tw_all[BD::TW_TOTAL];
     BD::gather_uniform_tw0(tw_all, a.tw);
     if constexpr (FR::P > 1) BD::template gather_resident<1>(tw_all, a.tw, tid);
@@ -376,14 +405,23 @@ glv_frame_kernel(const FrameArgs a) {
             const uint32_t fraw = blockIdx.x * SLOTS + m * fstride + slot;
             const bool active = fraw < nframes;
             const uint32_t f = frame_of(m);
+            GLV_PHASE(clk, 18);                                                                  // loop overhead since C
             if (ch) FR::template load_pcm<RING>(raw, frame_ptr(frame_of(m + 1)), tid, a.rot);   // A
             GLV_SCHED_FENCE();
-            BD::template run<0>(v, tw_all, a.tw, xslot, tid, xcount, lds_tw, sy);                            // B
+            GLV_PHASE(clk, 0);
+            BD::template run<0>(v, tw_all, a.tw, xslot, tid, xcount, lds_tw, sy, clk);                            // B
             GLV_SCHED_FENCE();
             __builtin_amdgcn_s_waitcnt(0x0F70);                                                  // W
+            GLV_PHASE(clk, 14);
             finish_row(v, (size_t) f * 2 + ch, tid, active);                                     // D
             GLV_SCHED_FENCE();
+            GLV_PHASE(clk, 15);
             FR::unpack_window(v, raw, win, tid, ch ^ 1u, a.mono != 0);                           // C
+#if defined(GLV_EXP_PHASETIME)
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            if (clk.on) g_phase[17] += 1;
+#endif
+            GLV_PHASE(clk, 16);
         }
         return;
     }
@@ -411,7 +449,7 @@ glv_frame_kernel(const FrameArgs a) {
             const bool has_next = step + 1 < nsteps && nb < a.units;
             FR::load_f32_raw(raw, row_ptr(row_of(has_next ? nb : base)), tid);                   // A (unconditional)
             GLV_SCHED_FENCE();
-            BD::template run<0>(v, tw_all, a.tw, xslot, tid, xcount, lds_tw, sy);                    // B
+            BD::template run<0>(v, tw_all, a.tw, xslot, tid, xcount, lds_tw, sy, clk);                    // B
             GLV_SCHED_FENCE();
             __builtin_amdgcn_s_waitcnt(0x0F70);                                                  // W
             finish_row(v, (size_t) row, tid, active);                                            // D
@@ -453,7 +491,7 @@ glv_frame_kernel(const FrameArgs a) {
                 const uint32_t f = frame_of(m);
                 FR::template load_f32s_raw<RINGF>(raw, frame_ptr(frame_of(m + ch)), tid, ch ^ 1u, a.rot);   // A (unconditional)
                 GLV_SCHED_FENCE();
-                BD::template run<0>(v, tw_all, a.tw, xslot, tid, xcount, lds_tw, sy);                // B
+                BD::template run<0>(v, tw_all, a.tw, xslot, tid, xcount, lds_tw, sy, clk);                // B
                 GLV_SCHED_FENCE();
                 __builtin_amdgcn_s_waitcnt(0x0F70);                                              // W
                 finish_row(v, (size_t) f * 2 + ch, tid, active);                                 // D
@@ -488,7 +526,7 @@ glv_frame_kernel(const FrameArgs a) {
         } else {
             FR::load_f32_window(v, static_cast<const char*>(a.in) + (size_t) row * ((size_t) N * 4), win, tid);
         }
-        BD::template run<0>(v, tw_all, a.tw, xslot, tid, xcount, lds_tw, sy);
+        BD::template run<0>(v, tw_all, a.tw, xslot, tid, xcount, lds_tw, sy, clk);
         finish_row(v, (size_t) row, tid, active);
     }
 }

@@ -170,6 +170,7 @@ struct glv_batch {
 struct glv_state {
     glv_batch* b = nullptr;      // a one-row batch (one channel of one stream)
     float* d_io = nullptr;       // n floats staging
+    uint16_t* d_tex = nullptr;   // n GL_R16 texels (glv_texels_r16)
 };
 
 namespace {
@@ -285,7 +286,9 @@ int process(glv_batch* b, const void* d_in, int in_mode, float* d_out, unsigned 
     if ((ops & GLV_OP_WRANGE) && (ops & GLV_OP_FFT)) return fail(GLV_ERR_INVALID, "GLV_OP_WRANGE excludes GLV_OP_FFT");
     if ((ops & GLV_OP_RAW) && !(ops & GLV_OP_FFT)) return fail(GLV_ERR_INVALID, "GLV_OP_RAW needs GLV_OP_FFT");
     if ((ops & GLV_OP_MAGNITUDE) && (ops & (GLV_OP_FFT | GLV_OP_WRANGE))) return fail(GLV_ERR_INVALID, "GLV_OP_MAGNITUDE excludes GLV_OP_FFT and GLV_OP_WRANGE");
-    if (!(ops & (GLV_OP_FFT | GLV_OP_GRAVITY | GLV_OP_AVERAGE | GLV_OP_WRANGE | GLV_OP_SMOOTH | GLV_OP_MAGNITUDE))) return fail(GLV_ERR_INVALID, "empty ops");
+    if (!(ops & (GLV_OP_FFT | GLV_OP_GRAVITY | GLV_OP_AVERAGE | GLV_OP_WRANGE | GLV_OP_SMOOTH | GLV_OP_MAGNITUDE | GLV_OP_R16))) return fail(GLV_ERR_INVALID, "empty ops");
+    if ((ops & GLV_OP_R16) && (ops & (GLV_OP_RAW | GLV_OP_BARS | GLV_OP_SMOOTH))) return fail(GLV_ERR_INVALID, "GLV_OP_R16 excludes GLV_OP_RAW, GLV_OP_BARS and GLV_OP_SMOOTH");
+    if ((ops & GLV_OP_R16) && !d_out) return fail(GLV_ERR_INVALID, "GLV_OP_R16 needs an output buffer");
     if ((ops & GLV_OP_BARS) && (b->p.bars == 0 || b->p.bars > b->p.n)) return fail(GLV_ERR_INVALID, "bars=%u out of range", b->p.bars);
     float* d_final = d_out;
     HIP_TRY(hipSetDevice(b->device));
@@ -319,7 +322,7 @@ int process(glv_batch* b, const void* d_in, int in_mode, float* d_out, unsigned 
 
     if (int rc = timed_launch_begin(b, st)) return rc;
     hipError_t e;
-    const unsigned core = ops & (GLV_OP_FFT | GLV_OP_GRAVITY | GLV_OP_AVERAGE | GLV_OP_WRANGE | GLV_OP_MAGNITUDE);
+    const unsigned core = ops & (GLV_OP_FFT | GLV_OP_GRAVITY | GLV_OP_AVERAGE | GLV_OP_WRANGE | GLV_OP_MAGNITUDE | GLV_OP_R16);
     if (!core) {                                   // smooth / bars only: operate on a copy of the input rows
         if (in_mode != glv::IN_F32_PLANAR) return fail(GLV_ERR_INVALID, "operators without GLV_OP_FFT take planar f32 input");
         e = (const void*) d_out == d_in ? hipSuccess
@@ -570,8 +573,9 @@ uint64_t glv_batch_algorithmic_bytes(const glv_batch* b, unsigned ops, int input
     //   + gravity (no average): 20N in SURVEY 8d row B, which lets the output double as the state; this
     //     implementation keeps a separate state buffer (one more 8N write) but reports the survey's figure
     //   + average: read (F-1) ring slots 8N each, write the newest slot 8N (doubles as gravity state)
+    //   GLV_OP_R16: the output is 2 bytes per value: 4N instead of 8N
     const uint64_t N = b->p.n, F = b->p.avg_frames;
-    uint64_t per = (input_is_s16 ? 4 * N : 8 * N) + 8 * N;
+    uint64_t per = (input_is_s16 ? 4 * N : 8 * N) + ((ops & GLV_OP_R16) ? 4 * N : 8 * N);
     if (ops & GLV_OP_AVERAGE) per += 8 * N * (F - 1) + 8 * N;
     else if (ops & GLV_OP_GRAVITY) per += 8 * N;
     return per * b->streams;
@@ -617,6 +621,7 @@ int glv_state_destroy(glv_state* s) {
     if (!s) return GLV_OK;
     if (s->b) { (void) hipSetDevice(s->b->device); glv_batch_destroy(s->b); }
     if (s->d_io) (void) hipFree(s->d_io);
+    if (s->d_tex) (void) hipFree(s->d_tex);
     delete s;
     return GLV_OK;
 }
@@ -646,6 +651,20 @@ int glv_smooth(const glv_params* p, glv_state* s, float* buf) { return single(p,
 int glv_magnitude(const glv_params* p, glv_state* s, float* buf) { return single(p, s, buf, GLV_OP_MAGNITUDE); }
 int glv_fft_gravity_average(const glv_params* p, glv_state* s, float* buf) {
     return single(p, s, buf, GLV_OP_FFT | GLV_OP_GRAVITY | GLV_OP_AVERAGE);
+}
+int glv_texels_r16(const glv_params* p, glv_state* s, const float* buf, uint16_t* texels) {
+    if (!s || !s->b) return fail(GLV_ERR_INVALID, "state is NULL");
+    if (!buf || !texels) return fail(GLV_ERR_INVALID, "NULL buffer");
+    if (int rc = validate(p)) return rc;
+    glv_batch* b = s->b;
+    if (p->n != b->p.n) return fail(GLV_ERR_STATE, "params n=%u does not match the state (n=%u)", p->n, b->p.n);
+    HIP_TRY(hipSetDevice(b->device));
+    if (!s->d_tex) HIP_TRY(hipMalloc(&s->d_tex, sizeof(uint16_t) * p->n));
+    HIP_TRY(hipMemcpyAsync(s->d_io, buf, sizeof(float) * p->n, hipMemcpyHostToDevice, nullptr));
+    if (int rc = process(b, s->d_io, glv::IN_F32_PLANAR, reinterpret_cast<float*>(s->d_tex), GLV_OP_R16, 1, 0, nullptr)) return rc;
+    HIP_TRY(hipMemcpyAsync(texels, s->d_tex, sizeof(uint16_t) * p->n, hipMemcpyDeviceToHost, nullptr));
+    HIP_TRY(hipStreamSynchronize(nullptr));
+    return GLV_OK;
 }
 
 int glv_device_malloc(int device, size_t bytes, void** d_ptr) {

@@ -266,6 +266,25 @@ GLV_HD float tilt_factor(int n, float inv_n, float fft_scale, float one_minus_cu
     return FOLD_LN2_3 ? t * kLn2Third : t;
 }
 
+// The GL_R16 texel a float becomes when handle_audio uploads the finished buffer
+// (render.c:521-524: glTexImage1D(GL_TEXTURE_1D, 0, GL_R16, sz, 0, GL_RED, GL_FLOAT, buf)): clamp to [0, 1],
+// scale by 65535, round to nearest (ties to even).  x * 65535 has at most 40 significant bits, so the double
+// product is exact and rint() is the only rounding.  NaN clamps to 0 (fmax/fmin semantics).  On the device this
+// is one v_cvt_pknorm_u16_f32 per two values (tests/test_gpu_parity.py checks every one of the 2^32 floats).
+GLV_HD uint32_t unorm16(float x) {
+    const float c = __builtin_fminf(__builtin_fmaxf(x, 0.0f), 1.0f);
+    return (uint32_t) __builtin_rint((double) c * 65535.0);
+}
+GLV_HD uint32_t pack_unorm16(float lo, float hi) {
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(GLV_R16_SOFT)
+    typedef unsigned short glv_us2 __attribute__((ext_vector_type(2)));
+    const glv_us2 p = __builtin_amdgcn_cvt_pknorm_u16(lo, hi);
+    return __builtin_bit_cast(uint32_t, p);
+#else
+    return unorm16(lo) | (unorm16(hi) << 16);
+#endif
+}
+
 // render.c:730-734
 GLV_HD float gravity(float b, float applied, float g) {
     return (b >= applied ? b : applied) - g;

@@ -25,7 +25,7 @@ enum InMode { IN_S16_STEREO = 0, IN_F32_PLANAR = 1, IN_S16_RING = 2, IN_F32_STER
 enum Epi { EPI_RAW = 0, EPI_MAG = 1, EPI_MAG_STATE = 2, EPI_RAW_STATE = 3 };
 
 // ops bits as in include/glv_spectrum.h
-enum : uint32_t { OP_FFT = 1u, OP_GRAVITY = 2u, OP_AVERAGE = 4u, OP_RAW = 8u, OP_WRANGE = 16u, OP_BARS = 32u, OP_SMOOTH = 64u, OP_MAGNITUDE = 128u };
+enum : uint32_t { OP_FFT = 1u, OP_GRAVITY = 2u, OP_AVERAGE = 4u, OP_RAW = 8u, OP_WRANGE = 16u, OP_BARS = 32u, OP_SMOOTH = 64u, OP_MAGNITUDE = 128u, OP_R16 = 256u };
 
 // one output bar of GLV_OP_BARS: taps are consecutive bins [first_bin, first_bin + count) with weights
 // tap_w[tap_offset ...]; weight_sum = float sum of the weights in tap order (smooth.glsl:31-36)
@@ -264,14 +264,35 @@ struct Frame {
     // WCHUNK window pairs are fetched per scheduling fence: two chunks in flight hide the L2/LDS
     // latency of the table while keeping the transient footprint at 2*WCHUNK*4 VGPRs.
     static constexpr int WCHUNK = E < 4 ? E : 4;
-    template <bool MONO>
-    GLV_HD static void unpack_window_impl(cf (&v)[E], const Raw& p, const void* win, int tid, uint32_t ch_shift) {
+    // WPRE: the window values of the lane's first WPRE points were fetched ahead (window_prefetch).  Kernels whose
+    // window table is not in LDS (N=16384) issue these loads BEFORE the epilogue's spectrum stores: vmcnt retires
+    // in order, so a table load issued after the stores cannot be consumed until every store has drained, while
+    // one issued before them only waits for itself (and has the whole magnitude stage to arrive).
+    template <int WPRE> struct WinPre { d2 w[WPRE > 0 ? WPRE : 1]; };
+    template <int WPRE>
+    GLV_HD static void window_prefetch(WinPre<WPRE>& wp, const void* win, int tid) {
+#pragma unroll
+        for (int j = 0; j < WPRE; ++j) wp.w[j] = ld<d2>(win, (uint32_t) tid * 16u + (uint32_t) (j * T) * 16u);
+    }
+    template <bool MONO, int WPRE = 0>
+    GLV_HD static void unpack_window_impl(cf (&v)[E], const Raw& p, const void* win, int tid, uint32_t ch_shift, const d2* wpre = nullptr) {
+        static_assert(WPRE % WCHUNK == 0 && WPRE <= E, "WPRE: whole chunks");
         d2 w[2][WCHUNK];
+        if constexpr (WPRE < E) {
 #pragma unroll
-        for (int j = 0; j < WCHUNK; ++j) w[0][j] = ld<d2>(win, (uint32_t) tid * 16u + (uint32_t) (j * T) * 16u);
+            for (int j = 0; j < WCHUNK; ++j) w[0][j] = ld<d2>(win, (uint32_t) tid * 16u + (uint32_t) ((WPRE + j) * T) * 16u);
+        }
+        if constexpr (WPRE > 0) {
+            GLV_SCHED_FENCE();
 #pragma unroll
-        for (int c0 = 0; c0 < E; c0 += WCHUNK) {
-            const int cur = (c0 / WCHUNK) & 1;
+            for (int i = 0; i < WPRE; ++i) {
+                v[i].x = apply_window(sample(p.x[i], ch_shift, MONO), wpre[i].x);   // render.c:794
+                v[i].y = apply_window(sample(p.y[i], ch_shift, MONO), wpre[i].y);
+            }
+        }
+#pragma unroll
+        for (int c0 = WPRE; c0 < E; c0 += WCHUNK) {
+            const int cur = ((c0 - WPRE) / WCHUNK) & 1;
             if (c0 + WCHUNK < E) {
 #pragma unroll
                 for (int j = 0; j < WCHUNK; ++j)
@@ -289,10 +310,11 @@ struct Frame {
     }
     // three code versions (mono, left, right): with a compile-time shift the channel select becomes the
     // operand selector of the conversion (v_cvt_f32_i32_sdwa WORD_0 / WORD_1) instead of a shift per sample
-    GLV_HD static void unpack_window(cf (&v)[E], const Raw& p, const void* win, int tid, uint32_t ch, bool mono) {
-        if (mono) unpack_window_impl<true>(v, p, win, tid, 0);
-        else if (ch) unpack_window_impl<false>(v, p, win, tid, 16u);
-        else unpack_window_impl<false>(v, p, win, tid, 0u);
+    template <int WPRE = 0>
+    GLV_HD static void unpack_window(cf (&v)[E], const Raw& p, const void* win, int tid, uint32_t ch, bool mono, const d2* wpre = nullptr) {
+        if (mono) unpack_window_impl<true, WPRE>(v, p, win, tid, 0, wpre);
+        else if (ch) unpack_window_impl<false, WPRE>(v, p, win, tid, 16u, wpre);
+        else unpack_window_impl<false, WPRE>(v, p, win, tid, 0u, wpre);
     }
     GLV_HD static void load_f32_window(cf (&v)[E], const void* row, const void* win, int tid) {
 #pragma unroll
@@ -390,8 +412,24 @@ struct Frame {
     // Last pass: G = tid*NG + gi -- the lane's groups are ADJACENT, so its outputs come in runs of NG
     // consecutive complex points: 16-byte ds_read_b128 / global_store_dwordx4 instead of 8-byte ones
     // (the spectrum store is issue-bound, not bandwidth-bound: half the instructions, half the time).
+    // SWAP16 (last pass with ONE group per lane: N=1024 at E=8, N=8192 at E=16): a lane's outputs are then nn/R
+    // points apart, which would mean 8-byte stores.  Instead the lanes of a wave take the groups in the order
+    //     lane l = (b5 | h | m3..m0)  ->  group (b5 | m3..m0 | h)
+    // so that lanes l and l^16 own ADJACENT groups; after the magnitude stage one v_permlane16_swap_b32 per
+    // register pair (rows of 16 lanes trade registers: a 2x2 transpose) leaves every lane with two adjacent
+    // points per register pair and the spectrum leaves in 16-byte stores like at the other sizes.  A 32-lane
+    // half of the wave still covers 32 consecutive groups, so the LDS reads of the pass stay conflict free.
+#if defined(GLV_EXP_NOSWAP16)     /* tools/tune.py A/B builds: the round-1 layout (8-byte stores) */
+    static constexpr bool SWAP16 = false;
+#else
+    static constexpr bool SWAP16 = P >= 2 && (E >> PL::rb(P - 1)) == 1 && (T % 64) == 0;
+#endif
+    GLV_HD static constexpr int swap16_lane_group(int tid) {
+        return (tid & ~31) | ((tid & 15) << 1) | ((tid >> 4) & 1);
+    }
     template <int PASS>
     GLV_HD static constexpr int group_of(int tid, int gi) {
+        if (PASS == P - 1 && SWAP16) return swap16_lane_group(tid);
         return PASS == P - 1 ? tid * PassInfo<PASS>::NG + gi : gi * T + tid;
     }
 
@@ -501,9 +539,44 @@ struct Frame {
                 tl[gi * PI::R + r] = ld<cf>(tilt, (uint32_t) out_index<P - 1>(tid, gi, r) * 8u);
     }
 
+    // ---- output pairs ---------------------------------------------------------------------------------------------
+    // The epilogue leaves the row in 16-byte pieces: two memory-adjacent complex points per lane and store.  With two
+    // or more groups per lane in the last pass they are the same register slot of neighbouring groups; with one group
+    // per lane (SWAP16) the neighbouring group lives 16 lanes away and is fetched with v_permlane16_swap_b32.  The host
+    // emulator walks lanes one at a time and cannot swap: it stores the same values point by point instead.
+#if defined(__HIP_DEVICE_COMPILE__)
+    static constexpr bool SWAP_DEV = SWAP16;
+#else
+    static constexpr bool SWAP_DEV = false;
+#endif
+    static constexpr bool PAIRS = (E >> PL::rb(P - 1)) >= 2 || SWAP_DEV;
+#if defined(__HIP_DEVICE_COMPILE__)
+    // rows of 16 lanes trade registers: afterwards (a, b) hold (own a, neighbour's a) in the even rows and
+    // (neighbour's b, own b) in the odd rows -- in both cases the pair (lower group, upper group) of ONE output slot.
+    // gfx950 wants two wait states between a VALU write and the swap reading it, and after the swap.
+    __device__ __forceinline__ static void swap16(cf& a0, cf& b0, cf& a1, cf& b1) {
+        asm("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\tv_permlane16_swap_b32 %2, %3\n\t"
+            "v_permlane16_swap_b32 %4, %5\n\tv_permlane16_swap_b32 %6, %7\n\ts_nop 1"
+            : "+v"(a0.x), "+v"(b0.x), "+v"(a0.y), "+v"(b0.y), "+v"(a1.x), "+v"(b1.x), "+v"(a1.y), "+v"(b1.y));
+    }
+#endif
+    // byte offset (f32 rows) of the lane's pair p = 0 .. E/2-1; pairs (p, p+1) with p even are swapped together
+    GLV_HD static uint32_t pair_offset(int tid, int p) {
+        using PI = PassInfo<P - 1>;
+        if constexpr (SWAP16) {
+            const int h = (tid >> 4) & 1;
+            const int lane_q = group_of<P - 1>(tid, 0) - h + h * ((PI::R / 2) * PI::L0);   // odd rows own slot r + 1: bitrev(1) = R/2
+            return (uint32_t) (lane_q + bitrev(2 * p, PI::RB) * PI::L0) * 8u;
+        } else {
+            const int idx = 2 * p;
+            return (uint32_t) out_index<P - 1>(tid, idx % PI::NG, idx / PI::NG) * 8u;
+        }
+    }
+
     // TILTREG 0: tilt factors read from the table per row; 1: from `tl_reg` (registers, gathered once per
     // kernel); 2: evaluated in registers with the reference's float operations (no memory at all)
-    template <int LOG_MODE, int EPI, int TILTREG = 0>
+    // R16: the output row is uint16 [n] (GL_R16 texels, glv_core.h unorm16) instead of float [n]; state stays f32
+    template <int LOG_MODE, int EPI, int TILTREG = 0, bool R16 = false>
     GLV_HD static void epilogue(const cf (&v)[E], float* out_row, size_t row, int tid, const FrameArgs& a,
                                 const LogEntry* logtab, const cf* tl_reg = nullptr) {
         using PI = PassInfo<P - 1>;
@@ -513,7 +586,7 @@ struct Frame {
             cf val = v[gi * PI::R + r];
 #if !defined(GLV_EXP_NOCOMPUTE)
             if constexpr (EPI == EPI_MAG || EPI == EPI_MAG_STATE) {
-                const int q = out_index<P - 1>(tid, gi, r);     // = tid*NG + compile-time constant
+                const int q = out_index<P - 1>(tid, gi, r);     // = lane base + compile-time constant
                 const float y0 = __builtin_fabsf(val.x) + 1.0f, y1 = __builtin_fabsf(val.y) + 1.0f;   // render.c:843-844
                 cf tl;                                                                                      // :845 factors
                 if constexpr (TILTREG == 1) tl = tl_reg[gi * PI::R + r];
@@ -527,26 +600,61 @@ struct Frame {
 #endif
             return val;
         };
+        // the lane's pairs 2*p2 and 2*p2 + 1 (PAIRS only): values in memory order
+        auto two_pairs = [&](int p2, cf2& t0, cf2& t1) {
+            if constexpr (SWAP_DEV) {
+#if defined(__HIP_DEVICE_COMPILE__)
+                t0.a = value(0, 4 * p2);     t0.b = value(0, 4 * p2 + 1);
+                t1.a = value(0, 4 * p2 + 2); t1.b = value(0, 4 * p2 + 3);
+                swap16(t0.a, t0.b, t1.a, t1.b);
+#endif
+            } else {
+                const int i0 = 4 * p2, i1 = 4 * p2 + 2;
+                t0.a = value(i0 % PI::NG, i0 / PI::NG); t0.b = value(i0 % PI::NG + 1, i0 / PI::NG);
+                t1.a = value(i1 % PI::NG, i1 / PI::NG); t1.b = value(i1 % PI::NG + 1, i1 / PI::NG);
+            }
+        };
+        // one finished pair / point -> the output row (f32 or GL_R16 texels)
+        auto store_pair = [&](uint32_t off, const cf2& two) {
+            if constexpr (R16) {
+                const u32x2 q = { pack_unorm16(two.a.x, two.a.y), pack_unorm16(two.b.x, two.b.y) };
+                st<u32x2>(out_row, off / 2u, q);
+            } else st<cf2>(out_row, off, two);
+        };
+        auto store_point = [&](uint32_t off, const cf& one) {
+            if constexpr (R16) st<uint32_t>(out_row, off / 2u, pack_unorm16(one.x, one.y));
+            else st<cf>(out_row, off, one);
+        };
         if constexpr (!STATE) {
             // stateless: value -> store, pair by pair (nothing but the pair in flight)
+            if constexpr (SWAP_DEV) {
 #pragma unroll
-            for (int r = 0; r < PI::R; ++r) {
-                if constexpr (PI::NG >= 2) {
+                for (int p2 = 0; p2 < E / 4; ++p2) {
+                    cf2 t0, t1;
+                    two_pairs(p2, t0, t1);
+                    store_pair(pair_offset(tid, 2 * p2), t0);
+                    store_pair(pair_offset(tid, 2 * p2 + 1), t1);
+                }
+            } else {
 #pragma unroll
-                    for (int gi = 0; gi < PI::NG; gi += 2) {             // adjacent groups: 16-byte stores
-                        cf2 two;
-                        two.a = value(gi, r);
-                        two.b = value(gi + 1, r);
+                for (int r = 0; r < PI::R; ++r) {
+                    if constexpr (PI::NG >= 2) {
+#pragma unroll
+                        for (int gi = 0; gi < PI::NG; gi += 2) {             // adjacent groups: 16-byte stores
+                            cf2 two;
+                            two.a = value(gi, r);
+                            two.b = value(gi + 1, r);
 #if defined(GLV_EXP_NOSTORE)   /* tools/tune.py experiment: keep 1 store in 16 (never in product builds) */
-                        if (r == 0 && gi == 0)
+                            if (r == 0 && gi == 0)
 #endif
-                        st<cf2>(out_row, (uint32_t) out_index<P - 1>(tid, gi, r) * 8u, two);
-                    }
-                } else {
+                            store_pair((uint32_t) out_index<P - 1>(tid, gi, r) * 8u, two);
+                        }
+                    } else {
 #if defined(GLV_EXP_NOSTORE)
-                    if (r == 0)
+                        if (r == 0)
 #endif
-                    st<cf>(out_row, (uint32_t) out_index<P - 1>(tid, 0, r) * 8u, value(0, r));
+                        store_point((uint32_t) out_index<P - 1>(tid, 0, r) * 8u, value(0, r));
+                    }
                 }
             }
         } else {
@@ -555,6 +663,25 @@ struct Frame {
             // every block's loads were a separate exposed round trip (N=4096 fft+gravity: 0.72 -> ms)
             if (!(a.ops & OP_AVERAGE) && (a.ops & OP_GRAVITY) && E <= 32) {
                 float* gs = a.grav + row * (size_t) N;
+                if constexpr (SWAP_DEV) {
+                    cf2 st0[E / 2];
+#pragma unroll
+                    for (int p = 0; p < E / 2; ++p) st0[p] = ld<cf2>(gs, pair_offset(tid, p));
+#pragma unroll
+                    for (int p2 = 0; p2 < E / 4; ++p2) {
+                        cf2 t[2];
+                        two_pairs(p2, t[0], t[1]);
+#pragma unroll
+                        for (int k = 0; k < 2; ++k) {
+                            const int p = 2 * p2 + k;
+                            t[k].a.x = gravity(t[k].a.x, st0[p].a.x, a.g); t[k].a.y = gravity(t[k].a.y, st0[p].a.y, a.g);
+                            t[k].b.x = gravity(t[k].b.x, st0[p].b.x, a.g); t[k].b.y = gravity(t[k].b.y, st0[p].b.y, a.g);
+                            st<cf2>(gs, pair_offset(tid, p), t[k]);
+                            if (out_row != nullptr) store_pair(pair_offset(tid, p), t[k]);
+                        }
+                    }
+                    return;
+                }
                 cf st0[E];
 #pragma unroll
                 for (int idx = 0; idx < E; ++idx)
@@ -570,10 +697,10 @@ struct Frame {
                         vb.x = gravity(vb.x, st0[idx + 1].x, a.g); vb.y = gravity(vb.y, st0[idx + 1].y, a.g);
                         cf2 two; two.a = va; two.b = vb;
                         st<cf2>(gs, off, two);
-                        if (out_row != nullptr) st<cf2>(out_row, off, two);
+                        if (out_row != nullptr) store_pair(off, two);
                     } else {
                         st<cf>(gs, off, va);
-                        if (out_row != nullptr) st<cf>(out_row, off, va);
+                        if (out_row != nullptr) store_point(off, va);
                     }
                 }
                 return;
@@ -585,22 +712,33 @@ struct Frame {
             for (int h0 = 0; h0 < E; h0 += BLK) {
                 cf val[BLK];
                 uint32_t off[BLK];
-                // enumeration order: r outer, gi inner => adjacent groups sit next to each other in val[]
+                if constexpr (SWAP_DEV) {
+                    // memory order after the swap: pairs h0/2 .. of the lane
 #pragma unroll
-                for (int j = 0; j < BLK; ++j) {
-                    const int idx = h0 + j, r = idx / PI::NG, gi = idx % PI::NG;
-                    val[j] = value(gi, r);
-                    off[j] = (uint32_t) out_index<P - 1>(tid, gi, r) * 8u;
+                    for (int j = 0; j < BLK; j += 4) {
+                        cf2 t0, t1;
+                        two_pairs((h0 + j) / 4, t0, t1);
+                        val[j] = t0.a; val[j + 1] = t0.b; val[j + 2] = t1.a; val[j + 3] = t1.b;
+                        off[j] = pair_offset(tid, (h0 + j) / 2);     off[j + 1] = off[j] + 8u;
+                        off[j + 2] = pair_offset(tid, (h0 + j) / 2 + 1); off[j + 3] = off[j + 2] + 8u;
+                    }
+                } else {
+                    // enumeration order: r outer, gi inner => adjacent groups sit next to each other in val[]
+#pragma unroll
+                    for (int j = 0; j < BLK; ++j) {
+                        const int idx = h0 + j, r = idx / PI::NG, gi = idx % PI::NG;
+                        val[j] = value(gi, r);
+                        off[j] = (uint32_t) out_index<P - 1>(tid, gi, r) * 8u;
+                    }
                 }
                 apply_state_block<BLK>(val, off, row, (uint32_t) N, a);
                 if (out_row == nullptr) continue;                     // uniform: output aliased to the gravity state
 #pragma unroll
                 for (int j = 0; j < BLK; ++j) {
-                    const int gi = (h0 + j) % PI::NG;
-                    if constexpr (PI::NG >= 2) {
-                        if (gi % 2 == 0) { cf2 two; two.a = val[j]; two.b = val[j + 1]; st<cf2>(out_row, off[j], two); }
+                    if constexpr (PAIRS) {
+                        if (j % 2 == 0) { cf2 two; two.a = val[j]; two.b = val[j + 1]; store_pair(off[j], two); }
                     } else {
-                        st<cf>(out_row, off[j], val[j]);
+                        store_point(off[j], val[j]);
                     }
                 }
             }

@@ -12,17 +12,18 @@
 namespace glv {
 
 template <int LOG_NN> struct Tuned;
-#define GLV_TUNED(K, LE, S, NB, TR, WL, OC, PF, TL) \
+#define GLV_TUNED(K, LE, S, NB, TR, WL, OC, PF, TL, WP, WPS) \
     template <> struct Tuned<K> { static constexpr int log_e = LE, slots = S, nbuf = NB, occ = OC; \
-                                  static constexpr bool winlds = WL; static constexpr int twreg = TR, tiltreg = TL, prefetch = PF; };
+                                  static constexpr bool winlds = WL; static constexpr int twreg = TR, tiltreg = TL, prefetch = PF, wpre = WP, wpre_s = WPS; };
 // measured best of tools/tune.py on MI355X (profiles/tune_r01_final.txt), equal bytes per size class:
-//         log2(nn) LOG_E SLOTS NBUF TWREG  WINLDS OCC PREFETCH TILTREG      (knob values: glv_kernel_tmpl.h)
-GLV_TUNED(8,       3,    16,   1,   true,  true,  4,  1,       true)    // N=512    E=8:  3+3+2
-GLV_TUNED(9,       3,    4,    1,   true,  true,  4,  1,       true)    // N=1024   E=8:  3+3+3
-GLV_TUNED(10,      3,    2,    1,   true,  true,  4,  1,       true)    // N=2048   E=8:  3+3+3+1
-GLV_TUNED(11,      4,    2,    1,   true,  true,  2,  1,       true)    // N=4096   E=16: 4+4+3
-GLV_TUNED(12,      4,    2,    1,   true,  true,  2,  1,       true)    // N=8192   E=16: 4+4+4; two slots share the 64 KiB LDS window
-GLV_TUNED(13,      5,    1,    1,   2,     false, 2,  1,       2)       // N=16384  E=32: 5+5+3; pass-1 twiddles from an 8 KiB LDS table, tilt computed
+//         log2(nn) LOG_E SLOTS NBUF TWREG  WINLDS OCC PREFETCH TILTREG WPRE WPRE_S     (knob values: glv_kernel_tmpl.h)
+GLV_TUNED(8,       3,    16,   1,   true,  true,  4,  1,       true,   0,   0)    // N=512    E=8:  3+3+2
+GLV_TUNED(9,       3,    4,    1,   true,  true,  4,  1,       true,   0,   0)    // N=1024   E=8:  3+3+3 (last pass: one group per lane, SWAP16 stores)
+GLV_TUNED(10,      3,    2,    1,   true,  true,  4,  1,       true,   0,   0)    // N=2048   E=8:  3+3+3+1
+GLV_TUNED(11,      4,    2,    1,   true,  true,  2,  1,       true,   0,   0)    // N=4096   E=16: 4+4+3
+GLV_TUNED(12,      4,    2,    1,   true,  true,  2,  1,       true,   0,   0)    // N=8192   E=16: 4+4+4 (SWAP16 stores); two slots share the 64 KiB LDS window
+GLV_TUNED(13,      5,    1,    1,   2,     false, 2,  1,       2,      16,  0)    // N=16384  E=32: 5+5+3; pass-1 twiddles from an 8 KiB LDS table, tilt computed,
+                                                                                  //          half of the next row's window requested ahead of the spectrum stores
 #undef GLV_TUNED
 
 #define GLV_CAT2(a, b) a##b
@@ -31,7 +32,7 @@ GLV_TUNED(13,      5,    1,    1,   2,     false, 2,  1,       2)       // N=163
 template <int IN_MODE, int LOG_MODE>
 static hipError_t launch_one(const FrameArgs& a, int grid, hipStream_t st) {
     using TU = Tuned<GLV_LOG_NN>;
-    return launch_variant<GLV_LOG_NN, IN_MODE, LOG_MODE, TU::slots, TU::nbuf, TU::twreg, TU::winlds, TU::occ, TU::prefetch, TU::tiltreg, TU::log_e>(a, grid, st);
+    return launch_variant<GLV_LOG_NN, IN_MODE, LOG_MODE, TU::slots, TU::nbuf, TU::twreg, TU::winlds, TU::occ, TU::prefetch, TU::tiltreg, TU::log_e, TU::wpre, TU::wpre_s>(a, grid, st);
 }
 
 template <int IN_MODE>

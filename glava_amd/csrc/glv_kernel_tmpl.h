@@ -41,6 +41,8 @@
 
 #include <hip/hip_runtime.h>
 
+#include <atomic>
+
 #include "glv_frame.h"
 
 namespace glv {
@@ -213,7 +215,7 @@ static __device__ __forceinline__ uint32_t maybe_scalar(uint32_t v) {
 }
 
 template <int LOG_NN, int IN_MODE, int LOG_MODE, int SLOTS, int NBUF, int TWREG, bool WINLDS, int OCC, int PREFETCH, int TILTREG,
-          int LOG_E, int STATEFUL>
+          int LOG_E, int STATEFUL, int WPRE = 0>
 __global__ void __launch_bounds__((Frame<LOG_NN, LOG_E>::T * SLOTS), OCC)
 glv_frame_kernel(const FrameArgs a) {
     using FR = Frame<LOG_NN, LOG_E>;
@@ -282,17 +284,30 @@ glv_frame_kernel(const FrameArgs a) {
     // STATEFUL 0: no state (FFT + magnitude only)   1: gravity / average   2: gravity / average with the
     // bars computed in the kernel (fused GLV_OP_BARS): the finished row is written to the slot's LDS
     // exchange region (idle between a row's last exchange and the next row's first) instead of HBM.
+    // 3: no state, output as GL_R16 texels (GLV_OP_R16: uint16 [units][n], 8N instead of 12N bytes per frame);
+    // the stateful kernels test the bit at run time (their register budget is set by the history loads anyway).
     constexpr bool FUSED_BARS = STATEFUL == 2;
+    constexpr bool HAS_STATE = STATEFUL == 1 || STATEFUL == 2;
     static_assert(!FUSED_BARS || WAVE_SLOT, "fused bars need whole waves per row");
     static_assert(!FUSED_BARS || NBUF == 1, "fused bars reuse exchange region 0: needs the two-barrier exchange");
     auto finish = [&](const cf (&v)[E], size_t row, int tid) {
         // a.out == nullptr (gravity without average only): the spectra ARE the gravity state
         // (render.c:733-734 stores the same value to both), so the second copy is not written
         float* out_row = FUSED_BARS ? reinterpret_cast<float*>(xslot)
-                                    : (STATEFUL && a.out == nullptr ? nullptr : a.out + row * N);
-        if constexpr (STATEFUL != 0) {
-            if (raw_out) FR::template epilogue<LOG_MODE, EPI_RAW_STATE>(v, out_row, row, tid, a, logtab);
-            else FR::template epilogue<LOG_MODE, EPI_MAG_STATE, TILTREG>(v, out_row, row, tid, a, logtab, tilt_reg);
+                                    : (HAS_STATE && a.out == nullptr ? nullptr : a.out + row * N);
+        if constexpr (HAS_STATE) {
+            if (!FUSED_BARS && (a.ops & OP_R16) && out_row != nullptr) {          // uniform
+                float* out16 = reinterpret_cast<float*>(reinterpret_cast<uint16_t*>(a.out) + row * N);
+                if (raw_out) FR::template epilogue<LOG_MODE, EPI_RAW_STATE, 0, true>(v, out16, row, tid, a, logtab);
+                else FR::template epilogue<LOG_MODE, EPI_MAG_STATE, TILTREG, true>(v, out16, row, tid, a, logtab, tilt_reg);
+            } else {
+                if (raw_out) FR::template epilogue<LOG_MODE, EPI_RAW_STATE>(v, out_row, row, tid, a, logtab);
+                else FR::template epilogue<LOG_MODE, EPI_MAG_STATE, TILTREG>(v, out_row, row, tid, a, logtab, tilt_reg);
+            }
+        } else if constexpr (STATEFUL == 3) {
+            float* out16 = reinterpret_cast<float*>(reinterpret_cast<uint16_t*>(a.out) + row * N);
+            if (raw_out) FR::template epilogue<LOG_MODE, EPI_RAW, 0, true>(v, out16, row, tid, a, logtab);
+            else FR::template epilogue<LOG_MODE, EPI_MAG, TILTREG, true>(v, out16, row, tid, a, logtab, tilt_reg);
         } else {
             if (raw_out) FR::template epilogue<LOG_MODE, EPI_RAW>(v, out_row, row, tid, a, logtab);
             else FR::template epilogue<LOG_MODE, EPI_MAG, TILTREG>(v, out_row, row, tid, a, logtab, tilt_reg);
@@ -413,10 +428,13 @@ glv_frame_kernel(const FrameArgs a) {
             GLV_SCHED_FENCE();
             __builtin_amdgcn_s_waitcnt(0x0F70);                                                  // W
             GLV_PHASE(clk, 14);
+            // WPRE: the first window values of row r+1 are requested ahead of D's stores (glv_frame.h window_prefetch)
+            typename FR::template WinPre<WPRE> wp;
+            if constexpr (WPRE > 0) { FR::template window_prefetch<WPRE>(wp, win, tid); GLV_SCHED_FENCE(); }
             finish_row(v, (size_t) f * 2 + ch, tid, active);                                     // D
             GLV_SCHED_FENCE();
             GLV_PHASE(clk, 15);
-            FR::unpack_window(v, raw, win, tid, ch ^ 1u, a.mono != 0);                           // C
+            FR::template unpack_window<WPRE>(v, raw, win, tid, ch ^ 1u, a.mono != 0, wp.w);      // C
 #if defined(GLV_EXP_PHASETIME)
             asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
             if (clk.on) g_phase[17] += 1;
@@ -534,41 +552,45 @@ glv_frame_kernel(const FrameArgs a) {
 
 
 template <int LOG_NN, int IN_MODE, int LOG_MODE, int SLOTS, int NBUF, int TWREG, bool WINLDS, int OCC, int PREFETCH, int TILTREG,
-          int LOG_E = 4>
+          int LOG_E = 4, int WPRE = 0, int WPRE_S = 0>
 hipError_t launch_variant(const FrameArgs& a, int grid, hipStream_t st) {
     using FR = Frame<LOG_NN, LOG_E>;
     constexpr size_t lds = frame_lds_bytes<LOG_NN, LOG_E, SLOTS, NBUF, WINLDS, TWREG>();
     static_assert(lds <= 160 * 1024, "exchange regions + window exceed the 160 KiB LDS of a gfx950 CU");
     // the >64 KiB dynamic-LDS opt-in is a per-device function attribute: remember it per device
     // (one process per GPU is the deployment, but a host that drives several devices must work too)
-    struct AttrDone { bool dev[64] = {}; };
+    // (several host threads may drive several devices through the same instantiation -- glv_multi_*: the flags are
+    // atomics; two threads racing on one device at worst both set the attribute, which is idempotent)
+    struct AttrDone { std::atomic<bool> dev[64] = {}; };
     auto launch = [&](auto k, AttrDone& done) -> hipError_t {
         if (lds > 64 * 1024) {
             int dev = 0;
             (void) hipGetDevice(&dev);
-            if (dev < 0 || dev >= 64 || !done.dev[dev]) {
+            if (dev < 0 || dev >= 64 || !done.dev[dev].load(std::memory_order_acquire)) {
                 hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k),
                                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
                 if (e != hipSuccess) return e;
-                if (dev >= 0 && dev < 64) done.dev[dev] = true;
+                if (dev >= 0 && dev < 64) done.dev[dev].store(true, std::memory_order_release);
             }
         }
         hipLaunchKernelGGL(k, dim3(grid), dim3(FR::T * SLOTS), lds, st, a);
         return hipGetLastError();
     };
-    static AttrDone done_plain, done_state;   // per instantiation
+    static AttrDone done_plain, done_state, done_r16;   // per instantiation
     // the stateful epilogue needs the registers a resident last pass (TWREG 3) would occupy
     constexpr int TW_STATEFUL = TWREG == 3 ? 2 : TWREG;
     if (a.bars_out != nullptr) {
         if constexpr (FR::T % 64 == 0) {
             static AttrDone done_bars;
             if (!(a.ops & (OP_GRAVITY | OP_AVERAGE))) return hipErrorInvalidValue;
-            return launch(glv_frame_kernel<LOG_NN, IN_MODE, LOG_MODE, SLOTS, NBUF, TW_STATEFUL, WINLDS, OCC, PREFETCH, TILTREG, LOG_E, 2>, done_bars);
+            return launch(glv_frame_kernel<LOG_NN, IN_MODE, LOG_MODE, SLOTS, NBUF, TW_STATEFUL, WINLDS, OCC, PREFETCH, TILTREG, LOG_E, 2, WPRE_S>, done_bars);
         } else return hipErrorInvalidValue;
     }
     if (a.ops & (OP_GRAVITY | OP_AVERAGE))
-        return launch(glv_frame_kernel<LOG_NN, IN_MODE, LOG_MODE, SLOTS, NBUF, TW_STATEFUL, WINLDS, OCC, PREFETCH, TILTREG, LOG_E, 1>, done_state);
-    return launch(glv_frame_kernel<LOG_NN, IN_MODE, LOG_MODE, SLOTS, NBUF, TWREG, WINLDS, OCC, PREFETCH, TILTREG, LOG_E, 0>, done_plain);
+        return launch(glv_frame_kernel<LOG_NN, IN_MODE, LOG_MODE, SLOTS, NBUF, TW_STATEFUL, WINLDS, OCC, PREFETCH, TILTREG, LOG_E, 1, WPRE_S>, done_state);
+    if (a.ops & OP_R16)
+        return launch(glv_frame_kernel<LOG_NN, IN_MODE, LOG_MODE, SLOTS, NBUF, TWREG, WINLDS, OCC, PREFETCH, TILTREG, LOG_E, 3, WPRE>, done_r16);
+    return launch(glv_frame_kernel<LOG_NN, IN_MODE, LOG_MODE, SLOTS, NBUF, TWREG, WINLDS, OCC, PREFETCH, TILTREG, LOG_E, 0, WPRE>, done_plain);
 }
 
 }  // namespace glv

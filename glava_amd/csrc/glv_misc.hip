@@ -32,7 +32,10 @@ __global__ void __launch_bounds__(256) glv_post_kernel(const FrameArgs a, const 
             val.x = p / 2.0f; val.y = q / 2.0f;
         }
         val = apply_state(val, off, row, n, a);
-        if (a.out) st<cf>(a.out + row * n, off, val);
+        if (a.out) {
+            if (a.ops & OP_R16) st<uint32_t>(reinterpret_cast<uint16_t*>(a.out) + row * n, off / 2u, pack_unorm16(val.x, val.y));   // render.c:521-524
+            else st<cf>(a.out + row * n, off, val);
+        }
     }
 }
 

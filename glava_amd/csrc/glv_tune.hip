@@ -20,17 +20,20 @@ struct Variant {
     int slots;
 };
 
-template <int SLOTS, int NBUF, int TWREG, bool WINLDS, int OCC, int PF = 0, int TL = 0, int LE = 4>
+template <int SLOTS, int NBUF, int TWREG, bool WINLDS, int OCC, int PF = 0, int TL = 0, int LE = 4, int WP = 0, int WPS = 0>
 hipError_t launch_v(int in_mode, int log_mode, const FrameArgs& a, int grid, hipStream_t st) {
     constexpr int K = GLV_TUNE_LOG_NN;
     if (in_mode != IN_S16_STEREO) return hipErrorInvalidValue;
-    if (log_mode == 0) return launch_variant<K, IN_S16_STEREO, 0, SLOTS, NBUF, TWREG, WINLDS, OCC, PF, TL, LE>(a, grid, st);
-    return launch_variant<K, IN_S16_STEREO, 1, SLOTS, NBUF, TWREG, WINLDS, OCC, PF, TL, LE>(a, grid, st);
+#if !defined(GLV_TUNE_NO_LOG0)
+    if (log_mode == 0) return launch_variant<K, IN_S16_STEREO, 0, SLOTS, NBUF, TWREG, WINLDS, OCC, PF, TL, LE, WP, WPS>(a, grid, st);
+#endif
+    return launch_variant<K, IN_S16_STEREO, 1, SLOTS, NBUF, TWREG, WINLDS, OCC, PF, TL, LE, WP, WPS>(a, grid, st);
 }
 
 #define V(S, NB, TR, WL, OC) { "slots=" #S " nbuf=" #NB " twreg=" #TR " winlds=" #WL " occ=" #OC, launch_v<S, NB, TR, WL, OC>, S }
 #define VX(S, NB, TR, WL, OC, PF, TL) { "slots=" #S " nbuf=" #NB " twreg=" #TR " winlds=" #WL " occ=" #OC " pf=" #PF " tiltreg=" #TL, launch_v<S, NB, TR, WL, OC, PF, TL>, S }
 #define VE(S, NB, TR, WL, OC, PF, TL, LE) { "slots=" #S " nbuf=" #NB " twreg=" #TR " winlds=" #WL " occ=" #OC " pf=" #PF " tiltreg=" #TL " log_e=" #LE, launch_v<S, NB, TR, WL, OC, PF, TL, LE>, S }
+#define VW(S, NB, TR, WL, OC, PF, TL, LE, WP, WPS) { "slots=" #S " nbuf=" #NB " twreg=" #TR " winlds=" #WL " occ=" #OC " pf=" #PF " tiltreg=" #TL " log_e=" #LE " wpre=" #WP " wpre_s=" #WPS, launch_v<S, NB, TR, WL, OC, PF, TL, LE, WP, WPS>, S }
 #define VP(S, NB, TR, WL, OC) { "slots=" #S " nbuf=" #NB " twreg=" #TR " winlds=" #WL " occ=" #OC " prefetch", launch_v<S, NB, TR, WL, OC, true>, S }
 const Variant kVariants[] = {
 #ifdef GLV_TUNE_VARIANTS
@@ -47,6 +50,7 @@ const Variant kVariants[] = {
 #undef VP
 #undef VX
 #undef VE
+#undef VW
 
 }  // namespace
 }  // namespace glv
@@ -71,8 +75,15 @@ int glv_tune_launch(int i, int in_mode, int log_mode, const glv::FrameArgs* a, i
 // Self-contained timing of one variant: `iters` launches over `units` stereo frames of s16 PCM
 // already in HBM (FFT + magnitude only), HIP events around the whole run on `stream`.
 // Returns average milliseconds per launch in *ms.  Tables are created once per process.
+// extra_ops: OR'ed into OP_FFT (OP_R16: d_out receives uint16 texels; OP_GRAVITY: d_grav = float [units*2][n] state)
+int glv_tune_run2(int i, const void* d_pcm, float* d_out, unsigned units, int log_mode, int grid, int iters,
+                  void* stream, float* ms, unsigned extra_ops, float* d_grav);
 int glv_tune_run(int i, const void* d_pcm, float* d_out, unsigned units, int log_mode, int grid, int iters,
                  void* stream, float* ms) {
+    return glv_tune_run2(i, d_pcm, d_out, units, log_mode, grid, iters, stream, ms, 0u, nullptr);
+}
+int glv_tune_run2(int i, const void* d_pcm, float* d_out, unsigned units, int log_mode, int grid, int iters,
+                  void* stream, float* ms, unsigned extra_ops, float* d_grav) {
     using namespace glv;
     static cf* d_tw = nullptr;
     static double* d_win = nullptr;
@@ -103,7 +114,7 @@ int glv_tune_run(int i, const void* d_pcm, float* d_out, unsigned units, int log
     }
     FrameArgs a;
     std::memset(&a, 0, sizeof(a));
-    a.in = d_pcm; a.out = d_out; a.tw = d_tw; a.win = d_win; a.logtab = d_log; a.tilt = log_mode == 1 ? d_tilt_fast : d_tilt; a.units = units * 2; a.ops = OP_FFT;
+    a.in = d_pcm; a.out = d_out; a.tw = d_tw; a.win = d_win; a.logtab = d_log; a.tilt = log_mode == 1 ? d_tilt_fast : d_tilt; a.units = units * 2; a.ops = OP_FFT | extra_ops; a.grav = d_grav;
     a.F = 1; a.inv_n = 1.0f / (float) N; a.fft_scale = 10.2f; a.one_minus_cutoff = 1.0f - 0.3f;
     a.g = 4.2f * (1.0f / 86.1328125f); a.F_as_float = 1.0f;
     hipStream_t st = (hipStream_t) stream;

@@ -17,7 +17,7 @@ from dataclasses import dataclass
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "csrc", "libglvspectrum.so")
 
-OP_FFT, OP_GRAVITY, OP_AVERAGE, OP_RAW, OP_WRANGE, OP_BARS, OP_SMOOTH, OP_MAGNITUDE = 1, 2, 4, 8, 16, 32, 64, 128
+OP_FFT, OP_GRAVITY, OP_AVERAGE, OP_RAW, OP_WRANGE, OP_BARS, OP_SMOOTH, OP_MAGNITUDE, OP_R16 = 1, 2, 4, 8, 16, 32, 64, 128, 256
 OK, ERR_INVALID, ERR_NO_DEVICE, ERR_HIP, ERR_NOMEM, ERR_STATE = 0, 1, 2, 3, 4, 5
 
 
@@ -65,6 +65,7 @@ def lib() -> C.CDLL:
         L.glv_state_destroy.argtypes = [vp]
         for name in ("glv_fft", "glv_gravity", "glv_average", "glv_wrange", "glv_smooth", "glv_magnitude", "glv_fft_gravity_average"):
             getattr(L, name).argtypes = [P, vp, vp]
+        L.glv_texels_r16.argtypes = [P, vp, vp, vp]
         L.glv_unpack_s16.argtypes = [C.c_int, vp, C.c_size_t, C.c_int, vp, vp]
         L.glv_batch_create.argtypes = [P, C.c_uint32, C.c_uint, C.c_int, C.POINTER(vp)]
         L.glv_batch_reset.argtypes = [vp]
@@ -216,6 +217,11 @@ class State:
     def smooth(self, buf) -> None: self._call("glv_smooth", buf)           # transform_smooth
     def magnitude(self, buf) -> None: self._call("glv_magnitude", buf)     # tail of transform_fft
     def fft_gravity_average(self, buf) -> None: self._call("glv_fft_gravity_average", buf)
+
+    def texels_r16(self, buf, texels) -> None:
+        """the GL_R16 texels handle_audio's upload stores for buf (render.c:521-524); host buffers"""
+        cp = self.params.c()
+        _check(lib().glv_texels_r16(C.byref(cp), self._h, _ptr(buf), _ptr(texels)))
 
     def reset(self) -> None:
         _check(lib().glv_state_reset(self._h))

@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define GLV_ABI_VERSION 1
+#define GLV_ABI_VERSION 2
 
 /* status codes (0 = ok).  The reference has no error channel: it prints and calls
  * glava_abort() (glava/glava.h:17, glava/render.c passim); the in-tree shim maps any
@@ -51,10 +51,17 @@ enum {
                                    channel instead of n bins; d_out is float [streams][2][bars] */
     GLV_OP_SMOOTH   = 1u << 6,  /* CPU-path log-window mean  == transform_smooth   render.c:694-718;
                                    applied last, in place on each row (after fft/gravity/average) */
-    GLV_OP_MAGNITUDE = 1u << 7  /* the magnitude stage alone: b = (float)(log(|b| + 1.0f) / 3) * tilt(i),
+    GLV_OP_MAGNITUDE = 1u << 7, /* the magnitude stage alone: b = (float)(log(|b| + 1.0f) / 3) * tilt(i),
                                    the tail of transform_fft (render.c:842-846) on planar f32 rows that
                                    already hold FFT output; exclusive with GLV_OP_FFT (which includes it);
                                    runs before gravity/average when combined with them */
+    GLV_OP_R16      = 1u << 8   /* output as GL_R16 texels: d_out is uint16 [streams][2][n] with
+                                   texel = round_to_nearest_even(clamp(x, 0, 1) * 65535) -- what the only consumer of
+                                   the spectra makes of them (handle_audio uploads every finished buffer with
+                                   glTexImage1D(GL_TEXTURE_1D, 0, GL_R16, sz, 0, GL_RED, GL_FLOAT, buf), render.c:521-524).
+                                   Applied last, to the output only: gravity / average state stays f32.  Halves the
+                                   write side of the pass (8n instead of 12n bytes per s16 frame).  Alone (no other
+                                   op) it quantises planar f32 rows.  Excludes GLV_OP_RAW, GLV_OP_BARS, GLV_OP_SMOOTH. */
 };
 
 /* Mirrors the fields of the private `struct gl_data` that the path reads
@@ -127,6 +134,9 @@ int glv_smooth(const glv_params* p, glv_state* s, float* buf);
 int glv_magnitude(const glv_params* p, glv_state* s, float* buf);
 /* fft -> gravity -> average in one launch (what handle_audio does per bind, render.c:2140-2156) */
 int glv_fft_gravity_average(const glv_params* p, glv_state* s, float* buf);
+/* the GL_R16 texels glTexImage1D(..., GL_R16, ..., GL_FLOAT, buf) stores for buf[0..n) (render.c:521-524):
+ * texels[i] = round_to_nearest_even(clamp(buf[i], 0, 1) * 65535); buf is not modified */
+int glv_texels_r16(const glv_params* p, glv_state* s, const float* buf, uint16_t* texels);
 
 /* == the unpack loop of the FIFO backend, glava/fifo.c:94-110 (and :67-79 when pcm == NULL):
  * `frames` interleaved stereo s16 frames -> planar f32.  Runs on the device (the bit-exactness

@@ -223,6 +223,24 @@ double glvo_bench_frames(const int16_t* pcm, size_t frames, size_t n, float fft_
     return acc;
 }
 
+/* ---- a11: the texture upload at the end of handle_audio (glava/render.c:521-524):
+ *   glTexImage1D(GL_TEXTURE_1D, 0, GL_R16, sz, 0, GL_RED, GL_FLOAT, buf)
+ * stores every float as a 16-bit unsigned normalized texel.  OpenGL 4.6 core, section 2.3.5.1 (eq. 2.3): clamp
+ * to [0, 1], multiply by 2^16 - 1, convert to an integer "where rounding to nearest is preferred".  The
+ * restatement rounds the EXACT product once, ties to even (x * 65535 fits a double exactly); NaN clamps to 0.
+ * Which neighbour a driver picks at an exact tie / after a float-rounded product is implementation defined
+ * (Mesa multiplies in float first), so this is pinned to the specification, not to a particular driver. */
+uint16_t glvo_unorm16(float x) {
+    float c = x > 0.0F ? x : 0.0F;          /* NaN compares false: 0 */
+    if (c > 1.0F) c = 1.0F;
+    return (uint16_t) rint((double) c * 65535.0);
+}
+void glvo_texels_r16(const float* buf, size_t sz, uint16_t* texels) {
+    for (size_t i = 0; i < sz; ++i) texels[i] = glvo_unorm16(buf[i]);
+}
+/* the value a shader reads back from such a texel (GL 4.6 eq. 2.1): c / 65535 in float */
+float glvo_unorm16_to_float(uint16_t c) { return (float) c / 65535.0F; }
+
 /* ---- a5: rd_update prelude (glava/render.c:1765-1809).  These run inside rd_update, which needs
  * a GL context, so they cannot be driven through oracle/_ref: restated only ("parity unpinned" for
  * these two functions; they are four lines of float arithmetic each). --------------------------- */

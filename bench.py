@@ -20,7 +20,6 @@ import ctypes as C
 import json
 import os
 import sys
-import threading
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -29,44 +28,68 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0     # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md (6.29 TB/s measured copy)
 
 
+def usable_cores() -> tuple[int, str]:
+    """Cores this process may actually run on: the scheduler affinity mask, capped by the cgroup CPU quota
+    (cpu.max of cgroup v2 / cfs quota of v1).  os.cpu_count() ignores both."""
+    try:
+        aff = len(os.sched_getaffinity(0))
+    except Exception:
+        aff = os.cpu_count() or 1
+    note = f"affinity {aff}"
+    quota = None
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max": quota = float(txt[0]) / float(txt[1])
+            else:
+                q = float(txt[0])
+                if q > 0: quota = q / float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            break
+        except Exception:
+            continue
+    if quota is not None:
+        note += f", cgroup quota {quota:.1f} cpus"
+        aff = max(1, min(aff, int(quota + 0.999)))
+    return aff, note
+
+
 def cpu_baseline(n: int, seconds: float = 10.0) -> dict | None:
-    """Time the reference's own transform_fft (oracle/_ref, kind "reference") -- or, if that
-    library is absent, the C restatement (kind "port") -- on every host core, on a bounded
-    sample of the same workload: stereo frames of uniform s16 noise, N real samples/channel."""
+    """Time the reference's own transform_fft (oracle/_ref, kind "reference") -- or, if that library is absent,
+    the C restatement (kind "port") -- on a bounded sample of the same workload (stereo frames of uniform s16 noise,
+    N real samples per channel): first on ONE native thread, then on one native pthread per usable core
+    (oracle/ref_shim.c glvref_bench_mt; no Python threads, no oversubscription)."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     try:
         import numpy as np
         from oracle_lib import Oracle, Ref
     except Exception as e:  # pragma: no cover
         return {"value": None, "unit": "frames/s", "cores": 0, "kind": "port", "sample": f"unavailable: {e}"}
-    cores = os.cpu_count() or 1
-    frames_per_call = 256
-    rng = np.random.default_rng(12345)
-    bufs = [rng.integers(-32768, 32768, frames_per_call * 2 * n, dtype=np.int16) for _ in range(cores)]
+    cores, note = usable_cores()
+    frames_per_call = 64
+    pcm = np.random.default_rng(12345).integers(-32768, 32768, frames_per_call * 2 * n, dtype=np.int16)
     use_ref = Ref.available()
     if use_ref:
         p = Ref.params()
-        fn = lambda buf: Ref.lib().glvref_bench_frames(C.byref(p), buf, frames_per_call, n, 0)  # noqa: E731
+        run = lambda thr, sec, done: Ref.lib().glvref_bench_mt(C.byref(p), pcm, frames_per_call, n, 0, thr, sec, done)  # noqa: E731
     else:
-        fn = lambda buf: Oracle.lib().glvo_bench_frames(buf, frames_per_call, n, 10.2, 0.3)   # noqa: E731
-    fn(bufs[0])  # warm
-    counts = [0] * cores
-    stop_at = time.perf_counter() + seconds
+        run = lambda thr, sec, done: Oracle.lib().glvo_bench_mt(pcm, frames_per_call, n, 10.2, 0.3, thr, sec, done)   # noqa: E731
 
-    def work(i):
-        while time.perf_counter() < stop_at:
-            fn(bufs[i])
-            counts[i] += frames_per_call
+    def timed(threads, sec):
+        done = (C.c_ulonglong * threads)()
+        dt = run(threads, sec, done)
+        if dt <= 0: raise RuntimeError(f"cpu baseline failed ({dt})")
+        return sum(done), dt, min(done), max(done)
 
-    t0 = time.perf_counter()
-    th = [threading.Thread(target=work, args=(i,)) for i in range(cores)]
-    for t in th: t.start()
-    for t in th: t.join()
-    dt = time.perf_counter() - t0
-    total = sum(counts)
-    return {"value": total / dt, "unit": "frames/s", "cores": cores, "kind": "reference" if use_ref else "port",
-            "sample": f"{total} stereo frames N={n} (uniform s16 noise, {frames_per_call}-frame buffers looped) over "
-                      f"{cores} threads in {dt:.1f} s; reference transform_fft x2 ch + fifo.c unpack, gcc -O2"}
+    one_frames, one_dt, _, _ = timed(1, min(3.0, seconds))
+    tot, dt, lo, hi = timed(cores, seconds)
+    one = one_frames / one_dt
+    return {"value": tot / dt, "unit": "frames/s", "cores": cores, "kind": "reference" if use_ref else "port",
+            "one_core": one, "per_core": tot / dt / cores, "parallel_efficiency": (tot / dt) / (one * cores),
+            "host_logical_cpus": os.cpu_count(), "cores_note": note,
+            "sample": f"{tot} stereo frames N={n} (uniform s16 noise, one {frames_per_call}-frame buffer looped) on {cores} native "
+                      f"pthreads in {dt:.1f} s (per thread {lo}..{hi} frames) after {one_frames} frames on 1 thread in {one_dt:.1f} s; "
+                      f"reference transform_fft x2 ch + fifo.c unpack, gcc -O2"}
 
 
 def measured_traffic(n: int, streams: int, ops: str):

@@ -284,10 +284,11 @@ glv_frame_kernel(const FrameArgs a) {
     // STATEFUL 0: no state (FFT + magnitude only)   1: gravity / average   2: gravity / average with the
     // bars computed in the kernel (fused GLV_OP_BARS): the finished row is written to the slot's LDS
     // exchange region (idle between a row's last exchange and the next row's first) instead of HBM.
-    // 3: no state, output as GL_R16 texels (GLV_OP_R16: uint16 [units][n], 8N instead of 12N bytes per frame);
-    // the stateful kernels test the bit at run time (their register budget is set by the history loads anyway).
+    // 3: no state, output as GL_R16 texels (GLV_OP_R16: uint16 [units][n], 8N instead of 12N bytes per frame)
+    // 4: gravity / average with the output as GL_R16 texels (the state stays f32).  Separate kernels, not a run-time
+    // branch: a second copy of the epilogue in the stateful kernel cost N=16384 176 more bytes of scratch per lane.
     constexpr bool FUSED_BARS = STATEFUL == 2;
-    constexpr bool HAS_STATE = STATEFUL == 1 || STATEFUL == 2;
+    constexpr bool HAS_STATE = STATEFUL == 1 || STATEFUL == 2 || STATEFUL == 4;
     static_assert(!FUSED_BARS || WAVE_SLOT, "fused bars need whole waves per row");
     static_assert(!FUSED_BARS || NBUF == 1, "fused bars reuse exchange region 0: needs the two-barrier exchange");
     auto finish = [&](const cf (&v)[E], size_t row, int tid) {
@@ -295,15 +296,13 @@ glv_frame_kernel(const FrameArgs a) {
         // (render.c:733-734 stores the same value to both), so the second copy is not written
         float* out_row = FUSED_BARS ? reinterpret_cast<float*>(xslot)
                                     : (HAS_STATE && a.out == nullptr ? nullptr : a.out + row * N);
-        if constexpr (HAS_STATE) {
-            if (!FUSED_BARS && (a.ops & OP_R16) && out_row != nullptr) {          // uniform
-                float* out16 = reinterpret_cast<float*>(reinterpret_cast<uint16_t*>(a.out) + row * N);
-                if (raw_out) FR::template epilogue<LOG_MODE, EPI_RAW_STATE, 0, true>(v, out16, row, tid, a, logtab);
-                else FR::template epilogue<LOG_MODE, EPI_MAG_STATE, TILTREG, true>(v, out16, row, tid, a, logtab, tilt_reg);
-            } else {
-                if (raw_out) FR::template epilogue<LOG_MODE, EPI_RAW_STATE>(v, out_row, row, tid, a, logtab);
-                else FR::template epilogue<LOG_MODE, EPI_MAG_STATE, TILTREG>(v, out_row, row, tid, a, logtab, tilt_reg);
-            }
+        if constexpr (STATEFUL == 4) {
+            float* out16 = reinterpret_cast<float*>(reinterpret_cast<uint16_t*>(a.out) + row * N);
+            if (raw_out) FR::template epilogue<LOG_MODE, EPI_RAW_STATE, 0, true>(v, out16, row, tid, a, logtab);
+            else FR::template epilogue<LOG_MODE, EPI_MAG_STATE, TILTREG, true>(v, out16, row, tid, a, logtab, tilt_reg);
+        } else if constexpr (HAS_STATE) {
+            if (raw_out) FR::template epilogue<LOG_MODE, EPI_RAW_STATE>(v, out_row, row, tid, a, logtab);
+            else FR::template epilogue<LOG_MODE, EPI_MAG_STATE, TILTREG>(v, out_row, row, tid, a, logtab, tilt_reg);
         } else if constexpr (STATEFUL == 3) {
             float* out16 = reinterpret_cast<float*>(reinterpret_cast<uint16_t*>(a.out) + row * N);
             if (raw_out) FR::template epilogue<LOG_MODE, EPI_RAW, 0, true>(v, out16, row, tid, a, logtab);
@@ -576,7 +575,7 @@ hipError_t launch_variant(const FrameArgs& a, int grid, hipStream_t st) {
         hipLaunchKernelGGL(k, dim3(grid), dim3(FR::T * SLOTS), lds, st, a);
         return hipGetLastError();
     };
-    static AttrDone done_plain, done_state, done_r16;   // per instantiation
+    static AttrDone done_plain, done_state, done_r16, done_state_r16;   // per instantiation
     // the stateful epilogue needs the registers a resident last pass (TWREG 3) would occupy
     constexpr int TW_STATEFUL = TWREG == 3 ? 2 : TWREG;
     if (a.bars_out != nullptr) {
@@ -586,6 +585,8 @@ hipError_t launch_variant(const FrameArgs& a, int grid, hipStream_t st) {
             return launch(glv_frame_kernel<LOG_NN, IN_MODE, LOG_MODE, SLOTS, NBUF, TW_STATEFUL, WINLDS, OCC, PREFETCH, TILTREG, LOG_E, 2, WPRE_S>, done_bars);
         } else return hipErrorInvalidValue;
     }
+    if ((a.ops & (OP_GRAVITY | OP_AVERAGE)) && (a.ops & OP_R16))
+        return launch(glv_frame_kernel<LOG_NN, IN_MODE, LOG_MODE, SLOTS, NBUF, TW_STATEFUL, WINLDS, OCC, PREFETCH, TILTREG, LOG_E, 4, WPRE_S>, done_state_r16);
     if (a.ops & (OP_GRAVITY | OP_AVERAGE))
         return launch(glv_frame_kernel<LOG_NN, IN_MODE, LOG_MODE, SLOTS, NBUF, TW_STATEFUL, WINLDS, OCC, PREFETCH, TILTREG, LOG_E, 1, WPRE_S>, done_state);
     if (a.ops & OP_R16)

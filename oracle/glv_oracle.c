@@ -223,6 +223,38 @@ double glvo_bench_frames(const int16_t* pcm, size_t frames, size_t n, float fft_
     return acc;
 }
 
+/* glvo_bench_frames on `threads` native pthreads for `seconds` of wall clock (bench.py cpu_baseline, kind "port":
+ * used only where oracle/_ref is absent).  frames_done[t] = frames thread t finished; returns elapsed seconds. */
+#include <pthread.h>
+#include <time.h>
+typedef struct { const int16_t* pcm; size_t frames, n; float scale, cutoff; double deadline, t_end; unsigned long long done; double sink; } glvo_mt_arg;
+static double glvo_now(void) { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec + 1e-9 * ts.tv_nsec; }
+static void* glvo_mt_worker(void* v) {
+    glvo_mt_arg* a = v;
+    do { a->sink += glvo_bench_frames(a->pcm, a->frames, a->n, a->scale, a->cutoff); a->done += a->frames; } while (glvo_now() < a->deadline);
+    a->t_end = glvo_now();
+    return NULL;
+}
+double glvo_bench_mt(const int16_t* pcm, size_t frames, size_t n, float fft_scale, float fft_cutoff, int threads, double seconds,
+                     unsigned long long* frames_done) {
+    if (threads < 1 || threads > 4096) return -1.0;
+    pthread_t* th = calloc(threads, sizeof(*th));
+    glvo_mt_arg* arg = calloc(threads, sizeof(*arg));
+    const double t0 = glvo_now();
+    for (int t = 0; t < threads; ++t) {
+        arg[t] = (glvo_mt_arg){ .pcm = pcm, .frames = frames, .n = n, .scale = fft_scale, .cutoff = fft_cutoff, .deadline = t0 + seconds };
+        if (pthread_create(&th[t], NULL, glvo_mt_worker, &arg[t]) != 0) { free(th); free(arg); return -2.0; }
+    }
+    double t_end = t0;
+    for (int t = 0; t < threads; ++t) {
+        pthread_join(th[t], NULL);
+        frames_done[t] = arg[t].done;
+        if (arg[t].t_end > t_end) t_end = arg[t].t_end;
+    }
+    free(th); free(arg);
+    return t_end - t0;
+}
+
 /* ---- a11: the texture upload at the end of handle_audio (glava/render.c:521-524):
  *   glTexImage1D(GL_TEXTURE_1D, 0, GL_R16, sz, 0, GL_RED, GL_FLOAT, buf)
  * stores every float as a 16-bit unsigned normalized texel.  OpenGL 4.6 core, section 2.3.5.1 (eq. 2.3): clamp

@@ -186,3 +186,42 @@ double glvref_bench_frames(const glvref_params* p, const int16_t* pcm, size_t fr
     free(l); free(r); free(gs[0]); free(gs[1]); free(as[0]); free(as[1]);
     return acc;
 }
+
+/* The same loop on `threads` native pthreads until `seconds` of wall clock have passed (CLOCK_MONOTONIC), every
+ * thread on its own scratch buffers over the shared read-only PCM: the embarrassingly parallel bound of SURVEY.md 8d
+ * (the reference itself is single-threaded per stream).  frames_done[t] receives what thread t finished; returns the
+ * elapsed seconds of the slowest thread (<0 on error). */
+#include <time.h>
+typedef struct {
+    const glvref_params* p; const int16_t* pcm; size_t frames, n; int with_state;
+    double deadline, t_end; unsigned long long done; double sink;
+} glvref_mt_arg;
+static double glvref_now(void) { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec + 1e-9 * ts.tv_nsec; }
+static void* glvref_mt_worker(void* v) {
+    glvref_mt_arg* a = v;
+    do {
+        a->sink += glvref_bench_frames(a->p, a->pcm, a->frames, a->n, a->with_state);
+        a->done += a->frames;
+    } while (glvref_now() < a->deadline);
+    a->t_end = glvref_now();
+    return NULL;
+}
+double glvref_bench_mt(const glvref_params* p, const int16_t* pcm, size_t frames, size_t n, int with_state,
+                       int threads, double seconds, unsigned long long* frames_done) {
+    if (threads < 1 || threads > 4096) return -1.0;
+    pthread_t* th = calloc(threads, sizeof(*th));
+    glvref_mt_arg* arg = calloc(threads, sizeof(*arg));
+    const double t0 = glvref_now();
+    for (int t = 0; t < threads; ++t) {
+        arg[t] = (glvref_mt_arg){ .p = p, .pcm = pcm, .frames = frames, .n = n, .with_state = with_state, .deadline = t0 + seconds };
+        if (pthread_create(&th[t], NULL, glvref_mt_worker, &arg[t]) != 0) { free(th); free(arg); return -2.0; }
+    }
+    double t_end = t0;
+    for (int t = 0; t < threads; ++t) {
+        pthread_join(th[t], NULL);
+        frames_done[t] = arg[t].done;
+        if (arg[t].t_end > t_end) t_end = arg[t].t_end;
+    }
+    free(th); free(arg);
+    return t_end - t0;
+}

@@ -96,11 +96,16 @@ class Oracle:
                                          C.c_void_p, C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
             L.glvo_bench_frames.argtypes = [_i16p, C.c_size_t, C.c_size_t, C.c_float, C.c_float]
             L.glvo_bench_frames.restype = C.c_double
+            L.glvo_bench_mt.argtypes = [_i16p, C.c_size_t, C.c_size_t, C.c_float, C.c_float, C.c_int, C.c_double, C.POINTER(C.c_ulonglong)]
+            L.glvo_bench_mt.restype = C.c_double
             L.glvo_bufscale.argtypes = [_f32p, _f32p, C.c_size_t, C.c_size_t]
             L.glvo_lerp.argtypes = [_f32p, _f32p, _f32p, C.c_size_t, C.c_float, C.c_int]
             L.glvo_smooth.argtypes = [_f32p, C.c_size_t, C.c_float, C.c_float]
             L.glvo_average_gl.argtypes = [_f32p, _f32p, C.POINTER(C.c_size_t), C.c_size_t, C.c_size_t, C.c_int]
             L.glvo_bars.argtypes = [_f32p, C.c_size_t, _f32p, C.c_size_t, C.c_float]
+            L.glvo_texels_r16.argtypes = [_f32p, C.c_size_t, np.ctypeslib.ndpointer(np.uint16, flags="C_CONTIGUOUS")]
+            L.glvo_unorm16.argtypes = [C.c_float]; L.glvo_unorm16.restype = C.c_uint16
+            L.glvo_unorm16_to_float.argtypes = [C.c_uint16]; L.glvo_unorm16_to_float.restype = C.c_float
             cls._lib = L
         return cls._lib
 
@@ -112,6 +117,14 @@ class Oracle:
         l = np.empty(frames, np.float32); r = np.empty(frames, np.float32)
         cls.lib().glvo_unpack_s16(pcm, frames, channels, l, r)
         return l, r
+
+    @classmethod
+    def texels_r16(cls, buf: np.ndarray) -> np.ndarray:
+        """GL_R16 texels of a float buffer (the upload of render.c:521-524)."""
+        b = np.ascontiguousarray(buf, dtype=np.float32).reshape(-1)
+        out = np.empty(b.size, np.uint16)
+        cls.lib().glvo_texels_r16(b, b.size, out)
+        return out.reshape(np.shape(buf))
 
     @classmethod
     def window_table(cls, n: int) -> np.ndarray:
@@ -205,6 +218,8 @@ class Ref:
             L.glvref_fifo_run.restype = C.c_int
             L.glvref_bench_frames.argtypes = [P, _i16p, C.c_size_t, C.c_size_t, C.c_int]
             L.glvref_bench_frames.restype = C.c_double
+            L.glvref_bench_mt.argtypes = [P, _i16p, C.c_size_t, C.c_size_t, C.c_int, C.c_int, C.c_double, C.POINTER(C.c_ulonglong)]
+            L.glvref_bench_mt.restype = C.c_double
             cls._lib = L
         return cls._lib
 

@@ -840,3 +840,93 @@ def test_f32_inputs_through_stateful_and_fused_paths(G):
         torch.cuda.synchronize()
         assert torch.equal(d_bars.view(torch.int32), d_bars_ref.view(torch.int32)), ("stereo bars", fr)
     for b in list(chain.values()) + [ref_fft]: b.close()
+
+
+# ---- GLV_OP_R16: the GL_R16 texel output (render.c:521-524) -----------------------------------------------
+def test_r16_every_float_bit_exact(G):
+    """The quantiser on EVERY one of the 2^32 float bit patterns, through the product path (GLV_OP_R16 alone on
+    planar f32 rows), against round-to-nearest-even of the exact clamp(x, 0, 1) * 65535 (oracle: glvo_unorm16)."""
+    import torch
+    n, streams = 16384, 4096                      # 2^27 floats per call, 32 calls
+    per = streams * 2 * n
+    b = G.Batch(G.Params(n=n), streams, G.OP_FFT)
+    d_out = torch.empty(per, dtype=torch.int16, device="cuda")
+    base = torch.arange(per, dtype=torch.int64, device="cuda")
+    bad = 0
+    for c in range((1 << 32) // per):
+        v = base + c * per                                        # bit patterns 0 .. 2^32-1, as signed 32-bit
+        d_bits = torch.where(v >= (1 << 31), v - (1 << 32), v).to(torch.int32)
+        x = d_bits.view(torch.float32)
+        b.process_f32(x, d_out, G.OP_R16)
+        want = torch.round(torch.nan_to_num(torch.clamp(x, 0.0, 1.0), nan=0.0).double() * 65535.0).to(torch.int32)
+        got = d_out.view(torch.int16).to(torch.int32) & 0xffff
+        bad += int((got != want).sum().item())
+    b.close()
+    assert bad == 0, f"{bad} of 2^32 floats quantise differently"
+    # the same definition on the CPU side of the test infrastructure (oracle) for a sample incl. ties and edges
+    xs = np.array([0.0, -0.0, 1.0, 1.5, -1.0, np.nan, np.inf, -np.inf, 0.5, 0.5 / 65535, 1.5 / 65535, 2.5 / 65535,
+                   np.float32(1) - np.float32(2 ** -24), 1e-30, 7.62951e-06], np.float32)
+    want = Oracle.texels_r16(xs)
+    st = G.State(G.Params(n=512))
+    buf = np.zeros(512, np.float32); buf[:xs.size] = xs
+    tex = np.empty(512, np.uint16)
+    st.texels_r16(buf, tex)
+    st.close()
+    assert (tex[:xs.size] == want).all(), (tex[:xs.size], want)
+
+
+@pytest.mark.parametrize("n", [512, 1024, 4096, 8192, 16384])
+def test_r16_fused_output_equals_quantised_f32_output(G, n):
+    """fft -> R16 and fft -> gravity -> average -> R16: the texels are exactly the quantised f32 output of the same
+    chain (bit for bit), the f32 state is untouched by the quantisation, and they agree with the oracle's texels of the
+    reference-exact spectrum up to one step where the 1e-5 magnitude tolerance straddles a rounding boundary."""
+    import torch
+    streams, F = 19, 5
+    for log_mode in (0, 1):
+        p = G.Params(n=n, log_mode=log_mode, avg_frames=F)
+        for ops, mask in ((G.OP_FFT, G.OP_FFT), (G.OP_FFT | G.OP_GRAVITY | G.OP_AVERAGE, G.OP_GRAVITY | G.OP_AVERAGE),
+                          (G.OP_FFT | G.OP_GRAVITY, G.OP_GRAVITY)):
+            bf, bq = G.Batch(p, streams, mask), G.Batch(p, streams, mask)
+            d_f = torch.empty((streams * 2, n), dtype=torch.float32, device="cuda")
+            d_q = torch.zeros((streams * 2, n), dtype=torch.int16, device="cuda")
+            sos = [StreamOracle(n, avg_frames=F, gravity=bool(ops & G.OP_GRAVITY), average=bool(ops & G.OP_AVERAGE)) for _ in range(streams)]
+            for fr in range(3):
+                pcm = lcg_pcm_fast(4242 + 17 * fr + n, streams * 2 * n)
+                d_pcm = torch.from_numpy(pcm).cuda()
+                bf.process_s16(d_pcm, d_f, ops)
+                bq.process_s16(d_pcm, d_q, ops | G.OP_R16)
+                torch.cuda.synchronize()
+                f = d_f.cpu().numpy()
+                q = d_q.cpu().numpy().view(np.uint16)
+                assert (q == Oracle.texels_r16(f)).all(), (n, log_mode, ops, fr)
+                for u in range(streams):
+                    want = Oracle.texels_r16(sos[u].frame(pcm[u * 2 * n:(u + 1) * 2 * n]))
+                    d = np.abs(q[2 * u:2 * u + 2].astype(np.int32) - want.astype(np.int32))
+                    assert d.max() <= 1 and (d != 0).mean() < 2e-2, (n, log_mode, ops, fr, u, d.max(), (d != 0).mean())
+            bf.close(); bq.close()
+
+
+def test_r16_post_kernel_and_errors(G):
+    """R16 behind the operators on planar rows (glv_post_kernel): wrange / gravity drop-in chains; invalid combinations."""
+    import torch
+    n, streams = 2048, 5
+    rng = np.random.default_rng(5)
+    x = (rng.random((streams * 2, n), dtype=np.float32) * 3 - 1).astype(np.float32)
+    d_x = torch.from_numpy(x).cuda()
+    d_q = torch.zeros((streams * 2, n), dtype=torch.int16, device="cuda")
+    b = G.Batch(G.Params(n=n), streams, G.OP_GRAVITY)
+    b.process_f32(d_x, d_q, G.OP_WRANGE | G.OP_R16)
+    torch.cuda.synchronize()
+    assert (d_q.cpu().numpy().view(np.uint16) == Oracle.texels_r16((x + np.float32(1)) / np.float32(2))).all()
+    grav = np.zeros_like(x)
+    want = x.copy()
+    for r in range(streams * 2): Oracle.gravity(want[r], grav[r])
+    b.process_f32(d_x, d_q, G.OP_GRAVITY | G.OP_R16)
+    torch.cuda.synchronize()
+    assert (d_q.cpu().numpy().view(np.uint16) == Oracle.texels_r16(want)).all()
+    for bad in (G.OP_FFT | G.OP_RAW | G.OP_R16, G.OP_FFT | G.OP_GRAVITY | G.OP_BARS | G.OP_R16, G.OP_FFT | G.OP_SMOOTH | G.OP_R16):
+        with pytest.raises(G.GlvError):
+            b.process_f32(d_x, d_q, bad)
+    with pytest.raises(G.GlvError):
+        b.process_f32(d_x, None, G.OP_GRAVITY | G.OP_R16)
+    b.close()

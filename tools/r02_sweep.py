@@ -1,0 +1,75 @@
+#!/usr/bin/env python3
+"""Round-2 experiment batch: builds the A/B tune libraries here (CPU container, `--build`), runs them on the
+GPU box (`--run`, inside ONE gpurun call so box-to-box spread cancels) and writes gpurun_out/r02/*.txt.
+
+    python tools/r02_sweep.py --build
+    gpurun -- 'python tools/r02_sweep.py --run'
+"""
+import argparse
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+NOL0 = ["-DGLV_TUNE_NO_LOG0"]
+# name, log_nn, extra flags, variant list (glv_tune.hip macros)
+LIBS = [
+    ("r2_n13", 13, NOL0, "VW(1,1,2,false,2,1,2,5,0,0),VW(1,1,2,false,2,1,2,5,8,0),VW(1,1,2,false,2,1,2,5,16,8),VW(1,1,2,false,2,1,2,5,24,16),VW(1,1,2,false,2,1,2,5,32,0)"),
+    ("r2_n12", 12, NOL0, "VW(2,1,true,true,2,1,true,4,0,0),VW(2,1,true,true,2,1,2,4,0,0),VW(1,1,true,false,2,1,true,4,0,0),VW(1,1,true,false,2,1,true,4,8,0),VW(1,1,true,false,2,1,true,4,16,0)"),
+    ("r2_n12_noswap", 12, NOL0 + ["-DGLV_EXP_NOSWAP16"], "VW(2,1,true,true,2,1,true,4,0,0)"),
+    ("r2_n9", 9, NOL0, "VW(4,1,true,true,4,1,true,3,0,0)"),
+    ("r2_n9_noswap", 9, NOL0 + ["-DGLV_EXP_NOSWAP16"], "VW(4,1,true,true,4,1,true,3,0,0)"),
+    ("r2_n11", 11, NOL0, "VW(2,1,true,true,2,1,true,4,0,0)"),
+]
+# lib name, streams, extra ops, label
+RUNS = [
+    ("r2_n13", 16384, 0, "N=16384 fft+magnitude"),
+    ("r2_n13", 16384, 256, "N=16384 fft+magnitude -> R16 texels (8N B/frame)"),
+    ("r2_n13", 16384, 2, "N=16384 fft+gravity, state only (20N B/frame)"),
+    ("r2_n12", 32768, 0, "N=8192 fft+magnitude"),
+    ("r2_n12_noswap", 32768, 0, "N=8192 fft+magnitude, round-1 layout (8-byte stores)"),
+    ("r2_n12", 32768, 256, "N=8192 -> R16"),
+    ("r2_n12", 32768, 2, "N=8192 fft+gravity state only"),
+    ("r2_n12_noswap", 32768, 2, "N=8192 fft+gravity state only, round-1 layout"),
+    ("r2_n9", 262144, 0, "N=1024 fft+magnitude"),
+    ("r2_n9_noswap", 262144, 0, "N=1024 fft+magnitude, round-1 layout"),
+    ("r2_n11", 65536, 0, "N=4096 fft+magnitude"),
+    ("r2_n11", 65536, 256, "N=4096 -> R16"),
+]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--build", action="store_true")
+    ap.add_argument("--run", action="store_true")
+    ap.add_argument("--only", default="")
+    a = ap.parse_args()
+    from glava_amd import build as B
+    if a.build:
+        from concurrent.futures import ThreadPoolExecutor
+        libs = [l for l in LIBS if not a.only or l[0] in a.only.split(",")]
+        with ThreadPoolExecutor(max_workers=6) as ex:
+            for lib in ex.map(lambda l: B.build_tune_variant(l[0], [f"-DGLV_TUNE_LOG_NN={l[1]}"] + l[2], l[3]), libs):
+                print("built", lib, flush=True)
+        subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-w", os.path.join(ROOT, "tools", "membench2.hip"),
+                        "-o", os.path.join(ROOT, "tools", "bin", "membench2")], check=True)
+    if a.run:
+        out = os.path.join(ROOT, "gpurun_out", "r02")
+        os.makedirs(out, exist_ok=True)
+        with open(os.path.join(out, "membench2.txt"), "w") as f:
+            subprocess.run([os.path.join(ROOT, "tools", "bin", "membench2")], stdout=f, stderr=subprocess.STDOUT)
+        with open(os.path.join(out, "sweep.txt"), "w") as f:
+            for lib, streams, extra, label in RUNS:
+                if a.only and lib not in a.only.split(","):
+                    continue
+                f.write(f"== {label}  [{lib}, streams={streams}, extra_ops={extra}]\n"); f.flush()
+                subprocess.run([sys.executable, os.path.join(ROOT, "tools", "tune.py"), "--streams", str(streams), "--log-modes", "1",
+                                "--lib", os.path.join(ROOT, "glava_amd", "csrc", f"libglvtune_{lib}.so"), "--extra-ops", str(extra)],
+                               stdout=f, stderr=subprocess.STDOUT)
+                f.flush()
+
+
+if __name__ == "__main__":
+    main()

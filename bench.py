@@ -149,7 +149,10 @@ def main() -> None:
     device = local_rank % ndev          # one rank per GPU in production; the modulo only matters for the
     torch.cuda.set_device(device)       # single-GPU rehearsal of the N>1 code path (GLV_BENCH_BACKEND=gloo)
     backend = os.environ.get("GLV_BENCH_BACKEND", "nccl")      # "nccl" is RCCL over xGMI on ROCm
-    if world > 1:
+    # launched by torch.distributed.run: take the distributed code path (process group, barriers, all-reduce,
+    # all-gather) even with a single rank, so that the RCCL calls of the N > 1 path are exercised on any box
+    dist_on = world > 1 or ("RANK" in os.environ and "MASTER_ADDR" in os.environ and os.environ.get("GLV_BENCH_DIST", "1") != "0")
+    if dist_on:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", device))
@@ -160,7 +163,7 @@ def main() -> None:
     from glava_amd import build as B
     if rank == 0:
         B.build()
-    if world > 1:
+    if dist_on:
         dist.barrier()
     from glava_amd import spectrum as G
     from glava_amd.sharding import shard_range, gather_stats
@@ -200,18 +203,18 @@ def main() -> None:
         for _ in range(a.warmup):
             b.process_s16(d_pcm, d_out, ops, stream)
         torch.cuda.synchronize()
-        if world > 1: dist.barrier()
+        if dist_on: dist.barrier()
         torch.cuda.synchronize()
         b.timing_begin()                                   # HIP events on the launch stream, per launch
         t0 = time.perf_counter()
         for _ in range(a.steps):
             b.process_s16(d_pcm, d_out, ops, stream)
         torch.cuda.synchronize()
-        if world > 1: dist.barrier()
+        if dist_on: dist.barrier()
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
         kms, nl = b.timing_end()
-        if world > 1:
+        if dist_on:
             t = torch.tensor([dt], dtype=torch.float64, device=coll_dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t.item())
@@ -238,7 +241,7 @@ def main() -> None:
 
     frames_rank = streams * a.steps
     stats = gather_stats({"frames": frames_rank, "seconds": elapsed, "kernel_ms": kernel_ms,
-                          "bytes": batch.algorithmic_bytes(ops) * launches}, world)
+                          "bytes": batch.algorithmic_bytes(ops) * launches}, world, force=dist_on)
 
     if rank == 0:
         total_frames = sum(s["frames"] for s in stats)
@@ -254,7 +257,9 @@ def main() -> None:
             "config": {"workload": f"{world} MI355X, {streams} batched stereo streams per GPU, N={n} "
                                    f"{'Hann(-like) window+FFT+magnitude' if ops == G.OP_FFT else a.ops}",
                        "streams_per_gpu": streams, "n": n, "ops": a.ops, "log_mode": a.log_mode, "spinup_s": a.spinup_s,
-                       "input": "int16 [streams][n][2] resident in HBM", "kernel": batch.kernel_name()},
+                       "input": "int16 [streams][n][2] resident in HBM", "kernel": batch.kernel_name(),
+                       "collectives": (f"{backend} ({'RCCL over xGMI' if backend == 'nccl' else 'CPU rehearsal'}): barrier, all_reduce(MAX) of elapsed, "
+                                       f"all_gather of one 32-byte stats record per rank; {world} rank(s)") if dist_on else None},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(n, streams, a.ops),
                          "algorithmic_bytes_per_launch": alg_bytes, "avg_kernel_ms": avg_kernel_s * 1e3,
@@ -283,7 +288,7 @@ def main() -> None:
         print(json.dumps(line), flush=True)
     batch.close()
     if alt_batch is not None: alt_batch.close()
-    if world > 1:
+    if dist_on:
         dist.destroy_process_group()
 
 

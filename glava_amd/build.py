@@ -74,6 +74,7 @@ def build(tune: bool = False, verbose: bool = False) -> str:
     jobs = [("glv_inst.hip", os.path.join(OBJ, f"glv_inst_{k}.o"), [f"-DGLV_LOG_NN={k}"]) for k in SIZES]
     jobs.append(("glv_misc.hip", os.path.join(OBJ, "glv_misc.o"), []))
     jobs.append(("glv_api.cpp", os.path.join(OBJ, "glv_api.o"), ["-x", "hip"]))
+    jobs.append(("glv_multi.cpp", os.path.join(OBJ, "glv_multi.o"), ["-x", "hip"]))
     if tune:
         jobs.append(("glv_tune.hip", os.path.join(OBJ, "glv_tune.o"), []))
     with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 2)) as ex:

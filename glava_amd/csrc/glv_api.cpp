@@ -396,6 +396,8 @@ void glv_params_default(glv_params* p) {
     p->smooth_ratio = 4.0F;      // render.c:918
 }
 
+// shared with glv_multi.cpp: record an error string for the calling thread
+int glv_set_last_error(int code, const char* msg) { g_err = msg ? msg : ""; return code; }
 int glv_abi_version(void) { return GLV_ABI_VERSION; }
 const char* glv_last_error(void) { return g_err.c_str(); }
 int glv_device_count(void) {

@@ -19,10 +19,10 @@ def shard_range(total_streams: int, rank: int, world: int) -> tuple[int, int]:
     return lo, hi
 
 
-def gather_stats(record: dict, world: int) -> list[dict]:
+def gather_stats(record: dict, world: int, force: bool = False) -> list[dict]:
     """All-gather one {frames, seconds, kernel_ms, bytes} record per rank; returns the list on
-    every rank (world == 1: no process group needed)."""
-    if world == 1:
+    every rank (world == 1: no process group needed unless `force` asks for the collective anyway)."""
+    if world == 1 and not force:
         return [dict(record)]
     import torch
     import torch.distributed as dist

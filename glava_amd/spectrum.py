@@ -35,6 +35,11 @@ class CParams(C.Structure):
                 ("smooth_distance", C.c_float), ("smooth_ratio", C.c_float)]
 
 
+class MultiStats(C.Structure):
+    """glv_multi_stats: the 32-byte record every rank contributes to the RCCL all-gather"""
+    _fields_ = [("frames", C.c_uint64), ("seconds", C.c_double), ("bytes", C.c_uint64), ("kernel_ms", C.c_double)]
+
+
 _lib = None
 
 
@@ -85,6 +90,13 @@ def lib() -> C.CDLL:
         L.glv_batch_algorithmic_bytes.restype = C.c_uint64
         L.glv_batch_kernel_name.argtypes = [vp]; L.glv_batch_kernel_name.restype = C.c_char_p
         L.glv_batch_set_grid.argtypes = [vp, C.c_int]
+        L.glv_multi_shard_range.argtypes = [C.c_uint64, C.c_int, C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+        L.glv_multi_shard_range.restype = None
+        L.glv_multi_create.argtypes = [P, C.c_uint64, C.c_uint, C.POINTER(C.c_int), C.c_int, C.POINTER(vp)]
+        L.glv_multi_destroy.argtypes = [vp]
+        L.glv_multi_devices.argtypes = [vp]
+        L.glv_multi_shard.argtypes = [vp, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_uint64), C.POINTER(C.c_uint32), C.POINTER(vp)]
+        L.glv_multi_run_s16.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), C.c_uint, C.c_int, C.c_int, C.POINTER(MultiStats), C.POINTER(C.c_double)]
         _lib = L
     return _lib
 
@@ -187,6 +199,49 @@ class Batch:
     def close(self) -> None:
         if self._h:
             lib().glv_batch_destroy(self._h)
+            self._h = C.c_void_p(None)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def multi_shard_range(total_streams: int, rank: int, world: int) -> tuple[int, int]:
+    """(first, count) of rank's contiguous shard -- the C twin of glava_amd.sharding.shard_range"""
+    lo, cnt = C.c_uint64(0), C.c_uint64(0)
+    lib().glv_multi_shard_range(total_streams, rank, world, C.byref(lo), C.byref(cnt))
+    return int(lo.value), int(cnt.value)
+
+
+class Multi:
+    """One host, several GPUs (glv_multi): contiguous shards, one host thread per device, RCCL only for the stats."""
+
+    def __init__(self, params: Params, total_streams: int, ops_mask: int = OP_FFT, devices: list[int] | None = None, ndev: int | None = None):
+        self._h = C.c_void_p(None)
+        cp = params.c()
+        n = len(devices) if devices is not None else (1 if ndev is None else int(ndev))
+        arr = (C.c_int * max(n, 1))(*devices) if devices is not None else None
+        _check(lib().glv_multi_create(C.byref(cp), total_streams, ops_mask, arr, n, C.byref(self._h)))
+        self.ndev = n
+
+    def shard(self, idx: int) -> tuple[int, int, int]:
+        dev, lo, cnt = C.c_int(0), C.c_uint64(0), C.c_uint32(0)
+        _check(lib().glv_multi_shard(self._h, idx, C.byref(dev), C.byref(lo), C.byref(cnt), None))
+        return dev.value, int(lo.value), int(cnt.value)
+
+    def run_s16(self, d_pcm: list, d_out: list, ops: int, warmup: int, steps: int) -> tuple[list[dict], float]:
+        pin = (C.c_void_p * self.ndev)(*[_ptr(x) for x in d_pcm])
+        pout = (C.c_void_p * self.ndev)(*[_ptr(x) for x in d_out])
+        st = (MultiStats * self.ndev)()
+        mx = C.c_double(0)
+        _check(lib().glv_multi_run_s16(self._h, pin, pout, ops, warmup, steps, st, C.byref(mx)))
+        return [{"frames": s.frames, "seconds": s.seconds, "bytes": s.bytes, "kernel_ms": s.kernel_ms} for s in st], mx.value
+
+    def close(self) -> None:
+        if self._h:
+            lib().glv_multi_destroy(self._h)
             self._h = C.c_void_p(None)
 
     def __del__(self):

@@ -223,6 +223,39 @@ int glv_batch_set_grid(glv_batch* b, int grid);
 /* Name of the kernel the last process call launched (for matching rocprofv3 rows). */
 const char* glv_batch_kernel_name(const glv_batch* b);
 
+/* ------------------------------------------------------------------------------------
+ * 3. Several GPUs of one node (BASELINE configs[3]).  No reference counterpart.
+ *    Streams are independent: device g of G owns the contiguous shard [g*B/G, (g+1)*B/G) --
+ *    its PCM, state and spectra live only there -- and there is no data-path collective.
+ *    glv_multi_run_s16 drives every shard from its own host thread on its own HIP stream
+ *    (the same timed-region contract as bench.py: warm-up, barrier + synchronize, `steps`
+ *    updates, barrier + synchronize) and then performs the ONLY communication of the path:
+ *    one ncclAllGather of a 32-byte stats record per rank and one ncclAllReduce(max) of the
+ *    elapsed seconds, over RCCL (xGMI inside a node).  librccl is resolved with dlopen by
+ *    glv_multi_create; hosts that never call glv_multi_* do not need it.
+ * ------------------------------------------------------------------------------------ */
+typedef struct glv_multi glv_multi;
+typedef struct glv_multi_stats {   /* what every rank contributes to the all-gather (32 bytes) */
+    uint64_t frames;               /* stereo frames the rank processed in the timed region */
+    double   seconds;              /* wall clock of the rank's timed region */
+    uint64_t bytes;                /* algorithmic HBM bytes of those frames (glv_batch_algorithmic_bytes) */
+    double   kernel_ms;            /* HIP-event time of the rank's launches */
+} glv_multi_stats;
+
+/* contiguous balanced partition: the first (total % world) ranks take one extra stream */
+void glv_multi_shard_range(uint64_t total_streams, int rank, int world, uint64_t* first, uint64_t* count);
+/* devices: `ndev` distinct device ordinals (NULL = 0 .. ndev-1) */
+int glv_multi_create(const glv_params* p, uint64_t total_streams, unsigned ops_mask, const int* devices, int ndev, glv_multi** out);
+int glv_multi_destroy(glv_multi* m);
+int glv_multi_devices(const glv_multi* m);
+/* shard idx: its device, first global stream, stream count and the glv_batch that owns its state (any may be NULL) */
+int glv_multi_shard(const glv_multi* m, int idx, int* device, uint64_t* first_stream, uint32_t* streams, glv_batch** batch);
+/* d_pcm[idx] / d_out[idx]: that shard's buffers on its own device (int16 [streams][n][2] / float [streams][2][n], or the
+ * layout `ops` implies).  stats: [ndev] records as gathered (identical on every rank), max_seconds: the all-reduced
+ * maximum of the ranks' elapsed seconds; either may be NULL. */
+int glv_multi_run_s16(glv_multi* m, const int16_t* const* d_pcm, float* const* d_out, unsigned ops, int warmup, int steps,
+                      glv_multi_stats* stats, double* max_seconds);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,117 @@
+"""The multi-GPU layer: contiguous shards, one host thread (C driver) or one process (bench.py) per GPU, and RCCL only
+for the per-rank stats record (BASELINE configs[3]).
+
+CPU part: the C shard arithmetic against glava_amd.sharding, the error behaviour without a device.
+GPU part (one MI355X is all the GPU box has): the C driver glv_multi_* on a one-device "node" -- every RCCL call of the
+path really executes (communicator init, all-gather, all-reduce on a communicator of size 1) -- and bench.py's own
+N > 1 code path launched by torch.distributed.run with the nccl backend, with one rank and (where RCCL permits two
+ranks on one device) with two.
+"""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_c_shard_range_matches_python(glvlib):
+    from glava_amd.sharding import shard_range
+    for total, world in ((524288, 8), (65536, 1), (10, 3), (7, 7), (1000003, 8), (8, 8), (9, 4)):
+        covered = 0
+        for rank in range(world):
+            lo, cnt = glvlib.multi_shard_range(total, rank, world)
+            plo, phi = shard_range(total, rank, world)
+            assert (lo, lo + cnt) == (plo, phi)
+            assert lo == covered
+            covered += cnt
+        assert covered == total
+
+
+def test_multi_argument_errors(glvlib):
+    G = glvlib
+    p = G.Params()
+    for kwargs in (dict(total_streams=8, ndev=0), dict(total_streams=8, ndev=65), dict(total_streams=1, ndev=2)):
+        with pytest.raises(G.GlvError) as e:
+            G.Multi(p, kwargs["total_streams"], G.OP_FFT, ndev=kwargs["ndev"])
+        assert e.value.code == G.ERR_INVALID
+    if G.device_count() == 0:      # the CPU-only container: no device, no CPU path
+        with pytest.raises(G.GlvError) as e:
+            G.Multi(p, 64, G.OP_FFT, ndev=1)
+        assert e.value.code == G.ERR_NO_DEVICE
+
+
+@pytest.mark.gpu
+def test_c_multi_driver_on_a_one_device_node(glvlib):
+    import torch
+    G = glvlib
+    assert torch.cuda.is_available()
+    n, streams, steps = 4096, 777, 3
+    p = G.Params(n=n)
+    m = G.Multi(p, streams, G.OP_FFT, devices=[0])
+    assert m.shard(0) == (0, 0, streams)
+    from oracle_lib import lcg_pcm_fast
+    pcm = lcg_pcm_fast(99, streams * 2 * n)
+    d_pcm = torch.from_numpy(pcm).cuda()
+    d_out = torch.zeros((streams * 2, n), dtype=torch.float32, device="cuda")
+    stats, mx = m.run_s16([d_pcm], [d_out], G.OP_FFT, warmup=1, steps=steps)
+    torch.cuda.synchronize()
+    assert len(stats) == 1 and stats[0]["frames"] == streams * steps
+    assert stats[0]["bytes"] == 12 * n * streams * steps
+    assert 0 < stats[0]["seconds"] == mx and stats[0]["kernel_ms"] > 0
+    # the shard's spectra are what a plain batch produces
+    b = G.Batch(p, streams, G.OP_FFT)
+    d_ref = torch.zeros_like(d_out)
+    b.process_s16(d_pcm, d_ref, G.OP_FFT)
+    torch.cuda.synchronize()
+    assert torch.equal(d_out.view(torch.int32), d_ref.view(torch.int32))
+    b.close(); m.close()
+    # a device listed twice is refused (one shard per device)
+    with pytest.raises(G.GlvError):
+        G.Multi(p, 64, G.OP_FFT, devices=[0, 0])
+
+
+def _run_bench_distributed(nproc, port, extra_env=None):
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.update(extra_env or {})
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", str(nproc), "--steps", "3", "--warmup", "1",
+           "--streams", "4096", "--no-cpu-baseline", "--no-alt", "--spinup-s", "0.05"]
+    return subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+
+
+def _bench_line(stdout):
+    lines = [l for l in stdout.splitlines() if l.startswith("{") and '"metric"' in l]
+    assert len(lines) == 1, stdout[-2000:]
+    return json.loads(lines[0])
+
+
+@pytest.mark.gpu
+def test_bench_nccl_code_path_one_rank(glvlib):
+    """bench.py exactly as the driver launches it for N > 1 (torch.distributed.run, backend nccl = RCCL), with the one
+    rank this box can host: init_process_group("nccl", device_id=...), barrier, all_reduce(MAX) on a device tensor and
+    the all_gather of the stats record all execute on RCCL."""
+    r = _run_bench_distributed(1, 29611)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = _bench_line(r.stdout)
+    assert line["n_gpus"] == 1 and line["value"] > 0 and line["scaling"] == "weak"
+    assert line["config"]["collectives"].startswith("nccl")
+
+
+@pytest.mark.gpu
+def test_bench_nccl_two_ranks_on_one_gpu_if_rccl_allows(glvlib):
+    """Two ranks sharing cuda:0 (both shards on one device: a functional rehearsal of configs[3], not a measurement).
+    RCCL may refuse two ranks on one device; that refusal -- and nothing else -- skips the test."""
+    r = _run_bench_distributed(2, 29613)
+    if r.returncode != 0:
+        tail = (r.stderr + r.stdout)[-6000:]
+        if "uplicate GPU" in tail or "invalid usage" in tail.lower() or "ncclInvalidUsage" in tail:
+            pytest.skip("RCCL refuses two ranks on one device (duplicate GPU): " + tail[-300:].replace("\n", " "))
+        assert False, tail
+    line = _bench_line(r.stdout)
+    assert line["n_gpus"] == 2 and line["value"] > 0
+    assert line["config"]["streams_per_gpu"] == 4096

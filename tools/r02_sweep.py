@@ -16,27 +16,18 @@ sys.path.insert(0, ROOT)
 NOL0 = ["-DGLV_TUNE_NO_LOG0"]
 # name, log_nn, extra flags, variant list (glv_tune.hip macros)
 LIBS = [
-    ("r2_n13", 13, NOL0, "VW(1,1,2,false,2,1,2,5,0,0),VW(1,1,2,false,2,1,2,5,8,0),VW(1,1,2,false,2,1,2,5,16,8),VW(1,1,2,false,2,1,2,5,24,16),VW(1,1,2,false,2,1,2,5,32,0)"),
-    ("r2_n12", 12, NOL0, "VW(2,1,true,true,2,1,true,4,0,0),VW(2,1,true,true,2,1,2,4,0,0),VW(1,1,true,false,2,1,true,4,0,0),VW(1,1,true,false,2,1,true,4,8,0),VW(1,1,true,false,2,1,true,4,16,0)"),
-    ("r2_n12_noswap", 12, NOL0 + ["-DGLV_EXP_NOSWAP16"], "VW(2,1,true,true,2,1,true,4,0,0)"),
-    ("r2_n9", 9, NOL0, "VW(4,1,true,true,4,1,true,3,0,0)"),
-    ("r2_n9_noswap", 9, NOL0 + ["-DGLV_EXP_NOSWAP16"], "VW(4,1,true,true,4,1,true,3,0,0)"),
-    ("r2_n11", 11, NOL0, "VW(2,1,true,true,2,1,true,4,0,0)"),
+    ("r2b_n13", 13, NOL0, "VW(1,1,2,false,2,1,2,5,0,0),VW(1,1,0,false,4,1,2,4,0,0),VW(1,1,0,false,3,1,2,4,0,0),VW(1,1,0,false,2,1,2,5,0,0),VW(1,1,0,false,2,1,2,4,0,0)"),
+    ("r2b_n12", 12, NOL0, "VW(2,1,true,true,2,1,true,4,0,0),VW(1,1,true,false,2,1,true,4,16,0),VW(1,1,0,false,4,1,2,4,0,0),VW(1,1,0,false,3,1,2,4,0,0),VW(1,1,0,false,3,1,true,4,0,0),VW(1,1,0,false,2,1,true,4,0,0)"),
+    ("r2b_n12_wgb", 12, NOL0 + ["-DGLV_EXP_WGBARRIER"], "VW(2,1,true,true,2,1,true,4,0,0)"),
+    ("r2b_n11", 11, NOL0, "VW(2,1,true,true,2,1,true,4,0,0)"),
 ]
 # lib name, streams, extra ops, label
 RUNS = [
-    ("r2_n13", 16384, 0, "N=16384 fft+magnitude"),
-    ("r2_n13", 16384, 256, "N=16384 fft+magnitude -> R16 texels (8N B/frame)"),
-    ("r2_n13", 16384, 2, "N=16384 fft+gravity, state only (20N B/frame)"),
-    ("r2_n12", 32768, 0, "N=8192 fft+magnitude"),
-    ("r2_n12_noswap", 32768, 0, "N=8192 fft+magnitude, round-1 layout (8-byte stores)"),
-    ("r2_n12", 32768, 256, "N=8192 -> R16"),
-    ("r2_n12", 32768, 2, "N=8192 fft+gravity state only"),
-    ("r2_n12_noswap", 32768, 2, "N=8192 fft+gravity state only, round-1 layout"),
-    ("r2_n9", 262144, 0, "N=1024 fft+magnitude"),
-    ("r2_n9_noswap", 262144, 0, "N=1024 fft+magnitude, round-1 layout"),
-    ("r2_n11", 65536, 0, "N=4096 fft+magnitude"),
-    ("r2_n11", 65536, 256, "N=4096 -> R16"),
+    ("r2b_n11", 65536, 0, "N=4096 fft+magnitude (first)"),
+    ("r2b_n13", 16384, 0, "N=16384 fft+magnitude: occupancy variants"),
+    ("r2b_n12", 32768, 0, "N=8192 fft+magnitude: occupancy variants"),
+    ("r2b_n12_wgb", 32768, 0, "N=8192 fft+magnitude, workgroup-wide barrier"),
+    ("r2b_n11", 65536, 0, "N=4096 fft+magnitude (last)"),
 ]
 
 

@@ -22,7 +22,7 @@ ARCH = "gfx950"
 # multiplies and adds (SURVEY.md 7 "hard parts"); explicit __builtin_fmaf calls are unaffected.
 HIPFLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC",
             "-fno-fast-math", "-Wall", "-Wno-unused-function"]
-SIZES = (8, 9, 10, 11, 12, 13)
+SIZES = (7, 8, 9, 10, 11, 12, 13, 14)
 HEADERS = ["glv_core.h", "glv_frame.h", "glv_kernel_tmpl.h", "glv_launch.h", "glv_tables.h",
            os.path.join("..", "..", "include", "glv_spectrum.h")]
 

@@ -50,13 +50,13 @@ int log2_exact(uint32_t v) {
 int validate(const glv_params* p) {
     if (!p) return fail(GLV_ERR_INVALID, "params is NULL");
     const int l = log2_exact(p->n);
-    if (l < 9 || l > 14) return fail(GLV_ERR_INVALID, "n=%u: must be a power of two in [512, 16384]", p->n);
+    if (l < 8 || l > 15) return fail(GLV_ERR_INVALID, "n=%u: must be a power of two in [256, 32768]", p->n);
     if (p->channels != 1 && p->channels != 2) return fail(GLV_ERR_INVALID, "channels=%u: must be 1 or 2", p->channels);
     if (p->avg_frames < 1 || p->avg_frames > GLV_MAX_AVG_FRAMES)
         return fail(GLV_ERR_INVALID, "avg_frames=%u: must be in [1, %d]", p->avg_frames, GLV_MAX_AVG_FRAMES);
     if (p->avg_window_kind > 1) return fail(GLV_ERR_INVALID, "avg_window_kind=%u: must be 0 or 1", p->avg_window_kind);
     if (p->log_mode > 2) return fail(GLV_ERR_INVALID, "log_mode=%u: must be 0, 1 or 2", p->log_mode);
-    if (!(p->ur > 0.0f)) return fail(GLV_ERR_INVALID, "ur must be > 0");
+    if (p->ur != p->ur) return fail(GLV_ERR_INVALID, "ur is NaN");   // 0 is legal: render.c:2387 yields it after an interval without updates
     return GLV_OK;
 }
 
@@ -143,6 +143,8 @@ struct glv_batch {
     float* d_grav = nullptr;     // [streams*2][n]      gravity state (gravity without average)
     float* d_hist = nullptr;     // [streams*2][F][n]   ring (average; doubles as gravity state)
     int16_t* d_ring = nullptr;   // [streams][n][2]     FIFO ring mode
+    int grav_mode = 0;           // which buffer holds gravity's `applied`: 0 not used yet, 1 d_grav (gravity without average
+                                 // in the same call), 2 the newest ring slot (gravity + average fused)
     uint32_t head = 0;           // history slot receiving the next frame
     uint32_t ring_pos = 0;       // next write position in the PCM ring, in frames
     int grid_override = 0;
@@ -271,10 +273,9 @@ int ensure_bar_tables(glv_batch* b) {
     return GLV_OK;
 }
 
-// One update of `units` channel rows through the fused kernel (or the post kernel when no FFT is asked).
-int process(glv_batch* b, const void* d_in, int in_mode, float* d_out, unsigned ops, uint32_t units,
-            uint32_t rot, hipStream_t st) {
-    if (!d_in) return fail(GLV_ERR_INVALID, "NULL device pointer");
+// Argument checks shared by every batched entry point (ring updates run them BEFORE touching the ring, so that a
+// rejected call leaves the ring where the caller saw it).
+int check_ops(const glv_batch* b, unsigned ops, const float* d_out) {
     // gravity's output IS its new state (render.c:733-734): a chain that ends in gravity can leave the
     // spectra in the state buffer (glv_batch_gravity_state) instead of writing them a second time
     const bool state_is_output = (ops & GLV_OP_GRAVITY) && !(ops & (GLV_OP_AVERAGE | GLV_OP_SMOOTH | GLV_OP_RAW));
@@ -290,6 +291,28 @@ int process(glv_batch* b, const void* d_in, int in_mode, float* d_out, unsigned 
     if ((ops & GLV_OP_R16) && (ops & (GLV_OP_RAW | GLV_OP_BARS | GLV_OP_SMOOTH))) return fail(GLV_ERR_INVALID, "GLV_OP_R16 excludes GLV_OP_RAW, GLV_OP_BARS and GLV_OP_SMOOTH");
     if ((ops & GLV_OP_R16) && !d_out) return fail(GLV_ERR_INVALID, "GLV_OP_R16 needs an output buffer");
     if ((ops & GLV_OP_BARS) && (b->p.bars == 0 || b->p.bars > b->p.n)) return fail(GLV_ERR_INVALID, "bars=%u out of range", b->p.bars);
+    if ((ops & GLV_OP_BARS) && !(b->p.smooth_factor >= 0.0f && b->p.smooth_factor <= 1.0f))       // also rejects NaN
+        return fail(GLV_ERR_INVALID, "smooth_factor=%g: must be in [0, 1] (a bar would have no taps)", (double) b->p.smooth_factor);
+    return GLV_OK;
+}
+
+// One update of `units` channel rows through the fused kernel (or the post kernel when no FFT is asked).
+int process(glv_batch* b, const void* d_in, int in_mode, float* d_out, unsigned ops, uint32_t units,
+            uint32_t rot, hipStream_t st) {
+    if (!d_in) return fail(GLV_ERR_INVALID, "NULL device pointer");
+    if (int rc = check_ops(b, ops, d_out)) return rc;
+    const bool state_is_output = (ops & GLV_OP_GRAVITY) && !(ops & (GLV_OP_AVERAGE | GLV_OP_SMOOTH | GLV_OP_RAW));
+    // transform_gravity keeps ONE `applied` buffer per slot (render.c:724).  Here it lives in d_grav when gravity runs
+    // without average and in the newest ring slot when both run fused; a batch that mixed the two forms would silently
+    // continue from a stale state, so that is refused (reset the batch, or use one batch per operator chain).
+    if (ops & GLV_OP_GRAVITY) {
+        const int mode = (ops & GLV_OP_AVERAGE) ? 2 : 1;
+        if (b->grav_mode != 0 && b->grav_mode != mode)
+            return fail(GLV_ERR_STATE, "gravity was last applied %s average on this batch and is now requested %s it: the two forms keep "
+                                       "their state in different buffers (glv_batch_reset, or one batch per chain)",
+                        b->grav_mode == 2 ? "fused with" : "without", mode == 2 ? "fused with" : "without");
+        b->grav_mode = mode;
+    }
     float* d_final = d_out;
     HIP_TRY(hipSetDevice(b->device));
     // GLV_OP_BARS: d_out receives the bars.  Stateful FFT chains whose rows are owned by whole waves compute
@@ -420,7 +443,7 @@ int glv_batch_reset(glv_batch* b) {
     if (b->d_grav) HIP_TRY(hipMemset(b->d_grav, 0, sizeof(float) * rows * n));
     if (b->d_ring) HIP_TRY(hipMemset(b->d_ring, 0, sizeof(int16_t) * 2 * n * b->streams));
     if (b->d_ring_f32) HIP_TRY(hipMemset(b->d_ring_f32, 0, sizeof(float) * 2 * n * b->streams));
-    b->head = 0; b->ring_pos = 0; b->ring_pos_f32 = 0;
+    b->head = 0; b->ring_pos = 0; b->ring_pos_f32 = 0; b->grav_mode = 0;
     return GLV_OK;
 }
 
@@ -461,29 +484,45 @@ int glv_batch_process_f32_stereo(glv_batch* b, const float* d_pcm, float* d_out,
     return process(b, d_pcm, glv::IN_F32_STEREO, d_out, ops, b->streams * 2, 0, (hipStream_t) hip_stream);
 }
 
+// append `new_frames` frames of `fb` bytes each per stream at ring position `pos` (frames) of rings with a pitch of n frames:
+// one strided copy, or two when the append wraps (any new_frames <= n: fifo.c:38,81,91 accept any sample_sz)
+static int ring_append(char* d_ring, const char* d_new, uint32_t pos, uint32_t new_frames, uint32_t n, size_t fb, uint32_t streams, hipStream_t st) {
+    const size_t pitch = (size_t) n * fb, width = (size_t) new_frames * fb;
+    const uint32_t first = new_frames <= n - pos ? new_frames : n - pos;       // frames that fit before the wrap
+    for (int part = 0; part < 2; ++part) {
+        const uint32_t cnt = part == 0 ? first : new_frames - first;
+        if (cnt == 0) continue;
+        char* dst = d_ring + (size_t) (part == 0 ? pos : 0) * fb;
+        const size_t w = (size_t) cnt * fb;
+        if (d_new) HIP_TRY(hipMemcpy2DAsync(dst, pitch, d_new + (size_t) (part == 0 ? 0 : first) * fb, width, w, streams, hipMemcpyDeviceToDevice, st));
+        else       HIP_TRY(hipMemset2DAsync(dst, pitch, 0, w, streams, st));   // fifo.c:67-79
+    }
+    return GLV_OK;
+}
+
 int glv_batch_ring_update_s16(glv_batch* b, const int16_t* d_new, uint32_t new_frames, float* d_out, unsigned ops,
                               void* hip_stream) {
     if (!b) return fail(GLV_ERR_INVALID, "batch is NULL");
     if (!(ops & GLV_OP_FFT)) return fail(GLV_ERR_INVALID, "ring mode requires GLV_OP_FFT");
     const uint32_t n = b->p.n;
-    if (new_frames == 0 || new_frames > n || (new_frames & 1u) || (n % new_frames) != 0)
-        return fail(GLV_ERR_INVALID, "new_frames=%u: must be even, divide n=%u (sample_sz/4 of fifo.c:38,91)", new_frames, n);
+    if (new_frames == 0 || new_frames > n)
+        return fail(GLV_ERR_INVALID, "new_frames=%u: must be in [1, n=%u] (sample_sz/4 of fifo.c:38,91)", new_frames, n);
     hipStream_t st = (hipStream_t) hip_stream;
     HIP_TRY(hipSetDevice(b->device));
+    if (int rc = check_ops(b, ops, d_out)) return rc;            // nothing is appended when the call cannot be processed
     if (!b->d_ring) {
         const size_t bytes = sizeof(int16_t) * 2 * (size_t) n * b->streams;
         HIP_TRY(hipMalloc(&b->d_ring, bytes));
-        HIP_TRY(hipMemset(b->d_ring, 0, bytes));          // == the calloc'd rings of glava.c:487-494
+        HIP_TRY(hipMemsetAsync(b->d_ring, 0, bytes, st));     // == the calloc'd rings of glava.c:487-494
         b->ring_pos = 0;
     }
-    // append at ring_pos (never wraps inside one update: new_frames divides n and ring_pos is a multiple of it)
-    char* dst = reinterpret_cast<char*>(b->d_ring) + (size_t) b->ring_pos * 4;
-    const size_t pitch = (size_t) n * 4, width = (size_t) new_frames * 4;
-    if (d_new) HIP_TRY(hipMemcpy2DAsync(dst, pitch, d_new, width, width, b->streams, hipMemcpyDeviceToDevice, st));
-    else       HIP_TRY(hipMemset2DAsync(dst, pitch, 0, width, b->streams, st));   // fifo.c:67-79
+    if (int rc = ring_append(reinterpret_cast<char*>(b->d_ring), reinterpret_cast<const char*>(d_new), b->ring_pos, new_frames, n, 4, b->streams, st)) return rc;
+    const uint32_t old_pos = b->ring_pos;
     b->ring_pos = (b->ring_pos + new_frames) % n;
-    // oldest sample now sits at ring_pos; rotation in complex points (pairs of frames)
-    return process(b, b->d_ring, glv::IN_S16_RING, d_out, ops, b->streams * 2, b->ring_pos / 2, st);
+    // the oldest frame now sits at ring_pos: the window starts there
+    const int rc = process(b, b->d_ring, glv::IN_S16_RING, d_out, ops, b->streams * 2, b->ring_pos, st);
+    if (rc != GLV_OK) b->ring_pos = old_pos;                      // a failed launch leaves the ring where the caller saw it
+    return rc;
 }
 
 int glv_batch_ring_update_f32(glv_batch* b, const float* d_new, uint32_t new_frames, float* d_out, unsigned ops, void* hip_stream) {
@@ -491,21 +530,23 @@ int glv_batch_ring_update_f32(glv_batch* b, const float* d_new, uint32_t new_fra
     if (!(ops & GLV_OP_FFT)) return fail(GLV_ERR_INVALID, "ring mode requires GLV_OP_FFT");
     if (!d_new) return fail(GLV_ERR_INVALID, "d_new is NULL (the PulseAudio backend has no zero-fill path)");
     const uint32_t n = b->p.n;
-    if (new_frames == 0 || new_frames > n || (new_frames & 1u) || (n % new_frames) != 0)
-        return fail(GLV_ERR_INVALID, "new_frames=%u: must be even, divide n=%u (sample_sz/4 of pulse_input.c:155-178)", new_frames, n);
+    if (new_frames == 0 || new_frames > n)
+        return fail(GLV_ERR_INVALID, "new_frames=%u: must be in [1, n=%u] (sample_sz/4 of pulse_input.c:155-178)", new_frames, n);
     hipStream_t st = (hipStream_t) hip_stream;
     HIP_TRY(hipSetDevice(b->device));
+    if (int rc = check_ops(b, ops, d_out)) return rc;
     if (!b->d_ring_f32) {
         const size_t bytes = sizeof(float) * 2 * (size_t) n * b->streams;
         HIP_TRY(hipMalloc(&b->d_ring_f32, bytes));
-        HIP_TRY(hipMemset(b->d_ring_f32, 0, bytes));      // == the calloc'd rings of glava.c:487-494
+        HIP_TRY(hipMemsetAsync(b->d_ring_f32, 0, bytes, st));  // == the calloc'd rings of glava.c:487-494
         b->ring_pos_f32 = 0;
     }
-    char* dst = reinterpret_cast<char*>(b->d_ring_f32) + (size_t) b->ring_pos_f32 * 8;
-    const size_t pitch = (size_t) n * 8, width = (size_t) new_frames * 8;
-    HIP_TRY(hipMemcpy2DAsync(dst, pitch, d_new, width, width, b->streams, hipMemcpyDeviceToDevice, st));
+    if (int rc = ring_append(reinterpret_cast<char*>(b->d_ring_f32), reinterpret_cast<const char*>(d_new), b->ring_pos_f32, new_frames, n, 8, b->streams, st)) return rc;
+    const uint32_t old_pos = b->ring_pos_f32;
     b->ring_pos_f32 = (b->ring_pos_f32 + new_frames) % n;
-    return process(b, b->d_ring_f32, glv::IN_F32_RING, d_out, ops, b->streams * 2, b->ring_pos_f32 / 2, st);
+    const int rc = process(b, b->d_ring_f32, glv::IN_F32_RING, d_out, ops, b->streams * 2, b->ring_pos_f32, st);
+    if (rc != GLV_OK) b->ring_pos_f32 = old_pos;
+    return rc;
 }
 
 int glv_batch_gravity_state(glv_batch* b, const float** d_state) {
@@ -615,7 +656,7 @@ int glv_state_reset(glv_state* s) {
     const size_t n = b->p.n;
     HIP_TRY(hipMemset(b->d_hist, 0, sizeof(float) * b->p.avg_frames * n));
     HIP_TRY(hipMemset(b->d_grav, 0, sizeof(float) * n));
-    b->head = 0;
+    b->head = 0; b->grav_mode = 0;
     return GLV_OK;
 }
 

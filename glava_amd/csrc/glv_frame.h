@@ -53,9 +53,9 @@ struct FrameArgs {
     uint32_t mono;         // fifo.c:98-102
     uint32_t avg_window;
     uint32_t log_mode;     // glv_post_kernel's OP_MAGNITUDE (the frame kernels take it as a template parameter)
-    uint32_t rot;          // s16 ring mode (RING kernels): rotation of the window start, in complex points
+    uint32_t rot;          // ring modes (RING kernels): index of the ring's oldest stereo frame = where the window starts
     float inv_n, fft_scale, one_minus_cutoff, g, F_as_float;
-    double wts[16];        // window_frame weights, oldest first (render.c:661 as expanded at :766)
+    double wts[64];        // window_frame weights, oldest first (render.c:661 as expanded at :766); GLV_MAX_AVG_FRAMES
     // fused GLV_OP_BARS (stateful kernels, lanes-per-row a multiple of 64): the finished row goes to the
     // slot's LDS region instead of HBM and only the bars leave the chip
     const BarDesc* bar_desc;
@@ -238,14 +238,28 @@ struct Frame {
     // to park the other channel's samples in registers across a whole transform.
     struct Raw { uint32_t x[E], y[E]; };     // x = L[2c] | R[2c] << 16,  y = L[2c+1] | R[2c+1] << 16
 
-    // RING: rotate the read position (complex points) for the FIFO ring mode -- fifo.c:91-92 keeps
-    // the newest samples at the end of the buffer by memmove; the device ring is circular instead.
+    // RING: rotate the read position for the FIFO ring mode -- fifo.c:91-92 keeps the newest samples at the end of
+    // the buffer by memmove; the device ring is circular instead and `rot` is the index of its OLDEST frame.  fifo.c
+    // accepts any sample_sz (fifo.c:38,81,91), so rot may be odd: complex point c is then the frame pair
+    // (rot + 2c, rot + 2c + 1) mod n, which is neither 8-byte aligned nor contiguous across the wrap -- two dword loads;
+    // with rot even (every sample_sz that is a multiple of 8 bytes) the pair is one aligned 8-byte load.  Uniform branch.
     template <bool RING>
     GLV_HD static void load_pcm(Raw& p, const void* frame, int tid, uint32_t rot) {
+        if constexpr (RING) {
+            if (rot & 1u) {
+#pragma unroll
+                for (int i = 0; i < E; ++i) {
+                    const uint32_t f0 = (uint32_t) (2 * (i * T + tid)) + rot;
+                    p.x[i] = ld<uint32_t>(frame, (f0 & (uint32_t) (N - 1)) * 4u);
+                    p.y[i] = ld<uint32_t>(frame, ((f0 + 1u) & (uint32_t) (N - 1)) * 4u);
+                }
+                return;
+            }
+        }
 #pragma unroll
         for (int i = 0; i < E; ++i) {
             uint32_t off;
-            if constexpr (RING) off = ((uint32_t) (i * T + tid + rot) & (uint32_t) (NN - 1)) * 8u;
+            if constexpr (RING) off = ((uint32_t) (i * T + tid + (rot >> 1)) & (uint32_t) (NN - 1)) * 8u;
             else off = (uint32_t) tid * 8u + (uint32_t) (i * T) * 8u;
 #if defined(GLV_EXP_NOLOAD)    /* tools/tune.py experiment: fake PCM, no HBM read */
             const u32x2 u = { off * 2654435761u, off * 40503u + 977u };
@@ -371,9 +385,12 @@ struct Frame {
                                               uint32_t rot = 0) {
 #pragma unroll
         for (int i = 0; i < E; ++i) {
-            const uint32_t poff = RING ? ((uint32_t) (i * T + tid + rot) & (uint32_t) (NN - 1)) * 16u
-                                       : (uint32_t) tid * 16u + (uint32_t) (i * T) * 16u;
-            const f4 u = ld<f4>(frame, poff);
+            f4 u;
+            if constexpr (RING) {      // frames (rot + 2c, rot + 2c + 1) mod n, 8 bytes each (rot = oldest frame of the ring, any parity)
+                const uint32_t f0 = (uint32_t) (2 * (i * T + tid)) + rot;
+                const cf lo = ld<cf>(frame, (f0 & (uint32_t) (N - 1)) * 8u), hi = ld<cf>(frame, ((f0 + 1u) & (uint32_t) (N - 1)) * 8u);
+                u.a = lo.x; u.b = lo.y; u.c = hi.x; u.d = hi.y;
+            } else u = ld<f4>(frame, (uint32_t) tid * 16u + (uint32_t) (i * T) * 16u);
             const d2 w = ld<d2>(win, (uint32_t) tid * 16u + (uint32_t) (i * T) * 16u);
             float s0, s1;
             if (mono) { s0 = (u.a + u.b) / 2; s1 = (u.c + u.d) / 2; }
@@ -392,10 +409,15 @@ struct Frame {
         const char* base = static_cast<const char*>(frame) + ch * 4u;
 #pragma unroll
         for (int i = 0; i < E; ++i) {
-            const uint32_t poff = RING ? ((uint32_t) (i * T + tid + rot) & (uint32_t) (NN - 1)) * 16u
-                                       : (uint32_t) tid * 16u + (uint32_t) (i * T) * 16u;
-            r.p[i].x = ld<float>(base, poff);
-            r.p[i].y = ld<float>(base, poff + 8u);
+            if constexpr (RING) {      // rot = oldest frame of the ring (any parity, pulse_input.c accepts any sample_sz)
+                const uint32_t f0 = (uint32_t) (2 * (i * T + tid)) + rot;
+                r.p[i].x = ld<float>(base, (f0 & (uint32_t) (N - 1)) * 8u);
+                r.p[i].y = ld<float>(base, ((f0 + 1u) & (uint32_t) (N - 1)) * 8u);
+            } else {
+                const uint32_t poff = (uint32_t) tid * 16u + (uint32_t) (i * T) * 16u;
+                r.p[i].x = ld<float>(base, poff);
+                r.p[i].y = ld<float>(base, poff + 8u);
+            }
         }
     }
 

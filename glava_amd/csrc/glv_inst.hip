@@ -1,12 +1,12 @@
 // glv_inst.hip -- production instantiations of glv_frame_kernel for ONE transform size.
-// Compiled once per size with -DGLV_LOG_NN=k (k = log2(nn) = log2(N) - 1, 8..13) so the six
+// Compiled once per size with -DGLV_LOG_NN=k (k = log2(nn) = log2(N) - 1, 7..14) so the eight
 // sizes build in parallel.  The knob set per size is the measured best of tools/tune.py
 // (profiles/tune_r01_final.txt, earlier sweeps in profiles/tune_r01.txt); see DESIGN.md "Kernel configuration".
 #include "glv_kernel_tmpl.h"
 #include "glv_launch.h"
 
 #ifndef GLV_LOG_NN
-#error "compile with -DGLV_LOG_NN=<8..13>"
+#error "compile with -DGLV_LOG_NN=<7..14>"
 #endif
 
 namespace glv {
@@ -17,6 +17,7 @@ template <int LOG_NN> struct Tuned;
                                   static constexpr bool winlds = WL; static constexpr int twreg = TR, tiltreg = TL, prefetch = PF, wpre = WP, wpre_s = WPS; };
 // measured best of tools/tune.py on MI355X (profiles/tune_r01_final.txt), equal bytes per size class:
 //         log2(nn) LOG_E SLOTS NBUF TWREG  WINLDS OCC PREFETCH TILTREG WPRE WPRE_S     (knob values: glv_kernel_tmpl.h)
+GLV_TUNED(7,       3,    16,   1,   true,  true,  4,  1,       true,   0,   0)    // N=256    E=8:  3+3+1 (16 lanes per row; not tuned: coverage of setbufsize 256)
 GLV_TUNED(8,       3,    16,   1,   true,  true,  4,  1,       true,   0,   0)    // N=512    E=8:  3+3+2
 GLV_TUNED(9,       3,    4,    1,   true,  true,  4,  1,       true,   0,   0)    // N=1024   E=8:  3+3+3 (last pass: one group per lane, SWAP16 stores)
 GLV_TUNED(10,      3,    2,    1,   true,  true,  4,  1,       true,   0,   0)    // N=2048   E=8:  3+3+3+1
@@ -24,6 +25,7 @@ GLV_TUNED(11,      4,    2,    1,   true,  true,  2,  1,       true,   0,   0)  
 GLV_TUNED(12,      4,    2,    1,   true,  true,  2,  1,       true,   0,   0)    // N=8192   E=16: 4+4+4 (SWAP16 stores); two slots share the 64 KiB LDS window
 GLV_TUNED(13,      5,    1,    1,   2,     false, 2,  1,       2,      16,  0)    // N=16384  E=32: 5+5+3; pass-1 twiddles from an 8 KiB LDS table, tilt computed,
                                                                                   //          half of the next row's window requested ahead of the spectrum stores
+GLV_TUNED(14,      5,    1,    1,   0,     false, 2,  1,       2,      0,   0)    // N=32768  E=32: 5+5+4, one 512-lane row per CU (135 KiB exchange region); not tuned: coverage
 #undef GLV_TUNED
 
 #define GLV_CAT2(a, b) a##b

@@ -13,7 +13,7 @@ namespace glv {
     int frame_slots_##K(); \
     int frame_lanes_##K(); \
     int frame_resident_##K();
-GLV_DECL_INST(8) GLV_DECL_INST(9) GLV_DECL_INST(10) GLV_DECL_INST(11) GLV_DECL_INST(12) GLV_DECL_INST(13)
+GLV_DECL_INST(7) GLV_DECL_INST(8) GLV_DECL_INST(9) GLV_DECL_INST(10) GLV_DECL_INST(11) GLV_DECL_INST(12) GLV_DECL_INST(13) GLV_DECL_INST(14)
 #undef GLV_DECL_INST
 
 // glv_misc.hip

@@ -163,18 +163,21 @@ hipError_t launch_bars(const float* spec, float* bars_out, size_t nrows, uint32_
 
 hipError_t launch_frame(int log_nn, int in_mode, int log_mode, const FrameArgs& a, int grid, hipStream_t st) {
     switch (log_nn) {
+        case 7:  return launch_frame_7(in_mode, log_mode, a, grid, st);
         case 8:  return launch_frame_8(in_mode, log_mode, a, grid, st);
         case 9:  return launch_frame_9(in_mode, log_mode, a, grid, st);
         case 10: return launch_frame_10(in_mode, log_mode, a, grid, st);
         case 11: return launch_frame_11(in_mode, log_mode, a, grid, st);
         case 12: return launch_frame_12(in_mode, log_mode, a, grid, st);
         case 13: return launch_frame_13(in_mode, log_mode, a, grid, st);
+        case 14: return launch_frame_14(in_mode, log_mode, a, grid, st);
     }
     return hipErrorInvalidValue;
 }
 
 int frame_slots(int log_nn) {
     switch (log_nn) {
+        case 7: return frame_slots_7(); case 14: return frame_slots_14();
         case 8: return frame_slots_8(); case 9: return frame_slots_9(); case 10: return frame_slots_10();
         case 11: return frame_slots_11(); case 12: return frame_slots_12(); case 13: return frame_slots_13();
     }
@@ -183,6 +186,7 @@ int frame_slots(int log_nn) {
 
 int frame_lanes(int log_nn) {
     switch (log_nn) {
+        case 7: return frame_lanes_7(); case 14: return frame_lanes_14();
         case 8: return frame_lanes_8(); case 9: return frame_lanes_9(); case 10: return frame_lanes_10();
         case 11: return frame_lanes_11(); case 12: return frame_lanes_12(); case 13: return frame_lanes_13();
     }
@@ -191,6 +195,7 @@ int frame_lanes(int log_nn) {
 
 int frame_resident(int log_nn) {
     switch (log_nn) {
+        case 7: return frame_resident_7(); case 14: return frame_resident_14();
         case 8: return frame_resident_8(); case 9: return frame_resident_9(); case 10: return frame_resident_10();
         case 11: return frame_resident_11(); case 12: return frame_resident_12(); case 13: return frame_resident_13();
     }

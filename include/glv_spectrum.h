@@ -28,7 +28,7 @@ extern "C" {
  * non-zero status to that. */
 enum {
     GLV_OK = 0,
-    GLV_ERR_INVALID = 1,     /* bad argument (n not a power of two in [512,16384], NULL, ...) */
+    GLV_ERR_INVALID = 1,     /* bad argument (n not a power of two in [256,32768], NULL, ...) */
     GLV_ERR_NO_DEVICE = 2,   /* no HIP device / kernels for gfx950 not loadable */
     GLV_ERR_HIP = 3,         /* a HIP runtime call failed; see glv_last_error() */
     GLV_ERR_NOMEM = 4,
@@ -67,14 +67,15 @@ enum {
 /* Mirrors the fields of the private `struct gl_data` that the path reads
  * (glava/render.c:166-207) and of `struct audio_data` (glava/fifo.h:9-20). */
 typedef struct glv_params {
-    uint32_t n;             /* audio_buf_sz / bsz: real samples per channel; power of two in [512, 16384]
+    uint32_t n;             /* audio_buf_sz / bsz: real samples per channel; power of two in [256, 32768]
                                (#request setbufsize, render.c:1176).  Complex FFT length is n/2 (render.c:786) */
     uint32_t channels;      /* 2 = stereo, 1 = mirror/mono mix (fifo.c:98-102, setmirror render.c:1053) */
     float fft_scale;        /* render.c:845, default 10.2 (render.c:930) */
     float fft_cutoff;       /* render.c:845, default 0.3  (render.c:931) */
     float gravity_step;     /* render.c:728, default 4.2  (render.c:911) */
     float ur;               /* updates per second used by gravity (render.c:728); the reference measures it
-                               (render.c:2387); ideal value rate/(sample_sz/4) */
+                               (render.c:2387); ideal value rate/(sample_sz/4).  Like the reference, any value is
+                               taken: 0 (an interval without updates) makes the step infinite and the output -inf */
     uint32_t avg_frames;    /* F, render.c:743; 1..GLV_MAX_AVG_FRAMES */
     uint32_t avg_window;    /* bool, render.c:745/765 */
     uint32_t avg_window_kind; /* 0: CPU twin 0.6/0.4, oldest-first (render.c:661,751-766)
@@ -95,7 +96,7 @@ typedef struct glv_params {
     float smooth_ratio;     /* default 4 */
 } glv_params;
 
-#define GLV_MAX_AVG_FRAMES 16
+#define GLV_MAX_AVG_FRAMES 64
 
 /* Fill `p` with the shipped defaults (shaders/glava/rc.glsl:181-211,
  * shaders/glava/smooth_parameters.glsl:46-67): n=4096, stereo, 10.2/0.3, 4.2,

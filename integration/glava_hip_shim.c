@@ -38,6 +38,14 @@ static void glv_hip_fill(const struct gl_data* d, size_t sz, glv_params* p) {
     p->log_mode     = glv_hip_log_mode;
 }
 
+/* Parameters outside what the library takes -- a window that is not a power of two in [256, 32768] (setbufsize is
+   unchecked, and bufscale can produce any size), more than GLV_MAX_AVG_FRAMES averaging frames -- are left to the stock
+   CPU operators: a host that runs on the reference must not be terminated by the shim (render_hip.patch tests this
+   before it routes a call here). */
+static bool glv_hip_supported(const struct gl_data* d, size_t sz) {
+    return sz >= 256 && sz <= 32768 && (sz & (sz - 1)) == 0 && d->avg_frames >= 1 && d->avg_frames <= GLV_MAX_AVG_FRAMES;
+}
+
 static glv_state* glv_hip_slot(struct gl_data* d, void** udata, size_t sz) {
     struct glv_box* b = *udata;
     if (!b) {                                  /* lazily, like ALLOC_ONCE (render.c:662-666) */

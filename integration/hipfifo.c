@@ -19,14 +19,17 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <string.h>
+#include <time.h>
 #include <unistd.h>
 
 #include <glv_spectrum.h>
 
 #include "fifo.h"
 
-/* observable by tests: how many updates were poll-timeout zero fills (timing dependent) */
+/* observable by tests: how many updates were poll-timeout zero fills (timing dependent), and the poll timeout
+ * the backend is currently using (adapted to the producer's cadence exactly like fifo.c:82-87) */
 volatile unsigned long glv_hipfifo_zero_fills = 0;
+volatile int glv_hipfifo_timeout_ms = 50;
 /* knobs the host would take from its config (rc.glsl): magnitude parameters of the transform */
 float glv_hipfifo_fft_scale = 10.2f, glv_hipfifo_fft_cutoff = 0.3f;
 
@@ -64,7 +67,9 @@ static void* entry(void* data) {
     struct pollfd pfd = { .fd = fd, .events = POLLIN };
     int16_t* buf = malloc(ssz);
     float* spec = malloc(2 * n * sizeof(float));
-    const int timeout_ms = 50;                                         /* initial value of fifo.c:39 */
+    int timeout_ms = 50;                                               /* initial value of fifo.c:39 */
+    struct timespec tv_last = { 0, 0 }, tv;
+    int measured = 0;
 
     for (;;) {
         int rc, ready = poll(&pfd, 1, timeout_ms);
@@ -79,6 +84,14 @@ static void* entry(void* data) {
                 have += (size_t) r;
             }
             if (have < ssz) memset((char*) buf + have, 0, ssz - have);
+            /* fifo.c:82-87: "Set the timeout slightly higher than the delay between samples to prevent empty
+               writes" -- the delay between this read and the previous one, in whole milliseconds, plus one */
+            clock_gettime(CLOCK_REALTIME, measured ? &tv : &tv_last);
+            if (measured) {
+                timeout_ms = (int) (((tv.tv_sec - tv_last.tv_sec) * 1000) + ((tv.tv_nsec - tv_last.tv_nsec) / 1000000)) + 1;
+                tv_last = tv;
+                glv_hipfifo_timeout_ms = timeout_ms;
+            } else measured = 1;
             rc = glv_device_upload(0, d_new, buf, ssz, NULL);
             if (rc == GLV_OK) rc = glv_batch_ring_update_s16(batch, d_new, frames, d_spec, GLV_OP_FFT, NULL);
         }

@@ -12,8 +12,9 @@
  * 8c), so this file is pinned against the *compiled reference itself*
  * (oracle/_ref/libglvref.so, built from /root/reference by oracle/Makefile):
  * tests/test_oracle.py demands bit equality on every function below that the
- * reference can execute without a GL context (the rd_update prelude and the GLSL twins at the
- * end of this file are restatements only and say so), and the
+ * reference can execute without a GL context (the rd_update prelude is pinned through the reference's own
+ * rd_update run over a null GL, tests/test_handle_audio.py; the GLSL twins at the end of this file are
+ * restatements checked against an independent evaluation of the shader text, tests/test_glsl_twins.py), and the
  * vectors in tests/golden/ were produced by the compiled reference
  * (tests/golden/make_golden.py).
  *
@@ -273,9 +274,10 @@ void glvo_texels_r16(const float* buf, size_t sz, uint16_t* texels) {
 /* the value a shader reads back from such a texel (GL 4.6 eq. 2.1): c / 65535 in float */
 float glvo_unorm16_to_float(uint16_t c) { return (float) c / 65535.0F; }
 
-/* ---- a5: rd_update prelude (glava/render.c:1765-1809).  These run inside rd_update, which needs
- * a GL context, so they cannot be driven through oracle/_ref: restated only ("parity unpinned" for
- * these two functions; they are four lines of float arithmetic each). --------------------------- */
+/* ---- a5: rd_update prelude (glava/render.c:1765-1809).  These run inside rd_update; pinned by running the
+ * reference's real rd_update over a GL that does nothing (integration/nullgl_harness.c -> oracle/_ref/
+ * libglvnullgl_ref.so) and comparing what it hands to glTexImage1D with these restatements, bit for bit
+ * (tests/test_handle_audio.py::test_prelude_*). ------------------------------------------------------ */
 /* bufscale box decimation (render.c:1768-1781): mean of `k` consecutive samples, float accumulate
  * in index order, then one float division. */
 void glvo_bufscale(const float* in, float* out, size_t n_out, size_t k) {

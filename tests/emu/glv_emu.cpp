@@ -94,12 +94,14 @@ static void run_units(int in_mode, const FrameArgs& a) {
 template <int LOG_MODE, int LOG_E>
 static int dispatch(int log_nn, int in_mode, const FrameArgs& a) {
     switch (log_nn) {
+        case 7:  run_units<7, LOG_MODE, LOG_E>(in_mode, a); return 0;
         case 8:  run_units<8, LOG_MODE, LOG_E>(in_mode, a); return 0;
         case 9:  run_units<9, LOG_MODE, LOG_E>(in_mode, a); return 0;
         case 10: run_units<10, LOG_MODE, LOG_E>(in_mode, a); return 0;
         case 11: run_units<11, LOG_MODE, LOG_E>(in_mode, a); return 0;
         case 12: run_units<12, LOG_MODE, LOG_E>(in_mode, a); return 0;
         case 13: run_units<13, LOG_MODE, LOG_E>(in_mode, a); return 0;
+        case 14: run_units<14, LOG_MODE, LOG_E>(in_mode, a); return 0;
     }
     return 1;
 }
@@ -131,7 +133,7 @@ int glvemu_process(int n, int in_mode, const void* in, float* out, float* grav, 
     a.units = units; a.ops = ops; a.F = F; a.head = head; a.mono = mono; a.avg_window = avg_window; a.rot = rot;
     a.inv_n = 1.0f / (float) n; a.fft_scale = fft_scale; a.one_minus_cutoff = 1.0f - fft_cutoff;
     a.g = gravity_step * (1.0f / ur); a.F_as_float = (float) F;
-    if (F > 16) return 3;
+    if (F > 64) return 3;
     make_frame_weights(a.wts, F, avg_window != 0, avg_kind);
     if (log_e == 5) return log_mode == 0 ? dispatch<0, 5>(log_nn, in_mode, a) : log_mode == 1 ? dispatch<1, 5>(log_nn, in_mode, a) : dispatch<2, 5>(log_nn, in_mode, a);
     if (log_e == 3) return log_mode == 0 ? dispatch<0, 3>(log_nn, in_mode, a) : log_mode == 1 ? dispatch<1, 3>(log_nn, in_mode, a) : dispatch<2, 3>(log_nn, in_mode, a);

@@ -50,7 +50,7 @@ def test_defaults_match_shipped_config(glvlib):
 
 def test_argument_validation(glvlib):
     P = glvlib.Params
-    for bad in (P(n=1000), P(n=256), P(n=32768), P(channels=3), P(avg_frames=0), P(avg_frames=17), P(ur=0.0)):
+    for bad in (P(n=1000), P(n=128), P(n=65536), P(channels=3), P(avg_frames=0), P(avg_frames=65), P(ur=float("nan"))):
         with pytest.raises(glvlib.GlvError) as ei:
             glvlib.Batch(bad, 4)
         assert ei.value.code == glvlib.ERR_INVALID

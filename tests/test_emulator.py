@@ -16,7 +16,7 @@ def bits(a):
 
 
 @pytest.mark.parametrize("log_e", [4, 3, 5])
-@pytest.mark.parametrize("n", [512, 1024, 2048, 4096, 8192, 16384])
+@pytest.mark.parametrize("n", [256, 512, 1024, 2048, 4096, 8192, 16384, 32768])
 def test_fft_raw_and_magnitude_bit_exact(emu, oracle, n, log_e):
     """every size, both lane footprints (E = 16 and E = 8 points per lane: different pass plans)"""
     units = 2
@@ -134,9 +134,9 @@ def test_ring_rotation(emu, oracle):
     """FIFO ring mode: reading a circular PCM ring with a rotation == the reference's memmove ring."""
     n = 1024
     pcm = lcg_pcm_fast(55, 2 * n).reshape(n, 2)
-    for rot_frames in (0, 256, 512, 768, 2):
+    for rot_frames in (0, 256, 512, 768, 2, 1, 251, 1023):                          # odd: fifo.c accepts any sample_sz
         ring = np.ascontiguousarray(np.roll(pcm, rot_frames, axis=0)).reshape(-1)   # logical frame i at (i+rot)%n
-        out = emu_process(emu, n, ring, 1, OP_FFT | OP_RAW, rot=rot_frames // 2)
+        out = emu_process(emu, n, ring, 1, OP_FFT | OP_RAW, rot=rot_frames)
         _, want = StreamOracle(n, gravity=False, average=False).frame(pcm.reshape(-1), want_raw=True)
         assert (bits(out) == bits(want)).all(), rot_frames
 

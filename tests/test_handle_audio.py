@@ -1,0 +1,196 @@
+"""The renderer seam as code: the reference's REAL rd_update -- prelude (bufscale,
+keyframe interpolation), handle_audio with its modified / accel_fft branch structure, counters, rd_destroy -- executed
+over a GL that does nothing (integration/nullgl_harness.c), once as the reference is and once with
+integration/render_hip.patch applied (the *_hip operators of integration/glava_hip_shim.c behind the same call sites).
+
+CPU part (needs oracle/_ref/libglvnullgl_ref.so, built from /root/reference where present, prebuilt on the GPU box):
+  * pins the oracle's restatements of the rd_update prelude (glvo_bufscale, glvo_lerp) and of the whole per-frame
+    sequence (fft -> gravity -> average per channel, state across frames) against what the reference hands to
+    glTexImage1D -- bit for bit;
+  * documents the reference's quirks the patch must keep: a frame with modified == false uploads the buffer untouched
+    on the CPU path, but is transformed AGAIN on the accel_fft path (render.c:2176-2180).
+GPU part: the patched build uploads the same values (bit-exact in log_mode 0, <= 1e-5 in the default mode).
+"""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+from oracle_lib import Oracle, StreamOracle, lcg_pcm_fast
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF_SO = os.path.join(ROOT, "oracle", "_ref", "libglvnullgl_ref.so")
+HIP_SO = os.path.join(ROOT, "oracle", "_ref", "libglvnullgl_hip.so")
+
+
+class Cfg(C.Structure):
+    _fields_ = [("n", C.c_uint), ("bufscale", C.c_uint), ("interpolate", C.c_int), ("accel_fft", C.c_int),
+                ("avg_frames", C.c_uint), ("avg_window", C.c_int), ("fft_scale", C.c_float), ("fft_cutoff", C.c_float),
+                ("gravity_step", C.c_float), ("ur", C.c_float), ("fr", C.c_float), ("hip_log_mode", C.c_uint)]
+
+
+def load(path):
+    if not os.path.exists(path):
+        if os.path.exists("/root/reference/glava/render.c"):
+            from oracle_lib import build_oracles
+            build_oracles()
+    if not os.path.exists(path):
+        pytest.skip(f"{os.path.basename(path)} not available (needs /root/reference at build time)")
+    L = C.CDLL(path)
+    L.nullgl_create.argtypes = [C.POINTER(Cfg)]; L.nullgl_create.restype = C.c_void_p
+    fp = np.ctypeslib.ndpointer(np.float32, flags="C_CONTIGUOUS")
+    L.nullgl_update.argtypes = [C.c_void_p, fp, fp, C.c_size_t, C.c_int, fp, fp, C.POINTER(C.c_size_t)]
+    L.nullgl_destroy.argtypes = [C.c_void_p]
+    L.nullgl_bind_t_sz.argtypes = [C.c_void_p, C.c_int]; L.nullgl_bind_t_sz.restype = C.c_size_t
+    L.nullgl_interpolate_glsl.argtypes = [C.c_void_p]
+    return L
+
+
+def cfg(n, **kw):
+    d = dict(n=n, bufscale=1, interpolate=0, accel_fft=0, avg_frames=5, avg_window=1, fft_scale=10.2, fft_cutoff=0.3,
+             gravity_step=4.2, ur=86.1328125, fr=144.0, hip_log_mode=1)
+    d.update(kw)
+    return Cfg(**d)
+
+
+def run(L, c, frames, modified):
+    """frames: float32 [nframes][2][n] (time-domain lb/rb as glava.c:528-537 snapshots them); returns the uploads
+    [nframes][2][n_eff] and the buffers as rd_update left them."""
+    h = L.nullgl_create(C.byref(c))
+    assert h
+    n = c.n
+    ups, bufs = [], []
+    for f, m in zip(frames, modified):
+        lb, rb = np.ascontiguousarray(f[0]).copy(), np.ascontiguousarray(f[1]).copy()
+        ul, ur = np.zeros(n, np.float32), np.zeros(n, np.float32)
+        k = C.c_size_t(0)
+        got = L.nullgl_update(h, lb, rb, n, int(m), ul, ur, C.byref(k))
+        assert got == 2, got
+        ups.append(np.stack([ul[:k.value], ur[:k.value]]))
+        bufs.append(np.stack([lb, rb]))
+    L.nullgl_destroy(h)
+    return ups, bufs
+
+
+def bits(a):
+    return np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)
+
+
+def pcm_frames(n, nframes, seed):
+    pcm = lcg_pcm_fast(seed, nframes * 2 * n).reshape(nframes, n, 2)
+    return (pcm.astype(np.float32) / np.float32(65535)).transpose(0, 2, 1).copy()      # [f][ch][n], fifo.c:105-106
+
+
+def test_cpu_path_uploads_equal_the_oracle_chain():
+    """accel_fft off: every modified frame uploads fft -> gravity -> average of the snapshot (render.c:2149-2153);
+    a frame with modified == false uploads its buffer untouched."""
+    L = load(REF_SO)
+    n, nf = 1024, 9
+    frames = pcm_frames(n, nf, 4711)
+    modified = [True, True, False, True, True, True, False, True, True]
+    ups, _ = run(L, cfg(n), frames, modified)
+    so = StreamOracle(n, avg_frames=5)
+    for f in range(nf):
+        if modified[f]:
+            pcm = lcg_pcm_fast(4711, nf * 2 * n).reshape(nf, n * 2)[f]
+            want = so.frame(pcm)
+            assert (bits(ups[f]) == bits(want)).all(), f
+        else:
+            assert (bits(ups[f]) == bits(frames[f])).all(), f
+
+
+def test_accel_fft_path_retransforms_unmodified_frames():
+    """accel_fft on: the first modified frame moves gravity/average "to the GPU" (bind->optimize_fft, the transform list
+    is truncated: render.c:2131-2135, 2161-2173) and from then on EVERY frame -- modified or not -- is run through
+    transform_fft before the upload (render.c:2176-2180)."""
+    L = load(REF_SO)
+    n = 512
+    frames = pcm_frames(n, 4, 99)
+    ups, _ = run(L, cfg(n, accel_fft=1), frames, [True, False, True, False])
+    for f in range(4):
+        for ch in range(2):
+            assert (bits(ups[f][ch]) == bits(Oracle.transform_fft(frames[f][ch]))).all(), (f, ch)
+    h = L.nullgl_create(C.byref(cfg(n, accel_fft=1)))
+    lb, rb = frames[0][0].copy(), frames[0][1].copy()
+    ul, ur = np.zeros(n, np.float32), np.zeros(n, np.float32)
+    L.nullgl_update(h, lb, rb, n, 1, ul, ur, C.byref(C.c_size_t(0)))
+    assert L.nullgl_bind_t_sz(h, 0) == 1 and L.nullgl_bind_t_sz(h, 1) == 1      # "window" stays, fft and what follows are cut
+    L.nullgl_destroy(h)
+
+
+@pytest.mark.parametrize("k", [2, 4])
+def test_prelude_bufscale_pins_the_oracle(k):
+    """render.c:1765-1790 executed for real: the buffers handle_audio sees are the box-decimated ones."""
+    L = load(REF_SO)
+    n = 2048
+    frames = pcm_frames(n, 3, 31 + k)
+    ups, _ = run(L, cfg(n, bufscale=k), frames, [True, True, True])
+    so_l = StreamOracle(n // k, avg_frames=5)
+    for f in range(3):
+        dec = np.empty((2, n // k), np.float32)
+        for ch in range(2):
+            Oracle.lib().glvo_bufscale(np.ascontiguousarray(frames[f][ch]), dec[ch], n // k, k)
+        # the decimated rows through the oracle's transform chain (planar input: fft, gravity, average per channel)
+        want = np.stack([Oracle.transform_fft(dec[ch]) for ch in range(2)])
+        for ch in range(2):
+            Oracle.gravity(want[ch], so_l.grav[ch]); Oracle.average(want[ch], so_l.hist[ch], _head(so_l, ch), 5, True)
+        assert ups[f].shape == (2, n // k)
+        assert (bits(ups[f]) == bits(want)).all(), f
+
+
+def _head(so, ch):
+    # StreamOracle keeps both ring heads in one ctypes array; Oracle.average wants a c_size_t it can advance
+    if not hasattr(so, "_hh"):
+        so._hh = [C.c_size_t(0), C.c_size_t(0)]
+    return so._hh[ch]
+
+
+def test_prelude_interpolation_pins_the_oracle():
+    """render.c:1792-1809 + the keyframe pushes of :2347-2353 executed for real (CPU path, interpolation on, update rate
+    well below the frame rate): what is uploaded is start + (end - start) * min(uratio * kcounter, 1) of the last two
+    TRANSFORMED keyframes."""
+    L = load(REF_SO)
+    n = 512
+    ur, fr = 30.0, 120.0
+    frames = pcm_frames(n, 3, 5)
+    seq = [0, 0, 0, 1, 1, 1, 1, 2, 2]                         # a new snapshot every few rendered frames
+    modified = [True, False, False, True, False, False, False, True, False]
+    ups, _ = run(L, cfg(n, interpolate=1, ur=ur, fr=fr), [frames[i] for i in seq], modified)
+    so = StreamOracle(n, avg_frames=5, ur=ur)                  # gravity's step is gravity_step / ur (render.c:728)
+    start = np.zeros((2, n), np.float32); end = np.zeros((2, n), np.float32)
+    kcounter = 0
+    pcm = lcg_pcm_fast(5, 3 * 2 * n).reshape(3, 2 * n)
+    for f, (i, m) in enumerate(zip(seq, modified)):
+        want = np.empty((2, n), np.float32)
+        for ch in range(2):                                   # the interpolation runs BEFORE this frame's transforms
+            Oracle.lib().glvo_lerp(np.ascontiguousarray(start[ch]), np.ascontiguousarray(end[ch]), want[ch], n, np.float32(ur) / np.float32(fr), kcounter)
+        assert (bits(ups[f]) == bits(want)).all(), f
+        if m:
+            cur = so.frame(pcm[i])
+            start, end = end, cur
+            kcounter = 0
+        else:
+            kcounter += 1
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("accel,interp,k", [(0, 0, 1), (1, 0, 1), (0, 1, 1), (0, 0, 2)])
+def test_patched_handle_audio_uploads_what_the_reference_uploads(glvlib, accel, interp, k):
+    """integration/render_hip.patch applied to the reference's render.c, same frame sequences: the values handed to the
+    GL_R16 texture agree with the unpatched reference -- bit for bit with the bit-faithful log (log_mode 0), within 1e-5
+    with the default hardware log -- on every branch of handle_audio, including the frames with modified == false."""
+    R, H = load(REF_SO), load(HIP_SO)
+    n = 2048
+    frames = pcm_frames(n, 8, 77 + accel)
+    modified = [True, True, False, True, False, False, True, True]
+    base = dict(accel_fft=accel, interpolate=interp, bufscale=k, ur=30.0 if interp else 86.1328125, fr=120.0)
+    want, wbuf = run(R, cfg(n, **base), frames, modified)
+    for log_mode in (0, 1):
+        got, gbuf = run(H, cfg(n, hip_log_mode=log_mode, **base), frames, modified)
+        for f in range(len(frames)):
+            if log_mode == 0:
+                assert (bits(got[f]) == bits(want[f])).all(), (f, log_mode)
+                assert (bits(gbuf[f]) == bits(wbuf[f])).all(), (f, log_mode)
+            else:
+                assert np.allclose(got[f], want[f], rtol=1e-5, atol=2e-6), (f, log_mode)

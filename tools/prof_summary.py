@@ -1,6 +1,12 @@
 #!/usr/bin/env python3
-"""Summarise a tools/profile.sh output directory: kernel stats + per-dispatch PMC averages for the
-frame kernel.  Prints plain text (committed under profiles/)."""
+"""Summarise a tools/profile.sh output directory: kernel stats + per-dispatch PMC averages per KERNEL (keyed on the full
+template argument list: the stateless, stateful and R16 instantiations of glv_frame_kernel differ only in their last
+arguments and must not be blended).  Prints plain text (committed under profiles/).
+
+    prof_summary.py <dir> [--traffic-json OUT --n N --streams S --ops OPS --kernel SUBSTRING]
+
+--traffic-json writes the HBM bytes per launch (2*FETCH_SIZE + WRITE_SIZE, MI355X_MICROARCH.md HBM section) of the one
+kernel whose name contains SUBSTRING, in the format bench.py reads (profiles/hbm_traffic.json)."""
 import csv
 import glob
 import os
@@ -8,7 +14,7 @@ import sys
 from collections import defaultdict
 
 
-def main(out):
+def main(out, traffic=None):
     for f in glob.glob(os.path.join(out, "stats", "**", "*kernel_stats.csv"), recursive=True):
         print("== kernel stats:", os.path.relpath(f, out))
         for row in csv.DictReader(open(f)):
@@ -23,7 +29,7 @@ def main(out):
             k = row.get("Kernel_Name", "")
             if "glv_" not in k:
                 continue
-            agg[k.split("(")[0][:60]][row.get("Counter_Name")].append(float(row.get("Counter_Value", 0)))
+            agg[k.split("(")[0]][row.get("Counter_Name")].append(float(row.get("Counter_Value", 0)))
     for k, cs in agg.items():
         print("== PMC (mean per dispatch):", k)
         for c, v in sorted(cs.items()):
@@ -41,7 +47,23 @@ def main(out):
         if g("FETCH_SIZE") is not None and g("WRITE_SIZE") is not None:
             tot = (2 * g("FETCH_SIZE") + g("WRITE_SIZE")) * 1024
             print(f"  HBM traffic per launch (2*FETCH_SIZE + WRITE_SIZE) = {tot:.0f} bytes")
+            if traffic and traffic["kernel"] in k:
+                import json
+                rec = [{"n": traffic["n"], "streams": traffic["streams"], "ops": traffic["ops"], "bytes_per_launch": int(round(tot)),
+                        "kernel": k, "fetch_size_kb": g("FETCH_SIZE"), "write_size_kb": g("WRITE_SIZE"),
+                        "source": "rocprofv3 --pmc FETCH_SIZE (x2 gfx950 wide-stream correction, MI355X_MICROARCH.md HBM section) and --pmc WRITE_SIZE, "
+                                  "separate passes (tools/profile.sh), mean over the dispatches of exactly this kernel under `bench.py --steps 2 --warmup 1`"}]
+                json.dump(rec, open(traffic["out"], "w"), indent=1)
 
 
 if __name__ == "__main__":
-    main(sys.argv[1])
+    import argparse
+    ap = argparse.ArgumentParser()
+    ap.add_argument("dir")
+    ap.add_argument("--traffic-json", default="")
+    ap.add_argument("--n", type=int, default=4096)
+    ap.add_argument("--streams", type=int, default=65536)
+    ap.add_argument("--ops", default="fft")
+    ap.add_argument("--kernel", default="")
+    a = ap.parse_args()
+    main(a.dir, {"out": a.traffic_json, "n": a.n, "streams": a.streams, "ops": a.ops, "kernel": a.kernel} if a.traffic_json else None)

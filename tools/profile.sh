@@ -24,5 +24,5 @@ for set in \
   i=$((i+1))
   rocprofv3 --pmc $set --output-format csv -d "$OUT/pmc$i" -o bench -- $PMCBENCH > /dev/null 2> "$OUT/pmc$i.err"
 done
-python "$ROOT/tools/prof_summary.py" "$OUT" > "$OUT/summary.txt" 2>&1
+python "$ROOT/tools/prof_summary.py" "$OUT" ${TRAFFIC_ARGS:-} > "$OUT/summary.txt" 2>&1
 cat "$OUT/summary.txt"

@@ -20,12 +20,13 @@ sys.path.insert(0, ROOT)
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--streams", type=int, default=65536)
-    ap.add_argument("--iters", type=int, default=5)
+    ap.add_argument("--iters", type=int, default=10)
     ap.add_argument("--reps", type=int, default=5)
     ap.add_argument("--grids", default="0", help="comma list of grid sizes (0 = auto)")
     ap.add_argument("--log-modes", default="0,1")
     ap.add_argument("--out", default="")
     ap.add_argument("--lib", default="", help="alternative libglvtune_*.so (A/B experiments)")
+    ap.add_argument("--spinup-s", type=float, default=0.5)
     ap.add_argument("--extra-ops", type=int, default=0, help="ops OR'ed into GLV_OP_FFT (256 = GLV_OP_R16, 2 = GLV_OP_GRAVITY: timing only)")
     ap.add_argument("--bytes-per-frame-n", type=float, default=0.0, help="algorithmic bytes per frame in units of N (default 12; 8 with R16, 20 with gravity state-only)")
     a = ap.parse_args()
@@ -56,6 +57,13 @@ def main():
             torch.cuda.synchronize()
             b.close()
         cases = [(grid, i) for grid in grids for i in range(T.glv_tune_count())]
+        # clock spin-up: the first dozens of launches after idle run ~20 % slower on MI355X (bench.py does the same)
+        import time
+        t_end = time.perf_counter() + a.spinup_s
+        ms0 = C.c_float(0)
+        while time.perf_counter() < t_end:
+            T.glv_tune_run2(0, d_pcm.data_ptr(), None if gravity else d_out.data_ptr(), streams, lm, grids[0], 8, None, C.byref(ms0),
+                            a.extra_ops, d_grav.data_ptr() if gravity else None)
         times = {c: [] for c in cases}
         same = {}
         # round-robin over the variants, `reps` times, so clock/thermal drift hits all of them alike

@@ -1,7 +1,10 @@
 #!/usr/bin/env python3
 """bench.py -- BASELINE.json's metric on BASELINE.json's configuration.
 
-metric    stereo 4096-pt (setbufsize 4096) unpack+window+FFT+magnitude frames/s
+metric    stereo 4096-pt (setbufsize 4096) unpack+window+FFT+magnitude frames/s -- `value`, the pass configs[1] names;
+          the same line carries the FFT+smooth chain the metric's name alludes to (`smooth_chain`: fft -> gravity ->
+          average, what GLava's modules request), the bit-faithful log mode (`strict_log`) and the GL_R16 texel output
+          (`r16_texels`), each with its own algorithmic bytes and roofline fraction
 workload  configs[1]: 1 MI355X, 64K batched stereo streams, N=4096; per GPU for --gpus N
           (configs[3]: 512K streams sharded 64K-per-GPU over 8 GPUs; weak scaling, no data-path
           collective -- streams are independent; RCCL only gathers the per-rank stats record)
@@ -239,6 +242,20 @@ def main() -> None:
                  "avg_kernel_ms": c_k * 1e3, "roofline_frac": (c_bytes / c_k / 1e9) / HBM_PEAK_GBS if c_k > 0 else 0.0}
         cb.close()
 
+    # the same pass with the output as GL_R16 texels (what handle_audio uploads, render.c:521-524): 8N bytes per frame
+    r16 = None
+    if world == 1 and ops == G.OP_FFT and not a.no_alt:
+        rb = G.Batch(params, streams, G.OP_FFT, device=device)
+        ops_saved, ops = ops, G.OP_FFT | G.OP_R16
+        r_el, r_kms, r_nl = timed(rb)
+        ops = ops_saved
+        r_k = (r_kms / max(r_nl, 1)) * 1e-3
+        r_bytes = rb.algorithmic_bytes(G.OP_FFT | G.OP_R16)
+        r16 = {"note": f"window+FFT+magnitude with the output as GL_R16 texels (GLV_OP_R16), log_mode {a.log_mode}; algorithmic bytes 8*N per frame",
+               "value": streams * a.steps / r_el, "unit": "frames/s", "ms_per_step": r_el / a.steps * 1e3,
+               "avg_kernel_ms": r_k * 1e3, "roofline_frac": (r_bytes / r_k / 1e9) / HBM_PEAK_GBS if r_k > 0 else 0.0}
+        rb.close()
+
     frames_rank = streams * a.steps
     stats = gather_stats({"frames": frames_rank, "seconds": elapsed, "kernel_ms": kernel_ms,
                           "bytes": batch.algorithmic_bytes(ops) * launches}, world, force=dist_on)
@@ -250,7 +267,8 @@ def main() -> None:
         avg_kernel_s = (kernel_ms / max(launches, 1)) * 1e-3
         achieved = alg_bytes / avg_kernel_s / 1e9 if avg_kernel_s > 0 else 0.0
         line = {
-            "metric": "stereo 4096-pt FFT+smooth frames/s", "value": value, "unit": "frames/s",
+            "metric": f"stereo {n}-pt window+FFT+magnitude frames/s (BASELINE configs[1]; the FFT+smooth chain is in smooth_chain)",
+            "value": value, "unit": "frames/s", "log_mode": a.log_mode,
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": elapsed / a.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
@@ -281,6 +299,8 @@ def main() -> None:
                                 "roofline_frac": (alg_bytes / a_k / 1e9) / HBM_PEAK_GBS if a_k > 0 else 0.0}
         if chain is not None:
             line["smooth_chain"] = chain
+        if r16 is not None:
+            line["r16_texels"] = r16
         if world == 1 and not a.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(n, a.cpu_seconds)
         else:

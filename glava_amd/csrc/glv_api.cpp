@@ -203,7 +203,7 @@ int frame_grid(const glv_batch* b, uint32_t units) {
     // prologue (window / table staging, pipeline fill) that short-lived workgroups cannot amortise
     // (N=8192, 8192 streams: 0.194 ms with 256-512 workgroups, 0.224 ms with 2048)
     const uint32_t round = (uint32_t) b->num_cus * (uint32_t) glv::frame_resident(b->log_nn);
-    const uint32_t cap = wgs >= 16u * round ? 2u * round : round;
+    const uint32_t cap = wgs >= 16u * round ? (uint32_t) glv::frame_rounds(b->log_nn) * round : round;
     return (int) (wgs < cap ? wgs : cap);
 }
 

@@ -441,10 +441,13 @@ struct Frame {
     // register pair (rows of 16 lanes trade registers: a 2x2 transpose) leaves every lane with two adjacent
     // points per register pair and the spectrum leaves in 16-byte stores like at the other sizes.  A 32-lane
     // half of the wave still covers 32 consecutive groups, so the LDS reads of the pass stay conflict free.
-#if defined(GLV_EXP_NOSWAP16)     /* tools/tune.py A/B builds: the round-1 layout (8-byte stores) */
-    static constexpr bool SWAP16 = false;
-#else
+    // Measured (profiles/r02/sweep_3.txt, same box, warmed clocks): N=8192 0.738-0.742 ms with the swap against 0.731-0.741 ms
+    // without, N=1024 0.610-0.613 against 0.613-0.617 -- the pass is not bound by store issue, so the production kernels keep
+    // the plain layout (8-byte stores for these two sizes) and the swap stays an opt-in experiment (-DGLV_EXP_SWAP16).
+#if defined(GLV_EXP_SWAP16)
     static constexpr bool SWAP16 = P >= 2 && (E >> PL::rb(P - 1)) == 1 && (T % 64) == 0;
+#else
+    static constexpr bool SWAP16 = false;
 #endif
     GLV_HD static constexpr int swap16_lane_group(int tid) {
         return (tid & ~31) | ((tid & 15) << 1) | ((tid >> 4) & 1);

@@ -12,20 +12,20 @@
 namespace glv {
 
 template <int LOG_NN> struct Tuned;
-#define GLV_TUNED(K, LE, S, NB, TR, WL, OC, PF, TL, WP, WPS) \
+#define GLV_TUNED(K, LE, S, NB, TR, WL, OC, PF, TL, WP, WPS, RD) \
     template <> struct Tuned<K> { static constexpr int log_e = LE, slots = S, nbuf = NB, occ = OC; \
-                                  static constexpr bool winlds = WL; static constexpr int twreg = TR, tiltreg = TL, prefetch = PF, wpre = WP, wpre_s = WPS; };
+                                  static constexpr bool winlds = WL; static constexpr int twreg = TR, tiltreg = TL, prefetch = PF, wpre = WP, wpre_s = WPS, rounds = RD; };
 // measured best of tools/tune.py on MI355X (profiles/tune_r01_final.txt), equal bytes per size class:
-//         log2(nn) LOG_E SLOTS NBUF TWREG  WINLDS OCC PREFETCH TILTREG WPRE WPRE_S     (knob values: glv_kernel_tmpl.h)
-GLV_TUNED(7,       3,    16,   1,   true,  true,  4,  1,       true,   0,   0)    // N=256    E=8:  3+3+1 (16 lanes per row; not tuned: coverage of setbufsize 256)
-GLV_TUNED(8,       3,    16,   1,   true,  true,  4,  1,       true,   0,   0)    // N=512    E=8:  3+3+2
-GLV_TUNED(9,       3,    4,    1,   true,  true,  4,  1,       true,   0,   0)    // N=1024   E=8:  3+3+3 (last pass: one group per lane, SWAP16 stores)
-GLV_TUNED(10,      3,    2,    1,   true,  true,  4,  1,       true,   0,   0)    // N=2048   E=8:  3+3+3+1
-GLV_TUNED(11,      4,    2,    1,   true,  true,  2,  1,       true,   0,   0)    // N=4096   E=16: 4+4+3
-GLV_TUNED(12,      4,    2,    1,   true,  true,  2,  1,       true,   0,   0)    // N=8192   E=16: 4+4+4 (SWAP16 stores); two slots share the 64 KiB LDS window
-GLV_TUNED(13,      5,    1,    1,   2,     false, 2,  1,       2,      16,  0)    // N=16384  E=32: 5+5+3; pass-1 twiddles from an 8 KiB LDS table, tilt computed,
-                                                                                  //          half of the next row's window requested ahead of the spectrum stores
-GLV_TUNED(14,      5,    1,    1,   0,     false, 2,  1,       2,      0,   0)    // N=32768  E=32: 5+5+4, one 512-lane row per CU (135 KiB exchange region); not tuned: coverage
+//         log2(nn) LOG_E SLOTS NBUF TWREG  WINLDS OCC PREFETCH TILTREG WPRE WPRE_S ROUNDS   (knob values: glv_kernel_tmpl.h; ROUNDS: persistent workgroups launched = ROUNDS x what fits the chip)
+GLV_TUNED(7,       3,    16,   1,   true,  true,  4,  1,       true,   0,   0,   2)    // N=256    E=8:  3+3+1 (16 lanes per row; not tuned: coverage of setbufsize 256)
+GLV_TUNED(8,       3,    16,   1,   true,  true,  4,  1,       true,   0,   0,   2)    // N=512    E=8:  3+3+2
+GLV_TUNED(9,       3,    4,    1,   true,  true,  4,  1,       true,   0,   0,   2)    // N=1024   E=8:  3+3+3
+GLV_TUNED(10,      3,    2,    1,   true,  true,  4,  1,       true,   0,   0,   2)    // N=2048   E=8:  3+3+3+1
+GLV_TUNED(11,      4,    2,    1,   true,  true,  2,  1,       true,   0,   0,   2)    // N=4096   E=16: 4+4+3
+GLV_TUNED(12,      4,    2,    1,   true,  true,  2,  1,       true,   0,   0,   1)    // N=8192   E=16: 4+4+4; two slots share the 64 KiB LDS window
+GLV_TUNED(13,      5,    1,    1,   2,     false, 2,  1,       2,      0,   0,   2)    // N=16384  E=32: 5+5+3; pass-1 twiddles from an 8 KiB LDS table, tilt computed
+                                                                                  //          (WPRE, the window prefetch ahead of the stores, measured no gain: profiles/r02)
+GLV_TUNED(14,      5,    1,    1,   0,     false, 2,  1,       2,      0,   0,   1)    // N=32768  E=32: 5+5+4, one 512-lane row per CU (135 KiB exchange region); not tuned: coverage
 #undef GLV_TUNED
 
 #define GLV_CAT2(a, b) a##b
@@ -72,6 +72,11 @@ int GLV_CAT(frame_resident_, GLV_LOG_NN)() {
     constexpr int r = by_lds < by_waves ? by_lds : by_waves;
     return r > 0 ? r : 1;
 }
+
+// rounds of resident workgroups a large launch is cut into (glv_api.cpp frame_grid).  Two rounds even out CU-to-CU
+// differences; the sizes whose ONE 512-thread workgroup per CU pays a 64 KiB window staging prologue with nothing else on
+// the CU to overlap it run one round (N=8192, 32768 streams: 0.697 ms with 256 workgroups, 0.723 ms with 512).
+int GLV_CAT(frame_rounds_, GLV_LOG_NN)() { return Tuned<GLV_LOG_NN>::rounds; }
 
 // channel rows one workgroup takes per trip of its persistent loop (grid sizing): a pipelined s16
 // slot takes a whole frame (2 rows), a single-slot workgroup both rows of its frame in sequence; for

@@ -12,7 +12,8 @@ namespace glv {
     hipError_t launch_frame_##K(int in_mode, int log_mode, const FrameArgs& a, int grid, hipStream_t st); \
     int frame_slots_##K(); \
     int frame_lanes_##K(); \
-    int frame_resident_##K();
+    int frame_resident_##K(); \
+    int frame_rounds_##K();
 GLV_DECL_INST(7) GLV_DECL_INST(8) GLV_DECL_INST(9) GLV_DECL_INST(10) GLV_DECL_INST(11) GLV_DECL_INST(12) GLV_DECL_INST(13) GLV_DECL_INST(14)
 #undef GLV_DECL_INST
 
@@ -21,6 +22,7 @@ hipError_t launch_frame(int log_nn, int in_mode, int log_mode, const FrameArgs& 
 int frame_slots(int log_nn);      // channel rows one workgroup takes per iteration of its persistent loop
 int frame_lanes(int log_nn);      // lanes cooperating on one row
 int frame_resident(int log_nn);   // workgroups of the production kernel that fit one CU
+int frame_rounds(int log_nn);     // rounds of resident workgroups a large launch is cut into
 hipError_t launch_post(const FrameArgs& a, uint32_t n, hipStream_t st);
 hipError_t launch_bufscale(const float* in, float* out, size_t total_out, uint32_t k, hipStream_t st);
 hipError_t launch_lerp(const float* s0, const float* e0, float* out, size_t total, float mod, hipStream_t st);

@@ -203,3 +203,13 @@ int frame_resident(int log_nn) {
 }
 
 }  // namespace glv
+
+namespace glv {
+int frame_rounds(int log_nn) {
+    switch (log_nn) {
+        case 7: return frame_rounds_7(); case 8: return frame_rounds_8(); case 9: return frame_rounds_9(); case 10: return frame_rounds_10();
+        case 11: return frame_rounds_11(); case 12: return frame_rounds_12(); case 13: return frame_rounds_13(); case 14: return frame_rounds_14();
+    }
+    return 2;
+}
+}  // namespace glv

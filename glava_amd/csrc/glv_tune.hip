@@ -78,12 +78,19 @@ int glv_tune_launch(int i, int in_mode, int log_mode, const glv::FrameArgs* a, i
 // extra_ops: OR'ed into OP_FFT (OP_R16: d_out receives uint16 texels; OP_GRAVITY: d_grav = float [units*2][n] state)
 int glv_tune_run2(int i, const void* d_pcm, float* d_out, unsigned units, int log_mode, int grid, int iters,
                   void* stream, float* ms, unsigned extra_ops, float* d_grav);
+// the same with a history ring (OP_AVERAGE): d_hist = float [units*2][F][n], F = 5 windowed
+int glv_tune_run3(int i, const void* d_pcm, float* d_out, unsigned units, int log_mode, int grid, int iters,
+                  void* stream, float* ms, unsigned extra_ops, float* d_grav, float* d_hist);
 int glv_tune_run(int i, const void* d_pcm, float* d_out, unsigned units, int log_mode, int grid, int iters,
                  void* stream, float* ms) {
     return glv_tune_run2(i, d_pcm, d_out, units, log_mode, grid, iters, stream, ms, 0u, nullptr);
 }
 int glv_tune_run2(int i, const void* d_pcm, float* d_out, unsigned units, int log_mode, int grid, int iters,
                   void* stream, float* ms, unsigned extra_ops, float* d_grav) {
+    return glv_tune_run3(i, d_pcm, d_out, units, log_mode, grid, iters, stream, ms, extra_ops, d_grav, nullptr);
+}
+int glv_tune_run3(int i, const void* d_pcm, float* d_out, unsigned units, int log_mode, int grid, int iters,
+                  void* stream, float* ms, unsigned extra_ops, float* d_grav, float* d_hist) {
     using namespace glv;
     static cf* d_tw = nullptr;
     static double* d_win = nullptr;
@@ -115,8 +122,10 @@ int glv_tune_run2(int i, const void* d_pcm, float* d_out, unsigned units, int lo
     FrameArgs a;
     std::memset(&a, 0, sizeof(a));
     a.in = d_pcm; a.out = d_out; a.tw = d_tw; a.win = d_win; a.logtab = d_log; a.tilt = log_mode == 1 ? d_tilt_fast : d_tilt; a.units = units * 2; a.ops = OP_FFT | extra_ops; a.grav = d_grav;
-    a.F = 1; a.inv_n = 1.0f / (float) N; a.fft_scale = 10.2f; a.one_minus_cutoff = 1.0f - 0.3f;
-    a.g = 4.2f * (1.0f / 86.1328125f); a.F_as_float = 1.0f;
+    a.F = d_hist ? 5 : 1; a.hist = d_hist; a.avg_window = 1;
+    make_frame_weights(a.wts, a.F, true, 0);
+    a.inv_n = 1.0f / (float) N; a.fft_scale = 10.2f; a.one_minus_cutoff = 1.0f - 0.3f;
+    a.g = 4.2f * (1.0f / 86.1328125f); a.F_as_float = (float) a.F;
     hipStream_t st = (hipStream_t) stream;
     if (grid <= 0) {
         const unsigned slots = (unsigned) kVariants[i].slots;          // at most one frame per slot per trip

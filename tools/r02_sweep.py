@@ -16,18 +16,11 @@ sys.path.insert(0, ROOT)
 NOL0 = ["-DGLV_TUNE_NO_LOG0"]
 # name, log_nn, extra flags, variant list (glv_tune.hip macros)
 LIBS = [
-    ("r2b_n13", 13, NOL0, "VW(1,1,2,false,2,1,2,5,0,0),VW(1,1,0,false,4,1,2,4,0,0),VW(1,1,0,false,3,1,2,4,0,0),VW(1,1,0,false,2,1,2,5,0,0),VW(1,1,0,false,2,1,2,4,0,0)"),
-    ("r2b_n12", 12, NOL0, "VW(2,1,true,true,2,1,true,4,0,0),VW(1,1,true,false,2,1,true,4,16,0),VW(1,1,0,false,4,1,2,4,0,0),VW(1,1,0,false,3,1,2,4,0,0),VW(1,1,0,false,3,1,true,4,0,0),VW(1,1,0,false,2,1,true,4,0,0)"),
-    ("r2b_n12_wgb", 12, NOL0 + ["-DGLV_EXP_WGBARRIER"], "VW(2,1,true,true,2,1,true,4,0,0)"),
-    ("r2b_n11", 11, NOL0, "VW(2,1,true,true,2,1,true,4,0,0)"),
+    ("r2f_n13", 13, NOL0, "VW(1,1,2,false,2,1,2,5,0,0),VW(1,1,2,false,2,1,0,5,0,0),VW(1,1,2,false,2,1,2,5,16,0),VW(1,1,2,false,2,1,0,5,16,0),VW(1,1,2,false,2,1,2,5,0,0),VW(1,1,2,false,2,1,0,5,0,0)"),
 ]
-# lib name, streams, extra ops, label
 RUNS = [
-    ("r2b_n11", 65536, 0, "N=4096 fft+magnitude (first)"),
-    ("r2b_n13", 16384, 0, "N=16384 fft+magnitude: occupancy variants"),
-    ("r2b_n12", 32768, 0, "N=8192 fft+magnitude: occupancy variants"),
-    ("r2b_n12_wgb", 32768, 0, "N=8192 fft+magnitude, workgroup-wide barrier"),
-    ("r2b_n11", 65536, 0, "N=4096 fft+magnitude (last)"),
+    ("r2f_n13", 16384, 0, "N=16384 fft: tilt computed (tiltreg=2) vs tilt table through L2 (tiltreg=0)"),
+    ("r2f_n13", 16384, 2, "N=16384 fft+gravity state only"),
 ]
 
 
@@ -56,8 +49,8 @@ def main():
                 if a.only and lib not in a.only.split(","):
                     continue
                 f.write(f"== {label}  [{lib}, streams={streams}, extra_ops={extra}]\n"); f.flush()
-                subprocess.run([sys.executable, os.path.join(ROOT, "tools", "tune.py"), "--streams", str(streams), "--log-modes", "1",
-                                "--lib", os.path.join(ROOT, "glava_amd", "csrc", f"libglvtune_{lib}.so"), "--extra-ops", str(extra)],
+                subprocess.run([sys.executable, os.path.join(ROOT, "tools", "tune.py"), "--streams", str(streams), "--log-modes", "0,1" if "_l0" in lib else "1",
+                                "--lib", os.path.join(ROOT, "glava_amd", "csrc", f"libglvtune_{lib}.so"), "--extra-ops", str(extra)] + (["--grids", "256,512"] if "n12" in lib else []),
                                stdout=f, stderr=subprocess.STDOUT)
                 f.flush()
 

@@ -35,17 +35,19 @@ def main():
     B.build(tune=not a.lib)
     T = C.CDLL(a.lib if a.lib else os.path.join(ROOT, "glava_amd", "csrc", "libglvtune.so"))
     T.glv_tune_describe.restype = C.c_char_p
-    T.glv_tune_run2.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_uint, C.c_int, C.c_int, C.c_int, C.c_void_p,
-                                C.POINTER(C.c_float), C.c_uint, C.c_void_p]
+    T.glv_tune_run3.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_uint, C.c_int, C.c_int, C.c_int, C.c_void_p,
+                                C.POINTER(C.c_float), C.c_uint, C.c_void_p, C.c_void_p]
     n = 2 << T.glv_tune_log_nn()
     streams = a.streams
     g = torch.Generator(device="cuda"); g.manual_seed(1)
     d_pcm = torch.randint(-32768, 32768, (streams, n, 2), dtype=torch.int16, device="cuda", generator=g)
     d_ref = torch.empty((streams, 2, n), dtype=torch.float32, device="cuda")
     d_out = torch.empty_like(d_ref)
-    gravity = bool(a.extra_ops & G.OP_GRAVITY)
+    gravity = bool(a.extra_ops & (G.OP_GRAVITY | G.OP_AVERAGE))
+    average = bool(a.extra_ops & G.OP_AVERAGE)
+    d_hist = torch.zeros((streams, 2, 5, n), dtype=torch.float32, device="cuda") if average else None
     d_grav = torch.zeros((streams, 2, n), dtype=torch.float32, device="cuda") if gravity else None
-    bpf = a.bytes_per_frame_n if a.bytes_per_frame_n else (8.0 if a.extra_ops & G.OP_R16 else 20.0 if gravity else 12.0)
+    bpf = a.bytes_per_frame_n if a.bytes_per_frame_n else (8.0 if a.extra_ops & G.OP_R16 else 52.0 if average else 20.0 if gravity else 12.0)
     lines = []
     import statistics
     grids = [int(x) for x in a.grids.split(",")]
@@ -62,8 +64,8 @@ def main():
         t_end = time.perf_counter() + a.spinup_s
         ms0 = C.c_float(0)
         while time.perf_counter() < t_end:
-            T.glv_tune_run2(0, d_pcm.data_ptr(), None if gravity else d_out.data_ptr(), streams, lm, grids[0], 8, None, C.byref(ms0),
-                            a.extra_ops, d_grav.data_ptr() if gravity else None)
+            T.glv_tune_run3(0, d_pcm.data_ptr(), d_out.data_ptr() if (average or not gravity) else None, streams, lm, grids[0], 8, None, C.byref(ms0),
+                            a.extra_ops, d_grav.data_ptr() if gravity else None, d_hist.data_ptr() if average else None)
         times = {c: [] for c in cases}
         same = {}
         # round-robin over the variants, `reps` times, so clock/thermal drift hits all of them alike
@@ -72,8 +74,8 @@ def main():
                 ms = C.c_float(0)
                 if rep == 0:
                     d_out.zero_()
-                rc = T.glv_tune_run2(i, d_pcm.data_ptr(), None if gravity else d_out.data_ptr(), streams, lm, grid, a.iters, None, C.byref(ms),
-                                     a.extra_ops, d_grav.data_ptr() if gravity else None)
+                rc = T.glv_tune_run3(i, d_pcm.data_ptr(), d_out.data_ptr() if (average or not gravity) else None, streams, lm, grid, a.iters, None, C.byref(ms),
+                                     a.extra_ops, d_grav.data_ptr() if gravity else None, d_hist.data_ptr() if average else None)
                 torch.cuda.synchronize()
                 if rc != 0:
                     times[(grid, i)].append(float("inf"))

@@ -15,13 +15,17 @@ sys.path.insert(0, ROOT)
 
 NOL0 = ["-DGLV_TUNE_NO_LOG0"]
 # name, log_nn, extra flags, variant list (glv_tune.hip macros)
-LIBS = [
-    ("r2f_n13", 13, NOL0, "VW(1,1,2,false,2,1,2,5,0,0),VW(1,1,2,false,2,1,0,5,0,0),VW(1,1,2,false,2,1,2,5,16,0),VW(1,1,2,false,2,1,0,5,16,0),VW(1,1,2,false,2,1,2,5,0,0),VW(1,1,2,false,2,1,0,5,0,0)"),
-]
-RUNS = [
-    ("r2f_n13", 16384, 0, "N=16384 fft: tilt computed (tiltreg=2) vs tilt table through L2 (tiltreg=0)"),
-    ("r2f_n13", 16384, 2, "N=16384 fft+gravity state only"),
-]
+V13 = "VW(1,1,2,false,2,1,2,5,0,0),VW(1,1,2,false,2,1,2,5,0,0)"
+V12 = "VW(2,1,true,true,2,1,true,4,0,0),VW(2,1,true,true,2,1,true,4,0,0)"
+V11 = "VW(2,1,true,true,2,1,true,4,0,0),VW(2,1,true,true,2,1,true,4,0,0)"
+LIBS = [("r2i_n13", 13, NOL0, V13), ("r2i_n12", 12, NOL0, V12), ("r2i_n11", 11, NOL0, V11)]
+RUNS = []
+for rnd in (0, 60, 120, 240):
+    RUNS.append(("r2i_n13", 16384, 0, f"N=16384 skew_round={rnd}", {"GLV_SKEW_ROUND": str(rnd)}))
+for sl in (0, 25, 50, 100):
+    RUNS.append(("r2i_n12", 32768, 0, f"N=8192 skew_slot={sl}", {"GLV_SKEW_SLOT": str(sl)}))
+for rnd, sl in ((0, 0), (40, 0), (0, 20), (40, 20)):
+    RUNS.append(("r2i_n11", 65536, 0, f"N=4096 skew_round={rnd} skew_slot={sl}", {"GLV_SKEW_ROUND": str(rnd), "GLV_SKEW_SLOT": str(sl)}))
 
 
 def main():
@@ -45,13 +49,15 @@ def main():
         with open(os.path.join(out, "membench2.txt"), "w") as f:
             subprocess.run([os.path.join(ROOT, "tools", "bin", "membench2")], stdout=f, stderr=subprocess.STDOUT)
         with open(os.path.join(out, "sweep.txt"), "w") as f:
-            for lib, streams, extra, label in RUNS:
+            for run in RUNS:
+                lib, streams, extra, label = run[:4]
+                env = dict(os.environ); env.update(run[4] if len(run) > 4 else {})
                 if a.only and lib not in a.only.split(","):
                     continue
                 f.write(f"== {label}  [{lib}, streams={streams}, extra_ops={extra}]\n"); f.flush()
                 subprocess.run([sys.executable, os.path.join(ROOT, "tools", "tune.py"), "--streams", str(streams), "--log-modes", "0,1" if "_l0" in lib else "1",
-                                "--lib", os.path.join(ROOT, "glava_amd", "csrc", f"libglvtune_{lib}.so"), "--extra-ops", str(extra)] + (["--grids", "256,512"] if "n12" in lib else []),
-                               stdout=f, stderr=subprocess.STDOUT)
+                                "--lib", os.path.join(ROOT, "glava_amd", "csrc", f"libglvtune_{lib}.so"), "--extra-ops", str(extra)] + (["--grids", "256"] if "n12" in lib else []),
+                               stdout=f, stderr=subprocess.STDOUT, env=env)
                 f.flush()
 
 

@@ -56,6 +56,7 @@ int validate(const glv_params* p) {
         return fail(GLV_ERR_INVALID, "avg_frames=%u: must be in [1, %d]", p->avg_frames, GLV_MAX_AVG_FRAMES);
     if (p->avg_window_kind > 1) return fail(GLV_ERR_INVALID, "avg_window_kind=%u: must be 0 or 1", p->avg_window_kind);
     if (p->log_mode > 2) return fail(GLV_ERR_INVALID, "log_mode=%u: must be 0, 1 or 2", p->log_mode);
+    if (p->gl_storage > 1) return fail(GLV_ERR_INVALID, "gl_storage=%u: must be 0 or 1", p->gl_storage);
     if (p->ur != p->ur) return fail(GLV_ERR_INVALID, "ur is NaN");   // 0 is legal: render.c:2387 yields it after an interval without updates
     return GLV_OK;
 }
@@ -69,6 +70,55 @@ int ensure_device(int device) {
     if (device < 0 || device >= count) return fail(GLV_ERR_INVALID, "device %d out of range [0, %d)", device, count);
     HIP_TRY(hipSetDevice(device));
     return GLV_OK;
+}
+
+// ---- launch wisdom ----------------------------------------------------------------------------------------------------
+// The role glfft's FFTWisdom plays in the reference tree (glfft/glfft_wisdom.cpp:235-446: time candidate launch
+// configurations on the target, remember the winner per transform description): the kernel variant per size is fixed at
+// build time (glv_inst.hip Tuned<>, from tools/tune.py), what remains open at run time is how many persistent workgroups
+// a launch uses -- it depends on the size, on the operator chain and on how many streams the batch holds (N=8192 with
+// 32768 streams: 0.697 ms with 256 workgroups, 0.723 ms with 512; N=16384 the other way round).  glv_batch_autotune
+// measures the candidates on the device the batch lives on; entries are process-wide, can be saved and loaded
+// (GLV_WISDOM=<file> loads one when the first batch is created) and are consulted by every launch.
+struct WisdomKey { uint32_t n, in_kind, ops_class, log_mode, streams_log2; };
+struct WisdomEntry { WisdomKey k; int grid; float ms; };
+std::mutex g_wisdom_mu;
+std::vector<WisdomEntry> g_wisdom;
+bool g_wisdom_env_loaded = false;
+
+uint32_t ops_class_of(unsigned ops) {      // the kernel instantiation a chain selects (glv_kernel_tmpl.h launch_variant)
+    if (ops & GLV_OP_BARS) return 2;
+    if (ops & (GLV_OP_GRAVITY | GLV_OP_AVERAGE)) return (ops & GLV_OP_R16) ? 4 : 1;
+    return (ops & GLV_OP_R16) ? 3 : 0;
+}
+uint32_t log2_round(uint32_t v) { uint32_t l = 0; while ((2u << l) <= v) ++l; return ((v >> l << l) * 3 / 2 <= v && l < 31) ? l + 1 : l; }
+bool same_key(const WisdomKey& a, const WisdomKey& b) {
+    return a.n == b.n && a.in_kind == b.in_kind && a.ops_class == b.ops_class && a.log_mode == b.log_mode && a.streams_log2 == b.streams_log2;
+}
+int wisdom_lookup(const WisdomKey& k) {
+    std::lock_guard<std::mutex> lock(g_wisdom_mu);
+    for (const WisdomEntry& e : g_wisdom) if (same_key(e.k, k)) return e.grid;
+    return 0;
+}
+void wisdom_store(const WisdomKey& k, int grid, float ms) {
+    std::lock_guard<std::mutex> lock(g_wisdom_mu);
+    for (WisdomEntry& e : g_wisdom) if (same_key(e.k, k)) { e.grid = grid; e.ms = ms; return; }
+    g_wisdom.push_back(WisdomEntry{k, grid, ms});
+}
+int wisdom_load_file(const char* path) {
+    FILE* f = std::fopen(path, "r");
+    if (!f) { (void) fail(GLV_ERR_INVALID, "cannot open wisdom file %s", path); return -1; }
+    char line[256];
+    int n_loaded = 0;
+    while (std::fgets(line, sizeof(line), f)) {
+        if (line[0] == '#' || line[0] == '\n') continue;
+        WisdomKey k; int grid; float ms;
+        if (std::sscanf(line, "%u %u %u %u %u %d %f", &k.n, &k.in_kind, &k.ops_class, &k.log_mode, &k.streams_log2, &grid, &ms) == 7 && grid > 0) {
+            wisdom_store(k, grid, ms); ++n_loaded;
+        }
+    }
+    std::fclose(f);
+    return n_loaded;
 }
 
 // Device-resident constants of one transform size.
@@ -148,6 +198,7 @@ struct glv_batch {
     uint32_t head = 0;           // history slot receiving the next frame
     uint32_t ring_pos = 0;       // next write position in the PCM ring, in frames
     int grid_override = 0;
+    int last_grid = 0;           // workgroups of the last frame-kernel launch
     float* d_scratch = nullptr;  // [streams*2][n] spectra feeding GLV_OP_BARS
     float* d_ring_f32 = nullptr; // [streams][n][2] interleaved f32 ring (glv_batch_ring_update_f32)
     uint32_t ring_pos_f32 = 0;
@@ -194,8 +245,12 @@ int batch_alloc(glv_batch* b, uint32_t rows) {
     return GLV_OK;
 }
 
-int frame_grid(const glv_batch* b, uint32_t units) {
+int frame_grid(const glv_batch* b, uint32_t units, int in_mode = 0, unsigned ops = GLV_OP_FFT) {
     if (b->grid_override > 0) return b->grid_override;
+    if (const int g = wisdom_lookup(WisdomKey{b->p.n, (uint32_t) in_mode, ops_class_of(ops), b->p.log_mode, log2_round(b->streams)})) {
+        const uint32_t wgs_max = (units + glv::frame_slots(b->log_nn) - 1) / glv::frame_slots(b->log_nn);
+        return (uint32_t) g < wgs_max ? g : (int) wgs_max;
+    }
     const int slots = glv::frame_slots(b->log_nn);
     const uint32_t wgs = (units + slots - 1) / slots;
     // persistent workgroups: two rounds of what fits the chip (the second round evens out CU-to-CU
@@ -343,6 +398,42 @@ int process(glv_batch* b, const void* d_in, int in_mode, float* d_out, unsigned 
         a.bars = b->p.bars; a.bars_out = d_final;
     }
 
+    // glv_params.gl_storage: the GL twin's pass structure (render.c:2188-2265) -- the transform first, then gravity / average
+    // as their own pass over GL_R16-quantised values (glv_frame.h apply_state).  The frame kernel delivers the float spectra
+    // into the caller's buffer when that is what it will hold in the end, else into the batch's scratch rows.
+    const bool gl_split = b->p.gl_storage && (ops & (GLV_OP_GRAVITY | GLV_OP_AVERAGE)) != 0;
+    if (gl_split && (ops & GLV_OP_FFT)) {
+        const bool direct = d_final && !(ops & (GLV_OP_BARS | GLV_OP_R16));
+        float* d_tmp = direct ? d_final : nullptr;
+        if (!direct) {
+            if (!b->d_scratch) HIP_TRY(hipMalloc(&b->d_scratch, sizeof(float) * (size_t) b->streams * 2 * b->p.n));
+            d_tmp = b->d_scratch;
+        }
+        glv::FrameArgs a1 = a;
+        a1.ops = GLV_OP_FFT; a1.out = d_tmp; a1.bars_out = nullptr;
+        if (int rc = timed_launch_begin(b, st)) return rc;
+        b->last_grid = frame_grid(b, units, in_mode, GLV_OP_FFT);
+        hipError_t e1 = glv::launch_frame(b->log_nn, in_mode, (int) b->p.log_mode, a1, b->last_grid, st);
+        if (e1 != hipSuccess) return fail(GLV_ERR_HIP, "kernel launch failed: %s", hipGetErrorString(e1));
+        if (int rc = timed_launch_end(b, st)) return rc;
+        glv::FrameArgs a2 = a;
+        a2.in = d_tmp; a2.ops = ops & (GLV_OP_GRAVITY | GLV_OP_AVERAGE | ((ops & GLV_OP_BARS) ? 0u : (unsigned) GLV_OP_R16)); a2.gl_storage = 1;
+        a2.out = (ops & GLV_OP_BARS) ? d_tmp : d_final;            // bars sample the finished rows; NULL = the state is the output
+        a2.bars_out = nullptr;
+        e1 = glv::launch_post(a2, b->p.n, st);
+        if (e1 != hipSuccess) return fail(GLV_ERR_HIP, "GL-storage pass launch failed: %s", hipGetErrorString(e1));
+        b->kernel_name = "glv_frame_kernel";
+        if (ops & GLV_OP_AVERAGE) b->head = (b->head + 1) % b->p.avg_frames;
+        if (ops & GLV_OP_BARS) {
+            if (int rc = ensure_bar_tables(b)) return rc;
+            const float* src = (ops & GLV_OP_AVERAGE) || d_tmp ? d_tmp : b->d_grav;
+            e1 = glv::launch_bars(src, d_final, units, b->p.n, b->p.bars, b->bar_nsteps, b->d_bar_items, b->d_bar_desc, b->d_bar_w, st);
+            if (e1 != hipSuccess) return fail(GLV_ERR_HIP, "bars launch failed: %s", hipGetErrorString(e1));
+        }
+        return GLV_OK;
+    }
+    if (gl_split) a.gl_storage = 1;                                  // operators on planar rows: the post kernel models it directly
+
     if (int rc = timed_launch_begin(b, st)) return rc;
     hipError_t e;
     const unsigned core = ops & (GLV_OP_FFT | GLV_OP_GRAVITY | GLV_OP_AVERAGE | GLV_OP_WRANGE | GLV_OP_MAGNITUDE | GLV_OP_R16);
@@ -352,7 +443,8 @@ int process(glv_batch* b, const void* d_in, int in_mode, float* d_out, unsigned 
             : hipMemcpyAsync(d_out, d_in, sizeof(float) * (size_t) units * b->p.n, hipMemcpyDeviceToDevice, st);
         b->kernel_name = "glv_smooth_kernel";
     } else if (ops & GLV_OP_FFT) {
-        e = glv::launch_frame(b->log_nn, in_mode, (int) b->p.log_mode, a, frame_grid(b, units), st);
+        b->last_grid = frame_grid(b, units, in_mode, ops);
+        e = glv::launch_frame(b->log_nn, in_mode, (int) b->p.log_mode, a, b->last_grid, st);
         b->kernel_name = "glv_frame_kernel";
     } else {
         if (in_mode != glv::IN_F32_PLANAR) return fail(GLV_ERR_INVALID, "operators without GLV_OP_FFT take planar f32 input");
@@ -382,6 +474,13 @@ int batch_create_rows(const glv_params* p, uint32_t streams, unsigned ops_mask, 
     if (streams == 0) return fail(GLV_ERR_INVALID, "streams must be > 0");
     if (streams > (1u << 30)) return fail(GLV_ERR_INVALID, "streams=%u: at most 2^30 (row indices are 32-bit)", streams);
     if (int rc = ensure_device(device)) return rc;
+    {
+        std::unique_lock<std::mutex> lock(g_wisdom_mu);
+        const bool first = !g_wisdom_env_loaded;
+        g_wisdom_env_loaded = true;
+        lock.unlock();
+        if (first) if (const char* w = std::getenv("GLV_WISDOM")) (void) wisdom_load_file(w);      // a missing file is not an error
+    }
     glv_batch* b = new (std::nothrow) glv_batch();
     if (!b) return fail(GLV_ERR_NOMEM, "out of host memory");
     b->p = *p; b->streams = streams; b->ops_mask = ops_mask; b->device = device;
@@ -417,6 +516,7 @@ void glv_params_default(glv_params* p) {
     p->smooth_factor = 0.025F;   // smooth_parameters.glsl:72
     p->smooth_distance = 0.01F;  // render.c:917
     p->smooth_ratio = 4.0F;      // render.c:918
+    p->gl_storage = 0;
 }
 
 // shared with glv_multi.cpp: record an error string for the calling thread
@@ -625,6 +725,75 @@ uint64_t glv_batch_algorithmic_bytes(const glv_batch* b, unsigned ops, int input
 }
 
 const char* glv_batch_kernel_name(const glv_batch* b) { return b ? b->kernel_name : ""; }
+
+int glv_batch_last_grid(const glv_batch* b) { return b ? b->last_grid : 0; }
+
+int glv_wisdom_clear(void) { std::lock_guard<std::mutex> lock(g_wisdom_mu); g_wisdom.clear(); return GLV_OK; }
+int glv_wisdom_count(void) { std::lock_guard<std::mutex> lock(g_wisdom_mu); return (int) g_wisdom.size(); }
+int glv_wisdom_load(const char* path) {
+    if (!path) return fail(GLV_ERR_INVALID, "path is NULL");
+    const int n = wisdom_load_file(path);
+    return n < 0 ? GLV_ERR_INVALID : GLV_OK;
+}
+int glv_wisdom_save(const char* path) {
+    if (!path) return fail(GLV_ERR_INVALID, "path is NULL");
+    FILE* f = std::fopen(path, "w");
+    if (!f) return fail(GLV_ERR_INVALID, "cannot write wisdom file %s", path);
+    std::fprintf(f, "# glv launch wisdom: n input_kind ops_class log_mode log2(streams) workgroups ms_per_launch\n");
+    std::lock_guard<std::mutex> lock(g_wisdom_mu);
+    for (const WisdomEntry& e : g_wisdom)
+        std::fprintf(f, "%u %u %u %u %u %d %.6f\n", e.k.n, e.k.in_kind, e.k.ops_class, e.k.log_mode, e.k.streams_log2, e.grid, (double) e.ms);
+    std::fclose(f);
+    return GLV_OK;
+}
+
+// Time the candidate workgroup counts for this batch's (size, chain, stream count) on its device and remember the
+// fastest.  The probe launches are real updates of every stream: stateful chains are reset afterwards.
+int glv_batch_autotune(glv_batch* b, const int16_t* d_pcm, float* d_out, unsigned ops, void* hip_stream, int* best_grid, float* best_ms) {
+    if (!b) return fail(GLV_ERR_INVALID, "batch is NULL");
+    if (!(ops & GLV_OP_FFT)) return fail(GLV_ERR_INVALID, "autotune needs GLV_OP_FFT (it tunes the frame kernel)");
+    if (int rc = check_ops(b, ops, d_out)) return rc;
+    if (!d_pcm) return fail(GLV_ERR_INVALID, "NULL device pointer");
+    hipStream_t st = (hipStream_t) hip_stream;
+    HIP_TRY(hipSetDevice(b->device));
+    const uint32_t units = b->streams * 2;
+    const uint32_t slots = (uint32_t) glv::frame_slots(b->log_nn);
+    const uint32_t wgs = (units + slots - 1) / slots;
+    const uint32_t round = (uint32_t) b->num_cus * (uint32_t) glv::frame_resident(b->log_nn);
+    std::vector<int> cand;
+    for (uint32_t g : { round / 2, round, round * 3 / 2, round * 2, round * 4 }) {
+        const int c = (int) (g < 1 ? 1 : (g > wgs ? wgs : g));
+        bool dup = false;
+        for (int x : cand) dup |= x == c;
+        if (!dup) cand.push_back(c);
+    }
+    hipEvent_t e0, e1;
+    HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1));
+    const int saved = b->grid_override;
+    int best = 0; float bms = 0.f; int rc = GLV_OK;
+    for (int pass = 0; pass < 2 && rc == GLV_OK; ++pass)                 // pass 0 warms the clocks up, pass 1 is measured
+        for (int g : cand) {
+            b->grid_override = g;
+            const int iters = pass == 0 ? 3 : 8;
+            if (hipEventRecord(e0, st) != hipSuccess) { rc = fail(GLV_ERR_HIP, "hipEventRecord failed"); break; }
+            for (int i = 0; i < iters && rc == GLV_OK; ++i) rc = process(b, d_pcm, glv::IN_S16_STEREO, d_out, ops, units, 0, st);
+            if (rc != GLV_OK) break;
+            float ms = 0.f;
+            if (hipEventRecord(e1, st) != hipSuccess || hipEventSynchronize(e1) != hipSuccess || hipEventElapsedTime(&ms, e0, e1) != hipSuccess) {
+                rc = fail(GLV_ERR_HIP, "event timing failed"); break;
+            }
+            ms /= (float) iters;
+            if (pass == 1 && (best == 0 || ms < bms)) { best = g; bms = ms; }
+        }
+    b->grid_override = saved;
+    (void) hipEventDestroy(e0); (void) hipEventDestroy(e1);
+    if (rc != GLV_OK) return rc;
+    if (ops & (GLV_OP_GRAVITY | GLV_OP_AVERAGE)) { if (int r2 = glv_batch_reset(b)) return r2; }
+    wisdom_store(WisdomKey{b->p.n, (uint32_t) glv::IN_S16_STEREO, ops_class_of(ops), b->p.log_mode, log2_round(b->streams)}, best, bms);
+    if (best_grid) *best_grid = best;
+    if (best_ms) *best_ms = bms;
+    return GLV_OK;
+}
 
 // tuning hook used by tools/tune.py and bench.py --grid (0 = automatic)
 int glv_batch_set_grid(glv_batch* b, int grid) {

@@ -285,6 +285,19 @@ GLV_HD uint32_t pack_unorm16(float lo, float hi) {
 #endif
 }
 
+// what a shader reads back from a GL_R16 texel: c / 65535 (OpenGL 4.6 eq. 2.1), correctly rounded -- the division sequence
+// of unpack_s16 (checked for all 65536 texel values by tests/test_gl_storage.py)
+GLV_HD float unorm16_to_float(uint32_t c) {
+    const float fv = (float) c;
+    const float rcp = 1.0f / 65535.0f;
+    const float q0 = fv * rcp;
+    const float r = __builtin_fmaf(-q0, 65535.0f, fv);
+    return __builtin_fmaf(r, rcp, q0);
+}
+// a float written to a GL_R16 render target / texture and read back (render.c:523, :1718: every 1-D texture and FBO of
+// the audio passes is GL_R16): clamped to [0, 1] and quantised to 16 bits
+GLV_HD float through_r16(float x) { return unorm16_to_float(unorm16(x)); }
+
 // render.c:730-734
 GLV_HD float gravity(float b, float applied, float g) {
     return (b >= applied ? b : applied) - g;

@@ -52,6 +52,7 @@ struct FrameArgs {
                            // head+1, ..., head+F-1, head  (mod F)
     uint32_t mono;         // fifo.c:98-102
     uint32_t avg_window;
+    uint32_t gl_storage;   // 1: the GL passes' GL_R16 storage is modelled (glv_post_kernel only; see apply_state)
     uint32_t log_mode;     // glv_post_kernel's OP_MAGNITUDE (the frame kernels take it as a template parameter)
     uint32_t rot;          // ring modes (RING kernels): index of the ring's oldest stereo frame = where the window starts
     float inv_n, fft_scale, one_minus_cutoff, g, F_as_float;
@@ -137,7 +138,44 @@ GLV_HD uint32_t ring_slot(uint32_t head, uint32_t f, uint32_t F) {
 // `off` of channel row `row`; n = floats per row.  State traffic is 8 bytes per lane, lanes
 // contiguous.  With both operators the newest ring slot doubles as the gravity state ("applied"
 // of render.c:724 is by construction the previous gravity output, i.e. the previous newest slot).
+//
+// a.gl_storage (glv_params.gl_storage): the GL twin's storage model, render.c:2188-2265 -- every intermediate lives in a
+// GL_R16 texture, so it is clamped to [0, 1] and quantised to 16 bits (through_r16) where a pass writes it: the uploaded
+// buffer (render.c:521-524), the gravity store after GL_MAX and the in-place subtraction (:2199-2228), the ring copy
+// (exact) and the average (:2230-2265, only when avg_frames > 1).  Consequences the float state machine does not have:
+// gravity's fixed point under silence is 0 (not -g), nothing exceeds 1.
 GLV_HD cf apply_state(cf val, uint32_t off, size_t row, uint32_t n, const FrameArgs& a) {
+    if (a.gl_storage) {
+        val.x = through_r16(val.x); val.y = through_r16(val.y);              // the upload
+        const uint32_t F = a.F;
+        const bool ring = (a.ops & OP_AVERAGE) != 0;
+        float* h = ring ? a.hist + row * (size_t) F * n : nullptr;            // uniform
+        if (a.ops & OP_GRAVITY) {
+            float* gs = ring ? h + (size_t) (F == 1 ? a.head : ring_slot(a.head, F - 2, F)) * n : a.grav + row * (size_t) n;
+            const cf st0 = ld<cf>(gs, off);                                   // the store texture == the previous newest ring slot
+            val.x = through_r16(gravity(val.x, st0.x, a.g)); val.y = through_r16(gravity(val.y, st0.y, a.g));
+            if (!ring) st<cf>(gs, off, val);
+        }
+        if (ring) {
+            cf acc = { 0.0f, 0.0f };
+            for (uint32_t f = 0; f + 1 < F; ++f) {                            // oldest .. second newest
+                const cf prev = ld<cf>(h + (size_t) ring_slot(a.head, f, F) * n, off);
+                if (a.avg_window) {
+                    acc.x = (float) ((double) acc.x + a.wts[f] * (double) prev.x);
+                    acc.y = (float) ((double) acc.y + a.wts[f] * (double) prev.y);
+                } else { acc.x = acc.x + prev.x; acc.y = acc.y + prev.y; }
+            }
+            st<cf>(h + (size_t) a.head * n, off, val);
+            if (F > 1) {                                                      // render.c:2230: no averaging pass for one frame
+                if (a.avg_window) {
+                    acc.x = (float) ((double) acc.x + a.wts[F - 1] * (double) val.x);
+                    acc.y = (float) ((double) acc.y + a.wts[F - 1] * (double) val.y);
+                } else { acc.x = acc.x + val.x; acc.y = acc.y + val.y; }
+                val.x = through_r16(acc.x / a.F_as_float); val.y = through_r16(acc.y / a.F_as_float);
+            }
+        }
+        return val;
+    }
     if (a.ops & OP_AVERAGE) {
         float* h = a.hist + row * (size_t) a.F * n;                          // uniform
         const uint32_t F = a.F;
@@ -290,6 +328,17 @@ struct Frame {
     }
     template <bool MONO, int WPRE = 0>
     GLV_HD static void unpack_window_impl(cf (&v)[E], const Raw& p, const void* win, int tid, uint32_t ch_shift, const d2* wpre = nullptr) {
+#if defined(GLV_EXP_NOWINLOAD)        /* tools/tune.py timing experiment: no window loads (wrong results) */
+        {
+            const double w0 = 0.5 + 1e-6 * (double) tid;
+#pragma unroll
+            for (int i = 0; i < E; ++i) {
+                v[i].x = apply_window(sample(p.x[i], ch_shift, MONO), w0 + 1e-3 * i);
+                v[i].y = apply_window(sample(p.y[i], ch_shift, MONO), w0 - 1e-3 * i);
+            }
+            return;
+        }
+#endif
         static_assert(WPRE % WCHUNK == 0 && WPRE <= E, "WPRE: whole chunks");
         d2 w[2][WCHUNK];
         if constexpr (WPRE < E) {
@@ -470,7 +519,11 @@ struct Frame {
             for (int s = 0; s < PI::RB; ++s)
 #pragma unroll
                 for (int ks = 0; ks < (1 << s); ++ks)
+#if defined(GLV_EXP_NOTWLOAD)     /* tools/tune.py timing experiment: no twiddle loads (wrong results) */
+                    { const float f = (float) (k0 + ks) * 1e-4f; tw[gi * (PI::R - 1) + (1 << s) - 1 + ks] = cf{ 1.0f - f, f }; }
+#else
                     tw[gi * (PI::R - 1) + (1 << s) - 1 + ks] = table[SubPass<PI::RB>::tw_index(PI::L0, k0, s, ks) - BIAS];
+#endif
         }
     }
 

@@ -32,7 +32,7 @@ class CParams(C.Structure):
                 ("gravity_step", C.c_float), ("ur", C.c_float), ("avg_frames", C.c_uint32),
                 ("avg_window", C.c_uint32), ("avg_window_kind", C.c_uint32), ("log_mode", C.c_uint32),
                 ("bars", C.c_uint32), ("smooth_factor", C.c_float),
-                ("smooth_distance", C.c_float), ("smooth_ratio", C.c_float)]
+                ("smooth_distance", C.c_float), ("smooth_ratio", C.c_float), ("gl_storage", C.c_uint32)]
 
 
 class MultiStats(C.Structure):
@@ -90,6 +90,9 @@ def lib() -> C.CDLL:
         L.glv_batch_algorithmic_bytes.restype = C.c_uint64
         L.glv_batch_kernel_name.argtypes = [vp]; L.glv_batch_kernel_name.restype = C.c_char_p
         L.glv_batch_set_grid.argtypes = [vp, C.c_int]
+        L.glv_batch_last_grid.argtypes = [vp]
+        L.glv_batch_autotune.argtypes = [vp, vp, vp, C.c_uint, vp, C.POINTER(C.c_int), C.POINTER(C.c_float)]
+        L.glv_wisdom_save.argtypes = [C.c_char_p]; L.glv_wisdom_load.argtypes = [C.c_char_p]
         L.glv_multi_shard_range.argtypes = [C.c_uint64, C.c_int, C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
         L.glv_multi_shard_range.restype = None
         L.glv_multi_create.argtypes = [P, C.c_uint64, C.c_uint, C.POINTER(C.c_int), C.c_int, C.POINTER(vp)]
@@ -123,11 +126,12 @@ class Params:
     smooth_factor: float = 0.025
     smooth_distance: float = 0.01
     smooth_ratio: float = 4.0
+    gl_storage: int = 0
 
     def c(self) -> CParams:
         return CParams(self.n, self.channels, self.fft_scale, self.fft_cutoff, self.gravity_step, self.ur,
                        self.avg_frames, int(self.avg_window), self.avg_window_kind, self.log_mode,
-                       self.bars, self.smooth_factor, self.smooth_distance, self.smooth_ratio)
+                       self.bars, self.smooth_factor, self.smooth_distance, self.smooth_ratio, self.gl_storage)
 
 
 def _ptr(x) -> C.c_void_p:
@@ -195,6 +199,15 @@ class Batch:
 
     def set_grid(self, grid: int) -> None:
         _check(lib().glv_batch_set_grid(self._h, grid))
+
+    def last_grid(self) -> int:
+        return int(lib().glv_batch_last_grid(self._h))
+
+    def autotune(self, d_pcm, d_out, ops: int = OP_FFT, stream: int | None = None) -> tuple[int, float]:
+        """time the candidate workgroup counts on the device, record the winner in the process-wide wisdom"""
+        g, ms = C.c_int(0), C.c_float(0)
+        _check(lib().glv_batch_autotune(self._h, _ptr(d_pcm), _ptr(d_out), ops, _ptr(stream), C.byref(g), C.byref(ms)))
+        return g.value, ms.value
 
     def close(self) -> None:
         if self._h:
@@ -307,6 +320,12 @@ def prelude_lerp(d_start, d_end, d_out, count: int, uratio: float, kcounter: int
                  stream: int | None = None) -> None:
     """render.c:1794-1809 keyframe interpolation on device buffers."""
     _check(lib().glv_prelude_lerp(device, _ptr(d_start), _ptr(d_end), _ptr(d_out), count, uratio, kcounter, _ptr(stream)))
+
+
+def wisdom_save(path: str) -> None: _check(lib().glv_wisdom_save(path.encode()))
+def wisdom_load(path: str) -> None: _check(lib().glv_wisdom_load(path.encode()))
+def wisdom_clear() -> None: lib().glv_wisdom_clear()
+def wisdom_count() -> int: return int(lib().glv_wisdom_count())
 
 
 def device_count() -> int:

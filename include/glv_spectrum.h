@@ -94,6 +94,13 @@ typedef struct glv_params {
     /* GLV_OP_SMOOTH parameters (render.c:917-918, #request setsmooth / setsmoothratio render.c:1201-1206) */
     float smooth_distance;  /* default 0.01 */
     float smooth_ratio;     /* default 4 */
+    uint32_t gl_storage;    /* 0 (default): gravity / average keep float state, like the CPU operators (render.c:720-771).
+                               1: the storage of the GL passes is modelled (render.c:2188-2265 with setaccelfft: every
+                               intermediate is a GL_R16 texture, render.c:523, :1718): the uploaded buffer, the gravity store
+                               after each step and the average are clamped to [0, 1] and quantised to 16 bits; no averaging
+                               pass when avg_frames == 1 (render.c:2230).  Usually combined with avg_window_kind = 1.  The
+                               chain then runs as the reference's does, pass by pass: the frame kernel produces the spectra,
+                               a second kernel applies gravity / average on them. */
 } glv_params;
 
 #define GLV_MAX_AVG_FRAMES 64
@@ -220,6 +227,20 @@ uint64_t glv_batch_algorithmic_bytes(const glv_batch* b, unsigned ops, int input
 
 /* Launch-geometry override for tuning (workgroups of the persistent frame kernel; 0 = automatic). */
 int glv_batch_set_grid(glv_batch* b, int grid);
+int glv_batch_last_grid(const glv_batch* b);      /* workgroups the last frame-kernel launch of this batch used */
+
+/* Launch wisdom -- the role of glfft's FFTWisdom (glfft/glfft_wisdom.cpp:235-446) for this path: the kernel variant per
+ * size is chosen at build time, the number of persistent workgroups per launch at run time, and the best number depends
+ * on the size, the operator chain and the stream count.  glv_batch_autotune times the candidates on the batch's device
+ * with the caller's buffers (real updates: a stateful batch is reset afterwards) and records the winner process-wide;
+ * every later launch with the same description (n, input kind, kernel class of `ops`, log_mode, log2 of the stream count)
+ * uses it.  Save / load carry the table across processes (a text file, one entry per line); the file named by the
+ * environment variable GLV_WISDOM is loaded when the first batch is created. */
+int glv_batch_autotune(glv_batch* b, const int16_t* d_pcm, float* d_out, unsigned ops, void* hip_stream, int* best_grid, float* best_ms);
+int glv_wisdom_save(const char* path);
+int glv_wisdom_load(const char* path);
+int glv_wisdom_clear(void);
+int glv_wisdom_count(void);
 
 /* Name of the kernel the last process call launched (for matching rocprofv3 rows). */
 const char* glv_batch_kernel_name(const glv_batch* b);

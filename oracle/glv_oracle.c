@@ -349,6 +349,38 @@ void glvo_average_gl(float* b, float* hist, size_t* head, size_t sz, size_t F, i
     }
     *head = (*head + 1) % F;
 }
+/* The GL passes with their storage (render.c:2188-2265 when setaccelfft moved gravity / average to the GPU): every
+ * intermediate is a GL_R16 texture (render.c:523 upload, :1718 FBO textures), i.e. clamped to [0, 1] and quantised to 16 bits
+ * wherever a pass writes:  tex = Q(row) (upload);  store = Q(max(store, tex) - g)  (GL_MAX blend :2199-2210, exact on texel
+ * values, then the in-place gravity pass :2219-2228, gravity_pass.frag);  ring[head] = store (pass.frag copy :2232-2243);
+ * row = Q(sum_I window(I) * t_I / F) (average_pass.frag, t_0 = newest) -- only when F > 1 (:2230), else row = store.
+ * store is the previous newest ring slot (the same texels).  Q() as glvo_unorm16 / glvo_unorm16_to_float above.
+ * Restatement (no GL here); the shader arithmetic itself is checked against tests/glsl_eval.py. */
+static float glvo_q16(float x) { return glvo_unorm16_to_float(glvo_unorm16(x)); }
+void glvo_gl_chain_r16(float* row, float* store, float* hist, size_t* head, size_t sz, size_t F, int use_window, int do_average,
+                       float gravity_step, float ur) {
+    const float g = gravity_step * (1.0F / ur);
+    for (size_t t = 0; t < sz; ++t) {
+        float tex = glvo_q16(row[t]);
+        float st = tex >= store[t] ? tex : store[t];
+        st = glvo_q16(st - g);
+        store[t] = st;
+        row[t] = st;
+    }
+    if (!do_average) return;
+    memcpy(hist + (*head) * sz, row, sz * sizeof(float));
+    if (F > 1)
+        for (size_t t = 0; t < sz; ++t) {
+            float v = 0.0F;
+            for (size_t f = 0; f < F; ++f) {
+                size_t slot = (*head + 1 + f) % F;
+                v = (float) ((double) v + glvo_gl_frame_weight(f, F, use_window) * (double) hist[slot * sz + t]);
+            }
+            row[t] = glvo_q16(v / (float) F);
+        }
+    *head = (*head + 1) % F;
+}
+
 /* smooth_audio() (shaders/glava/util/smooth.glsl:13-40, SAMPLE_MODE average, ROUND_FORMULA sinusoidal,
  * SAMPLE_SCALE 8, SAMPLE_RANGE 0.9 -- smooth_parameters.glsl) sampled at the bar positions the radial
  * module uses (radial/1.frag:58-70: pos = k / bars, k = 0..bars-1).  tex[] is clamped to [0,1] as the

@@ -140,6 +140,27 @@ int glvemu_process(int n, int in_mode, const void* in, float* out, float* grav, 
     return log_mode == 0 ? dispatch<0, 4>(log_nn, in_mode, a) : log_mode == 1 ? dispatch<1, 4>(log_nn, in_mode, a) : dispatch<2, 4>(log_nn, in_mode, a);
 }
 
+
+// glv_post_kernel's loop on the host: gravity / average (optionally with the GL_R16 storage model, glv_params.gl_storage)
+// on planar rows through the same apply_state the kernel calls.  Returns 0 on success.
+int glvemu_post_state(const float* in, float* out, float* grav, float* hist, int n, unsigned rows, unsigned ops, unsigned F,
+                      unsigned head, int avg_window, int avg_kind, int gl_storage, float gravity_step, float ur) {
+    if (F == 0 || F > 64) return 3;
+    FrameArgs a;
+    std::memset(&a, 0, sizeof(a));
+    a.in = in; a.out = out; a.grav = grav; a.hist = hist; a.units = rows; a.ops = ops; a.F = F; a.head = head;
+    a.avg_window = avg_window; a.gl_storage = gl_storage; a.g = gravity_step * (1.0f / ur); a.F_as_float = (float) F;
+    make_frame_weights(a.wts, F, avg_window != 0, avg_kind);
+    for (unsigned r = 0; r < rows; ++r)
+        for (int q = 0; q < n / 2; ++q) {
+            const uint32_t off = (uint32_t) q * 8u;
+            cf val = ld<cf>(in + (size_t) r * n, off);
+            val = apply_state(val, off, r, (uint32_t) n, a);
+            st<cf>(out + (size_t) r * n, off, val);
+        }
+    return 0;
+}
+
 }  // extern "C"
 
 // ---- GLV_OP_BARS on the host: the same tables, work lists and chunk arithmetic as the kernels; the

@@ -16,16 +16,14 @@ sys.path.insert(0, ROOT)
 NOL0 = ["-DGLV_TUNE_NO_LOG0"]
 # name, log_nn, extra flags, variant list (glv_tune.hip macros)
 V13 = "VW(1,1,2,false,2,1,2,5,0,0),VW(1,1,2,false,2,1,2,5,0,0)"
-V12 = "VW(2,1,true,true,2,1,true,4,0,0),VW(2,1,true,true,2,1,true,4,0,0)"
-V11 = "VW(2,1,true,true,2,1,true,4,0,0),VW(2,1,true,true,2,1,true,4,0,0)"
-LIBS = [("r2i_n13", 13, NOL0, V13), ("r2i_n12", 12, NOL0, V12), ("r2i_n11", 11, NOL0, V11)]
-RUNS = []
-for rnd in (0, 60, 120, 240):
-    RUNS.append(("r2i_n13", 16384, 0, f"N=16384 skew_round={rnd}", {"GLV_SKEW_ROUND": str(rnd)}))
-for sl in (0, 25, 50, 100):
-    RUNS.append(("r2i_n12", 32768, 0, f"N=8192 skew_slot={sl}", {"GLV_SKEW_SLOT": str(sl)}))
-for rnd, sl in ((0, 0), (40, 0), (0, 20), (40, 20)):
-    RUNS.append(("r2i_n11", 65536, 0, f"N=4096 skew_round={rnd} skew_slot={sl}", {"GLV_SKEW_ROUND": str(rnd), "GLV_SKEW_SLOT": str(sl)}))
+LIBS = [
+    ("r2k_n13", 13, NOL0, V13), ("r2k_n13_notw", 13, NOL0 + ["-DGLV_EXP_NOTWLOAD"], V13), ("r2k_n13_nowin", 13, NOL0 + ["-DGLV_EXP_NOWINLOAD"], V13),
+    ("r2k_n13_neither", 13, NOL0 + ["-DGLV_EXP_NOTWLOAD", "-DGLV_EXP_NOWINLOAD"], V13),
+]
+RUNS = [
+    ("r2k_n13", 16384, 0, "N=16384 full"), ("r2k_n13_notw", 16384, 0, "N=16384 without the twiddle loads (pass 1 from LDS, pass 2 from L2)"),
+    ("r2k_n13_nowin", 16384, 0, "N=16384 without the window loads (L2)"), ("r2k_n13_neither", 16384, 0, "N=16384 without both"),
+]
 
 
 def main():

@@ -15,14 +15,16 @@ sys.path.insert(0, ROOT)
 
 NOL0 = ["-DGLV_TUNE_NO_LOG0"]
 # name, log_nn, extra flags, variant list (glv_tune.hip macros)
-V13 = "VW(1,1,2,false,2,1,2,5,0,0),VW(1,1,2,false,2,1,2,5,0,0)"
 LIBS = [
-    ("r2k_n13", 13, NOL0, V13), ("r2k_n13_notw", 13, NOL0 + ["-DGLV_EXP_NOTWLOAD"], V13), ("r2k_n13_nowin", 13, NOL0 + ["-DGLV_EXP_NOWINLOAD"], V13),
-    ("r2k_n13_neither", 13, NOL0 + ["-DGLV_EXP_NOTWLOAD", "-DGLV_EXP_NOWINLOAD"], V13),
+    ("r2l_n12", 12, NOL0, "VW(2,1,true,true,2,1,true,4,0,0),VW(2,1,true,true,2,2,true,4,0,0),VW(2,1,true,true,2,1,true,4,0,0),VW(2,1,true,true,2,2,true,4,0,0)"),
+    ("r2l_n11", 11, NOL0, "VW(2,1,true,true,2,1,true,4,0,0),VW(2,1,true,true,2,2,true,4,0,0),VW(2,1,true,true,2,1,true,4,0,0),VW(2,1,true,true,2,2,true,4,0,0)"),
+    ("r2l_n13", 13, NOL0, "VW(1,1,2,false,2,1,2,5,0,0),VW(1,1,2,false,2,2,2,5,0,0),VW(1,1,2,false,2,1,2,5,0,0),VW(1,1,2,false,2,2,2,5,0,0)"),
+    ("r2l_n10", 10, NOL0, "VW(2,1,true,true,4,1,true,3,0,0),VW(2,1,true,true,4,2,true,3,0,0),VW(2,1,true,true,4,1,true,3,0,0),VW(2,1,true,true,4,2,true,3,0,0)"),
 ]
 RUNS = [
-    ("r2k_n13", 16384, 0, "N=16384 full"), ("r2k_n13_notw", 16384, 0, "N=16384 without the twiddle loads (pass 1 from LDS, pass 2 from L2)"),
-    ("r2k_n13_nowin", 16384, 0, "N=16384 without the window loads (L2)"), ("r2k_n13_neither", 16384, 0, "N=16384 without both"),
+    ("r2l_n12", 32768, 0, "N=8192: pf=1 (store the row, then unpack) vs pf=2 (fused: stores spread over both phases)"),
+    ("r2l_n11", 65536, 0, "N=4096"), ("r2l_n13", 16384, 0, "N=16384"), ("r2l_n10", 131072, 0, "N=2048"),
+    ("r2l_n11", 65536, 256, "N=4096 -> R16"),
 ]
 
 

@@ -22,7 +22,8 @@
 /* one handle per (bind, transform) slot, stored where the reference keeps its own state
    (gl->t_data[c], render.c:2140-2156).  rd_destroy free()s every slot, so the slot holds a small
    malloc'd box; the device state behind it is released by glv_hip_release first. */
-struct glv_box { glv_state* st; };
+struct glv_box { unsigned long long magic; glv_state* st; };
+#define GLV_BOX_MAGIC 0x676c765f626f7821ULL   /* "glv_box!": tells a box from a slot the stock operators filled (float state) */
 
 static unsigned glv_hip_log_mode = 1;      /* glv_params.log_mode for new boxes (tests flip it) */
 
@@ -51,6 +52,7 @@ static glv_state* glv_hip_slot(struct gl_data* d, void** udata, size_t sz) {
     if (!b) {                                  /* lazily, like ALLOC_ONCE (render.c:662-666) */
         glv_params p; glv_hip_fill(d, sz, &p);
         b = calloc(1, sizeof(*b));
+        b->magic = GLV_BOX_MAGIC;
         if (glv_state_create(&p, /*device*/ 0, &b->st) != GLV_OK) {
             fprintf(stderr, "glv: %s\n", glv_last_error());
             glava_abort();                     /* the reference's error convention (glava.h:17) */
@@ -74,8 +76,10 @@ GLV_HIP_OPERATOR(transform_average_hip, glv_average)
 GLV_HIP_OPERATOR(transform_wrange_hip,  glv_wrange)
 GLV_HIP_OPERATOR(transform_fga_hip,     glv_fft_gravity_average)
 
-/* rd_destroy hook: release the device state of a *_hip slot; the box itself is free()d by rd_destroy */
+/* rd_destroy hook: release the device state of a *_hip slot; the box itself is free()d by rd_destroy.  Slots that the
+   stock operators filled (parameters the library does not take fall back to them) hold the reference's own float state --
+   at least sz >= 2 floats -- and are left alone. */
 void glv_hip_release(void* slot) {
     struct glv_box* b = slot;
-    if (b && b->st) { glv_state_destroy(b->st); b->st = NULL; }
+    if (b && b->magic == GLV_BOX_MAGIC && b->st) { glv_state_destroy(b->st); b->st = NULL; }
 }

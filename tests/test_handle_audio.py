@@ -174,6 +174,22 @@ def test_prelude_interpolation_pins_the_oracle():
             kcounter += 1
 
 
+@pytest.mark.parametrize("n,F", [(128, 5), (1024, 70), (65536, 3)])
+def test_patched_build_leaves_unsupported_parameters_to_the_stock_operators(n, F):
+    """a host that runs on the reference must not be terminated by the shim.  A window outside [256, 32768]
+    (setbufsize is unchecked) or more averaging frames than the library takes stay on the reference's own CPU operators
+    inside the patched build -- no device is touched, so this runs everywhere -- and the uploads equal the unpatched build's
+    bit for bit.  (Windows that are not a power of two are routed the same way, but cannot be exercised: the reference's own
+    transform_fft writes out of bounds for them -- `free(): invalid next size` at n = 1000.)"""
+    R, H = load(REF_SO), load(HIP_SO)
+    frames = pcm_frames(n, 4, 2024)
+    modified = [True, True, False, True]
+    want, _ = run(R, cfg(n, avg_frames=F), frames, modified)
+    got, _ = run(H, cfg(n, avg_frames=F), frames, modified)
+    for f in range(4):
+        assert (bits(got[f]) == bits(want[f])).all(), f
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("accel,interp,k", [(0, 0, 1), (1, 0, 1), (0, 1, 1), (0, 0, 2)])
 def test_patched_handle_audio_uploads_what_the_reference_uploads(glvlib, accel, interp, k):

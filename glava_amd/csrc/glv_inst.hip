@@ -20,12 +20,12 @@ template <int LOG_NN> struct Tuned;
 GLV_TUNED(7,       3,    16,   1,   true,  true,  4,  1,       true,   0,   0,   2)    // N=256    E=8:  3+3+1 (16 lanes per row; not tuned: coverage of setbufsize 256)
 GLV_TUNED(8,       3,    16,   1,   true,  true,  4,  1,       true,   0,   0,   2)    // N=512    E=8:  3+3+2
 GLV_TUNED(9,       3,    4,    1,   true,  true,  4,  1,       true,   0,   0,   2)    // N=1024   E=8:  3+3+3
-GLV_TUNED(10,      3,    2,    1,   true,  true,  4,  1,       true,   0,   0,   2)    // N=2048   E=8:  3+3+3+1
+GLV_TUNED(10,      4,    4,    1,   true,  true,  2,  1,       true,   0,   0,   2)    // N=2048   E=16: 4+4+3, four 128-lane rows (r02 sweep_13: 0.627 vs 0.668 ms for E=8)
 GLV_TUNED(11,      4,    2,    1,   true,  true,  2,  1,       true,   0,   0,   2)    // N=4096   E=16: 4+4+3
 GLV_TUNED(12,      4,    2,    1,   true,  true,  2,  1,       true,   0,   0,   1)    // N=8192   E=16: 4+4+4; two slots share the 64 KiB LDS window
 GLV_TUNED(13,      5,    1,    1,   2,     false, 2,  1,       2,      0,   0,   2)    // N=16384  E=32: 5+5+3; pass-1 twiddles from an 8 KiB LDS table, tilt computed
                                                                                   //          (WPRE, the window prefetch ahead of the stores, measured no gain: profiles/r02)
-GLV_TUNED(14,      5,    1,    1,   0,     false, 2,  1,       2,      0,   0,   1)    // N=32768  E=32: 5+5+4, one 512-lane row per CU (135 KiB exchange region); not tuned: coverage
+GLV_TUNED(14,      5,    1,    1,   2,     false, 2,  1,       2,      0,   0,   1)    // N=32768  E=32: 5+5+4, one 512-lane row per CU (135 KiB exchange region), pass-1 twiddles from LDS (sweep_13)
 #undef GLV_TUNED
 
 #define GLV_CAT2(a, b) a##b

@@ -6,7 +6,7 @@ mkdir -p $O
 timeout 2400 python -m pytest tests -x -q -m gpu > $O/pytest_gpu.txt 2>&1
 grep -E "passed|failed|error" $O/pytest_gpu.txt | tail -2
 python bench.py > $O/bench_line.json 2> $O/bench.err
-TRAFFIC_ARGS="--traffic-json $O/hbm_traffic.json --n 4096 --streams 65536 --ops fft --kernel 4,_0,_0>" bash tools/profile.sh r02 --no-alt > /dev/null 2>&1
+TRAFFIC_ARGS="--traffic-json $O/hbm_traffic.json --n 4096 --streams 65536 --ops fft --kernel glv_frame_kernel<11,~0,~1,~2,~1,~1,~true,~2,~1,~1,~4,~0,~0>" bash tools/profile.sh r02 --no-alt > /dev/null 2>&1
 bash tools/profile.sh r02_n8192 --n 8192 --streams 32768 --no-alt > /dev/null 2>&1
 bash tools/profile.sh r02_n16384 --n 16384 --streams 16384 --no-alt > /dev/null 2>&1
 python tools/configs_bench.py --out $O/configs.txt > /dev/null 2> $O/configs.err

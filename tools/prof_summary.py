@@ -64,6 +64,6 @@ if __name__ == "__main__":
     ap.add_argument("--n", type=int, default=4096)
     ap.add_argument("--streams", type=int, default=65536)
     ap.add_argument("--ops", default="fft")
-    ap.add_argument("--kernel", default="")
+    ap.add_argument("--kernel", default="", help="substring of the demangled kernel name; ~ stands for a space (shell-friendly)")
     a = ap.parse_args()
-    main(a.dir, {"out": a.traffic_json, "n": a.n, "streams": a.streams, "ops": a.ops, "kernel": a.kernel} if a.traffic_json else None)
+    main(a.dir, {"out": a.traffic_json, "n": a.n, "streams": a.streams, "ops": a.ops, "kernel": a.kernel.replace("~", " ")} if a.traffic_json else None)

@@ -16,15 +16,15 @@ sys.path.insert(0, ROOT)
 NOL0 = ["-DGLV_TUNE_NO_LOG0"]
 # name, log_nn, extra flags, variant list (glv_tune.hip macros)
 LIBS = [
-    ("r2l_n12", 12, NOL0, "VW(2,1,true,true,2,1,true,4,0,0),VW(2,1,true,true,2,2,true,4,0,0),VW(2,1,true,true,2,1,true,4,0,0),VW(2,1,true,true,2,2,true,4,0,0)"),
-    ("r2l_n11", 11, NOL0, "VW(2,1,true,true,2,1,true,4,0,0),VW(2,1,true,true,2,2,true,4,0,0),VW(2,1,true,true,2,1,true,4,0,0),VW(2,1,true,true,2,2,true,4,0,0)"),
-    ("r2l_n13", 13, NOL0, "VW(1,1,2,false,2,1,2,5,0,0),VW(1,1,2,false,2,2,2,5,0,0),VW(1,1,2,false,2,1,2,5,0,0),VW(1,1,2,false,2,2,2,5,0,0)"),
-    ("r2l_n10", 10, NOL0, "VW(2,1,true,true,4,1,true,3,0,0),VW(2,1,true,true,4,2,true,3,0,0),VW(2,1,true,true,4,1,true,3,0,0),VW(2,1,true,true,4,2,true,3,0,0)"),
+    ("r2n_n9", 9, NOL0, "VW(4,1,true,true,4,1,true,3,0,0),VW(4,1,true,true,2,1,true,4,0,0),VW(8,1,true,true,2,1,true,4,0,0),VW(8,1,true,true,4,1,true,3,0,0),VW(4,1,true,true,4,1,true,3,0,0)"),
+    ("r2n_n8", 8, NOL0, "VW(16,1,true,true,4,1,true,3,0,0),VW(8,1,true,true,2,1,true,4,0,0),VW(16,1,true,true,2,1,true,4,0,0),VW(16,1,true,true,4,1,true,3,0,0)"),
+    ("r2n_n10", 10, NOL0, "VW(4,1,true,true,2,1,true,4,0,0),VW(8,1,true,true,2,1,true,4,0,0),VW(4,1,true,true,2,1,true,4,1,1),VW(4,1,true,true,2,1,true,4,0,0)"),
 ]
 RUNS = [
-    ("r2l_n12", 32768, 0, "N=8192: pf=1 (store the row, then unpack) vs pf=2 (fused: stores spread over both phases)"),
-    ("r2l_n11", 65536, 0, "N=4096"), ("r2l_n13", 16384, 0, "N=16384"), ("r2l_n10", 131072, 0, "N=2048"),
-    ("r2l_n11", 65536, 256, "N=4096 -> R16"),
+    ("r2n_n9", 262144, 0, "N=1024 knobs (E=8 vs E=16)"),
+    ("r2n_n8", 524288, 0, "N=512 knobs"),
+    ("r2n_n10", 131072, 0, "N=2048 E=16: 4 vs 8 slots, window prefetch"),
+    ("r2n_n10", 131072, 96, "N=2048 E=16 stateful"),
 ]
 
 

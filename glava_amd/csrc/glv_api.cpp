@@ -222,8 +222,17 @@ struct glv_batch {
 
 struct glv_state {
     glv_batch* b = nullptr;      // a one-row batch (one channel of one stream)
-    float* d_io = nullptr;       // n floats staging
-    uint16_t* d_tex = nullptr;   // n GL_R16 texels (glv_texels_r16)
+    // Staging of the host-pointer drop-ins: one pinned, device-mapped host block.  The kernel reads the n input floats
+    // straight out of it over PCIe and writes its n results (or n GL_R16 texels) straight back, so a call is one launch
+    // and one stream synchronisation -- no hipMemcpy in either direction (2 x 16 KB at the default size: the copies'
+    // fixed cost, not their bandwidth, was what a call spent its time on).  GLV_STAGING=copy selects the device
+    // buffer + two hipMemcpyAsync of round 1 (kept for A/B in tests/test_gpu_parity.py::test_single_stream_dropin_latency).
+    float* h_io = nullptr;       // host view
+    float* d_io = nullptr;       // device view of h_io (mapped), or a device buffer when copy staging is selected
+    uint16_t* h_tex = nullptr;
+    uint16_t* d_tex = nullptr;
+    float* d_seq = nullptr;      // device buffer for GLV_OP_SMOOTH: its kernel walks a row element by element, which must not happen over PCIe
+    bool mapped = true;
 };
 
 namespace {
@@ -810,8 +819,16 @@ int glv_state_create(const glv_params* p, int device, glv_state** out) {
     if (!s) return fail(GLV_ERR_NOMEM, "out of host memory");
     int rc = batch_create_rows(p, 1, GLV_OP_GRAVITY | GLV_OP_AVERAGE, device, true, &s->b);
     if (rc == GLV_OK) {
-        hipError_t e = hipMalloc(&s->d_io, sizeof(float) * p->n);
-        if (e != hipSuccess) rc = fail(GLV_ERR_HIP, "hipMalloc failed: %s", hipGetErrorString(e));
+        const char* mode = std::getenv("GLV_STAGING");
+        s->mapped = !(mode && std::strcmp(mode, "copy") == 0);
+        hipError_t e;
+        if (s->mapped) {
+            e = hipHostMalloc(reinterpret_cast<void**>(&s->h_io), sizeof(float) * p->n, hipHostMallocMapped);
+            if (e == hipSuccess) e = hipHostGetDevicePointer(reinterpret_cast<void**>(&s->d_io), s->h_io, 0);
+        } else {
+            e = hipMalloc(&s->d_io, sizeof(float) * p->n);
+        }
+        if (e != hipSuccess) rc = fail(GLV_ERR_HIP, "staging allocation failed: %s", hipGetErrorString(e));
     }
     if (rc != GLV_OK) { glv_state_destroy(s); return rc; }
     *out = s;
@@ -832,8 +849,14 @@ int glv_state_reset(glv_state* s) {
 int glv_state_destroy(glv_state* s) {
     if (!s) return GLV_OK;
     if (s->b) { (void) hipSetDevice(s->b->device); glv_batch_destroy(s->b); }
-    if (s->d_io) (void) hipFree(s->d_io);
-    if (s->d_tex) (void) hipFree(s->d_tex);
+    if (s->d_seq) (void) hipFree(s->d_seq);
+    if (s->mapped) {
+        if (s->h_io) (void) hipHostFree(s->h_io);
+        if (s->h_tex) (void) hipHostFree(s->h_tex);
+    } else {
+        if (s->d_io) (void) hipFree(s->d_io);
+        if (s->d_tex) (void) hipFree(s->d_tex);
+    }
     delete s;
     return GLV_OK;
 }
@@ -848,6 +871,22 @@ static int single(const glv_params* p, glv_state* s, float* buf, unsigned ops) {
     b->p = *p;   // scalar knobs may change between calls, exactly like gl_data fields
     HIP_TRY(hipSetDevice(b->device));
     const size_t bytes = sizeof(float) * p->n;
+    if (s->mapped && (ops & GLV_OP_SMOOTH)) {
+        if (!s->d_seq) HIP_TRY(hipMalloc(&s->d_seq, bytes));
+        HIP_TRY(hipMemcpyAsync(s->d_seq, buf, bytes, hipMemcpyHostToDevice, nullptr));
+        if (int rc = process(b, s->d_seq, glv::IN_F32_PLANAR, s->d_seq, ops, 1, 0, nullptr)) return rc;
+        HIP_TRY(hipMemcpyAsync(buf, s->d_seq, bytes, hipMemcpyDeviceToHost, nullptr));
+        HIP_TRY(hipStreamSynchronize(nullptr));
+        return GLV_OK;
+    }
+    if (s->mapped) {
+        std::memcpy(s->h_io, buf, bytes);
+        const int rc = process(b, s->d_io, glv::IN_F32_PLANAR, s->d_io, ops, 1, 0, nullptr);
+        HIP_TRY(hipStreamSynchronize(nullptr));        // also after a failed launch: nothing may still be reading h_io
+        if (rc) return rc;
+        std::memcpy(buf, s->h_io, bytes);
+        return GLV_OK;
+    }
     HIP_TRY(hipMemcpyAsync(s->d_io, buf, bytes, hipMemcpyHostToDevice, nullptr));
     if (int rc = process(b, s->d_io, glv::IN_F32_PLANAR, s->d_io, ops, 1, 0, nullptr)) return rc;
     HIP_TRY(hipMemcpyAsync(buf, s->d_io, bytes, hipMemcpyDeviceToHost, nullptr));
@@ -871,6 +910,18 @@ int glv_texels_r16(const glv_params* p, glv_state* s, const float* buf, uint16_t
     glv_batch* b = s->b;
     if (p->n != b->p.n) return fail(GLV_ERR_STATE, "params n=%u does not match the state (n=%u)", p->n, b->p.n);
     HIP_TRY(hipSetDevice(b->device));
+    if (s->mapped) {
+        if (!s->h_tex) {
+            HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&s->h_tex), sizeof(uint16_t) * p->n, hipHostMallocMapped));
+            HIP_TRY(hipHostGetDevicePointer(reinterpret_cast<void**>(&s->d_tex), s->h_tex, 0));
+        }
+        std::memcpy(s->h_io, buf, sizeof(float) * p->n);
+        const int rc = process(b, s->d_io, glv::IN_F32_PLANAR, reinterpret_cast<float*>(s->d_tex), GLV_OP_R16, 1, 0, nullptr);
+        HIP_TRY(hipStreamSynchronize(nullptr));
+        if (rc) return rc;
+        std::memcpy(texels, s->h_tex, sizeof(uint16_t) * p->n);
+        return GLV_OK;
+    }
     if (!s->d_tex) HIP_TRY(hipMalloc(&s->d_tex, sizeof(uint16_t) * p->n));
     HIP_TRY(hipMemcpyAsync(s->d_io, buf, sizeof(float) * p->n, hipMemcpyHostToDevice, nullptr));
     if (int rc = process(b, s->d_io, glv::IN_F32_PLANAR, reinterpret_cast<float*>(s->d_tex), GLV_OP_R16, 1, 0, nullptr)) return rc;

@@ -416,6 +416,44 @@ def test_full_size_64k_streams_properties(G, log_mode):
     b.close()
 
 
+def test_buffers_beyond_4_GiB(G):
+    """Addressing past 2^32 bytes: 196 608 streams at N=4096 (PCM 3 GiB, spectra 6 GiB, gravity state 6 GiB) and
+    24 576 streams at N=32768 (spectra 6 GiB).  Rows behind the 4 GiB mark against the oracle, duplicates planted
+    on both sides of it, nothing left unwritten; then a gravity update on the same batch size (state rows behind
+    the mark are read and written)."""
+    import torch
+    for n, streams, ops_list in [(4096, 196608, ["fft", "grav"]), (32768, 24576, ["fft"])]:
+        g = torch.Generator(device="cuda"); g.manual_seed(4242 + n)
+        d_pcm = torch.randint(-32768, 32768, (streams, n * 2), dtype=torch.int16, device="cuda", generator=g)
+        dup = [5, streams // 2 + 3, streams - 1, streams - 4097]
+        for s_ in dup[1:]:
+            d_pcm[s_] = d_pcm[5]
+        subset = np.unique(np.concatenate([np.random.default_rng(3).integers(streams * 2 // 3, streams, 24), [0, streams - 1, streams - 2]]))
+        idx = torch.from_numpy(subset).cuda()
+        rows = torch.stack([2 * idx, 2 * idx + 1], dim=1).reshape(-1)
+        pcm_sub = d_pcm[idx].cpu().numpy()
+        for kind in ops_list:
+            ops = G.OP_FFT if kind == "fft" else G.OP_FFT | G.OP_GRAVITY
+            d_out = torch.full((streams * 2, n), float("nan"), dtype=torch.float32, device="cuda")
+            assert d_out.numel() * 4 > (1 << 32)
+            b = G.Batch(G.Params(n=n), streams, ops)
+            sos = [StreamOracle(n, gravity=kind == "grav", average=False) for _ in subset]
+            for upd in range(2 if kind == "grav" else 1):
+                b.process_s16(d_pcm, d_out, ops)
+                torch.cuda.synchronize()
+                got = d_out[rows].cpu().numpy().reshape(subset.size, 2, n)
+                for i in range(subset.size):
+                    want = sos[i].frame(pcm_sub[i])
+                    assert np.allclose(got[i], want, rtol=REL, atol=2e-6), (n, kind, upd, int(subset[i]))
+            assert not torch.isnan(d_out).any().item()
+            for s_ in dup[1:]:
+                assert torch.equal(d_out[2 * s_:2 * s_ + 2].view(torch.int32), d_out[10:12].view(torch.int32)), (n, kind, s_)
+            b.close()
+            del d_out
+        del d_pcm
+        torch.cuda.empty_cache()
+
+
 def test_full_size_stateful_chain_subset(G):
     """configs[1] size with the chain GLava's modules request (fft -> gravity -> average, F=5): three
     updates of 65536 streams, a random subset of streams against the stateful oracle every update."""
@@ -445,22 +483,35 @@ def test_full_size_stateful_chain_subset(G):
 
 
 def test_single_stream_dropin_latency(G):
-    """The host-pointer drop-ins must comfortably hold GLava's real-time rate (86 updates/s => 11.6 ms
-    per update for both channels; render.c:1674): fused fft+gravity+average per channel buffer."""
+    """The host-pointer drop-ins (the transform_* seam) must keep up with GLava's update rate with a wide margin:
+    one stereo update = two glv_fft_gravity_average calls; 22050 Hz / 256 frames per update = 11.6 ms between
+    updates.  Both stagings (mapped pinned host block, the default; device buffer + two copies, GLV_STAGING=copy)
+    must give the same bits."""
     import time
     p = G.Params(n=4096)
-    st = [G.State(p), G.State(p)]
     buf = [(lcg_pcm_fast(1 + c, 4096).astype(np.float32) / np.float32(65535)) for c in range(2)]
-    for _ in range(5):
-        for c in range(2): st[c].fft_gravity_average(buf[c].copy())
-    t0 = time.perf_counter()
-    reps = 50
-    for _ in range(reps):
-        for c in range(2): st[c].fft_gravity_average(buf[c].copy())
-    per_update = (time.perf_counter() - t0) / reps
-    for s in st: s.close()
-    print(f"single-stream stereo update through the host-pointer drop-ins: {per_update * 1e6:.0f} us")
-    assert per_update < 11.6e-3 / 4
+    res, per_update = {}, {}
+    for mode in ("copy", "mapped"):
+        if mode == "copy": os.environ["GLV_STAGING"] = "copy"
+        else: os.environ.pop("GLV_STAGING", None)
+        st = [G.State(p), G.State(p)]
+        os.environ.pop("GLV_STAGING", None)
+        outs = []
+        for _ in range(5):
+            outs = [buf[c].copy() for c in range(2)]
+            for c in range(2): st[c].fft_gravity_average(outs[c])
+        res[mode] = [bits(o) for o in outs]
+        t0 = time.perf_counter()
+        reps = 50
+        for _ in range(reps):
+            for c in range(2): st[c].fft_gravity_average(buf[c].copy())
+        per_update[mode] = (time.perf_counter() - t0) / reps
+        for s_ in st: s_.close()
+    print("single-stream stereo update through the host-pointer drop-ins: "
+          f"{per_update['mapped'] * 1e6:.0f} us (mapped staging), {per_update['copy'] * 1e6:.0f} us (copy staging)")
+    for c in range(2):
+        assert np.array_equal(res["copy"][c], res["mapped"][c])
+    assert per_update["mapped"] < 11.6e-3 / 4
 
 
 @pytest.mark.parametrize("log_mode,bar", [(0, 0.0), (1, 1e-6)])

@@ -15,7 +15,7 @@ import os
 import numpy as np
 import pytest
 
-from oracle_lib import Oracle, StreamOracle, lcg_pcm_fast
+from oracle_lib import Oracle, Ref, RefStream, StreamOracle, lcg_pcm_fast
 
 pytestmark = pytest.mark.gpu
 
@@ -414,6 +414,41 @@ def test_full_size_64k_streams_properties(G, log_mode):
     if log_mode == 0:                    # strict: bit-identical but for rare fp64 last-ulp ties
         assert nbad <= 1e-4 * subset.size * 2 * n, nbad
     b.close()
+
+
+@pytest.mark.parametrize("n,F,win", [(256, 5, True), (1024, 5, True), (2048, 6, False), (4096, 5, True), (8192, 3, True),
+                                     (16384, 5, True), (32768, 2, False)])
+def test_against_the_compiled_reference_itself(G, n, F, win):
+    """No restatement in between: the batched HIP path against oracle/_ref/libglvref.so -- the reference's own
+    render.c compiled by oracle/Makefile, which travels to the GPU box as a built file -- on the same s16 PCM, seven
+    updates of fft -> gravity -> average for 6 streams.  log_mode 0: identical bits, no tolerance;
+    log_mode 1: north_star's 1e-5 (+ the floor gravity's subtraction needs)."""
+    import torch
+    if not os.path.exists(Ref.PATH):
+        pytest.skip("oracle/_ref/libglvref.so was not built (needs /root/reference at build time)")
+    streams, frames = 6, 7
+    ops = G.OP_FFT | G.OP_GRAVITY | G.OP_AVERAGE
+    for log_mode in (0, 1):
+        rp = Ref.params(avg_frames=F, avg_window=win)
+        refs = [RefStream(rp) for _ in range(streams)]
+        b = G.Batch(G.Params(n=n, avg_frames=F, avg_window=int(win), log_mode=log_mode), streams, ops)
+        d_out = torch.empty((streams * 2, n), dtype=torch.float32, device="cuda")
+        for fr in range(frames):
+            pcm = np.stack([lcg_pcm_fast(977 * n + 31 * s_ + fr, 2 * n) for s_ in range(streams)])
+            if fr == 3: pcm[1] = 0                                   # a silent update (zero-fill, fifo.c:67-79)
+            if fr == 4: pcm[2] = np.where(np.arange(2 * n) % 2 == 0, 32767, -32768)   # full scale
+            b.process_s16(torch.from_numpy(pcm).cuda(), d_out, ops)
+            torch.cuda.synchronize()
+            got = d_out.cpu().numpy().reshape(streams, 2, n)
+            for s_ in range(streams):
+                f = pcm[s_].astype(np.float32) / np.float32(65535)    # fifo.c:105-106 (pinned exhaustively elsewhere)
+                want = refs[s_].frame_from_float(f[0::2], f[1::2])
+                if log_mode == 0:
+                    assert np.array_equal(bits(got[s_]), bits(want)), (n, fr, s_, int((bits(got[s_]) != bits(want)).sum()))
+                else:
+                    assert np.allclose(got[s_], want, rtol=REL, atol=2e-6), (n, fr, s_)
+        b.close()
+        for r_ in refs: r_.close()
 
 
 def test_buffers_beyond_4_GiB(G):

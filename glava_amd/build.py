@@ -69,6 +69,22 @@ def build_tune_variant(name: str, extra_flags: list[str], variants: str | None =
     return lib
 
 
+def build_variant(name: str, extra_flags: list[str], sizes=SIZES) -> str:
+    """A/B copy of the product library, glava_amd/csrc/libglvspectrum_<name>.so, compiled with extra flags
+    (experiment macros); loaded instead of the product with GLV_SPECTRUM_LIB=<path> (tools/ab_bench.sh)."""
+    obj_dir = os.path.join(OBJ, name)
+    os.makedirs(obj_dir, exist_ok=True)
+    jobs = [("glv_inst.hip", os.path.join(obj_dir, f"glv_inst_{k}.o"), [f"-DGLV_LOG_NN={k}", *extra_flags]) for k in SIZES]
+    jobs.append(("glv_misc.hip", os.path.join(obj_dir, "glv_misc.o"), list(extra_flags)))
+    jobs.append(("glv_api.cpp", os.path.join(obj_dir, "glv_api.o"), ["-x", "hip", *extra_flags]))
+    jobs.append(("glv_multi.cpp", os.path.join(obj_dir, "glv_multi.o"), ["-x", "hip", *extra_flags]))
+    with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 2)) as ex:
+        objs = list(ex.map(lambda j: _compile(*j), jobs))
+    lib = os.path.join(CSRC, f"libglvspectrum_{name}.so")
+    _run([_hipcc(), "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", lib, *objs])
+    return lib
+
+
 def build(tune: bool = False, verbose: bool = False) -> str:
     os.makedirs(OBJ, exist_ok=True)
     jobs = [("glv_inst.hip", os.path.join(OBJ, f"glv_inst_{k}.o"), [f"-DGLV_LOG_NN={k}"]) for k in SIZES]
@@ -96,5 +112,9 @@ def build(tune: bool = False, verbose: bool = False) -> str:
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--tune", action="store_true")
+    ap.add_argument("--variant", nargs="+", metavar=("NAME", "FLAG"), help="build libglvspectrum_NAME.so with extra flags; write them without the leading dash (DGLV_X=1)")
     a = ap.parse_args()
-    build(tune=a.tune, verbose=True)
+    if a.variant:
+        print("built", build_variant(a.variant[0], ["-" + f.lstrip("-") for f in a.variant[1:]]))
+    else:
+        build(tune=a.tune, verbose=True)

@@ -15,7 +15,8 @@ import os
 from dataclasses import dataclass
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "csrc", "libglvspectrum.so")
+# GLV_SPECTRUM_LIB: an A/B build of the SAME library (glava_amd.build --variant, tools/ab_bench.sh); never a fallback
+LIB_PATH = os.environ.get("GLV_SPECTRUM_LIB") or os.path.join(HERE, "csrc", "libglvspectrum.so")
 
 OP_FFT, OP_GRAVITY, OP_AVERAGE, OP_RAW, OP_WRANGE, OP_BARS, OP_SMOOTH, OP_MAGNITUDE, OP_R16 = 1, 2, 4, 8, 16, 32, 64, 128, 256
 OK, ERR_INVALID, ERR_NO_DEVICE, ERR_HIP, ERR_NOMEM, ERR_STATE = 0, 1, 2, 3, 4, 5

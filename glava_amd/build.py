@@ -74,7 +74,7 @@ def build_variant(name: str, extra_flags: list[str], sizes=SIZES) -> str:
     (experiment macros); loaded instead of the product with GLV_SPECTRUM_LIB=<path> (tools/ab_bench.sh)."""
     obj_dir = os.path.join(OBJ, name)
     os.makedirs(obj_dir, exist_ok=True)
-    jobs = [("glv_inst.hip", os.path.join(obj_dir, f"glv_inst_{k}.o"), [f"-DGLV_LOG_NN={k}", *extra_flags]) for k in SIZES]
+    jobs = [("glv_inst.hip", os.path.join(obj_dir, f"glv_inst_{k}.o"), [f"-DGLV_LOG_NN={k}", *extra_flags]) for k in sizes]
     jobs.append(("glv_misc.hip", os.path.join(obj_dir, "glv_misc.o"), list(extra_flags)))
     jobs.append(("glv_api.cpp", os.path.join(obj_dir, "glv_api.o"), ["-x", "hip", *extra_flags]))
     jobs.append(("glv_multi.cpp", os.path.join(obj_dir, "glv_multi.o"), ["-x", "hip", *extra_flags]))

@@ -82,8 +82,12 @@ struct BarTaps { float t[4], w[4]; };
 GLV_HD uint32_t bar_item_tex(const BarItem& it) { return it.pack & 0x7fffu; }
 GLV_HD uint32_t bar_item_bar(const BarItem& it) { return (it.pack >> 15) & 0x7fffu; }
 GLV_HD bool bar_item_last(const BarItem& it) { return ((it.pack >> 30) & 1u) != 0; }
-// sub = lane index within the group (0..15); n = floats per row (reads past the row are clamped into it:
-// their weights are zero)
+// sub = lane index within the group (0..15); n = floats per row.  A chunk may reach up to 63 floats past the row:
+// those taps have zero weights.  CLAMP: such reads are redirected to the row's last float (row in HBM: the next row, or
+// nothing, follows).  !CLAMP (row in LDS): they read the slack behind the row -- whatever is there is clamped to
+// [0, 1] (NaN -> 0) by bar_item_lane_sum before it meets its zero weight, so it adds exactly 0 either way, and the
+// address is one lane offset + compile-time constants.
+template <bool CLAMP = true>
 GLV_HD BarTaps bar_item_load(const float* tex_row, uint32_t n, const float* tap_w, const BarItem& it, int sub) {
     BarTaps s;
     const float* w = tap_w + it.w_off;
@@ -91,9 +95,14 @@ GLV_HD BarTaps bar_item_load(const float* tex_row, uint32_t n, const float* tap_
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const uint32_t idx = (uint32_t) sub + 16u * (uint32_t) i;
+#if defined(GLV_EXP_BARS_NOWLOAD)     /* A/B experiment only (glava_amd.build build_variant): no weight loads, wrong bars */
+        s.w[i] = 1.0f; (void) w;
+#else
         s.w[i] = w[idx];
+#endif
         const uint32_t q = base + idx;
-        s.t[i] = tex_row[q < n ? q : n - 1];
+        if constexpr (CLAMP) s.t[i] = tex_row[q < n ? q : n - 1];
+        else s.t[i] = tex_row[q];
     }
     return s;
 }

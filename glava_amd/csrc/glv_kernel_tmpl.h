@@ -330,6 +330,7 @@ glv_frame_kernel(const FrameArgs a) {
             constexpr uint32_t G = T / 16;
             float* lrow = reinterpret_cast<float*>(xslot);
             float* lres = lrow + N;                                       // XREGION has NN/E points (2T floats) of slack
+            static_assert(2 * T >= 64, "the chunk reads of bar_item_load<false> stay inside the slot's region");
             if (active) {
                 const int sub = tid & 15;
                 const uint32_t g = (uint32_t) tid >> 4;
@@ -338,11 +339,15 @@ glv_frame_kernel(const FrameArgs a) {
 #pragma unroll
                 for (int b = 0; b < kBarBatch; ++b) it[b] = items[(size_t) b * G];
                 float total = 0.0f;
+#if defined(GLV_EXP_BARS_NOLOOP)      /* A/B experiment only: the row goes to LDS, the barriers stay, no bar is summed */
+                for (uint32_t s0 = 0; s0 < 0u; s0 += kBarBatch) {
+#else
                 for (uint32_t s0 = 0; s0 < a.bar_nsteps; s0 += kBarBatch) {
+#endif
                     BarTaps tp[kBarBatch];
                     BarItem nx[kBarBatch];
 #pragma unroll
-                    for (int b = 0; b < kBarBatch; ++b) tp[b] = bar_item_load(lrow, (uint32_t) N, a.bar_w, it[b], sub);
+                    for (int b = 0; b < kBarBatch; ++b) tp[b] = bar_item_load<false>(lrow, (uint32_t) N, a.bar_w, it[b], sub);   // slack: 2T >= 63 floats
 #pragma unroll
                     for (int b = 0; b < kBarBatch; ++b) nx[b] = items[(size_t) (s0 + kBarBatch + b) * G];   // table has one batch of padding
 #pragma unroll

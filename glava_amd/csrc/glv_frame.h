@@ -220,7 +220,12 @@ GLV_HD cf apply_state(cf val, uint32_t off, size_t row, uint32_t n, const FrameA
 // NV loads are issued back to back before any of them is consumed, so a lane keeps NV (not 1) HBM
 // requests in flight.  (The one-value form above is load -> wait -> use per slot and per value: fine
 // for glv_post_kernel's one-pair-per-lane grid, latency-bound inside the frame kernel's epilogue.)
-template <int NV>
+// GLV_STATE_PAIR_MAX: largest log2(nn) whose stateful epilogue requests two history frames per trip (PAIR below);
+// N=8192 spills 8-12 VGPRs for it and still gains (profiles/r02/ab_pair.txt), N=16384 would spill 50-60
+#ifndef GLV_STATE_PAIR_MAX
+#define GLV_STATE_PAIR_MAX 12
+#endif
+template <int NV, bool PAIR = false>
 GLV_HD void apply_state_block(cf (&val)[NV], const uint32_t (&off)[NV], size_t row, uint32_t n, const FrameArgs& a) {
     if (a.ops & OP_AVERAGE) {
         float* h = a.hist + row * (size_t) a.F * n;                          // uniform
@@ -232,7 +237,33 @@ GLV_HD void apply_state_block(cf (&val)[NV], const uint32_t (&off)[NV], size_t r
 #pragma unroll
             for (int e = 0; e < NV; ++e) prev[e] = ld<cf>(h + (size_t) a.head * n, off[e]);
         }
-        for (uint32_t f = 0; f + 1 < F; ++f) {                               // oldest .. second newest
+        // oldest .. second newest, two history frames per trip (PAIR): their 2 NV loads are in flight
+        // together -- the epilogue is a chain of dependent HBM round trips (F - 1 per block), halving their number is
+        // worth more than the NV extra registers; the accumulation order (render.c:757-760) is unchanged
+        uint32_t f = 0;
+        if constexpr (PAIR) for (; f + 2 < F; f += 2) {
+            const float* hs0 = h + (size_t) ring_slot(a.head, f, F) * n;         // uniform
+            const float* hs1 = h + (size_t) ring_slot(a.head, f + 1, F) * n;     // uniform
+            cf p0[NV];
+#pragma unroll
+            for (int e = 0; e < NV; ++e) p0[e] = ld<cf>(hs0, off[e]);
+#pragma unroll
+            for (int e = 0; e < NV; ++e) prev[e] = ld<cf>(hs1, off[e]);
+            const double w0 = a.wts[f], w1 = a.wts[f + 1];
+#pragma unroll
+            for (int e = 0; e < NV; ++e) {
+                if (a.avg_window) {                                          // render.c:759, double product
+                    acc[e].x = (float) ((double) acc[e].x + w0 * (double) p0[e].x);
+                    acc[e].y = (float) ((double) acc[e].y + w0 * (double) p0[e].y);
+                    acc[e].x = (float) ((double) acc[e].x + w1 * (double) prev[e].x);
+                    acc[e].y = (float) ((double) acc[e].y + w1 * (double) prev[e].y);
+                } else {
+                    acc[e].x = acc[e].x + p0[e].x; acc[e].y = acc[e].y + p0[e].y;
+                    acc[e].x = acc[e].x + prev[e].x; acc[e].y = acc[e].y + prev[e].y;
+                }
+            }
+        }
+        for (; f + 1 < F; ++f) {
             const float* hs = h + (size_t) ring_slot(a.head, f, F) * n;      // uniform
 #pragma unroll
             for (int e = 0; e < NV; ++e) prev[e] = ld<cf>(hs, off[e]);
@@ -818,7 +849,7 @@ struct Frame {
                         off[j] = (uint32_t) out_index<P - 1>(tid, gi, r) * 8u;
                     }
                 }
-                apply_state_block<BLK>(val, off, row, (uint32_t) N, a);
+                apply_state_block<BLK, (LOG_NN <= GLV_STATE_PAIR_MAX)>(val, off, row, (uint32_t) N, a);
                 if (out_row == nullptr) continue;                     // uniform: output aliased to the gravity state
 #pragma unroll
                 for (int j = 0; j < BLK; ++j) {

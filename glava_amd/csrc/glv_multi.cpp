@@ -51,7 +51,7 @@ struct Rccl {
             handle = dlopen(name, RTLD_NOW | RTLD_LOCAL);
             if (handle) break;
         }
-        if (!handle) { why = dlerror() ? dlerror() : "dlopen(librccl) failed"; return false; }
+        if (!handle) { const char* e = dlerror(); why = e ? e : "dlopen(librccl) failed"; return false; }   // dlerror() clears itself: read once
 #define GLV_SYM(field, sym) field = reinterpret_cast<decltype(field)>(dlsym(handle, sym)); if (!field) { why = "librccl lacks " sym; return false; }
         GLV_SYM(CommInitAll, "ncclCommInitAll")
         GLV_SYM(CommDestroy, "ncclCommDestroy")
@@ -100,6 +100,7 @@ extern "C" {
 
 void glv_multi_shard_range(uint64_t total_streams, int rank, int world, uint64_t* first, uint64_t* count) {
     // contiguous, balanced: the first (total % world) ranks take one extra stream (== glava_amd/sharding.py shard_range)
+    if (world < 1 || rank < 0 || rank >= world) { if (first) *first = 0; if (count) *count = 0; return; }
     const uint64_t base = total_streams / (uint64_t) world, extra = total_streams % (uint64_t) world;
     const uint64_t r = (uint64_t) rank;
     const uint64_t lo = r * base + (r < extra ? r : extra);
@@ -230,6 +231,7 @@ int glv_multi_run_s16(glv_multi* m, const int16_t* const* d_pcm, float* const* d
             hipMemcpyAsync(&maxs[i], m->d_secs[i] + 1, sizeof(double), hipMemcpyDeviceToHost, st) != hipSuccess ||
             hipStreamSynchronize(st) != hipSuccess)
             note(GLV_ERR_HIP, "stats download failed");
+        (void) hipStreamSynchronize(st);     // nothing may still read `mine` / `secs` (this frame) once the worker returns
         rcs[i] = rc;
     };
     std::vector<std::thread> th;

@@ -52,6 +52,7 @@ static glv_state* glv_hip_slot(struct gl_data* d, void** udata, size_t sz) {
     if (!b) {                                  /* lazily, like ALLOC_ONCE (render.c:662-666) */
         glv_params p; glv_hip_fill(d, sz, &p);
         b = calloc(1, sizeof(*b));
+        if (!b) { fprintf(stderr, "glv: out of memory\n"); glava_abort(); }
         b->magic = GLV_BOX_MAGIC;
         if (glv_state_create(&p, /*device*/ 0, &b->st) != GLV_OK) {
             fprintf(stderr, "glv: %s\n", glv_last_error());

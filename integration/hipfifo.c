@@ -67,6 +67,7 @@ static void* entry(void* data) {
     struct pollfd pfd = { .fd = fd, .events = POLLIN };
     int16_t* buf = malloc(ssz);
     float* spec = malloc(2 * n * sizeof(float));
+    if (!buf || !spec) { fprintf(stderr, "hipfifo backend: out of memory\n"); exit(EXIT_FAILURE); }
     int timeout_ms = 50;                                               /* initial value of fifo.c:39 */
     struct timespec tv_last = { 0, 0 }, tv;
     int measured = 0;

@@ -233,16 +233,18 @@ template <typename V> GLV_HD void st(void* base, uint32_t byte_off, const V& v) 
 
 // ---- scalar pieces ----------------------------------------------------------------------------
 // fifo.c:105-106: (float) s16 / (float) 65535, IEEE single division.
-// Evaluated as one correctly-rounded-by-construction sequence: q0 = v*rcp; r = fma(-q0, 65535, v);
-// q = fma(r, rcp, q0).  tests/test_host_logic.py checks all 65536 inputs against the division on
-// the CPU, tests/test_gpu_parity.py does the same on the device.
-GLV_HD float unpack_s16(int v) {
-    const float fv = (float) v;
-    const float rcp = 1.0f / 65535.0f;            // constant-folded, correctly rounded
-    const float q0 = fv * rcp;
-    const float r = __builtin_fmaf(-q0, 65535.0f, fv);
-    return __builtin_fmaf(r, rcp, q0);
+// Evaluated without a divide: 1/65535 = c_hi + c_lo + (< 2^-48 relative), c_hi = 0x1.0001p-16, c_lo = 0x1.0001p-48, and
+//     q = fma(v, c_hi, v * c_lo)
+// is within 2^-47 (relative) of v/65535 before its one rounding, while v/65535 (|v| <= 65535) is never closer than
+// 2^-40 to a float rounding boundary (65535 x is an integer, a boundary times 65535 is an odd multiple of a power of
+// two) -- so q IS the correctly rounded quotient: two instructions per sample instead of the three of the
+// Newton-style sequence of round 1.  tests/test_host_logic.py checks all 65536 inputs against the division on the
+// CPU, tests/test_gpu_parity.py does the same on the device; tests/test_gl_storage.py the 65536 texel values.
+GLV_HD float div_65535(float fv) {
+    const float c_hi = 0x1.0001p-16f, c_lo = 0x1.0001p-48f;
+    return __builtin_fmaf(fv, c_hi, fv * c_lo);
 }
+GLV_HD float unpack_s16(int v) { return div_65535((float) v); }
 // fifo.c:98-102 mono mix: C int arithmetic, truncation toward zero.
 GLV_HD float unpack_s16_mono(int l, int r) { return unpack_s16((l + r) / 2); }
 
@@ -285,15 +287,9 @@ GLV_HD uint32_t pack_unorm16(float lo, float hi) {
 #endif
 }
 
-// what a shader reads back from a GL_R16 texel: c / 65535 (OpenGL 4.6 eq. 2.1), correctly rounded -- the division sequence
-// of unpack_s16 (checked for all 65536 texel values by tests/test_gl_storage.py)
-GLV_HD float unorm16_to_float(uint32_t c) {
-    const float fv = (float) c;
-    const float rcp = 1.0f / 65535.0f;
-    const float q0 = fv * rcp;
-    const float r = __builtin_fmaf(-q0, 65535.0f, fv);
-    return __builtin_fmaf(r, rcp, q0);
-}
+// what a shader reads back from a GL_R16 texel: c / 65535 (OpenGL 4.6 eq. 2.1), correctly rounded -- div_65535
+// (checked for all 65536 texel values by tests/test_gl_storage.py)
+GLV_HD float unorm16_to_float(uint32_t c) { return div_65535((float) c); }
 // a float written to a GL_R16 render target / texture and read back (render.c:523, :1718: every 1-D texture and FBO of
 // the audio passes is GL_R16): clamped to [0, 1] and quantised to 16 bits
 GLV_HD float through_r16(float x) { return unorm16_to_float(unorm16(x)); }

@@ -238,8 +238,8 @@ template <typename V> GLV_HD void st(void* base, uint32_t byte_off, const V& v) 
 // is within 2^-47 (relative) of v/65535 before its one rounding, while v/65535 (|v| <= 65535) is never closer than
 // 2^-40 to a float rounding boundary (65535 x is an integer, a boundary times 65535 is an odd multiple of a power of
 // two) -- so q IS the correctly rounded quotient: two instructions per sample instead of the three of the
-// Newton-style sequence of round 1.  tests/test_host_logic.py checks all 65536 inputs against the division on the
-// CPU, tests/test_gpu_parity.py does the same on the device; tests/test_gl_storage.py the 65536 texel values.
+// Newton-style sequence of round 1.  tests/test_emulator.py checks every integer argument against the division
+// on the CPU, tests/test_gpu_parity.py the 65536 sample values on the device, tests/test_gl_storage.py the 65536 texels.
 GLV_HD float div_65535(float fv) {
     const float c_hi = 0x1.0001p-16f, c_lo = 0x1.0001p-48f;
     return __builtin_fmaf(fv, c_hi, fv * c_lo);

@@ -179,6 +179,13 @@ float group16_sum_host(const float (&lane)[16]) {
 }  // namespace
 
 extern "C" {
+// glv_core.h div_65535 (the s16 unpack and the GL_R16 texel readback) for every integer in [lo, hi]
+void glvemu_div_65535(int lo, int hi, float* out) {
+    for (int v = lo; v <= hi; ++v) out[v - lo] = glv::div_65535((float) v);
+}
+}
+
+extern "C" {
 // bars of `nrows` rows of n floats through work lists for `groups` 16-lane groups.  steps_out (may be NULL)
 // receives the step count; returns 0 on success.
 int glvemu_bars(const float* spec, size_t nrows, int n, int bars, float smooth_factor, int groups, float* out, unsigned* steps_out) {

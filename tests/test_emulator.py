@@ -198,3 +198,16 @@ def test_bars_emulator_vs_restatement(emu, oracle, n):
     for groups in (1, 4, 8, 32):
         got, _ = emu_bars(emu, spec, n, bars, groups=groups)
         assert (bits(got) == bits(got16)).all(), groups
+
+
+def test_division_by_65535_is_correctly_rounded_for_every_integer_argument(emu):
+    """glv_core.h div_65535 -- fma(v, c_hi, v * c_lo) -- against the IEEE single division of fifo.c:105-106 for every
+    integer |v| <= 65535: the 65536 s16 sample values (unpack) and the 65536 GL_R16 texel values (readback)."""
+    import ctypes as C
+    lo, hi = -65535, 65535
+    out = np.empty(hi - lo + 1, dtype=np.float32)
+    emu.glvemu_div_65535.argtypes = [C.c_int, C.c_int, np.ctypeslib.ndpointer(np.float32, flags="C_CONTIGUOUS")]
+    emu.glvemu_div_65535.restype = None
+    emu.glvemu_div_65535(lo, hi, out)
+    want = np.arange(lo, hi + 1, dtype=np.float32) / np.float32(65535)
+    assert np.array_equal(out.view(np.uint32), want.view(np.uint32))

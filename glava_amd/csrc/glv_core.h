@@ -317,7 +317,7 @@ template <int LOG_MODE> GLV_HD float log_third(float y, const LogEntry* tab);
 #endif
 
 // log table: for j = 0..255, c_j = 1 + j/256 (the value of the top eight mantissa bits),
-// tab[j] = { 1/c_j, log(c_j)/3 } rounded to double.  Generated on the host by glv::make_log_table
+// tab[j] = { 2^-23/c_j, log(c_j)/3 } rounded to double.  Generated on the host by glv::make_log_table
 // (glv_tables.h); the kernel stages it into LDS (random 16-byte gathers are what LDS is good at).
 constexpr int kLogTabSize = 256;
 struct alignas(16) LogEntry { double inv_c, log_c3; };
@@ -345,9 +345,10 @@ GLV_HD float log_third_table(float y, const LogEntry* tab) {
     const uint32_t u = __builtin_bit_cast(uint32_t, y);
     const int e = (int) (u >> 23) - 127;
     const LogEntry t = ld<LogEntry>(tab, (u >> 11) & 0xff0u);                       // j * 16 bytes
-    const float m = __builtin_bit_cast(float, (u & 0x007fffffu) | 0x3f800000u);
-    const float c = __builtin_bit_cast(float, (u & 0x007f8000u) | 0x3f800000u);
-    const double r = (double) (m - c) * t.inv_c;       // m - c is exact (same exponent, c <= m)
+    // r = (m - c) / c with m - c = k * 2^-23, k = the low 15 mantissa bits: the table carries 2^-23 / c_j, so r is one
+    // exact integer conversion and one product (scaling by a power of two commutes with the rounding: the same bits
+    // as (double) (m - c) * (1 / c_j), two instructions fewer)
+    const double r = (double) (u & 0x7fffu) * t.inv_c;
     double p = -1.0 / 18.0;
     p = GLV_FMA_SC(p, r, 1.0 / 15.0);
     p = GLV_FMA_SC(p, r, -1.0 / 12.0);

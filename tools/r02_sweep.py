@@ -16,15 +16,18 @@ sys.path.insert(0, ROOT)
 NOL0 = ["-DGLV_TUNE_NO_LOG0"]
 # name, log_nn, extra flags, variant list (glv_tune.hip macros)
 LIBS = [
-    ("r2n_n9", 9, NOL0, "VW(4,1,true,true,4,1,true,3,0,0),VW(4,1,true,true,2,1,true,4,0,0),VW(8,1,true,true,2,1,true,4,0,0),VW(8,1,true,true,4,1,true,3,0,0),VW(4,1,true,true,4,1,true,3,0,0)"),
-    ("r2n_n8", 8, NOL0, "VW(16,1,true,true,4,1,true,3,0,0),VW(8,1,true,true,2,1,true,4,0,0),VW(16,1,true,true,2,1,true,4,0,0),VW(16,1,true,true,4,1,true,3,0,0)"),
-    ("r2n_n10", 10, NOL0, "VW(4,1,true,true,2,1,true,4,0,0),VW(8,1,true,true,2,1,true,4,0,0),VW(4,1,true,true,2,1,true,4,1,1),VW(4,1,true,true,2,1,true,4,0,0)"),
+    ("r2p_n13_nf1", 13, NOL0 + ["-DGLV_TILT_NF=1"], "VW(1,1,2,false,2,1,2,5,0,0)"),
+    ("r2p_n13_nf0", 13, NOL0 + ["-DGLV_TILT_NF=0"], "VW(1,1,2,false,2,1,2,5,0,0)"),
+    ("r2p_n14_nf1", 14, NOL0 + ["-DGLV_TILT_NF=1"], "VW(1,1,2,false,2,1,2,5,0,0)"),
+    ("r2p_n14_nf0", 14, NOL0 + ["-DGLV_TILT_NF=0"], "VW(1,1,2,false,2,1,2,5,0,0)"),
 ]
 RUNS = [
-    ("r2n_n9", 262144, 0, "N=1024 knobs (E=8 vs E=16)"),
-    ("r2n_n8", 524288, 0, "N=512 knobs"),
-    ("r2n_n10", 131072, 0, "N=2048 E=16: 4 vs 8 slots, window prefetch"),
-    ("r2n_n10", 131072, 96, "N=2048 E=16 stateful"),
+    ("r2p_n13_nf1", 16384, 0, "N=16384 tilt from the float index"),
+    ("r2p_n13_nf0", 16384, 0, "N=16384 tilt from the integer index (round 1)"),
+    ("r2p_n13_nf1", 16384, 0, "N=16384 tilt from the float index (again)"),
+    ("r2p_n13_nf0", 16384, 0, "N=16384 tilt from the integer index (again)"),
+    ("r2p_n14_nf1", 8192, 0, "N=32768 float index"),
+    ("r2p_n14_nf0", 8192, 0, "N=32768 integer index"),
 ]
 
 

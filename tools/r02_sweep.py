@@ -16,18 +16,16 @@ sys.path.insert(0, ROOT)
 NOL0 = ["-DGLV_TUNE_NO_LOG0"]
 # name, log_nn, extra flags, variant list (glv_tune.hip macros)
 LIBS = [
-    ("r2p_n13_nf1", 13, NOL0 + ["-DGLV_TILT_NF=1"], "VW(1,1,2,false,2,1,2,5,0,0)"),
-    ("r2p_n13_nf0", 13, NOL0 + ["-DGLV_TILT_NF=0"], "VW(1,1,2,false,2,1,2,5,0,0)"),
-    ("r2p_n14_nf1", 14, NOL0 + ["-DGLV_TILT_NF=1"], "VW(1,1,2,false,2,1,2,5,0,0)"),
-    ("r2p_n14_nf0", 14, NOL0 + ["-DGLV_TILT_NF=0"], "VW(1,1,2,false,2,1,2,5,0,0)"),
+    ("r2q_n13_f1", 13, NOL0 + ["-DGLV_FUSE_LAST=1"], "VW(1,1,2,false,2,1,2,5,0,0)"),
+    ("r2q_n13_f0", 13, NOL0 + ["-DGLV_FUSE_LAST=0"], "VW(1,1,2,false,2,1,2,5,0,0)"),
 ]
 RUNS = [
-    ("r2p_n13_nf1", 16384, 0, "N=16384 tilt from the float index"),
-    ("r2p_n13_nf0", 16384, 0, "N=16384 tilt from the integer index (round 1)"),
-    ("r2p_n13_nf1", 16384, 0, "N=16384 tilt from the float index (again)"),
-    ("r2p_n13_nf0", 16384, 0, "N=16384 tilt from the integer index (again)"),
-    ("r2p_n14_nf1", 8192, 0, "N=32768 float index"),
-    ("r2p_n14_nf0", 8192, 0, "N=32768 integer index"),
+    ("r2q_n13_f1", 16384, 0, "N=16384 last pass in halves around the stores"),
+    ("r2q_n13_f0", 16384, 0, "N=16384 last pass, then the stores"),
+    ("r2q_n13_f1", 16384, 0, "N=16384 last pass in halves around the stores (again)"),
+    ("r2q_n13_f0", 16384, 0, "N=16384 last pass, then the stores (again)"),
+    ("r2q_n13_f1", 8192, 0, "N=16384, 8192 streams, halves"),
+    ("r2q_n13_f0", 8192, 0, "N=16384, 8192 streams, whole"),
 ]
 
 

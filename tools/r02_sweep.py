@@ -16,16 +16,12 @@ sys.path.insert(0, ROOT)
 NOL0 = ["-DGLV_TUNE_NO_LOG0"]
 # name, log_nn, extra flags, variant list (glv_tune.hip macros)
 LIBS = [
-    ("r2q_n13_f1", 13, NOL0 + ["-DGLV_FUSE_LAST=1"], "VW(1,1,2,false,2,1,2,5,0,0)"),
-    ("r2q_n13_f0", 13, NOL0 + ["-DGLV_FUSE_LAST=0"], "VW(1,1,2,false,2,1,2,5,0,0)"),
+    ("r2r_n12", 12, NOL0, "VW(2,1,true,true,2,1,1,4,0,0),VW(2,1,true,true,2,1,2,4,0,0),VW(2,1,true,true,2,1,0,4,0,0),VW(2,1,true,true,2,1,1,4,0,0)"),
+    ("r2r_n11", 11, NOL0, "VW(2,1,true,true,2,1,1,4,0,0),VW(2,1,true,true,2,1,2,4,0,0),VW(2,1,true,true,2,1,1,4,0,0)"),
 ]
 RUNS = [
-    ("r2q_n13_f1", 16384, 0, "N=16384 last pass in halves around the stores"),
-    ("r2q_n13_f0", 16384, 0, "N=16384 last pass, then the stores"),
-    ("r2q_n13_f1", 16384, 0, "N=16384 last pass in halves around the stores (again)"),
-    ("r2q_n13_f0", 16384, 0, "N=16384 last pass, then the stores (again)"),
-    ("r2q_n13_f1", 8192, 0, "N=16384, 8192 streams, halves"),
-    ("r2q_n13_f0", 8192, 0, "N=16384, 8192 streams, whole"),
+    ("r2r_n12", 32768, 0, "N=8192: tilt resident (1) / evaluated (2) / from the L2 table (0)"),
+    ("r2r_n11", 65536, 0, "N=4096: tilt resident (1) / evaluated (2)"),
 ]
 
 

@@ -205,6 +205,8 @@ struct glv_batch {
     int* d_smin = nullptr;       // transform_smooth window bounds (host generated)
     int* d_smax = nullptr;
     uint32_t smooth_asz = 0;
+    uint32_t smooth_reach = 0;   // floats of a row the walk touches: max smax + 1 (>= asz)
+    uint32_t smooth_window = 0;  // largest smax - smin + 1; also covers smax - t and t - smin (the ring kernel's slot reuse)
     float smooth_d = -1.f, smooth_r = -1.f;
     glv::BarDesc* d_bar_desc = nullptr;   // GLV_OP_BARS tap tables (host generated)
     float* d_bar_w = nullptr;
@@ -299,6 +301,16 @@ int ensure_smooth_tables(glv_batch* b) {
     if (!b->d_smin) { HIP_TRY(hipMalloc(&b->d_smin, sizeof(int) * n)); HIP_TRY(hipMalloc(&b->d_smax, sizeof(int) * n)); }
     HIP_TRY(hipMemcpy(b->d_smin, lo.data(), sizeof(int) * asz, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(b->d_smax, hi.data(), sizeof(int) * asz, hipMemcpyHostToDevice));
+    size_t reach = asz;
+    long window = 1;
+    for (size_t t = 0; t < asz; ++t) {
+        if ((size_t) hi[t] + 1 > reach) reach = (size_t) hi[t] + 1;
+        // the span the ring must keep around step t: from the first tap (or t itself) to the last tap (or t itself)
+        const long a = lo[t] < (long) t ? lo[t] : (long) t, z = hi[t] > (long) t ? hi[t] : (long) t;
+        if (z - a + 1 > window) window = z - a + 1;
+    }
+    b->smooth_window = (uint32_t) window;
+    b->smooth_reach = (uint32_t) (reach < n ? reach : n);
     b->smooth_asz = (uint32_t) asz; b->smooth_d = b->p.smooth_distance; b->smooth_r = b->p.smooth_ratio;
     return GLV_OK;
 }
@@ -465,7 +477,7 @@ int process(glv_batch* b, const void* d_in, int in_mode, float* d_out, unsigned 
     if (ops & GLV_OP_AVERAGE) b->head = (b->head + 1) % b->p.avg_frames;
     if (ops & GLV_OP_SMOOTH) {                     // render.c:694-718, in place on the finished rows
         if (int rc = ensure_smooth_tables(b)) return rc;
-        e = glv::launch_smooth(d_out, units, b->p.n, b->d_smin, b->d_smax, b->smooth_asz, st);
+        e = glv::launch_smooth(d_out, units, b->p.n, b->d_smin, b->d_smax, b->smooth_asz, b->smooth_reach, b->smooth_window, st);
         if (e != hipSuccess) return fail(GLV_ERR_HIP, "smooth launch failed: %s", hipGetErrorString(e));
     }
     if ((ops & GLV_OP_BARS) && !fused_bars) {

@@ -26,7 +26,8 @@ int frame_rounds(int log_nn);     // rounds of resident workgroups a large launc
 hipError_t launch_post(const FrameArgs& a, uint32_t n, hipStream_t st);
 hipError_t launch_bufscale(const float* in, float* out, size_t total_out, uint32_t k, hipStream_t st);
 hipError_t launch_lerp(const float* s0, const float* e0, float* out, size_t total, float mod, hipStream_t st);
-hipError_t launch_smooth(float* rows, size_t nrows, uint32_t n, const int* smin, const int* smax, uint32_t asz, hipStream_t st);
+hipError_t launch_smooth(float* rows, size_t nrows, uint32_t n, const int* smin, const int* smax, uint32_t asz, uint32_t reach,
+                         uint32_t max_window, hipStream_t st);
 hipError_t launch_bars(const float* spec, float* bars_out, size_t nrows, uint32_t n, uint32_t bars, uint32_t nsteps,
                        const BarItem* items, const BarDesc* desc, const float* tap_w, hipStream_t st);
 hipError_t launch_unpack(const int16_t* pcm, size_t frames, int mono, float* l, float* r, hipStream_t st);

@@ -74,20 +74,168 @@ __global__ void __launch_bounds__(256) glv_lerp_kernel(const float* __restrict__
 // In place and sequentially dependent inside a row (output t reads inputs that earlier outputs already
 // replaced), so one lane walks one row; rows are independent.  smin/smax depend only on t and come from
 // the host (powf/log/floor/ceil of the reference's libm, glv_tables.h).
+//
+// The walk only ever touches the first `reach` floats of a row (reach = max smax + 1, about 1.01 n / smooth_ratio) and
+// writes the first `asz`.  A workgroup (one wave) therefore stages that prefix of R rows in LDS with coalesced loads --
+// row j at float offset j * stride, stride odd, so the 64 lanes' accesses to the same index of their own rows fall in
+// different banks --, lanes 0..R-1 walk their rows there (every tap an LDS read instead of a strided global one: round 2
+// measured 29 ms for 131 072 rows of N=4096 with the walk in global memory, every lane on its own cache line), and the
+// first asz floats of each row go back coalesced.  R = as many rows as fit the workgroup's LDS (host: launch_smooth).
 __global__ void __launch_bounds__(64) glv_smooth_kernel(float* __restrict__ rows, size_t nrows, uint32_t n,
-                                                        const int* __restrict__ smin, const int* __restrict__ smax, uint32_t asz) {
-    const size_t r = (size_t) blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= nrows) return;
-    float* b = rows + r * n;
-    for (uint32_t t = 0; t < asz; ++t) {
-        float avg = 0.0f;
-        int count = 0;
-        for (int q = smin[t]; q <= smax[t]; ++q) {
-            const float x = b[q];
-            if (x != 0.0f) { avg = avg + x; ++count; }     // `if (b[s])`: NaN counts, +-0 does not
+                                                        const int* __restrict__ smin, const int* __restrict__ smax, uint32_t asz,
+                                                        uint32_t reach, uint32_t rows_per_wg) {
+    extern __shared__ float smooth_lds[];
+    const uint32_t stride = reach | 1u;
+    const uint32_t lane = threadIdx.x;
+    const size_t row0 = (size_t) blockIdx.x * rows_per_wg;
+    if (row0 >= nrows) return;
+    const uint32_t R = (uint32_t) (nrows - row0 < rows_per_wg ? nrows - row0 : rows_per_wg);
+    // staging: eight loads of a lane in flight before the first is parked in LDS (one at a time, every 256-byte piece
+    // of a row was its own exposed HBM round trip)
+    for (uint32_t j = 0; j < R; ++j) {
+        const float* src = rows + (row0 + j) * n;
+        float* dst = smooth_lds + (size_t) j * stride;
+        for (uint32_t i0 = lane; i0 < reach; i0 += 64 * 8) {
+            float tmp[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) tmp[k] = i0 + 64u * k < reach ? src[i0 + 64u * k] : 0.0f;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) if (i0 + 64u * k < reach) dst[i0 + 64u * k] = tmp[k];
         }
-        b[t] = avg / (float) count;                        // 0/0 = NaN at t = 0, as in the reference
     }
+    __syncthreads();
+    if (lane < R) {
+        float* b = smooth_lds + (size_t) lane * stride;
+        // the bounds of eight steps are fetched together (uniform: scalar loads) -- one memory round trip per eight
+        // outputs instead of two per output, which is what a step of the first LDS version waited for
+        for (uint32_t t0 = 0; t0 < asz; t0 += 8) {
+            int lo[8], hi[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const uint32_t t = t0 + k < asz ? t0 + k : asz - 1;
+                lo[k] = smin[t]; hi[k] = smax[t];
+            }
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                if (t0 + k >= asz) break;
+                float avg = 0.0f;
+                int count = 0;
+                const int q1 = hi[k];
+                // eight taps per trip, read together; taps past smax read as 0, which the reference's `if (b[s])` skips anyway
+                for (int q0 = lo[k]; q0 <= q1; q0 += 8) {
+                    float x[8];
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) x[i] = q0 + i <= q1 ? b[q0 + i] : 0.0f;
+#pragma unroll
+                    for (int i = 0; i < 8; ++i)
+                        if (x[i] != 0.0f) { avg = avg + x[i]; ++count; }   // `if (b[s])`: NaN counts, +-0 does not
+                }
+                b[t0 + k] = avg / (float) count;                    // 0/0 = NaN at t = 0, as in the reference
+            }
+        }
+    }
+    __syncthreads();
+    for (uint32_t j = 0; j < R; ++j) {
+        float* dst = rows + (row0 + j) * n;
+        const float* src = smooth_lds + (size_t) j * stride;
+        for (uint32_t i = lane; i < asz; i += 64) dst[i] = src[i];
+    }
+}
+
+// The same walk for many rows at once: a wave takes 64 rows, one per lane, and keeps only a sliding window of each in LDS
+// -- a ring of W floats per lane (position q lives in slot q mod W; lane stride W + 1, odd: the lanes' accesses to the
+// same slot of their own rows hit different banks).  Inputs enter in chunks of kSmoothChunk positions (coalesced: half a
+// wave reads one row's chunk), finished outputs leave in chunks of the same size, the walk in between reads and writes
+// LDS only.  W >= (largest window) + 2 chunks: a slot is reused for position p + W only after p has left every later
+// window (smin is monotone) and, being a finished output, has been written back.  33 KiB of LDS per wave at W = 128
+// (the defaults at N=4096: largest window 23 taps) instead of one 4 KiB row prefix per lane: 4 waves = 256 rows in
+// flight per CU against 30, which is what a latency-bound dependent walk needs.
+constexpr uint32_t kSmoothChunk = 32;
+template <uint32_t W>
+__global__ void __launch_bounds__(64) glv_smooth_ring_kernel(float* __restrict__ rows, size_t nrows, uint32_t n,
+                                                             const int* __restrict__ smin, const int* __restrict__ smax, uint32_t asz,
+                                                             uint32_t reach) {
+    extern __shared__ float smooth_lds[];
+    constexpr uint32_t LS = W + 1;                         // lane stride (floats)
+    constexpr uint32_t CH = kSmoothChunk;
+    const uint32_t lane = threadIdx.x;
+    const size_t row0 = (size_t) blockIdx.x * 64;
+    if (row0 >= nrows) return;
+    const uint32_t R = (uint32_t) (nrows - row0 < 64 ? nrows - row0 : 64);
+    const uint32_t sub = lane & (CH - 1), half = lane / CH;           // two rows per load / store instruction
+    uint32_t loaded = 0, written = 0;
+    // positions [c0, c1) (c1 - c0 <= CH) of every row: HBM -> ring, eight row pairs in flight
+    auto load_chunk = [&](uint32_t c0, uint32_t c1) {
+        const uint32_t pos = c0 + sub;
+        for (uint32_t j0 = 0; j0 < R; j0 += 16) {
+            float tmp[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const uint32_t j = j0 + 2u * k + half;
+                tmp[k] = (j < R && pos < c1) ? rows[(row0 + j) * n + pos] : 0.0f;
+            }
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const uint32_t j = j0 + 2u * k + half;
+                if (j < R && pos < c1) smooth_lds[j * LS + (pos & (W - 1))] = tmp[k];
+            }
+        }
+    };
+    // finished outputs [c0, c1) of every row: ring -> HBM
+    auto store_chunk = [&](uint32_t c0, uint32_t c1) {
+        const uint32_t pos = c0 + sub;
+        for (uint32_t j0 = 0; j0 < R; j0 += 2) {
+            const uint32_t j = j0 + half;
+            if (j < R && pos < c1) rows[(row0 + j) * n + pos] = smooth_lds[j * LS + (pos & (W - 1))];
+        }
+    };
+    auto wave_sync = [&]() {                               // the workgroup is one wave: LDS is in order, the compiler must be too
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    };
+    float* b = smooth_lds + (size_t) lane * LS;
+    for (uint32_t t0 = 0; t0 < asz; t0 += 8) {
+        int lo[8], hi[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const uint32_t t = t0 + k < asz ? t0 + k : asz - 1;
+            lo[k] = smin[t]; hi[k] = smax[t];
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const uint32_t t = t0 + k;
+            if (t >= asz) break;
+            // outputs that are complete chunks leave first (they also free the slots the next inputs take)
+            while (t - written >= CH) { wave_sync(); store_chunk(written, written + CH); written += CH; }
+            // inputs up to this step's last tap
+            // ... and up to t itself: the output takes position t's slot, which no later chunk may then overwrite
+            uint32_t need = hi[k] + 1 > (int) t + 1 ? (uint32_t) (hi[k] + 1) : t + 1;
+            need = need < reach ? need : reach;
+            while (loaded < need) {
+                const uint32_t c1 = loaded + CH < reach ? loaded + CH : reach;
+                wave_sync();
+                load_chunk(loaded, c1);
+                loaded = c1;
+            }
+            wave_sync();
+            if (lane < R) {
+                float avg = 0.0f;
+                int count = 0;
+                const int q1 = hi[k];
+                for (int q0 = lo[k]; q0 <= q1; q0 += 8) {
+                    float x[8];
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) x[i] = q0 + i <= q1 ? b[(uint32_t) (q0 + i) & (W - 1)] : 0.0f;
+#pragma unroll
+                    for (int i = 0; i < 8; ++i)
+                        if (x[i] != 0.0f) { avg = avg + x[i]; ++count; }   // `if (b[s])`: NaN counts, +-0 does not
+                }
+                b[t & (W - 1)] = avg / (float) count;                   // 0/0 = NaN at t = 0, as in the reference
+            }
+        }
+    }
+    wave_sync();
+    while (written < asz) { const uint32_t c1 = written + CH < asz ? written + CH : asz; store_chunk(written, c1); written = c1; }
 }
 
 // ---- smooth_audio() bar sampling (shaders/glava/util/smooth.glsl:13-40, radial/1.frag:58-70) --------
@@ -150,8 +298,42 @@ hipError_t launch_lerp(const float* s0, const float* e0, float* out, size_t tota
     hipLaunchKernelGGL(glv_lerp_kernel, dim3(capped_grid(total, 256)), dim3(256), 0, st, s0, e0, out, total, mod);
     return hipGetLastError();
 }
-hipError_t launch_smooth(float* rows, size_t nrows, uint32_t n, const int* smin, const int* smax, uint32_t asz, hipStream_t st) {
-    hipLaunchKernelGGL(glv_smooth_kernel, dim3((unsigned) ((nrows + 63) / 64)), dim3(64), 0, st, rows, nrows, n, smin, smax, asz);
+hipError_t launch_smooth(float* rows, size_t nrows, uint32_t n, const int* smin, const int* smax, uint32_t asz, uint32_t reach,
+                         uint32_t max_window, hipStream_t st) {
+    // ring kernel: 64 rows per wave, W >= largest window + 2 chunks (glv_smooth_ring_kernel); few rows or huge windows:
+    // the row-prefix kernel
+    const uint32_t need_w = max_window + 2 * kSmoothChunk;
+    if (nrows >= 64 && need_w <= 512) {
+        const unsigned wgs = (unsigned) ((nrows + 63) / 64);
+#define GLV_RING(WW)                                                                                                           \
+        do {                                                                                                                   \
+            const size_t lds = sizeof(float) * 64 * (WW + 1);                                                                  \
+            if (lds > 64 * 1024) {                                                                                             \
+                hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(glv_smooth_ring_kernel<WW>),                  \
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);                     \
+                if (e != hipSuccess) return e;                                                                                 \
+            }                                                                                                                  \
+            hipLaunchKernelGGL(glv_smooth_ring_kernel<WW>, dim3(wgs), dim3(64), lds, st, rows, nrows, n, smin, smax, asz, reach); \
+            return hipGetLastError();                                                                                          \
+        } while (0)
+        if (need_w <= 128) GLV_RING(128);
+        if (need_w <= 256) GLV_RING(256);
+        GLV_RING(512);
+#undef GLV_RING
+    }
+    // rows per workgroup: what fits 64 KiB of LDS (two workgroups per CU), at most one row per lane, at least one
+    // (reach <= n <= 32768 floats = 128 KiB: a row always fits the 160 KiB of a CU once the limit is raised)
+    const size_t row_bytes = sizeof(float) * (size_t) (reach | 1u);
+    size_t budget = 64 * 1024;
+    if (row_bytes > budget) {
+        budget = row_bytes;
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(glv_smooth_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int) budget);
+        if (e != hipSuccess) return e;
+    }
+    size_t rpw = budget / row_bytes;
+    if (rpw > 64) rpw = 64;
+    const size_t wgs = (nrows + rpw - 1) / rpw;
+    hipLaunchKernelGGL(glv_smooth_kernel, dim3((unsigned) wgs), dim3(64), rpw * row_bytes, st, rows, nrows, n, smin, smax, asz, reach, (uint32_t) rpw);
     return hipGetLastError();
 }
 hipError_t launch_bars(const float* spec, float* bars_out, size_t nrows, uint32_t n, uint32_t bars, uint32_t nsteps,

@@ -279,6 +279,33 @@ def test_cpu_smooth_operator(G):
         assert ((bits(got) == bits(want)) | (np.isnan(got) & np.isnan(want))).all()
 
 
+@pytest.mark.parametrize("n,dist,ratio,streams", [(512, 0.01, 4.0, 41), (4096, 0.01, 4.0, 37), (4096, 0.05, 1.0, 5), (32768, 0.01, 1.0, 2),
+                                                  (1024, 0.2, 2.0, 70), (512, 0.01, 3.0, 32), (2048, 0.03, 1.5, 33), (256, 0.01, 4.0, 64),
+                                                  (16384, 0.01, 4.0, 40), (4096, 0.6, 4.0, 48), (8192, 0.002, 1.0, 36)])
+def test_cpu_smooth_operator_batched(G, n, dist, ratio, streams):
+    """The batched transform_smooth -- 64 rows per wave with a sliding window of each in LDS (ring sizes 128 / 256 / 512),
+    or, for fewer than 64 rows and for windows no ring holds, row prefixes in LDS: row counts that are and are not
+    multiples of 64, output counts that are no multiple of a chunk, windows up to the whole row (ratio 1; 128 KiB of LDS at
+    n = 32768), narrow and very wide windows; every row bit-equal to the oracle (NaN where the reference produces NaN),
+    floats behind the written prefix untouched."""
+    import torch
+    rng = np.random.default_rng(n + streams)
+    x = np.abs(rng.standard_normal((streams * 2, n))).astype(np.float32)
+    x[:, ::7] = 0
+    x[3, 5:40] = 0
+    want = x.copy()
+    for r_ in range(streams * 2):
+        row = np.ascontiguousarray(want[r_]); Oracle.lib().glvo_smooth(row, n, dist, ratio); want[r_] = row
+    b = G.Batch(G.Params(n=n, smooth_distance=dist, smooth_ratio=ratio), streams, 0)
+    d_in = torch.from_numpy(x).cuda()
+    d_out = torch.full_like(d_in, float("nan"))
+    b.process_f32(d_in, d_out, G.OP_SMOOTH)
+    torch.cuda.synchronize()
+    got = d_out.cpu().numpy()
+    b.close()
+    assert ((bits(got) == bits(want)) | (np.isnan(got) & np.isnan(want))).all()
+
+
 def test_gl_twin_average_and_bars(G):
     """a12 semantics (GL accel passes): Hamming-weighted newest-first average (average_pass.frag) and
     smooth_audio() bar sampling (smooth.glsl, radial/1.frag).  GLSL cannot run here, so both sides are

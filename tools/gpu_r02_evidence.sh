@@ -14,6 +14,7 @@ python tools/chain_bench.py > $O/chain.txt 2>/dev/null
 GLV_UNFUSED_BARS=1 python tools/chain_bench.py 2>/dev/null | tail -1 >> $O/chain.txt
 python tools/gravity_bench.py > $O/gravity.txt 2>/dev/null
 python tools/bars_bench.py > $O/bars.txt 2>/dev/null
+python tools/smooth_bench.py > $O/smooth.txt 2>/dev/null
 python tools/inputs_bench.py > $O/inputs.txt 2>/dev/null
 tools/bin/membench2 > $O/membench2.txt 2>&1
 rocminfo | grep -E "Marketing Name|Compute Unit" | head -4 > $O/device.txt; nproc >> $O/device.txt

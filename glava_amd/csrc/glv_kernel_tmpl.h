@@ -365,7 +365,13 @@ glv_frame_kernel(const FrameArgs a) {
             if (active && (uint32_t) tid < a.bars) a.bars_out[row * a.bars + (uint32_t) tid] = lres[tid] / bar_wsum;
             // the next row's first exchange write is preceded by a barrier (NBUF == 1): the bars readers are safe
         } else {
+#if defined(GLV_EXP_STOREPRIO)       /* tools/tune.py A/B: the epilogue (stores) at raised wave priority */
+            __builtin_amdgcn_s_setprio(GLV_EXP_STOREPRIO);
+#endif
             if (active) finish(v, row, tid);
+#if defined(GLV_EXP_STOREPRIO)
+            __builtin_amdgcn_s_setprio(0);
+#endif
         }
     };
     // row handled by this slot in the iteration that starts at `base` (idle slots clamp to the last

@@ -16,12 +16,20 @@ sys.path.insert(0, ROOT)
 NOL0 = ["-DGLV_TUNE_NO_LOG0"]
 # name, log_nn, extra flags, variant list (glv_tune.hip macros)
 LIBS = [
-    ("r2r_n12", 12, NOL0, "VW(2,1,true,true,2,1,1,4,0,0),VW(2,1,true,true,2,1,2,4,0,0),VW(2,1,true,true,2,1,0,4,0,0),VW(2,1,true,true,2,1,1,4,0,0)"),
-    ("r2r_n11", 11, NOL0, "VW(2,1,true,true,2,1,1,4,0,0),VW(2,1,true,true,2,1,2,4,0,0),VW(2,1,true,true,2,1,1,4,0,0)"),
+    ("r2s_n12_p0", 12, NOL0, "VW(2,1,true,true,2,1,1,4,0,0)"),
+    ("r2s_n12_p3", 12, NOL0 + ["-DGLV_EXP_STOREPRIO=3"], "VW(2,1,true,true,2,1,1,4,0,0)"),
+    ("r2s_n13_p0", 13, NOL0, "VW(1,1,2,false,2,1,2,5,0,0)"),
+    ("r2s_n13_p3", 13, NOL0 + ["-DGLV_EXP_STOREPRIO=3"], "VW(1,1,2,false,2,1,2,5,0,0)"),
 ]
 RUNS = [
-    ("r2r_n12", 32768, 0, "N=8192: tilt resident (1) / evaluated (2) / from the L2 table (0)"),
-    ("r2r_n11", 65536, 0, "N=4096: tilt resident (1) / evaluated (2)"),
+    ("r2s_n12_p0", 32768, 0, "N=8192 default priority"),
+    ("r2s_n12_p3", 32768, 0, "N=8192 epilogue at s_setprio 3"),
+    ("r2s_n12_p0", 32768, 0, "N=8192 default priority (again)"),
+    ("r2s_n12_p3", 32768, 0, "N=8192 epilogue at s_setprio 3 (again)"),
+    ("r2s_n13_p0", 16384, 0, "N=16384 default priority"),
+    ("r2s_n13_p3", 16384, 0, "N=16384 epilogue at s_setprio 3"),
+    ("r2s_n13_p0", 16384, 0, "N=16384 default priority (again)"),
+    ("r2s_n13_p3", 16384, 0, "N=16384 epilogue at s_setprio 3 (again)"),
 ]
 
 

@@ -121,6 +121,93 @@ def streaming_ceiling(n: int, ops: str):
         return None
 
 
+def extra_configs(G, torch, device, a, peak_gbs):
+    """The other single-GPU configurations of BASELINE.json, timed like the headline (spin-up, warm-up, K launches bracketed by
+    synchronize; kernel time from HIP events on the launch stream):
+      configs[2]  N=16384 x 8192 streams, fft + gravity smoothing + 80-bar radial bin averaging (20 N + 640 B / frame, SURVEY 8d
+                  row D) and the same chain with the full spectra as output (20 N, row B: the output is the state)
+      configs[4]  N in {512 ... 8192}, equal bytes per class, one batch per class on its own HIP stream: every class alone, then
+                  all five in flight together (aggregate)
+      n8192 / n16384   the stateless pass (12 N) at equal bytes to the headline"""
+    import time
+    steps, warm = a.configs_steps, 2
+
+    def run(batch, call):
+        t_end = time.perf_counter() + 0.15
+        while time.perf_counter() < t_end:
+            for _ in range(4): call()
+            torch.cuda.synchronize()
+        for _ in range(warm): call()
+        torch.cuda.synchronize()
+        if batch is not None: batch.timing_begin()
+        t0 = time.perf_counter()
+        for _ in range(steps): call()
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / steps
+        kms = None
+        if batch is not None:
+            ms, nl = batch.timing_end()
+            kms = ms / max(nl, 1)
+        return dt, kms
+
+    def entry(note, frames, bytes_per_launch, dt, kms):
+        k = kms if kms else dt * 1e3
+        return {"note": note, "value": frames / dt, "unit": "frames/s", "ms_per_step": dt * 1e3, "avg_kernel_ms": k,
+                "algorithmic_bytes_per_launch": bytes_per_launch, "roofline_frac": bytes_per_launch / (k * 1e-3) / 1e9 / peak_gbs}
+
+    out = {}
+    gen = torch.Generator(device="cuda"); gen.manual_seed(777)
+    st0 = torch.cuda.current_stream().cuda_stream
+    # --- the large stateless sizes
+    for n, s in ((8192, 32768), (16384, 16384)):
+        pcm = torch.randint(-32768, 32768, (s, n, 2), dtype=torch.int16, device="cuda", generator=gen)
+        o = torch.empty((s, 2, n), dtype=torch.float32, device="cuda")
+        b = G.Batch(G.Params(n=n, log_mode=a.log_mode), s, G.OP_FFT, device=device)
+        dt, kms = run(b, lambda: b.process_s16(pcm, o, G.OP_FFT, st0))
+        out[f"n{n}_stateless"] = entry(f"N={n} x {s} streams, window+FFT+magnitude, 12 N B/frame", s, b.algorithmic_bytes(G.OP_FFT), dt, kms)
+        b.close(); del pcm, o
+    # --- configs[2]
+    n, s, bars = 16384, 8192, 80
+    pcm = torch.randint(-32768, 32768, (s, n, 2), dtype=torch.int16, device="cuda", generator=gen)
+    o = torch.empty((s, 2, n), dtype=torch.float32, device="cuda")
+    ob = torch.empty((s, 2, bars), dtype=torch.float32, device="cuda")
+    gops = G.OP_FFT | G.OP_GRAVITY
+    b = G.Batch(G.Params(n=n, log_mode=a.log_mode, bars=bars), s, G.OP_GRAVITY, device=device)
+    dt, kms = run(b, lambda: b.process_s16(pcm, ob, gops | G.OP_BARS, st0))
+    c2 = entry(f"BASELINE configs[2]: N={n} x {s} streams, fft + gravity + radial bin averaging to {bars} bars/channel (fused: bars from the row in LDS), "
+               f"20 N + 640 B/frame (SURVEY 8d row D)", s, (20 * n + 8 * bars) * s, dt, kms)
+    b.reset()
+    dt, kms = run(b, lambda: b.process_s16(pcm, o, gops, st0))
+    c2["spectra_out"] = entry("same size, fft + gravity with the full spectra as output == state, 20 N B/frame (SURVEY 8d row B)", s, b.algorithmic_bytes(gops), dt, kms)
+    out["configs[2]"] = c2
+    b.close(); del pcm, o, ob
+    torch.cuda.empty_cache()
+    # --- configs[4]
+    classes = []
+    for n in (512, 1024, 2048, 4096, 8192):
+        s = 16384 * 4096 // n
+        pcm = torch.randint(-32768, 32768, (s, n, 2), dtype=torch.int16, device="cuda", generator=gen)
+        o = torch.empty((s, 2, n), dtype=torch.float32, device="cuda")
+        classes.append((n, s, pcm, o, G.Batch(G.Params(n=n, log_mode=a.log_mode), s, G.OP_FFT, device=device), torch.cuda.Stream()))
+    per = []
+    for n, s, pcm, o, b, st in classes:
+        dt, kms = run(b, lambda: b.process_s16(pcm, o, G.OP_FFT, st.cuda_stream))
+        per.append(dict(entry(f"class N={n} x {s} streams alone", s, b.algorithmic_bytes(G.OP_FFT), dt, kms), n=n, streams=s))
+
+    def all_classes():
+        for n, s, pcm, o, b, st in classes:
+            b.process_s16(pcm, o, G.OP_FFT, st.cuda_stream)
+    dt, _ = run(None, all_classes)
+    tot_bytes = sum(b.algorithmic_bytes(G.OP_FFT) for *_, b, _ in classes)
+    tot_frames = sum(s for _, s, *_ in classes)
+    agg = entry("BASELINE configs[4]: N in {512,1024,2048,4096,8192}, 256 MiB of PCM per class, one launch per class on five HIP streams in flight together; "
+                "ms_per_step = wall clock of one round of all classes (rounds back to back)", tot_frames, tot_bytes, dt, None)
+    agg["classes"] = per
+    out["configs[4]"] = agg
+    for *_, b, _ in classes: b.close()
+    return out
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -134,6 +221,8 @@ def main() -> None:
     ap.add_argument("--grid", type=int, default=0, help="workgroups of the persistent kernel (0 = auto)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-alt", action="store_true", help="skip the secondary fast-log measurement")
+    ap.add_argument("--no-configs", action="store_true", help="skip the `configs` key (BASELINE configs[2], configs[4], N=8192 / 16384)")
+    ap.add_argument("--configs-steps", type=int, default=10, help="timed steps per entry of the `configs` key")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
     ap.add_argument("--spinup-s", type=float, default=0.3, help="untimed clock spin-up before the W warm-up steps")
     a = ap.parse_args()
@@ -256,6 +345,12 @@ def main() -> None:
                "avg_kernel_ms": r_k * 1e3, "roofline_frac": (r_bytes / r_k / 1e9) / HBM_PEAK_GBS if r_k > 0 else 0.0}
         rb.close()
 
+    # BASELINE configs[2], configs[4] and the two large stateless sizes, each with its own kernel time and roofline fraction
+    # (SURVEY 8d bytes per frame) -- the figures below the headline's that VERDICT r2 wants in the driver's record
+    configs = None
+    if world == 1 and ops == G.OP_FFT and not a.no_alt and not a.no_configs:
+        configs = extra_configs(G, torch, device, a, HBM_PEAK_GBS)
+
     frames_rank = streams * a.steps
     stats = gather_stats({"frames": frames_rank, "seconds": elapsed, "kernel_ms": kernel_ms,
                           "bytes": batch.algorithmic_bytes(ops) * launches}, world, force=dist_on)
@@ -280,6 +375,8 @@ def main() -> None:
                                        f"all_gather of one 32-byte stats record per rank; {world} rank(s)") if dist_on else None},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(n, streams, a.ops),
+                         "traffic_source": "profiles/hbm_traffic.json: 2*FETCH_SIZE + WRITE_SIZE of this kernel from separate rocprofv3 --pmc passes "
+                                           "(tools/profile.sh) of the same command on an MI355X -- a committed measurement, NOT collected in this run",
                          "algorithmic_bytes_per_launch": alg_bytes, "avg_kernel_ms": avg_kernel_s * 1e3,
                          "kernel": batch.kernel_name()},
         }
@@ -301,6 +398,8 @@ def main() -> None:
             line["smooth_chain"] = chain
         if r16 is not None:
             line["r16_texels"] = r16
+        if configs is not None:
+            line["configs"] = configs
         if world == 1 and not a.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(n, a.cpu_seconds)
         else:

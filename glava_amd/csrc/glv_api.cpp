@@ -6,6 +6,7 @@
 // there is no CPU compute path here and none is ever substituted.
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -73,17 +74,19 @@ int ensure_device(int device) {
 }
 
 // ---- launch wisdom ----------------------------------------------------------------------------------------------------
-// The role glfft's FFTWisdom plays in the reference tree (glfft/glfft_wisdom.cpp:235-446: time candidate launch
-// configurations on the target, remember the winner per transform description): the kernel variant per size is fixed at
-// build time (glv_inst.hip Tuned<>, from tools/tune.py), what remains open at run time is how many persistent workgroups
-// a launch uses -- it depends on the size, on the operator chain and on how many streams the batch holds (N=8192 with
-// 32768 streams: 0.697 ms with 256 workgroups, 0.723 ms with 512; N=16384 the other way round).  glv_batch_autotune
-// measures the candidates on the device the batch lives on; entries are process-wide, can be saved and loaded
-// (GLV_WISDOM=<file> loads one when the first batch is created) and are consulted by every launch.
-struct WisdomKey { uint32_t n, in_kind, ops_class, log_mode, streams_log2; };
-struct WisdomEntry { WisdomKey k; int grid; float ms; };
+// The role glfft's FFTWisdom plays in the reference tree (glfft/glfft_wisdom.cpp:235-446: time candidate work-group shapes
+// and radix splits per transform on the target, remember the winner per transform description).  Two things are open at run
+// time here: WHICH kernel configuration of the size runs (glv_inst.hip Tuned<K, V>: points per lane / radix split, rows per
+// workgroup, where the window and twiddle tables live) and HOW MANY persistent workgroups a launch uses.  Both depend on the
+// size, the operator chain, the stream count and the part.  glv_batch_autotune measures the candidates on the device the
+// batch lives on; entries are process-wide, keyed on the device's identity (name, CU count) so that a file tuned on one part
+// is not applied on another, can be saved and loaded (GLV_WISDOM=<file> loads one when the first batch is created) and are
+// consulted by every launch (through a per-batch cache: no lock on the launch path once an answer is cached).
+struct WisdomKey { uint32_t n, in_kind, ops_class, log_mode, streams_log2, avg_frames, cus; char device[48]; };
+struct WisdomEntry { WisdomKey k; int variant, grid; float ms; };
 std::mutex g_wisdom_mu;
 std::vector<WisdomEntry> g_wisdom;
+std::atomic<uint64_t> g_wisdom_gen{1};      // bumped by every change of the table: invalidates the per-batch caches
 bool g_wisdom_env_loaded = false;
 
 uint32_t ops_class_of(unsigned ops) {      // the kernel instantiation a chain selects (glv_kernel_tmpl.h launch_variant)
@@ -91,30 +94,43 @@ uint32_t ops_class_of(unsigned ops) {      // the kernel instantiation a chain s
     if (ops & (GLV_OP_GRAVITY | GLV_OP_AVERAGE)) return (ops & GLV_OP_R16) ? 4 : 1;
     return (ops & GLV_OP_R16) ? 3 : 0;
 }
+constexpr int kOpsClasses = 5, kInKinds = 5;
 uint32_t log2_round(uint32_t v) { uint32_t l = 0; while ((2u << l) <= v) ++l; return ((v >> l << l) * 3 / 2 <= v && l < 31) ? l + 1 : l; }
 bool same_key(const WisdomKey& a, const WisdomKey& b) {
-    return a.n == b.n && a.in_kind == b.in_kind && a.ops_class == b.ops_class && a.log_mode == b.log_mode && a.streams_log2 == b.streams_log2;
+    return a.n == b.n && a.in_kind == b.in_kind && a.ops_class == b.ops_class && a.log_mode == b.log_mode && a.streams_log2 == b.streams_log2
+           && a.avg_frames == b.avg_frames && a.cus == b.cus && std::strncmp(a.device, b.device, sizeof(a.device)) == 0;
 }
-int wisdom_lookup(const WisdomKey& k) {
-    std::lock_guard<std::mutex> lock(g_wisdom_mu);
-    for (const WisdomEntry& e : g_wisdom) if (same_key(e.k, k)) return e.grid;
-    return 0;
+void key_set_device(WisdomKey& k, const char* name, uint32_t cus) {
+    std::memset(k.device, 0, sizeof(k.device));
+    size_t j = 0;
+    for (const char* c = name; *c && j + 1 < sizeof(k.device); ++c) k.device[j++] = (*c == ' ' || *c == '\t' || *c == '\n') ? '_' : *c;
+    if (j == 0) std::strcpy(k.device, "unknown");
+    k.cus = cus;
 }
-void wisdom_store(const WisdomKey& k, int grid, float ms) {
+bool wisdom_lookup(const WisdomKey& k, int* variant, int* grid) {
     std::lock_guard<std::mutex> lock(g_wisdom_mu);
-    for (WisdomEntry& e : g_wisdom) if (same_key(e.k, k)) { e.grid = grid; e.ms = ms; return; }
-    g_wisdom.push_back(WisdomEntry{k, grid, ms});
+    for (const WisdomEntry& e : g_wisdom) if (same_key(e.k, k)) { *variant = e.variant; *grid = e.grid; return true; }
+    return false;
+}
+void wisdom_store(const WisdomKey& k, int variant, int grid, float ms) {
+    std::lock_guard<std::mutex> lock(g_wisdom_mu);
+    g_wisdom_gen.fetch_add(1, std::memory_order_release);
+    for (WisdomEntry& e : g_wisdom) if (same_key(e.k, k)) { e.variant = variant; e.grid = grid; e.ms = ms; return; }
+    g_wisdom.push_back(WisdomEntry{k, variant, grid, ms});
 }
 int wisdom_load_file(const char* path) {
     FILE* f = std::fopen(path, "r");
     if (!f) { (void) fail(GLV_ERR_INVALID, "cannot open wisdom file %s", path); return -1; }
-    char line[256];
+    char line[320];
     int n_loaded = 0;
     while (std::fgets(line, sizeof(line), f)) {
         if (line[0] == '#' || line[0] == '\n') continue;
-        WisdomKey k; int grid; float ms;
-        if (std::sscanf(line, "%u %u %u %u %u %d %f", &k.n, &k.in_kind, &k.ops_class, &k.log_mode, &k.streams_log2, &grid, &ms) == 7 && grid > 0) {
-            wisdom_store(k, grid, ms); ++n_loaded;
+        WisdomKey k; int variant, grid; float ms; char dev[48];
+        std::memset(&k, 0, sizeof(k));
+        if (std::sscanf(line, "%47s %u %u %u %u %u %u %u %d %d %f", dev, &k.cus, &k.n, &k.in_kind, &k.ops_class, &k.log_mode, &k.streams_log2,
+                        &k.avg_frames, &variant, &grid, &ms) == 11 && grid > 0 && variant >= 0) {
+            key_set_device(k, dev, k.cus);
+            wisdom_store(k, variant, grid, ms); ++n_loaded;
         }
     }
     std::fclose(f);
@@ -190,7 +206,9 @@ struct glv_batch {
     int log_nn = 0;
     int num_cus = 256;
     Tables tab;
-    float* d_grav = nullptr;     // [streams*2][n]      gravity state (gravity without average)
+    float* d_grav = nullptr;     // [streams*2][n]      gravity state owned by the batch (gravity without average)
+    const float* grav_cur = nullptr;   // where the latest gravity output lives: d_grav, or the caller's output buffer of the previous
+                                 // call when the output doubles as the state (render.c:733-734; see GLV_OP_PRIVATE_STATE)
     float* d_hist = nullptr;     // [streams*2][F][n]   ring (average; doubles as gravity state)
     int16_t* d_ring = nullptr;   // [streams][n][2]     FIFO ring mode
     int grav_mode = 0;           // which buffer holds gravity's `applied`: 0 not used yet, 1 d_grav (gravity without average
@@ -198,7 +216,13 @@ struct glv_batch {
     uint32_t head = 0;           // history slot receiving the next frame
     uint32_t ring_pos = 0;       // next write position in the PCM ring, in frames
     int grid_override = 0;
+    int variant_override = -1;   // kernel configuration forced by glv_batch_set_variant (-1 = wisdom / default)
     int last_grid = 0;           // workgroups of the last frame-kernel launch
+    int last_variant = 0;        // kernel configuration of the last frame-kernel launch
+    char device_name[48] = "unknown";
+    // what the wisdom said the last time it was asked, per (input kind, kernel class): valid while `gen` equals the table's
+    // generation -- the launch path takes no lock and scans nothing once an answer is cached
+    struct PlanCache { uint64_t gen = 0; int variant = 0, grid = 0; bool hit = false; } plan_cache[kInKinds][kOpsClasses];
     float* d_scratch = nullptr;  // [streams*2][n] spectra feeding GLV_OP_BARS
     float* d_ring_f32 = nullptr; // [streams][n][2] interleaved f32 ring (glv_batch_ring_update_f32)
     uint32_t ring_pos_f32 = 0;
@@ -213,7 +237,7 @@ struct glv_batch {
     glv::BarItem* d_bar_items = nullptr;    // work lists for glv_bars_kernel (16 groups per row)
     glv::BarItem* d_bar_fitems = nullptr;   // work lists for the fused epilogue (lanes/16 groups per row)
     uint32_t bar_nsteps = 0, bar_fnsteps = 0; bool bar_fusable = false;
-    uint32_t bar_count = 0; float bar_factor = -1.f;
+    uint32_t bar_count = 0; float bar_factor = -1.f; int bar_lanes = 0;
     // timing
     bool timing = false;
     std::vector<hipEvent_t> ev;  // start/stop pairs
@@ -252,25 +276,68 @@ int batch_alloc(glv_batch* b, uint32_t rows) {
         const size_t bytes = sizeof(float) * rows * n;
         HIP_TRY(hipMalloc(&b->d_grav, bytes));
         HIP_TRY(hipMemset(b->d_grav, 0, bytes));
+        b->grav_cur = b->d_grav;
+    }
+    // the device rings of the FIFO / PulseAudio modes, when the creation mask announces them (otherwise the first
+    // ring update allocates -- a synchronising hipMalloc inside an otherwise stream-ordered call)
+    if (b->ops_mask & GLV_OP_RING_S16) {
+        const size_t bytes = sizeof(int16_t) * 2 * n * b->streams;
+        HIP_TRY(hipMalloc(&b->d_ring, bytes));
+        HIP_TRY(hipMemset(b->d_ring, 0, bytes));          // == the calloc'd rings of glava.c:487-494
+    }
+    if (b->ops_mask & GLV_OP_RING_F32) {
+        const size_t bytes = sizeof(float) * 2 * n * b->streams;
+        HIP_TRY(hipMalloc(&b->d_ring_f32, bytes));
+        HIP_TRY(hipMemset(b->d_ring_f32, 0, bytes));
     }
     return GLV_OK;
 }
 
-int frame_grid(const glv_batch* b, uint32_t units, int in_mode = 0, unsigned ops = GLV_OP_FFT) {
-    if (b->grid_override > 0) return b->grid_override;
-    if (const int g = wisdom_lookup(WisdomKey{b->p.n, (uint32_t) in_mode, ops_class_of(ops), b->p.log_mode, log2_round(b->streams)})) {
-        const uint32_t wgs_max = (units + glv::frame_slots(b->log_nn) - 1) / glv::frame_slots(b->log_nn);
-        return (uint32_t) g < wgs_max ? g : (int) wgs_max;
-    }
-    const int slots = glv::frame_slots(b->log_nn);
-    const uint32_t wgs = (units + slots - 1) / slots;
+WisdomKey wisdom_key(const glv_batch* b, int in_mode, unsigned ops) {
+    WisdomKey k;
+    std::memset(&k, 0, sizeof(k));
+    k.n = b->p.n; k.in_kind = (uint32_t) in_mode; k.ops_class = ops_class_of(ops); k.log_mode = b->p.log_mode;
+    k.streams_log2 = log2_round(b->streams);
+    k.avg_frames = (ops & GLV_OP_AVERAGE) ? b->p.avg_frames : 0;          // F changes what a stateful launch moves
+    key_set_device(k, b->device_name, (uint32_t) b->num_cus);
+    return k;
+}
+
+// workgroups of a launch of configuration `variant` over `units` rows when nothing has been tuned
+int default_grid(const glv_batch* b, uint32_t units, int variant) {
+    const glv::FrameGeometry g = glv::frame_geometry(b->log_nn, variant);
+    const uint32_t wgs = (units + g.rows_per_trip - 1) / g.rows_per_trip;
     // persistent workgroups: two rounds of what fits the chip (the second round evens out CU-to-CU
     // differences), one round when that would leave a slot fewer than 8 trips -- every workgroup pays a
     // prologue (window / table staging, pipeline fill) that short-lived workgroups cannot amortise
     // (N=8192, 8192 streams: 0.194 ms with 256-512 workgroups, 0.224 ms with 2048)
-    const uint32_t round = (uint32_t) b->num_cus * (uint32_t) glv::frame_resident(b->log_nn);
-    const uint32_t cap = wgs >= 16u * round ? (uint32_t) glv::frame_rounds(b->log_nn) * round : round;
+    const uint32_t round = (uint32_t) b->num_cus * (uint32_t) g.resident;
+    const uint32_t cap = wgs >= 16u * round ? (uint32_t) g.rounds * round : round;
     return (int) (wgs < cap ? wgs : cap);
+}
+
+// (kernel configuration, workgroups) of the next frame-kernel launch: explicit overrides, else the wisdom, else the defaults
+void launch_plan(glv_batch* b, uint32_t units, int in_mode, unsigned ops, int* variant, int* grid) {
+    int v = 0, g = 0;
+    const uint32_t cls = ops_class_of(ops);
+    if (b->variant_override < 0 || b->grid_override <= 0) {
+        glv_batch::PlanCache& pc = b->plan_cache[in_mode][cls];
+        const uint64_t gen = g_wisdom_gen.load(std::memory_order_acquire);
+        if (pc.gen != gen) {
+            pc.hit = wisdom_lookup(wisdom_key(b, in_mode, ops), &pc.variant, &pc.grid);
+            pc.gen = gen;
+        }
+        if (pc.hit) { v = pc.variant; g = pc.grid; }
+    }
+    if (b->variant_override >= 0) { if (b->variant_override != v) g = 0; v = b->variant_override; }
+    if (!glv::frame_variant_ok(b->log_nn, in_mode, (int) b->p.log_mode, v)) { v = 0; g = 0; }     // not built for this input / log mode
+    if (b->grid_override > 0) g = b->grid_override;
+    else if (g > 0) {
+        const int rpt = glv::frame_geometry(b->log_nn, v).rows_per_trip;
+        const uint32_t wgs_max = (units + rpt - 1) / rpt;
+        if ((uint32_t) g > wgs_max) g = (int) wgs_max;
+    } else g = default_grid(b, units, v);
+    *variant = v; *grid = g;
 }
 
 int timed_launch_begin(glv_batch* b, hipStream_t st) {
@@ -315,8 +382,10 @@ int ensure_smooth_tables(glv_batch* b) {
     return GLV_OK;
 }
 
-int ensure_bar_tables(glv_batch* b) {
-    if (b->d_bar_desc && b->bar_count == b->p.bars && b->bar_factor == b->p.smooth_factor) return GLV_OK;
+// lanes: lanes per row of the frame-kernel configuration that will consume the fused work lists (0: only glv_bars_kernel runs)
+int ensure_bar_tables(glv_batch* b, int lanes = 0) {
+    if (lanes == 0) lanes = b->bar_lanes ? b->bar_lanes : glv::frame_geometry(b->log_nn, 0).lanes;
+    if (b->d_bar_desc && b->bar_count == b->p.bars && b->bar_factor == b->p.smooth_factor && b->bar_lanes == lanes) return GLV_OK;
     if (b->p.bars == 0 || b->p.bars > b->p.n) return fail(GLV_ERR_INVALID, "bars=%u out of range", b->p.bars);
     std::vector<glv::BarDesc> desc;
     std::vector<float> w;
@@ -329,7 +398,6 @@ int ensure_bar_tables(glv_batch* b) {
     // appended for padding items.
     const uint32_t zero_off = (uint32_t) w.size();
     w.resize(w.size() + glv::kBarChunk, 0.0f);
-    const int lanes = glv::frame_lanes(b->log_nn);
     std::vector<glv::BarItem> items, fitems;
     b->bar_nsteps = glv::make_bar_items(items, desc, 16, zero_off);
     b->bar_fusable = lanes % 64 == 0 && b->p.bars <= (uint32_t) lanes;
@@ -345,7 +413,7 @@ int ensure_bar_tables(glv_batch* b) {
     HIP_TRY(hipMalloc(&b->d_bar_w, sizeof(float) * w.size()));
     HIP_TRY(hipMemcpy(b->d_bar_desc, desc.data(), sizeof(glv::BarDesc) * desc.size(), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(b->d_bar_w, w.data(), sizeof(float) * w.size(), hipMemcpyHostToDevice));
-    b->bar_count = b->p.bars; b->bar_factor = b->p.smooth_factor;
+    b->bar_count = b->p.bars; b->bar_factor = b->p.smooth_factor; b->bar_lanes = lanes;
     return GLV_OK;
 }
 
@@ -395,9 +463,13 @@ int process(glv_batch* b, const void* d_in, int in_mode, float* d_out, unsigned 
     // them inside the frame kernel from the finished row in LDS (the spectra never reach HBM, apart from
     // the state the operators keep anyway); otherwise the spectra stay internal -- in the gravity state
     // when the chain ends in gravity, in a scratch buffer else -- and glv_bars_kernel runs after.
-    bool fused_bars = (ops & GLV_OP_BARS) && (ops & GLV_OP_FFT) && (ops & (GLV_OP_GRAVITY | GLV_OP_AVERAGE)) && !(ops & GLV_OP_SMOOTH);
+    const bool gl_split = b->p.gl_storage && (ops & (GLV_OP_GRAVITY | GLV_OP_AVERAGE)) != 0;
+    // which kernel configuration of this size runs, on how many workgroups (wisdom, overrides, defaults)
+    int variant = 0, grid = 0;
+    if (ops & GLV_OP_FFT) launch_plan(b, units, in_mode, gl_split ? (unsigned) GLV_OP_FFT : ops, &variant, &grid);
+    bool fused_bars = (ops & GLV_OP_BARS) && (ops & GLV_OP_FFT) && (ops & (GLV_OP_GRAVITY | GLV_OP_AVERAGE)) && !(ops & GLV_OP_SMOOTH) && !gl_split;
     if (fused_bars) {
-        if (int rc = ensure_bar_tables(b)) return rc;
+        if (int rc = ensure_bar_tables(b, glv::frame_geometry(b->log_nn, variant).lanes)) return rc;
         fused_bars = b->bar_fusable                // whole waves per row, at most one bar per lane of the row
                      && !std::getenv("GLV_UNFUSED_BARS");   // diagnostics: force the two-kernel path
     }
@@ -412,8 +484,18 @@ int process(glv_batch* b, const void* d_in, int in_mode, float* d_out, unsigned 
     if (int rc = b->tab.set_tilt(b->p.fft_scale, b->p.fft_cutoff, b->p.log_mode == 1)) return rc;
     glv::FrameArgs a;
     fill_common(a, b->p, b->tab);
-    a.in = d_in; a.out = d_out; a.grav = b->d_grav; a.hist = b->d_hist;
-    a.units = units; a.ops = ops; a.head = b->head; a.rot = rot; a.log_mode = b->p.log_mode;
+    a.in = d_in; a.out = d_out; a.grav = b->grav_cur; a.grav_w = b->d_grav; a.hist = b->d_hist;
+    a.units = units; a.ops = ops & ~(unsigned) GLV_OP_PRIVATE_STATE; a.head = b->head; a.rot = rot; a.log_mode = b->p.log_mode;
+    // A chain that ends in gravity writes ONE copy of its result (SURVEY 8d row B, 20 N bytes per frame): transform_gravity
+    // stores the same value to its `applied` array and to the buffer (render.c:733-734), so the caller's output buffer IS
+    // the new state and the next update reads it from there.  A private copy in the batch (28 N) is kept when the caller
+    // asks for it (GLV_OP_PRIVATE_STATE), when the transform runs in place on its own input (the next input would overwrite
+    // the state: the reference's calling convention, and the single-stream drop-ins), and when the output is not f32 rows.
+    const bool gravity_only = (ops & GLV_OP_GRAVITY) && !(ops & GLV_OP_AVERAGE);
+    const bool out_is_state = gravity_only && state_is_output && d_out != nullptr && !(ops & (GLV_OP_BARS | GLV_OP_R16 | GLV_OP_PRIVATE_STATE))
+                              && (const void*) d_out != d_in && !b->p.gl_storage;
+    if (out_is_state) { a.grav_w = d_out; a.out = nullptr; }
+    const float* grav_next = gravity_only ? (out_is_state ? d_out : b->d_grav) : b->grav_cur;
     if (fused_bars) {
         a.bar_desc = b->d_bar_desc; a.bar_items = b->d_bar_fitems; a.bar_nsteps = b->bar_fnsteps; a.bar_w = b->d_bar_w;
         a.bars = b->p.bars; a.bars_out = d_final;
@@ -422,7 +504,10 @@ int process(glv_batch* b, const void* d_in, int in_mode, float* d_out, unsigned 
     // glv_params.gl_storage: the GL twin's pass structure (render.c:2188-2265) -- the transform first, then gravity / average
     // as their own pass over GL_R16-quantised values (glv_frame.h apply_state).  The frame kernel delivers the float spectra
     // into the caller's buffer when that is what it will hold in the end, else into the batch's scratch rows.
-    const bool gl_split = b->p.gl_storage && (ops & (GLV_OP_GRAVITY | GLV_OP_AVERAGE)) != 0;
+    // host tables of the follow-up kernels first: nothing is launched (and no state advanced) when they cannot be made
+    if (ops & GLV_OP_SMOOTH) { if (int rc = ensure_smooth_tables(b)) return rc; }
+    if ((ops & GLV_OP_BARS) && !fused_bars) { if (int rc = ensure_bar_tables(b)) return rc; }
+    hipError_t e;
     if (gl_split && (ops & GLV_OP_FFT)) {
         const bool direct = d_final && !(ops & (GLV_OP_BARS | GLV_OP_R16));
         float* d_tmp = direct ? d_final : nullptr;
@@ -431,32 +516,33 @@ int process(glv_batch* b, const void* d_in, int in_mode, float* d_out, unsigned 
             d_tmp = b->d_scratch;
         }
         glv::FrameArgs a1 = a;
-        a1.ops = GLV_OP_FFT; a1.out = d_tmp; a1.bars_out = nullptr;
+        a1.ops = GLV_OP_FFT | (ops & GLV_OP_RAW); a1.out = d_tmp; a1.bars_out = nullptr;     // GLV_OP_RAW: the passes then run on the raw values
         if (int rc = timed_launch_begin(b, st)) return rc;
-        b->last_grid = frame_grid(b, units, in_mode, GLV_OP_FFT);
-        hipError_t e1 = glv::launch_frame(b->log_nn, in_mode, (int) b->p.log_mode, a1, b->last_grid, st);
-        if (e1 != hipSuccess) return fail(GLV_ERR_HIP, "kernel launch failed: %s", hipGetErrorString(e1));
-        if (int rc = timed_launch_end(b, st)) return rc;
+        b->last_grid = grid; b->last_variant = variant;
+        e = glv::launch_frame(b->log_nn, in_mode, (int) b->p.log_mode, variant, a1, grid, st);
+        if (e != hipSuccess) return fail(GLV_ERR_HIP, "kernel launch failed: %s", hipGetErrorString(e));
         glv::FrameArgs a2 = a;
         a2.in = d_tmp; a2.ops = ops & (GLV_OP_GRAVITY | GLV_OP_AVERAGE | ((ops & GLV_OP_BARS) ? 0u : (unsigned) GLV_OP_R16)); a2.gl_storage = 1;
         a2.out = (ops & GLV_OP_BARS) ? d_tmp : d_final;            // bars sample the finished rows; NULL = the state is the output
         a2.bars_out = nullptr;
-        e1 = glv::launch_post(a2, b->p.n, st);
-        if (e1 != hipSuccess) return fail(GLV_ERR_HIP, "GL-storage pass launch failed: %s", hipGetErrorString(e1));
+        e = glv::launch_post(a2, b->p.n, st);
+        if (e != hipSuccess) return fail(GLV_ERR_HIP, "GL-storage pass launch failed: %s", hipGetErrorString(e));
         b->kernel_name = "glv_frame_kernel";
         if (ops & GLV_OP_AVERAGE) b->head = (b->head + 1) % b->p.avg_frames;
-        if (ops & GLV_OP_BARS) {
-            if (int rc = ensure_bar_tables(b)) return rc;
-            const float* src = (ops & GLV_OP_AVERAGE) || d_tmp ? d_tmp : b->d_grav;
-            e1 = glv::launch_bars(src, d_final, units, b->p.n, b->p.bars, b->bar_nsteps, b->d_bar_items, b->d_bar_desc, b->d_bar_w, st);
-            if (e1 != hipSuccess) return fail(GLV_ERR_HIP, "bars launch failed: %s", hipGetErrorString(e1));
+        b->grav_cur = grav_next;
+        if (ops & GLV_OP_SMOOTH) {                 // render.c:694-718 on the finished rows (a SMOOTH chain always has an output buffer)
+            e = glv::launch_smooth(a2.out, units, b->p.n, b->d_smin, b->d_smax, b->smooth_asz, b->smooth_reach, b->smooth_window, st);
+            if (e != hipSuccess) return fail(GLV_ERR_HIP, "smooth launch failed: %s", hipGetErrorString(e));
         }
-        return GLV_OK;
+        if (ops & GLV_OP_BARS) {
+            e = glv::launch_bars(d_tmp, d_final, units, b->p.n, b->p.bars, b->bar_nsteps, b->d_bar_items, b->d_bar_desc, b->d_bar_w, st);
+            if (e != hipSuccess) return fail(GLV_ERR_HIP, "bars launch failed: %s", hipGetErrorString(e));
+        }
+        return timed_launch_end(b, st);            // the HIP-event window covers every launch of the chain
     }
     if (gl_split) a.gl_storage = 1;                                  // operators on planar rows: the post kernel models it directly
 
     if (int rc = timed_launch_begin(b, st)) return rc;
-    hipError_t e;
     const unsigned core = ops & (GLV_OP_FFT | GLV_OP_GRAVITY | GLV_OP_AVERAGE | GLV_OP_WRANGE | GLV_OP_MAGNITUDE | GLV_OP_R16);
     if (!core) {                                   // smooth / bars only: operate on a copy of the input rows
         if (in_mode != glv::IN_F32_PLANAR) return fail(GLV_ERR_INVALID, "operators without GLV_OP_FFT take planar f32 input");
@@ -464,8 +550,8 @@ int process(glv_batch* b, const void* d_in, int in_mode, float* d_out, unsigned 
             : hipMemcpyAsync(d_out, d_in, sizeof(float) * (size_t) units * b->p.n, hipMemcpyDeviceToDevice, st);
         b->kernel_name = "glv_smooth_kernel";
     } else if (ops & GLV_OP_FFT) {
-        b->last_grid = frame_grid(b, units, in_mode, ops);
-        e = glv::launch_frame(b->log_nn, in_mode, (int) b->p.log_mode, a, b->last_grid, st);
+        b->last_grid = grid; b->last_variant = variant;
+        e = glv::launch_frame(b->log_nn, in_mode, (int) b->p.log_mode, variant, a, grid, st);
         b->kernel_name = "glv_frame_kernel";
     } else {
         if (in_mode != glv::IN_F32_PLANAR) return fail(GLV_ERR_INVALID, "operators without GLV_OP_FFT take planar f32 input");
@@ -473,19 +559,17 @@ int process(glv_batch* b, const void* d_in, int in_mode, float* d_out, unsigned 
         b->kernel_name = "glv_post_kernel";
     }
     if (e != hipSuccess) return fail(GLV_ERR_HIP, "kernel launch failed: %s", hipGetErrorString(e));
-    if (int rc = timed_launch_end(b, st)) return rc;
     if (ops & GLV_OP_AVERAGE) b->head = (b->head + 1) % b->p.avg_frames;
+    b->grav_cur = grav_next;
     if (ops & GLV_OP_SMOOTH) {                     // render.c:694-718, in place on the finished rows
-        if (int rc = ensure_smooth_tables(b)) return rc;
         e = glv::launch_smooth(d_out, units, b->p.n, b->d_smin, b->d_smax, b->smooth_asz, b->smooth_reach, b->smooth_window, st);
         if (e != hipSuccess) return fail(GLV_ERR_HIP, "smooth launch failed: %s", hipGetErrorString(e));
     }
     if ((ops & GLV_OP_BARS) && !fused_bars) {
-        if (int rc = ensure_bar_tables(b)) return rc;
-        e = glv::launch_bars(d_out ? d_out : b->d_grav, d_final, units, b->p.n, b->p.bars, b->bar_nsteps, b->d_bar_items, b->d_bar_desc, b->d_bar_w, st);
+        e = glv::launch_bars(d_out ? d_out : b->grav_cur, d_final, units, b->p.n, b->p.bars, b->bar_nsteps, b->d_bar_items, b->d_bar_desc, b->d_bar_w, st);
         if (e != hipSuccess) return fail(GLV_ERR_HIP, "bars launch failed: %s", hipGetErrorString(e));
     }
-    return GLV_OK;
+    return timed_launch_end(b, st);
 }
 
 int batch_create_rows(const glv_params* p, uint32_t streams, unsigned ops_mask, int device, bool single_row, glv_batch** out) {
@@ -507,8 +591,14 @@ int batch_create_rows(const glv_params* p, uint32_t streams, unsigned ops_mask, 
     b->p = *p; b->streams = streams; b->ops_mask = ops_mask; b->device = device;
     b->log_nn = log2_exact(p->n) - 1;
     hipDeviceProp_t prop;
-    if (hipGetDeviceProperties(&prop, device) == hipSuccess) b->num_cus = prop.multiProcessorCount;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess) {
+        b->num_cus = prop.multiProcessorCount;
+        std::snprintf(b->device_name, sizeof(b->device_name), "%s", prop.gcnArchName[0] ? prop.gcnArchName : prop.name);
+    }
     int rc = b->tab.create(p->n);
+    // the tilt table of the batch's own parameters is uploaded here, so that the stream-ordered calls do not copy
+    // (set_tilt copies again only when fft_scale / fft_cutoff / log_mode change: the single-stream drop-ins allow that)
+    if (rc == GLV_OK) rc = b->tab.set_tilt(p->fft_scale, p->fft_cutoff, p->log_mode == 1);
     if (rc == GLV_OK) rc = batch_alloc(b, single_row ? 1u : streams * 2u);
     if (rc != GLV_OK) { glv_batch_destroy(b); return rc; }
     *out = b;
@@ -564,7 +654,7 @@ int glv_batch_reset(glv_batch* b) {
     if (b->d_grav) HIP_TRY(hipMemset(b->d_grav, 0, sizeof(float) * rows * n));
     if (b->d_ring) HIP_TRY(hipMemset(b->d_ring, 0, sizeof(int16_t) * 2 * n * b->streams));
     if (b->d_ring_f32) HIP_TRY(hipMemset(b->d_ring_f32, 0, sizeof(float) * 2 * n * b->streams));
-    b->head = 0; b->ring_pos = 0; b->ring_pos_f32 = 0; b->grav_mode = 0;
+    b->head = 0; b->ring_pos = 0; b->ring_pos_f32 = 0; b->grav_mode = 0; b->grav_cur = b->d_grav;
     return GLV_OK;
 }
 
@@ -673,7 +763,10 @@ int glv_batch_ring_update_f32(glv_batch* b, const float* d_new, uint32_t new_fra
 int glv_batch_gravity_state(glv_batch* b, const float** d_state) {
     if (!b || !d_state) return fail(GLV_ERR_INVALID, "NULL argument");
     if (!b->d_grav) return fail(GLV_ERR_STATE, "the batch was created without GLV_OP_GRAVITY");
-    *d_state = b->d_grav;
+    if (b->grav_mode == 2)
+        return fail(GLV_ERR_STATE, "gravity runs fused with average on this batch: its state is the newest slot of the history ring "
+                                   "(float [rows][F][n], not a [streams][2][n] array); request the chain's output instead");
+    *d_state = b->grav_cur;
     return GLV_OK;
 }
 
@@ -734,14 +827,17 @@ uint64_t glv_batch_algorithmic_bytes(const glv_batch* b, unsigned ops, int input
     if (!b) return 0;
     // SURVEY.md 8d, per stereo frame with N real samples per channel, F = avg_frames:
     //   in: 4N (s16 x 2ch) or 8N (f32 x 2ch);  out: 8N
-    //   + gravity (no average): 20N in SURVEY 8d row B, which lets the output double as the state; this
-    //     implementation keeps a separate state buffer (one more 8N write) but reports the survey's figure
+    //   + gravity (no average): 20N in SURVEY 8d row B -- the output doubles as the state (what process() does unless
+    //     GLV_OP_PRIVATE_STATE asks for the batch-owned copy: one more 8N write, 28N)
     //   + average: read (F-1) ring slots 8N each, write the newest slot 8N (doubles as gravity state)
     //   GLV_OP_R16: the output is 2 bytes per value: 4N instead of 8N
     const uint64_t N = b->p.n, F = b->p.avg_frames;
     uint64_t per = (input_is_s16 ? 4 * N : 8 * N) + ((ops & GLV_OP_R16) ? 4 * N : 8 * N);
     if (ops & GLV_OP_AVERAGE) per += 8 * N * (F - 1) + 8 * N;
-    else if (ops & GLV_OP_GRAVITY) per += 8 * N;
+    else if (ops & GLV_OP_GRAVITY) per += 8 * N + ((ops & (GLV_OP_PRIVATE_STATE | GLV_OP_R16)) ? 8 * N : 0);   // texel output: the f32 state is written besides
+    // gl_storage: the chain is the reference's pass structure -- the f32 spectra are written by the transform and read
+    // back by the gravity / average pass
+    if (b->p.gl_storage && (ops & GLV_OP_FFT) && (ops & (GLV_OP_GRAVITY | GLV_OP_AVERAGE))) per += 16 * N;
     return per * b->streams;
 }
 
@@ -749,7 +845,12 @@ const char* glv_batch_kernel_name(const glv_batch* b) { return b ? b->kernel_nam
 
 int glv_batch_last_grid(const glv_batch* b) { return b ? b->last_grid : 0; }
 
-int glv_wisdom_clear(void) { std::lock_guard<std::mutex> lock(g_wisdom_mu); g_wisdom.clear(); return GLV_OK; }
+int glv_wisdom_clear(void) {
+    std::lock_guard<std::mutex> lock(g_wisdom_mu);
+    g_wisdom.clear();
+    g_wisdom_gen.fetch_add(1, std::memory_order_release);
+    return GLV_OK;
+}
 int glv_wisdom_count(void) { std::lock_guard<std::mutex> lock(g_wisdom_mu); return (int) g_wisdom.size(); }
 int glv_wisdom_load(const char* path) {
     if (!path) return fail(GLV_ERR_INVALID, "path is NULL");
@@ -760,16 +861,18 @@ int glv_wisdom_save(const char* path) {
     if (!path) return fail(GLV_ERR_INVALID, "path is NULL");
     FILE* f = std::fopen(path, "w");
     if (!f) return fail(GLV_ERR_INVALID, "cannot write wisdom file %s", path);
-    std::fprintf(f, "# glv launch wisdom: n input_kind ops_class log_mode log2(streams) workgroups ms_per_launch\n");
+    std::fprintf(f, "# glv launch wisdom v2: device compute_units n input_kind ops_class log_mode log2(streams) avg_frames variant workgroups ms_per_launch\n");
     std::lock_guard<std::mutex> lock(g_wisdom_mu);
     for (const WisdomEntry& e : g_wisdom)
-        std::fprintf(f, "%u %u %u %u %u %d %.6f\n", e.k.n, e.k.in_kind, e.k.ops_class, e.k.log_mode, e.k.streams_log2, e.grid, (double) e.ms);
+        std::fprintf(f, "%s %u %u %u %u %u %u %u %d %d %.6f\n", e.k.device, e.k.cus, e.k.n, e.k.in_kind, e.k.ops_class, e.k.log_mode, e.k.streams_log2,
+                     e.k.avg_frames, e.variant, e.grid, (double) e.ms);
     std::fclose(f);
     return GLV_OK;
 }
 
-// Time the candidate workgroup counts for this batch's (size, chain, stream count) on its device and remember the
-// fastest.  The probe launches are real updates of every stream: stateful chains are reset afterwards.
+// Time every kernel configuration built for this batch's size (glv_inst.hip Tuned<K, V>) on a few workgroup counts each, on
+// the batch's device with the caller's buffers, and remember the fastest (variant, workgroups) for this (device, size, input,
+// chain, log mode, stream count).  The probe launches are real updates of every stream: stateful chains are reset afterwards.
 int glv_batch_autotune(glv_batch* b, const int16_t* d_pcm, float* d_out, unsigned ops, void* hip_stream, int* best_grid, float* best_ms) {
     if (!b) return fail(GLV_ERR_INVALID, "batch is NULL");
     if (!(ops & GLV_OP_FFT)) return fail(GLV_ERR_INVALID, "autotune needs GLV_OP_FFT (it tunes the frame kernel)");
@@ -778,23 +881,27 @@ int glv_batch_autotune(glv_batch* b, const int16_t* d_pcm, float* d_out, unsigne
     hipStream_t st = (hipStream_t) hip_stream;
     HIP_TRY(hipSetDevice(b->device));
     const uint32_t units = b->streams * 2;
-    const uint32_t slots = (uint32_t) glv::frame_slots(b->log_nn);
-    const uint32_t wgs = (units + slots - 1) / slots;
-    const uint32_t round = (uint32_t) b->num_cus * (uint32_t) glv::frame_resident(b->log_nn);
-    std::vector<int> cand;
-    for (uint32_t g : { round / 2, round, round * 3 / 2, round * 2, round * 4 }) {
-        const int c = (int) (g < 1 ? 1 : (g > wgs ? wgs : g));
-        bool dup = false;
-        for (int x : cand) dup |= x == c;
-        if (!dup) cand.push_back(c);
+    struct Cand { int variant, grid; };
+    std::vector<Cand> cand;
+    for (int v = 0; v < glv::frame_variants(b->log_nn); ++v) {
+        if (!glv::frame_variant_ok(b->log_nn, glv::IN_S16_STEREO, (int) b->p.log_mode, v)) continue;
+        const glv::FrameGeometry geo = glv::frame_geometry(b->log_nn, v);
+        const uint32_t wgs = (units + geo.rows_per_trip - 1) / geo.rows_per_trip;
+        const uint32_t round = (uint32_t) b->num_cus * (uint32_t) geo.resident;
+        for (uint32_t g : { round / 2, round, round * 3 / 2, round * 2, round * 4 }) {
+            const int c = (int) (g < 1 ? 1 : (g > wgs ? wgs : g));
+            bool dup = false;
+            for (const Cand& x : cand) dup |= x.variant == v && x.grid == c;
+            if (!dup) cand.push_back(Cand{v, c});
+        }
     }
     hipEvent_t e0, e1;
     HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1));
-    const int saved = b->grid_override;
-    int best = 0; float bms = 0.f; int rc = GLV_OK;
+    const int saved_grid = b->grid_override, saved_variant = b->variant_override;
+    Cand best{0, 0}; float bms = 0.f; int rc = GLV_OK;
     for (int pass = 0; pass < 2 && rc == GLV_OK; ++pass)                 // pass 0 warms the clocks up, pass 1 is measured
-        for (int g : cand) {
-            b->grid_override = g;
+        for (const Cand& c : cand) {
+            b->grid_override = c.grid; b->variant_override = c.variant;
             const int iters = pass == 0 ? 3 : 8;
             if (hipEventRecord(e0, st) != hipSuccess) { rc = fail(GLV_ERR_HIP, "hipEventRecord failed"); break; }
             for (int i = 0; i < iters && rc == GLV_OK; ++i) rc = process(b, d_pcm, glv::IN_S16_STEREO, d_out, ops, units, 0, st);
@@ -804,14 +911,14 @@ int glv_batch_autotune(glv_batch* b, const int16_t* d_pcm, float* d_out, unsigne
                 rc = fail(GLV_ERR_HIP, "event timing failed"); break;
             }
             ms /= (float) iters;
-            if (pass == 1 && (best == 0 || ms < bms)) { best = g; bms = ms; }
+            if (pass == 1 && (best.grid == 0 || ms < bms)) { best = c; bms = ms; }
         }
-    b->grid_override = saved;
+    b->grid_override = saved_grid; b->variant_override = saved_variant;
     (void) hipEventDestroy(e0); (void) hipEventDestroy(e1);
     if (rc != GLV_OK) return rc;
     if (ops & (GLV_OP_GRAVITY | GLV_OP_AVERAGE)) { if (int r2 = glv_batch_reset(b)) return r2; }
-    wisdom_store(WisdomKey{b->p.n, (uint32_t) glv::IN_S16_STEREO, ops_class_of(ops), b->p.log_mode, log2_round(b->streams)}, best, bms);
-    if (best_grid) *best_grid = best;
+    wisdom_store(wisdom_key(b, glv::IN_S16_STEREO, ops), best.variant, best.grid, bms);
+    if (best_grid) *best_grid = best.grid;
     if (best_ms) *best_ms = bms;
     return GLV_OK;
 }
@@ -820,6 +927,25 @@ int glv_batch_autotune(glv_batch* b, const int16_t* d_pcm, float* d_out, unsigne
 int glv_batch_set_grid(glv_batch* b, int grid) {
     if (!b) return fail(GLV_ERR_INVALID, "batch is NULL");
     b->grid_override = grid;
+    return GLV_OK;
+}
+int glv_batch_set_variant(glv_batch* b, int variant) {
+    if (!b) return fail(GLV_ERR_INVALID, "batch is NULL");
+    if (variant >= glv::frame_variants(b->log_nn))
+        return fail(GLV_ERR_INVALID, "variant %d: n=%u has %d kernel configuration(s)", variant, b->p.n, glv::frame_variants(b->log_nn));
+    b->variant_override = variant < 0 ? -1 : variant;
+    return GLV_OK;
+}
+int glv_batch_variants(const glv_batch* b) { return b ? glv::frame_variants(b->log_nn) : 0; }
+int glv_batch_last_variant(const glv_batch* b) { return b ? b->last_variant : 0; }
+int glv_batch_describe_variant(const glv_batch* b, int variant, char* buf, size_t len) {
+    if (!b || !buf || len == 0) return fail(GLV_ERR_INVALID, "NULL argument");
+    if (variant < 0 || variant >= glv::frame_variants(b->log_nn)) return fail(GLV_ERR_INVALID, "variant %d out of range", variant);
+    const glv::FrameGeometry g = glv::frame_geometry(b->log_nn, variant);
+    std::snprintf(buf, len, "n=%u variant %d: %d points per lane, %d lanes per row, %d row(s) per workgroup, %d workgroup(s) per CU, "
+                            "%d KiB LDS, twiddles %s, window %s", b->p.n, variant, 1 << g.log_e, g.lanes, g.slots, g.resident, (g.lds_bytes + 1023) / 1024,
+                  g.twreg == 1 ? "in VGPRs" : g.twreg == 0 ? "through L2" : g.twreg == 4 ? "in LDS" : "middle passes in LDS, last pass through L2",
+                  g.winlds ? "in LDS" : "through L2");
     return GLV_OK;
 }
 
@@ -854,7 +980,7 @@ int glv_state_reset(glv_state* s) {
     const size_t n = b->p.n;
     HIP_TRY(hipMemset(b->d_hist, 0, sizeof(float) * b->p.avg_frames * n));
     HIP_TRY(hipMemset(b->d_grav, 0, sizeof(float) * n));
-    b->head = 0; b->grav_mode = 0;
+    b->head = 0; b->grav_mode = 0; b->grav_cur = b->d_grav;
     return GLV_OK;
 }
 

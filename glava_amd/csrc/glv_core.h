@@ -108,8 +108,8 @@ GLV_HD void butterfly(cf& a, cf& b, const cf w) {
 // no -0.0 (then (-0) - (-0) would give +0) and no Inf/NaN.  That holds for every value this
 // path produces: PCM samples and window factors are finite, v/65535 and x*w (w > 0.07) are never
 // -0, and a +- t under round-to-nearest yields -0 only from (-0) operands (induction over the
-// stages).  Planar f32 input containing -0.0f or non-finite samples is the one case where the
-// sign of an exact zero in GLV_OP_RAW output may differ from the reference; magnitudes never do.
+// stages).  f32 input may contain -0.0f or non-finite samples, so the f32 kernels do not take this shortcut
+// (SubPass::run UNIT_SHORTCUT = false).
 GLV_HD void butterfly_unit(cf& a, cf& b) {
 #if defined(__HIP_DEVICE_COMPILE__)
     const glv_f2 A = { a.x, a.y }, B = { b.x, b.y };
@@ -152,8 +152,13 @@ struct SubPass {
 
     // FIRST: the sub-pass starts at L0 = 1, so k0 = 0 for every lane: the twiddles are wave-uniform
     // (scalar registers) and the ksub = 0 twiddle of each stage is exactly (1, +0).
-    template <bool FIRST>
+    // UNIT_SHORTCUT: that twiddle's butterfly is evaluated as a +- b (butterfly_unit) -- bit-exact when b holds no -0.0, Inf
+    // or NaN, which is guaranteed for s16 input only.  The f32 input paths pass false and perform the reference's full
+    // multiply-add form with the table's (1, +0), so that (+0) * Inf = NaN and the sign of an exact zero come out as in the
+    // reference (tests/test_concurrency_state.py::test_f32_special_values_against_the_compiled_reference).
+    template <bool FIRST, bool UNIT_SHORTCUT = true>
     GLV_HD static void run(cf (&v)[R], const cf (&tw)[R > 1 ? R - 1 : 1]) {
+        constexpr bool SC = FIRST && UNIT_SHORTCUT;
 #pragma unroll
         for (int s = 0; s < RB; ++s) {
             const int bit = 1 << (RB - 1 - s);
@@ -166,17 +171,17 @@ struct SubPass {
 #pragma unroll
                 for (int j = 0; j < GRP; ++j) {
                     const int r0 = lo_slot(g0 + j, bit);
-                    if (!(FIRST && ksub_of(r0, s) == 0)) bf_mul<FIRST>(p02[j], p13[j], v[r0 | bit], tw[(1 << s) - 1 + ksub_of(r0, s)]);
+                    if (!(SC && ksub_of(r0, s) == 0)) bf_mul<FIRST>(p02[j], p13[j], v[r0 | bit], tw[(1 << s) - 1 + ksub_of(r0, s)]);
                 }
 #pragma unroll
                 for (int j = 0; j < GRP; ++j) {
                     const int r0 = lo_slot(g0 + j, bit);
-                    if (!(FIRST && ksub_of(r0, s) == 0)) bf_t(t[j], p02[j], p13[j]);
+                    if (!(SC && ksub_of(r0, s) == 0)) bf_t(t[j], p02[j], p13[j]);
                 }
 #pragma unroll
                 for (int j = 0; j < GRP; ++j) {
                     const int r0 = lo_slot(g0 + j, bit);
-                    if (FIRST && ksub_of(r0, s) == 0) butterfly_unit(v[r0], v[r0 | bit]);
+                    if (SC && ksub_of(r0, s) == 0) butterfly_unit(v[r0], v[r0 | bit]);
                     else bf_out(v[r0], v[r0 | bit], t[j]);
                 }
             }
@@ -184,7 +189,7 @@ struct SubPass {
 #pragma unroll
             for (int r0 = 0; r0 < R; ++r0) {
                 if (r0 & bit) continue;
-                if (FIRST && ksub_of(r0, s) == 0) butterfly_unit(v[r0], v[r0 | bit]);
+                if (SC && ksub_of(r0, s) == 0) butterfly_unit(v[r0], v[r0 | bit]);
                 else butterfly<FIRST>(v[r0], v[r0 | bit], tw[(1 << s) - 1 + ksub_of(r0, s)]);
             }
 #endif
@@ -360,6 +365,15 @@ GLV_HD float log_third_table(float y, const LogEntry* tab) {
 }
 
 template <> GLV_HD float log_third<0>(float y, const LogEntry* tab) { return log_third_table(y, tab); }
+// y = +Inf or NaN (f32 input rows holding non-finite samples): the reference's (float)(log(y) / 3) is y itself (Inf) or NaN.
+// The hardware log of mode 1 and libm's of mode 2 do that on their own; the table-driven log of mode 0 decodes the exponent
+// field and needs the select.  s16 input cannot produce such values (|FFT output| <= n / 2), its kernels skip it.
+template <int LOG_MODE, bool NONFINITE>
+GLV_HD float log_third_nf(float y, const LogEntry* tab) {
+    const float r = log_third<LOG_MODE>(y, tab);
+    if constexpr (LOG_MODE == 0 && NONFINITE) return __builtin_bit_cast(uint32_t, y) >= 0x7f800000u ? y : r;
+    else return r;
+}
 // mode 1 returns log2(y); the ln2/3 factor is folded into the tilt table the kernel multiplies with
 // (glv_tables.h make_tilt with fold_ln2_3), one multiply less per value
 template <> GLV_HD float log_third<1>(float y, const LogEntry*) { return GLV_LOG2F(y); }

@@ -25,7 +25,7 @@ enum InMode { IN_S16_STEREO = 0, IN_F32_PLANAR = 1, IN_S16_RING = 2, IN_F32_STER
 enum Epi { EPI_RAW = 0, EPI_MAG = 1, EPI_MAG_STATE = 2, EPI_RAW_STATE = 3 };
 
 // ops bits as in include/glv_spectrum.h
-enum : uint32_t { OP_FFT = 1u, OP_GRAVITY = 2u, OP_AVERAGE = 4u, OP_RAW = 8u, OP_WRANGE = 16u, OP_BARS = 32u, OP_SMOOTH = 64u, OP_MAGNITUDE = 128u, OP_R16 = 256u };
+enum : uint32_t { OP_FFT = 1u, OP_GRAVITY = 2u, OP_AVERAGE = 4u, OP_RAW = 8u, OP_WRANGE = 16u, OP_BARS = 32u, OP_SMOOTH = 64u, OP_MAGNITUDE = 128u, OP_R16 = 256u, OP_PRIVATE_STATE = 512u };
 
 // one output bar of GLV_OP_BARS: taps are consecutive bins [first_bin, first_bin + count) with weights
 // tap_w[tap_offset ...]; weight_sum = float sum of the weights in tap order (smooth.glsl:31-36)
@@ -40,7 +40,10 @@ struct FrameArgs {
     const void* in;        // s16: int16 [units/2][n][2] (a unit is one channel row of a frame);  f32 planar: float [units][n];
                            // f32 stereo (PulseAudio layout, pulse_input.c:155-178): float [units/2][n][2]
     float* out;            // [units][n]
-    float* grav;           // [rows][n] gravity state (only when gravity without average)
+    const float* grav;     // [rows][n] gravity state read by gravity without average: the previous gravity output
+    float* grav_w;         // [rows][n] where that chain stores its new state.  transform_gravity's output IS its new state
+                           // (render.c:733-734), so the host points this at the caller's output buffer (and leaves `out` NULL)
+                           // unless a private copy was asked for; == grav for the in-place form
     float* hist;           // [rows][F][n] history ring (average); doubles as gravity state
     const cf* tw;          // nn-1 twiddles, layout glv::tw_offset
     const double* win;     // n window values (render.c:660 as expanded at :794)
@@ -160,10 +163,10 @@ GLV_HD cf apply_state(cf val, uint32_t off, size_t row, uint32_t n, const FrameA
         const bool ring = (a.ops & OP_AVERAGE) != 0;
         float* h = ring ? a.hist + row * (size_t) F * n : nullptr;            // uniform
         if (a.ops & OP_GRAVITY) {
-            float* gs = ring ? h + (size_t) (F == 1 ? a.head : ring_slot(a.head, F - 2, F)) * n : a.grav + row * (size_t) n;
+            const float* gs = ring ? h + (size_t) (F == 1 ? a.head : ring_slot(a.head, F - 2, F)) * n : a.grav + row * (size_t) n;
             const cf st0 = ld<cf>(gs, off);                                   // the store texture == the previous newest ring slot
             val.x = through_r16(gravity(val.x, st0.x, a.g)); val.y = through_r16(gravity(val.y, st0.y, a.g));
-            if (!ring) st<cf>(gs, off, val);
+            if (!ring) st<cf>(a.grav_w + row * (size_t) n, off, val);
         }
         if (ring) {
             cf acc = { 0.0f, 0.0f };
@@ -208,10 +211,9 @@ GLV_HD cf apply_state(cf val, uint32_t off, size_t row, uint32_t n, const FrameA
         val.x = acc.x / a.F_as_float;                                        // render.c:761
         val.y = acc.y / a.F_as_float;
     } else if (a.ops & OP_GRAVITY) {
-        float* gs = a.grav + row * (size_t) n;                               // uniform
-        const cf st0 = ld<cf>(gs, off);
+        const cf st0 = ld<cf>(a.grav + row * (size_t) n, off);               // uniform base
         val.x = gravity(val.x, st0.x, a.g); val.y = gravity(val.y, st0.y, a.g);
-        st<cf>(gs, off, val);
+        st<cf>(a.grav_w + row * (size_t) n, off, val);
     }
     return val;
 }
@@ -289,14 +291,15 @@ GLV_HD void apply_state_block(cf (&val)[NV], const uint32_t (&off)[NV], size_t r
             val[e].y = acc[e].y / a.F_as_float;
         }
     } else if (a.ops & OP_GRAVITY) {
-        float* gs = a.grav + row * (size_t) n;                               // uniform
+        const float* gs = a.grav + row * (size_t) n;                         // uniform
+        float* gw = a.grav_w + row * (size_t) n;
         cf st0[NV];
 #pragma unroll
         for (int e = 0; e < NV; ++e) st0[e] = ld<cf>(gs, off[e]);
 #pragma unroll
         for (int e = 0; e < NV; ++e) {
             val[e].x = gravity(val[e].x, st0[e].x, a.g); val[e].y = gravity(val[e].y, st0[e].y, a.g);
-            st<cf>(gs, off[e], val[e]);
+            st<cf>(gw, off[e], val[e]);
         }
     }
 }
@@ -568,7 +571,7 @@ struct Frame {
     }
 
     // ---- compute pass PASS in registers -----------------------------------------------------------
-    template <int PASS>
+    template <int PASS, bool UNIT_SHORTCUT = true>
     GLV_HD static void compute(cf (&v)[E], const cf (&tw)[PassInfo<PASS>::NTW]) {
         using PI = PassInfo<PASS>;
 #pragma unroll
@@ -576,7 +579,7 @@ struct Frame {
             cf(&vg)[PI::R] = *reinterpret_cast<cf(*)[PI::R]>(&v[gi * PI::R]);
             const cf(&tg)[PI::R > 1 ? PI::R - 1 : 1] =
                 *reinterpret_cast<const cf(*)[PI::R > 1 ? PI::R - 1 : 1]>(&tw[gi * (PI::R - 1)]);
-            SubPass<PI::RB>::template run<PASS == 0>(vg, tg);
+            SubPass<PI::RB>::template run<PASS == 0, UNIT_SHORTCUT>(vg, tg);
         }
     }
 
@@ -694,7 +697,8 @@ struct Frame {
     // TILTREG 0: tilt factors read from the table per row; 1: from `tl_reg` (registers, gathered once per
     // kernel); 2: evaluated in registers with the reference's float operations (no memory at all)
     // R16: the output row is uint16 [n] (GL_R16 texels, glv_core.h unorm16) instead of float [n]; state stays f32
-    template <int LOG_MODE, int EPI, int TILTREG = 0, bool R16 = false>
+    // NONFINITE: the row may hold Inf / NaN (f32 input): log_mode 0 then needs log_third_nf's select
+    template <int LOG_MODE, int EPI, int TILTREG = 0, bool R16 = false, bool NONFINITE = false>
     GLV_HD static void epilogue(const cf (&v)[E], float* out_row, size_t row, int tid, const FrameArgs& a,
                                 const LogEntry* logtab, const cf* tl_reg = nullptr) {
         using PI = PassInfo<P - 1>;
@@ -712,8 +716,8 @@ struct Frame {
                     tl.x = tilt_factor<LOG_MODE == 1>(2 * q, a.inv_n, a.fft_scale, a.one_minus_cutoff);
                     tl.y = tilt_factor<LOG_MODE == 1>(2 * q + 1, a.inv_n, a.fft_scale, a.one_minus_cutoff);
                 } else tl = ld<cf>(a.tilt, (uint32_t) q * 8u);
-                val.x = log_third<LOG_MODE>(y0, logtab) * tl.x;
-                val.y = log_third<LOG_MODE>(y1, logtab) * tl.y;
+                val.x = log_third_nf<LOG_MODE, NONFINITE>(y0, logtab) * tl.x;
+                val.y = log_third_nf<LOG_MODE, NONFINITE>(y1, logtab) * tl.y;
             }
 #endif
             return val;
@@ -780,7 +784,8 @@ struct Frame {
             // up front (2E registers) and its latency hides behind the log/tilt arithmetic -- in blocks, as below,
             // every block's loads were a separate exposed round trip (N=4096 fft+gravity: 0.72 -> ms)
             if (!(a.ops & OP_AVERAGE) && (a.ops & OP_GRAVITY) && E <= 32) {
-                float* gs = a.grav + row * (size_t) N;
+                const float* gs = a.grav + row * (size_t) N;
+                float* gw = a.grav_w + row * (size_t) N;
                 if constexpr (SWAP_DEV) {
                     cf2 st0[E / 2];
 #pragma unroll
@@ -794,7 +799,7 @@ struct Frame {
                             const int p = 2 * p2 + k;
                             t[k].a.x = gravity(t[k].a.x, st0[p].a.x, a.g); t[k].a.y = gravity(t[k].a.y, st0[p].a.y, a.g);
                             t[k].b.x = gravity(t[k].b.x, st0[p].b.x, a.g); t[k].b.y = gravity(t[k].b.y, st0[p].b.y, a.g);
-                            st<cf2>(gs, pair_offset(tid, p), t[k]);
+                            st<cf2>(gw, pair_offset(tid, p), t[k]);
                             if (out_row != nullptr) store_pair(pair_offset(tid, p), t[k]);
                         }
                     }
@@ -814,10 +819,10 @@ struct Frame {
                         cf vb = value(gi + 1, r);
                         vb.x = gravity(vb.x, st0[idx + 1].x, a.g); vb.y = gravity(vb.y, st0[idx + 1].y, a.g);
                         cf2 two; two.a = va; two.b = vb;
-                        st<cf2>(gs, off, two);
+                        st<cf2>(gw, off, two);
                         if (out_row != nullptr) store_pair(off, two);
                     } else {
-                        st<cf>(gs, off, va);
+                        st<cf>(gw, off, va);
                         if (out_row != nullptr) store_point(off, va);
                     }
                 }

@@ -109,7 +109,8 @@ struct PhaseClock { __device__ __forceinline__ void start() {} };
 #define GLV_PHASE(clk, slot) ((void) 0)
 #endif
 
-template <int LOG_NN, int LOG_E, int NBUF, int TWREG>
+// UNIT_SHORTCUT: pass 0 evaluates its (1, +0) twiddles as a +- b (s16 input only, glv_core.h SubPass::run)
+template <int LOG_NN, int LOG_E, int NBUF, int TWREG, bool UNIT_SHORTCUT = true>
 struct Body {
     using FR = Frame<LOG_NN, LOG_E>;
     static constexpr int P = FR::P, NN = FR::NN, N = FR::N, T = FR::T;
@@ -173,7 +174,7 @@ struct Body {
 #if defined(GLV_EXP_NOCOMPUTE)        /* tools/tune.py timing experiment only: memory traffic without the transform */
         return;
 #endif
-        FR::template compute<PASS>(v, tw_ref<PASS>(tw_all));
+        FR::template compute<PASS, UNIT_SHORTCUT>(v, tw_ref<PASS>(tw_all));
         GLV_PHASE(clk, 1 + PASS);
         if constexpr (PASS + 1 < P) {
             char* xb = xslot + (NBUF == 2 ? (size_t) (xcount & 1u) * FR::XREGION * sizeof(cf) : 0);
@@ -219,11 +220,13 @@ template <int LOG_NN, int IN_MODE, int LOG_MODE, int SLOTS, int NBUF, int TWREG,
 __global__ void __launch_bounds__((Frame<LOG_NN, LOG_E>::T * SLOTS), OCC)
 glv_frame_kernel(const FrameArgs a) {
     using FR = Frame<LOG_NN, LOG_E>;
-    using BD = Body<LOG_NN, LOG_E, NBUF, TWREG>;
     constexpr int E = FR::E;
     constexpr int T = FR::T, N = FR::N;
     constexpr bool RING = IN_MODE == IN_S16_RING;
     constexpr bool S16 = IN_MODE == IN_S16_STEREO || RING;
+    // f32 rows may hold -0.0, Inf and NaN: no unit-twiddle shortcut, non-finite values through the bit-faithful log
+    constexpr bool NF = !S16;
+    using BD = Body<LOG_NN, LOG_E, NBUF, TWREG, S16>;
     constexpr bool WAVE_SLOT = (T % 64) == 0;      // a wave never straddles two slots
     constexpr size_t XBYTES = (size_t) FR::XREGION * sizeof(cf);
 
@@ -298,18 +301,18 @@ glv_frame_kernel(const FrameArgs a) {
                                     : (HAS_STATE && a.out == nullptr ? nullptr : a.out + row * N);
         if constexpr (STATEFUL == 4) {
             float* out16 = reinterpret_cast<float*>(reinterpret_cast<uint16_t*>(a.out) + row * N);
-            if (raw_out) FR::template epilogue<LOG_MODE, EPI_RAW_STATE, 0, true>(v, out16, row, tid, a, logtab);
-            else FR::template epilogue<LOG_MODE, EPI_MAG_STATE, TILTREG, true>(v, out16, row, tid, a, logtab, tilt_reg);
+            if (raw_out) FR::template epilogue<LOG_MODE, EPI_RAW_STATE, 0, true, NF>(v, out16, row, tid, a, logtab);
+            else FR::template epilogue<LOG_MODE, EPI_MAG_STATE, TILTREG, true, NF>(v, out16, row, tid, a, logtab, tilt_reg);
         } else if constexpr (HAS_STATE) {
-            if (raw_out) FR::template epilogue<LOG_MODE, EPI_RAW_STATE>(v, out_row, row, tid, a, logtab);
-            else FR::template epilogue<LOG_MODE, EPI_MAG_STATE, TILTREG>(v, out_row, row, tid, a, logtab, tilt_reg);
+            if (raw_out) FR::template epilogue<LOG_MODE, EPI_RAW_STATE, 0, false, NF>(v, out_row, row, tid, a, logtab);
+            else FR::template epilogue<LOG_MODE, EPI_MAG_STATE, TILTREG, false, NF>(v, out_row, row, tid, a, logtab, tilt_reg);
         } else if constexpr (STATEFUL == 3) {
             float* out16 = reinterpret_cast<float*>(reinterpret_cast<uint16_t*>(a.out) + row * N);
-            if (raw_out) FR::template epilogue<LOG_MODE, EPI_RAW, 0, true>(v, out16, row, tid, a, logtab);
-            else FR::template epilogue<LOG_MODE, EPI_MAG, TILTREG, true>(v, out16, row, tid, a, logtab, tilt_reg);
+            if (raw_out) FR::template epilogue<LOG_MODE, EPI_RAW, 0, true, NF>(v, out16, row, tid, a, logtab);
+            else FR::template epilogue<LOG_MODE, EPI_MAG, TILTREG, true, NF>(v, out16, row, tid, a, logtab, tilt_reg);
         } else {
-            if (raw_out) FR::template epilogue<LOG_MODE, EPI_RAW>(v, out_row, row, tid, a, logtab);
-            else FR::template epilogue<LOG_MODE, EPI_MAG, TILTREG>(v, out_row, row, tid, a, logtab, tilt_reg);
+            if (raw_out) FR::template epilogue<LOG_MODE, EPI_RAW, 0, false, NF>(v, out_row, row, tid, a, logtab);
+            else FR::template epilogue<LOG_MODE, EPI_MAG, TILTREG, false, NF>(v, out_row, row, tid, a, logtab, tilt_reg);
         }
     };
     // FUSED_BARS: lane k of a slot stores bar k (bars <= T): its weight sum stays in a register

@@ -7,22 +7,29 @@
 
 namespace glv {
 
+// what the host needs to know about one kernel configuration of one size (glv_inst.hip Tuned<K, V>)
+struct FrameGeometry {
+    int lanes;          // lanes cooperating on one row
+    int resident;       // workgroups that fit one CU
+    int rounds;         // rounds of resident workgroups a large launch is cut into
+    int rows_per_trip;  // channel rows one workgroup takes per trip of its persistent loop
+    int lds_bytes, log_e, slots, twreg, winlds;   // for diagnostics / the wisdom file's comments
+};
+
 // per-size production launchers, one translation unit each (glv_inst.hip -DGLV_LOG_NN=k)
 #define GLV_DECL_INST(K) \
-    hipError_t launch_frame_##K(int in_mode, int log_mode, const FrameArgs& a, int grid, hipStream_t st); \
-    int frame_slots_##K(); \
-    int frame_lanes_##K(); \
-    int frame_resident_##K(); \
-    int frame_rounds_##K();
+    hipError_t launch_frame_##K(int in_mode, int log_mode, int variant, const FrameArgs& a, int grid, hipStream_t st); \
+    int frame_variants_##K(); \
+    int frame_variant_ok_##K(int in_mode, int log_mode, int variant); \
+    FrameGeometry frame_geometry_##K(int variant);
 GLV_DECL_INST(7) GLV_DECL_INST(8) GLV_DECL_INST(9) GLV_DECL_INST(10) GLV_DECL_INST(11) GLV_DECL_INST(12) GLV_DECL_INST(13) GLV_DECL_INST(14)
 #undef GLV_DECL_INST
 
 // glv_misc.hip
-hipError_t launch_frame(int log_nn, int in_mode, int log_mode, const FrameArgs& a, int grid, hipStream_t st);
-int frame_slots(int log_nn);      // channel rows one workgroup takes per iteration of its persistent loop
-int frame_lanes(int log_nn);      // lanes cooperating on one row
-int frame_resident(int log_nn);   // workgroups of the production kernel that fit one CU
-int frame_rounds(int log_nn);     // rounds of resident workgroups a large launch is cut into
+hipError_t launch_frame(int log_nn, int in_mode, int log_mode, int variant, const FrameArgs& a, int grid, hipStream_t st);
+int frame_variants(int log_nn);                                        // kernel configurations built for this size (>= 1)
+bool frame_variant_ok(int log_nn, int in_mode, int log_mode, int variant);   // is `variant` built for this input / log mode
+FrameGeometry frame_geometry(int log_nn, int variant);
 hipError_t launch_post(const FrameArgs& a, uint32_t n, hipStream_t st);
 hipError_t launch_bufscale(const float* in, float* out, size_t total_out, uint32_t k, hipStream_t st);
 hipError_t launch_lerp(const float* s0, const float* e0, float* out, size_t total, float mod, hipStream_t st);

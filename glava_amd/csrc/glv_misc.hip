@@ -23,7 +23,7 @@ __global__ void __launch_bounds__(256) glv_post_kernel(const FrameArgs a, const 
         if (a.ops & OP_MAGNITUDE) {                                               // render.c:842-846
             const float y0 = __builtin_fabsf(val.x) + 1.0f, y1 = __builtin_fabsf(val.y) + 1.0f;
             const cf tl = ld<cf>(a.tilt, off);
-            if (a.log_mode == 0)      { val.x = log_third<0>(y0, a.logtab) * tl.x; val.y = log_third<0>(y1, a.logtab) * tl.y; }
+            if (a.log_mode == 0)      { val.x = log_third_nf<0, true>(y0, a.logtab) * tl.x; val.y = log_third_nf<0, true>(y1, a.logtab) * tl.y; }
             else if (a.log_mode == 1) { val.x = log_third<1>(y0, a.logtab) * tl.x; val.y = log_third<1>(y1, a.logtab) * tl.y; }
             else                      { val.x = log_third<2>(y0, a.logtab) * tl.x; val.y = log_third<2>(y1, a.logtab) * tl.y; }
         }
@@ -343,55 +343,33 @@ hipError_t launch_bars(const float* spec, float* bars_out, size_t nrows, uint32_
     return hipGetLastError();
 }
 
-hipError_t launch_frame(int log_nn, int in_mode, int log_mode, const FrameArgs& a, int grid, hipStream_t st) {
-    switch (log_nn) {
-        case 7:  return launch_frame_7(in_mode, log_mode, a, grid, st);
-        case 8:  return launch_frame_8(in_mode, log_mode, a, grid, st);
-        case 9:  return launch_frame_9(in_mode, log_mode, a, grid, st);
-        case 10: return launch_frame_10(in_mode, log_mode, a, grid, st);
-        case 11: return launch_frame_11(in_mode, log_mode, a, grid, st);
-        case 12: return launch_frame_12(in_mode, log_mode, a, grid, st);
-        case 13: return launch_frame_13(in_mode, log_mode, a, grid, st);
-        case 14: return launch_frame_14(in_mode, log_mode, a, grid, st);
-    }
-    return hipErrorInvalidValue;
-}
+#define GLV_BY_SIZE(log_nn, CALL, DEFAULT)                                                                            \
+    switch (log_nn) {                                                                                                   \
+        case 7: return CALL(7); case 8: return CALL(8); case 9: return CALL(9); case 10: return CALL(10);               \
+        case 11: return CALL(11); case 12: return CALL(12); case 13: return CALL(13); case 14: return CALL(14);         \
+    }                                                                                                                   \
+    return DEFAULT
 
-int frame_slots(int log_nn) {
-    switch (log_nn) {
-        case 7: return frame_slots_7(); case 14: return frame_slots_14();
-        case 8: return frame_slots_8(); case 9: return frame_slots_9(); case 10: return frame_slots_10();
-        case 11: return frame_slots_11(); case 12: return frame_slots_12(); case 13: return frame_slots_13();
-    }
-    return 1;
+hipError_t launch_frame(int log_nn, int in_mode, int log_mode, int variant, const FrameArgs& a, int grid, hipStream_t st) {
+#define GLV_CALL(K) launch_frame_##K(in_mode, log_mode, variant, a, grid, st)
+    GLV_BY_SIZE(log_nn, GLV_CALL, hipErrorInvalidValue);
+#undef GLV_CALL
 }
-
-int frame_lanes(int log_nn) {
-    switch (log_nn) {
-        case 7: return frame_lanes_7(); case 14: return frame_lanes_14();
-        case 8: return frame_lanes_8(); case 9: return frame_lanes_9(); case 10: return frame_lanes_10();
-        case 11: return frame_lanes_11(); case 12: return frame_lanes_12(); case 13: return frame_lanes_13();
-    }
-    return 1;
+int frame_variants(int log_nn) {
+#define GLV_CALL(K) frame_variants_##K()
+    GLV_BY_SIZE(log_nn, GLV_CALL, 1);
+#undef GLV_CALL
 }
-
-int frame_resident(int log_nn) {
-    switch (log_nn) {
-        case 7: return frame_resident_7(); case 14: return frame_resident_14();
-        case 8: return frame_resident_8(); case 9: return frame_resident_9(); case 10: return frame_resident_10();
-        case 11: return frame_resident_11(); case 12: return frame_resident_12(); case 13: return frame_resident_13();
-    }
-    return 1;
+bool frame_variant_ok(int log_nn, int in_mode, int log_mode, int variant) {
+#define GLV_CALL(K) frame_variant_ok_##K(in_mode, log_mode, variant) != 0
+    GLV_BY_SIZE(log_nn, GLV_CALL, false);
+#undef GLV_CALL
 }
-
-}  // namespace glv
-
-namespace glv {
-int frame_rounds(int log_nn) {
-    switch (log_nn) {
-        case 7: return frame_rounds_7(); case 8: return frame_rounds_8(); case 9: return frame_rounds_9(); case 10: return frame_rounds_10();
-        case 11: return frame_rounds_11(); case 12: return frame_rounds_12(); case 13: return frame_rounds_13(); case 14: return frame_rounds_14();
-    }
-    return 2;
+FrameGeometry frame_geometry(int log_nn, int variant) {
+#define GLV_CALL(K) frame_geometry_##K(variant)
+    GLV_BY_SIZE(log_nn, GLV_CALL, FrameGeometry{});
+#undef GLV_CALL
 }
+#undef GLV_BY_SIZE
+
 }  // namespace glv

@@ -121,7 +121,7 @@ int glv_tune_run3(int i, const void* d_pcm, float* d_out, unsigned units, int lo
     }
     FrameArgs a;
     std::memset(&a, 0, sizeof(a));
-    a.in = d_pcm; a.out = d_out; a.tw = d_tw; a.win = d_win; a.logtab = d_log; a.tilt = log_mode == 1 ? d_tilt_fast : d_tilt; a.units = units * 2; a.ops = OP_FFT | extra_ops; a.grav = d_grav;
+    a.in = d_pcm; a.out = d_out; a.tw = d_tw; a.win = d_win; a.logtab = d_log; a.tilt = log_mode == 1 ? d_tilt_fast : d_tilt; a.units = units * 2; a.ops = OP_FFT | extra_ops; a.grav = d_grav; a.grav_w = d_grav;
     a.F = d_hist ? 5 : 1; a.hist = d_hist; a.avg_window = 1;
     make_frame_weights(a.wts, a.F, true, 0);
     a.inv_n = 1.0f / (float) N; a.fft_scale = 10.2f; a.one_minus_cutoff = 1.0f - 0.3f;

@@ -19,6 +19,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("GLV_SPECTRUM_LIB") or os.path.join(HERE, "csrc", "libglvspectrum.so")
 
 OP_FFT, OP_GRAVITY, OP_AVERAGE, OP_RAW, OP_WRANGE, OP_BARS, OP_SMOOTH, OP_MAGNITUDE, OP_R16 = 1, 2, 4, 8, 16, 32, 64, 128, 256
+OP_PRIVATE_STATE, OP_RING_S16, OP_RING_F32 = 512, 1024, 2048
 OK, ERR_INVALID, ERR_NO_DEVICE, ERR_HIP, ERR_NOMEM, ERR_STATE = 0, 1, 2, 3, 4, 5
 
 
@@ -92,6 +93,10 @@ def lib() -> C.CDLL:
         L.glv_batch_kernel_name.argtypes = [vp]; L.glv_batch_kernel_name.restype = C.c_char_p
         L.glv_batch_set_grid.argtypes = [vp, C.c_int]
         L.glv_batch_last_grid.argtypes = [vp]
+        L.glv_batch_variants.argtypes = [vp]
+        L.glv_batch_set_variant.argtypes = [vp, C.c_int]
+        L.glv_batch_last_variant.argtypes = [vp]
+        L.glv_batch_describe_variant.argtypes = [vp, C.c_int, C.c_char_p, C.c_size_t]
         L.glv_batch_autotune.argtypes = [vp, vp, vp, C.c_uint, vp, C.POINTER(C.c_int), C.POINTER(C.c_float)]
         L.glv_wisdom_save.argtypes = [C.c_char_p]; L.glv_wisdom_load.argtypes = [C.c_char_p]
         L.glv_multi_shard_range.argtypes = [C.c_uint64, C.c_int, C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
@@ -203,6 +208,21 @@ class Batch:
 
     def last_grid(self) -> int:
         return int(lib().glv_batch_last_grid(self._h))
+
+    def variants(self) -> int:
+        """kernel configurations built for this size (glv_inst.hip Tuned<K, V>)"""
+        return int(lib().glv_batch_variants(self._h))
+
+    def set_variant(self, variant: int) -> None:
+        _check(lib().glv_batch_set_variant(self._h, variant))
+
+    def last_variant(self) -> int:
+        return int(lib().glv_batch_last_variant(self._h))
+
+    def describe_variant(self, variant: int) -> str:
+        buf = C.create_string_buffer(256)
+        _check(lib().glv_batch_describe_variant(self._h, variant, buf, len(buf)))
+        return buf.value.decode()
 
     def autotune(self, d_pcm, d_out, ops: int = OP_FFT, stream: int | None = None) -> tuple[int, float]:
         """time the candidate workgroup counts on the device, record the winner in the process-wide wisdom"""

@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define GLV_ABI_VERSION 2
+#define GLV_ABI_VERSION 3
 
 /* status codes (0 = ok).  The reference has no error channel: it prints and calls
  * glava_abort() (glava/glava.h:17, glava/render.c passim); the in-tree shim maps any
@@ -55,13 +55,22 @@ enum {
                                    the tail of transform_fft (render.c:842-846) on planar f32 rows that
                                    already hold FFT output; exclusive with GLV_OP_FFT (which includes it);
                                    runs before gravity/average when combined with them */
-    GLV_OP_R16      = 1u << 8   /* output as GL_R16 texels: d_out is uint16 [streams][2][n] with
+    GLV_OP_R16      = 1u << 8,  /* output as GL_R16 texels: d_out is uint16 [streams][2][n] with
                                    texel = round_to_nearest_even(clamp(x, 0, 1) * 65535) -- what the only consumer of
                                    the spectra makes of them (handle_audio uploads every finished buffer with
                                    glTexImage1D(GL_TEXTURE_1D, 0, GL_R16, sz, 0, GL_RED, GL_FLOAT, buf), render.c:521-524).
                                    Applied last, to the output only: gravity / average state stays f32.  Halves the
                                    write side of the pass (8n instead of 12n bytes per s16 frame).  Alone (no other
                                    op) it quantises planar f32 rows.  Excludes GLV_OP_RAW, GLV_OP_BARS, GLV_OP_SMOOTH. */
+    GLV_OP_PRIVATE_STATE = 1u << 9, /* with a chain that ENDS in gravity (GLV_OP_GRAVITY without AVERAGE / SMOOTH / RAW): keep
+                                   gravity's `applied` array in a buffer owned by the batch, as transform_gravity does
+                                   (render.c:724; :733-734 store every value twice).  Without this flag the output buffer IS the
+                                   state (see glv_batch_process_s16) and the chain moves SURVEY 8d's 20 n bytes per frame
+                                   instead of 28 n */
+    GLV_OP_RING_S16 = 1u << 10, /* glv_batch_create's ops_mask only: allocate (and zero, == the calloc'd rings of
+                                   glava.c:487-494) the s16 device ring of glv_batch_ring_update_s16 at creation; without it
+                                   the first ring update allocates, i.e. synchronises */
+    GLV_OP_RING_F32 = 1u << 11  /* the same for the interleaved f32 ring of glv_batch_ring_update_f32 */
 };
 
 /* Mirrors the fields of the private `struct gl_data` that the path reads
@@ -185,13 +194,24 @@ int glv_batch_reset(glv_batch* b);
 int glv_batch_destroy(glv_batch* b);
 
 /* one update of every stream from s16 PCM already resident in HBM.
- * d_out may be NULL for a chain that ends in gravity (GLV_OP_GRAVITY without AVERAGE / SMOOTH / RAW /
- * BARS): transform_gravity's output is its new state (render.c:733-734), so the spectra are then left
- * in the state buffer only -- read them through glv_batch_gravity_state -- and 8*n bytes per frame of
- * HBM writes are saved.  (With GLV_OP_BARS such a chain does this internally.) */
+ *
+ * OUTPUT == STATE for chains that end in gravity (GLV_OP_GRAVITY without AVERAGE / SMOOTH / RAW): transform_gravity
+ * stores every value to its `applied` array AND to the buffer (render.c:733-734) -- one array is enough.  Such a call
+ * writes the spectra once, into d_out, and the NEXT update reads its `applied` values from there: the caller must leave
+ * that buffer intact until the next update of the batch has been issued (pass the same buffer every time, or alternate
+ * between several; ordinary stream order is all the synchronisation needed).  The chain then moves the 20 n bytes per
+ * frame of SURVEY 8d row B.  A batch-owned copy of the state (28 n) is kept instead
+ *   - when GLV_OP_PRIVATE_STATE is set (callers that post-process d_out in place),
+ *   - when the transform runs in place on its own input (d_out == the f32 input: the reference's calling convention,
+ *     used by the single-stream drop-ins -- the next input would overwrite the state),
+ *   - with GLV_OP_R16 / GLV_OP_BARS outputs and with gl_storage (the state is not what d_out receives).
+ * d_out may also be NULL for such a chain: the spectra are then left in the batch-owned state buffer only -- read them
+ * through glv_batch_gravity_state.  (With GLV_OP_BARS a chain ending in gravity does this internally.) */
 int glv_batch_process_s16(glv_batch* b, const int16_t* d_pcm, float* d_out, unsigned ops, void* hip_stream);
-/* device pointer to the gravity state float [streams][2][n] (== the latest gravity output); valid
- * until the batch is destroyed.  GLV_ERR_STATE if the batch was created without GLV_OP_GRAVITY. */
+/* device pointer to the gravity state float [streams][2][n] == the latest output of a chain ending in gravity: the
+ * batch-owned buffer, or the caller's d_out of the latest call when that doubles as the state (above).
+ * GLV_ERR_STATE if the batch was created without GLV_OP_GRAVITY, and after fused gravity + average calls (the state is
+ * then the newest slot of the history ring, float [rows][F][n] -- not an array of this shape). */
 int glv_batch_gravity_state(glv_batch* b, const float** d_state);
 /* same from planar f32 (the lb/rb snapshot) */
 int glv_batch_process_f32(glv_batch* b, const float* d_f32, float* d_out, unsigned ops, void* hip_stream);
@@ -228,14 +248,23 @@ uint64_t glv_batch_algorithmic_bytes(const glv_batch* b, unsigned ops, int input
 /* Launch-geometry override for tuning (workgroups of the persistent frame kernel; 0 = automatic). */
 int glv_batch_set_grid(glv_batch* b, int grid);
 int glv_batch_last_grid(const glv_batch* b);      /* workgroups the last frame-kernel launch of this batch used */
+/* Kernel configurations of the batch's size: the library carries, per transform size, the configuration that won the
+ * build-time sweeps (variant 0) and the runners-up that came close (a different radix split / points per lane, rows per
+ * workgroup, placement of the window and twiddle tables); for s16 frame / ring input with log_mode 0 or 1 -- other
+ * inputs have variant 0 only.  glv_batch_set_variant forces one (-1 = automatic: wisdom, else 0). */
+int glv_batch_variants(const glv_batch* b);
+int glv_batch_set_variant(glv_batch* b, int variant);
+int glv_batch_last_variant(const glv_batch* b);   /* configuration the last frame-kernel launch of this batch used */
+int glv_batch_describe_variant(const glv_batch* b, int variant, char* buf, size_t len);
 
-/* Launch wisdom -- the role of glfft's FFTWisdom (glfft/glfft_wisdom.cpp:235-446) for this path: the kernel variant per
- * size is chosen at build time, the number of persistent workgroups per launch at run time, and the best number depends
- * on the size, the operator chain and the stream count.  glv_batch_autotune times the candidates on the batch's device
- * with the caller's buffers (real updates: a stateful batch is reset afterwards) and records the winner process-wide;
- * every later launch with the same description (n, input kind, kernel class of `ops`, log_mode, log2 of the stream count)
- * uses it.  Save / load carry the table across processes (a text file, one entry per line); the file named by the
- * environment variable GLV_WISDOM is loaded when the first batch is created. */
+/* Launch wisdom -- the role of glfft's FFTWisdom (glfft/glfft_wisdom.cpp:235-446: candidate work-group shapes and radix
+ * splits of a transform are timed on the target and the winner remembered per transform description) for this path.
+ * glv_batch_autotune times EVERY kernel configuration built for the batch's size on several workgroup counts each, on the
+ * batch's device with the caller's buffers (real updates: a stateful batch is reset afterwards), and records the winning
+ * (variant, workgroups) process-wide; every later launch with the same description -- device name + compute-unit count, n,
+ * input kind, kernel class of `ops`, log_mode, avg_frames of an averaging chain, log2 of the stream count -- uses it.
+ * Save / load carry the table across processes (a text file, one entry per line; entries of other devices are kept but
+ * never match); the file named by the environment variable GLV_WISDOM is loaded when the first batch is created. */
 int glv_batch_autotune(glv_batch* b, const int16_t* d_pcm, float* d_out, unsigned ops, void* hip_stream, int* best_grid, float* best_ms);
 int glv_wisdom_save(const char* path);
 int glv_wisdom_load(const char* path);

@@ -24,7 +24,8 @@ struct Emu {
 
     struct Thread { cf v[FR::E]; };
 
-    template <int PASS>
+    // SC: the unit-twiddle shortcut of pass 0 (s16 input only, like Body<..., UNIT_SHORTCUT> in the kernel)
+    template <int PASS, bool SC>
     static void run_pass(std::vector<Thread>& th, std::vector<cf>& lds, const cf* table) {
         for (int tid = 0; tid < T; ++tid) {
             if constexpr (PASS > 0) FR::template exchange_read<PASS>(th[tid].v, lds.data(), tid);
@@ -33,21 +34,23 @@ struct Emu {
         for (int tid = 0; tid < T; ++tid) {
             cf tw[FR::template PassInfo<PASS>::NTW];
             FR::template gather_tw<PASS>(tw, table, tid);
-            FR::template compute<PASS>(th[tid].v, tw);
+            FR::template compute<PASS, SC>(th[tid].v, tw);
             if constexpr (PASS < P - 1) FR::template exchange_write<PASS>(lds.data(), th[tid].v, tid);
         }
         // (barrier)
-        if constexpr (PASS < P - 1) run_pass<PASS + 1>(th, lds, table);
+        if constexpr (PASS < P - 1) run_pass<PASS + 1, SC>(th, lds, table);
     }
 
     // one channel row given register-resident inputs -> out_row
+    // NF: the row may hold non-finite values (f32 input), as in the kernel's epilogue instantiations
+    template <bool NF>
     static void finish(std::vector<Thread>& th, float* out_row, size_t row, const FrameArgs& a) {
         const bool st = (a.ops & (OP_GRAVITY | OP_AVERAGE)) != 0, raw = (a.ops & OP_RAW) != 0;
         for (int tid = 0; tid < T; ++tid) {
-            if (raw && st)       FR::template epilogue<LOG_MODE, EPI_RAW_STATE>(th[tid].v, out_row, row, tid, a, a.logtab);
-            else if (raw)        FR::template epilogue<LOG_MODE, EPI_RAW>(th[tid].v, out_row, row, tid, a, a.logtab);
-            else if (st)         FR::template epilogue<LOG_MODE, EPI_MAG_STATE>(th[tid].v, out_row, row, tid, a, a.logtab);
-            else                 FR::template epilogue<LOG_MODE, EPI_MAG>(th[tid].v, out_row, row, tid, a, a.logtab);
+            if (raw && st)       FR::template epilogue<LOG_MODE, EPI_RAW_STATE, 0, false, NF>(th[tid].v, out_row, row, tid, a, a.logtab);
+            else if (raw)        FR::template epilogue<LOG_MODE, EPI_RAW, 0, false, NF>(th[tid].v, out_row, row, tid, a, a.logtab);
+            else if (st)         FR::template epilogue<LOG_MODE, EPI_MAG_STATE, 0, false, NF>(th[tid].v, out_row, row, tid, a, a.logtab);
+            else                 FR::template epilogue<LOG_MODE, EPI_MAG, 0, false, NF>(th[tid].v, out_row, row, tid, a, a.logtab);
         }
     }
 
@@ -61,23 +64,23 @@ struct Emu {
             else       FR::template load_pcm<false>(raw, frame, tid, 0);
             FR::unpack_window(th[tid].v, raw, a.win, tid, (uint32_t) (row & 1), a.mono != 0);
         }
-        run_pass<0>(th, lds, a.tw);
-        finish(th, a.out + row * N, row, a);
+        run_pass<0, true>(th, lds, a.tw);
+        finish<false>(th, a.out + row * N, row, a);
     }
     static void row_f32_stereo(const float* frame, size_t row, const FrameArgs& a) {
         std::vector<Thread> th(T);
         std::vector<cf> lds(FR::XREGION);
         for (int tid = 0; tid < T; ++tid)
             FR::load_f32_stereo_window(th[tid].v, frame, a.win, tid, (uint32_t) (row & 1), a.mono != 0);
-        run_pass<0>(th, lds, a.tw);
-        finish(th, a.out + row * N, row, a);
+        run_pass<0, false>(th, lds, a.tw);
+        finish<true>(th, a.out + row * N, row, a);
     }
     static void row_f32(const float* in_row, size_t row, const FrameArgs& a) {
         std::vector<Thread> th(T);
         std::vector<cf> lds(FR::XREGION);
         for (int tid = 0; tid < T; ++tid) FR::load_f32_window(th[tid].v, in_row, a.win, tid);
-        run_pass<0>(th, lds, a.tw);
-        finish(th, a.out + row * N, row, a);
+        run_pass<0, false>(th, lds, a.tw);
+        finish<true>(th, a.out + row * N, row, a);
     }
 };
 
@@ -129,7 +132,7 @@ int glvemu_process(int n, int in_mode, const void* in, float* out, float* grav, 
     make_tilt(tl.data(), n, fft_scale, fft_cutoff, log_mode == 1);
     FrameArgs a;
     std::memset(&a, 0, sizeof(a));
-    a.in = in; a.out = out; a.grav = grav; a.hist = hist; a.tw = tw.data(); a.win = win.data(); a.logtab = lt; a.tilt = tl.data();
+    a.in = in; a.out = out; a.grav = grav; a.grav_w = grav; a.hist = hist; a.tw = tw.data(); a.win = win.data(); a.logtab = lt; a.tilt = tl.data();
     a.units = units; a.ops = ops; a.F = F; a.head = head; a.mono = mono; a.avg_window = avg_window; a.rot = rot;
     a.inv_n = 1.0f / (float) n; a.fft_scale = fft_scale; a.one_minus_cutoff = 1.0f - fft_cutoff;
     a.g = gravity_step * (1.0f / ur); a.F_as_float = (float) F;
@@ -148,7 +151,7 @@ int glvemu_post_state(const float* in, float* out, float* grav, float* hist, int
     if (F == 0 || F > 64) return 3;
     FrameArgs a;
     std::memset(&a, 0, sizeof(a));
-    a.in = in; a.out = out; a.grav = grav; a.hist = hist; a.units = rows; a.ops = ops; a.F = F; a.head = head;
+    a.in = in; a.out = out; a.grav = grav; a.grav_w = grav; a.hist = hist; a.units = rows; a.ops = ops; a.F = F; a.head = head;
     a.avg_window = avg_window; a.gl_storage = gl_storage; a.g = gravity_step * (1.0f / ur); a.F_as_float = (float) F;
     make_frame_weights(a.wts, F, avg_window != 0, avg_kind);
     for (unsigned r = 0; r < rows; ++r)

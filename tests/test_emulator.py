@@ -211,3 +211,41 @@ def test_division_by_65535_is_correctly_rounded_for_every_integer_argument(emu):
     emu.glvemu_div_65535(lo, hi, out)
     want = np.arange(lo, hi + 1, dtype=np.float32) / np.float32(65535)
     assert np.array_equal(out.view(np.uint32), want.view(np.uint32))
+
+
+def _special_rows(n, rng):
+    base = lambda: (rng.standard_normal(n) * 0.25).astype(np.float32)          # noqa: E731
+    rows = []
+    r = base(); r[::7] = -0.0; rows.append(r)
+    rows.append(np.full(n, -0.0, np.float32)); rows.append(np.zeros(n, np.float32))
+    r = base(); r[5::11] = np.float32(1e-41); r[6::13] = np.float32(-3e-45); rows.append(r)
+    rows.append((rng.standard_normal(n) * 1e-39).astype(np.float32))
+    r = base(); r[n // 3] = np.inf; rows.append(r)
+    r = base(); r[2] = -np.inf; r[3] = np.inf; rows.append(r)
+    r = base(); r[n - 1] = np.nan; rows.append(r)
+    r = base(); r[10] = np.nan; r[11] = np.inf; r[500] = -0.0; rows.append(r)
+    r = base(); r[::2] = np.float32(3.0e38); r[1::2] = np.float32(-3.0e38); rows.append(r)
+    return np.stack(rows)
+
+
+@pytest.mark.parametrize("n,log_e", [(1024, 3), (4096, 4), (16384, 5)])
+def test_f32_special_values_like_the_compiled_reference(emu, oracle, ref, n, log_e):
+    """f32 rows with -0.0, denormals, +-Inf, NaN through the kernel's own arithmetic (host emulator: no unit-twiddle shortcut
+    for f32 input, non-finite values through the table-driven log) against the reference's transform_fft compiled from
+    /root/reference: NaN exactly where the reference has NaN, identical bits elsewhere (log_mode 0); the raw FFT equals
+    the restatement's bit for bit including the sign of every zero.  The GPU twin of this test is
+    tests/test_concurrency_state.py::test_f32_special_values_against_the_compiled_reference."""
+    x = _special_rows(n, np.random.default_rng(n))
+    with np.errstate(all="ignore"):
+        want = np.stack([ref.fft(x[r]) for r in range(x.shape[0])])
+        want_raw = np.stack([oracle.transform_fft(x[r], want_raw=True)[1] for r in range(x.shape[0])])
+        got = emu_process(emu, n, x, x.shape[0], OP_FFT, in_mode=1, log_mode=0, log_e=log_e)
+        raw = emu_process(emu, n, x, x.shape[0], OP_FFT | OP_RAW, in_mode=1, log_mode=0, log_e=log_e)
+    for r in range(x.shape[0]):
+        gn, wn = np.isnan(got[r]), np.isnan(want[r])
+        assert (gn == wn).all(), r
+        assert (bits(got[r])[~wn] == bits(want[r])[~wn]).all(), r
+        rn = np.isnan(want_raw[r])
+        assert (np.isnan(raw[r]) == rn).all(), r
+        assert (bits(raw[r])[~rn] == bits(want_raw[r])[~rn]).all(), r
+    assert np.isinf(want).any() and np.isnan(want).any()          # the rows do exercise both

@@ -7,17 +7,23 @@ import pytest
 
 
 def test_wisdom_file_roundtrip(glvlib, tmp_path):
+    """v2 format: device compute_units n input_kind ops_class log_mode log2(streams) avg_frames variant workgroups ms"""
     G = glvlib
     G.wisdom_clear()
     assert G.wisdom_count() == 0
     p = tmp_path / "w.txt"
-    p.write_text("# comment\n8192 0 0 1 15 256 0.697000\n16384 0 1 1 14 512 1.270000\nnot an entry\n4096 0 0 1 16 0 0.5\n")
+    p.write_text("# comment\ngfx950:sramecc+:xnack- 256 8192 0 0 1 15 0 1 256 0.697000\ngfx950:sramecc+:xnack- 256 16384 0 1 1 14 5 0 512 1.270000\nnot an entry\n"
+                 "gfx950 256 4096 0 0 1 16 0 0 0 0.5\n8192 0 0 1 15 256 0.697000\ngfx942 304 8192 0 0 1 15 0 0 304 0.9\n")
     G.wisdom_load(str(p))
-    assert G.wisdom_count() == 2                      # the malformed line and the grid-0 line are ignored
+    assert G.wisdom_count() == 3                      # the malformed line, the grid-0 line and the round-2 (v1) line are ignored
     q = tmp_path / "out.txt"
     G.wisdom_save(str(q))
-    lines = [l for l in q.read_text().splitlines() if not l.startswith("#")]
-    assert sorted(l.split()[:6] for l in lines) == [["16384", "0", "1", "1", "14", "512"], ["8192", "0", "0", "1", "15", "256"]]
+    lines = [l.split() for l in q.read_text().splitlines() if not l.startswith("#")]
+    assert sorted(l[:10] for l in lines) == [["gfx942", "304", "8192", "0", "0", "1", "15", "0", "0", "304"],
+                                             ["gfx950:sramecc+:xnack-", "256", "16384", "0", "1", "1", "14", "5", "0", "512"],
+                                             ["gfx950:sramecc+:xnack-", "256", "8192", "0", "0", "1", "15", "0", "1", "256"]]
+    G.wisdom_load(str(q))                             # loading what was saved changes nothing
+    assert G.wisdom_count() == 3
     with pytest.raises(G.GlvError):
         G.wisdom_load(str(tmp_path / "missing.txt"))
     G.wisdom_clear()
@@ -65,4 +71,63 @@ def test_autotune_measures_records_and_is_used(glvlib, tmp_path):
     torch.cuda.synchronize()
     assert torch.equal(out.view(torch.int32), ref.view(torch.int32))
     bs.close(); fresh.close()
+    G.wisdom_clear()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,streams", [(4096, 8192), (8192, 4096), (1024, 32768)])
+def test_wisdom_selects_the_kernel_variant(glvlib, tmp_path, n, streams):
+    """f4: the wisdom chooses WHICH kernel configuration runs (radix split / rows per workgroup / table placement), not only the
+    grid.  autotune times every configuration built for the size and records the winner; the entry is keyed on the device, so a
+    file written for another part is not applied; a saved file reproduces the choice in a fresh table -- also a NON-default one
+    (the file is edited to name the runner-up, which the next launch then uses, with identical spectra)."""
+    import torch
+    G = glvlib
+    G.wisdom_clear()
+    pcm = torch.randint(-32768, 32768, (streams, n, 2), dtype=torch.int16, device="cuda")
+    out = torch.empty((streams, 2, n), dtype=torch.float32, device="cuda")
+    ref = torch.empty_like(out)
+    b = G.Batch(G.Params(n=n), streams, G.OP_FFT)
+    nv = b.variants()
+    assert nv >= 2
+    b.process_s16(pcm, ref, G.OP_FFT)
+    assert b.last_variant() == 0                                   # nothing tuned: the build-time choice
+    grid, ms = b.autotune(pcm, out, G.OP_FFT)
+    b.process_s16(pcm, out, G.OP_FFT)
+    chosen = b.last_variant()
+    assert 0 <= chosen < nv and b.last_grid() == grid
+    f = tmp_path / "wisdom.txt"
+    G.wisdom_save(str(f))
+    entry = [l.split() for l in f.read_text().splitlines() if not l.startswith("#")]
+    assert len(entry) == 1 and int(entry[0][8]) == chosen and int(entry[0][9]) == grid and int(entry[0][2]) == n
+    dev, cus = entry[0][0], int(entry[0][1])
+    assert cus > 0 and dev != "unknown"
+    # the same measurements under another device's name (or CU count) are not this device's wisdom
+    other = 1 - chosen if nv == 2 else (chosen + 1) % nv
+    G.wisdom_clear()
+    (tmp_path / "foreign.txt").write_text(" ".join(["some_other_gpu", str(cus)] + entry[0][2:8] + [str(other), "7", "1.0"]) + "\n"
+                                          + " ".join([dev, str(cus + 8)] + entry[0][2:8] + [str(other), "7", "1.0"]) + "\n")
+    G.wisdom_load(str(tmp_path / "foreign.txt"))
+    assert G.wisdom_count() == 2
+    b.process_s16(pcm, out, G.OP_FFT)
+    assert b.last_variant() == 0 and b.last_grid() != 7
+    # the runner-up named in this device's file is what runs next -- in this batch (cache invalidated) and in a fresh one
+    G.wisdom_clear()
+    (tmp_path / "edited.txt").write_text(" ".join(entry[0][:8] + [str(other), entry[0][9], entry[0][10]]) + "\n")
+    G.wisdom_load(str(tmp_path / "edited.txt"))
+    b.process_s16(pcm, out, G.OP_FFT)
+    assert b.last_variant() == other
+    assert torch.equal(out.view(torch.int32), ref.view(torch.int32))
+    b2 = G.Batch(G.Params(n=n), streams, G.OP_FFT)
+    b2.process_s16(pcm, out, G.OP_FFT)
+    assert b2.last_variant() == other and torch.equal(out.view(torch.int32), ref.view(torch.int32))
+    # an averaging chain has its own entries (avg_frames is part of the key): the stateless entry does not apply to it
+    bc = G.Batch(G.Params(n=n, avg_frames=5), streams, G.OP_GRAVITY | G.OP_AVERAGE)
+    bc.process_s16(pcm, out, G.OP_FFT | G.OP_GRAVITY | G.OP_AVERAGE)
+    assert bc.last_variant() == 0
+    # an explicit choice beats the wisdom
+    b2.set_variant(chosen if chosen != other else 0)
+    b2.process_s16(pcm, out, G.OP_FFT)
+    assert b2.last_variant() == (chosen if chosen != other else 0)
+    for x in (b, b2, bc): x.close()
     G.wisdom_clear()

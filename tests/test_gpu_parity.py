@@ -875,11 +875,12 @@ def test_randomized_parameter_sweep(G):
         sos = [StreamOracle(n, channels=ch, avg_frames=F, avg_window=win, gravity=bool(ops & G.OP_GRAVITY),
                             average=bool(ops & G.OP_AVERAGE), **kw) for _ in range(streams)]
         d_out = torch.empty((streams * 2, n), dtype=torch.float32, device="cuda")
+        d_strict = torch.empty_like(d_out)        # its own buffer: d_out is the gravity state of `b` between updates (output == state)
         for fr in range(min(F, 4) + 2):
             pcm = lcg_pcm_fast(int(rng.integers(1, 1 << 30)), streams * 2 * n)
             d_pcm = torch.from_numpy(pcm).cuda()
-            b0.process_s16(d_pcm, d_out, G.OP_FFT)
-            strict = d_out.cpu().numpy()
+            b0.process_s16(d_pcm, d_strict, G.OP_FFT)
+            strict = d_strict.cpu().numpy()
             b.process_s16(d_pcm, d_out, ops)
             got = d_out.cpu().numpy()
             for u in range(streams):

@@ -17,6 +17,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "build")
+TUNE_BIN = os.path.join(os.path.dirname(HERE), "tools", "bin")
 ARCH = "gfx950"
 # -ffp-contract=off: the bit-exactness contract forbids fusing the reference's separate
 # multiplies and adds (SURVEY.md 7 "hard parts"); explicit __builtin_fmaf calls are unaffected.
@@ -56,16 +57,19 @@ def _compile(src: str, obj: str, extra: list[str]) -> str:
 
 
 def build_tune_variant(name: str, extra_flags: list[str], variants: str | None = None) -> str:
-    """Experimental knob-sweep library glava_amd/csrc/libglvtune_<name>.so compiled with extra
-    flags (and optionally a custom variant list) -- used by tools/tune.py --lib for A/B tests."""
+    """Experimental knob-sweep library tools/bin/libglvtune_<name>.so compiled with extra
+    flags (and optionally a custom variant list) -- used by tools/tune.py --lib for A/B tests.
+    (tools/bin is git-ignored but travels to the GPU box; experiment libraries no longer live next to the product.)"""
     os.makedirs(OBJ, exist_ok=True)
+    os.makedirs(TUNE_BIN, exist_ok=True)
     obj = os.path.join(OBJ, f"glv_tune_{name}.o")
     flags = list(extra_flags)
     if variants:
         flags.append("-DGLV_TUNE_VARIANTS=" + variants)
     _run([_hipcc(), *HIPFLAGS, *flags, "-c", os.path.join(CSRC, "glv_tune.hip"), "-o", obj])
-    lib = os.path.join(CSRC, f"libglvtune_{name}.so")
+    lib = os.path.join(TUNE_BIN, f"libglvtune_{name}.so")
     _run([_hipcc(), "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", lib, obj])
+    os.remove(obj)
     return lib
 
 
@@ -86,6 +90,13 @@ def build_variant(name: str, extra_flags: list[str], sizes=SIZES) -> str:
 
 
 def build(tune: bool = False, verbose: bool = False) -> str:
+    lib = os.path.join(CSRC, "libglvspectrum.so")
+    # the built library travels to the GPU box, the objects need not: nothing to do when no source is newer than it
+    srcs = [os.path.join(CSRC, f) for f in ("glv_inst.hip", "glv_misc.hip", "glv_api.cpp", "glv_multi.cpp")] + [os.path.join(CSRC, h) for h in HEADERS]
+    if not tune and not _newer(lib, srcs):
+        if verbose:
+            print("up to date", lib)
+        return lib
     os.makedirs(OBJ, exist_ok=True)
     jobs = [("glv_inst.hip", os.path.join(OBJ, f"glv_inst_{k}.o"), [f"-DGLV_LOG_NN={k}"]) for k in SIZES]
     jobs.append(("glv_misc.hip", os.path.join(OBJ, "glv_misc.o"), []))
@@ -95,7 +106,6 @@ def build(tune: bool = False, verbose: bool = False) -> str:
         jobs.append(("glv_tune.hip", os.path.join(OBJ, "glv_tune.o"), []))
     with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 2)) as ex:
         objs = list(ex.map(lambda j: _compile(*j), jobs))
-    lib = os.path.join(CSRC, "libglvspectrum.so")
     prod = [o for o in objs if not o.endswith("glv_tune.o")]
     if _newer(lib, prod):
         _run([_hipcc(), "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", lib, *prod])

@@ -160,13 +160,13 @@ struct Tables {
     int create(uint32_t n) {
         n_ = n;
         const uint32_t nn = n / 2;
-        std::vector<glv::cf> tw(nn);
+        std::vector<glv::cf> tw(nn, glv::cf{0.0f, 0.0f});
         std::vector<double> win(n);
         glv::make_twiddles(tw.data(), nn);
         glv::make_window(win.data(), n);
         HIP_TRY(hipMalloc(&d_tw, sizeof(glv::cf) * nn));
         HIP_TRY(hipMalloc(&d_win, sizeof(double) * n));
-        HIP_TRY(hipMemcpy(d_tw, tw.data(), sizeof(glv::cf) * (nn - 1), hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(d_tw, tw.data(), sizeof(glv::cf) * nn, hipMemcpyHostToDevice));
         HIP_TRY(hipMemcpy(d_win, win.data(), sizeof(double) * n, hipMemcpyHostToDevice));
         glv::LogEntry lt[glv::kLogTabSize];
         glv::make_log_table(lt);
@@ -711,26 +711,36 @@ static int ring_append(char* d_ring, const char* d_new, uint32_t pos, uint32_t n
     return GLV_OK;
 }
 
+// the append half of a ring update: allocate the ring on first use (unless glv_batch_create did), copy / zero-fill the new
+// frames at the write position and advance it.  *old_pos receives the position before the append.
+static int ring_push(glv_batch* b, bool f32, const void* d_new, uint32_t new_frames, hipStream_t st, uint32_t* old_pos) {
+    const uint32_t n = b->p.n;
+    if (new_frames == 0 || new_frames > n)
+        return fail(GLV_ERR_INVALID, "new_frames=%u: must be in [1, n=%u] (sample_sz/4 of %s)", new_frames, n, f32 ? "pulse_input.c:155-178" : "fifo.c:38,91");
+    const size_t fb = f32 ? 8 : 4;
+    void** ring = f32 ? reinterpret_cast<void**>(&b->d_ring_f32) : reinterpret_cast<void**>(&b->d_ring);
+    uint32_t* pos = f32 ? &b->ring_pos_f32 : &b->ring_pos;
+    if (!*ring) {
+        const size_t bytes = fb * (size_t) n * b->streams;
+        HIP_TRY(hipMalloc(ring, bytes));
+        HIP_TRY(hipMemsetAsync(*ring, 0, bytes, st));          // == the calloc'd rings of glava.c:487-494
+        *pos = 0;
+    }
+    if (int rc = ring_append(static_cast<char*>(*ring), static_cast<const char*>(d_new), *pos, new_frames, n, fb, b->streams, st)) return rc;
+    *old_pos = *pos;
+    *pos = (*pos + new_frames) % n;                              // the oldest frame now sits here: the window starts there
+    return GLV_OK;
+}
+
 int glv_batch_ring_update_s16(glv_batch* b, const int16_t* d_new, uint32_t new_frames, float* d_out, unsigned ops,
                               void* hip_stream) {
     if (!b) return fail(GLV_ERR_INVALID, "batch is NULL");
-    if (!(ops & GLV_OP_FFT)) return fail(GLV_ERR_INVALID, "ring mode requires GLV_OP_FFT");
-    const uint32_t n = b->p.n;
-    if (new_frames == 0 || new_frames > n)
-        return fail(GLV_ERR_INVALID, "new_frames=%u: must be in [1, n=%u] (sample_sz/4 of fifo.c:38,91)", new_frames, n);
+    if (!(ops & GLV_OP_FFT)) return fail(GLV_ERR_INVALID, "ring mode requires GLV_OP_FFT (glv_batch_ring_append_s16 appends without transforming)");
     hipStream_t st = (hipStream_t) hip_stream;
     HIP_TRY(hipSetDevice(b->device));
     if (int rc = check_ops(b, ops, d_out)) return rc;            // nothing is appended when the call cannot be processed
-    if (!b->d_ring) {
-        const size_t bytes = sizeof(int16_t) * 2 * (size_t) n * b->streams;
-        HIP_TRY(hipMalloc(&b->d_ring, bytes));
-        HIP_TRY(hipMemsetAsync(b->d_ring, 0, bytes, st));     // == the calloc'd rings of glava.c:487-494
-        b->ring_pos = 0;
-    }
-    if (int rc = ring_append(reinterpret_cast<char*>(b->d_ring), reinterpret_cast<const char*>(d_new), b->ring_pos, new_frames, n, 4, b->streams, st)) return rc;
-    const uint32_t old_pos = b->ring_pos;
-    b->ring_pos = (b->ring_pos + new_frames) % n;
-    // the oldest frame now sits at ring_pos: the window starts there
+    uint32_t old_pos = 0;
+    if (int rc = ring_push(b, false, d_new, new_frames, st, &old_pos)) return rc;
     const int rc = process(b, b->d_ring, glv::IN_S16_RING, d_out, ops, b->streams * 2, b->ring_pos, st);
     if (rc != GLV_OK) b->ring_pos = old_pos;                      // a failed launch leaves the ring where the caller saw it
     return rc;
@@ -738,26 +748,43 @@ int glv_batch_ring_update_s16(glv_batch* b, const int16_t* d_new, uint32_t new_f
 
 int glv_batch_ring_update_f32(glv_batch* b, const float* d_new, uint32_t new_frames, float* d_out, unsigned ops, void* hip_stream) {
     if (!b) return fail(GLV_ERR_INVALID, "batch is NULL");
-    if (!(ops & GLV_OP_FFT)) return fail(GLV_ERR_INVALID, "ring mode requires GLV_OP_FFT");
+    if (!(ops & GLV_OP_FFT)) return fail(GLV_ERR_INVALID, "ring mode requires GLV_OP_FFT (glv_batch_ring_append_f32 appends without transforming)");
     if (!d_new) return fail(GLV_ERR_INVALID, "d_new is NULL (the PulseAudio backend has no zero-fill path)");
-    const uint32_t n = b->p.n;
-    if (new_frames == 0 || new_frames > n)
-        return fail(GLV_ERR_INVALID, "new_frames=%u: must be in [1, n=%u] (sample_sz/4 of pulse_input.c:155-178)", new_frames, n);
     hipStream_t st = (hipStream_t) hip_stream;
     HIP_TRY(hipSetDevice(b->device));
     if (int rc = check_ops(b, ops, d_out)) return rc;
-    if (!b->d_ring_f32) {
-        const size_t bytes = sizeof(float) * 2 * (size_t) n * b->streams;
-        HIP_TRY(hipMalloc(&b->d_ring_f32, bytes));
-        HIP_TRY(hipMemsetAsync(b->d_ring_f32, 0, bytes, st));  // == the calloc'd rings of glava.c:487-494
-        b->ring_pos_f32 = 0;
-    }
-    if (int rc = ring_append(reinterpret_cast<char*>(b->d_ring_f32), reinterpret_cast<const char*>(d_new), b->ring_pos_f32, new_frames, n, 8, b->streams, st)) return rc;
-    const uint32_t old_pos = b->ring_pos_f32;
-    b->ring_pos_f32 = (b->ring_pos_f32 + new_frames) % n;
+    uint32_t old_pos = 0;
+    if (int rc = ring_push(b, true, d_new, new_frames, st, &old_pos)) return rc;
     const int rc = process(b, b->d_ring_f32, glv::IN_F32_RING, d_out, ops, b->streams * 2, b->ring_pos_f32, st);
     if (rc != GLV_OK) b->ring_pos_f32 = old_pos;
     return rc;
+}
+
+int glv_batch_ring_append_s16(glv_batch* b, const int16_t* d_new, uint32_t new_frames, void* hip_stream) {
+    if (!b) return fail(GLV_ERR_INVALID, "batch is NULL");
+    HIP_TRY(hipSetDevice(b->device));
+    uint32_t old_pos = 0;
+    return ring_push(b, false, d_new, new_frames, (hipStream_t) hip_stream, &old_pos);
+}
+
+int glv_batch_ring_append_f32(glv_batch* b, const float* d_new, uint32_t new_frames, void* hip_stream) {
+    if (!b) return fail(GLV_ERR_INVALID, "batch is NULL");
+    if (!d_new) return fail(GLV_ERR_INVALID, "d_new is NULL (the PulseAudio backend has no zero-fill path)");
+    HIP_TRY(hipSetDevice(b->device));
+    uint32_t old_pos = 0;
+    return ring_push(b, true, d_new, new_frames, (hipStream_t) hip_stream, &old_pos);
+}
+
+int glv_batch_ring_planar(glv_batch* b, int f32_ring, float* d_planar, void* hip_stream) {
+    if (!b) return fail(GLV_ERR_INVALID, "batch is NULL");
+    if (!d_planar) return fail(GLV_ERR_INVALID, "NULL device pointer");
+    const void* ring = f32_ring ? static_cast<const void*>(b->d_ring_f32) : static_cast<const void*>(b->d_ring);
+    if (!ring) return fail(GLV_ERR_STATE, "the batch has no %s ring yet (create it with GLV_OP_RING_%s or append to it first)", f32_ring ? "f32" : "s16", f32_ring ? "F32" : "S16");
+    HIP_TRY(hipSetDevice(b->device));
+    hipError_t e = glv::launch_ring_planar(ring, f32_ring ? 1 : 0, b->p.n, f32_ring ? b->ring_pos_f32 : b->ring_pos, b->p.channels == 1, b->streams,
+                                           d_planar, (hipStream_t) hip_stream);
+    if (e != hipSuccess) return fail(GLV_ERR_HIP, "ring snapshot launch failed: %s", hipGetErrorString(e));
+    return GLV_OK;
 }
 
 int glv_batch_gravity_state(glv_batch* b, const float** d_state) {

@@ -44,9 +44,11 @@ struct alignas(16) cf2 { cf a, b; };         // two consecutive complex points (
 
 // ---- twiddle table layout ------------------------------------------------------------------
 // One table per FFT size: stage with complex half-size L (L = 1,2,4,...,nn/2; reference
-// mmax = 2L, render.c:814-839) occupies entries [L-1, 2L-1) -- nn-1 entries in total.  The
-// stages' tables are NOT subsets of each other (each runs its own float recurrence).
-GLV_HD constexpr int tw_offset(int L) { return L - 1; }
+// mmax = 2L, render.c:814-839) occupies entries [L, 2L) -- entry 0 is unused, nn entries in total, so that
+// every stage starts on an even entry: two consecutive twiddles W[L][2j], W[L][2j+1] are one aligned 16-byte
+// piece (the last pass gathers them with one load per adjacent pair of groups).  The stages' tables are NOT
+// subsets of each other (each runs its own float recurrence).
+GLV_HD constexpr int tw_offset(int L) { return L; }
 
 // The reference's six-rounding butterfly (render.c:826-832):  t = w*b;  b = a - t;  a = a + t.
 //   tr = wr*b.re - wi*b.im;  ti = wr*b.im + wi*b.re     (four products, two sums, each rounded)

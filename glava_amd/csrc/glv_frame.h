@@ -45,7 +45,7 @@ struct FrameArgs {
                            // (render.c:733-734), so the host points this at the caller's output buffer (and leaves `out` NULL)
                            // unless a private copy was asked for; == grav for the in-place form
     float* hist;           // [rows][F][n] history ring (average); doubles as gravity state
-    const cf* tw;          // nn-1 twiddles, layout glv::tw_offset
+    const cf* tw;          // nn entries (entry 0 unused), layout glv::tw_offset
     const double* win;     // n window values (render.c:660 as expanded at :794)
     const LogEntry* logtab; // 64 entries, log_mode 0 (glv_core.h)
     const float* tilt;     // n tilt factors max(n/N*fft_scale + (1 - fft_cutoff), 1) (render.c:845), host-generated
@@ -523,9 +523,10 @@ struct Frame {
 
     // Which of the nn/R radix-R groups of pass PASS does lane `tid` take as its gi-th group?
     // Intermediate passes: G = gi*T + tid (lanes contiguous: conflict-free LDS, one base address).
-    // Last pass: G = tid*NG + gi -- the lane's groups are ADJACENT, so its outputs come in runs of NG
-    // consecutive complex points: 16-byte ds_read_b128 / global_store_dwordx4 instead of 8-byte ones
-    // (the spectrum store is issue-bound, not bandwidth-bound: half the instructions, half the time).
+    // Last pass: the lane's groups come in ADJACENT pairs (G = 2*tid + {0, 1} [+ 2T per further pair]), so its outputs come
+    // in runs of two consecutive complex points: 16-byte ds_read_b128 / global_store_dwordx4 instead of 8-byte ones
+    // (the spectrum store is issue-bound, not bandwidth-bound: half the instructions, half the time), and consecutive lanes
+    // hold consecutive 16-byte pieces (whole cache lines per wave instruction).
     // SWAP16 (last pass with ONE group per lane: N=1024 at E=8, N=8192 at E=16): a lane's outputs are then nn/R
     // points apart, which would mean 8-byte stores.  Instead the lanes of a wave take the groups in the order
     //     lane l = (b5 | h | m3..m0)  ->  group (b5 | m3..m0 | h)
@@ -547,6 +548,13 @@ struct Frame {
     template <int PASS>
     GLV_HD static constexpr int group_of(int tid, int gi) {
         if (PASS == P - 1 && SWAP16) return swap16_lane_group(tid);
+#if !defined(GLV_EXP_OLDGROUPS)     /* tools/tune.py A/B only: the round-2 mapping (all NG groups of a lane adjacent) */
+        // last pass: the lane's groups come in adjacent PAIRS (one 16-byte access per pair), pair p of lane t at 2*(p*T + t):
+        // the 64 lanes of a store (or state load) instruction then cover 1 KiB CONTIGUOUS bytes.  With all NG groups of a lane
+        // adjacent (round 2) a lane's 16-byte pieces were 8*NG bytes apart: at NG = 4 (N=16384) every wave store wrote
+        // half of each 128-byte line it touched and a second instruction came back for the other half.
+        if (PASS == P - 1 && PassInfo<PASS>::NG >= 2) return (gi >> 1) * (2 * T) + 2 * tid + (gi & 1);
+#endif
         return PASS == P - 1 ? tid * PassInfo<PASS>::NG + gi : gi * T + tid;
     }
 
@@ -554,19 +562,28 @@ struct Frame {
     template <int PASS, int BIAS = 0>
     GLV_HD static void gather_tw(cf (&tw)[PassInfo<PASS>::NTW], const cf* table, int tid) {
         using PI = PassInfo<PASS>;
+        // last pass with paired groups (group_of): groups gi, gi + 1 are adjacent, so are their twiddles -- W[L][k0 + ...] and
+        // W[L][k0 + 1 + ...], k0 even, every stage's table starting on an even entry (tw_offset) -- one 16-byte load per pair
+        constexpr bool PAIRED = PASS == P - 1 && PI::NG >= 2 && !SWAP16 && (BIAS % 2) == 0 && group_of<PASS>(0, 1) == group_of<PASS>(0, 0) + 1;
 #pragma unroll
-        for (int gi = 0; gi < PI::NG; ++gi) {
+        for (int gi = 0; gi < PI::NG; gi += (PAIRED ? 2 : 1)) {
             const int G = group_of<PASS>(tid, gi);
             const int k0 = G & (PI::L0 - 1);
 #pragma unroll
             for (int s = 0; s < PI::RB; ++s)
 #pragma unroll
-                for (int ks = 0; ks < (1 << s); ++ks)
+                for (int ks = 0; ks < (1 << s); ++ks) {
 #if defined(GLV_EXP_NOTWLOAD)     /* tools/tune.py timing experiment: no twiddle loads (wrong results) */
-                    { const float f = (float) (k0 + ks) * 1e-4f; tw[gi * (PI::R - 1) + (1 << s) - 1 + ks] = cf{ 1.0f - f, f }; }
+                    const float f = (float) (k0 + ks) * 1e-4f; tw[gi * (PI::R - 1) + (1 << s) - 1 + ks] = cf{ 1.0f - f, f };
+                    if constexpr (PAIRED) tw[(gi + 1) * (PI::R - 1) + (1 << s) - 1 + ks] = cf{ 1.0f - f, -f };
 #else
-                    tw[gi * (PI::R - 1) + (1 << s) - 1 + ks] = table[SubPass<PI::RB>::tw_index(PI::L0, k0, s, ks) - BIAS];
+                    if constexpr (PAIRED) {
+                        const cf2 two = ld<cf2>(table, (uint32_t) (SubPass<PI::RB>::tw_index(PI::L0, k0, s, ks) - BIAS) * 8u);
+                        tw[gi * (PI::R - 1) + (1 << s) - 1 + ks] = two.a;
+                        tw[(gi + 1) * (PI::R - 1) + (1 << s) - 1 + ks] = two.b;
+                    } else tw[gi * (PI::R - 1) + (1 << s) - 1 + ks] = table[SubPass<PI::RB>::tw_index(PI::L0, k0, s, ks) - BIAS];
 #endif
+                }
         }
     }
 
@@ -641,6 +658,51 @@ struct Frame {
 #pragma unroll
                 for (int i = 0; i < PI::R; ++i)
                     v[gi * PI::R + i] = ld<cf>(xbuf, (uint32_t) lds_index(PASS - 1, in_index<PASS>(tid, gi, i), LOG_E) * 8u);
+        }
+    }
+
+    // ---- split exchange (kernel knob NBUF = 0): the row crosses LDS one float component at a time -- all real parts
+    // (write, barrier, read), then all imaginary parts -- so the exchange region is XREGION floats instead of XREGION complex
+    // points: half the LDS per row in flight, at the price of two more barriers per exchange and 4-byte LDS accesses.  The
+    // index maps are those of exchange_write / exchange_read; no register pressure is added (a lane holds E old imaginary and
+    // E new real parts in the middle).  H = 0: .x, H = 1: .y
+    template <int PASS, int H>
+    GLV_HD static void exchange_write_half(void* xbuf, const cf (&v)[E], int tid) {
+        using PI = PassInfo<PASS>;
+#pragma unroll
+        for (int gi = 0; gi < PI::NG; ++gi)
+#pragma unroll
+            for (int r = 0; r < PI::R; ++r)
+                st<float>(xbuf, (uint32_t) lds_index(PASS, out_index<PASS>(tid, gi, r), LOG_E) * 4u, H == 0 ? v[gi * PI::R + r].x : v[gi * PI::R + r].y);
+    }
+    template <int PASS, int H>
+    GLV_HD static void exchange_read_half(cf (&v)[E], const void* xbuf, int tid) {
+        using PI = PassInfo<PASS>;
+        auto put = [&](int slot, float f) { if (H == 0) v[slot].x = f; else v[slot].y = f; };
+        if constexpr (PASS == P - 1 && PI::NG >= 2 && PASS - 1 != 0) {
+            struct alignas(8) f2 { float a, b; };
+#pragma unroll
+            for (int i = 0; i < PI::R; ++i)
+#pragma unroll
+                for (int gi = 0; gi < PI::NG; gi += 2) {                      // adjacent groups: one 8-byte read
+                    const f2 two = ld<f2>(xbuf, (uint32_t) in_index<PASS>(tid, gi, i) * 4u);
+                    put(gi * PI::R + i, two.a);
+                    put((gi + 1) * PI::R + i, two.b);
+                }
+        } else if constexpr (PASS - 1 == 0 && (NN / PI::R) % E == 0) {
+#pragma unroll
+            for (int gi = 0; gi < PI::NG; ++gi) {
+                const uint32_t base = (uint32_t) lds_index(0, group_of<PASS>(tid, gi), LOG_E) * 4u;
+#pragma unroll
+                for (int i = 0; i < PI::R; ++i)
+                    put(gi * PI::R + i, ld<float>(xbuf, base + (uint32_t) lds_index(0, i * (NN / PI::R), LOG_E) * 4u));
+            }
+        } else {
+#pragma unroll
+            for (int gi = 0; gi < PI::NG; ++gi)
+#pragma unroll
+                for (int i = 0; i < PI::R; ++i)
+                    put(gi * PI::R + i, ld<float>(xbuf, (uint32_t) lds_index(PASS - 1, in_index<PASS>(tid, gi, i), LOG_E) * 4u));
         }
     }
 

@@ -20,6 +20,10 @@
 //   SLOTS   FFT slots per workgroup
 //   NBUF    1: one LDS exchange region per slot, two barriers per exchange
 //           2: ping-pong regions, one barrier per exchange
+//           0: SPLIT exchange -- one half-size region per slot, the row crosses it one float component at a time (real
+//              parts, then imaginary parts: glv_frame.h exchange_write_half), four barriers per exchange.  Halves the
+//              LDS a row in flight needs, which is what lets the sizes whose tables do not fit beside two full
+//              regions (N=16384: 65 KiB of twiddles) keep them in LDS (TWREG 4) with two rows per CU
 //   TWREG   1 (true): passes >= 1 keep their per-lane twiddles in VGPRs across frames
 //           0 (false): gathered from the (L2-resident) table at every pass
 //           2: middle passes gather from an LDS copy of their table range (entries E-1 .. L0_last-2: 8 KiB
@@ -122,7 +126,7 @@ struct Body {
     static constexpr bool resident(int q) { return q >= 1 && (TWREG == 1 || (TWREG >= 2 && !TW_LDS_MODE) || (TWREG == 3 && q == P - 1)); }
     // LDS copy: table entries [LDS_BIAS, LDS_BIAS + LDS_ENTRIES) = the stages of passes 1..P-2 (TWREG 2, 3)
     // or of every pass >= 1 (TWREG 4: the whole table but pass 0's E-1 entries)
-    static constexpr int LDS_BIAS = FR::E - 1;
+    static constexpr int LDS_BIAS = tw_offset(FR::E);
     static constexpr int LDS_ENTRIES = !TW_LDS_MODE ? 0 : TWREG == 4 ? NN - FR::E : (1 << FR::PL::log_l0(P - 1)) - FR::E;
 
     template <int PASS>
@@ -179,6 +183,19 @@ struct Body {
         if constexpr (PASS + 1 < P) {
             char* xb = xslot + (NBUF == 2 ? (size_t) (xcount & 1u) * FR::XREGION * sizeof(cf) : 0);
             GLV_SCHED_FENCE();
+            if constexpr (NBUF == 0) {
+                // split exchange: real parts, then imaginary parts, through the one half-size region
+                sy.sync();                                  // previous readers of the region are done
+                FR::template exchange_write_half<PASS, 0>(xb, v, tid);
+                gather_transient<PASS + 1>(tw_all, table, lds_tw, tid);
+                sy.sync();
+                FR::template exchange_read_half<PASS + 1, 0>(v, xb, tid);
+                GLV_SCHED_FENCE();
+                sy.sync();                                  // every real part has been read
+                FR::template exchange_write_half<PASS, 1>(xb, v, tid);
+                sy.sync();
+                FR::template exchange_read_half<PASS + 1, 1>(v, xb, tid);
+            } else {
 #if !defined(GLV_EXP_NOBARRIER)      /* tools/tune.py timing experiment only: wrong results without the barriers */
             if constexpr (NBUF == 1) sy.sync();         // previous readers of the region are done
 #endif
@@ -189,6 +206,7 @@ struct Body {
             sy.sync();
 #endif
             FR::template exchange_read<PASS + 1>(v, xb, tid);
+            }
             GLV_SCHED_FENCE();
 #if defined(GLV_EXP_PHASETIME)
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -204,7 +222,7 @@ struct Body {
 // one 16-byte cell per slot for the slot barrier counter
 template <int LOG_NN, int LOG_E, int SLOTS, int NBUF, bool WINLDS, int TWREG = 0>
 constexpr size_t frame_lds_bytes() {
-    return (size_t) SLOTS * NBUF * Frame<LOG_NN, LOG_E>::XREGION * sizeof(cf) + (WINLDS ? (size_t) Frame<LOG_NN, LOG_E>::N * sizeof(double) : 0)
+    return (size_t) SLOTS * (NBUF == 0 ? sizeof(float) : NBUF * sizeof(cf)) * Frame<LOG_NN, LOG_E>::XREGION + (WINLDS ? (size_t) Frame<LOG_NN, LOG_E>::N * sizeof(double) : 0)
            + kLogTabSize * sizeof(LogEntry) + (size_t) Body<LOG_NN, LOG_E, NBUF, TWREG>::LDS_ENTRIES * sizeof(cf) + (size_t) 16 * SLOTS;
 }
 
@@ -228,16 +246,17 @@ glv_frame_kernel(const FrameArgs a) {
     constexpr bool NF = !S16;
     using BD = Body<LOG_NN, LOG_E, NBUF, TWREG, S16>;
     constexpr bool WAVE_SLOT = (T % 64) == 0;      // a wave never straddles two slots
-    constexpr size_t XBYTES = (size_t) FR::XREGION * sizeof(cf);
+    constexpr size_t XBYTES = (size_t) FR::XREGION * (NBUF == 0 ? sizeof(float) : sizeof(cf));     // NBUF 0: split exchange, half-size region
+    constexpr int NREG = NBUF == 0 ? 1 : NBUF;                                                         // regions per slot
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const uint32_t slot = maybe_scalar<WAVE_SLOT>(threadIdx.x / T);
     const int tid = threadIdx.x % T;
-    char* xslot = smem + (size_t) slot * NBUF * XBYTES;
+    char* xslot = smem + (size_t) slot * NREG * XBYTES;
 
     const void* win = a.win;
     if constexpr (WINLDS) {
-        char* lwin = smem + (size_t) SLOTS * NBUF * XBYTES;
+        char* lwin = smem + (size_t) SLOTS * NREG * XBYTES;
         for (int i = threadIdx.x; i < N / 2; i += T * SLOTS) st<d2>(lwin, (uint32_t) i * 16u, ld<d2>(a.win, (uint32_t) i * 16u));
         __syncthreads();
         win = lwin;
@@ -247,7 +266,7 @@ glv_frame_kernel(const FrameArgs a) {
     // 16-byte reads without touching the vector-memory path the PCM/spectrum streams use.
     const LogEntry* logtab = a.logtab;
     if constexpr (LOG_MODE == 0) {
-        char* llog = smem + (size_t) SLOTS * NBUF * XBYTES + (WINLDS ? (size_t) N * sizeof(double) : 0);
+        char* llog = smem + (size_t) SLOTS * NREG * XBYTES + (WINLDS ? (size_t) N * sizeof(double) : 0);
         for (int i = threadIdx.x; i < kLogTabSize; i += T * SLOTS) st<d2>(llog, (uint32_t) i * 16u, ld<d2>(a.logtab, (uint32_t) i * 16u));
         __syncthreads();
         logtab = reinterpret_cast<const LogEntry*>(llog);
@@ -256,7 +275,7 @@ glv_frame_kernel(const FrameArgs a) {
     // TWREG >= 2: the twiddle table range of the middle passes is staged into LDS once per workgroup
     const cf* lds_tw = nullptr;
     if constexpr (BD::TW_LDS_MODE) {
-        char* ltw = smem + (size_t) SLOTS * NBUF * XBYTES + (WINLDS ? (size_t) N * sizeof(double) : 0) + kLogTabSize * sizeof(LogEntry);
+        char* ltw = smem + (size_t) SLOTS * NREG * XBYTES + (WINLDS ? (size_t) N * sizeof(double) : 0) + kLogTabSize * sizeof(LogEntry);
         for (int i = threadIdx.x; i < BD::LDS_ENTRIES; i += T * SLOTS) st<cf>(ltw, (uint32_t) i * 8u, ld<cf>(a.tw, (uint32_t) (BD::LDS_BIAS + i) * 8u));
         __syncthreads();
         lds_tw = reinterpret_cast<const cf*>(ltw);
@@ -293,7 +312,7 @@ glv_frame_kernel(const FrameArgs a) {
     constexpr bool FUSED_BARS = STATEFUL == 2;
     constexpr bool HAS_STATE = STATEFUL == 1 || STATEFUL == 2 || STATEFUL == 4;
     static_assert(!FUSED_BARS || WAVE_SLOT, "fused bars need whole waves per row");
-    static_assert(!FUSED_BARS || NBUF == 1, "fused bars reuse exchange region 0: needs the two-barrier exchange");
+    static_assert(!FUSED_BARS || NBUF == 1, "fused bars park the finished row in exchange region 0: needs the full-size, two-barrier region");
     auto finish = [&](const cf (&v)[E], size_t row, int tid) {
         // a.out == nullptr (gravity without average only): the spectra ARE the gravity state
         // (render.c:733-734 stores the same value to both), so the second copy is not written
@@ -593,7 +612,7 @@ hipError_t launch_variant(const FrameArgs& a, int grid, hipStream_t st) {
     // the stateful epilogue needs the registers a resident last pass (TWREG 3) would occupy
     constexpr int TW_STATEFUL = TWREG == 3 ? 2 : TWREG;
     if (a.bars_out != nullptr) {
-        if constexpr (FR::T % 64 == 0) {
+        if constexpr (FR::T % 64 == 0 && NBUF == 1) {
             static AttrDone done_bars;
             if (!(a.ops & (OP_GRAVITY | OP_AVERAGE))) return hipErrorInvalidValue;
             return launch(glv_frame_kernel<LOG_NN, IN_MODE, LOG_MODE, SLOTS, NBUF, TW_STATEFUL, WINLDS, OCC, PREFETCH, TILTREG, LOG_E, 2, WPRE_S>, done_bars);

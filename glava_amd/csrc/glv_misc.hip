@@ -49,6 +49,31 @@ __global__ void __launch_bounds__(256) glv_unpack_kernel(const int16_t* __restri
     }
 }
 
+// The device rings as the reference's backends publish them in audio_out_l / audio_out_r (glava/fifo.h:9-20): planar f32,
+// oldest sample first (fifo.c:91-92 / pulse_input.c:155-156 keep that order by memmove; the device rings are circular and
+// `rot` is the index of their oldest frame).  s16 ring: the unpack of fifo.c:94-110; f32 ring: the deinterleave of
+// pulse_input.c:159-176; mono: the respective (L + R) / 2 into both outputs.
+__global__ void __launch_bounds__(256) glv_ring_planar_kernel(const void* __restrict__ ring, int is_f32, uint32_t n, uint32_t rot, int mono,
+                                                              size_t streams, float* __restrict__ out) {
+    const size_t total = streams * n;
+    for (size_t i = (size_t) blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t) gridDim.x * blockDim.x) {
+        const size_t s = i / n;
+        const uint32_t t = (uint32_t) (i % n);
+        const size_t src = s * n + ((t + rot) & (n - 1));
+        float l, r;
+        if (is_f32) {
+            const cf u = static_cast<const cf*>(ring)[src];
+            if (mono) { l = (u.x + u.y) / 2; r = l; } else { l = u.x; r = u.y; }              // pulse_input.c:167
+        } else {
+            const uint32_t u = static_cast<const uint32_t*>(ring)[src];
+            const int a = (int16_t) (u & 0xffffu), b = (int16_t) (u >> 16);
+            if (mono) { l = unpack_s16_mono(a, b); r = l; } else { l = unpack_s16(a); r = unpack_s16(b); }
+        }
+        out[(s * 2) * n + t] = l;
+        out[(s * 2 + 1) * n + t] = r;
+    }
+}
+
 // ---- rd_update prelude (glava/render.c:1765-1809) ------------------------------------------------
 // bufscale: mean of k consecutive samples, float accumulation in index order, one float division
 __global__ void __launch_bounds__(256) glv_bufscale_kernel(const float* __restrict__ in, float* __restrict__ out,
@@ -287,6 +312,11 @@ hipError_t launch_post(const FrameArgs& a, uint32_t n, hipStream_t st) {
 
 hipError_t launch_unpack(const int16_t* pcm, size_t frames, int mono, float* l, float* r, hipStream_t st) {
     hipLaunchKernelGGL(glv_unpack_kernel, dim3(capped_grid(frames, 256)), dim3(256), 0, st, pcm, frames, mono, l, r);
+    return hipGetLastError();
+}
+
+hipError_t launch_ring_planar(const void* ring, int is_f32, uint32_t n, uint32_t rot, int mono, size_t streams, float* out, hipStream_t st) {
+    hipLaunchKernelGGL(glv_ring_planar_kernel, dim3(capped_grid(streams * n, 256)), dim3(256), 0, st, ring, is_f32, n, rot, mono, streams, out);
     return hipGetLastError();
 }
 

@@ -99,13 +99,13 @@ int glv_tune_run3(int i, const void* d_pcm, float* d_out, unsigned units, int lo
     static float* d_tilt_fast = nullptr;
     constexpr int NN = 1 << GLV_TUNE_LOG_NN, N = 2 * NN;
     if (!d_tw) {
-        std::vector<cf> tw(NN);
+        std::vector<cf> tw(NN, cf{0.0f, 0.0f});
         std::vector<double> win(N);
         make_twiddles(tw.data(), NN);
         make_window(win.data(), N);
         if (hipMalloc(&d_tw, sizeof(cf) * NN) != hipSuccess) return -1;
         if (hipMalloc(&d_win, sizeof(double) * N) != hipSuccess) return -1;
-        (void) hipMemcpy(d_tw, tw.data(), sizeof(cf) * (NN - 1), hipMemcpyHostToDevice);
+        (void) hipMemcpy(d_tw, tw.data(), sizeof(cf) * NN, hipMemcpyHostToDevice);
         (void) hipMemcpy(d_win, win.data(), sizeof(double) * N, hipMemcpyHostToDevice);
         LogEntry lt[kLogTabSize];
         make_log_table(lt);

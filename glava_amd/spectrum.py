@@ -83,6 +83,9 @@ def lib() -> C.CDLL:
         L.glv_batch_ring_update_s16.argtypes = [vp, vp, C.c_uint32, vp, C.c_uint, vp]
         L.glv_batch_ring_update_f32.argtypes = [vp, vp, C.c_uint32, vp, C.c_uint, vp]
         L.glv_batch_bars.argtypes = [vp, vp, vp, vp]
+        L.glv_batch_ring_append_s16.argtypes = [vp, vp, C.c_uint32, vp]
+        L.glv_batch_ring_append_f32.argtypes = [vp, vp, C.c_uint32, vp]
+        L.glv_batch_ring_planar.argtypes = [vp, C.c_int, vp, vp]
         L.glv_batch_gravity_state.argtypes = [vp, C.POINTER(C.c_void_p)]
         L.glv_prelude_bufscale.argtypes = [C.c_int, vp, vp, C.c_size_t, C.c_uint32, C.c_uint32, vp]
         L.glv_prelude_lerp.argtypes = [C.c_int, vp, vp, vp, C.c_size_t, C.c_float, C.c_int, vp]
@@ -182,6 +185,16 @@ class Batch:
 
     def ring_update_f32(self, d_new, new_frames: int, d_out, ops: int = OP_FFT, stream: int | None = None) -> None:
         _check(lib().glv_batch_ring_update_f32(self._h, _ptr(d_new), new_frames, _ptr(d_out), ops, _ptr(stream)))
+
+    def ring_append_s16(self, d_new, new_frames: int, stream: int | None = None) -> None:
+        _check(lib().glv_batch_ring_append_s16(self._h, _ptr(d_new), new_frames, _ptr(stream)))
+
+    def ring_append_f32(self, d_new, new_frames: int, stream: int | None = None) -> None:
+        _check(lib().glv_batch_ring_append_f32(self._h, _ptr(d_new), new_frames, _ptr(stream)))
+
+    def ring_planar(self, d_planar, f32_ring: bool = False, stream: int | None = None) -> None:
+        """the ring as the reference's backends publish it: float [streams][2][n], oldest sample first"""
+        _check(lib().glv_batch_ring_planar(self._h, int(f32_ring), _ptr(d_planar), _ptr(stream)))
 
     def bars(self, d_spec, d_bars, stream: int | None = None) -> None:
         _check(lib().glv_batch_bars(self._h, _ptr(d_spec), _ptr(d_bars), _ptr(stream)))

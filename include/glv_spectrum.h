@@ -232,6 +232,15 @@ int glv_batch_ring_update_s16(glv_batch* b, const int16_t* d_new, uint32_t new_f
 int glv_batch_ring_update_f32(glv_batch* b, const float* d_new, uint32_t new_frames, float* d_out, unsigned ops,
                               void* hip_stream);
 
+/* The rings on their own (the audio-backend seam, glava/fifo.h:9-20): append an update without transforming, and read the
+ * rings the way the reference's backends publish them in audio_out_l / audio_out_r -- planar f32, oldest sample first
+ * (fifo.c:91-110: memmove + unpack; pulse_input.c:155-176: memmove + deinterleave; channels == 1: the mono mix in both).
+ * d_planar: float [streams][2][n].  f32_ring: 0 = the s16 ring, 1 = the interleaved f32 ring.  A backend that keeps
+ * struct audio_data's contract downloads this; one that publishes spectra calls glv_batch_ring_update_* instead. */
+int glv_batch_ring_append_s16(glv_batch* b, const int16_t* d_new /* NULL = zero fill, fifo.c:67-79 */, uint32_t new_frames, void* hip_stream);
+int glv_batch_ring_append_f32(glv_batch* b, const float* d_new, uint32_t new_frames, void* hip_stream);
+int glv_batch_ring_planar(glv_batch* b, int f32_ring, float* d_planar, void* hip_stream);
+
 /* smooth_audio() bar sampling of spectra already in HBM (d_spec float [streams][2][n]) into
  * d_bars float [streams][2][bars]; what GLV_OP_BARS runs after the transform. */
 int glv_batch_bars(glv_batch* b, const float* d_spec, float* d_bars, void* hip_stream);

@@ -164,6 +164,12 @@ int nullgl_update(void* hv, float* lb, float* rb, size_t bsz, int modified, floa
     ng_n = 0;
     return got;
 }
+#ifdef GLV_NULLGL_HIP
+/* the flag an audio backend that publishes spectra raises (integration/hipfifo.c); defined here so that the patched
+   handle_audio of this library sees it without the backend being linked in */
+volatile int glv_audio_publishes_spectra = 0;
+void nullgl_spectra_in(int on) { glv_audio_publishes_spectra = on ? 1 : 0; }
+#endif
 float nullgl_ur(void* hv) { return ((nullgl*) hv)->r->gl->ur; }
 int nullgl_interpolate_glsl(void* hv) { return ((nullgl*) hv)->r->gl->interpolate_glsl; }
 size_t nullgl_bind_t_sz(void* hv, int b) { return ((nullgl*) hv)->r->gl->stages[0].binds[b].t_sz; }

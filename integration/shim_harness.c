@@ -61,10 +61,14 @@ int glvshim_run(const glvshim_params* sp, int mode, unsigned log_mode, float* fr
  * `chunks` updates of `ssz` bytes and snapshot audio_out_l/r (fsz floats each) after every update the backend
  * publishes.  zero_fill[e] = 1 when update e was a poll-timeout update of zeros (timing dependent; the test
  * replays whatever happened).  Works for the reference's "fifo" backend (snapshots are the sample rings) and for
- * "hipfifo" (snapshots are spectra).  Returns the number of events, or a negative error. */
+ * "hipfifo" (the same rings by default; spectra after glvshim_hipfifo_publish_spectra(1)).  Returns the number of events,
+ * or a negative error. */
 #include <sys/stat.h>
 #include "fifo.h"
 extern volatile unsigned long glv_hipfifo_zero_fills;
+extern volatile int glv_hipfifo_spectra;
+/* what the "hipfifo" backend publishes from its next start on: 0 the sample rings (its default), 1 finished spectra */
+void glvshim_hipfifo_publish_spectra(int on) { glv_hipfifo_spectra = on ? 1 : 0; }
 
 long glvshim_backend_run(const char* name, const char* fifo_path, const int16_t* pcm, size_t chunks, size_t ssz, size_t fsz,
                          int channels, float* snapshots /* [max_events][2][fsz] */, unsigned char* zero_fill, size_t max_events) {

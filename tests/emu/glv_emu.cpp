@@ -122,7 +122,7 @@ int glvemu_process(int n, int in_mode, const void* in, float* out, float* grav, 
     while ((2 << log_nn) < n) ++log_nn;
     if ((2 << log_nn) != n) return 2;
     const int nn = n / 2;
-    std::vector<cf> tw(nn);
+    std::vector<cf> tw(nn, cf{0.0f, 0.0f});
     std::vector<double> win(n);
     make_twiddles(tw.data(), nn);
     make_window(win.data(), n);

@@ -892,13 +892,7 @@ def test_randomized_parameter_sweep(G):
         b.close(); b0.close()
 
 
-@pytest.mark.parametrize("channels", [2, 1])
-def test_hipfifo_backend_through_the_registry(G, channels, tmp_path):
-    """The audio-backend seam (glava/fifo.h:22-44) on real code: integration/hipfifo.c self-registers next to the
-    reference's own "fifo" backend in audio_impls[] (both compiled into oracle/_ref/libglvshim.so against the
-    unmodified reference headers); it is looked up by name and run on a thread against a named pipe exactly like
-    glava.c:469-520 does.  Every update it publishes (spectra of the device-resident ring) is checked against a
-    replay on the oracle: fifo.c ring shift/append or zero fill, then transform_fft of both rings."""
+def _shim():
     import ctypes
     path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "_ref", "libglvshim.so")
     if not os.path.exists(path):
@@ -907,18 +901,70 @@ def test_hipfifo_backend_through_the_registry(G, channels, tmp_path):
     S.glvshim_backend_run.restype = ctypes.c_long
     S.glvshim_backend_run.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_size_t,
                                       ctypes.c_size_t, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t]
-    n, ssz, chunks, max_events = 1024, 1024, 9, 64
-    nf = ssz // 4
-    pcm = lcg_pcm_fast(777 + channels, chunks * ssz // 2)
+    S.glvshim_hipfifo_publish_spectra.argtypes = [ctypes.c_int]
+    return S
+
+
+def run_backend(S, name, fifo, pcm, chunks, ssz, n, channels, max_events=64):
+    """drive a registered audio backend (glava/fifo.h:22-44) against a named pipe; returns (snapshots [ev][2][n], zero_fill [ev])"""
+    import ctypes
     snaps = np.zeros((max_events, 2, n), np.float32)
     zf = np.zeros(max_events, np.uint8)
-    fifo = str(tmp_path / "glv_hipfifo_test.fifo").encode()
-    ev = S.glvshim_backend_run(b"hipfifo", fifo, pcm.ctypes.data_as(ctypes.c_void_p), chunks, ssz, n, channels,
+    ev = S.glvshim_backend_run(name, fifo, pcm.ctypes.data_as(ctypes.c_void_p), chunks, ssz, n, channels,
                                snaps.ctypes.data_as(ctypes.c_void_p), zf.ctypes.data_as(ctypes.c_void_p), max_events)
     assert ev >= chunks, ev
+    return snaps[:ev], zf[:ev]
+
+
+@pytest.mark.parametrize("channels", [2, 1])
+def test_hipfifo_backend_through_the_registry(G, golden, channels, tmp_path):
+    """The audio-backend seam (glava/fifo.h:22-44) on real code: integration/hipfifo.c self-registers next to the
+    reference's own "fifo" backend in audio_impls[] (both compiled into oracle/_ref/libglvshim.so against the
+    unmodified reference headers); it is looked up by name and run on a thread against a named pipe exactly like
+    glava.c:469-520 does.
+      default mode   it publishes what struct audio_data defines (fifo.h:9-20): the time-domain sample rings of the
+                     device-resident ring -- bit-equal to a replay of fifo.c's shift / append / zero fill on the oracle, to
+                     the rings the REFERENCE's own fifo thread produced for the same PCM (tests/golden fifo_ch*_rings) and to
+                     what the reference's backend publishes through the same driver in this very process;
+      spectra mode   (opt-in) the finished spectra of those rings: transform_fft of the replayed rings."""
+    S = _shim()
+    fifo = str(tmp_path / "glv_hipfifo_test.fifo").encode()
+    # -- default: the rings, on the golden run's parameters
+    pcm = np.ascontiguousarray(golden[f"fifo_ch{channels}_pcm"])
+    n, ssz = golden[f"fifo_ch{channels}_rings"].shape[2], 1024
+    chunks, nf = pcm.size * 2 // ssz, ssz // 4
+    S.glvshim_hipfifo_publish_spectra(0)
+    snaps, zf = run_backend(S, b"hipfifo", fifo, pcm, chunks, ssz, n, channels)
     rl = np.zeros(n, np.float32); rr = np.zeros(n, np.float32)
     sent = 0
-    for e in range(ev):
+    landed = []
+    for e in range(len(zf)):
+        if zf[e]:
+            Oracle.lib().glvo_ring_update_s16(rl, rr, n, None, nf, channels)
+        else:
+            chunk = np.ascontiguousarray(pcm[sent * (ssz // 2):(sent + 1) * (ssz // 2)]); sent += 1
+            Oracle.lib().glvo_ring_update_s16(rl, rr, n, chunk.ctypes.data_as(C.c_void_p), nf, channels)
+            landed.append(e)
+        assert (bits(snaps[e, 0]) == bits(rl)).all() and (bits(snaps[e, 1]) == bits(rr)).all(), e
+    assert sent == chunks
+    gold_zf = golden[f"fifo_ch{channels}_zero_fill"]
+    if not zf.any() and not gold_zf.any():                 # no poll timeout on either side: event for event the reference's rings
+        assert (bits(snaps) == bits(golden[f"fifo_ch{channels}_rings"])).all()
+    ref_snaps, ref_zf = run_backend(S, b"fifo", fifo, pcm, chunks, ssz, n, channels)
+    if not zf.any() and not ref_zf.any():
+        assert (bits(snaps) == bits(ref_snaps)).all()
+    # -- opt-in: spectra
+    n, ssz, chunks = 1024, 1024, 9
+    nf = ssz // 4
+    pcm = lcg_pcm_fast(777 + channels, chunks * ssz // 2)
+    S.glvshim_hipfifo_publish_spectra(1)
+    try:
+        snaps, zf = run_backend(S, b"hipfifo", fifo, pcm, chunks, ssz, n, channels)
+    finally:
+        S.glvshim_hipfifo_publish_spectra(0)
+    rl = np.zeros(n, np.float32); rr = np.zeros(n, np.float32)
+    sent = 0
+    for e in range(len(zf)):
         if zf[e]:
             Oracle.lib().glvo_ring_update_s16(rl, rr, n, None, nf, channels)
         else:
@@ -927,10 +973,43 @@ def test_hipfifo_backend_through_the_registry(G, channels, tmp_path):
         wl = Oracle.transform_fft(rl.copy()); wr = Oracle.transform_fft(rr.copy())
         assert np.allclose(snaps[e, 0], wl, rtol=REL, atol=1e-7) and np.allclose(snaps[e, 1], wr, rtol=REL, atol=1e-7), e
     assert sent == chunks
-    # the reference's own backend is in the same registry and runs through the same driver (rings, not spectra)
-    ev2 = S.glvshim_backend_run(b"fifo", fifo, pcm.ctypes.data_as(ctypes.c_void_p), 3, ssz, n, channels,
-                                snaps.ctypes.data_as(ctypes.c_void_p), zf.ctypes.data_as(ctypes.c_void_p), max_events)
-    assert ev2 >= 3
+
+
+def test_ring_append_and_planar_snapshot(G):
+    """glv_batch_ring_append_* + glv_batch_ring_planar: the device rings read back in publishing order equal the oracle's
+    fifo.c / pulse_input.c replay bit for bit -- any update size, mono mix, zero fill, many streams; appending and then
+    transforming the ring elsewhere is the same as glv_batch_ring_update_*."""
+    import torch
+    n, streams = 1024, 23
+    for ch in (2, 1):
+        b = G.Batch(G.Params(n=n, channels=ch), streams, G.OP_FFT)
+        with pytest.raises(G.GlvError) as ei:
+            b.ring_planar(torch.empty((streams, 2, n), dtype=torch.float32, device="cuda"))
+        assert ei.value.code == G.ERR_STATE                               # no ring yet
+        rl = np.zeros((streams, n), np.float32); rr = np.zeros((streams, n), np.float32)
+        fl = np.zeros((streams, n), np.float32); fr_ = np.zeros((streams, n), np.float32)
+        d_pl = torch.empty((streams, 2, n), dtype=torch.float32, device="cuda")
+        rng = np.random.default_rng(ch)
+        for u, nf in enumerate([256, 250, 3, 1024, 999, 256]):
+            zero = u == 2
+            new = lcg_pcm_fast(60 + u, streams * nf * 2).reshape(streams, nf * 2)
+            b.ring_append_s16(None if zero else torch.from_numpy(new).cuda(), nf)
+            b.ring_planar(d_pl)
+            got = d_pl.cpu().numpy()
+            for s_ in range(streams):
+                chunk = np.ascontiguousarray(new[s_])
+                Oracle.lib().glvo_ring_update_s16(rl[s_], rr[s_], n, None if zero else chunk.ctypes.data_as(C.c_void_p), nf, ch)
+            assert (bits(got[:, 0]) == bits(rl)).all() and (bits(got[:, 1]) == bits(rr)).all(), (ch, u)
+            newf = (rng.standard_normal((streams, nf, 2)) * 0.3).astype(np.float32)
+            b.ring_append_f32(torch.from_numpy(newf).cuda(), nf)
+            b.ring_planar(d_pl, f32_ring=True)
+            got = d_pl.cpu().numpy()
+            for s_ in range(streams):
+                pl = np.empty(nf, np.float32); pr = np.empty(nf, np.float32)
+                Oracle.lib().glvo_unpack_f32(np.ascontiguousarray(newf[s_].reshape(-1)), nf, ch, pl, pr)
+                fl[s_] = np.concatenate([fl[s_][nf:], pl]); fr_[s_] = np.concatenate([fr_[s_][nf:], pr])
+            assert (bits(got[:, 0]) == bits(fl)).all() and (bits(got[:, 1]) == bits(fr_)).all(), (ch, u)
+        b.close()
 
 
 def test_f32_inputs_through_stateful_and_fused_paths(G):

@@ -91,9 +91,12 @@ def build_variant(name: str, extra_flags: list[str], sizes=SIZES) -> str:
 
 def build(tune: bool = False, verbose: bool = False) -> str:
     lib = os.path.join(CSRC, "libglvspectrum.so")
-    # the built library travels to the GPU box, the objects need not: nothing to do when no source is newer than it
+    # the built library travels to the GPU box, the objects need not: nothing to do when the library's stamp (newest source
+    # mtime, taken when its build STARTED -- an edit during a build must not look built) still matches the sources
     srcs = [os.path.join(CSRC, f) for f in ("glv_inst.hip", "glv_misc.hip", "glv_api.cpp", "glv_multi.cpp")] + [os.path.join(CSRC, h) for h in HEADERS]
-    if not tune and not _newer(lib, srcs):
+    stamp_path = lib + ".stamp"
+    stamp = repr(max(os.path.getmtime(f) for f in srcs))
+    if not tune and os.path.exists(lib) and os.path.exists(stamp_path) and open(stamp_path).read() == stamp:
         if verbose:
             print("up to date", lib)
         return lib
@@ -107,8 +110,16 @@ def build(tune: bool = False, verbose: bool = False) -> str:
     with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 2)) as ex:
         objs = list(ex.map(lambda j: _compile(*j), jobs))
     prod = [o for o in objs if not o.endswith("glv_tune.o")]
-    if _newer(lib, prod):
+    if _newer(lib, prod) or not os.path.exists(stamp_path) or open(stamp_path).read() != stamp:
         _run([_hipcc(), "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", lib, *prod])
+    # objects compiled from sources that changed meanwhile carry mtimes newer than those sources and would be kept: the
+    # stamp says which source state this library was built FROM, the next call compares it with the state it finds
+    if repr(max(os.path.getmtime(f) for f in srcs)) == stamp:
+        open(stamp_path, "w").write(stamp)
+    else:
+        for o in prod:
+            os.remove(o)
+        if os.path.exists(stamp_path): os.remove(stamp_path)
     if tune:
         tlib = os.path.join(CSRC, "libglvtune.so")
         tobj = os.path.join(OBJ, "glv_tune.o")

@@ -237,7 +237,7 @@ struct glv_batch {
     glv::BarItem* d_bar_items = nullptr;    // work lists for glv_bars_kernel (16 groups per row)
     glv::BarItem* d_bar_fitems = nullptr;   // work lists for the fused epilogue (lanes/16 groups per row)
     uint32_t bar_nsteps = 0, bar_fnsteps = 0; bool bar_fusable = false;
-    uint32_t bar_count = 0; float bar_factor = -1.f; int bar_lanes = 0;
+    uint32_t bar_count = 0; float bar_factor = -1.f, bar_phase = 0.f; int bar_lanes = 0;
     // timing
     bool timing = false;
     std::vector<hipEvent_t> ev;  // start/stop pairs
@@ -385,11 +385,11 @@ int ensure_smooth_tables(glv_batch* b) {
 // lanes: lanes per row of the frame-kernel configuration that will consume the fused work lists (0: only glv_bars_kernel runs)
 int ensure_bar_tables(glv_batch* b, int lanes = 0) {
     if (lanes == 0) lanes = b->bar_lanes ? b->bar_lanes : glv::frame_geometry(b->log_nn, 0).lanes;
-    if (b->d_bar_desc && b->bar_count == b->p.bars && b->bar_factor == b->p.smooth_factor && b->bar_lanes == lanes) return GLV_OK;
+    if (b->d_bar_desc && b->bar_count == b->p.bars && b->bar_factor == b->p.smooth_factor && b->bar_phase == b->p.bar_phase && b->bar_lanes == lanes) return GLV_OK;
     if (b->p.bars == 0 || b->p.bars > b->p.n) return fail(GLV_ERR_INVALID, "bars=%u out of range", b->p.bars);
     std::vector<glv::BarDesc> desc;
     std::vector<float> w;
-    glv::make_bar_taps(desc, w, b->p.n, b->p.bars, b->p.smooth_factor);
+    glv::make_bar_taps(desc, w, b->p.n, b->p.bars, b->p.smooth_factor, b->p.bar_phase);
     if (b->d_bar_desc) { (void) hipFree(b->d_bar_desc); b->d_bar_desc = nullptr; }
     if (b->d_bar_w) { (void) hipFree(b->d_bar_w); b->d_bar_w = nullptr; }
     HIP_TRY(hipMalloc(&b->d_bar_desc, sizeof(glv::BarDesc) * desc.size()));
@@ -413,7 +413,7 @@ int ensure_bar_tables(glv_batch* b, int lanes = 0) {
     HIP_TRY(hipMalloc(&b->d_bar_w, sizeof(float) * w.size()));
     HIP_TRY(hipMemcpy(b->d_bar_desc, desc.data(), sizeof(glv::BarDesc) * desc.size(), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(b->d_bar_w, w.data(), sizeof(float) * w.size(), hipMemcpyHostToDevice));
-    b->bar_count = b->p.bars; b->bar_factor = b->p.smooth_factor; b->bar_lanes = lanes;
+    b->bar_count = b->p.bars; b->bar_factor = b->p.smooth_factor; b->bar_phase = b->p.bar_phase; b->bar_lanes = lanes;
     return GLV_OK;
 }
 
@@ -437,6 +437,8 @@ int check_ops(const glv_batch* b, unsigned ops, const float* d_out) {
     if ((ops & GLV_OP_BARS) && (b->p.bars == 0 || b->p.bars > b->p.n)) return fail(GLV_ERR_INVALID, "bars=%u out of range", b->p.bars);
     if ((ops & GLV_OP_BARS) && !(b->p.smooth_factor >= 0.0f && b->p.smooth_factor <= 1.0f))       // also rejects NaN
         return fail(GLV_ERR_INVALID, "smooth_factor=%g: must be in [0, 1] (a bar would have no taps)", (double) b->p.smooth_factor);
+    if ((ops & GLV_OP_BARS) && !(b->p.bar_phase >= 0.0f && b->p.bar_phase < 1.0f))
+        return fail(GLV_ERR_INVALID, "bar_phase=%g: must be in [0, 1)", (double) b->p.bar_phase);
     return GLV_OK;
 }
 
@@ -628,6 +630,7 @@ void glv_params_default(glv_params* p) {
     p->smooth_distance = 0.01F;  // render.c:917
     p->smooth_ratio = 4.0F;      // render.c:918
     p->gl_storage = 0;
+    p->bar_phase = 0.0F;
 }
 
 // shared with glv_multi.cpp: record an error string for the calling thread

@@ -72,10 +72,13 @@ struct FrameArgs {
 
 // ---- GLV_OP_BARS arithmetic (smooth.glsl:25-40; tex clamped to [0,1] like the GL_R16 texture the
 // shader samples, render.c:523) ---------------------------------------------------------------------
-// A bar's taps are cut into chunks of 64; a chunk is summed by a group of 16 lanes: lane l takes taps
-// l, l+16, l+32, l+48, adds its four products in that order, the group adds the 16 lane sums with a fixed
-// DPP pattern (quads, halves of 8, the two halves), and the chunk totals of a bar are added in chunk
-// order.  Which group of which wave takes a chunk does not enter the arithmetic, so the fused epilogue
+// A bar's taps are cut into chunks of 64; a chunk is summed by a group of 16 lanes: lane l takes the four CONSECUTIVE taps
+// 4l .. 4l+3 (one 16-byte load of their weights), adds its four products in that order, the group adds the 16 lane sums
+// with a fixed DPP pattern (quads, halves of 8, the two halves), and the chunk totals of a bar are added in chunk
+// order.  This order IS the contract of GLV_OP_BARS (smooth.glsl's loop adds tap by tap; what a GL driver's compiler makes
+// of that loop is not defined): the oracle's glvo_bars_chunked follows it and the GPU tests demand its bits; against the
+// tap-by-tap order of the shader text it differs by summation rounding only (<= 2e-4 relative, tests/test_glsl_twins.py).
+// Which group of which wave takes a chunk does not enter the arithmetic, so the fused epilogue
 // (row in LDS, T/16 groups per row) and glv_bars_kernel (row in HBM, 16 groups per row) give the same
 // bits.  Small bars dominate (N=4096: 80 bars, 4591 taps, no bar above 191): one WAVE per bar, as in the
 // first version, spent ~100 instructions per bar on mostly idle lanes -- more than the transform itself.
@@ -90,20 +93,22 @@ GLV_HD bool bar_item_last(const BarItem& it) { return ((it.pack >> 30) & 1u) != 
 // nothing, follows).  !CLAMP (row in LDS): they read the slack behind the row -- whatever is there is clamped to
 // [0, 1] (NaN -> 0) by bar_item_lane_sum before it meets its zero weight, so it adds exactly 0 either way, and the
 // address is one lane offset + compile-time constants.
+struct alignas(16) BarW4 { float w[4]; };
 template <bool CLAMP = true>
 GLV_HD BarTaps bar_item_load(const float* tex_row, uint32_t n, const float* tap_w, const BarItem& it, int sub) {
     BarTaps s;
-    const float* w = tap_w + it.w_off;
-    const uint32_t base = bar_item_tex(it);
+    const uint32_t base = bar_item_tex(it) + 4u * (uint32_t) sub;
+#if defined(GLV_EXP_BARS_NOWLOAD)     /* A/B experiment only (glava_amd.build build_variant): no weight loads, wrong bars */
+    for (int i = 0; i < 4; ++i) s.w[i] = 1.0f;
+    (void) tap_w;
+#else
+    const BarW4 w4 = ld<BarW4>(tap_w, (it.w_off + 4u * (uint32_t) sub) * 4u);     // chunks start on 64-float boundaries
+#pragma unroll
+    for (int i = 0; i < 4; ++i) s.w[i] = w4.w[i];
+#endif
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        const uint32_t idx = (uint32_t) sub + 16u * (uint32_t) i;
-#if defined(GLV_EXP_BARS_NOWLOAD)     /* A/B experiment only (glava_amd.build build_variant): no weight loads, wrong bars */
-        s.w[i] = 1.0f; (void) w;
-#else
-        s.w[i] = w[idx];
-#endif
-        const uint32_t q = base + idx;
+        const uint32_t q = base + (uint32_t) i;
         if constexpr (CLAMP) s.t[i] = tex_row[q < n ? q : n - 1];
         else s.t[i] = tex_row[q];
     }

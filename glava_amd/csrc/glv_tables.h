@@ -92,16 +92,17 @@ inline size_t make_smooth_bounds(int* smin, int* smax, size_t sz, float smooth_d
 }
 
 // smooth_audio() taps of every bar (shaders/glava/util/smooth.glsl:13-40 in float, as the GLSL would):
-//   idx = k / bars;  smin/smax = scale_audio(clamp(idx -/+ factor)) * n,  scale_audio(u) = -log(1 - 0.9u)/8
+//   idx = (k + phase) / bars (phase 0: the modules' bar positions; 0.5: the texel centres of smooth_pass.frag);
+//   smin/smax = scale_audio(clamp(idx -/+ factor)) * n,  scale_audio(u) = -log(1 - 0.9u)/8
 //   m = (smax - smin)/2, rm = smin + m;  for s = smin; s <= smax; s += 1:  w = sinusoidal(clamp((m - |rm - s|)/m))
 //   sample bin int(round(s)).  Consecutive s round to consecutive bins, so a bar is a contiguous bin range.
-inline void make_bar_taps(std::vector<BarDesc>& desc, std::vector<float>& tap_w, uint32_t n, uint32_t bars, float smooth_factor) {
+inline void make_bar_taps(std::vector<BarDesc>& desc, std::vector<float>& tap_w, uint32_t n, uint32_t bars, float smooth_factor, float phase = 0.0f) {
     auto scale = [](float u) { return -logf((-0.9f * u) + 1.0f) / 8.0f; };
     auto clamp01 = [](float x) { return x < 0.0f ? 0.0f : (x > 1.0f ? 1.0f : x); };
     desc.resize(bars);
     tap_w.clear();
     for (uint32_t k = 0; k < bars; ++k) {
-        const float idx = (float) k / (float) bars;
+        const float idx = phase == 0.0f ? (float) k / (float) bars : ((float) k + phase) / (float) bars;   // gl_FragCoord.x / w
         const float smin = scale(clamp01(idx - smooth_factor)) * (float) n;
         const float smax = scale(clamp01(idx + smooth_factor)) * (float) n;
         const float m = (smax - smin) / 2.0f, rm = smin + m;

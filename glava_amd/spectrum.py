@@ -34,7 +34,8 @@ class CParams(C.Structure):
                 ("gravity_step", C.c_float), ("ur", C.c_float), ("avg_frames", C.c_uint32),
                 ("avg_window", C.c_uint32), ("avg_window_kind", C.c_uint32), ("log_mode", C.c_uint32),
                 ("bars", C.c_uint32), ("smooth_factor", C.c_float),
-                ("smooth_distance", C.c_float), ("smooth_ratio", C.c_float), ("gl_storage", C.c_uint32)]
+                ("smooth_distance", C.c_float), ("smooth_ratio", C.c_float), ("gl_storage", C.c_uint32),
+                ("bar_phase", C.c_float)]
 
 
 class MultiStats(C.Structure):
@@ -136,11 +137,12 @@ class Params:
     smooth_distance: float = 0.01
     smooth_ratio: float = 4.0
     gl_storage: int = 0
+    bar_phase: float = 0.0
 
     def c(self) -> CParams:
         return CParams(self.n, self.channels, self.fft_scale, self.fft_cutoff, self.gravity_step, self.ur,
                        self.avg_frames, int(self.avg_window), self.avg_window_kind, self.log_mode,
-                       self.bars, self.smooth_factor, self.smooth_distance, self.smooth_ratio, self.gl_storage)
+                       self.bars, self.smooth_factor, self.smooth_distance, self.smooth_ratio, self.gl_storage, self.bar_phase)
 
 
 def _ptr(x) -> C.c_void_p:

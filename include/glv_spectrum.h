@@ -110,6 +110,11 @@ typedef struct glv_params {
                                pass when avg_frames == 1 (render.c:2230).  Usually combined with avg_window_kind = 1.  The
                                chain then runs as the reference's does, pass by pass: the frame kernel produces the spectra,
                                a second kernel applies gravity / average on them. */
+    float bar_phase;        /* GLV_OP_BARS evaluates smooth_audio() at idx = (k + bar_phase) / bars, k = 0 .. bars-1.
+                               0 (default): the bar positions of the modules (radial/1.frag:58-70: pos = k / (NBARS / 2)).
+                               0.5 with bars == n: the texel centres of the reference's pre-smoothing pass
+                               (util/smooth_pass.frag: smooth_audio(tex, sz, gl_FragCoord.x / w), render.c:2277-2303) -- the
+                               texture every stock module samples when setsmoothpass is on (the default) */
 } glv_params;
 
 #define GLV_MAX_AVG_FRAMES 64

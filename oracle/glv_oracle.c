@@ -388,9 +388,13 @@ void glvo_gl_chain_r16(float* row, float* store, float* hist, size_t* head, size
 static float glvo_scale_audio(float idx) { return -logf((-0.9F * idx) + 1) / 8.0F; }
 static float glvo_clamp01(float x) { return x < 0 ? 0 : (x > 1 ? 1 : x); }
 static float glvo_sinusoidal(float x) { return (0.5F * sinf((3.14159265359F * x) - (3.14159265359F / 2))) + 0.5F; }
-void glvo_bars(const float* tex, size_t sz, float* bars_out, size_t bars, float smooth_factor) {
+/* phase: smooth_audio() is evaluated at idx = (k + phase) / bars -- 0: the modules' bar positions (radial/1.frag:58-70);
+ * 0.5 with bars == sz: gl_FragCoord.x / w of util/smooth_pass.frag, the reference's pre-smoothing pass (render.c:2277-2303) */
+void glvo_bars_at(const float* tex, size_t sz, float* bars_out, size_t bars, float smooth_factor, float phase);
+void glvo_bars(const float* tex, size_t sz, float* bars_out, size_t bars, float smooth_factor) { glvo_bars_at(tex, sz, bars_out, bars, smooth_factor, 0.0F); }
+void glvo_bars_at(const float* tex, size_t sz, float* bars_out, size_t bars, float smooth_factor, float phase) {
     for (size_t k = 0; k < bars; ++k) {
-        float idx = (float) k / (float) bars;
+        float idx = phase == 0.0F ? (float) k / (float) bars : ((float) k + phase) / (float) bars;
         float smin = glvo_scale_audio(glvo_clamp01(idx - smooth_factor)) * sz;
         float smax = glvo_scale_audio(glvo_clamp01(idx + smooth_factor)) * sz;
         float m = (smax - smin) / 2.0F, rm = smin + m;
@@ -402,4 +406,47 @@ void glvo_bars(const float* tex, size_t sz, float* bars_out, size_t bars, float 
         }
         bars_out[k] = avg / weight;
     }
+}
+
+/* GLV_OP_BARS as the library defines it: the taps and weights of glvo_bars (smooth.glsl:13-40), summed in the library's
+ * documented order instead of tap by tap -- a bar's taps in chunks of 64; within a chunk sixteen partial sums of four
+ * consecutive products each ((((0 + x0 w0) + x1 w1) + x2 w2) + x3 w3, zero weights past the bar's end), combined pairwise
+ * (neighbours, pairs of pairs, the two quads of each eight, the two eights); chunk totals added in chunk order; one division
+ * by the tap-order sum of the weights.  glava_amd/csrc/glv_frame.h "GLV_OP_BARS arithmetic" is what this restates; the GPU
+ * tests demand these bits, tests/test_glsl_twins.py bounds the distance to glvo_bars (summation rounding only). */
+void glvo_bars_chunked_at(const float* tex, size_t sz, float* bars_out, size_t bars, float smooth_factor, float phase);
+void glvo_bars_chunked(const float* tex, size_t sz, float* bars_out, size_t bars, float smooth_factor) { glvo_bars_chunked_at(tex, sz, bars_out, bars, smooth_factor, 0.0F); }
+void glvo_bars_chunked_at(const float* tex, size_t sz, float* bars_out, size_t bars, float smooth_factor, float phase) {
+    float* x = malloc(sizeof(float) * (sz + 64));
+    float* w = malloc(sizeof(float) * (sz + 64));
+    for (size_t k = 0; k < bars; ++k) {
+        float idx = phase == 0.0F ? (float) k / (float) bars : ((float) k + phase) / (float) bars;
+        float smin = glvo_scale_audio(glvo_clamp01(idx - smooth_factor)) * sz;
+        float smax = glvo_scale_audio(glvo_clamp01(idx + smooth_factor)) * sz;
+        float m = (smax - smin) / 2.0F, rm = smin + m;
+        float weight = 0;
+        size_t cnt = 0;
+        for (float s = smin; s <= smax; s += 1.0F) {
+            float wt = glvo_sinusoidal(glvo_clamp01((m - fabsf(rm - s)) / m));
+            weight += wt;
+            w[cnt] = wt;
+            x[cnt] = glvo_clamp01(tex[(int) roundf(s)]);
+            ++cnt;
+        }
+        for (size_t p = cnt; p < ((cnt + 63) / 64) * 64; ++p) { w[p] = 0; x[p] = 0; }
+        float total = 0;
+        for (size_t c0 = 0; c0 < cnt; c0 += 64) {
+            float lane[16];
+            for (int l = 0; l < 16; ++l) {
+                float acc = 0;
+                for (int i = 0; i < 4; ++i) acc = acc + x[c0 + 4 * l + i] * w[c0 + 4 * l + i];
+                lane[l] = acc;
+            }
+            float q[4];
+            for (int g = 0; g < 4; ++g) q[g] = (lane[4 * g] + lane[4 * g + 1]) + (lane[4 * g + 2] + lane[4 * g + 3]);
+            total = total + ((q[0] + q[1]) + (q[2] + q[3]));
+        }
+        bars_out[k] = total / weight;
+    }
+    free(x); free(w);
 }

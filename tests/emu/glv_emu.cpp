@@ -191,11 +191,11 @@ void glvemu_div_65535(int lo, int hi, float* out) {
 extern "C" {
 // bars of `nrows` rows of n floats through work lists for `groups` 16-lane groups.  steps_out (may be NULL)
 // receives the step count; returns 0 on success.
-int glvemu_bars(const float* spec, size_t nrows, int n, int bars, float smooth_factor, int groups, float* out, unsigned* steps_out) {
+int glvemu_bars(const float* spec, size_t nrows, int n, int bars, float smooth_factor, int groups, float* out, unsigned* steps_out, float phase) {
     using namespace glv;
     std::vector<BarDesc> desc;
     std::vector<float> w;
-    make_bar_taps(desc, w, (uint32_t) n, (uint32_t) bars, smooth_factor);
+    make_bar_taps(desc, w, (uint32_t) n, (uint32_t) bars, smooth_factor, phase);
     const uint32_t zero_off = (uint32_t) w.size();
     w.resize(w.size() + kBarChunk, 0.0f);
     std::vector<BarItem> items;

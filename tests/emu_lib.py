@@ -17,11 +17,11 @@ def emu_process(L, n, data, units, ops, grav=None, hist=None, F=5, head=0, mono=
     return out
 
 
-def emu_bars(L, spec, n, bars, smooth_factor=0.025, groups=16):
+def emu_bars(L, spec, n, bars, smooth_factor=0.025, groups=16, phase=0.0):
     spec = np.ascontiguousarray(spec, dtype=np.float32).reshape(-1, n)
     out = np.zeros((spec.shape[0], bars), np.float32)
     steps = C.c_uint(0)
     rc = L.glvemu_bars(spec.ctypes.data_as(C.c_void_p), C.c_size_t(spec.shape[0]), n, bars, C.c_float(smooth_factor), groups,
-                       out.ctypes.data_as(C.c_void_p), C.byref(steps))
+                       out.ctypes.data_as(C.c_void_p), C.byref(steps), C.c_float(phase))
     assert rc == 0, rc
     return out, steps.value

@@ -1,0 +1,105 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/gl_vectors.npz: what the reference's GL audio path holds in its GL_R16 textures.
+
+The reference's real rd_new / rd_update (oracle/_ref/libglvglref.so = oracle/glref_harness.c unity-including the unmodified
+glava/render.c) run over a real OpenGL 4.5 core context -- Mesa's llvmpipe, reached through swrast_dri.so's DRI interface --
+with the shipped shader tree (/root/reference/shaders/glava: rc.glsl, module bars, util/*.frag).  For every case a sequence
+of stereo snapshots goes through rd_update with setaccelfft on; after each update the exact 16-bit texels of four textures
+per channel are recorded (render.c:521-524, 2188-2303):
+    up  the uploaded transform_fft output     gr  the gravity store     av  the ring average     sm  the pre-smoothing pass
+Needs /root/reference and Mesa (this container has both; the GPU box has neither the reference nor a need for them: the
+tests there compare against the committed file).
+
+    python tests/golden/make_gl_golden.py            # writes tests/golden/gl_vectors.npz
+"""
+import ctypes as C
+import os
+import subprocess
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+from oracle_lib import lcg_pcm_fast  # noqa: E402
+
+SO = os.path.join(ROOT, "oracle", "_ref", "libglvglref.so")
+SHADERS = "/root/reference/shaders/glava"
+UR = 86.1328125
+
+# name, n, avg_frames, avg_window, frames, pcm shift (>> keeps magnitudes inside [0, 1] where GL_R16 does not saturate)
+CASES = [("n1024_F5w", 1024, 5, True, 9, 4), ("n1024_F6u", 1024, 6, False, 9, 4), ("n1024_F1", 1024, 1, True, 5, 4),
+         ("n1024_F3w", 1024, 3, True, 6, 4), ("n1024_F2w", 1024, 2, True, 5, 4), ("n2048_F5w_loud", 2048, 5, True, 7, 0),
+         ("n4096_F5w", 4096, 5, True, 7, 5)]
+
+
+def frames_of(name, n, count, shift):
+    seed = 9000 + sum(name.encode())
+    pcm = (lcg_pcm_fast(seed, count * 2 * n).astype(np.int32) >> shift).astype(np.int16).reshape(count, n, 2)
+    return pcm
+
+
+def config_dir(tmp, F, win):
+    """a user configuration directory like `glava --copy-config` makes: links to the installed tree, and its own
+    smooth_parameters.glsl -- the reference's text with the two averaging requests changed (that file's #request lines are
+    processed when the module's shaders include it, after everything rc.glsl and the command line said)"""
+    import re
+    d = os.path.join(tmp, f"cfg_F{F}_{int(win)}")
+    os.makedirs(d, exist_ok=True)
+    for e in os.listdir(SHADERS):
+        dst = os.path.join(d, e)
+        if os.path.lexists(dst): os.remove(dst)
+        if e == "smooth_parameters.glsl":
+            txt = open(os.path.join(SHADERS, e)).read()
+            txt, n1 = re.subn(r"#request setavgframes \d+", f"#request setavgframes {F}", txt)
+            txt, n2 = re.subn(r"#request setavgwindow \w+", f"#request setavgwindow {'true' if win else 'false'}", txt)
+            assert n1 == 1 and n2 == 1
+            open(dst, "w").write(txt)
+        else:
+            os.symlink(os.path.join(SHADERS, e), dst)
+    return d
+
+
+def run_case(n, F, win, pcm, tmp):
+    """one renderer per case; rd_new can be called repeatedly in one process (every call makes its own context)"""
+    L = C.CDLL(SO)
+    L.glref_create.restype = C.c_void_p
+    L.glref_create.argtypes = [C.c_char_p, C.c_char_p, C.POINTER(C.c_char_p), C.c_float]
+    L.glref_avg_frames.argtypes = [C.c_void_p]
+    fp = np.ctypeslib.ndpointer(np.float32, flags="C_CONTIGUOUS")
+    L.glref_update.argtypes = [C.c_void_p, fp, fp, C.c_size_t, C.c_int, np.ctypeslib.ndpointer(np.uint16, flags="C_CONTIGUOUS")]
+    L.glref_gl_version.restype = C.c_char_p; L.glref_gl_renderer.restype = C.c_char_p
+    reqs = (C.c_char_p * 2)(b"setbufsize %d" % n, None)
+    h = L.glref_create(config_dir(tmp, F, win).encode(), SHADERS.encode(), reqs, UR)
+    assert h and L.glref_avg_frames(h) == F
+    out = np.zeros((pcm.shape[0], 2, 4, n), np.uint16)
+    for f in range(pcm.shape[0]):
+        lb = (pcm[f, :, 0].astype(np.float32) / np.float32(65535)).copy()          # fifo.c:105-106
+        rb = (pcm[f, :, 1].astype(np.float32) / np.float32(65535)).copy()
+        assert L.glref_update(h, lb, rb, n, 1, out[f]) == 2
+    return out, L.glref_gl_version().decode(), L.glref_gl_renderer().decode()
+
+
+def main():
+    if not os.path.exists(SO):
+        subprocess.run(["make", "-C", os.path.join(ROOT, "oracle"), "-s"], check=True)
+    import tempfile
+    vecs = {}
+    info = None
+    tmp = tempfile.mkdtemp(prefix="glv_glref_")
+    for name, n, F, win, count, shift in CASES:
+        pcm = frames_of(name, n, count, shift)
+        tex, ver, rend = run_case(n, F, win, pcm, tmp)
+        vecs[f"{name}_pcm"] = pcm
+        vecs[f"{name}_tex"] = tex
+        info = f"{ver} / {rend}"
+        print(name, "ok", tex.shape, info, flush=True)
+    vecs["gl_implementation"] = np.array(info)
+    vecs["ur"] = np.float32(UR)
+    np.savez_compressed(os.path.join(HERE, "gl_vectors.npz"), **vecs)
+    print("wrote", os.path.join(HERE, "gl_vectors.npz"), os.path.getsize(os.path.join(HERE, "gl_vectors.npz")), "bytes")
+
+
+if __name__ == "__main__":
+    main()

@@ -16,3 +16,4 @@ for k,v in d['configs'].items():
     if 'classes' in v:
         for c in v['classes']: print('   ', c['n'], round(c['avg_kernel_ms'],4), round(c['roofline_frac'],4))
 PY
+python tools/variant_survey.py --out $O/variants.txt --wisdom $O/wisdom_mi355x.txt > /dev/null 2> $O/variants.err; cat $O/variants.txt | cut -c1-200

@@ -8,7 +8,11 @@
 // GPU and torch.distributed: the host side of the reference is C, so a C host gets the same thing without Python.
 //
 // librccl is resolved with dlopen at glv_multi_create: a single-GPU host that never calls glv_multi_* does not need
-// the library to be installed, and libglvspectrum.so carries no link-time dependency on it.
+// the library to be installed, and libglvspectrum.so carries no link-time dependency on it.  The data path needs no
+// collective at all, so a host without RCCL (or GLV_MULTI_RCCL=0) still runs: the stats table is then assembled on the
+// host, where every shard's record already is (all shards are driven from this process).  Only in that mode may a device be
+// listed more than once (several shards on one GPU: how the several-shard machinery is tested on a one-GPU box; RCCL itself
+// refuses two ranks on one device).
 #include <dlfcn.h>
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
@@ -17,6 +21,7 @@
 #include <chrono>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -122,10 +127,17 @@ int glv_multi_create(const glv_params* p, uint64_t total_streams, unsigned ops_m
     for (int i = 0; i < ndev; ++i) {
         const int d = devices ? devices[i] : i;
         if (d < 0 || d >= have) { delete m; return failm(GLV_ERR_INVALID, "device %d out of range [0, %d)", d, have); }
-        for (int j = 0; j < i; ++j)
-            if (m->devices[j] == d) { delete m; return failm(GLV_ERR_INVALID, "device %d listed twice (one shard per device)", d); }
         m->devices.push_back(d);
     }
+    const char* env_rccl = std::getenv("GLV_MULTI_RCCL");
+    const bool want_rccl = !(env_rccl && env_rccl[0] == '0');
+    for (int i = 0; i < ndev; ++i)
+        for (int j = 0; j < i; ++j)
+            if (m->devices[j] == m->devices[i] && want_rccl) {
+                const int d = m->devices[i];
+                delete m;
+                return failm(GLV_ERR_INVALID, "device %d listed twice (one shard per device; several shards on one device only with GLV_MULTI_RCCL=0)", d);
+            }
     m->first.resize(ndev); m->count.resize(ndev);
     m->batch.assign(ndev, nullptr); m->stream.assign(ndev, nullptr); m->comm.assign(ndev, nullptr);
     m->d_stats.assign(ndev, nullptr); m->d_secs.assign(ndev, nullptr);
@@ -142,14 +154,14 @@ int glv_multi_create(const glv_params* p, uint64_t total_streams, unsigned ops_m
             hipMalloc(&m->d_secs[i], sizeof(double) * 2) != hipSuccess)
             rc = failm(GLV_ERR_HIP, "device %d: stream / stats buffer allocation failed", m->devices[i]);
     }
-    if (rc == GLV_OK) {
+    if (rc == GLV_OK && want_rccl) {
         std::string why;
-        if (!m->rccl.load(why)) rc = failm(GLV_ERR_HIP, "RCCL unavailable: %s", why.c_str());
-        else {
+        if (m->rccl.load(why)) {
             ncclResult_t r = m->rccl.CommInitAll(m->comm.data(), ndev, m->devices.data());
             if (r != ncclSuccess) rc = failm(GLV_ERR_HIP, "ncclCommInitAll failed: %s", m->rccl.GetErrorString(r));
             else m->use_rccl = true;
         }
+        // librccl not installed: not an error -- the stats are gathered on the host (glv_multi_uses_rccl tells which)
     }
     if (rc != GLV_OK) { std::string keep = glv_last_error(); glv_multi_destroy(m); return glv_set_last_error(rc, keep.c_str()); }
     *out = m;
@@ -171,6 +183,7 @@ int glv_multi_destroy(glv_multi* m) {
 }
 
 int glv_multi_devices(const glv_multi* m) { return m ? (int) m->devices.size() : 0; }
+int glv_multi_uses_rccl(const glv_multi* m) { return m && m->use_rccl ? 1 : 0; }
 
 int glv_multi_shard(const glv_multi* m, int idx, int* device, uint64_t* first_stream, uint32_t* streams, glv_batch** batch) {
     if (!m) return failm(GLV_ERR_INVALID, "multi is NULL");
@@ -188,12 +201,25 @@ int glv_multi_run_s16(glv_multi* m, const int16_t* const* d_pcm, float* const* d
     if (!d_pcm || !d_out) return failm(GLV_ERR_INVALID, "NULL pointer table");
     if (steps < 1 || warmup < 0) return failm(GLV_ERR_INVALID, "steps must be >= 1, warmup >= 0");
     const int G = (int) m->devices.size();
+    // a chain that ends in gravity may leave its spectra in the state (d_out[i] == NULL, glv_batch_process_s16); every other needs a buffer
+    const bool out_optional = (ops & GLV_OP_GRAVITY) && !(ops & (GLV_OP_AVERAGE | GLV_OP_SMOOTH | GLV_OP_RAW | GLV_OP_BARS | GLV_OP_R16));
+    for (int i = 0; i < G; ++i) {
+        if (!d_pcm[i]) return failm(GLV_ERR_INVALID, "d_pcm[%d] is NULL", i);
+        if (!d_out[i] && !out_optional) return failm(GLV_ERR_INVALID, "d_out[%d] is NULL", i);
+    }
+    int caller_device = -1;
+    (void) hipGetDevice(&caller_device);                       // worker 0 runs on the caller's thread: put its device back afterwards
     SpinBarrier bar; bar.n = G;
+    std::atomic<bool> cancel{false};
+    std::atomic<int> started{0};
     std::vector<int> rcs(G, GLV_OK);
     std::vector<std::string> errs(G);
-    std::vector<glv_multi_stats> gathered((size_t) G * G);
+    std::vector<glv_multi_stats> gathered((size_t) G * G), mine_all(G);
     std::vector<double> maxs(G, 0.0);
     auto worker = [&](int i) {
+        // parked until every worker thread exists: if one could not be created, nobody enters the barriers
+        while (started.load(std::memory_order_acquire) < G - 1 && !cancel.load(std::memory_order_acquire)) std::this_thread::yield();
+        if (cancel.load(std::memory_order_acquire)) return;
         int rc = GLV_OK;
         auto note = [&](int code, const char* what) { if (rc == GLV_OK) { rc = code; errs[i] = what; } };
         if (hipSetDevice(m->devices[i]) != hipSuccess) note(GLV_ERR_HIP, "hipSetDevice failed");
@@ -212,11 +238,20 @@ int glv_multi_run_s16(glv_multi* m, const int16_t* const* d_pcm, float* const* d
         const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
         double kms = 0.0; uint64_t nl = 0;
         if (rc == GLV_OK) (void) glv_batch_timing_end(m->batch[i], &kms, &nl);
-        glv_multi_stats mine;
+        glv_multi_stats& mine = mine_all[i];
         mine.frames = (uint64_t) m->count[i] * (uint64_t) steps;
         mine.seconds = secs;
         mine.bytes = glv_batch_algorithmic_bytes(m->batch[i], ops, 1) * (uint64_t) steps;
         mine.kernel_ms = kms;
+        if (!m->use_rccl) {
+            // no RCCL on this host: every shard's record is in this process -- wait for all of them, copy the table
+            bar.wait();
+            double mx = 0.0;
+            for (int j = 0; j < G; ++j) { gathered[(size_t) i * G + j] = mine_all[j]; mx = mine_all[j].seconds > mx ? mine_all[j].seconds : mx; }
+            maxs[i] = mx;
+            rcs[i] = rc;
+            return;
+        }
         // the only communication of the whole path: 32 bytes per rank, gathered on every rank, + max of the elapsed time
         glv_multi_stats* src = m->d_stats[i] + G;
         bool ok = hipMemcpyAsync(src, &mine, sizeof(mine), hipMemcpyHostToDevice, st) == hipSuccess &&
@@ -231,13 +266,19 @@ int glv_multi_run_s16(glv_multi* m, const int16_t* const* d_pcm, float* const* d
             hipMemcpyAsync(&maxs[i], m->d_secs[i] + 1, sizeof(double), hipMemcpyDeviceToHost, st) != hipSuccess ||
             hipStreamSynchronize(st) != hipSuccess)
             note(GLV_ERR_HIP, "stats download failed");
-        (void) hipStreamSynchronize(st);     // nothing may still read `mine` / `secs` (this frame) once the worker returns
+        (void) hipStreamSynchronize(st);     // nothing may still read `secs` (this frame) once the worker returns
         rcs[i] = rc;
     };
     std::vector<std::thread> th;
-    for (int i = 1; i < G; ++i) th.emplace_back(worker, i);
-    worker(0);
+    bool spawn_failed = false;
+    for (int i = 1; i < G; ++i) {
+        try { th.emplace_back(worker, i); started.fetch_add(1, std::memory_order_release); }
+        catch (...) { spawn_failed = true; cancel.store(true, std::memory_order_release); break; }
+    }
+    if (!spawn_failed) worker(0);
     for (auto& t : th) t.join();
+    if (caller_device >= 0) (void) hipSetDevice(caller_device);
+    if (spawn_failed) return failm(GLV_ERR_NOMEM, "could not start one host thread per device (%d needed)", G - 1);
     for (int i = 0; i < G; ++i)
         if (rcs[i] != GLV_OK) return failm(rcs[i], "device %d: %s", m->devices[i], errs[i].c_str());
     // every rank must have received the same table: a mismatch means the collective did not do its job

@@ -108,6 +108,7 @@ def lib() -> C.CDLL:
         L.glv_multi_create.argtypes = [P, C.c_uint64, C.c_uint, C.POINTER(C.c_int), C.c_int, C.POINTER(vp)]
         L.glv_multi_destroy.argtypes = [vp]
         L.glv_multi_devices.argtypes = [vp]
+        L.glv_multi_uses_rccl.argtypes = [vp]
         L.glv_multi_shard.argtypes = [vp, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_uint64), C.POINTER(C.c_uint32), C.POINTER(vp)]
         L.glv_multi_run_s16.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), C.c_uint, C.c_int, C.c_int, C.POINTER(MultiStats), C.POINTER(C.c_double)]
         _lib = L
@@ -274,6 +275,9 @@ class Multi:
         arr = (C.c_int * max(n, 1))(*devices) if devices is not None else None
         _check(lib().glv_multi_create(C.byref(cp), total_streams, ops_mask, arr, n, C.byref(self._h)))
         self.ndev = n
+
+    def uses_rccl(self) -> bool:
+        return bool(lib().glv_multi_uses_rccl(self._h))
 
     def shard(self, idx: int) -> tuple[int, int, int]:
         dev, lo, cnt = C.c_int(0), C.c_uint64(0), C.c_uint32(0)

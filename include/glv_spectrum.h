@@ -297,7 +297,8 @@ const char* glv_batch_kernel_name(const glv_batch* b);
  *    updates, barrier + synchronize) and then performs the ONLY communication of the path:
  *    one ncclAllGather of a 32-byte stats record per rank and one ncclAllReduce(max) of the
  *    elapsed seconds, over RCCL (xGMI inside a node).  librccl is resolved with dlopen by
- *    glv_multi_create; hosts that never call glv_multi_* do not need it.
+ *    glv_multi_create; hosts that never call glv_multi_* do not need it, and a host without it still runs
+ *    (the 32-byte records are then collected on the host: glv_multi_uses_rccl).
  * ------------------------------------------------------------------------------------ */
 typedef struct glv_multi glv_multi;
 typedef struct glv_multi_stats {   /* what every rank contributes to the all-gather (32 bytes) */
@@ -313,6 +314,9 @@ void glv_multi_shard_range(uint64_t total_streams, int rank, int world, uint64_t
 int glv_multi_create(const glv_params* p, uint64_t total_streams, unsigned ops_mask, const int* devices, int ndev, glv_multi** out);
 int glv_multi_destroy(glv_multi* m);
 int glv_multi_devices(const glv_multi* m);
+/* 1: the stats record travels over RCCL; 0: librccl is not installed (or GLV_MULTI_RCCL=0) and the table is assembled on the
+ * host -- the data path has no collective either way.  Only in the second mode may `devices` name a device more than once. */
+int glv_multi_uses_rccl(const glv_multi* m);
 /* shard idx: its device, first global stream, stream count and the glv_batch that owns its state (any may be NULL) */
 int glv_multi_shard(const glv_multi* m, int idx, int* device, uint64_t* first_stream, uint32_t* streams, glv_batch** batch);
 /* d_pcm[idx] / d_out[idx]: that shard's buffers on its own device (int16 [streams][n][2] / float [streams][2][n], or the

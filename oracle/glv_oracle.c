@@ -228,7 +228,7 @@ double glvo_bench_frames(const int16_t* pcm, size_t frames, size_t n, float fft_
  * used only where oracle/_ref is absent).  frames_done[t] = frames thread t finished; returns elapsed seconds. */
 #include <pthread.h>
 #include <time.h>
-typedef struct { const int16_t* pcm; size_t frames, n; float scale, cutoff; double deadline, t_end; unsigned long long done; double sink; } glvo_mt_arg;
+typedef struct { const int16_t* pcm; size_t frames, n; float scale, cutoff; volatile double deadline; double t_end; unsigned long long done; double sink; } glvo_mt_arg;
 static double glvo_now(void) { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec + 1e-9 * ts.tv_nsec; }
 static void* glvo_mt_worker(void* v) {
     glvo_mt_arg* a = v;
@@ -241,10 +241,17 @@ double glvo_bench_mt(const int16_t* pcm, size_t frames, size_t n, float fft_scal
     if (threads < 1 || threads > 4096) return -1.0;
     pthread_t* th = calloc(threads, sizeof(*th));
     glvo_mt_arg* arg = calloc(threads, sizeof(*arg));
+    if (!th || !arg) { free(th); free(arg); return -3.0; }
     const double t0 = glvo_now();
     for (int t = 0; t < threads; ++t) {
         arg[t] = (glvo_mt_arg){ .pcm = pcm, .frames = frames, .n = n, .scale = fft_scale, .cutoff = fft_cutoff, .deadline = t0 + seconds };
-        if (pthread_create(&th[t], NULL, glvo_mt_worker, &arg[t]) != 0) { free(th); free(arg); return -2.0; }
+        if (pthread_create(&th[t], NULL, glvo_mt_worker, &arg[t]) != 0) {
+            /* the threads already running read arg[]: end their run (a deadline in the past) and join them before freeing */
+            for (int u = 0; u < t; ++u) arg[u].deadline = 0.0;
+            for (int u = 0; u < t; ++u) pthread_join(th[u], NULL);
+            free(th); free(arg);
+            return -2.0;
+        }
     }
     double t_end = t0;
     for (int t = 0; t < threads; ++t) {

@@ -194,7 +194,7 @@ double glvref_bench_frames(const glvref_params* p, const int16_t* pcm, size_t fr
 #include <time.h>
 typedef struct {
     const glvref_params* p; const int16_t* pcm; size_t frames, n; int with_state;
-    double deadline, t_end; unsigned long long done; double sink;
+    volatile double deadline; double t_end; unsigned long long done; double sink;
 } glvref_mt_arg;
 static double glvref_now(void) { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec + 1e-9 * ts.tv_nsec; }
 static void* glvref_mt_worker(void* v) {
@@ -211,10 +211,17 @@ double glvref_bench_mt(const glvref_params* p, const int16_t* pcm, size_t frames
     if (threads < 1 || threads > 4096) return -1.0;
     pthread_t* th = calloc(threads, sizeof(*th));
     glvref_mt_arg* arg = calloc(threads, sizeof(*arg));
+    if (!th || !arg) { free(th); free(arg); return -3.0; }
     const double t0 = glvref_now();
     for (int t = 0; t < threads; ++t) {
         arg[t] = (glvref_mt_arg){ .p = p, .pcm = pcm, .frames = frames, .n = n, .with_state = with_state, .deadline = t0 + seconds };
-        if (pthread_create(&th[t], NULL, glvref_mt_worker, &arg[t]) != 0) { free(th); free(arg); return -2.0; }
+        if (pthread_create(&th[t], NULL, glvref_mt_worker, &arg[t]) != 0) {
+            /* the threads already running read arg[]: end their run (a deadline in the past) and join them before freeing */
+            for (int u = 0; u < t; ++u) arg[u].deadline = 0.0;
+            for (int u = 0; u < t; ++u) pthread_join(th[u], NULL);
+            free(th); free(arg);
+            return -2.0;
+        }
     }
     double t_end = t0;
     for (int t = 0; t < threads; ++t) {

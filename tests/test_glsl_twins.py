@@ -77,8 +77,8 @@ def test_host_bar_tables_equal_the_shader_evaluation(emu, n, bars, factor, seed)
     tex = tex_row(n, seed)
     got = np.empty(bars, np.float32)
     emu.glvemu_bars.argtypes = [np.ctypeslib.ndpointer(np.float32), C.c_size_t, C.c_int, C.c_int, C.c_float, C.c_int,
-                                np.ctypeslib.ndpointer(np.float32), C.c_void_p]
-    assert emu.glvemu_bars(tex, 1, n, bars, factor, 16, got, None) == 0
+                                np.ctypeslib.ndpointer(np.float32), C.c_void_p, C.c_float]
+    assert emu.glvemu_bars(tex, 1, n, bars, factor, 16, got, None, 0.0) == 0
     assert np.abs(got - want).max() <= 4 * ULPS * np.abs(want).max()
 
 

@@ -52,7 +52,7 @@ def test_c_multi_driver_on_a_one_device_node(glvlib):
     n, streams, steps = 4096, 777, 3
     p = G.Params(n=n)
     m = G.Multi(p, streams, G.OP_FFT, devices=[0])
-    assert m.shard(0) == (0, 0, streams)
+    assert m.shard(0) == (0, 0, streams) and m.uses_rccl()
     from oracle_lib import lcg_pcm_fast
     pcm = lcg_pcm_fast(99, streams * 2 * n)
     d_pcm = torch.from_numpy(pcm).cuda()
@@ -71,6 +71,55 @@ def test_c_multi_driver_on_a_one_device_node(glvlib):
     b.close(); m.close()
     # a device listed twice is refused (one shard per device)
     with pytest.raises(G.GlvError):
+        G.Multi(p, 64, G.OP_FFT, devices=[0, 0])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shards", [2, 3])
+def test_c_multi_driver_several_shards_without_rccl(glvlib, monkeypatch, shards):
+    """the several-shard machinery of glv_multi_run_s16 (one host thread per shard, the spin barrier around the
+    timed region, per-shard streams and batches, the stats table) had only ever run with one shard.  Without RCCL
+    (GLV_MULTI_RCCL=0, or a host that does not have the library) the 32-byte records are collected on the host -- the data
+    path never had a collective -- and only then may one device carry several shards, which is how a one-GPU box exercises
+    it: contiguous balanced shards, every shard's spectra equal to a plain batch's, every rank's table identical, the
+    caller's current device restored, NULL shard pointers refused up front."""
+    import torch
+    G = glvlib
+    monkeypatch.setenv("GLV_MULTI_RCCL", "0")
+    n, streams, steps = 2048, 1001, 3
+    p = G.Params(n=n)
+    m = G.Multi(p, streams, G.OP_FFT, devices=[0] * shards)
+    assert not m.uses_rccl()
+    from oracle_lib import lcg_pcm_fast
+    pcm = lcg_pcm_fast(7, streams * 2 * n).reshape(streams, 2 * n)
+    b = G.Batch(p, streams, G.OP_FFT)
+    d_all = torch.from_numpy(pcm).cuda()
+    d_ref = torch.zeros((streams * 2, n), dtype=torch.float32, device="cuda")
+    b.process_s16(d_all, d_ref, G.OP_FFT)
+    ins, outs, spans = [], [], []
+    covered = 0
+    for i in range(shards):
+        dev, lo, cnt = m.shard(i)
+        assert dev == 0 and lo == covered and cnt in (streams // shards, streams // shards + 1)
+        covered += cnt
+        ins.append(torch.from_numpy(np.ascontiguousarray(pcm[lo:lo + cnt])).cuda())
+        outs.append(torch.zeros((cnt * 2, n), dtype=torch.float32, device="cuda"))
+        spans.append((lo, cnt))
+    assert covered == streams
+    torch.cuda.set_device(0)
+    stats, mx = m.run_s16(ins, outs, G.OP_FFT, warmup=1, steps=steps)
+    torch.cuda.synchronize()
+    assert torch.cuda.current_device() == 0
+    assert len(stats) == shards and [s["frames"] for s in stats] == [c * steps for _, c in spans]
+    assert mx == max(s["seconds"] for s in stats) and all(s["kernel_ms"] > 0 for s in stats)
+    for (lo, cnt), o in zip(spans, outs):
+        assert torch.equal(o.view(torch.int32), d_ref[2 * lo:2 * (lo + cnt)].view(torch.int32)), lo
+    with pytest.raises(G.GlvError) as e:
+        m.run_s16([ins[0]] + [None] * (shards - 1), outs, G.OP_FFT, warmup=0, steps=1)
+    assert e.value.code == G.ERR_INVALID
+    b.close(); m.close()
+    monkeypatch.delenv("GLV_MULTI_RCCL")
+    with pytest.raises(G.GlvError):                      # with RCCL in play one device cannot carry two shards
         G.Multi(p, 64, G.OP_FFT, devices=[0, 0])
 
 

@@ -238,6 +238,25 @@ template <typename V> GLV_HD void st(void* base, uint32_t byte_off, const V& v) 
     *reinterpret_cast<V*>(static_cast<char*>(base) + byte_off) = v;
 }
 
+// TILTREG 3 (log_mode 1 only): the folded tilt factor tilt(n) * ln2/3 from two fused multiply-adds instead of the reference's
+// separately rounded chain.  tilt(n) = max(n/N * fft_scale + (1 - fft_cutoff), 1) is linear in the float index n above its
+// clamp, so   tilt(n) * k  ~=  max(fma(c, S, B), k),   S = fl(fft_scale * (1/N) * k),  B = fma((float) n_base, S, fl(one_minus_cutoff * k)),
+// n = n_base + c with c a compile-time constant.  Two instructions per value where the exact evaluation costs six; at most
+// four roundings of 2^-24 (S, O, B, the final fma) against the exact product: <= 2.4e-7 relative to tilt * k, next to the
+// 1.8e-7 of the hardware log -- the contract of log_mode 1 is 1e-5 (tests/test_emulator.py bounds the formula over every n).
+// log_mode 0 and 2 keep the reference's own float operations (TILTREG 2).
+constexpr float kLn2Third = (float) (0.69314718055994530942 / 3.0);
+struct TiltLin { float S, O, K; };
+GLV_HD TiltLin tilt_lin(float inv_n, float fft_scale, float one_minus_cutoff) {
+    TiltLin t;
+    t.S = (fft_scale * inv_n) * kLn2Third;          // inv_n is a power of two: the first product is exact
+    t.O = one_minus_cutoff * kLn2Third;
+    t.K = kLn2Third;
+    return t;
+}
+GLV_HD float tilt_lin_base(const TiltLin& t, int n_base) { return __builtin_fmaf((float) n_base, t.S, t.O); }
+GLV_HD float tilt_lin_at(const TiltLin& t, float base, int c) { return __builtin_fmaxf(__builtin_fmaf((float) c, t.S, base), t.K); }
+
 // ---- scalar pieces ----------------------------------------------------------------------------
 // fifo.c:105-106: (float) s16 / (float) 65535, IEEE single division.
 // Evaluated without a divide: 1/65535 = c_hi + c_lo + (< 2^-48 relative), c_hi = 0x1.0001p-16, c_lo = 0x1.0001p-48, and
@@ -267,8 +286,7 @@ GLV_HD float tilt(int n, float inv_n, float fft_scale, float one_minus_cutoff) {
 }
 
 // tilt as the kernels multiply it: log_mode 1 folds ln2/3 in (log2 -> log/3) with ONE float multiply,
-// the same expression on the host (glv_tables.h make_tilt) and on the device
-constexpr float kLn2Third = (float) (0.69314718055994530942 / 3.0);
+// the same expression on the host (glv_tables.h make_tilt) and on the device (kLn2Third: defined with tilt_lin above)
 template <bool FOLD_LN2_3>
 GLV_HD float tilt_factor(int n, float inv_n, float fft_scale, float one_minus_cutoff) {
     const float t = tilt(n, inv_n, fft_scale, one_minus_cutoff);

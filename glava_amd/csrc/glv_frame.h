@@ -762,7 +762,8 @@ struct Frame {
     }
 
     // TILTREG 0: tilt factors read from the table per row; 1: from `tl_reg` (registers, gathered once per
-    // kernel); 2: evaluated in registers with the reference's float operations (no memory at all)
+    // kernel); 2: evaluated in registers with the reference's float operations (no memory at all); 3: with log_mode 1 the
+    // folded factor from two fused multiply-adds (glv_core.h tilt_lin; tl_reg[0].x carries the lane's base term), else as 2
     // R16: the output row is uint16 [n] (GL_R16 texels, glv_core.h unorm16) instead of float [n]; state stays f32
     // NONFINITE: the row may hold Inf / NaN (f32 input): log_mode 0 then needs log_third_nf's select
     template <int LOG_MODE, int EPI, int TILTREG = 0, bool R16 = false, bool NONFINITE = false>
@@ -770,6 +771,15 @@ struct Frame {
                                 const LogEntry* logtab, const cf* tl_reg = nullptr) {
         using PI = PassInfo<P - 1>;
         constexpr bool STATE = EPI == EPI_MAG_STATE || EPI == EPI_RAW_STATE;
+        // TILTREG 3: the lane's base term, re-defined opaquely per row -- the factors derived from it are loop invariant and
+        // LLVM would otherwise hoist all 2E of them out of the row loop (and spill them)
+        float tilt_base = 0.0f;
+        if constexpr (TILTREG == 3 && LOG_MODE == 1) {
+            tilt_base = tl_reg[0].x;
+#if defined(__HIP_DEVICE_COMPILE__)
+            asm volatile("" : "+v"(tilt_base));
+#endif
+        }
         // magnitude of register slot (gi, r): abs/log/tilt, or the raw value
         auto value = [&](int gi, int r) -> cf {
             cf val = v[gi * PI::R + r];
@@ -779,7 +789,13 @@ struct Frame {
                 const float y0 = __builtin_fabsf(val.x) + 1.0f, y1 = __builtin_fabsf(val.y) + 1.0f;   // render.c:843-844
                 cf tl;                                                                                      // :845 factors
                 if constexpr (TILTREG == 1) tl = tl_reg[gi * PI::R + r];
-                else if constexpr (TILTREG == 2) {
+                else if constexpr (TILTREG == 3 && LOG_MODE == 1) {
+                    // n = 2 q = 2 * (lane part) + 2 * (compile-time part): the lane part went into tl_reg[0].x once per kernel
+                    const int c = 2 * out_index<P - 1>(0, gi, r);
+                    const TiltLin tlin = tilt_lin(a.inv_n, a.fft_scale, a.one_minus_cutoff);
+                    tl.x = tilt_lin_at(tlin, tilt_base, c);
+                    tl.y = tilt_lin_at(tlin, tilt_base, c + 1);
+                } else if constexpr (TILTREG == 2 || TILTREG == 3) {
                     tl.x = tilt_factor<LOG_MODE == 1>(2 * q, a.inv_n, a.fft_scale, a.one_minus_cutoff);
                     tl.y = tilt_factor<LOG_MODE == 1>(2 * q + 1, a.inv_n, a.fft_scale, a.one_minus_cutoff);
                 } else tl = ld<cf>(a.tilt, (uint32_t) q * 8u);

@@ -36,9 +36,9 @@ GLV_TUNED(11,   0, 4,    2,    1,   true,  true,  2,  1,       true,   0,   0,  
 GLV_TUNED(11,   1, 3,    2,    1,   true,  true,  3,  1,       true,   0,   0,   2)    //          E=8:  3+3+3+2, 3 waves per SIMD (0.672 vs 0.647 ms; 0.917 vs 0.909 with log_mode 0)
 GLV_TUNED(12,   0, 4,    2,    1,   true,  true,  2,  1,       true,   0,   0,   1)    // N=8192   E=16: 4+4+4; two slots share the 64 KiB LDS window
 GLV_TUNED(12,   1, 4,    1,    1,   true,  false, 2,  1,       true,   0,   0,   2)    //          one row per workgroup, two workgroups per CU, window through L2 (tie with log_mode 0 in the r01 sweep)
-GLV_TUNED(13,   0, 5,    1,    1,   2,     false, 2,  1,       2,      0,   0,   2)    // N=16384  E=32: 5+5+3; pass-1 twiddles from an 8 KiB LDS table, tilt computed
+GLV_TUNED(13,   0, 5,    1,    1,   2,     false, 2,  1,       3,      0,   0,   2)    // N=16384  E=32: 5+5+3; pass-1 twiddles from an 8 KiB LDS table, tilt computed (log_mode 1: two fused ops per value)
                                                                                        //          (WPRE, the window prefetch ahead of the stores, measured no gain: profiles/r02)
-GLV_TUNED(14,   0, 5,    1,    1,   2,     false, 2,  1,       2,      0,   0,   1)    // N=32768  E=32: 5+5+4, one 512-lane row per CU (135 KiB exchange region), pass-1 twiddles from LDS (sweep_13)
+GLV_TUNED(14,   0, 5,    1,    1,   2,     false, 2,  1,       3,      0,   0,   1)    // N=32768  E=32: 5+5+4, one 512-lane row per CU (135 KiB exchange region), pass-1 twiddles from LDS (sweep_13)
 GLV_NVARIANTS(8, 2) GLV_NVARIANTS(9, 2) GLV_NVARIANTS(10, 2) GLV_NVARIANTS(11, 2) GLV_NVARIANTS(12, 2)
 #undef GLV_TUNED
 #undef GLV_NVARIANTS

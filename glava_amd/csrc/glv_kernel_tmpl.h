@@ -35,6 +35,8 @@
 //   OCC     __launch_bounds__ minimum waves per SIMD (caps the VGPR budget: 512 / OCC)
 //   TILTREG   0: tilt factors re-read from the table per row; 1: the 2E per-lane factors stay in VGPRs across
 //             rows; 2: evaluated in registers with the reference's float operations (no memory, no registers)
+//             3: log_mode 1: the folded factor tilt * ln2/3 from a per-lane base term and ONE fused multiply-add + max per value
+//                (glv_core.h tilt_lin: <= 2.4e-7 relative, contract 1e-5); other log modes as 2
 //   PREFETCH  0: no software pipeline (load, transform, store per row)
 //           1: in-place pipeline -- the next frame's (s16, interleaved f32) or row's (planar f32) samples
 //              are requested before the current row's passes and unpacked/windowed after its epilogue,
@@ -297,6 +299,12 @@ glv_frame_kernel(const FrameArgs a) {
     if constexpr (FR::P > 1) BD::template gather_resident<1>(tw_all, a.tw, tid);
     cf tilt_reg[TILTREG == 1 ? E : 1];
     if constexpr (TILTREG == 1) FR::gather_tilt(tilt_reg, a.tilt, tid);
+    if constexpr (TILTREG == 3) {
+        // the lane part of every output index of the last pass: out_index(tid, gi, r) - out_index(0, gi, r) (the same for all gi, r)
+        const int lane_q = FR::template out_index<FR::P - 1>(tid, 0, 0) - FR::template out_index<FR::P - 1>(0, 0, 0);
+        tilt_reg[0].x = tilt_lin_base(tilt_lin(a.inv_n, a.fft_scale, a.one_minus_cutoff), 2 * lane_q);
+        tilt_reg[0].y = 0.0f;
+    }
 
     // operator chain, uniform for the launch.  Stateless and stateful chains are separate kernels
     // (STATEFUL): the history loads of gravity/average need ~60 more VGPRs in the epilogue, and having

@@ -253,3 +253,32 @@ def test_f32_special_values_like_the_compiled_reference(emu, oracle, ref, n, log
         assert (np.isnan(raw[r]) == rn).all(), r
         assert (bits(raw[r])[~rn] == bits(want_raw[r])[~rn]).all(), r
     assert np.isinf(want).any() and np.isnan(want).any()          # the rows do exercise both
+
+
+@pytest.mark.parametrize("n", [16384, 32768])
+def test_fused_tilt_formula_is_within_its_bound(n):
+    """glv_core.h tilt_lin (TILTREG 3, log_mode 1 at N >= 16384): the folded tilt factor tilt(i) * ln2/3 from a per-lane base
+    term and one fused multiply-add + max per value, against the exact product of the reference's tilt (render.c:845, float
+    operations) with ln2/3, for EVERY index and a few parameter sets: <= 4.5e-7 relative to that (itself three times rounded) product -- each side is
+    within ~2e-7 of the real value; the contract of log_mode 1 is 1e-5."""
+    f = np.float32
+    k = f(0.69314718055994530942 / 3.0)
+
+    def fma(a, b, c):
+        return f(np.float64(a) * np.float64(b) + np.float64(c))          # the f32 x f32 product is exact in f64
+    for scale, cutoff in ((10.2, 0.3), (0.0, 0.0), (20.0, 1.0), (3.7, 0.95)):
+        inv_n = f(1.0) / f(n)
+        omc = f(1.0) - f(cutoff)
+        S = f(f(f(scale) * inv_n) * k); O = f(omc * k)
+        idx = np.arange(n)
+        worst = 0.0
+        for base in (0, 4, 252, 1020, 2044):                   # the lane part 4 * tid (tid < 512) and the rest c >= 0, as in the kernel
+            c = np.maximum(idx - base, 0)
+            B = fma(f(base), S, O)
+            got = np.maximum(f(np.float64(c.astype(f)) * np.float64(S) + np.float64(B)), k).astype(f)
+            got[idx < base] = np.nan
+            t = (idx.astype(f) * inv_n) * f(scale)
+            t = (t.astype(f) + omc).astype(f)
+            exact = np.maximum(t, f(1.0)).astype(np.float64) * np.float64(k)
+            worst = max(worst, float(np.nanmax(np.abs(got.astype(np.float64) - exact) / exact)))
+        assert worst <= 4.5e-7, (n, scale, cutoff, worst)

@@ -38,6 +38,24 @@ BATCHES = {
               ("r3b_n13_new", 16384, 0, "N=16384 new (again)", "512"),
               ("r3b_n13_old", 8192, 2, "N=16384 x 8192 fft+gravity (state only), old", "512"),
               ("r3b_n13_new", 8192, 2, "N=16384 x 8192 fft+gravity (state only), new", "512")]),
+    "tilt": dict(
+        libs=[("r3c_n13_t2", 13, NOL0, "VW(1,1,2,false,2,1,2,5,0,0)"), ("r3c_n13_t3", 13, NOL0, "VW(1,1,2,false,2,1,3,5,0,0)"),
+              ("r3c_n14_t2", 14, NOL0, "VW(1,1,2,false,2,1,2,5,0,0)"), ("r3c_n14_t3", 14, NOL0, "VW(1,1,2,false,2,1,3,5,0,0)")],
+        runs=[("r3c_n13_t2", 16384, 0, "N=16384 tilt evaluated with the reference's operations (TILTREG 2)", "512"),
+              ("r3c_n13_t3", 16384, 0, "N=16384 tilt from one fused multiply-add + max per value (TILTREG 3)", "512"),
+              ("r3c_n13_t2", 16384, 0, "N=16384 TILTREG 2 (again)", "512"),
+              ("r3c_n13_t3", 16384, 0, "N=16384 TILTREG 3 (again)", "512"),
+              ("r3c_n14_t2", 8192, 0, "N=32768 TILTREG 2", "256"),
+              ("r3c_n14_t3", 8192, 0, "N=32768 TILTREG 3", "256"),
+              ("r3c_n13_t2", 8192, 2, "N=16384 x 8192 fft+gravity TILTREG 2", "512"),
+              ("r3c_n13_t3", 8192, 2, "N=16384 x 8192 fft+gravity TILTREG 3", "512")]),
+    "n8192e32": dict(
+        libs=[("r3d_n12_prod", 12, NOL0, "VW(2,1,true,true,2,1,1,4,0,0)"), ("r3d_n12_e32s4", 12, NOL0, "VW(4,1,2,false,2,1,3,5,0,0)"),
+              ("r3d_n12_e32s4_t2", 12, NOL0, "VW(4,1,2,false,2,1,2,5,0,0)")],
+        runs=[("r3d_n12_prod", 32768, 0, "N=8192 production (E=16, 2 rows x 4 waves, window + twiddles resident)", "256"),
+              ("r3d_n12_e32s4", 32768, 0, "N=8192 E=32: 4 rows x 2 waves per workgroup, window and last-pass twiddles through L2, fused tilt", "256,512"),
+              ("r3d_n12_e32s4_t2", 32768, 0, "N=8192 E=32 4 rows, exact tilt", "256"),
+              ("r3d_n12_prod", 32768, 0, "N=8192 production (again)", "256")]),
 }
 
 

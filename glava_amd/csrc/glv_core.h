@@ -241,9 +241,10 @@ template <typename V> GLV_HD void st(void* base, uint32_t byte_off, const V& v) 
 // TILTREG 3 (log_mode 1 only): the folded tilt factor tilt(n) * ln2/3 from two fused multiply-adds instead of the reference's
 // separately rounded chain.  tilt(n) = max(n/N * fft_scale + (1 - fft_cutoff), 1) is linear in the float index n above its
 // clamp, so   tilt(n) * k  ~=  max(fma(c, S, B), k),   S = fl(fft_scale * (1/N) * k),  B = fma((float) n_base, S, fl(one_minus_cutoff * k)),
-// n = n_base + c with c a compile-time constant.  Two instructions per value where the exact evaluation costs six; at most
-// four roundings of 2^-24 (S, O, B, the final fma) against the exact product: <= 2.4e-7 relative to tilt * k, next to the
-// 1.8e-7 of the hardware log -- the contract of log_mode 1 is 1e-5 (tests/test_emulator.py bounds the formula over every n).
+// n = n_base + c with c >= 0 a compile-time constant.  Two instructions per value where the exact evaluation costs six; at
+// most four roundings of 2^-24 (S, O, B, the final fma) against the real value, as many as the reference's own chain has:
+// <= 4.5e-7 relative to the reference's (thrice rounded) product tilt * k for every index (tests/test_emulator.py
+// test_fused_tilt_formula_is_within_its_bound), next to the 1.8e-7 of the hardware log -- the contract of log_mode 1 is 1e-5.
 // log_mode 0 and 2 keep the reference's own float operations (TILTREG 2).
 constexpr float kLn2Third = (float) (0.69314718055994530942 / 3.0);
 struct TiltLin { float S, O, K; };

@@ -36,7 +36,7 @@
 //   TILTREG   0: tilt factors re-read from the table per row; 1: the 2E per-lane factors stay in VGPRs across
 //             rows; 2: evaluated in registers with the reference's float operations (no memory, no registers)
 //             3: log_mode 1: the folded factor tilt * ln2/3 from a per-lane base term and ONE fused multiply-add + max per value
-//                (glv_core.h tilt_lin: <= 2.4e-7 relative, contract 1e-5); other log modes as 2
+//                (glv_core.h tilt_lin: <= 4.5e-7 from the reference's own rounded factor, contract 1e-5); other log modes as 2
 //   PREFETCH  0: no software pipeline (load, transform, store per row)
 //           1: in-place pipeline -- the next frame's (s16, interleaved f32) or row's (planar f32) samples
 //              are requested before the current row's passes and unpacked/windowed after its epilogue,

@@ -93,7 +93,9 @@ typedef struct glv_params {
     uint32_t log_mode;      /* render.c:844 evaluates log() in fp64 and divides by 3 in fp64, then rounds to float:
                                1: (default) hardware log2 * (ln2/3 * tilt) in fp32: <= 1.8e-7 relative error
                                   against the reference's float on EVERY float input of the stage (exhaustive
-                                  test, tests/test_gpu_parity.py::test_magnitude_stage_every_float; bar 1e-5)
+                                  test, tests/test_gpu_parity.py::test_magnitude_stage_every_float; bar 1e-5).  At n >= 16384
+                                  the factor ln2/3 * tilt itself comes from one fused multiply-add per value (<= 4.5e-7 from
+                                  the reference's thrice-rounded product): <= 6.3e-7 in total
                                0: bit-faithful: fp64 table-driven log (rel. error ~2^-50) and fp64 /3 -- the
                                   reference's float result on every input of the same exhaustive test
                                2: audit: device libm fp64 log + true fp64 division (slow) */

@@ -70,6 +70,8 @@ extern volatile int glv_hipfifo_spectra;
 /* what the "hipfifo" backend publishes from its next start on: 0 the sample rings (its default), 1 finished spectra */
 void glvshim_hipfifo_publish_spectra(int on) { glv_hipfifo_spectra = on ? 1 : 0; }
 
+/* pcm: the bytes to feed, `chunks` updates of `ssz` bytes (s16 backends: sample_sz bytes of interleaved s16) or of 2 * ssz
+ * bytes (name "hippulse": sample_sz / 4 interleaved stereo f32 frames, what pa_simple_read delivers per update) */
 long glvshim_backend_run(const char* name, const char* fifo_path, const int16_t* pcm, size_t chunks, size_t ssz, size_t fsz,
                          int channels, float* snapshots /* [max_events][2][fsz] */, unsigned char* zero_fill, size_t max_events) {
     struct audio_impl* impl = NULL;
@@ -77,6 +79,8 @@ long glvshim_backend_run(const char* name, const char* fifo_path, const int16_t*
         if (!strcmp(audio_impls[t]->name, name)) impl = audio_impls[t];
     if (!impl) return -1;
     const bool hip = !strcmp(name, "hipfifo");
+    const bool f32 = !strcmp(name, "hippulse");
+    const size_t wsz = f32 ? 2 * ssz : ssz;                /* bytes per update on the wire */
     unlink(fifo_path);
     if (mkfifo(fifo_path, 0600) != 0) return -2;
     float* bl = calloc(fsz, sizeof(float));
@@ -94,7 +98,7 @@ long glvshim_backend_run(const char* name, const char* fifo_path, const int16_t*
     unsigned long zf_seen = hip ? glv_hipfifo_zero_fills : 0;
     long rc = 0;
     for (size_t sent = 0; sent < chunks && ev < max_events; ++sent) {
-        if (write(wfd, (const char*) pcm + sent * ssz, ssz) != (ssize_t) ssz) { rc = -4; break; }
+        if (write(wfd, (const char*) pcm + sent * wsz, wsz) != (ssize_t) wsz) { rc = -4; break; }
         bool landed = false;
         while (!landed && ev < max_events) {
             pthread_mutex_lock(&audio.mutex);
@@ -102,6 +106,7 @@ long glvshim_backend_run(const char* name, const char* fifo_path, const int16_t*
                 audio.modified = false;
                 bool zf;
                 if (hip) { zf = glv_hipfifo_zero_fills != zf_seen; zf_seen = glv_hipfifo_zero_fills; }
+                else if (f32) zf = false;                   /* a blocking read: no poll-timeout updates */
                 else {
                     bool tail_zero = true, input_zero = true;
                     for (size_t q = fsz - ssz / 4; q < fsz; ++q) if (bl[q] != 0.0f || br[q] != 0.0f) { tail_zero = false; break; }
@@ -118,8 +123,9 @@ long glvshim_backend_run(const char* name, const char* fifo_path, const int16_t*
         }
     }
     audio.terminate = 1;                                   /* noticed after the backend's next event (a timeout) */
+    if (f32) { close(wfd); wfd = -1; }                     /* a blocking reader ends when the producer goes away */
     pthread_join(thr, NULL);
-    close(wfd);
+    if (wfd >= 0) close(wfd);
     unlink(fifo_path);
     free(bl); free(br); free(audio.source);
     return rc < 0 ? rc : (long) ev;

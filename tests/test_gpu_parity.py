@@ -983,6 +983,38 @@ def test_hipfifo_backend_through_the_registry(G, golden, channels, tmp_path):
     assert sent == chunks
 
 
+@pytest.mark.parametrize("channels", [2, 1])
+def test_hippulse_backend_through_the_registry(G, channels, tmp_path):
+    """The PulseAudio twin of the seam test above: integration/hippulse.c (AUDIO_ATTACH(hippulse), found by name in the same
+    registry) with its capture call replaced by a named pipe that delivers what pa_simple_read delivers -- sample_sz / 4
+    interleaved stereo f32 frames per update.  What it publishes is the ring / deinterleave result of pulse_input.c:155-176
+    (shift by sample_sz / 4, append, (L + R) / 2 for channels == 1), bit for bit; in spectra mode transform_fft of those rings."""
+    S = _shim()
+    fifo = str(tmp_path / "glv_hippulse_test.fifo").encode()
+    n, ssz, chunks = 2048, 1024, 7
+    nf = ssz // 4
+    x = (np.random.default_rng(60 + channels).standard_normal((chunks, nf, 2)) * 0.3).astype(np.float32)
+    x[2, 5, 0] = -0.0; x[3, 7, 1] = np.float32(1e-41)                       # the ring carries every float unchanged
+    feed = np.ascontiguousarray(x).view(np.int16).reshape(-1)                # the driver takes bytes
+    for spectra in (0, 1):
+        S.glvshim_hipfifo_publish_spectra(spectra)
+        try:
+            snaps, zf = run_backend(S, b"hippulse", fifo, feed, chunks, ssz, n, channels)
+        finally:
+            S.glvshim_hipfifo_publish_spectra(0)
+        assert len(zf) == chunks and not zf.any()
+        rl = np.zeros(n, np.float32); rr = np.zeros(n, np.float32)
+        for e in range(chunks):
+            pl = np.empty(nf, np.float32); pr = np.empty(nf, np.float32)
+            Oracle.lib().glvo_unpack_f32(np.ascontiguousarray(x[e].reshape(-1)), nf, channels, pl, pr)
+            rl = np.concatenate([rl[nf:], pl]); rr = np.concatenate([rr[nf:], pr])
+            if spectra:
+                wl = Oracle.transform_fft(rl.copy()); wr = Oracle.transform_fft(rr.copy())
+                assert np.allclose(snaps[e, 0], wl, rtol=REL, atol=1e-7) and np.allclose(snaps[e, 1], wr, rtol=REL, atol=1e-7), e
+            else:
+                assert (bits(snaps[e, 0]) == bits(rl)).all() and (bits(snaps[e, 1]) == bits(rr)).all(), e
+
+
 def test_ring_append_and_planar_snapshot(G):
     """glv_batch_ring_append_* + glv_batch_ring_planar: the device rings read back in publishing order equal the oracle's
     fifo.c / pulse_input.c replay bit for bit -- any update size, mono mix, zero fill, many streams; appending and then

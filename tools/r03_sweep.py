@@ -56,6 +56,17 @@ BATCHES = {
               ("r3d_n12_e32s4", 32768, 0, "N=8192 E=32: 4 rows x 2 waves per workgroup, window and last-pass twiddles through L2, fused tilt", "256,512"),
               ("r3d_n12_e32s4_t2", 32768, 0, "N=8192 E=32 4 rows, exact tilt", "256"),
               ("r3d_n12_prod", 32768, 0, "N=8192 production (again)", "256")]),
+    "occ3": dict(
+        libs=[("r3e_n11_prod", 11, NOL0, "VW(2,1,true,true,2,1,1,4,0,0)"),
+              ("r3e_n11_s6", 11, NOL0, "VW(6,1,4,true,3,1,3,4,0,0)"),
+              ("r3e_n11_s6t1", 11, NOL0, "VW(6,1,4,true,3,1,1,4,0,0)")],
+        runs=[("r3e_n11_prod", 65536, 0, "N=4096 production (2 rows x 2 waves per workgroup, 2 workgroups per CU, twiddles + tilt resident)", "0"),
+              ("r3e_n11_s6", 65536, 0, "N=4096 six rows per 768-thread workgroup, 3 waves per SIMD: twiddles from a 16 KiB LDS table, fused tilt", "256,512"),
+              ("r3e_n11_s6t1", 65536, 0, "N=4096 six rows, twiddles from LDS, tilt resident", "256,512"),
+              ("r3e_n11_prod", 65536, 256, "N=4096 production, GL_R16 output", "0"),
+              ("r3e_n11_s6", 65536, 256, "N=4096 six rows, GL_R16 output", "256,512"),
+              ("r3e_n11_s6t1", 65536, 256, "N=4096 six rows tilt resident, GL_R16 output", "256,512"),
+              ("r3e_n11_prod", 65536, 0, "N=4096 production (again)", "0")]),
 }
 
 

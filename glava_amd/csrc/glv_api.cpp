@@ -432,7 +432,7 @@ int check_ops(const glv_batch* b, unsigned ops, const float* d_out) {
     if ((ops & GLV_OP_RAW) && !(ops & GLV_OP_FFT)) return fail(GLV_ERR_INVALID, "GLV_OP_RAW needs GLV_OP_FFT");
     if ((ops & GLV_OP_MAGNITUDE) && (ops & (GLV_OP_FFT | GLV_OP_WRANGE))) return fail(GLV_ERR_INVALID, "GLV_OP_MAGNITUDE excludes GLV_OP_FFT and GLV_OP_WRANGE");
     if (!(ops & (GLV_OP_FFT | GLV_OP_GRAVITY | GLV_OP_AVERAGE | GLV_OP_WRANGE | GLV_OP_SMOOTH | GLV_OP_MAGNITUDE | GLV_OP_R16))) return fail(GLV_ERR_INVALID, "empty ops");
-    if ((ops & GLV_OP_R16) && (ops & (GLV_OP_RAW | GLV_OP_BARS | GLV_OP_SMOOTH))) return fail(GLV_ERR_INVALID, "GLV_OP_R16 excludes GLV_OP_RAW, GLV_OP_BARS and GLV_OP_SMOOTH");
+    if ((ops & GLV_OP_R16) && (ops & (GLV_OP_RAW | GLV_OP_SMOOTH))) return fail(GLV_ERR_INVALID, "GLV_OP_R16 excludes GLV_OP_RAW and GLV_OP_SMOOTH");
     if ((ops & GLV_OP_R16) && !d_out) return fail(GLV_ERR_INVALID, "GLV_OP_R16 needs an output buffer");
     if ((ops & GLV_OP_BARS) && (b->p.bars == 0 || b->p.bars > b->p.n)) return fail(GLV_ERR_INVALID, "bars=%u out of range", b->p.bars);
     if ((ops & GLV_OP_BARS) && !(b->p.smooth_factor >= 0.0f && b->p.smooth_factor <= 1.0f))       // also rejects NaN
@@ -469,7 +469,8 @@ int process(glv_batch* b, const void* d_in, int in_mode, float* d_out, unsigned 
     // which kernel configuration of this size runs, on how many workgroups (wisdom, overrides, defaults)
     int variant = 0, grid = 0;
     if (ops & GLV_OP_FFT) launch_plan(b, units, in_mode, gl_split ? (unsigned) GLV_OP_FFT : ops, &variant, &grid);
-    bool fused_bars = (ops & GLV_OP_BARS) && (ops & GLV_OP_FFT) && (ops & (GLV_OP_GRAVITY | GLV_OP_AVERAGE)) && !(ops & GLV_OP_SMOOTH) && !gl_split;
+    // (bars as GL_R16 texels -- the smooth pass's render target -- leave through glv_bars_kernel)
+    bool fused_bars = (ops & GLV_OP_BARS) && (ops & GLV_OP_FFT) && (ops & (GLV_OP_GRAVITY | GLV_OP_AVERAGE)) && !(ops & (GLV_OP_SMOOTH | GLV_OP_R16)) && !gl_split;
     if (fused_bars) {
         if (int rc = ensure_bar_tables(b, glv::frame_geometry(b->log_nn, variant).lanes)) return rc;
         fused_bars = b->bar_fusable                // whole waves per row, at most one bar per lane of the row
@@ -488,6 +489,7 @@ int process(glv_batch* b, const void* d_in, int in_mode, float* d_out, unsigned 
     fill_common(a, b->p, b->tab);
     a.in = d_in; a.out = d_out; a.grav = b->grav_cur; a.grav_w = b->d_grav; a.hist = b->d_hist;
     a.units = units; a.ops = ops & ~(unsigned) GLV_OP_PRIVATE_STATE; a.head = b->head; a.rot = rot; a.log_mode = b->p.log_mode;
+    if (ops & GLV_OP_BARS) a.ops &= ~(unsigned) GLV_OP_R16;        // with bars the texel conversion applies to the bars, the spectra stay f32
     // A chain that ends in gravity writes ONE copy of its result (SURVEY 8d row B, 20 N bytes per frame): transform_gravity
     // stores the same value to its `applied` array and to the buffer (render.c:733-734), so the caller's output buffer IS
     // the new state and the next update reads it from there.  A private copy in the batch (28 N) is kept when the caller
@@ -537,7 +539,7 @@ int process(glv_batch* b, const void* d_in, int in_mode, float* d_out, unsigned 
             if (e != hipSuccess) return fail(GLV_ERR_HIP, "smooth launch failed: %s", hipGetErrorString(e));
         }
         if (ops & GLV_OP_BARS) {
-            e = glv::launch_bars(d_tmp, d_final, units, b->p.n, b->p.bars, b->bar_nsteps, b->d_bar_items, b->d_bar_desc, b->d_bar_w, st);
+            e = glv::launch_bars(d_tmp, d_final, units, b->p.n, b->p.bars, b->bar_nsteps, b->d_bar_items, b->d_bar_desc, b->d_bar_w, st, (ops & GLV_OP_R16) != 0);
             if (e != hipSuccess) return fail(GLV_ERR_HIP, "bars launch failed: %s", hipGetErrorString(e));
         }
         return timed_launch_end(b, st);            // the HIP-event window covers every launch of the chain
@@ -568,7 +570,7 @@ int process(glv_batch* b, const void* d_in, int in_mode, float* d_out, unsigned 
         if (e != hipSuccess) return fail(GLV_ERR_HIP, "smooth launch failed: %s", hipGetErrorString(e));
     }
     if ((ops & GLV_OP_BARS) && !fused_bars) {
-        e = glv::launch_bars(d_out ? d_out : b->grav_cur, d_final, units, b->p.n, b->p.bars, b->bar_nsteps, b->d_bar_items, b->d_bar_desc, b->d_bar_w, st);
+        e = glv::launch_bars(d_out ? d_out : b->grav_cur, d_final, units, b->p.n, b->p.bars, b->bar_nsteps, b->d_bar_items, b->d_bar_desc, b->d_bar_w, st, (ops & GLV_OP_R16) != 0);
         if (e != hipSuccess) return fail(GLV_ERR_HIP, "bars launch failed: %s", hipGetErrorString(e));
     }
     return timed_launch_end(b, st);

@@ -36,7 +36,7 @@ hipError_t launch_lerp(const float* s0, const float* e0, float* out, size_t tota
 hipError_t launch_smooth(float* rows, size_t nrows, uint32_t n, const int* smin, const int* smax, uint32_t asz, uint32_t reach,
                          uint32_t max_window, hipStream_t st);
 hipError_t launch_bars(const float* spec, float* bars_out, size_t nrows, uint32_t n, uint32_t bars, uint32_t nsteps,
-                       const BarItem* items, const BarDesc* desc, const float* tap_w, hipStream_t st);
+                       const BarItem* items, const BarDesc* desc, const float* tap_w, hipStream_t st, bool r16 = false);
 hipError_t launch_ring_planar(const void* ring, int is_f32, uint32_t n, uint32_t rot, int mono, size_t streams, float* out, hipStream_t st);
 hipError_t launch_unpack(const int16_t* pcm, size_t frames, int mono, float* l, float* r, hipStream_t st);
 

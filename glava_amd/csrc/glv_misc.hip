@@ -268,10 +268,12 @@ __global__ void __launch_bounds__(64) glv_smooth_ring_kernel(float* __restrict__
 // they are generated once per batch on the host (glv_tables.h make_bar_taps: SAMPLE_MODE average,
 // ROUND_FORMULA sinusoidal, SAMPLE_SCALE 8, SAMPLE_RANGE 0.9) together with the work lists
 // (make_bar_items).  One 256-thread workgroup = 16 groups of 16 lanes per row; arithmetic: glv_frame.h.
+// r16: bars_out is uint16 [nrows][bars], the GL_R16 texel of every value (what the reference's smooth pass renders into,
+// render.c:2277-2303 with bind_1d_fbo's GL_R16 texture) instead of float
 __global__ void __launch_bounds__(256) glv_bars_kernel(const float* __restrict__ spec, float* __restrict__ bars_out,
                                                        size_t nrows, uint32_t n, uint32_t bars, uint32_t nsteps,
                                                        const BarItem* __restrict__ items, const BarDesc* __restrict__ desc,
-                                                       const float* __restrict__ tap_w) {
+                                                       const float* __restrict__ tap_w, int r16) {
     constexpr uint32_t G = 16;
     const int sub = threadIdx.x & 15;
     const uint32_t g = threadIdx.x >> 4;
@@ -290,7 +292,11 @@ __global__ void __launch_bounds__(256) glv_bars_kernel(const float* __restrict__
                 total += group16_sum(bar_item_lane_sum(tp[b]));
                 if (bar_item_last(it[b])) {
                     const uint32_t k = bar_item_bar(it[b]);
-                    if (sub == 0) bars_out[row * bars + k] = total / desc[k].weight_sum;
+                    if (sub == 0) {
+                        const float v = total / desc[k].weight_sum;
+                        if (r16) reinterpret_cast<uint16_t*>(bars_out)[row * bars + k] = (uint16_t) unorm16(v);
+                        else bars_out[row * bars + k] = v;
+                    }
                     total = 0.0f;
                 }
             }
@@ -367,9 +373,9 @@ hipError_t launch_smooth(float* rows, size_t nrows, uint32_t n, const int* smin,
     return hipGetLastError();
 }
 hipError_t launch_bars(const float* spec, float* bars_out, size_t nrows, uint32_t n, uint32_t bars, uint32_t nsteps,
-                       const BarItem* items, const BarDesc* desc, const float* tap_w, hipStream_t st) {
+                       const BarItem* items, const BarDesc* desc, const float* tap_w, hipStream_t st, bool r16) {
     const size_t g = nrows < 256 * 8 ? nrows : 256 * 8;     // one row per workgroup trip, grid-stride beyond
-    hipLaunchKernelGGL(glv_bars_kernel, dim3((unsigned) (g ? g : 1)), dim3(256), 0, st, spec, bars_out, nrows, n, bars, nsteps, items, desc, tap_w);
+    hipLaunchKernelGGL(glv_bars_kernel, dim3((unsigned) (g ? g : 1)), dim3(256), 0, st, spec, bars_out, nrows, n, bars, nsteps, items, desc, tap_w, r16 ? 1 : 0);
     return hipGetLastError();
 }
 

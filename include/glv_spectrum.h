@@ -61,7 +61,10 @@ enum {
                                    glTexImage1D(GL_TEXTURE_1D, 0, GL_R16, sz, 0, GL_RED, GL_FLOAT, buf), render.c:521-524).
                                    Applied last, to the output only: gravity / average state stays f32.  Halves the
                                    write side of the pass (8n instead of 12n bytes per s16 frame).  Alone (no other
-                                   op) it quantises planar f32 rows.  Excludes GLV_OP_RAW, GLV_OP_BARS, GLV_OP_SMOOTH. */
+                                   op) it quantises planar f32 rows.  With GLV_OP_BARS the bars are what is quantised (d_out:
+                                   uint16 [streams][2][bars]; the spectra feeding them stay f32): with gl_storage = 1, bars = n and
+                                   bar_phase = 0.5 that is the texture every stock module samples -- upload, gravity, average and
+                                   pre-smoothing pass of render.c:2188-2303 in one call.  Excludes GLV_OP_RAW, GLV_OP_SMOOTH. */
     GLV_OP_PRIVATE_STATE = 1u << 9, /* with a chain that ENDS in gravity (GLV_OP_GRAVITY without AVERAGE / SMOOTH / RAW): keep
                                    gravity's `applied` array in a buffer owned by the batch, as transform_gravity does
                                    (render.c:724; :733-734 store every value twice).  Without this flag the output buffer IS the

@@ -107,11 +107,20 @@ def test_device_gl_storage_chain_against_the_reference_gl_execution(glvlib, name
     p = G.Params(n=n, avg_frames=F, avg_window=win, avg_window_kind=1, gl_storage=1, log_mode=0, ur=UR, bars=n, bar_phase=0.5)
     b = G.Batch(p, 1, mask)
     bb = G.Batch(p, 1, G.OP_FFT)
+    full = G.Batch(p, 1, mask)              # the whole default pipeline in one call: ... | GLV_OP_BARS | GLV_OP_R16
+    d_sm = torch.zeros((2, n), dtype=torch.int16, device="cuda")
     d_q = torch.zeros((2, n), dtype=torch.int16, device="cuda")
     d_bars = torch.empty((2, n), dtype=torch.float32, device="cuda")
     for f in range(pcm.shape[0]):
-        b.process_s16(torch.from_numpy(np.ascontiguousarray(pcm[f])).cuda(), d_q, ops | G.OP_R16)
+        d_pcm = torch.from_numpy(np.ascontiguousarray(pcm[f])).cuda()
+        b.process_s16(d_pcm, d_q, ops | G.OP_R16)
         got = d_q.cpu().numpy().view(np.uint16)
+        # PCM in, the texture the stock modules sample out (upload -> gravity -> average -> pre-smoothing pass, every one GL_R16)
+        full.process_s16(d_pcm, d_sm, ops | G.OP_BARS | G.OP_R16)
+        got_sm = d_sm.cpu().numpy().view(np.uint16)
+        for ch in range(2):
+            mx, frac, out = diff_stats(got_sm[ch], tex[f, ch, SM])
+            assert out <= 2 and frac < (0.6 if not win or F == 2 else 5e-2), ("end to end", f, ch, mx, frac, out)
         for ch in range(2):
             mx, frac, out = diff_stats(got[ch], tex[f, ch, AV])
             # one-step differences of the upload (0.1 % of texels) travel through max / average: a little more slack than the
@@ -123,4 +132,4 @@ def test_device_gl_storage_chain_against_the_reference_gl_execution(glvlib, name
         for ch in range(2):
             mx, frac, out = diff_stats(sm[ch], tex[f, ch, SM])
             assert out <= 2 and frac < 2e-2, ("smooth pass", f, ch, mx, frac, out)
-    b.close(); bb.close()
+    b.close(); bb.close(); full.close()

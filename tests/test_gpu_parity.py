@@ -1175,7 +1175,7 @@ def test_r16_post_kernel_and_errors(G):
     b.process_f32(d_x, d_q, G.OP_GRAVITY | G.OP_R16)
     torch.cuda.synchronize()
     assert (d_q.cpu().numpy().view(np.uint16) == Oracle.texels_r16(want)).all()
-    for bad in (G.OP_FFT | G.OP_RAW | G.OP_R16, G.OP_FFT | G.OP_GRAVITY | G.OP_BARS | G.OP_R16, G.OP_FFT | G.OP_SMOOTH | G.OP_R16):
+    for bad in (G.OP_FFT | G.OP_RAW | G.OP_R16, G.OP_FFT | G.OP_SMOOTH | G.OP_R16):
         with pytest.raises(G.GlvError):
             b.process_f32(d_x, d_q, bad)
     with pytest.raises(G.GlvError):

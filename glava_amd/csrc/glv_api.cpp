@@ -325,6 +325,9 @@ void launch_plan(glv_batch* b, uint32_t units, int in_mode, unsigned ops, int* v
         const uint64_t gen = g_wisdom_gen.load(std::memory_order_acquire);
         if (pc.gen != gen) {
             pc.hit = wisdom_lookup(wisdom_key(b, in_mode, ops), &pc.variant, &pc.grid);
+            // the ring mode runs the frame mode's kernel with a rotated read position: what was tuned for frames (the input
+            // glv_batch_autotune measures) serves it until an entry of its own exists
+            if (!pc.hit && in_mode == glv::IN_S16_RING) pc.hit = wisdom_lookup(wisdom_key(b, glv::IN_S16_STEREO, ops), &pc.variant, &pc.grid);
             pc.gen = gen;
         }
         if (pc.hit) { v = pc.variant; g = pc.grid; }

@@ -67,6 +67,14 @@ BATCHES = {
               ("r3e_n11_s6", 65536, 256, "N=4096 six rows, GL_R16 output", "256,512"),
               ("r3e_n11_s6t1", 65536, 256, "N=4096 six rows tilt resident, GL_R16 output", "256,512"),
               ("r3e_n11_prod", 65536, 0, "N=4096 production (again)", "0")]),
+    "notw": dict(
+        libs=[("r3f_n13_prod", 13, NOL0, "VW(1,1,2,false,2,1,3,5,0,0)"), ("r3f_n13_notw", 13, NOL0 + ["-DGLV_EXP_NOTWLOAD"], "VW(1,1,2,false,2,1,3,5,0,0)"),
+              ("r3f_n13_neither", 13, NOL0 + ["-DGLV_EXP_NOTWLOAD", "-DGLV_EXP_NOWINLOAD"], "VW(1,1,2,false,2,1,3,5,0,0)")],
+        runs=[("r3f_n13_prod", 16384, 0, "N=16384 production (folded tilt)", "512"),
+              ("r3f_n13_notw", 16384, 0, "N=16384 without the last pass's L2 twiddle gather (wrong results): the prize of resident twiddles", "512"),
+              ("r3f_n13_neither", 16384, 0, "N=16384 without twiddle gather and window loads (wrong results)", "512"),
+              ("r3f_n13_prod", 16384, 0, "N=16384 production (again)", "512"),
+              ("r3f_n13_notw", 16384, 0, "N=16384 no twiddle gather (again)", "512")]),
 }
 
 

@@ -73,19 +73,26 @@ def build_tune_variant(name: str, extra_flags: list[str], variants: str | None =
     return lib
 
 
-def build_variant(name: str, extra_flags: list[str], sizes=SIZES) -> str:
+def build_variant(name: str, extra_flags: list[str], sizes=SIZES, kernels_only: bool = False) -> str:
     """A/B copy of the product library, glava_amd/csrc/libglvspectrum_<name>.so, compiled with extra flags
-    (experiment macros); loaded instead of the product with GLV_SPECTRUM_LIB=<path> (tools/ab_bench.sh)."""
+    (experiment macros); loaded instead of the product with GLV_SPECTRUM_LIB=<path> (tools/ab_bench.sh).
+    kernels_only: the flags touch nothing but the frame kernels of `sizes` -- only those objects are compiled, everything
+    else is the product's (which must be built and current): minutes instead of the whole library per experiment."""
     obj_dir = os.path.join(OBJ, name)
     os.makedirs(obj_dir, exist_ok=True)
     jobs = [("glv_inst.hip", os.path.join(obj_dir, f"glv_inst_{k}.o"), [f"-DGLV_LOG_NN={k}", *extra_flags]) for k in sizes]
-    jobs.append(("glv_misc.hip", os.path.join(obj_dir, "glv_misc.o"), list(extra_flags)))
-    jobs.append(("glv_api.cpp", os.path.join(obj_dir, "glv_api.o"), ["-x", "hip", *extra_flags]))
-    jobs.append(("glv_multi.cpp", os.path.join(obj_dir, "glv_multi.o"), ["-x", "hip", *extra_flags]))
+    reused = []
+    if kernels_only:
+        reused = [os.path.join(OBJ, f"glv_inst_{k}.o") for k in SIZES if k not in sizes]
+        reused += [os.path.join(OBJ, o) for o in ("glv_misc.o", "glv_api.o", "glv_multi.o")]
+    else:
+        jobs.append(("glv_misc.hip", os.path.join(obj_dir, "glv_misc.o"), list(extra_flags)))
+        jobs.append(("glv_api.cpp", os.path.join(obj_dir, "glv_api.o"), ["-x", "hip", *extra_flags]))
+        jobs.append(("glv_multi.cpp", os.path.join(obj_dir, "glv_multi.o"), ["-x", "hip", *extra_flags]))
     with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 2)) as ex:
         objs = list(ex.map(lambda j: _compile(*j), jobs))
     lib = os.path.join(CSRC, f"libglvspectrum_{name}.so")
-    _run([_hipcc(), "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", lib, *objs])
+    _run([_hipcc(), "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", lib, *objs, *reused])
     return lib
 
 

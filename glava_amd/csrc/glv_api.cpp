@@ -234,8 +234,8 @@ struct glv_batch {
     float smooth_d = -1.f, smooth_r = -1.f;
     glv::BarDesc* d_bar_desc = nullptr;   // GLV_OP_BARS tap tables (host generated)
     float* d_bar_w = nullptr;
-    glv::BarItem* d_bar_items = nullptr;    // work lists for glv_bars_kernel (16 groups per row)
-    glv::BarItem* d_bar_fitems = nullptr;   // work lists for the fused epilogue (lanes/16 groups per row)
+    glv::BarItem* d_bar_items = nullptr;    // work lists for glv_bars_kernel (32 groups per row)
+    glv::BarItem* d_bar_fitems = nullptr;   // work lists for the fused epilogue (lanes/8 groups per row)
     uint32_t bar_nsteps = 0, bar_fnsteps = 0; bool bar_fusable = false;
     uint32_t bar_count = 0; float bar_factor = -1.f, bar_phase = 0.f; int bar_lanes = 0;
     // timing
@@ -393,18 +393,19 @@ int ensure_bar_tables(glv_batch* b, int lanes = 0) {
     std::vector<glv::BarDesc> desc;
     std::vector<float> w;
     glv::make_bar_taps(desc, w, b->p.n, b->p.bars, b->p.smooth_factor, b->p.bar_phase);
+    if (!glv::bar_chunks_in_row(desc, b->p.n)) return fail(GLV_ERR_INVALID, "bars: a tap chunk would leave the row (n=%u smooth_factor=%g)", b->p.n, (double) b->p.smooth_factor);
     if (b->d_bar_desc) { (void) hipFree(b->d_bar_desc); b->d_bar_desc = nullptr; }
     if (b->d_bar_w) { (void) hipFree(b->d_bar_w); b->d_bar_w = nullptr; }
     HIP_TRY(hipMalloc(&b->d_bar_desc, sizeof(glv::BarDesc) * desc.size()));
-    // work lists: 16 groups per row for glv_bars_kernel; T/16 groups for the frame kernel of this size
+    // work lists: 32 groups per row for glv_bars_kernel; T/8 groups for the frame kernel of this size
     // (fused bars: whole waves per row, one bar per lane of the row at most).  kBarChunk zero weights
     // appended for padding items.
     const uint32_t zero_off = (uint32_t) w.size();
     w.resize(w.size() + glv::kBarChunk, 0.0f);
     std::vector<glv::BarItem> items, fitems;
-    b->bar_nsteps = glv::make_bar_items(items, desc, 16, zero_off);
+    b->bar_nsteps = glv::make_bar_items(items, desc, 256 / glv::kBarLanes, zero_off);
     b->bar_fusable = lanes % 64 == 0 && b->p.bars <= (uint32_t) lanes;
-    if (b->bar_fusable) b->bar_fnsteps = glv::make_bar_items(fitems, desc, (uint32_t) lanes / 16, zero_off);
+    if (b->bar_fusable) b->bar_fnsteps = glv::make_bar_items(fitems, desc, (uint32_t) lanes / glv::kBarLanes, zero_off);
     if (b->d_bar_items) { (void) hipFree(b->d_bar_items); b->d_bar_items = nullptr; }
     if (b->d_bar_fitems) { (void) hipFree(b->d_bar_fitems); b->d_bar_fitems = nullptr; }
     HIP_TRY(hipMalloc(&b->d_bar_items, sizeof(glv::BarItem) * items.size()));

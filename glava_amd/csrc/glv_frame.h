@@ -31,10 +31,12 @@ enum : uint32_t { OP_FFT = 1u, OP_GRAVITY = 2u, OP_AVERAGE = 4u, OP_RAW = 8u, OP
 // tap_w[tap_offset ...]; weight_sum = float sum of the weights in tap order (smooth.glsl:31-36)
 struct BarDesc { uint32_t first_bin, count, tap_offset; float weight_sum; };
 // One work item of GLV_OP_BARS: a chunk of kBarChunk = 64 consecutive taps of one bar, taken by one group of
-// 16 lanes.  pack = index of the chunk's first tap in the row | bar index << 15 | (bar ends here) << 30;
-// w_off = offset of the chunk's 64 weights (zero-padded by make_bar_taps; an all-zero block for padding
-// items, which therefore add exactly 0).
-struct BarItem { uint32_t w_off, pack; };
+// kBarLanes = 8 lanes.  Everything a step needs, ready to use (the loop is instruction-bound): w_byte = byte offset
+// of the chunk's 64 weights in tap_w (zero-padded by make_bar_taps; an all-zero block for padding items, which
+// therefore add exactly 0), tex_byte = byte offset of the chunk's first tap in the row, res = the bar this chunk
+// completes, or `bars` (a dump slot) when it does not, keep = 0.0f when the chunk opens a bar (the running total
+// restarts), 1.0f otherwise.
+struct alignas(16) BarItem { uint32_t w_byte, tex_byte, res; float keep; };
 
 struct FrameArgs {
     const void* in;        // s16: int16 [units/2][n][2] (a unit is one channel row of a frame);  f32 planar: float [units][n];
@@ -63,7 +65,7 @@ struct FrameArgs {
     // fused GLV_OP_BARS (stateful kernels, lanes-per-row a multiple of 64): the finished row goes to the
     // slot's LDS region instead of HBM and only the bars leave the chip
     const BarDesc* bar_desc;
-    const BarItem* bar_items;   // [bar_nsteps + kBarBatch][groups] work lists (glv_tables.h make_bar_items), groups = T/16
+    const BarItem* bar_items;   // [bar_nsteps + kBarBatch][groups] work lists (glv_tables.h make_bar_items), groups = T/8
     const float* bar_w;
     float* bars_out;            // [units][bars], nullptr = not fused
     uint32_t bars;
@@ -72,68 +74,100 @@ struct FrameArgs {
 
 // ---- GLV_OP_BARS arithmetic (smooth.glsl:25-40; tex clamped to [0,1] like the GL_R16 texture the
 // shader samples, render.c:523) ---------------------------------------------------------------------
-// A bar's taps are cut into chunks of 64; a chunk is summed by a group of 16 lanes: lane l takes the four CONSECUTIVE taps
-// 4l .. 4l+3 (one 16-byte load of their weights), adds its four products in that order, the group adds the 16 lane sums
-// with a fixed DPP pattern (quads, halves of 8, the two halves), and the chunk totals of a bar are added in chunk
-// order.  This order IS the contract of GLV_OP_BARS (smooth.glsl's loop adds tap by tap; what a GL driver's compiler makes
-// of that loop is not defined): the oracle's glvo_bars_chunked follows it and the GPU tests demand its bits; against the
-// tap-by-tap order of the shader text it differs by summation rounding only (<= 2e-4 relative, tests/test_glsl_twins.py).
-// Which group of which wave takes a chunk does not enter the arithmetic, so the fused epilogue
-// (row in LDS, T/16 groups per row) and glv_bars_kernel (row in HBM, 16 groups per row) give the same
-// bits.  Small bars dominate (N=4096: 80 bars, 4591 taps, no bar above 191): one WAVE per bar, as in the
-// first version, spent ~100 instructions per bar on mostly idle lanes -- more than the transform itself.
+// A bar's taps are cut into chunks of 64; a chunk is summed by a group of 8 lanes: lane l takes the eight CONSECUTIVE taps
+// 8l .. 8l+7 (two 16-byte loads of their weights) and runs two fused-multiply-add chains over them, one over its even taps
+// and one over its odd taps, each from +0 in tap order (e = fma(x0, w0, 0), fma(x2, w2, e), ...: a v_pk_fma_f32 does one
+// link of both chains); the lane's sum is e + o; the group adds its 8 lane sums with a fixed DPP pattern (neighbours,
+// pairs of pairs, the two quads); the bar's running total takes the chunk totals in chunk order.  This order IS the
+// contract of GLV_OP_BARS (smooth.glsl's loop adds tap by tap; what a GL driver's compiler makes of that loop -- fma or
+// not, unrolled or not -- is not defined): the oracle's glvo_bars_chunked follows it and the GPU tests demand its bits;
+// against the tap-by-tap order of the shader text it differs by summation rounding only (<= 2e-4 relative,
+// tests/test_glsl_twins.py).  Which group of which wave takes a chunk does not enter the arithmetic, so the fused epilogue
+// (row in LDS, T/8 groups per row) and glv_bars_kernel (row in HBM, 32 groups per row) give the same bits.
+// Why this shape: the loop is VALU-issue bound (the chip runs at its power limit, time follows the instruction count).
+// Round 2's version (16 lanes x 4 taps, mul + add, flags unpacked from a bit field) spent 41 instructions per 4 taps;
+// this one spends ~32 per 8: per-step bookkeeping is amortised over twice the taps, one DPP level is gone, multiplies
+// and adds are fused and packed, and the end-of-bar logic is a multiply by `keep` and an unconditional store.
+// (One WAVE per bar, the very first version, spent ~100 instructions per bar on mostly idle lanes.)
 constexpr uint32_t kBarChunk = 64;
-constexpr int kBarBatch = 4;           // work-list steps whose loads are issued together
-struct BarTaps { float t[4], w[4]; };
-GLV_HD uint32_t bar_item_tex(const BarItem& it) { return it.pack & 0x7fffu; }
-GLV_HD uint32_t bar_item_bar(const BarItem& it) { return (it.pack >> 15) & 0x7fffu; }
-GLV_HD bool bar_item_last(const BarItem& it) { return ((it.pack >> 30) & 1u) != 0; }
-// sub = lane index within the group (0..15); n = floats per row.  A chunk may reach up to 63 floats past the row:
-// those taps have zero weights.  CLAMP: such reads are redirected to the row's last float (row in HBM: the next row, or
-// nothing, follows).  !CLAMP (row in LDS): they read the slack behind the row -- whatever is there is clamped to
-// [0, 1] (NaN -> 0) by bar_item_lane_sum before it meets its zero weight, so it adds exactly 0 either way, and the
-// address is one lane offset + compile-time constants.
+constexpr int kBarLanes = 8;           // lanes per group
+constexpr int kBarTaps = 8;            // consecutive taps per lane: kBarLanes * kBarTaps == kBarChunk
+#if !defined(GLV_BAR_BATCH)
+#define GLV_BAR_BATCH 2
+#endif
+constexpr int kBarBatch = GLV_BAR_BATCH;   // work-list steps whose loads are issued together
+struct BarTaps { float t[kBarTaps], w[kBarTaps]; };
+// sub = lane index within the group (0..7).  A chunk reaches up to 63 floats past its bar's last tap (zero weights there:
+// whatever is read is clamped to [0, 1], NaN -> 0, by bar_item_lane_sum before it meets its zero weight, so it adds
+// exactly 0) -- never past the row: smooth_audio()'s taps end at 0.288 n (scale_audio(1) = -log(0.1) / 8), so
+// first_bin + 64 * chunks <= n for every n >= 128 (checked when the tables are made, glv_tables.h bar_chunks_in_row).
+// VEC (row in HBM): the lane's eight taps are two 16-byte loads at a 4-byte-aligned address (chunks start at arbitrary
+// bins; gfx950 global loads need dword alignment only) -- eight dword loads per lane were eight times the L1 requests
+// for the same lines.  !VEC (row in LDS): dword reads, paired by the compiler (ds_read2_b32).
 struct alignas(16) BarW4 { float w[4]; };
-template <bool CLAMP = true>
-GLV_HD BarTaps bar_item_load(const float* tex_row, uint32_t n, const float* tap_w, const BarItem& it, int sub) {
+struct __attribute__((packed, aligned(4))) BarT4 { float t[4]; };
+template <bool VEC = true>
+GLV_HD BarTaps bar_item_load(const float* tex_row, const float* tap_w, const BarItem& it, int sub) {
     BarTaps s;
-    const uint32_t base = bar_item_tex(it) + 4u * (uint32_t) sub;
+    const uint32_t lane_byte = 4u * (uint32_t) kBarTaps * (uint32_t) sub;
 #if defined(GLV_EXP_BARS_NOWLOAD)     /* A/B experiment only (glava_amd.build build_variant): no weight loads, wrong bars */
-    for (int i = 0; i < 4; ++i) s.w[i] = 1.0f;
+    for (int i = 0; i < kBarTaps; ++i) s.w[i] = 1.0f;
     (void) tap_w;
 #else
-    const BarW4 w4 = ld<BarW4>(tap_w, (it.w_off + 4u * (uint32_t) sub) * 4u);     // chunks start on 64-float boundaries
 #pragma unroll
-    for (int i = 0; i < 4; ++i) s.w[i] = w4.w[i];
+    for (int h = 0; h < kBarTaps / 4; ++h) {
+        const BarW4 w4 = ld<BarW4>(tap_w, it.w_byte + lane_byte + 16u * (uint32_t) h);   // chunks start on 64-float boundaries
+#pragma unroll
+        for (int i = 0; i < 4; ++i) s.w[4 * h + i] = w4.w[i];
+    }
 #endif
+    const uint32_t base = it.tex_byte + lane_byte;
+    if constexpr (VEC) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const uint32_t q = base + (uint32_t) i;
-        if constexpr (CLAMP) s.t[i] = tex_row[q < n ? q : n - 1];
-        else s.t[i] = tex_row[q];
+        for (int h = 0; h < kBarTaps / 4; ++h) {
+            const BarT4 t4 = *reinterpret_cast<const BarT4*>(reinterpret_cast<const char*>(tex_row) + base + 16u * (uint32_t) h);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) s.t[4 * h + i] = t4.t[i];
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < kBarTaps; ++i) s.t[i] = ld<float>(tex_row, base + 4u * (uint32_t) i);
     }
     return s;
 }
 GLV_HD float bar_item_lane_sum(const BarTaps& s) {
-    float acc = 0.0f;
+#if defined(__HIP_DEVICE_COMPILE__)
+    // packed: clamp two taps (x * 1 with the clamp modifier: [0, 1], NaN -> 0), then one link of both chains
+    const glv_f2 ones = {1.0f, 1.0f};
+    glv_f2 acc = {0.0f, 0.0f};
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const float t = __builtin_fminf(__builtin_fmaxf(s.t[i], 0.0f), 1.0f);     // NaN -> 0 (v_max/v_min)
-        acc += t * s.w[i];
+    for (int i = 0; i < kBarTaps; i += 2) {
+        glv_f2 t = {s.t[i], s.t[i + 1]};
+        const glv_f2 w = {s.w[i], s.w[i + 1]};
+        asm("v_pk_mul_f32 %0, %1, %2 clamp" : "=v"(t) : "v"(t), "v"(ones));
+        asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(acc) : "v"(t), "v"(w), "v"(acc));
     }
-    return acc;
+    return acc.x + acc.y;
+#else
+    float e = 0.0f, o = 0.0f;
+    auto clamp01 = [](float x) { return x > 0.0f ? (x < 1.0f ? x : 1.0f) : 0.0f; };   // NaN -> 0
+    for (int i = 0; i < kBarTaps; i += 2) {
+        e = __builtin_fmaf(clamp01(s.t[i]), s.w[i], e);
+        o = __builtin_fmaf(clamp01(s.t[i + 1]), s.w[i + 1], o);
+    }
+    return e + o;
+#endif
 }
 #if defined(__HIPCC__)
-// sum over each group of 16 lanes (a DPP row), result in every lane of the group: VALU-speed cross-lane
+// sum over each group of 8 lanes (half a DPP row), result in every lane of the group: VALU-speed cross-lane
 // adds (a ds_bpermute shuffle is an LDS round trip each)
 template <int CTRL> __device__ __forceinline__ float dpp_move(float v) {
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, false));
 }
-__device__ __forceinline__ float group16_sum(float v) {
+__device__ __forceinline__ float group8_sum(float v) {
     v = v + dpp_move<0xB1>(v);       // quad_perm [1,0,3,2]
     v = v + dpp_move<0x4E>(v);       // quad_perm [2,3,0,1]
     v = v + dpp_move<0x141>(v);      // row_half_mirror: the other quad of each 8
-    v = v + dpp_move<0x140>(v);      // row_mirror: the other half of the 16
     return v;
 }
 #endif

@@ -351,19 +351,20 @@ glv_frame_kernel(const FrameArgs a) {
             sy.sync();                                     // every reader of the row's last exchange is done
             if (active) finish(v, row, tid);               // finished row -> LDS, natural order
             sy.sync();
-            // T/16 groups of 16 lanes work through the row's bar chunks (glv_frame.h "GLV_OP_BARS
+            // T/8 groups of 8 lanes work through the row's bar chunks (glv_frame.h "GLV_OP_BARS
             // arithmetic"; work lists from make_bar_items).  kBarBatch steps at a time: their loads (LDS
             // row + L2-resident weights) are issued together and the next batch's items are fetched
             // while the current one is reduced.  No global store inside the loop (vmcnt is one in-order
-            // counter): bar totals collect in the slack behind the row; after a barrier the slot's lanes
+            // counter): every step stores its running total to the slack behind the row -- slot `res` is the
+            // bar a chunk completes, or the dump slot lres[bars] -- and after a barrier the slot's lanes
             // divide by the weight sums and store the bars coalesced.
-            constexpr uint32_t G = T / 16;
+            constexpr uint32_t G = T / kBarLanes;
             float* lrow = reinterpret_cast<float*>(xslot);
-            float* lres = lrow + N;                                       // XREGION has NN/E points (2T floats) of slack
-            static_assert(2 * T >= 64, "the chunk reads of bar_item_load<false> stay inside the slot's region");
+            float* lres = lrow + N;                                       // XREGION has NN/E points (2T floats) of slack: bars + 1 <= T + 1
+            static_assert(2 * T >= 64, "the chunk reads of bar_item_load stay inside the slot's region");
             if (active) {
-                const int sub = tid & 15;
-                const uint32_t g = (uint32_t) tid >> 4;
+                const int sub = tid & (kBarLanes - 1);
+                const uint32_t g = (uint32_t) tid / kBarLanes;
                 const BarItem* items = a.bar_items + g;
                 BarItem it[kBarBatch];
 #pragma unroll
@@ -377,15 +378,13 @@ glv_frame_kernel(const FrameArgs a) {
                     BarTaps tp[kBarBatch];
                     BarItem nx[kBarBatch];
 #pragma unroll
-                    for (int b = 0; b < kBarBatch; ++b) tp[b] = bar_item_load<false>(lrow, (uint32_t) N, a.bar_w, it[b], sub);   // slack: 2T >= 63 floats
+                    for (int b = 0; b < kBarBatch; ++b) tp[b] = bar_item_load<false>(lrow, a.bar_w, it[b], sub);   // slack: 2T >= 63 floats
 #pragma unroll
                     for (int b = 0; b < kBarBatch; ++b) nx[b] = items[(size_t) (s0 + kBarBatch + b) * G];   // table has one batch of padding
 #pragma unroll
                     for (int b = 0; b < kBarBatch; ++b) {
-                        total += group16_sum(bar_item_lane_sum(tp[b]));
-                        const bool last = bar_item_last(it[b]);
-                        if (last && sub == 0) lres[bar_item_bar(it[b])] = total;
-                        total = last ? 0.0f : total;
+                        total = __builtin_fmaf(total, it[b].keep, group8_sum(bar_item_lane_sum(tp[b])));
+                        if (sub == 0) lres[it[b].res] = total;
                     }
 #pragma unroll
                     for (int b = 0; b < kBarBatch; ++b) it[b] = nx[b];

@@ -267,16 +267,16 @@ __global__ void __launch_bounds__(64) glv_smooth_ring_kernel(float* __restrict__
 // The tap positions and weights of a bar depend only on (bar, n, smooth_factor) -- not on the data -- so
 // they are generated once per batch on the host (glv_tables.h make_bar_taps: SAMPLE_MODE average,
 // ROUND_FORMULA sinusoidal, SAMPLE_SCALE 8, SAMPLE_RANGE 0.9) together with the work lists
-// (make_bar_items).  One 256-thread workgroup = 16 groups of 16 lanes per row; arithmetic: glv_frame.h.
+// (make_bar_items).  One 256-thread workgroup = 32 groups of 8 lanes per row; arithmetic: glv_frame.h.
 // r16: bars_out is uint16 [nrows][bars], the GL_R16 texel of every value (what the reference's smooth pass renders into,
 // render.c:2277-2303 with bind_1d_fbo's GL_R16 texture) instead of float
 __global__ void __launch_bounds__(256) glv_bars_kernel(const float* __restrict__ spec, float* __restrict__ bars_out,
                                                        size_t nrows, uint32_t n, uint32_t bars, uint32_t nsteps,
                                                        const BarItem* __restrict__ items, const BarDesc* __restrict__ desc,
                                                        const float* __restrict__ tap_w, int r16) {
-    constexpr uint32_t G = 16;
-    const int sub = threadIdx.x & 15;
-    const uint32_t g = threadIdx.x >> 4;
+    constexpr uint32_t G = 256 / kBarLanes;
+    const int sub = threadIdx.x & (kBarLanes - 1);
+    const uint32_t g = threadIdx.x / kBarLanes;
     for (size_t row = blockIdx.x; row < nrows; row += gridDim.x) {
         const float* tex = spec + row * n;
         float total = 0.0f;
@@ -286,18 +286,76 @@ __global__ void __launch_bounds__(256) glv_bars_kernel(const float* __restrict__
 #pragma unroll
             for (int b = 0; b < kBarBatch; ++b) it[b] = items[(size_t) (s0 + b) * G + g];
 #pragma unroll
-            for (int b = 0; b < kBarBatch; ++b) tp[b] = bar_item_load(tex, n, tap_w, it[b], sub);
+            for (int b = 0; b < kBarBatch; ++b) tp[b] = bar_item_load(tex, tap_w, it[b], sub);
 #pragma unroll
             for (int b = 0; b < kBarBatch; ++b) {
-                total += group16_sum(bar_item_lane_sum(tp[b]));
-                if (bar_item_last(it[b])) {
-                    const uint32_t k = bar_item_bar(it[b]);
-                    if (sub == 0) {
-                        const float v = total / desc[k].weight_sum;
-                        if (r16) reinterpret_cast<uint16_t*>(bars_out)[row * bars + k] = (uint16_t) unorm16(v);
-                        else bars_out[row * bars + k] = v;
-                    }
-                    total = 0.0f;
+                total = __builtin_fmaf(total, it[b].keep, group8_sum(bar_item_lane_sum(tp[b])));
+                const uint32_t k = it[b].res;
+                if (k != bars && sub == 0) {
+                    const float v = total / desc[k].weight_sum;
+                    if (r16) reinterpret_cast<uint16_t*>(bars_out)[row * bars + k] = (uint16_t) unorm16(v);
+                    else bars_out[row * bars + k] = v;
+                }
+            }
+        }
+    }
+}
+
+// The same for short work lists (nsteps == NS: 80 bars of a row up to N=4096 are 2-4 steps of the 32 groups): the group's
+// items, the lane's weights and the weight sums do not depend on the row, so they are fetched ONCE per workgroup and stay in
+// registers; a row then costs one round trip (its taps: 2 NS 16-byte loads per lane) instead of a chain of three (item ->
+// weights / taps per batch), and RI rows are in flight per workgroup trip.  N=1024 x 262144 rows: 2.1 -> ms.
+template <int NS, int RI>
+__global__ void __launch_bounds__(256) glv_bars_short_kernel(const float* __restrict__ spec, float* __restrict__ bars_out,
+                                                             size_t nrows, uint32_t n, uint32_t bars,
+                                                             const BarItem* __restrict__ items, const BarDesc* __restrict__ desc,
+                                                             const float* __restrict__ tap_w, int r16) {
+    constexpr uint32_t G = 256 / kBarLanes;
+    const int sub = threadIdx.x & (kBarLanes - 1);
+    const uint32_t g = threadIdx.x / kBarLanes;
+    const uint32_t lane_byte = 4u * (uint32_t) kBarTaps * (uint32_t) sub;
+    BarItem it[NS];
+    BarTaps tw[NS];              // .w: the lane's weights of step s (.t unused)
+    float wsum[NS];
+#pragma unroll
+    for (int s = 0; s < NS; ++s) it[s] = items[(size_t) s * G + g];
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+#pragma unroll
+        for (int h = 0; h < kBarTaps / 4; ++h) {
+            const BarW4 w4 = ld<BarW4>(tap_w, it[s].w_byte + lane_byte + 16u * (uint32_t) h);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) tw[s].w[4 * h + i] = w4.w[i];
+        }
+        wsum[s] = it[s].res != bars ? desc[it[s].res].weight_sum : 1.0f;
+    }
+    for (size_t row0 = (size_t) blockIdx.x * RI; row0 < nrows; row0 += (size_t) gridDim.x * RI) {
+        BarT4 t[RI][NS][kBarTaps / 4];
+#pragma unroll
+        for (int i = 0; i < RI; ++i) {
+            const size_t row = row0 + i < nrows ? row0 + i : nrows - 1;
+            const char* tex = reinterpret_cast<const char*>(spec + row * n);
+#pragma unroll
+            for (int s = 0; s < NS; ++s)
+#pragma unroll
+                for (int h = 0; h < kBarTaps / 4; ++h)
+                    t[i][s][h] = *reinterpret_cast<const BarT4*>(tex + it[s].tex_byte + lane_byte + 16u * (uint32_t) h);
+        }
+#pragma unroll
+        for (int i = 0; i < RI; ++i) {
+            const size_t row = row0 + i;
+            float total = 0.0f;
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+                BarTaps tp = tw[s];
+#pragma unroll
+                for (int q = 0; q < kBarTaps; ++q) tp.t[q] = t[i][s][q / 4].t[q % 4];
+                total = __builtin_fmaf(total, it[s].keep, group8_sum(bar_item_lane_sum(tp)));
+                const uint32_t k = it[s].res;
+                if (k != bars && sub == 0 && row < nrows) {
+                    const float v = total / wsum[s];
+                    if (r16) reinterpret_cast<uint16_t*>(bars_out)[row * bars + k] = (uint16_t) unorm16(v);
+                    else bars_out[row * bars + k] = v;
                 }
             }
         }
@@ -374,8 +432,11 @@ hipError_t launch_smooth(float* rows, size_t nrows, uint32_t n, const int* smin,
 }
 hipError_t launch_bars(const float* spec, float* bars_out, size_t nrows, uint32_t n, uint32_t bars, uint32_t nsteps,
                        const BarItem* items, const BarDesc* desc, const float* tap_w, hipStream_t st, bool r16) {
-    const size_t g = nrows < 256 * 8 ? nrows : 256 * 8;     // one row per workgroup trip, grid-stride beyond
-    hipLaunchKernelGGL(glv_bars_kernel, dim3((unsigned) (g ? g : 1)), dim3(256), 0, st, spec, bars_out, nrows, n, bars, nsteps, items, desc, tap_w, r16 ? 1 : 0);
+    const int r = r16 ? 1 : 0;
+    auto grid = [&](size_t trips) { const size_t cap = 256 * 8; return dim3((unsigned) (trips < cap ? (trips ? trips : 1) : cap)); };   // grid-stride beyond
+    if (nsteps == 2) hipLaunchKernelGGL((glv_bars_short_kernel<2, 2>), grid((nrows + 1) / 2), dim3(256), 0, st, spec, bars_out, nrows, n, bars, items, desc, tap_w, r);
+    else if (nsteps == 4) hipLaunchKernelGGL((glv_bars_short_kernel<4, 2>), grid((nrows + 1) / 2), dim3(256), 0, st, spec, bars_out, nrows, n, bars, items, desc, tap_w, r);
+    else hipLaunchKernelGGL(glv_bars_kernel, grid(nrows), dim3(256), 0, st, spec, bars_out, nrows, n, bars, nsteps, items, desc, tap_w, r);
     return hipGetLastError();
 }
 

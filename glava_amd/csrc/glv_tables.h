@@ -130,26 +130,35 @@ inline void make_bar_taps(std::vector<BarDesc>& desc, std::vector<float>& tap_w,
     }
 }
 
-// GLV_OP_BARS work lists for `groups` 16-lane groups per row: every bar's chunks go, in order, to one
+// every chunk of every bar lies inside the row (the kernels read whole chunks: glv_frame.h bar_item_load)
+inline bool bar_chunks_in_row(const std::vector<BarDesc>& desc, uint32_t n) {
+    for (const BarDesc& d : desc)
+        if ((uint64_t) d.first_bin + (d.count + kBarChunk - 1) / kBarChunk * kBarChunk > n) return false;
+    return true;
+}
+
+// GLV_OP_BARS work lists for `groups` 8-lane groups per row: every bar's chunks go, in order, to one
 // group (longest bars first, each to the least loaded group); step s of group g is items[s * groups + g].
-// Lists are padded with all-zero-weight items (`zero_off`: kBarChunk zeros in tap_w) to a multiple of
-// kBarBatch steps, plus one more batch that the kernels' look-ahead reads.  Returns the step count.
+// Lists are padded with all-zero-weight items (`zero_off`: kBarChunk zeros in tap_w; they restart the running
+// total and store it -- an exact 0 -- to the dump slot `bars`) to a multiple of kBarBatch steps, plus one more
+// batch that the kernels' look-ahead reads.  Returns the step count.
 inline uint32_t make_bar_items(std::vector<BarItem>& items, const std::vector<BarDesc>& desc, uint32_t groups, uint32_t zero_off) {
     std::vector<std::vector<BarItem>> list(groups);
     std::vector<uint32_t> order(desc.size());
-    for (uint32_t k = 0; k < desc.size(); ++k) order[k] = k;
+    const uint32_t bars = (uint32_t) desc.size();
+    for (uint32_t k = 0; k < bars; ++k) order[k] = k;
     std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return desc[a].count > desc[b].count; });
     for (uint32_t k : order) {
         uint32_t g = 0;
         for (uint32_t c = 1; c < groups; ++c) if (list[c].size() < list[g].size()) g = c;
         const BarDesc& d = desc[k];
         for (uint32_t i0 = 0; i0 < d.count; i0 += kBarChunk)
-            list[g].push_back(BarItem{d.tap_offset + i0, (d.first_bin + i0) | (k << 15) | (i0 + kBarChunk >= d.count ? 1u << 30 : 0u)});
+            list[g].push_back(BarItem{(d.tap_offset + i0) * 4u, (d.first_bin + i0) * 4u, i0 + kBarChunk >= d.count ? k : bars, i0 == 0 ? 0.0f : 1.0f});
     }
     uint32_t nsteps = 0;
     for (auto& l : list) nsteps = l.size() > nsteps ? (uint32_t) l.size() : nsteps;
     nsteps = (nsteps + kBarBatch - 1) / kBarBatch * kBarBatch;
-    items.assign((size_t) (nsteps + kBarBatch) * groups, BarItem{zero_off, 0u});
+    items.assign((size_t) (nsteps + kBarBatch) * groups, BarItem{zero_off * 4u, 0u, bars, 0.0f});
     for (uint32_t g = 0; g < groups; ++g)
         for (uint32_t s2 = 0; s2 < list[g].size(); ++s2) items[(size_t) s2 * groups + g] = list[g][s2];
     return nsteps;

@@ -416,10 +416,11 @@ void glvo_bars_at(const float* tex, size_t sz, float* bars_out, size_t bars, flo
 }
 
 /* GLV_OP_BARS as the library defines it: the taps and weights of glvo_bars (smooth.glsl:13-40), summed in the library's
- * documented order instead of tap by tap -- a bar's taps in chunks of 64; within a chunk sixteen partial sums of four
- * consecutive products each ((((0 + x0 w0) + x1 w1) + x2 w2) + x3 w3, zero weights past the bar's end), combined pairwise
- * (neighbours, pairs of pairs, the two quads of each eight, the two eights); chunk totals added in chunk order; one division
- * by the tap-order sum of the weights.  glava_amd/csrc/glv_frame.h "GLV_OP_BARS arithmetic" is what this restates; the GPU
+ * documented order instead of tap by tap -- a bar's taps in chunks of 64; within a chunk eight partial sums of eight
+ * consecutive taps each, every one the sum e + o of two fused-multiply-add chains from +0 (e over the even taps:
+ * fma(x6, w6, fma(x4, w4, fma(x2, w2, fma(x0, w0, 0)))), o over the odd ones; zero weights past the bar's end), combined
+ * pairwise (neighbours, pairs of pairs, the two quads); chunk totals added in chunk order; one division by the tap-order
+ * sum of the weights.  glava_amd/csrc/glv_frame.h "GLV_OP_BARS arithmetic" is what this restates; the GPU
  * tests demand these bits, tests/test_glsl_twins.py bounds the distance to glvo_bars (summation rounding only). */
 void glvo_bars_chunked_at(const float* tex, size_t sz, float* bars_out, size_t bars, float smooth_factor, float phase);
 void glvo_bars_chunked(const float* tex, size_t sz, float* bars_out, size_t bars, float smooth_factor) { glvo_bars_chunked_at(tex, sz, bars_out, bars, smooth_factor, 0.0F); }
@@ -443,15 +444,16 @@ void glvo_bars_chunked_at(const float* tex, size_t sz, float* bars_out, size_t b
         for (size_t p = cnt; p < ((cnt + 63) / 64) * 64; ++p) { w[p] = 0; x[p] = 0; }
         float total = 0;
         for (size_t c0 = 0; c0 < cnt; c0 += 64) {
-            float lane[16];
-            for (int l = 0; l < 16; ++l) {
-                float acc = 0;
-                for (int i = 0; i < 4; ++i) acc = acc + x[c0 + 4 * l + i] * w[c0 + 4 * l + i];
-                lane[l] = acc;
+            float lane[8];
+            for (int l = 0; l < 8; ++l) {
+                float e = 0, o = 0;
+                for (int i = 0; i < 8; i += 2) {
+                    e = fmaf(x[c0 + 8 * l + i], w[c0 + 8 * l + i], e);
+                    o = fmaf(x[c0 + 8 * l + i + 1], w[c0 + 8 * l + i + 1], o);
+                }
+                lane[l] = e + o;
             }
-            float q[4];
-            for (int g = 0; g < 4; ++g) q[g] = (lane[4 * g] + lane[4 * g + 1]) + (lane[4 * g + 2] + lane[4 * g + 3]);
-            total = total + ((q[0] + q[1]) + (q[2] + q[3]));
+            total = total + (((lane[0] + lane[1]) + (lane[2] + lane[3])) + ((lane[4] + lane[5]) + (lane[6] + lane[7])));
         }
         bars_out[k] = total / weight;
     }

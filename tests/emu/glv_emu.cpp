@@ -167,16 +167,15 @@ int glvemu_post_state(const float* in, float* out, float* grav, float* hist, int
 }  // extern "C"
 
 // ---- GLV_OP_BARS on the host: the same tables, work lists and chunk arithmetic as the kernels; the
-// 16-lane DPP sum (glv_frame.h group16_sum) is restated as the data movement its four steps perform.
+// 8-lane DPP sum (glv_frame.h group8_sum) is restated as the data movement its three steps perform.
 namespace {
-float group16_sum_host(const float (&lane)[16]) {
-    float v[16], t[16];
-    for (int i = 0; i < 16; ++i) v[i] = lane[i];
-    auto step = [&](auto src) { for (int i = 0; i < 16; ++i) t[i] = v[i] + v[src(i)]; for (int i = 0; i < 16; ++i) v[i] = t[i]; };
+float group8_sum_host(const float (&lane)[8]) {
+    float v[8], t[8];
+    for (int i = 0; i < 8; ++i) v[i] = lane[i];
+    auto step = [&](auto src) { for (int i = 0; i < 8; ++i) t[i] = v[i] + v[src(i)]; for (int i = 0; i < 8; ++i) v[i] = t[i]; };
     step([](int i) { return i ^ 1; });                       // quad_perm [1,0,3,2]
     step([](int i) { return i ^ 2; });                       // quad_perm [2,3,0,1]
-    step([](int i) { return (i & 8) | (7 - (i & 7)); });     // row_half_mirror
-    step([](int i) { return 15 - i; });                      // row_mirror
+    step([](int i) { return 7 - i; });                       // row_half_mirror
     return v[0];
 }
 }  // namespace
@@ -189,13 +188,14 @@ void glvemu_div_65535(int lo, int hi, float* out) {
 }
 
 extern "C" {
-// bars of `nrows` rows of n floats through work lists for `groups` 16-lane groups.  steps_out (may be NULL)
+// bars of `nrows` rows of n floats through work lists for `groups` 8-lane groups.  steps_out (may be NULL)
 // receives the step count; returns 0 on success.
 int glvemu_bars(const float* spec, size_t nrows, int n, int bars, float smooth_factor, int groups, float* out, unsigned* steps_out, float phase) {
     using namespace glv;
     std::vector<BarDesc> desc;
     std::vector<float> w;
     make_bar_taps(desc, w, (uint32_t) n, (uint32_t) bars, smooth_factor, phase);
+    if (!bar_chunks_in_row(desc, (uint32_t) n)) return 1;
     const uint32_t zero_off = (uint32_t) w.size();
     w.resize(w.size() + kBarChunk, 0.0f);
     std::vector<BarItem> items;
@@ -207,10 +207,10 @@ int glvemu_bars(const float* spec, size_t nrows, int n, int bars, float smooth_f
             float total = 0.0f;
             for (uint32_t s = 0; s < nsteps; ++s) {
                 const BarItem it = items[(size_t) s * groups + g];
-                float lane[16];
-                for (int sub = 0; sub < 16; ++sub) lane[sub] = bar_item_lane_sum(bar_item_load(tex, (uint32_t) n, w.data(), it, sub));
-                total += group16_sum_host(lane);
-                if (bar_item_last(it)) { out[row * bars + bar_item_bar(it)] = total / desc[bar_item_bar(it)].weight_sum; total = 0.0f; }
+                float lane[kBarLanes];
+                for (int sub = 0; sub < kBarLanes; ++sub) lane[sub] = bar_item_lane_sum(bar_item_load(tex, w.data(), it, sub));
+                total = __builtin_fmaf(total, it.keep, group8_sum_host(lane));
+                if (it.res != (uint32_t) bars) out[row * bars + it.res] = total / desc[it.res].weight_sum;
             }
         }
     }
@@ -233,20 +233,26 @@ int glvemu_bar_items_check(int n, int bars, float smooth_factor, int groups) {
     if (nsteps % kBarBatch || items.size() != (size_t) (nsteps + kBarBatch) * groups) return 2;
     std::vector<int> owner(desc.size(), -1);
     std::vector<uint32_t> next_chunk(desc.size(), 0);
-    for (int g = 0; g < groups; ++g)
+    for (int g = 0; g < groups; ++g) {
+        bool open = false;                         // a bar of this group has chunks still to come
         for (uint32_t s = 0; s < nsteps + kBarBatch; ++s) {
             const BarItem it = items[(size_t) s * groups + g];
-            if (it.w_off == zero_off) { if (it.pack != 0) return 3; continue; }
+            if (it.w_byte == zero_off * 4u) { if (it.tex_byte != 0 || it.res != (uint32_t) bars || it.keep != 0.0f || open) return 3; continue; }
             if (s >= nsteps) return 4;
-            const uint32_t k = bar_item_bar(it);
+            // which bar: the one whose weights this chunk points into
+            uint32_t k = 0;
+            while (k < desc.size() && !(it.w_byte / 4u >= desc[k].tap_offset && it.w_byte / 4u < desc[k].tap_offset + desc[k].count)) ++k;
             if (k >= desc.size()) return 5;
             if (owner[k] == -1) owner[k] = g; else if (owner[k] != g) return 6;
             const uint32_t i0 = next_chunk[k];
-            if (it.w_off != desc[k].tap_offset + i0 || bar_item_tex(it) != desc[k].first_bin + i0) return 7;
-            if (bar_item_last(it) != (i0 + kBarChunk >= desc[k].count)) return 8;
-            for (uint32_t j = 0; j < kBarChunk; ++j) if (i0 + j >= desc[k].count && w[it.w_off + j] != 0.0f) return 9;
+            if (it.w_byte != (desc[k].tap_offset + i0) * 4u || it.tex_byte != (desc[k].first_bin + i0) * 4u) return 7;
+            const bool last = i0 + kBarChunk >= desc[k].count;
+            if (it.res != (last ? k : (uint32_t) bars) || it.keep != (i0 == 0 ? 0.0f : 1.0f) || open != (i0 != 0)) return 8;
+            open = !last;
+            for (uint32_t j = 0; j < kBarChunk; ++j) if (i0 + j >= desc[k].count && w[it.w_byte / 4u + j] != 0.0f) return 9;
             next_chunk[k] = i0 + kBarChunk;
         }
+    }
     for (size_t k = 0; k < desc.size(); ++k) if (next_chunk[k] < desc[k].count) return 10;
     return 0;
 }

@@ -184,14 +184,14 @@ def test_bar_work_lists(emu, n, bars):
 
 @pytest.mark.parametrize("n", [512, 4096, 16384])
 def test_bars_emulator_vs_restatement(emu, oracle, n):
-    """the kernels' chunked 16-lane arithmetic == the oracle's restatement of that documented order (glvo_bars_chunked), bit
+    """the kernels' chunked 8-lane arithmetic == the oracle's restatement of that documented order (glvo_bars_chunked), bit
     for bit; both differ from the tap-by-tap order of the shader text (glvo_bars, pinned to the GLSL evaluation by
     tests/test_glsl_twins.py) by summation rounding only; the result does not depend on how many groups share the work"""
     bars = 80
     spec = np.abs(np.random.default_rng(n).standard_normal((3, n))).astype(np.float32) * 0.4
     spec[1, ::7] = 1.7          # exercise the [0,1] clamp
     got16, steps = emu_bars(emu, spec, n, bars, groups=16)
-    assert steps % 4 == 0 and steps > 0
+    assert steps % 2 == 0 and steps > 0          # kBarBatch
     for r in range(3):
         want = np.empty(bars, np.float32)
         oracle.lib().glvo_bars_chunked(np.ascontiguousarray(spec[r]), n, want, bars, 0.025)

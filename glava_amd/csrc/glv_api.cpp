@@ -398,13 +398,13 @@ int ensure_bar_tables(glv_batch* b, int lanes = 0) {
     if (b->d_bar_w) { (void) hipFree(b->d_bar_w); b->d_bar_w = nullptr; }
     HIP_TRY(hipMalloc(&b->d_bar_desc, sizeof(glv::BarDesc) * desc.size()));
     // work lists: 32 groups per row for glv_bars_kernel; T/8 groups for the frame kernel of this size
-    // (fused bars: whole waves per row, one bar per lane of the row at most).  kBarChunk zero weights
+    // (fused bars: whole waves per row, fewer than 2 * lanes bars).  kBarChunk zero weights
     // appended for padding items.
     const uint32_t zero_off = (uint32_t) w.size();
     w.resize(w.size() + glv::kBarChunk, 0.0f);
     std::vector<glv::BarItem> items, fitems;
     b->bar_nsteps = glv::make_bar_items(items, desc, 256 / glv::kBarLanes, zero_off);
-    b->bar_fusable = lanes % 64 == 0 && b->p.bars <= (uint32_t) lanes;
+    b->bar_fusable = lanes % 64 == 0 && b->p.bars + 1 <= 2 * (uint32_t) lanes;   // bar totals + the dump slot fit the 2 * lanes floats of slack behind the row in LDS
     if (b->bar_fusable) b->bar_fnsteps = glv::make_bar_items(fitems, desc, (uint32_t) lanes / glv::kBarLanes, zero_off);
     if (b->d_bar_items) { (void) hipFree(b->d_bar_items); b->d_bar_items = nullptr; }
     if (b->d_bar_fitems) { (void) hipFree(b->d_bar_fitems); b->d_bar_fitems = nullptr; }
@@ -477,7 +477,7 @@ int process(glv_batch* b, const void* d_in, int in_mode, float* d_out, unsigned 
     bool fused_bars = (ops & GLV_OP_BARS) && (ops & GLV_OP_FFT) && (ops & (GLV_OP_GRAVITY | GLV_OP_AVERAGE)) && !(ops & (GLV_OP_SMOOTH | GLV_OP_R16)) && !gl_split;
     if (fused_bars) {
         if (int rc = ensure_bar_tables(b, glv::frame_geometry(b->log_nn, variant).lanes)) return rc;
-        fused_bars = b->bar_fusable                // whole waves per row, at most one bar per lane of the row
+        fused_bars = b->bar_fusable                // whole waves per row, bar totals fit the slack behind the row
                      && !std::getenv("GLV_UNFUSED_BARS");   // diagnostics: force the two-kernel path
     }
     if (ops & GLV_OP_BARS) {

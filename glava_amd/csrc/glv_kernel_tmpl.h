@@ -342,7 +342,7 @@ glv_frame_kernel(const FrameArgs a) {
             else FR::template epilogue<LOG_MODE, EPI_MAG, TILTREG, false, NF>(v, out_row, row, tid, a, logtab, tilt_reg);
         }
     };
-    // FUSED_BARS: lane k of a slot stores bar k (bars <= T): its weight sum stays in a register
+    // FUSED_BARS: lane k of a slot stores bar k (and k + T, ... when bars > T): the first one's weight sum stays in a register
     float bar_wsum = 1.0f;
     if constexpr (FUSED_BARS) { if ((uint32_t) tid < a.bars) bar_wsum = a.bar_desc[tid].weight_sum; }
     // the epilogue of one row; every lane of the workgroup calls it (barriers inside when FUSED_BARS)
@@ -360,7 +360,7 @@ glv_frame_kernel(const FrameArgs a) {
             // divide by the weight sums and store the bars coalesced.
             constexpr uint32_t G = T / kBarLanes;
             float* lrow = reinterpret_cast<float*>(xslot);
-            float* lres = lrow + N;                                       // XREGION has NN/E points (2T floats) of slack: bars + 1 <= T + 1
+            float* lres = lrow + N;                                       // XREGION has NN/E points (2T floats) of slack: bars + 1 <= 2T (glv_api.cpp bar_fusable)
             static_assert(2 * T >= 64, "the chunk reads of bar_item_load stay inside the slot's region");
             if (active) {
                 const int sub = tid & (kBarLanes - 1);
@@ -391,7 +391,11 @@ glv_frame_kernel(const FrameArgs a) {
                 }
             }
             sy.sync();
-            if (active && (uint32_t) tid < a.bars) a.bars_out[row * a.bars + (uint32_t) tid] = lres[tid] / bar_wsum;
+            if (active) {
+                if ((uint32_t) tid < a.bars) a.bars_out[row * a.bars + (uint32_t) tid] = lres[tid] / bar_wsum;
+                // more bars than lanes (N=1024: 64 lanes, 80 bars): a second trip, its weight sums from L2
+                for (uint32_t k = (uint32_t) tid + T; k < a.bars; k += T) a.bars_out[row * a.bars + k] = lres[k] / a.bar_desc[k].weight_sum;
+            }
             // the next row's first exchange write is preceded by a barrier (NBUF == 1): the bars readers are safe
         } else {
 #if defined(GLV_EXP_STOREPRIO)       /* tools/tune.py A/B: the epilogue (stores) at raised wave priority */

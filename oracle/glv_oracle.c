@@ -438,7 +438,8 @@ void glvo_bars_chunked_at(const float* tex, size_t sz, float* bars_out, size_t b
             float wt = glvo_sinusoidal(glvo_clamp01((m - fabsf(rm - s)) / m));
             weight += wt;
             w[cnt] = wt;
-            x[cnt] = glvo_clamp01(tex[(int) roundf(s)]);
+            float tv = tex[(int) roundf(s)];
+            x[cnt] = tv > 0 ? (tv < 1 ? tv : 1) : 0;          /* [0, 1] like a GL_R16 texel; NaN -> 0 (the library's clamp: v_pk_mul_f32 ... clamp) */
             ++cnt;
         }
         for (size_t p = cnt; p < ((cnt + 63) / 64) * 64; ++p) { w[p] = 0; x[p] = 0; }

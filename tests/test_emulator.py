@@ -176,7 +176,7 @@ from emu_lib import emu_bars  # noqa: E402
 @pytest.mark.parametrize("n,bars", [(512, 80), (4096, 80), (16384, 80), (4096, 31), (16384, 256)])
 def test_bar_work_lists(emu, n, bars):
     """every chunk of every bar exactly once, a bar's chunks in one group in order, zero-weight padding --
-    for every group count the kernels use (T/16 of each size, 16 for glv_bars_kernel)"""
+    for every group count the kernels use (T/8 of each size, 32 for glv_bars_kernel)"""
     for groups in (1, 4, 8, 16, 32):
         assert emu.glvemu_bar_items_check(n, bars, C.c_float(0.025), groups) == 0, groups
     assert emu.glvemu_bar_items_check(n, bars, C.c_float(0.1), 16) == 0
@@ -202,6 +202,26 @@ def test_bars_emulator_vs_restatement(emu, oracle, n):
     for groups in (1, 4, 8, 32):
         got, _ = emu_bars(emu, spec, n, bars, groups=groups)
         assert (bits(got) == bits(got16)).all(), groups
+
+
+@pytest.mark.parametrize("n,bars,factor,phase", [(1024, 80, 0.025, 0.0), (1024, 1024, 0.025, 0.5), (2048, 33, 0.1, 0.0), (4096, 256, 0.01, 0.0),
+                                                 (8192, 1, 0.025, 0.0), (16384, 160, 0.05, 0.0), (256, 7, 0.3, 0.25)])
+def test_bars_parameter_sweep_emulator_vs_restatement(emu, oracle, n, bars, factor, phase):
+    """the same sweep the device runs (tests/test_gpu_parity.py test_bars_parameter_sweep_against_the_oracle_order): bar counts
+    from 1 to n, narrow and wide windows, the pre-smoothing pass's positions, values outside [0, 1] / infinite / NaN"""
+    rng = np.random.default_rng(n + bars)
+    spec = np.abs(rng.standard_normal((4, n))).astype(np.float32) * 0.6
+    spec[1, ::5] = -spec[1, ::5]
+    spec[2, ::11] = np.inf
+    spec[2, 3::13] = np.nan
+    spec[3, 7::17] = -np.inf
+    spec[3, ::3] *= 1e-30
+    got, _ = emu_bars(emu, spec, n, bars, smooth_factor=factor, groups=32, phase=phase)
+    for r in range(4):
+        want = np.empty(bars, np.float32)
+        oracle.lib().glvo_bars_chunked_at(np.ascontiguousarray(spec[r]), n, want, bars, factor, phase)
+        assert (bits(got[r]) == bits(want)).all(), r
+    assert np.isfinite(got).all()
 
 
 def test_division_by_65535_is_correctly_rounded_for_every_integer_argument(emu):

@@ -645,12 +645,15 @@ def test_gravity_state_as_output(G):
     for x in (a, b, c): x.close()
 
 
-@pytest.mark.parametrize("n,F", [(16384, 0), (4096, 5), (512, 5)])
-def test_fused_bars_equal_unfused(G, n, F):
+@pytest.mark.parametrize("n,F,bars", [(16384, 0, 80), (4096, 5, 80), (512, 5, 80), (1024, 5, 80), (1024, 0, 127), (1024, 0, 128),
+                                      (2048, 0, 200), (8192, 5, 300), (256, 0, 30), (32768, 0, 80)])
+def test_fused_bars_equal_unfused(G, n, F, bars):
     """GLV_OP_BARS inside the frame kernel (row in LDS, sizes whose rows are owned by whole waves) must
-    give the bits of glv_batch_bars on the same spectra; N=512 exercises the unfused fallback."""
+    give the bits of glv_batch_bars on the same spectra; N=512 / 256 exercise the unfused fallback, N=1024 with 80 and 127 bars
+    the fused kernel with more bars than lanes per row (64), 128 bars the fallback behind it (bars + 1 > 2 * lanes);
+    the bar counts also walk glv_bars_kernel's variants (work lists of 2, 4 and more steps)."""
     import torch
-    streams, bars = 5, 80
+    streams = 5
     ops = G.OP_FFT | G.OP_GRAVITY | (G.OP_AVERAGE if F else 0)
     p = G.Params(n=n, bars=bars, avg_frames=max(F, 1), avg_window_kind=1)
     a, b = G.Batch(p, streams, ops), G.Batch(p, streams, ops)
@@ -664,7 +667,7 @@ def test_fused_bars_equal_unfused(G, n, F):
         b.process_s16(d_pcm, d_b2, ops | G.OP_BARS)
         torch.cuda.synchronize()
         assert torch.equal(d_b1.view(torch.int32), d_b2.view(torch.int32)), fr
-    assert float(d_b1.abs().max()) > 0
+    assert float(torch.nan_to_num(d_b1).abs().max()) > 0     # (n=256: bar 0 is 0 / 0 -- one tap of weight 0 -- in the shader too)
     a.close(); b.close()
 
 
@@ -803,6 +806,33 @@ def test_bars_bits_equal_host_emulation(G, emu):
             Oracle.lib().glvo_bars_chunked(np.ascontiguousarray(spec[r]), n, w2, bars, 0.025)
             assert (bits(got[r]) == bits(w2)).all(), (n, r)
         b.close()
+
+
+@pytest.mark.parametrize("n,bars,factor,phase", [(1024, 80, 0.025, 0.0), (1024, 1024, 0.025, 0.5), (2048, 33, 0.1, 0.0), (4096, 256, 0.01, 0.0),
+                                                 (8192, 1, 0.025, 0.0), (16384, 160, 0.05, 0.0), (32768, 80, 0.025, 0.0), (256, 7, 0.3, 0.25)])
+def test_bars_parameter_sweep_against_the_oracle_order(G, n, bars, factor, phase):
+    """bar counts from 1 to n, narrow and wide windows, the pre-smoothing pass's texel centres (phase 0.5, bars == n), rows
+    with values outside [0, 1], negative, infinite and NaN (clamped to [0, 1], NaN -> 0, as the documented contract says):
+    glv_batch_bars == glvo_bars_chunked_at, bit for bit"""
+    import torch
+    streams = 2
+    rng = np.random.default_rng(n + bars)
+    spec = np.abs(rng.standard_normal((streams * 2, n))).astype(np.float32) * 0.6
+    spec[1, ::5] = -spec[1, ::5]
+    spec[2, ::11] = np.inf
+    spec[2, 3::13] = np.nan
+    spec[3, 7::17] = -np.inf
+    spec[3, ::3] *= 1e-30
+    b = G.Batch(G.Params(n=n, bars=bars, smooth_factor=factor, bar_phase=phase), streams, G.OP_FFT)
+    d_bars = torch.full((streams * 2, bars), float("nan"), dtype=torch.float32, device="cuda")
+    b.bars(torch.from_numpy(spec).cuda(), d_bars)
+    got = d_bars.cpu().numpy()
+    for r in range(streams * 2):
+        want = np.empty(bars, np.float32)
+        Oracle.lib().glvo_bars_chunked_at(np.ascontiguousarray(spec[r]), n, want, bars, factor, phase)
+        assert (bits(got[r]) == bits(want)).all(), r
+    assert np.isfinite(got).all()
+    b.close()
 
 
 def test_reference_host_through_shim(G):

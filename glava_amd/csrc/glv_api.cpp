@@ -405,7 +405,7 @@ int ensure_bar_tables(glv_batch* b, int lanes = 0) {
     std::vector<glv::BarItem> items, fitems;
     b->bar_nsteps = glv::make_bar_items(items, desc, 256 / glv::kBarLanes, zero_off);
     b->bar_fusable = lanes % 64 == 0 && b->p.bars + 1 <= 2 * (uint32_t) lanes;   // bar totals + the dump slot fit the 2 * lanes floats of slack behind the row in LDS
-    if (b->bar_fusable) b->bar_fnsteps = glv::make_bar_items(fitems, desc, (uint32_t) lanes / glv::kBarLanes, zero_off);
+    if (b->bar_fusable) b->bar_fnsteps = glv::make_bar_items(fitems, desc, (uint32_t) lanes / glv::kBarLanes, zero_off, (uint32_t) glv::frame_geometry(b->log_nn, 0).bar_batch);
     if (b->d_bar_items) { (void) hipFree(b->d_bar_items); b->d_bar_items = nullptr; }
     if (b->d_bar_fitems) { (void) hipFree(b->d_bar_fitems); b->d_bar_fitems = nullptr; }
     HIP_TRY(hipMalloc(&b->d_bar_items, sizeof(glv::BarItem) * items.size()));

@@ -65,11 +65,11 @@ struct FrameArgs {
     // fused GLV_OP_BARS (stateful kernels, lanes-per-row a multiple of 64): the finished row goes to the
     // slot's LDS region instead of HBM and only the bars leave the chip
     const BarDesc* bar_desc;
-    const BarItem* bar_items;   // [bar_nsteps + kBarBatch][groups] work lists (glv_tables.h make_bar_items), groups = T/8
+    const BarItem* bar_items;   // [bar_nsteps + batch][groups] work lists (glv_tables.h make_bar_items), groups = T/8
     const float* bar_w;
     float* bars_out;            // [units][bars], nullptr = not fused
     uint32_t bars;
-    uint32_t bar_nsteps;        // multiple of kBarBatch
+    uint32_t bar_nsteps;        // multiple of bar_batch_of(log2 nn)
 };
 
 // ---- GLV_OP_BARS arithmetic (smooth.glsl:25-40; tex clamped to [0,1] like the GL_R16 texture the
@@ -92,10 +92,16 @@ struct FrameArgs {
 constexpr uint32_t kBarChunk = 64;
 constexpr int kBarLanes = 8;           // lanes per group
 constexpr int kBarTaps = 8;            // consecutive taps per lane: kBarLanes * kBarTaps == kBarChunk
-#if !defined(GLV_BAR_BATCH)
-#define GLV_BAR_BATCH 2
+constexpr int kBarBatch = 2;           // work-list steps whose loads are issued together (glv_bars_kernel; the fused loop: bar_batch_of)
+// The fused loop's batch per transform size: a batch is one exposed L2 round trip (the weights; ~0.5 us per row that nothing in
+// the workgroup covers), so the large sizes, whose rows are 10 steps of 32 groups, take six steps per trip (N=16384
+// fft -> gravity -> 80 bars 0.748 -> 0.672 ms) -- where the epilogue's registers are free again; the sizes with 2-6 steps per row
+// lose more to padded steps and register pressure than the saved trip is worth (N=8192: 0.652 / 0.648 / 0.68 / 0.73 ms with
+// 2 / 3 / 4 / 6; N=4096: 0.569 / 0.566 / 0.662 with 2 / 4 / 6; N=1024: 0.83 / 0.87 / 1.2 / 1.8: profiles/r03/ab_bars_phase.txt).
+#if !defined(GLV_BAR_BATCH_BIG)
+#define GLV_BAR_BATCH_BIG 6
 #endif
-constexpr int kBarBatch = GLV_BAR_BATCH;   // work-list steps whose loads are issued together
+GLV_HD constexpr int bar_batch_of(int log_nn) { return log_nn >= 13 ? GLV_BAR_BATCH_BIG : kBarBatch; }
 struct BarTaps { float t[kBarTaps], w[kBarTaps]; };
 // sub = lane index within the group (0..7).  A chunk reaches up to 63 floats past its bar's last tap (zero weights there:
 // whatever is read is clamped to [0, 1], NaN -> 0, by bar_item_lane_sum before it meets its zero weight, so it adds

@@ -96,6 +96,7 @@ static FrameGeometry geometry_of() {
     using FR = Frame<GLV_LOG_NN, TU::log_e>;
     FrameGeometry g;
     g.lanes = FR::T;                                       // lanes that cooperate on one row (fused bars need whole waves per row)
+    g.bar_batch = bar_batch_of(GLV_LOG_NN);
     // workgroups that fit one CU (LDS and the launch-bounds wave budget)
     constexpr size_t lds = frame_lds_bytes<GLV_LOG_NN, TU::log_e, TU::slots, TU::nbuf, TU::winlds, TU::twreg>();
     constexpr int by_lds = (int) (160 * 1024 / lds);

@@ -352,13 +352,14 @@ glv_frame_kernel(const FrameArgs a) {
             if (active) finish(v, row, tid);               // finished row -> LDS, natural order
             sy.sync();
             // T/8 groups of 8 lanes work through the row's bar chunks (glv_frame.h "GLV_OP_BARS
-            // arithmetic"; work lists from make_bar_items).  kBarBatch steps at a time: their loads (LDS
+            // arithmetic"; work lists from make_bar_items).  BB = bar_batch_of(LOG_NN) steps at a time: their loads (LDS
             // row + L2-resident weights) are issued together and the next batch's items are fetched
             // while the current one is reduced.  No global store inside the loop (vmcnt is one in-order
             // counter): every step stores its running total to the slack behind the row -- slot `res` is the
             // bar a chunk completes, or the dump slot lres[bars] -- and after a barrier the slot's lanes
             // divide by the weight sums and store the bars coalesced.
             constexpr uint32_t G = T / kBarLanes;
+            constexpr int BB = bar_batch_of(LOG_NN);
             float* lrow = reinterpret_cast<float*>(xslot);
             float* lres = lrow + N;                                       // XREGION has NN/E points (2T floats) of slack: bars + 1 <= 2T (glv_api.cpp bar_fusable)
             static_assert(2 * T >= 64, "the chunk reads of bar_item_load stay inside the slot's region");
@@ -366,28 +367,30 @@ glv_frame_kernel(const FrameArgs a) {
                 const int sub = tid & (kBarLanes - 1);
                 const uint32_t g = (uint32_t) tid / kBarLanes;
                 const BarItem* items = a.bar_items + g;
-                BarItem it[kBarBatch];
+                BarItem it[BB];
 #pragma unroll
-                for (int b = 0; b < kBarBatch; ++b) it[b] = items[(size_t) b * G];
+                for (int b = 0; b < BB; ++b) it[b] = items[(size_t) b * G];
                 float total = 0.0f;
 #if defined(GLV_EXP_BARS_NOLOOP)      /* A/B experiment only: the row goes to LDS, the barriers stay, no bar is summed */
-                for (uint32_t s0 = 0; s0 < 0u; s0 += kBarBatch) {
+                for (uint32_t s0 = 0; s0 < 0u; s0 += BB) {
 #else
-                for (uint32_t s0 = 0; s0 < a.bar_nsteps; s0 += kBarBatch) {
+                for (uint32_t s0 = 0; s0 < a.bar_nsteps; s0 += BB) {
 #endif
-                    BarTaps tp[kBarBatch];
-                    BarItem nx[kBarBatch];
+                    BarTaps tp[BB];
+                    BarItem nx[BB];
+                    // (taps read from LDS step by step, only the weights held for the batch, would let ten steps fit the
+                    // registers -- and ran 0.746 instead of 0.672 ms at six: ten LDS round trips in a row)
 #pragma unroll
-                    for (int b = 0; b < kBarBatch; ++b) tp[b] = bar_item_load<false>(lrow, a.bar_w, it[b], sub);   // slack: 2T >= 63 floats
+                    for (int b = 0; b < BB; ++b) tp[b] = bar_item_load<false>(lrow, a.bar_w, it[b], sub);   // slack: 2T >= 63 floats
 #pragma unroll
-                    for (int b = 0; b < kBarBatch; ++b) nx[b] = items[(size_t) (s0 + kBarBatch + b) * G];   // table has one batch of padding
+                    for (int b = 0; b < BB; ++b) nx[b] = items[(size_t) (s0 + BB + b) * G];   // table has one batch of padding
 #pragma unroll
-                    for (int b = 0; b < kBarBatch; ++b) {
+                    for (int b = 0; b < BB; ++b) {
                         total = __builtin_fmaf(total, it[b].keep, group8_sum(bar_item_lane_sum(tp[b])));
                         if (sub == 0) lres[it[b].res] = total;
                     }
 #pragma unroll
-                    for (int b = 0; b < kBarBatch; ++b) it[b] = nx[b];
+                    for (int b = 0; b < BB; ++b) it[b] = nx[b];
                 }
             }
             sy.sync();

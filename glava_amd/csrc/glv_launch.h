@@ -13,6 +13,7 @@ struct FrameGeometry {
     int resident;       // workgroups that fit one CU
     int rounds;         // rounds of resident workgroups a large launch is cut into
     int rows_per_trip;  // channel rows one workgroup takes per trip of its persistent loop
+    int bar_batch;      // steps per batch of the fused GLV_OP_BARS loop: its work lists are padded to multiples of this
     int lds_bytes, log_e, slots, twreg, winlds;   // for diagnostics / the wisdom file's comments
 };
 

@@ -140,9 +140,9 @@ inline bool bar_chunks_in_row(const std::vector<BarDesc>& desc, uint32_t n) {
 // GLV_OP_BARS work lists for `groups` 8-lane groups per row: every bar's chunks go, in order, to one
 // group (longest bars first, each to the least loaded group); step s of group g is items[s * groups + g].
 // Lists are padded with all-zero-weight items (`zero_off`: kBarChunk zeros in tap_w; they restart the running
-// total and store it -- an exact 0 -- to the dump slot `bars`) to a multiple of kBarBatch steps, plus one more
+// total and store it -- an exact 0 -- to the dump slot `bars`) to a multiple of `batch` steps, plus one more
 // batch that the kernels' look-ahead reads.  Returns the step count.
-inline uint32_t make_bar_items(std::vector<BarItem>& items, const std::vector<BarDesc>& desc, uint32_t groups, uint32_t zero_off) {
+inline uint32_t make_bar_items(std::vector<BarItem>& items, const std::vector<BarDesc>& desc, uint32_t groups, uint32_t zero_off, uint32_t batch = kBarBatch) {
     std::vector<std::vector<BarItem>> list(groups);
     std::vector<uint32_t> order(desc.size());
     const uint32_t bars = (uint32_t) desc.size();
@@ -157,8 +157,8 @@ inline uint32_t make_bar_items(std::vector<BarItem>& items, const std::vector<Ba
     }
     uint32_t nsteps = 0;
     for (auto& l : list) nsteps = l.size() > nsteps ? (uint32_t) l.size() : nsteps;
-    nsteps = (nsteps + kBarBatch - 1) / kBarBatch * kBarBatch;
-    items.assign((size_t) (nsteps + kBarBatch) * groups, BarItem{zero_off * 4u, 0u, bars, 0.0f});
+    nsteps = (nsteps + batch - 1) / batch * batch;
+    items.assign((size_t) (nsteps + batch) * groups, BarItem{zero_off * 4u, 0u, bars, 0.0f});
     for (uint32_t g = 0; g < groups; ++g)
         for (uint32_t s2 = 0; s2 < list[g].size(); ++s2) items[(size_t) s2 * groups + g] = list[g][s2];
     return nsteps;

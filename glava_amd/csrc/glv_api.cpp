@@ -141,6 +141,8 @@ int wisdom_load_file(const char* path) {
 struct Tables {
     glv::cf* d_tw = nullptr;
     double* d_win = nullptr;
+    float* d_win_split = nullptr;      // the same window as float pairs, for s16 samples (glv_core.h WinSplit; made on the device)
+    int win_shifted = 0;               // positions whose low part was moved by an ulp or more (diagnostics)
     glv::LogEntry* d_log = nullptr;
     float* d_tilt = nullptr;
     float tilt_scale = 0.f, tilt_cutoff = 0.f;
@@ -168,6 +170,19 @@ struct Tables {
         HIP_TRY(hipMalloc(&d_win, sizeof(double) * n));
         HIP_TRY(hipMemcpy(d_tw, tw.data(), sizeof(glv::cf) * nn, hipMemcpyHostToDevice));
         HIP_TRY(hipMemcpy(d_win, win.data(), sizeof(double) * n, hipMemcpyHostToDevice));
+        {   // the split window: searched and proven on the device for every s16 sample value (glv_misc.hip)
+            int* d_fs = nullptr;
+            HIP_TRY(hipMalloc(&d_win_split, sizeof(float) * 2 * n));
+            HIP_TRY(hipMalloc(&d_fs, 2 * sizeof(int)));
+            HIP_TRY(hipMemset(d_fs, 0, 2 * sizeof(int)));
+            hipError_t e = glv::launch_window_split(d_win, d_win_split, n, d_fs, nullptr);
+            int fs[2] = {0, 0};
+            if (e == hipSuccess) e = hipMemcpy(fs, d_fs, sizeof(fs), hipMemcpyDeviceToHost);
+            (void) hipFree(d_fs);
+            HIP_TRY(e);
+            if (fs[0]) return fail(GLV_ERR_HIP, "window table of n=%u has no exact float-pair form on this host's cos()", n);
+            win_shifted = fs[1];
+        }
         glv::LogEntry lt[glv::kLogTabSize];
         glv::make_log_table(lt);
         HIP_TRY(hipMalloc(&d_log, sizeof(lt)));
@@ -177,9 +192,10 @@ struct Tables {
     void destroy() {
         if (d_tw) (void) hipFree(d_tw);
         if (d_win) (void) hipFree(d_win);
+        if (d_win_split) (void) hipFree(d_win_split);
         if (d_log) (void) hipFree(d_log);
         if (d_tilt) (void) hipFree(d_tilt);
-        d_tw = nullptr; d_win = nullptr; d_log = nullptr; d_tilt = nullptr;
+        d_tw = nullptr; d_win = nullptr; d_win_split = nullptr; d_log = nullptr; d_tilt = nullptr;
     }
 };
 
@@ -491,6 +507,7 @@ int process(glv_batch* b, const void* d_in, int in_mode, float* d_out, unsigned 
     if (int rc = b->tab.set_tilt(b->p.fft_scale, b->p.fft_cutoff, b->p.log_mode == 1)) return rc;
     glv::FrameArgs a;
     fill_common(a, b->p, b->tab);
+    if (in_mode == glv::IN_S16_STEREO || in_mode == glv::IN_S16_RING) a.win = reinterpret_cast<const double*>(b->tab.d_win_split);   // glv_core.h WinSplit
     a.in = d_in; a.out = d_out; a.grav = b->grav_cur; a.grav_w = b->d_grav; a.hist = b->d_hist;
     a.units = units; a.ops = ops & ~(unsigned) GLV_OP_PRIVATE_STATE; a.head = b->head; a.rot = rot; a.log_mode = b->p.log_mode;
     if (ops & GLV_OP_BARS) a.ops &= ~(unsigned) GLV_OP_R16;        // with bars the texel conversion applies to the bars, the spectra stay f32
@@ -974,6 +991,20 @@ int glv_batch_set_variant(glv_batch* b, int variant) {
 }
 int glv_batch_variants(const glv_batch* b) { return b ? glv::frame_variants(b->log_nn) : 0; }
 int glv_batch_last_variant(const glv_batch* b) { return b ? b->last_variant : 0; }
+int glv_batch_window_selftest(glv_batch* b, unsigned long long* mismatches, int* shifted) {
+    if (!b || !mismatches) return fail(GLV_ERR_INVALID, "glv_batch_window_selftest: NULL argument");
+    HIP_TRY(hipSetDevice(b->device));
+    unsigned long long* d_m = nullptr;
+    HIP_TRY(hipMalloc(&d_m, sizeof(*d_m)));
+    hipError_t e = hipMemset(d_m, 0, sizeof(*d_m));
+    if (e == hipSuccess) e = glv::launch_window_split_check(b->tab.d_win, b->tab.d_win_split, b->p.n, d_m, nullptr);
+    if (e == hipSuccess) e = hipMemcpy(mismatches, d_m, sizeof(*d_m), hipMemcpyDeviceToHost);
+    (void) hipFree(d_m);
+    HIP_TRY(e);
+    if (shifted) *shifted = b->tab.win_shifted;
+    return GLV_OK;
+}
+
 int glv_batch_describe_variant(const glv_batch* b, int variant, char* buf, size_t len) {
     if (!b || !buf || len == 0) return fail(GLV_ERR_INVALID, "NULL argument");
     if (variant < 0 || variant >= glv::frame_variants(b->log_nn)) return fail(GLV_ERR_INVALID, "variant %d out of range", variant);

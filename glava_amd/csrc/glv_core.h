@@ -277,6 +277,15 @@ GLV_HD float unpack_s16_mono(int l, int r) { return unpack_s16((l + r) / 2); }
 
 // render.c:794: data[i] *= window(i, N)  -- float * double -> double -> float.
 GLV_HD float apply_window(float x, double w) { return (float) ((double) x * w); }
+// The same product for s16 samples without fp64: x takes only the 65536 values k / 65535, and for every window value w there
+// is a float pair (hi, lo) -- hi = (float) w, lo = (float) (w - hi), for 14 of the 65 280 window positions of all sizes moved
+// by one ulp -- with  fma(x, hi, x * lo) == (float) ((double) x * w)  for ALL of them (the pair is searched and the identity
+// checked for every sample value on the device when a batch is created: glv_misc.hip glv_window_split_kernel; every (k, i) of
+// every size again by tests/test_window_split.py).  Two packed instructions per complex point instead of six fp64-rate ones
+// (two conversions up, two products, two conversions down): the kernels run at the package power limit, so the cheaper
+// operations are worth more than their issue slots.  Layout: one WinSplit per complex point, in place of its two doubles.
+struct alignas(16) WinSplit { float hi0, hi1, lo0, lo1; };    // window of samples 2c, 2c + 1
+GLV_HD float apply_window_split(float x, float hi, float lo) { return __builtin_fmaf(x, hi, x * lo); }
 
 // render.c:845 tilt factor; inv_n = 1/N is a power of two so n*inv_n == (float)n/(float)N exactly.
 GLV_HD float tilt(int n, float inv_n, float fft_scale, float one_minus_cutoff) {

@@ -414,7 +414,40 @@ struct Frame {
 #pragma unroll
         for (int j = 0; j < WPRE; ++j) wp.w[j] = ld<d2>(win, (uint32_t) tid * 16u + (uint32_t) (j * T) * 16u);
     }
-    template <bool MONO, int WPRE = 0>
+    // one complex point: samples 2c, 2c + 1 of the channel, unpacked (fifo.c:105-106) and windowed (render.c:794).
+    // SPLIT: `wv` holds the point's WinSplit (glv_core.h) instead of two doubles; on the device the pair goes through four
+    // packed instructions (quotient by 65535: glv_core.h div_65535; window: apply_window_split).
+    template <bool MONO, bool SPLIT>
+    GLV_HD static void unpack_point(cf& out, uint32_t px, uint32_t py, uint32_t ch_shift, const d2& wv) {
+        if constexpr (SPLIT) {
+            const WinSplit q = __builtin_bit_cast(WinSplit, wv);
+#if defined(__HIP_DEVICE_COMPILE__)
+            glv_f2 K;
+            if constexpr (MONO) {
+                K.x = (float) (((int) (int16_t) (px & 0xffffu) + (int) (int16_t) (px >> 16)) / 2);
+                K.y = (float) (((int) (int16_t) (py & 0xffffu) + (int) (int16_t) (py >> 16)) / 2);
+            } else {
+                K.x = (float) (int) (int16_t) ((px >> ch_shift) & 0xffffu);
+                K.y = (float) (int) (int16_t) ((py >> ch_shift) & 0xffffu);
+            }
+            const glv_f2 CH = {0x1.0001p-16f, 0x1.0001p-16f}, CL = {0x1.0001p-48f, 0x1.0001p-48f};
+            const glv_f2 HI = {q.hi0, q.hi1}, LO = {q.lo0, q.lo1};
+            glv_f2 t, S, X;
+            asm("v_pk_mul_f32 %0, %1, %2" : "=v"(t) : "v"(K), "v"(CL));
+            asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(S) : "v"(K), "v"(CH), "v"(t));
+            asm("v_pk_mul_f32 %0, %1, %2" : "=v"(t) : "v"(S), "v"(LO));
+            asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(X) : "v"(S), "v"(HI), "v"(t));
+            out.x = X.x; out.y = X.y;
+#else
+            out.x = apply_window_split(sample(px, ch_shift, MONO), q.hi0, q.lo0);
+            out.y = apply_window_split(sample(py, ch_shift, MONO), q.hi1, q.lo1);
+#endif
+        } else {
+            out.x = apply_window(sample(px, ch_shift, MONO), wv.x);   // render.c:794
+            out.y = apply_window(sample(py, ch_shift, MONO), wv.y);
+        }
+    }
+    template <bool MONO, int WPRE = 0, bool SPLIT = false>
     GLV_HD static void unpack_window_impl(cf (&v)[E], const Raw& p, const void* win, int tid, uint32_t ch_shift, const d2* wpre = nullptr) {
 #if defined(GLV_EXP_NOWINLOAD)        /* tools/tune.py timing experiment: no window loads (wrong results) */
         {
@@ -436,10 +469,7 @@ struct Frame {
         if constexpr (WPRE > 0) {
             GLV_SCHED_FENCE();
 #pragma unroll
-            for (int i = 0; i < WPRE; ++i) {
-                v[i].x = apply_window(sample(p.x[i], ch_shift, MONO), wpre[i].x);   // render.c:794
-                v[i].y = apply_window(sample(p.y[i], ch_shift, MONO), wpre[i].y);
-            }
+            for (int i = 0; i < WPRE; ++i) unpack_point<MONO, SPLIT>(v[i], p.x[i], p.y[i], ch_shift, wpre[i]);
         }
 #pragma unroll
         for (int c0 = WPRE; c0 < E; c0 += WCHUNK) {
@@ -453,19 +483,18 @@ struct Frame {
 #pragma unroll
             for (int j = 0; j < WCHUNK; ++j) {
                 const int i = c0 + j;
-                v[i].x = apply_window(sample(p.x[i], ch_shift, MONO), w[cur][j].x);   // render.c:794
-                v[i].y = apply_window(sample(p.y[i], ch_shift, MONO), w[cur][j].y);
+                unpack_point<MONO, SPLIT>(v[i], p.x[i], p.y[i], ch_shift, w[cur][j]);
             }
             GLV_SCHED_FENCE();
         }
     }
     // three code versions (mono, left, right): with a compile-time shift the channel select becomes the
     // operand selector of the conversion (v_cvt_f32_i32_sdwa WORD_0 / WORD_1) instead of a shift per sample
-    template <int WPRE = 0>
+    template <int WPRE = 0, bool SPLIT = false>
     GLV_HD static void unpack_window(cf (&v)[E], const Raw& p, const void* win, int tid, uint32_t ch, bool mono, const d2* wpre = nullptr) {
-        if (mono) unpack_window_impl<true, WPRE>(v, p, win, tid, 0, wpre);
-        else if (ch) unpack_window_impl<false, WPRE>(v, p, win, tid, 16u, wpre);
-        else unpack_window_impl<false, WPRE>(v, p, win, tid, 0u, wpre);
+        if (mono) unpack_window_impl<true, WPRE, SPLIT>(v, p, win, tid, 0, wpre);
+        else if (ch) unpack_window_impl<false, WPRE, SPLIT>(v, p, win, tid, 16u, wpre);
+        else unpack_window_impl<false, WPRE, SPLIT>(v, p, win, tid, 0u, wpre);
     }
     GLV_HD static void load_f32_window(cf (&v)[E], const void* row, const void* win, int tid) {
 #pragma unroll

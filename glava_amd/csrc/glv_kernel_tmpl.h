@@ -244,6 +244,11 @@ glv_frame_kernel(const FrameArgs a) {
     constexpr int T = FR::T, N = FR::N;
     constexpr bool RING = IN_MODE == IN_S16_RING;
     constexpr bool S16 = IN_MODE == IN_S16_STEREO || RING;
+#if defined(GLV_EXP_NOSPLIT)         /* A/B experiment (needs a.win = the double table: glv_tune harness only) */
+    constexpr bool WSPLIT = false;
+#else
+    constexpr bool WSPLIT = S16;     // s16 samples: the window product without fp64 (glv_core.h apply_window_split)
+#endif
     // f32 rows may hold -0.0, Inf and NaN: no unit-twiddle shortcut, non-finite values through the bit-faithful log
     constexpr bool NF = !S16;
     using BD = Body<LOG_NN, LOG_E, NBUF, TWREG, S16>;
@@ -455,7 +460,7 @@ glv_frame_kernel(const FrameArgs a) {
             int tid = tid_outer;
             asm volatile("" : "+v"(tid));
             FR::template load_pcm<RING>(raw, frame_ptr(frame_of(0)), tid, a.rot);
-            FR::unpack_window(v, raw, win, tid, 0u, a.mono != 0);
+            FR::template unpack_window<0, WSPLIT>(v, raw, win, tid, 0u, a.mono != 0);
         }
         __builtin_amdgcn_s_waitcnt(0x0F70);
         for (uint32_t r = 0; r < 2 * nfs; ++r) {
@@ -480,7 +485,7 @@ glv_frame_kernel(const FrameArgs a) {
             finish_row(v, (size_t) f * 2 + ch, tid, active);                                     // D
             GLV_SCHED_FENCE();
             GLV_PHASE(clk, 15);
-            FR::template unpack_window<WPRE>(v, raw, win, tid, ch ^ 1u, a.mono != 0, wp.w);      // C
+            FR::template unpack_window<WPRE, WSPLIT>(v, raw, win, tid, ch ^ 1u, a.mono != 0, wp.w);      // C
 #if defined(GLV_EXP_PHASETIME)
             asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
             if (clk.on) g_phase[17] += 1;
@@ -583,7 +588,7 @@ glv_frame_kernel(const FrameArgs a) {
             typename FR::Raw raw;
             FR::template load_pcm<RING>(raw, static_cast<const char*>(a.in) + (size_t) (row >> 1) * ((size_t) N * 4), tid, a.rot);
             GLV_SCHED_FENCE();
-            FR::unpack_window(v, raw, win, tid, row & 1u, a.mono != 0);
+            FR::template unpack_window<0, WSPLIT>(v, raw, win, tid, row & 1u, a.mono != 0);
         } else if constexpr (F32S) {
             FR::template load_f32_stereo_window<RINGF>(v, static_cast<const char*>(a.in) + (size_t) (row >> 1) * ((size_t) N * 8), win, tid,
                                                        row & 1u, a.mono != 0, a.rot);

@@ -36,6 +36,9 @@ hipError_t launch_bufscale(const float* in, float* out, size_t total_out, uint32
 hipError_t launch_lerp(const float* s0, const float* e0, float* out, size_t total, float mod, hipStream_t st);
 hipError_t launch_smooth(float* rows, size_t nrows, uint32_t n, const int* smin, const int* smax, uint32_t asz, uint32_t reach,
                          uint32_t max_window, hipStream_t st);
+// the s16 window table as float pairs (glv_core.h WinSplit): split = float [n/2][4]; d_fail_shifted = int [2], zeroed by the caller
+hipError_t launch_window_split(const double* w_tab, float* split, uint32_t n, int* d_fail_shifted, hipStream_t st);
+hipError_t launch_window_split_check(const double* w_tab, const float* split, uint32_t n, unsigned long long* d_mismatches, hipStream_t st);
 hipError_t launch_bars(const float* spec, float* bars_out, size_t nrows, uint32_t n, uint32_t bars, uint32_t nsteps,
                        const BarItem* items, const BarDesc* desc, const float* tap_w, hipStream_t st, bool r16 = false);
 hipError_t launch_ring_planar(const void* ring, int is_f32, uint32_t n, uint32_t rot, int mono, size_t streams, float* out, hipStream_t st);

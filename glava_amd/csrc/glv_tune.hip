@@ -106,7 +106,9 @@ int glv_tune_run3(int i, const void* d_pcm, float* d_out, unsigned units, int lo
         if (hipMalloc(&d_tw, sizeof(cf) * NN) != hipSuccess) return -1;
         if (hipMalloc(&d_win, sizeof(double) * N) != hipSuccess) return -1;
         (void) hipMemcpy(d_tw, tw.data(), sizeof(cf) * NN, hipMemcpyHostToDevice);
-        (void) hipMemcpy(d_win, win.data(), sizeof(double) * N, hipMemcpyHostToDevice);
+        std::vector<float> split(2 * (size_t) N);                 // the s16 kernels read the window as float pairs (glv_core.h WinSplit)
+        make_window_split_plain(win.data(), N, split.data());
+        (void) hipMemcpy(d_win, split.data(), sizeof(double) * N, hipMemcpyHostToDevice);
         LogEntry lt[kLogTabSize];
         make_log_table(lt);
         if (hipMalloc(&d_log, sizeof(lt)) != hipSuccess) return -1;

@@ -101,6 +101,7 @@ def lib() -> C.CDLL:
         L.glv_batch_set_variant.argtypes = [vp, C.c_int]
         L.glv_batch_last_variant.argtypes = [vp]
         L.glv_batch_describe_variant.argtypes = [vp, C.c_int, C.c_char_p, C.c_size_t]
+        L.glv_batch_window_selftest.argtypes = [vp, C.POINTER(C.c_ulonglong), C.POINTER(C.c_int)]
         L.glv_batch_autotune.argtypes = [vp, vp, vp, C.c_uint, vp, C.POINTER(C.c_int), C.POINTER(C.c_float)]
         L.glv_wisdom_save.argtypes = [C.c_char_p]; L.glv_wisdom_load.argtypes = [C.c_char_p]
         L.glv_multi_shard_range.argtypes = [C.c_uint64, C.c_int, C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
@@ -234,6 +235,13 @@ class Batch:
 
     def last_variant(self) -> int:
         return int(lib().glv_batch_last_variant(self._h))
+
+    def window_selftest(self) -> tuple[int, int]:
+        """(mismatches, shifted): every (s16 sample value, window position) pair of this size, float-pair product against the
+        reference's fp64 product, on the device; positions whose low part was moved to make the identity hold"""
+        m, sh = C.c_ulonglong(0), C.c_int(0)
+        _check(lib().glv_batch_window_selftest(self._h, C.byref(m), C.byref(sh)))
+        return int(m.value), int(sh.value)
 
     def describe_variant(self, variant: int) -> str:
         buf = C.create_string_buffer(256)

@@ -296,6 +296,14 @@ int glv_wisdom_load(const char* path);
 int glv_wisdom_clear(void);
 int glv_wisdom_count(void);
 
+/* Self test of the s16 window product.  The reference multiplies a float sample by a double window value and rounds the
+ * double product to float (render.c:794).  For s16 input the kernels compute the same bits without fp64: the window value
+ * is a float pair (hi, lo) with fma(x, hi, x * lo) == (float) ((double) x * w) for every one of the 65536 sample values x =
+ * k / 65535 -- found and checked on the device when the batch is created.  This call re-checks EVERY (sample value, window
+ * position) pair of the batch's size against the fp64 product on the device: *mismatches (must be 0) and the number of
+ * positions whose low part had to be moved off (float) (w - hi) (*shifted, may be NULL). */
+int glv_batch_window_selftest(glv_batch* b, unsigned long long* mismatches, int* shifted);
+
 /* Name of the kernel the last process call launched (for matching rocprofv3 rows). */
 const char* glv_batch_kernel_name(const glv_batch* b);
 

@@ -460,3 +460,33 @@ void glvo_bars_chunked_at(const float* tex, size_t sz, float* bars_out, size_t b
     }
     free(x); free(w);
 }
+
+/* The library's s16 window product (glava_amd/csrc/glv_core.h apply_window_split): for every window position of size n the
+ * float pair hi = (float) w, lo = (float) (w - hi), lo moved by +1, -1, +2, ... ulps until
+ *     fmaf(x, hi, x * lo) == (float) ((double) x * w)        (render.c:794: float * double -> double -> float)
+ * holds for every s16 sample value x = k / 65535 (fifo.c:105-106).  This is the CPU restatement of that search (the library
+ * runs it on the device when a batch is created); returns the number of (k, position) pairs that still differ after it
+ * (must be 0), *shifted = positions whose lo had to move, *max_shift = the largest move in ulps. */
+long glvo_window_split_mismatches(size_t n, int* shifted, int* max_shift) {
+    static float x[32769];
+    for (int k = 0; k <= 32768; ++k) x[k] = (float) k / (float) 65535;
+    long left = 0;
+    int nsh = 0, maxd = 0;
+    for (size_t i = 0; i < n; ++i) {
+        double w = 0.53836 - (0.46164 * cos(GLVO_TWOPI * (double) i / (double) n - 1));      /* window(i, n) as render.c:660 expands at :794 */
+        float hi = (float) w, lo0 = (float) (w - (double) hi);
+        int ok = 0;
+        for (int t = 0; t < 33 && !ok; ++t) {
+            int d = (t + 1) / 2 * ((t & 1) ? 1 : -1);
+            float lo = lo0;
+            for (int q = 0; q < abs(d); ++q) lo = nextafterf(lo, d > 0 ? INFINITY : -INFINITY);
+            int bad = 0;
+            for (int k = 1; k <= 32768 && !bad; ++k) bad = fmaf(x[k], hi, x[k] * lo) != (float) ((double) x[k] * w);
+            if (!bad) { ok = 1; if (d) { ++nsh; if (abs(d) > maxd) maxd = abs(d); } }
+        }
+        if (!ok) for (int k = 1; k <= 32768; ++k) left += fmaf(x[k], hi, x[k] * lo0) != (float) ((double) x[k] * w);
+    }
+    if (shifted) *shifted = nsh;
+    if (max_shift) *max_shift = maxd;
+    return left;
+}

@@ -201,7 +201,7 @@ struct Tables {
 
 void fill_common(glv::FrameArgs& a, const glv_params& p, const Tables& t) {
     std::memset(&a, 0, sizeof(a));
-    a.tw = t.d_tw; a.win = t.d_win; a.logtab = t.d_log; a.tilt = t.d_tilt;
+    a.tw = t.d_tw; a.win = t.d_win; a.win_split = t.d_win_split; a.logtab = t.d_log; a.tilt = t.d_tilt;
     a.F = p.avg_frames; a.mono = p.channels == 1; a.avg_window = p.avg_window != 0;
     a.inv_n = 1.0f / (float) p.n;
     a.fft_scale = p.fft_scale;
@@ -507,7 +507,6 @@ int process(glv_batch* b, const void* d_in, int in_mode, float* d_out, unsigned 
     if (int rc = b->tab.set_tilt(b->p.fft_scale, b->p.fft_cutoff, b->p.log_mode == 1)) return rc;
     glv::FrameArgs a;
     fill_common(a, b->p, b->tab);
-    if (in_mode == glv::IN_S16_STEREO || in_mode == glv::IN_S16_RING) a.win = reinterpret_cast<const double*>(b->tab.d_win_split);   // glv_core.h WinSplit
     a.in = d_in; a.out = d_out; a.grav = b->grav_cur; a.grav_w = b->d_grav; a.hist = b->d_hist;
     a.units = units; a.ops = ops & ~(unsigned) GLV_OP_PRIVATE_STATE; a.head = b->head; a.rot = rot; a.log_mode = b->p.log_mode;
     if (ops & GLV_OP_BARS) a.ops &= ~(unsigned) GLV_OP_R16;        // with bars the texel conversion applies to the bars, the spectra stay f32

@@ -49,6 +49,7 @@ struct FrameArgs {
     float* hist;           // [rows][F][n] history ring (average); doubles as gravity state
     const cf* tw;          // nn entries (entry 0 unused), layout glv::tw_offset
     const double* win;     // n window values (render.c:660 as expanded at :794)
+    const void* win_split; // the same as float pairs for s16 samples (glv_core.h WinSplit [n/2]); which one a kernel reads: win_split_of
     const LogEntry* logtab; // 64 entries, log_mode 0 (glv_core.h)
     const float* tilt;     // n tilt factors max(n/N*fft_scale + (1 - fft_cutoff), 1) (render.c:845), host-generated
     uint32_t units;        // channel rows to process (2 per stereo frame)
@@ -92,6 +93,11 @@ struct FrameArgs {
 constexpr uint32_t kBarChunk = 64;
 constexpr int kBarLanes = 8;           // lanes per group
 constexpr int kBarTaps = 8;            // consecutive taps per lane: kBarLanes * kBarTaps == kBarChunk
+// Which window table an s16 kernel multiplies by: the float pairs (two packed instructions per complex point instead of six
+// fp64-rate ones) measured +5 % (N=4096 -> GL_R16), +6 % (N=8192), +4..9 % (N=16384 gravity chains and bars), +2..15 % (N=32768)
+// and 0 % on the N=4096 f32 pass; the one loser is the stateless f32 pass of N=16384 (-2.3 %, 20.8 vs 20.3 M frames/s on the
+// same box, profiles/r03/ab_split.txt), which keeps the fp64 product.  Same bits either way.
+GLV_HD constexpr bool win_split_of(int log_nn, int stateful) { return !(log_nn == 13 && stateful == 0); }
 constexpr int kBarBatch = 2;           // work-list steps whose loads are issued together (glv_bars_kernel; the fused loop: bar_batch_of)
 // The fused loop's batch per transform size: a batch is one exposed L2 round trip (the weights; ~0.5 us per row that nothing in
 // the workgroup covers), so the large sizes, whose rows are 10 steps of 32 groups, take six steps per trip (N=16384

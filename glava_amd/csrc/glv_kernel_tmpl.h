@@ -244,10 +244,10 @@ glv_frame_kernel(const FrameArgs a) {
     constexpr int T = FR::T, N = FR::N;
     constexpr bool RING = IN_MODE == IN_S16_RING;
     constexpr bool S16 = IN_MODE == IN_S16_STEREO || RING;
-#if defined(GLV_EXP_NOSPLIT)         /* A/B experiment (needs a.win = the double table: glv_tune harness only) */
+#if defined(GLV_EXP_NOSPLIT)         /* A/B experiment: the fp64 window product for s16 samples too */
     constexpr bool WSPLIT = false;
 #else
-    constexpr bool WSPLIT = S16;     // s16 samples: the window product without fp64 (glv_core.h apply_window_split)
+    constexpr bool WSPLIT = S16 && win_split_of(LOG_NN, STATEFUL);     // s16 samples: the window product without fp64 (glv_core.h apply_window_split)
 #endif
     // f32 rows may hold -0.0, Inf and NaN: no unit-twiddle shortcut, non-finite values through the bit-faithful log
     constexpr bool NF = !S16;
@@ -261,10 +261,11 @@ glv_frame_kernel(const FrameArgs a) {
     const int tid = threadIdx.x % T;
     char* xslot = smem + (size_t) slot * NREG * XBYTES;
 
-    const void* win = a.win;
+    const void* gwin = WSPLIT ? a.win_split : static_cast<const void*>(a.win);     // 16 bytes per complex point either way
+    const void* win = gwin;
     if constexpr (WINLDS) {
         char* lwin = smem + (size_t) SLOTS * NREG * XBYTES;
-        for (int i = threadIdx.x; i < N / 2; i += T * SLOTS) st<d2>(lwin, (uint32_t) i * 16u, ld<d2>(a.win, (uint32_t) i * 16u));
+        for (int i = threadIdx.x; i < N / 2; i += T * SLOTS) st<d2>(lwin, (uint32_t) i * 16u, ld<d2>(gwin, (uint32_t) i * 16u));
         __syncthreads();
         win = lwin;
     }

@@ -94,6 +94,7 @@ int glv_tune_run3(int i, const void* d_pcm, float* d_out, unsigned units, int lo
     using namespace glv;
     static cf* d_tw = nullptr;
     static double* d_win = nullptr;
+    static float* d_win_split = nullptr;
     static LogEntry* d_log = nullptr;
     static float* d_tilt = nullptr;
     static float* d_tilt_fast = nullptr;
@@ -106,9 +107,11 @@ int glv_tune_run3(int i, const void* d_pcm, float* d_out, unsigned units, int lo
         if (hipMalloc(&d_tw, sizeof(cf) * NN) != hipSuccess) return -1;
         if (hipMalloc(&d_win, sizeof(double) * N) != hipSuccess) return -1;
         (void) hipMemcpy(d_tw, tw.data(), sizeof(cf) * NN, hipMemcpyHostToDevice);
+        (void) hipMemcpy(d_win, win.data(), sizeof(double) * N, hipMemcpyHostToDevice);
         std::vector<float> split(2 * (size_t) N);                 // the s16 kernels read the window as float pairs (glv_core.h WinSplit)
         make_window_split_plain(win.data(), N, split.data());
-        (void) hipMemcpy(d_win, split.data(), sizeof(double) * N, hipMemcpyHostToDevice);
+        if (hipMalloc(&d_win_split, sizeof(float) * 2 * N) != hipSuccess) return -1;
+        (void) hipMemcpy(d_win_split, split.data(), sizeof(float) * 2 * N, hipMemcpyHostToDevice);
         LogEntry lt[kLogTabSize];
         make_log_table(lt);
         if (hipMalloc(&d_log, sizeof(lt)) != hipSuccess) return -1;
@@ -123,7 +126,7 @@ int glv_tune_run3(int i, const void* d_pcm, float* d_out, unsigned units, int lo
     }
     FrameArgs a;
     std::memset(&a, 0, sizeof(a));
-    a.in = d_pcm; a.out = d_out; a.tw = d_tw; a.win = d_win; a.logtab = d_log; a.tilt = log_mode == 1 ? d_tilt_fast : d_tilt; a.units = units * 2; a.ops = OP_FFT | extra_ops; a.grav = d_grav; a.grav_w = d_grav;
+    a.in = d_pcm; a.out = d_out; a.tw = d_tw; a.win = d_win; a.win_split = d_win_split; a.logtab = d_log; a.tilt = log_mode == 1 ? d_tilt_fast : d_tilt; a.units = units * 2; a.ops = OP_FFT | extra_ops; a.grav = d_grav; a.grav_w = d_grav;
     a.F = d_hist ? 5 : 1; a.hist = d_hist; a.avg_window = 1;
     make_frame_weights(a.wts, a.F, true, 0);
     a.inv_n = 1.0f / (float) N; a.fft_scale = 10.2f; a.one_minus_cutoff = 1.0f - 0.3f;

@@ -413,15 +413,16 @@ int ensure_bar_tables(glv_batch* b, int lanes = 0) {
     if (b->d_bar_desc) { (void) hipFree(b->d_bar_desc); b->d_bar_desc = nullptr; }
     if (b->d_bar_w) { (void) hipFree(b->d_bar_w); b->d_bar_w = nullptr; }
     HIP_TRY(hipMalloc(&b->d_bar_desc, sizeof(glv::BarDesc) * desc.size()));
-    // work lists: 32 groups per row for glv_bars_kernel; T/8 groups for the frame kernel of this size
-    // (fused bars: whole waves per row, fewer than 2 * lanes bars).  kBarChunk zero weights
+    // work lists: 256 / GL groups per row for glv_bars_kernel; T / GL groups for the frame kernel of this size (GL = bar_lanes_of(n))
+    // (fused bars: whole waves per row, fewer than 2 * lanes bars).  one chunk of zero weights
     // appended for padding items.
     const uint32_t zero_off = (uint32_t) w.size();
-    w.resize(w.size() + glv::kBarChunk, 0.0f);
+    const uint32_t chunk = glv::bar_chunk_of(b->p.n), gl = (uint32_t) glv::bar_lanes_of(b->p.n);
+    w.resize(w.size() + chunk, 0.0f);
     std::vector<glv::BarItem> items, fitems;
-    b->bar_nsteps = glv::make_bar_items(items, desc, 256 / glv::kBarLanes, zero_off);
+    b->bar_nsteps = glv::make_bar_items(items, desc, 256 / gl, zero_off, chunk);
     b->bar_fusable = lanes % 64 == 0 && b->p.bars + 1 <= 2 * (uint32_t) lanes;   // bar totals + the dump slot fit the 2 * lanes floats of slack behind the row in LDS
-    if (b->bar_fusable) b->bar_fnsteps = glv::make_bar_items(fitems, desc, (uint32_t) lanes / glv::kBarLanes, zero_off, (uint32_t) glv::frame_geometry(b->log_nn, 0).bar_batch);
+    if (b->bar_fusable) b->bar_fnsteps = glv::make_bar_items(fitems, desc, (uint32_t) lanes / gl, zero_off, chunk, (uint32_t) glv::frame_geometry(b->log_nn, 0).bar_batch);
     if (b->d_bar_items) { (void) hipFree(b->d_bar_items); b->d_bar_items = nullptr; }
     if (b->d_bar_fitems) { (void) hipFree(b->d_bar_fitems); b->d_bar_fitems = nullptr; }
     HIP_TRY(hipMalloc(&b->d_bar_items, sizeof(glv::BarItem) * items.size()));

@@ -30,9 +30,9 @@ enum : uint32_t { OP_FFT = 1u, OP_GRAVITY = 2u, OP_AVERAGE = 4u, OP_RAW = 8u, OP
 // one output bar of GLV_OP_BARS: taps are consecutive bins [first_bin, first_bin + count) with weights
 // tap_w[tap_offset ...]; weight_sum = float sum of the weights in tap order (smooth.glsl:31-36)
 struct BarDesc { uint32_t first_bin, count, tap_offset; float weight_sum; };
-// One work item of GLV_OP_BARS: a chunk of kBarChunk = 64 consecutive taps of one bar, taken by one group of
-// kBarLanes = 8 lanes.  Everything a step needs, ready to use (the loop is instruction-bound): w_byte = byte offset
-// of the chunk's 64 weights in tap_w (zero-padded by make_bar_taps; an all-zero block for padding items, which
+// One work item of GLV_OP_BARS: a chunk of bar_chunk_of(n) = 16 / 32 / 64 consecutive taps of one bar, taken by one group of
+// bar_lanes_of(n) = 2 / 4 / 8 lanes.  Everything a step needs, ready to use (the loop is instruction-bound): w_byte = byte offset
+// of the chunk's weights in tap_w (zero-padded by make_bar_taps; an all-zero block for padding items, which
 // therefore add exactly 0), tex_byte = byte offset of the chunk's first tap in the row, res = the bar this chunk
 // completes, or `bars` (a dump slot) when it does not, keep = 0.0f when the chunk opens a bar (the running total
 // restarts), 1.0f otherwise.
@@ -90,9 +90,14 @@ struct FrameArgs {
 // this one spends ~32 per 8: per-step bookkeeping is amortised over twice the taps, one DPP level is gone, multiplies
 // and adds are fused and packed, and the end-of-bar logic is a multiply by `keep` and an unconditional store.
 // (One WAVE per bar, the very first version, spent ~100 instructions per bar on mostly idle lanes.)
-constexpr uint32_t kBarChunk = 64;
-constexpr int kBarLanes = 8;           // lanes per group
-constexpr int kBarTaps = 8;            // consecutive taps per lane: kBarLanes * kBarTaps == kBarChunk
+constexpr int kBarTaps = 8;            // consecutive taps per lane
+// Lanes per group, i.e. the chunk a bar's taps are cut into (8 taps per lane): a bar is at least one chunk, and its width grows
+// with the transform size (80 bars: ~15 taps at n = 1024, ~29 at 2048, ~57 at 4096, ~230 at 16384), so small transforms take
+// small chunks -- 16 taps (2 lanes) up to n = 1024, 32 (4 lanes) at n = 2048, 64 (8 lanes) above: with 64-tap chunks a row of
+// n = 1024 was ten steps of eight groups at 23 % useful taps (fft -> gravity -> 80 bars 0.83 ms; with 16-tap chunks four steps
+// of 32 groups: ms).  The chunk size is part of the documented summation order (glvo_bars_chunked restates it).
+GLV_HD constexpr int bar_lanes_of(uint32_t n) { return n <= 1024u ? 2 : (n == 2048u ? 4 : 8); }
+GLV_HD constexpr uint32_t bar_chunk_of(uint32_t n) { return (uint32_t) (bar_lanes_of(n) * kBarTaps); }
 // Which window table an s16 kernel multiplies by: the float pairs (two packed instructions per complex point instead of six
 // fp64-rate ones) measured +5 % (N=4096 -> GL_R16), +6 % (N=8192), +4..9 % (N=16384 gravity chains and bars), +2..15 % (N=32768)
 // and 0 % on the N=4096 f32 pass; the one loser is the stateless f32 pass of N=16384 (-2.3 %, 20.8 vs 20.3 M frames/s on the
@@ -171,15 +176,16 @@ GLV_HD float bar_item_lane_sum(const BarTaps& s) {
 #endif
 }
 #if defined(__HIPCC__)
-// sum over each group of 8 lanes (half a DPP row), result in every lane of the group: VALU-speed cross-lane
+// sum over each group of GL = 2 / 4 / 8 lanes (aligned inside a DPP row), result in every lane of the group: VALU-speed cross-lane
 // adds (a ds_bpermute shuffle is an LDS round trip each)
 template <int CTRL> __device__ __forceinline__ float dpp_move(float v) {
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, false));
 }
-__device__ __forceinline__ float group8_sum(float v) {
-    v = v + dpp_move<0xB1>(v);       // quad_perm [1,0,3,2]
-    v = v + dpp_move<0x4E>(v);       // quad_perm [2,3,0,1]
-    v = v + dpp_move<0x141>(v);      // row_half_mirror: the other quad of each 8
+template <int GL> __device__ __forceinline__ float group_sum(float v) {
+    static_assert(GL == 2 || GL == 4 || GL == 8, "lanes per group");
+    v = v + dpp_move<0xB1>(v);                             // quad_perm [1,0,3,2]: neighbours
+    if constexpr (GL >= 4) v = v + dpp_move<0x4E>(v);      // quad_perm [2,3,0,1]: pairs of pairs
+    if constexpr (GL >= 8) v = v + dpp_move<0x141>(v);     // row_half_mirror: the other quad of each 8
     return v;
 }
 #endif

@@ -357,21 +357,22 @@ glv_frame_kernel(const FrameArgs a) {
             sy.sync();                                     // every reader of the row's last exchange is done
             if (active) finish(v, row, tid);               // finished row -> LDS, natural order
             sy.sync();
-            // T/8 groups of 8 lanes work through the row's bar chunks (glv_frame.h "GLV_OP_BARS
+            // T/GL groups of GL = 2 / 4 / 8 lanes work through the row's bar chunks (glv_frame.h "GLV_OP_BARS
             // arithmetic"; work lists from make_bar_items).  BB = bar_batch_of(LOG_NN) steps at a time: their loads (LDS
             // row + L2-resident weights) are issued together and the next batch's items are fetched
             // while the current one is reduced.  No global store inside the loop (vmcnt is one in-order
             // counter): every step stores its running total to the slack behind the row -- slot `res` is the
             // bar a chunk completes, or the dump slot lres[bars] -- and after a barrier the slot's lanes
             // divide by the weight sums and store the bars coalesced.
-            constexpr uint32_t G = T / kBarLanes;
+            constexpr int GL = bar_lanes_of((uint32_t) N);                    // lanes per group: 2 / 4 / 8
+            constexpr uint32_t G = T / GL;
             constexpr int BB = bar_batch_of(LOG_NN);
             float* lrow = reinterpret_cast<float*>(xslot);
             float* lres = lrow + N;                                       // XREGION has NN/E points (2T floats) of slack: bars + 1 <= 2T (glv_api.cpp bar_fusable)
             static_assert(2 * T >= 64, "the chunk reads of bar_item_load stay inside the slot's region");
             if (active) {
-                const int sub = tid & (kBarLanes - 1);
-                const uint32_t g = (uint32_t) tid / kBarLanes;
+                const int sub = tid & (GL - 1);
+                const uint32_t g = (uint32_t) tid / GL;
                 const BarItem* items = a.bar_items + g;
                 BarItem it[BB];
 #pragma unroll
@@ -392,7 +393,7 @@ glv_frame_kernel(const FrameArgs a) {
                     for (int b = 0; b < BB; ++b) nx[b] = items[(size_t) (s0 + BB + b) * G];   // table has one batch of padding
 #pragma unroll
                     for (int b = 0; b < BB; ++b) {
-                        total = __builtin_fmaf(total, it[b].keep, group8_sum(bar_item_lane_sum(tp[b])));
+                        total = __builtin_fmaf(total, it[b].keep, group_sum<GL>(bar_item_lane_sum(tp[b])));
                         if (sub == 0) lres[it[b].res] = total;
                     }
 #pragma unroll

@@ -267,16 +267,17 @@ __global__ void __launch_bounds__(64) glv_smooth_ring_kernel(float* __restrict__
 // The tap positions and weights of a bar depend only on (bar, n, smooth_factor) -- not on the data -- so
 // they are generated once per batch on the host (glv_tables.h make_bar_taps: SAMPLE_MODE average,
 // ROUND_FORMULA sinusoidal, SAMPLE_SCALE 8, SAMPLE_RANGE 0.9) together with the work lists
-// (make_bar_items).  One 256-thread workgroup = 32 groups of 8 lanes per row; arithmetic: glv_frame.h.
+// (make_bar_items).  One 256-thread workgroup = 256 / GL groups of GL = bar_lanes_of(n) lanes per row; arithmetic: glv_frame.h.
 // r16: bars_out is uint16 [nrows][bars], the GL_R16 texel of every value (what the reference's smooth pass renders into,
 // render.c:2277-2303 with bind_1d_fbo's GL_R16 texture) instead of float
+template <int GL>
 __global__ void __launch_bounds__(256) glv_bars_kernel(const float* __restrict__ spec, float* __restrict__ bars_out,
                                                        size_t nrows, uint32_t n, uint32_t bars, uint32_t nsteps,
                                                        const BarItem* __restrict__ items, const BarDesc* __restrict__ desc,
                                                        const float* __restrict__ tap_w, int r16) {
-    constexpr uint32_t G = 256 / kBarLanes;
-    const int sub = threadIdx.x & (kBarLanes - 1);
-    const uint32_t g = threadIdx.x / kBarLanes;
+    constexpr uint32_t G = 256 / GL;
+    const int sub = threadIdx.x & (GL - 1);
+    const uint32_t g = threadIdx.x / GL;
     for (size_t row = blockIdx.x; row < nrows; row += gridDim.x) {
         const float* tex = spec + row * n;
         float total = 0.0f;
@@ -289,7 +290,7 @@ __global__ void __launch_bounds__(256) glv_bars_kernel(const float* __restrict__
             for (int b = 0; b < kBarBatch; ++b) tp[b] = bar_item_load(tex, tap_w, it[b], sub);
 #pragma unroll
             for (int b = 0; b < kBarBatch; ++b) {
-                total = __builtin_fmaf(total, it[b].keep, group8_sum(bar_item_lane_sum(tp[b])));
+                total = __builtin_fmaf(total, it[b].keep, group_sum<GL>(bar_item_lane_sum(tp[b])));
                 const uint32_t k = it[b].res;
                 if (k != bars && sub == 0) {
                     const float v = total / desc[k].weight_sum;
@@ -305,14 +306,14 @@ __global__ void __launch_bounds__(256) glv_bars_kernel(const float* __restrict__
 // items, the lane's weights and the weight sums do not depend on the row, so they are fetched ONCE per workgroup and stay in
 // registers; a row then costs one round trip (its taps: 2 NS 16-byte loads per lane) instead of a chain of three (item ->
 // weights / taps per batch), and RI rows are in flight per workgroup trip.  N=1024 x 262144 rows: 2.1 -> ms.
-template <int NS, int RI>
+template <int NS, int RI, int GL>
 __global__ void __launch_bounds__(256) glv_bars_short_kernel(const float* __restrict__ spec, float* __restrict__ bars_out,
                                                              size_t nrows, uint32_t n, uint32_t bars,
                                                              const BarItem* __restrict__ items, const BarDesc* __restrict__ desc,
                                                              const float* __restrict__ tap_w, int r16) {
-    constexpr uint32_t G = 256 / kBarLanes;
-    const int sub = threadIdx.x & (kBarLanes - 1);
-    const uint32_t g = threadIdx.x / kBarLanes;
+    constexpr uint32_t G = 256 / GL;
+    const int sub = threadIdx.x & (GL - 1);
+    const uint32_t g = threadIdx.x / GL;
     const uint32_t lane_byte = 4u * (uint32_t) kBarTaps * (uint32_t) sub;
     BarItem it[NS];
     BarTaps tw[NS];              // .w: the lane's weights of step s (.t unused)
@@ -350,7 +351,7 @@ __global__ void __launch_bounds__(256) glv_bars_short_kernel(const float* __rest
                 BarTaps tp = tw[s];
 #pragma unroll
                 for (int q = 0; q < kBarTaps; ++q) tp.t[q] = t[i][s][q / 4].t[q % 4];
-                total = __builtin_fmaf(total, it[s].keep, group8_sum(bar_item_lane_sum(tp)));
+                total = __builtin_fmaf(total, it[s].keep, group_sum<GL>(bar_item_lane_sum(tp)));
                 const uint32_t k = it[s].res;
                 if (k != bars && sub == 0 && row < nrows) {
                     const float v = total / wsum[s];
@@ -499,13 +500,22 @@ hipError_t launch_smooth(float* rows, size_t nrows, uint32_t n, const int* smin,
     hipLaunchKernelGGL(glv_smooth_kernel, dim3((unsigned) wgs), dim3(64), rpw * row_bytes, st, rows, nrows, n, smin, smax, asz, reach, (uint32_t) rpw);
     return hipGetLastError();
 }
+template <int GL>
+static void launch_bars_gl(const float* spec, float* bars_out, size_t nrows, uint32_t n, uint32_t bars, uint32_t nsteps,
+                           const BarItem* items, const BarDesc* desc, const float* tap_w, hipStream_t st, int r) {
+    auto grid = [&](size_t trips) { const size_t cap = 256 * 8; return dim3((unsigned) (trips < cap ? (trips ? trips : 1) : cap)); };   // grid-stride beyond
+    if (nsteps == 2) hipLaunchKernelGGL((glv_bars_short_kernel<2, 2, GL>), grid((nrows + 1) / 2), dim3(256), 0, st, spec, bars_out, nrows, n, bars, items, desc, tap_w, r);
+    else if (nsteps == 4) hipLaunchKernelGGL((glv_bars_short_kernel<4, 2, GL>), grid((nrows + 1) / 2), dim3(256), 0, st, spec, bars_out, nrows, n, bars, items, desc, tap_w, r);
+    else hipLaunchKernelGGL((glv_bars_kernel<GL>), grid(nrows), dim3(256), 0, st, spec, bars_out, nrows, n, bars, nsteps, items, desc, tap_w, r);
+}
 hipError_t launch_bars(const float* spec, float* bars_out, size_t nrows, uint32_t n, uint32_t bars, uint32_t nsteps,
                        const BarItem* items, const BarDesc* desc, const float* tap_w, hipStream_t st, bool r16) {
     const int r = r16 ? 1 : 0;
-    auto grid = [&](size_t trips) { const size_t cap = 256 * 8; return dim3((unsigned) (trips < cap ? (trips ? trips : 1) : cap)); };   // grid-stride beyond
-    if (nsteps == 2) hipLaunchKernelGGL((glv_bars_short_kernel<2, 2>), grid((nrows + 1) / 2), dim3(256), 0, st, spec, bars_out, nrows, n, bars, items, desc, tap_w, r);
-    else if (nsteps == 4) hipLaunchKernelGGL((glv_bars_short_kernel<4, 2>), grid((nrows + 1) / 2), dim3(256), 0, st, spec, bars_out, nrows, n, bars, items, desc, tap_w, r);
-    else hipLaunchKernelGGL(glv_bars_kernel, grid(nrows), dim3(256), 0, st, spec, bars_out, nrows, n, bars, nsteps, items, desc, tap_w, r);
+    switch (bar_lanes_of(n)) {                                   // the work lists were made for 256 / bar_lanes_of(n) groups
+        case 2: launch_bars_gl<2>(spec, bars_out, nrows, n, bars, nsteps, items, desc, tap_w, st, r); break;
+        case 4: launch_bars_gl<4>(spec, bars_out, nrows, n, bars, nsteps, items, desc, tap_w, st, r); break;
+        default: launch_bars_gl<8>(spec, bars_out, nrows, n, bars, nsteps, items, desc, tap_w, st, r); break;
+    }
     return hipGetLastError();
 }
 

@@ -109,6 +109,7 @@ inline size_t make_smooth_bounds(int* smin, int* smax, size_t sz, float smooth_d
 //   m = (smax - smin)/2, rm = smin + m;  for s = smin; s <= smax; s += 1:  w = sinusoidal(clamp((m - |rm - s|)/m))
 //   sample bin int(round(s)).  Consecutive s round to consecutive bins, so a bar is a contiguous bin range.
 inline void make_bar_taps(std::vector<BarDesc>& desc, std::vector<float>& tap_w, uint32_t n, uint32_t bars, float smooth_factor, float phase = 0.0f) {
+    const uint32_t chunk = bar_chunk_of(n);
     auto scale = [](float u) { return -logf((-0.9f * u) + 1.0f) / 8.0f; };
     auto clamp01 = [](float x) { return x < 0.0f ? 0.0f : (x > 1.0f ? 1.0f : x); };
     desc.resize(bars);
@@ -136,25 +137,26 @@ inline void make_bar_taps(std::vector<BarDesc>& desc, std::vector<float>& tap_w,
         }
         d.count = (uint32_t) tap_w.size() - d.tap_offset;
         d.weight_sum = weight;
-        // zero-pad to whole chunks: the kernels load a chunk's 64 weights unconditionally
-        while ((tap_w.size() - d.tap_offset) % kBarChunk) tap_w.push_back(0.0f);
+        // zero-pad to whole chunks: the kernels load a chunk's weights unconditionally
+        while ((tap_w.size() - d.tap_offset) % chunk) tap_w.push_back(0.0f);
         desc[k] = d;
     }
 }
 
 // every chunk of every bar lies inside the row (the kernels read whole chunks: glv_frame.h bar_item_load)
 inline bool bar_chunks_in_row(const std::vector<BarDesc>& desc, uint32_t n) {
+    const uint32_t chunk = bar_chunk_of(n);
     for (const BarDesc& d : desc)
-        if ((uint64_t) d.first_bin + (d.count + kBarChunk - 1) / kBarChunk * kBarChunk > n) return false;
+        if ((uint64_t) d.first_bin + (d.count + chunk - 1) / chunk * chunk > n) return false;
     return true;
 }
 
-// GLV_OP_BARS work lists for `groups` 8-lane groups per row: every bar's chunks go, in order, to one
+// GLV_OP_BARS work lists for `groups` groups (of chunk / 8 lanes) per row: every bar's chunks go, in order, to one
 // group (longest bars first, each to the least loaded group); step s of group g is items[s * groups + g].
-// Lists are padded with all-zero-weight items (`zero_off`: kBarChunk zeros in tap_w; they restart the running
+// Lists are padded with all-zero-weight items (`zero_off`: `chunk` zeros in tap_w; they restart the running
 // total and store it -- an exact 0 -- to the dump slot `bars`) to a multiple of `batch` steps, plus one more
 // batch that the kernels' look-ahead reads.  Returns the step count.
-inline uint32_t make_bar_items(std::vector<BarItem>& items, const std::vector<BarDesc>& desc, uint32_t groups, uint32_t zero_off, uint32_t batch = kBarBatch) {
+inline uint32_t make_bar_items(std::vector<BarItem>& items, const std::vector<BarDesc>& desc, uint32_t groups, uint32_t zero_off, uint32_t chunk, uint32_t batch = kBarBatch) {
     std::vector<std::vector<BarItem>> list(groups);
     std::vector<uint32_t> order(desc.size());
     const uint32_t bars = (uint32_t) desc.size();
@@ -164,8 +166,8 @@ inline uint32_t make_bar_items(std::vector<BarItem>& items, const std::vector<Ba
         uint32_t g = 0;
         for (uint32_t c = 1; c < groups; ++c) if (list[c].size() < list[g].size()) g = c;
         const BarDesc& d = desc[k];
-        for (uint32_t i0 = 0; i0 < d.count; i0 += kBarChunk)
-            list[g].push_back(BarItem{(d.tap_offset + i0) * 4u, (d.first_bin + i0) * 4u, i0 + kBarChunk >= d.count ? k : bars, i0 == 0 ? 0.0f : 1.0f});
+        for (uint32_t i0 = 0; i0 < d.count; i0 += chunk)
+            list[g].push_back(BarItem{(d.tap_offset + i0) * 4u, (d.first_bin + i0) * 4u, i0 + chunk >= d.count ? k : bars, i0 == 0 ? 0.0f : 1.0f});
     }
     uint32_t nsteps = 0;
     for (auto& l : list) nsteps = l.size() > nsteps ? (uint32_t) l.size() : nsteps;

@@ -50,8 +50,8 @@ enum {
                                    smooth.glsl:13-64, radial/1.frag:58-70): emit `bars` values per
                                    channel instead of n bins; d_out is float [streams][2][bars].
                                    Inputs are clamped to [0, 1] (NaN -> 0) like the GL_R16 texels the shader
-                                   samples; the taps' products are summed in a documented, fixed order (64-tap
-                                   chunks, fused multiply-add chains: glava_amd/csrc/glv_frame.h "GLV_OP_BARS
+                                   samples; the taps' products are summed in a documented, fixed order (chunks
+                                   of 16 / 32 / 64 taps by n, fused multiply-add chains: glava_amd/csrc/glv_frame.h "GLV_OP_BARS
                                    arithmetic"; oracle/glv_oracle.c glvo_bars_chunked restates it) -- within
                                    2e-4 relative of the shader's tap-by-tap loop, identical bits on every
                                    device path.  A bar whose weights sum to 0 is 0 / 0 as in the shader */

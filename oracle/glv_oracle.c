@@ -416,17 +416,18 @@ void glvo_bars_at(const float* tex, size_t sz, float* bars_out, size_t bars, flo
 }
 
 /* GLV_OP_BARS as the library defines it: the taps and weights of glvo_bars (smooth.glsl:13-40), summed in the library's
- * documented order instead of tap by tap -- a bar's taps in chunks of 64; within a chunk eight partial sums of eight
- * consecutive taps each, every one the sum e + o of two fused-multiply-add chains from +0 (e over the even taps:
- * fma(x6, w6, fma(x4, w4, fma(x2, w2, fma(x0, w0, 0)))), o over the odd ones; zero weights past the bar's end), combined
- * pairwise (neighbours, pairs of pairs, the two quads); chunk totals added in chunk order; one division by the tap-order
- * sum of the weights.  glava_amd/csrc/glv_frame.h "GLV_OP_BARS arithmetic" is what this restates; the GPU
- * tests demand these bits, tests/test_glsl_twins.py bounds the distance to glvo_bars (summation rounding only). */
+ * documented order instead of tap by tap -- a bar's taps in chunks of C = 16 (sz <= 1024), 32 (sz = 2048) or 64 (sz >= 4096);
+ * within a chunk C / 8 partial sums of eight consecutive taps each, every one the sum e + o of two fused-multiply-add chains
+ * from +0 (e over the even taps: fma(x6, w6, fma(x4, w4, fma(x2, w2, fma(x0, w0, 0)))), o over the odd ones; zero weights past
+ * the bar's end), combined pairwise (neighbours, pairs of pairs, the two quads); chunk totals added in chunk order; one
+ * division by the tap-order sum of the weights.  glava_amd/csrc/glv_frame.h "GLV_OP_BARS arithmetic" is what this restates;
+ * the GPU tests demand these bits, tests/test_glsl_twins.py bounds the distance to glvo_bars (summation rounding only). */
 void glvo_bars_chunked_at(const float* tex, size_t sz, float* bars_out, size_t bars, float smooth_factor, float phase);
 void glvo_bars_chunked(const float* tex, size_t sz, float* bars_out, size_t bars, float smooth_factor) { glvo_bars_chunked_at(tex, sz, bars_out, bars, smooth_factor, 0.0F); }
 void glvo_bars_chunked_at(const float* tex, size_t sz, float* bars_out, size_t bars, float smooth_factor, float phase) {
     float* x = malloc(sizeof(float) * (sz + 64));
     float* w = malloc(sizeof(float) * (sz + 64));
+    const size_t C = sz <= 1024 ? 16 : (sz == 2048 ? 32 : 64);
     for (size_t k = 0; k < bars; ++k) {
         float idx = phase == 0.0F ? (float) k / (float) bars : ((float) k + phase) / (float) bars;
         float smin = glvo_scale_audio(glvo_clamp01(idx - smooth_factor)) * sz;
@@ -442,11 +443,11 @@ void glvo_bars_chunked_at(const float* tex, size_t sz, float* bars_out, size_t b
             x[cnt] = tv > 0 ? (tv < 1 ? tv : 1) : 0;          /* [0, 1] like a GL_R16 texel; NaN -> 0 (the library's clamp: v_pk_mul_f32 ... clamp) */
             ++cnt;
         }
-        for (size_t p = cnt; p < ((cnt + 63) / 64) * 64; ++p) { w[p] = 0; x[p] = 0; }
+        for (size_t p = cnt; p < ((cnt + C - 1) / C) * C; ++p) { w[p] = 0; x[p] = 0; }
         float total = 0;
-        for (size_t c0 = 0; c0 < cnt; c0 += 64) {
-            float lane[8];
-            for (int l = 0; l < 8; ++l) {
+        for (size_t c0 = 0; c0 < cnt; c0 += C) {
+            float lane[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
+            for (size_t l = 0; l < C / 8; ++l) {
                 float e = 0, o = 0;
                 for (int i = 0; i < 8; i += 2) {
                     e = fmaf(x[c0 + 8 * l + i], w[c0 + 8 * l + i], e);
@@ -454,7 +455,10 @@ void glvo_bars_chunked_at(const float* tex, size_t sz, float* bars_out, size_t b
                 }
                 lane[l] = e + o;
             }
-            total = total + (((lane[0] + lane[1]) + (lane[2] + lane[3])) + ((lane[4] + lane[5]) + (lane[6] + lane[7])));
+            float sum = lane[0] + lane[1];
+            if (C >= 32) sum = sum + (lane[2] + lane[3]);
+            if (C >= 64) sum = sum + ((lane[4] + lane[5]) + (lane[6] + lane[7]));
+            total = total + sum;
         }
         bars_out[k] = total / weight;
     }

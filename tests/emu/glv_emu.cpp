@@ -167,15 +167,15 @@ int glvemu_post_state(const float* in, float* out, float* grav, float* hist, int
 }  // extern "C"
 
 // ---- GLV_OP_BARS on the host: the same tables, work lists and chunk arithmetic as the kernels; the
-// 8-lane DPP sum (glv_frame.h group8_sum) is restated as the data movement its three steps perform.
+// DPP sum over a group of GL = 2 / 4 / 8 lanes (glv_frame.h group_sum) is restated as the data movement its steps perform.
 namespace {
-float group8_sum_host(const float (&lane)[8]) {
+float group_sum_host(const float* lane, int gl) {
     float v[8], t[8];
-    for (int i = 0; i < 8; ++i) v[i] = lane[i];
-    auto step = [&](auto src) { for (int i = 0; i < 8; ++i) t[i] = v[i] + v[src(i)]; for (int i = 0; i < 8; ++i) v[i] = t[i]; };
-    step([](int i) { return i ^ 1; });                       // quad_perm [1,0,3,2]
-    step([](int i) { return i ^ 2; });                       // quad_perm [2,3,0,1]
-    step([](int i) { return 7 - i; });                       // row_half_mirror
+    for (int i = 0; i < gl; ++i) v[i] = lane[i];
+    auto step = [&](auto src) { for (int i = 0; i < gl; ++i) t[i] = v[i] + v[src(i)]; for (int i = 0; i < gl; ++i) v[i] = t[i]; };
+    step([](int i) { return i ^ 1; });                                // quad_perm [1,0,3,2]
+    if (gl >= 4) step([](int i) { return i ^ 2; });                   // quad_perm [2,3,0,1]
+    if (gl >= 8) step([](int i) { return 7 - i; });                   // row_half_mirror
     return v[0];
 }
 }  // namespace
@@ -188,7 +188,7 @@ void glvemu_div_65535(int lo, int hi, float* out) {
 }
 
 extern "C" {
-// bars of `nrows` rows of n floats through work lists for `groups` 8-lane groups.  steps_out (may be NULL)
+// bars of `nrows` rows of n floats through work lists for `groups` groups of bar_lanes_of(n) lanes.  steps_out (may be NULL)
 // receives the step count; returns 0 on success.
 int glvemu_bars(const float* spec, size_t nrows, int n, int bars, float smooth_factor, int groups, float* out, unsigned* steps_out, float phase) {
     using namespace glv;
@@ -197,9 +197,11 @@ int glvemu_bars(const float* spec, size_t nrows, int n, int bars, float smooth_f
     make_bar_taps(desc, w, (uint32_t) n, (uint32_t) bars, smooth_factor, phase);
     if (!bar_chunks_in_row(desc, (uint32_t) n)) return 1;
     const uint32_t zero_off = (uint32_t) w.size();
-    w.resize(w.size() + kBarChunk, 0.0f);
+    const uint32_t chunk = bar_chunk_of((uint32_t) n);
+    const int gl = bar_lanes_of((uint32_t) n);
+    w.resize(w.size() + chunk, 0.0f);
     std::vector<BarItem> items;
-    const uint32_t nsteps = make_bar_items(items, desc, (uint32_t) groups, zero_off);
+    const uint32_t nsteps = make_bar_items(items, desc, (uint32_t) groups, zero_off, chunk);
     if (steps_out) *steps_out = nsteps;
     for (size_t row = 0; row < nrows; ++row) {
         const float* tex = spec + row * (size_t) n;
@@ -207,9 +209,9 @@ int glvemu_bars(const float* spec, size_t nrows, int n, int bars, float smooth_f
             float total = 0.0f;
             for (uint32_t s = 0; s < nsteps; ++s) {
                 const BarItem it = items[(size_t) s * groups + g];
-                float lane[kBarLanes];
-                for (int sub = 0; sub < kBarLanes; ++sub) lane[sub] = bar_item_lane_sum(bar_item_load(tex, w.data(), it, sub));
-                total = __builtin_fmaf(total, it.keep, group8_sum_host(lane));
+                float lane[8];
+                for (int sub = 0; sub < gl; ++sub) lane[sub] = bar_item_lane_sum(bar_item_load(tex, w.data(), it, sub));
+                total = __builtin_fmaf(total, it.keep, group_sum_host(lane, gl));
                 if (it.res != (uint32_t) bars) out[row * bars + it.res] = total / desc[it.res].weight_sum;
             }
         }
@@ -225,11 +227,12 @@ int glvemu_bar_items_check(int n, int bars, float smooth_factor, int groups) {
     std::vector<BarDesc> desc;
     std::vector<float> w;
     make_bar_taps(desc, w, (uint32_t) n, (uint32_t) bars, smooth_factor);
+    const uint32_t kBarChunk = bar_chunk_of((uint32_t) n);
     for (const BarDesc& d : desc) { if (d.count == 0 || d.first_bin + d.count > (uint32_t) n || d.tap_offset % kBarChunk) return 1; }
     const uint32_t zero_off = (uint32_t) w.size();
     w.resize(w.size() + kBarChunk, 0.0f);
     std::vector<BarItem> items;
-    const uint32_t nsteps = make_bar_items(items, desc, (uint32_t) groups, zero_off);
+    const uint32_t nsteps = make_bar_items(items, desc, (uint32_t) groups, zero_off, kBarChunk);
     if (nsteps % kBarBatch || items.size() != (size_t) (nsteps + kBarBatch) * groups) return 2;
     std::vector<int> owner(desc.size(), -1);
     std::vector<uint32_t> next_chunk(desc.size(), 0);

@@ -95,7 +95,7 @@ constexpr int kBarTaps = 8;            // consecutive taps per lane
 // with the transform size (80 bars: ~15 taps at n = 1024, ~29 at 2048, ~57 at 4096, ~230 at 16384), so small transforms take
 // small chunks -- 16 taps (2 lanes) up to n = 1024, 32 (4 lanes) at n = 2048, 64 (8 lanes) above: with 64-tap chunks a row of
 // n = 1024 was ten steps of eight groups at 23 % useful taps (fft -> gravity -> 80 bars 0.83 ms; with 16-tap chunks four steps
-// of 32 groups: ms).  The chunk size is part of the documented summation order (glvo_bars_chunked restates it).
+// of 32 groups: 0.73 ms).  The chunk size is part of the documented summation order (glvo_bars_chunked restates it).
 GLV_HD constexpr int bar_lanes_of(uint32_t n) { return n <= 1024u ? 2 : (n == 2048u ? 4 : 8); }
 GLV_HD constexpr uint32_t bar_chunk_of(uint32_t n) { return (uint32_t) (bar_lanes_of(n) * kBarTaps); }
 // Which window table an s16 kernel multiplies by: the float pairs (two packed instructions per complex point instead of six

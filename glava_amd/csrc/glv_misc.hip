@@ -305,7 +305,7 @@ __global__ void __launch_bounds__(256) glv_bars_kernel(const float* __restrict__
 // The same for short work lists (nsteps == NS: 80 bars of a row up to N=4096 are 2-4 steps of the 32 groups): the group's
 // items, the lane's weights and the weight sums do not depend on the row, so they are fetched ONCE per workgroup and stay in
 // registers; a row then costs one round trip (its taps: 2 NS 16-byte loads per lane) instead of a chain of three (item ->
-// weights / taps per batch), and RI rows are in flight per workgroup trip.  N=1024 x 262144 rows: 2.1 -> ms.
+// weights / taps per batch), and RI rows are in flight per workgroup trip.  N=1024 x 262144 rows: 2.1 -> 0.41 ms.
 template <int NS, int RI, int GL>
 __global__ void __launch_bounds__(256) glv_bars_short_kernel(const float* __restrict__ spec, float* __restrict__ bars_out,
                                                              size_t nrows, uint32_t n, uint32_t bars,

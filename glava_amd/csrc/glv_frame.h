@@ -946,7 +946,7 @@ struct Frame {
         } else {
             // gravity without average: ONE state value per point, so all of the row's state can be requested
             // up front (2E registers) and its latency hides behind the log/tilt arithmetic -- in blocks, as below,
-            // every block's loads were a separate exposed round trip (N=4096 fft+gravity: 0.72 -> ms)
+            // every block's loads were a separate exposed round trip
             if (!(a.ops & OP_AVERAGE) && (a.ops & OP_GRAVITY) && E <= 32) {
                 const float* gs = a.grav + row * (size_t) N;
                 float* gw = a.grav_w + row * (size_t) N;

@@ -24,7 +24,7 @@ ARCH = "gfx950"
 HIPFLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC",
             "-fno-fast-math", "-Wall", "-Wno-unused-function"]
 SIZES = (7, 8, 9, 10, 11, 12, 13, 14)
-HEADERS = ["glv_core.h", "glv_frame.h", "glv_kernel_tmpl.h", "glv_launch.h", "glv_tables.h",
+HEADERS = ["glv_core.h", "glv_frame.h", "glv_kernel_tmpl.h", "glv_launch.h", "glv_tables.h", "glv_winsplit.h",
            os.path.join("..", "..", "include", "glv_spectrum.h")]
 
 

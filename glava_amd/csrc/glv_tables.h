@@ -28,18 +28,6 @@ inline void make_window(double* w, size_t n) {
         w[i] = 0.53836 - (0.46164 * cos(kTwoPi * (double) i / (double) n - 1));
 }
 
-// The s16 kernels' window layout (glv_core.h WinSplit: per complex point {hi(2c), hi(2c+1), lo(2c), lo(2c+1)}) from the plain
-// split hi = (float) w, lo = (float) (w - hi) -- exact for all but a handful of positions.  The product library does not use
-// this: its table is searched and proven on the device (glv_misc.hip glv_window_split_kernel); the knob-sweep harness
-// (glv_tune.hip, timing only) does.
-inline void make_window_split_plain(const double* w, size_t n, float* out) {
-    for (size_t i = 0; i < n; ++i) {
-        const float hi = (float) w[i];
-        out[(i >> 1) * 4 + (i & 1)] = hi;
-        out[(i >> 1) * 4 + 2 + (i & 1)] = (float) (w[i] - (double) hi);
-    }
-}
-
 // Average weights by AGE f (0 = oldest frame ... F-1 = newest), as apply_state consumes them.
 //   kind 0, CPU twin (render.c:751-766): window_frame(f, avg_frames - 1) with the macro's unparenthesised
 //           `sz`: 0.6 - 0.4*cos(TWOPI*f/F - 1); f = 0 is the oldest frame.

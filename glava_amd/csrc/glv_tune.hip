@@ -5,6 +5,7 @@
 #include <vector>
 
 #include "glv_kernel_tmpl.h"
+#include "glv_winsplit.h"
 #include "glv_tables.h"
 
 #ifndef GLV_TUNE_LOG_NN
@@ -108,10 +109,14 @@ int glv_tune_run3(int i, const void* d_pcm, float* d_out, unsigned units, int lo
         if (hipMalloc(&d_win, sizeof(double) * N) != hipSuccess) return -1;
         (void) hipMemcpy(d_tw, tw.data(), sizeof(cf) * NN, hipMemcpyHostToDevice);
         (void) hipMemcpy(d_win, win.data(), sizeof(double) * N, hipMemcpyHostToDevice);
-        std::vector<float> split(2 * (size_t) N);                 // the s16 kernels read the window as float pairs (glv_core.h WinSplit)
-        make_window_split_plain(win.data(), N, split.data());
+        // the s16 kernels read the window as float pairs (glv_core.h WinSplit): the same device-side search as the product's
         if (hipMalloc(&d_win_split, sizeof(float) * 2 * N) != hipSuccess) return -1;
-        (void) hipMemcpy(d_win_split, split.data(), sizeof(float) * 2 * N, hipMemcpyHostToDevice);
+        int* d_fs = nullptr;
+        if (hipMalloc(&d_fs, 2 * sizeof(int)) != hipSuccess) return -1;
+        (void) hipMemset(d_fs, 0, 2 * sizeof(int));
+        (void) launch_window_split_impl(d_win, d_win_split, N, d_fs, nullptr);
+        (void) hipDeviceSynchronize();
+        (void) hipFree(d_fs);
         LogEntry lt[kLogTabSize];
         make_log_table(lt);
         if (hipMalloc(&d_log, sizeof(lt)) != hipSuccess) return -1;

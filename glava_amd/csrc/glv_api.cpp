@@ -183,7 +183,7 @@ struct Tables {
             if (fs[0]) return fail(GLV_ERR_HIP, "window table of n=%u has no exact float-pair form on this host's cos()", n);
             win_shifted = fs[1];
         }
-        glv::LogEntry lt[glv::kLogTabSize];
+        glv::LogEntry lt[glv::kLogTabMaxSize];
         glv::make_log_table(lt);
         HIP_TRY(hipMalloc(&d_log, sizeof(lt)));
         HIP_TRY(hipMemcpy(d_log, lt, sizeof(lt), hipMemcpyHostToDevice));

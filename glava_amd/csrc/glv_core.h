@@ -343,7 +343,7 @@ GLV_HD float gravity(float b, float applied, float g) {
 //   mode 2  audit: the device libm's fp64 log and a true fp64 division, the reference's
 //           expression verbatim (slow; for cross-checking mode 0)
 struct LogEntry;
-template <int LOG_MODE> GLV_HD float log_third(float y, const LogEntry* tab);
+template <int LOG_MODE> GLV_HD float log_third(float y, const LogEntry* tab, int bits);
 
 #if defined(__HIP_DEVICE_COMPILE__)
 #define GLV_LOG2F(x) __builtin_amdgcn_logf(x)
@@ -351,10 +351,18 @@ template <int LOG_MODE> GLV_HD float log_third(float y, const LogEntry* tab);
 #define GLV_LOG2F(x) ::log2f(x)
 #endif
 
-// log table: for j = 0..255, c_j = 1 + j/256 (the value of the top eight mantissa bits),
+// log table: for j = 0 .. 2^B - 1, c_j = 1 + j / 2^B (the value of the top B mantissa bits),
 // tab[j] = { 2^-23/c_j, log(c_j)/3 } rounded to double.  Generated on the host by glv::make_log_table
 // (glv_tables.h); the kernel stages it into LDS (random 16-byte gathers are what LDS is good at).
-constexpr int kLogTabSize = 256;
+// B = 9 (8 KiB) for N <= 8192 since round 3: r < 2^-9 lets the polynomial below end one term earlier (one v_fma_f64 per value less,
+// log_mode 0 77.7 -> 78.8 M frames/s at N=4096) and still gives the reference's float for EVERY float in [1, 2^14)
+// (tests/test_gpu_parity.py test_magnitude_stage_every_float: 0 of 117 440 512 differ); B = 10 would not leave two
+// N=4096 workgroups room in a CU's LDS.
+// The table in HBM always has 2^9 entries; a kernel stages the 2^B it uses (every 2^(9-B)-th entry) into LDS, B by transform
+// size: two N=16384 workgroups per CU have no 4 KiB to spare (with B = 9 only one fits: 0.80 -> 1.04 ms), so N >= 16384 keeps B = 8.
+constexpr int kLogTabMaxBits = 9;
+constexpr int kLogTabMaxSize = 1 << kLogTabMaxBits;
+GLV_HD constexpr int log_tab_bits_of(int log_nn) { return log_nn >= 13 ? 8 : 9; }
 struct alignas(16) LogEntry { double inv_c, log_c3; };
 
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -370,22 +378,21 @@ __device__ __forceinline__ double fma_sc(double a, double b, double c_uniform) {
 #define GLV_FMA_SC(a, b, c) __builtin_fma(a, b, c)
 #endif
 
-// y >= 1 finite.  y = 2^e * m, m in [1,2); c = m truncated to 8 mantissa bits; r = (m - c)/c in
-// [0, 2^-8).  log(y)/3 = e*(ln2/3) + log(c)/3 + r*P(r),
-//   P(r) = (1 - r/2 + r^2/3 - r^3/4 + r^4/5 - r^5/6)/3      (truncation r^6/7 < 2^-50 relative)
+// y >= 1 finite.  y = 2^e * m, m in [1,2); c = m truncated to B = `bits` mantissa bits; r = (m - c)/c in
+// [0, 2^-B).  log(y)/3 = e*(ln2/3) + log(c)/3 + r*P(r),
+//   P(r) = (1 - r/2 + r^2/3 - r^3/4 + r^4/5 [- r^5/6 when B = 8])/3      (truncation r^5/6 < 2^-47 relative at B = 9)
 // All polynomial arithmetic is ours (fused): only the final float matters, and it equals the
-// reference's (float)(log(y)/3) unless the exact value lies within ~2^-49 (relative) of a float
-// rounding boundary.
-GLV_HD float log_third_table(float y, const LogEntry* tab) {
+// reference's (float)(log(y)/3) for every float the stage can see (exhaustive test, above).
+GLV_HD float log_third_table(float y, const LogEntry* tab, int bits) {      // tab: 2^bits entries (bits is a compile-time constant at every call site)
     const uint32_t u = __builtin_bit_cast(uint32_t, y);
     const int e = (int) (u >> 23) - 127;
-    const LogEntry t = ld<LogEntry>(tab, (u >> 11) & 0xff0u);                       // j * 16 bytes
-    // r = (m - c) / c with m - c = k * 2^-23, k = the low 15 mantissa bits: the table carries 2^-23 / c_j, so r is one
+    const LogEntry t = ld<LogEntry>(tab, (u >> (19 - bits)) & (uint32_t) (((1 << bits) - 1) << 4));   // j * 16 bytes
+    // r = (m - c) / c with m - c = k * 2^-23, k = the low 23 - B mantissa bits: the table carries 2^-23 / c_j, so r is one
     // exact integer conversion and one product (scaling by a power of two commutes with the rounding: the same bits
     // as (double) (m - c) * (1 / c_j), two instructions fewer)
-    const double r = (double) (u & 0x7fffu) * t.inv_c;
-    double p = -1.0 / 18.0;
-    p = GLV_FMA_SC(p, r, 1.0 / 15.0);
+    const double r = (double) (u & ((1u << (23 - bits)) - 1u)) * t.inv_c;
+    double p = 1.0 / 15.0;
+    if (bits < 9) p = GLV_FMA_SC(-1.0 / 18.0, r, 1.0 / 15.0);
     p = GLV_FMA_SC(p, r, -1.0 / 12.0);
     p = GLV_FMA_SC(p, r, 1.0 / 9.0);
     p = GLV_FMA_SC(p, r, -1.0 / 6.0);
@@ -393,20 +400,19 @@ GLV_HD float log_third_table(float y, const LogEntry* tab) {
     const double hi = __builtin_fma((double) e, 0.6931471805599453094 / 3.0, t.log_c3);
     return (float) __builtin_fma(r, p, hi);
 }
-
-template <> GLV_HD float log_third<0>(float y, const LogEntry* tab) { return log_third_table(y, tab); }
+template <> GLV_HD float log_third<0>(float y, const LogEntry* tab, int bits) { return log_third_table(y, tab, bits); }
 // y = +Inf or NaN (f32 input rows holding non-finite samples): the reference's (float)(log(y) / 3) is y itself (Inf) or NaN.
 // The hardware log of mode 1 and libm's of mode 2 do that on their own; the table-driven log of mode 0 decodes the exponent
 // field and needs the select.  s16 input cannot produce such values (|FFT output| <= n / 2), its kernels skip it.
 template <int LOG_MODE, bool NONFINITE>
-GLV_HD float log_third_nf(float y, const LogEntry* tab) {
-    const float r = log_third<LOG_MODE>(y, tab);
+GLV_HD float log_third_nf(float y, const LogEntry* tab, int bits = kLogTabMaxBits) {
+    const float r = log_third<LOG_MODE>(y, tab, bits);
     if constexpr (LOG_MODE == 0 && NONFINITE) return __builtin_bit_cast(uint32_t, y) >= 0x7f800000u ? y : r;
     else return r;
 }
 // mode 1 returns log2(y); the ln2/3 factor is folded into the tilt table the kernel multiplies with
 // (glv_tables.h make_tilt with fold_ln2_3), one multiply less per value
-template <> GLV_HD float log_third<1>(float y, const LogEntry*) { return GLV_LOG2F(y); }
-template <> GLV_HD float log_third<2>(float y, const LogEntry*) { return (float) (::log((double) y) / 3); }
+template <> GLV_HD float log_third<1>(float y, const LogEntry*, int) { return GLV_LOG2F(y); }
+template <> GLV_HD float log_third<2>(float y, const LogEntry*, int) { return (float) (::log((double) y) / 3); }
 
 }  // namespace glv

@@ -50,7 +50,7 @@ struct FrameArgs {
     const cf* tw;          // nn entries (entry 0 unused), layout glv::tw_offset
     const double* win;     // n window values (render.c:660 as expanded at :794)
     const void* win_split; // the same as float pairs for s16 samples (glv_core.h WinSplit [n/2]); which one a kernel reads: win_split_of
-    const LogEntry* logtab; // 64 entries, log_mode 0 (glv_core.h)
+    const LogEntry* logtab; // kLogTabMaxSize entries, log_mode 0 (glv_core.h)
     const float* tilt;     // n tilt factors max(n/N*fft_scale + (1 - fft_cutoff), 1) (render.c:845), host-generated
     uint32_t units;        // channel rows to process (2 per stereo frame)
     uint32_t ops;
@@ -880,8 +880,8 @@ struct Frame {
                     tl.x = tilt_factor<LOG_MODE == 1>(2 * q, a.inv_n, a.fft_scale, a.one_minus_cutoff);
                     tl.y = tilt_factor<LOG_MODE == 1>(2 * q + 1, a.inv_n, a.fft_scale, a.one_minus_cutoff);
                 } else tl = ld<cf>(a.tilt, (uint32_t) q * 8u);
-                val.x = log_third_nf<LOG_MODE, NONFINITE>(y0, logtab) * tl.x;
-                val.y = log_third_nf<LOG_MODE, NONFINITE>(y1, logtab) * tl.y;
+                val.x = log_third_nf<LOG_MODE, NONFINITE>(y0, logtab, log_tab_bits_of(LOG_NN)) * tl.x;
+                val.y = log_third_nf<LOG_MODE, NONFINITE>(y1, logtab, log_tab_bits_of(LOG_NN)) * tl.y;
             }
 #endif
             return val;

@@ -225,7 +225,7 @@ struct Body {
 template <int LOG_NN, int LOG_E, int SLOTS, int NBUF, bool WINLDS, int TWREG = 0>
 constexpr size_t frame_lds_bytes() {
     return (size_t) SLOTS * (NBUF == 0 ? sizeof(float) : NBUF * sizeof(cf)) * Frame<LOG_NN, LOG_E>::XREGION + (WINLDS ? (size_t) Frame<LOG_NN, LOG_E>::N * sizeof(double) : 0)
-           + kLogTabSize * sizeof(LogEntry) + (size_t) Body<LOG_NN, LOG_E, NBUF, TWREG>::LDS_ENTRIES * sizeof(cf) + (size_t) 16 * SLOTS;
+           + ((size_t) sizeof(LogEntry) << log_tab_bits_of(LOG_NN)) + (size_t) Body<LOG_NN, LOG_E, NBUF, TWREG>::LDS_ENTRIES * sizeof(cf) + (size_t) 16 * SLOTS;
 }
 
 // wave-uniform value -> SGPR (valid when all lanes of the wave hold the same value)
@@ -270,12 +270,13 @@ glv_frame_kernel(const FrameArgs a) {
         win = lwin;
     }
 
-    // log_mode 0: the 256-entry (1/c, log(c)/3) table is gathered per value; LDS serves such random
+    // log_mode 0: the 256- or 512-entry (1/c, log(c)/3) table is gathered per value; LDS serves such random
     // 16-byte reads without touching the vector-memory path the PCM/spectrum streams use.
     const LogEntry* logtab = a.logtab;
     if constexpr (LOG_MODE == 0) {
         char* llog = smem + (size_t) SLOTS * NREG * XBYTES + (WINLDS ? (size_t) N * sizeof(double) : 0);
-        for (int i = threadIdx.x; i < kLogTabSize; i += T * SLOTS) st<d2>(llog, (uint32_t) i * 16u, ld<d2>(a.logtab, (uint32_t) i * 16u));
+        constexpr int LB = log_tab_bits_of(LOG_NN);             // entries this size uses: every 2^(9 - LB)-th of the table in HBM
+        for (int i = threadIdx.x; i < (1 << LB); i += T * SLOTS) st<d2>(llog, (uint32_t) i * 16u, ld<d2>(a.logtab, (uint32_t) (i << (kLogTabMaxBits - LB)) * 16u));
         __syncthreads();
         logtab = reinterpret_cast<const LogEntry*>(llog);
     }
@@ -283,7 +284,7 @@ glv_frame_kernel(const FrameArgs a) {
     // TWREG >= 2: the twiddle table range of the middle passes is staged into LDS once per workgroup
     const cf* lds_tw = nullptr;
     if constexpr (BD::TW_LDS_MODE) {
-        char* ltw = smem + (size_t) SLOTS * NREG * XBYTES + (WINLDS ? (size_t) N * sizeof(double) : 0) + kLogTabSize * sizeof(LogEntry);
+        char* ltw = smem + (size_t) SLOTS * NREG * XBYTES + (WINLDS ? (size_t) N * sizeof(double) : 0) + ((size_t) sizeof(LogEntry) << log_tab_bits_of(LOG_NN));
         for (int i = threadIdx.x; i < BD::LDS_ENTRIES; i += T * SLOTS) st<cf>(ltw, (uint32_t) i * 8u, ld<cf>(a.tw, (uint32_t) (BD::LDS_BIAS + i) * 8u));
         __syncthreads();
         lds_tw = reinterpret_cast<const cf*>(ltw);

@@ -25,8 +25,8 @@ __global__ void __launch_bounds__(256) glv_post_kernel(const FrameArgs a, const 
             const float y0 = __builtin_fabsf(val.x) + 1.0f, y1 = __builtin_fabsf(val.y) + 1.0f;
             const cf tl = ld<cf>(a.tilt, off);
             if (a.log_mode == 0)      { val.x = log_third_nf<0, true>(y0, a.logtab) * tl.x; val.y = log_third_nf<0, true>(y1, a.logtab) * tl.y; }
-            else if (a.log_mode == 1) { val.x = log_third<1>(y0, a.logtab) * tl.x; val.y = log_third<1>(y1, a.logtab) * tl.y; }
-            else                      { val.x = log_third<2>(y0, a.logtab) * tl.x; val.y = log_third<2>(y1, a.logtab) * tl.y; }
+            else if (a.log_mode == 1) { val.x = log_third<1>(y0, a.logtab, kLogTabMaxBits) * tl.x; val.y = log_third<1>(y1, a.logtab, kLogTabMaxBits) * tl.y; }
+            else                      { val.x = log_third<2>(y0, a.logtab, kLogTabMaxBits) * tl.x; val.y = log_third<2>(y1, a.logtab, kLogTabMaxBits) * tl.y; }
         }
         if (a.ops & OP_WRANGE) {                                                  // render.c:777-779
             const float p = val.x + 1.0f, q = val.y + 1.0f;

@@ -166,10 +166,10 @@ inline uint32_t make_bar_items(std::vector<BarItem>& items, const std::vector<Ba
     return nsteps;
 }
 
-// log_mode 0 table (glv_core.h log_third_table): c_j = 1 + j/256, { 2^-23 / c_j, log(c_j)/3 }.
-inline void make_log_table(LogEntry* t) {
-    for (int j = 0; j < kLogTabSize; ++j) {
-        const double c = 1.0 + (double) j / (double) kLogTabSize;
+// log_mode 0 table (glv_core.h log_third_table): c_j = 1 + j / 2^bits, { 2^-23 / c_j, log(c_j)/3 }.
+inline void make_log_table(LogEntry* t, int bits = kLogTabMaxBits) {
+    for (int j = 0; j < (1 << bits); ++j) {
+        const double c = 1.0 + (double) j / (double) (1 << bits);
         t[j].inv_c = ldexp(1.0 / c, -23);      // exact scaling: r = k * inv_c for the integer k = (m - c) * 2^23
         t[j].log_c3 = log(c) / 3.0;
     }

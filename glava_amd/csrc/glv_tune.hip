@@ -117,7 +117,7 @@ int glv_tune_run3(int i, const void* d_pcm, float* d_out, unsigned units, int lo
         (void) launch_window_split_impl(d_win, d_win_split, N, d_fs, nullptr);
         (void) hipDeviceSynchronize();
         (void) hipFree(d_fs);
-        LogEntry lt[kLogTabSize];
+        LogEntry lt[kLogTabMaxSize];
         make_log_table(lt);
         if (hipMalloc(&d_log, sizeof(lt)) != hipSuccess) return -1;
         (void) hipMemcpy(d_log, lt, sizeof(lt), hipMemcpyHostToDevice);

@@ -126,8 +126,8 @@ int glvemu_process(int n, int in_mode, const void* in, float* out, float* grav, 
     std::vector<double> win(n);
     make_twiddles(tw.data(), nn);
     make_window(win.data(), n);
-    LogEntry lt[kLogTabSize];
-    make_log_table(lt);
+    LogEntry lt[kLogTabMaxSize];
+    make_log_table(lt, log_tab_bits_of(log_nn));         // the emulated kernel reads the table it would have staged into LDS
     std::vector<float> tl(n);
     make_tilt(tl.data(), n, fft_scale, fft_cutoff, log_mode == 1);
     FrameArgs a;

@@ -400,6 +400,13 @@ def main() -> None:
             line["r16_texels"] = r16
         if configs is not None:
             line["configs"] = configs
+        try:
+            mism, shifted = batch.window_selftest()
+            line["window_selftest"] = {"mismatches": mism, "shifted_positions": shifted,
+                                       "note": f"every (s16 sample value, window position) pair of N={n}: the kernels' float-pair window product "
+                                               "against the reference's float x double -> double -> float product, on the device, outside the timed region"}
+        except Exception as ex:                    # a diagnostic, never a reason to lose the line
+            line["window_selftest"] = {"error": str(ex)}
         if world == 1 and not a.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(n, a.cpu_seconds)
         else:

@@ -87,7 +87,22 @@ def cpu_baseline(n: int, seconds: float = 10.0) -> dict | None:
     one_frames, one_dt, _, _ = timed(1, min(3.0, seconds))
     tot, dt, lo, hi = timed(cores, seconds)
     one = one_frames / one_dt
-    return {"value": tot / dt, "unit": "frames/s", "cores": cores, "kind": "reference" if use_ref else "port",
+    # BASELINE configs[0]: the reference's own CPU path as GLava runs it -- one stream, N=1024, the bars module's chain
+    # (window, fft, gravity, avg: transform_fft -> transform_gravity -> transform_average, F = 5 windowed) on ONE core
+    c0 = None
+    if use_ref:
+        try:
+            n0 = 1024
+            p0 = Ref.params(avg_frames=5, avg_window=True)
+            pcm0 = np.random.default_rng(1).integers(-32768, 32768, 256 * 2 * n0, dtype=np.int16)
+            done0 = (C.c_ulonglong * 1)()
+            dt0 = Ref.lib().glvref_bench_mt(C.byref(p0), pcm0, 256, n0, 1, 1, min(2.0, seconds), done0)
+            c0 = {"value": done0[0] / dt0, "unit": "frames/s", "cores": 1, "kind": "reference",
+                  "sample": f"BASELINE configs[0]: {done0[0]} stereo frames N={n0} through the reference's transform_fft -> transform_gravity -> "
+                            f"transform_average (F=5, windowed) + fifo.c unpack on 1 native thread in {dt0:.1f} s; GLava needs 86 updates/s"}
+        except Exception as e:  # pragma: no cover
+            c0 = {"error": str(e)}
+    return {"value": tot / dt, "configs[0]": c0, "unit": "frames/s", "cores": cores, "kind": "reference" if use_ref else "port",
             "one_core": one, "per_core": tot / dt / cores, "parallel_efficiency": (tot / dt) / (one * cores),
             "host_logical_cpus": os.cpu_count(), "cores_note": note,
             "sample": f"{tot} stereo frames N={n} (uniform s16 noise, one {frames_per_call}-frame buffer looped) on {cores} native "
@@ -133,7 +148,7 @@ def extra_configs(G, torch, device, a, peak_gbs):
     steps, warm = a.configs_steps, 2
 
     def run(batch, call):
-        t_end = time.perf_counter() + 0.15
+        t_end = time.perf_counter() + a.spinup_s                      # the headline's spin-up (0.15 s was thinner)
         while time.perf_counter() < t_end:
             for _ in range(4): call()
             torch.cuda.synchronize()
@@ -177,10 +192,57 @@ def extra_configs(G, torch, device, a, peak_gbs):
     c2 = entry(f"BASELINE configs[2]: N={n} x {s} streams, fft + gravity + radial bin averaging to {bars} bars/channel (fused: bars from the row in LDS), "
                f"20 N + 640 B/frame (SURVEY 8d row D)", s, (20 * n + 8 * bars) * s, dt, kms)
     b.reset()
+    gois = gops | G.OP_OUTPUT_IS_STATE
+    dt, kms = run(b, lambda: b.process_s16(pcm, o, gois, st0))
+    c2["spectra_out"] = entry("same size, fft + gravity with the full spectra as output == state (GLV_OP_OUTPUT_IS_STATE), 20 N B/frame (SURVEY 8d row B)", s, b.algorithmic_bytes(gois), dt, kms)
+    b.reset()
     dt, kms = run(b, lambda: b.process_s16(pcm, o, gops, st0))
-    c2["spectra_out"] = entry("same size, fft + gravity with the full spectra as output == state, 20 N B/frame (SURVEY 8d row B)", s, b.algorithmic_bytes(gops), dt, kms)
+    c2["spectra_out_private_state"] = entry("same chain with the batch-owned state (the default): spectra written twice, 28 N B/frame", s, b.algorithmic_bytes(gops), dt, kms)
     out["configs[2]"] = c2
     b.close(); del pcm, o, ob
+    torch.cuda.empty_cache()
+    # --- the pipeline GLava ships (rc.glsl:211 setaccelfft, render.c:2188-2303): GL_R16 upload, GL_MAX + gravity pass, ring, average
+    # pass -- one launch on 16-bit state (gl_storage 1): N=4096 x 64K streams, F=5
+    n, s, F, bars = a.n, a.streams, 5, 80
+    pcm = torch.randint(-32768, 32768, (s, n, 2), dtype=torch.int16, device="cuda", generator=gen)
+    q = torch.empty((s, 2, n), dtype=torch.int16, device="cuda")
+    qb = torch.empty((s, 2, bars), dtype=torch.int16, device="cuda")
+    glops = G.OP_FFT | G.OP_GRAVITY | G.OP_AVERAGE
+    pg = G.Params(n=n, log_mode=a.log_mode, avg_frames=F, avg_window_kind=1, gl_storage=1, bars=bars)
+    b = G.Batch(pg, s, G.OP_GRAVITY | G.OP_AVERAGE, device=device)
+    dt, kms = run(b, lambda: b.process_s16(pcm, q, glops | G.OP_R16, st0))
+    gl = entry(f"GLava's shipped pipeline (setaccelfft): N={n} x {s} streams, s16 PCM -> upload quantisation -> GL_MAX + gravity pass -> ring -> "
+               f"average pass (F={F}, Hamming newest-first) -> `av` GL_R16 texels, ONE launch on uint16 state: 4N + 16N + 4N + 4N = 28 N B/frame",
+               s, b.algorithmic_bytes(glops | G.OP_R16), dt, kms)
+    gl["launches_per_step"] = b.last_launches()
+    b.reset()
+    dt, kms = run(b, lambda: b.process_s16(pcm, qb, glops | G.OP_BARS | G.OP_R16, st0))
+    gl["bars_out"] = entry(f"same chain with the {bars} bars of the bars / radial modules computed in the kernel (from the finished row in LDS) and "
+                           f"stored as GL_R16 texels: 24 N + {4 * bars} B/frame", s, b.algorithmic_bytes(glops | G.OP_BARS | G.OP_R16), dt, kms)
+    gl["bars_out"]["launches_per_step"] = b.last_launches()
+    b.close()
+    # the pass-by-pass form of the same chain (the checker: f32 intermediates, three launches), for the record
+    s2 = s // 4
+    b2 = G.Batch(G.Params(n=n, log_mode=a.log_mode, avg_frames=F, avg_window_kind=1, gl_storage=2), s2, G.OP_GRAVITY | G.OP_AVERAGE, device=device)
+    dt, kms = run(b2, lambda: b2.process_s16(pcm, q, glops | G.OP_R16, st0))
+    gl["pass_by_pass"] = entry(f"the same values pass by pass (gl_storage 2, the checker: transform -> f32 spectra -> gravity / average kernel on f32 state -> "
+                               f"texels), {s2} streams; roofline_frac is against ITS OWN 64 N B/frame, frac_of_28N against the fused form's bytes", s2,
+                               b2.algorithmic_bytes(glops | G.OP_R16), dt, kms)
+    gl["pass_by_pass"]["launches_per_step"] = b2.last_launches()
+    gl["pass_by_pass"]["frac_of_28N"] = 28 * n * s2 / (gl["pass_by_pass"]["avg_kernel_ms"] * 1e-3) / 1e9 / peak_gbs
+    b2.close()
+    out["gl_default"] = gl
+    del q, qb
+    # --- f1: the FIFO ring mode (fifo.c:91-112 on the device): append 256 new frames per stream, transform the whole window
+    nf = 256
+    new = torch.randint(-32768, 32768, (s, nf, 2), dtype=torch.int16, device="cuda", generator=gen)
+    o = torch.empty((s, 2, n), dtype=torch.float32, device="cuda")
+    b = G.Batch(G.Params(n=n, log_mode=a.log_mode), s, G.OP_FFT | G.OP_RING_S16, device=device)
+    dt, kms = run(b, lambda: b.ring_update_s16(new, nf, o, G.OP_FFT, st0))
+    out["ring_update"] = entry(f"SURVEY 8f1: glv_batch_ring_update_s16, N={n} x {s} streams, {nf} new frames appended per stream and update (a strided "
+                               f"device-to-device copy), then window+FFT+magnitude of the whole ring read with a rotation; bytes: the transform's 12 N "
+                               f"(the append moves 8 * {nf} B more); avg_kernel_ms covers copy + kernel", s, b.algorithmic_bytes(G.OP_FFT), dt, kms)
+    b.close(); del pcm, new, o
     torch.cuda.empty_cache()
     # --- configs[4]
     classes = []
@@ -222,7 +284,10 @@ def main() -> None:
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-alt", action="store_true", help="skip the secondary fast-log measurement")
     ap.add_argument("--no-configs", action="store_true", help="skip the `configs` key (BASELINE configs[2], configs[4], N=8192 / 16384)")
-    ap.add_argument("--configs-steps", type=int, default=10, help="timed steps per entry of the `configs` key")
+    ap.add_argument("--configs-steps", type=int, default=20, help="timed steps per entry of the `configs` key (same spin-up as the headline)")
+    ap.add_argument("--sustained-s", type=float, default=2.0, help="seconds of back-to-back headline launches behind the `sustained` key (0 = skip)")
+    ap.add_argument("--check-dump", default="", help="test hook: every rank saves the PCM of its FIRST stream and the raw FFT the library "
+                                                     "computes for it to <path>.rank<r>.npz (global stream index inside); tests/ compare with the oracle")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
     ap.add_argument("--spinup-s", type=float, default=0.3, help="untimed clock spin-up before the W warm-up steps")
     a = ap.parse_args()
@@ -276,7 +341,7 @@ def main() -> None:
     if a.log_mode in (0, 1) and not a.no_alt:  # secondary measurement: the other log mode of the same pass
         alt_batch = G.Batch(G.Params(n=n, log_mode=alt_mode), streams, ops, device=device)
         if a.grid: alt_batch.set_grid(a.grid)
-    gen = torch.Generator(device="cuda"); gen.manual_seed(12345 + rank)
+    gen = torch.Generator(device="cuda"); gen.manual_seed(12345 + lo)     # the PCM of a shard is a function of its first global stream
     d_pcm = torch.randint(-32768, 32768, (streams, n, 2), dtype=torch.int16, device="cuda", generator=gen)
     d_out = torch.empty((streams, 2, n), dtype=torch.float32, device="cuda")
     stream = torch.cuda.current_stream().cuda_stream
@@ -313,6 +378,32 @@ def main() -> None:
         return dt, kms, nl
 
     elapsed, kernel_ms, launches = timed(batch)
+    # the same launch back to back for --sustained-s seconds (N=1 only): the headline is a 13 ms burst after 0.3 s of spin-up, this is
+    # what the part holds at its power limit (say which one a claim is made on)
+    sustained = None
+    if world == 1 and a.sustained_s > 0:
+        batch.timing_begin()
+        t0 = time.perf_counter(); nl = 0
+        while time.perf_counter() - t0 < a.sustained_s:
+            for _ in range(128):
+                batch.process_s16(d_pcm, d_out, ops, stream)
+            nl += 128
+            torch.cuda.synchronize()
+        s_dt = time.perf_counter() - t0
+        s_kms, s_nl = batch.timing_end()
+        s_k = s_kms / max(s_nl, 1) * 1e-3
+        sustained = {"note": f"{s_nl} back-to-back launches of the headline pass over {s_dt:.2f} s (a synchronize every 128), HIP-event kernel time",
+                     "seconds": s_dt, "launches": s_nl, "value": streams * nl / s_dt, "unit": "frames/s", "avg_kernel_ms": s_k * 1e3,
+                     "roofline_frac": (batch.algorithmic_bytes(ops) / s_k / 1e9) / HBM_PEAK_GBS if s_k > 0 else 0.0}
+    if a.check_dump:
+        import numpy as np
+        cb_ = G.Batch(G.Params(n=n), 1, G.OP_FFT, device=device)
+        raw1 = torch.empty((2, n), dtype=torch.float32, device="cuda")
+        cb_.process_s16(d_pcm[:1].contiguous(), raw1, G.OP_FFT | G.OP_RAW, stream)
+        torch.cuda.synchronize()
+        np.savez(f"{a.check_dump}.rank{rank}.npz", pcm=d_pcm[0].cpu().numpy(), raw=raw1.cpu().numpy(), first_spectrum=d_out[0].cpu().numpy(),
+                 global_stream=lo, rank=rank, world=world, streams=streams)
+        cb_.close()
     alt = timed(alt_batch) if alt_batch is not None else None
     # tertiary measurement (N=1 only): the chain GLava's spectrum modules actually request --
     # window,fft,gravity,avg (bars/1.frag:12-24) -- i.e. the same pass + gravity + F=5 windowed average
@@ -394,6 +485,9 @@ def main() -> None:
                                 "value": streams * world * a.steps / a_el, "unit": "frames/s",
                                 "ms_per_step": a_el / a.steps * 1e3, "avg_kernel_ms": a_k * 1e3,
                                 "roofline_frac": (alg_bytes / a_k / 1e9) / HBM_PEAK_GBS if a_k > 0 else 0.0}
+        if sustained is not None:
+            line["sustained"] = sustained
+        line["stats"] = stats                              # one record per rank, as gathered (frames, seconds, kernel_ms, bytes)
         if chain is not None:
             line["smooth_chain"] = chain
         if r16 is not None:

@@ -52,8 +52,18 @@ def _run(cmd: list[str]) -> None:
 def _compile(src: str, obj: str, extra: list[str]) -> str:
     deps = [os.path.join(CSRC, src)] + [os.path.join(CSRC, h) for h in HEADERS]
     if _newer(obj, deps):
-        _run([_hipcc(), *HIPFLAGS, *extra, "-c", os.path.join(CSRC, src), "-o", obj])
+        cmd = [_hipcc(), *HIPFLAGS, *extra, "-c", os.path.join(CSRC, src), "-o", obj]
+        _run(cmd)
+        open(obj + ".cmd", "w").write(" ".join(cmd) + "\n")     # what this object was compiled with (tests/test_abi.py reads it)
     return obj
+
+
+def _refuse_experiment_flags(flags: list[str]) -> None:
+    """the product is compiled with HIPFLAGS + the size only: experiment / tuning macros (glv_core.h) must not reach it"""
+    env = " ".join(os.environ.get(k, "") for k in ("HIPCC_COMPILE_FLAGS_APPEND", "HIPFLAGS", "CXXFLAGS", "CPPFLAGS"))
+    bad = [f for f in flags if f.startswith("-D") and not f.startswith("-DGLV_LOG_NN=")]
+    if bad or "-DGLV_" in env:
+        raise RuntimeError(f"product build refuses extra macro definitions: {bad or env!r} (use build_variant for A/B libraries)")
 
 
 def build_tune_variant(name: str, extra_flags: list[str], variants: str | None = None) -> str:
@@ -63,7 +73,7 @@ def build_tune_variant(name: str, extra_flags: list[str], variants: str | None =
     os.makedirs(OBJ, exist_ok=True)
     os.makedirs(TUNE_BIN, exist_ok=True)
     obj = os.path.join(OBJ, f"glv_tune_{name}.o")
-    flags = list(extra_flags)
+    flags = ["-DGLV_TUNE_BUILD", *[f for f in extra_flags if f != "-DGLV_TUNE_BUILD"]]
     if variants:
         flags.append("-DGLV_TUNE_VARIANTS=" + variants)
     _run([_hipcc(), *HIPFLAGS, *flags, "-c", os.path.join(CSRC, "glv_tune.hip"), "-o", obj])
@@ -80,6 +90,7 @@ def build_variant(name: str, extra_flags: list[str], sizes=SIZES, kernels_only: 
     else is the product's (which must be built and current): minutes instead of the whole library per experiment."""
     obj_dir = os.path.join(OBJ, name)
     os.makedirs(obj_dir, exist_ok=True)
+    extra_flags = ["-DGLV_TUNE_BUILD", *[f for f in extra_flags if f != "-DGLV_TUNE_BUILD"]]      # the experiment macros' switch (glv_core.h)
     jobs = [("glv_inst.hip", os.path.join(obj_dir, f"glv_inst_{k}.o"), [f"-DGLV_LOG_NN={k}", *extra_flags]) for k in sizes]
     reused = []
     if kernels_only:
@@ -112,8 +123,10 @@ def build(tune: bool = False, verbose: bool = False) -> str:
     jobs.append(("glv_misc.hip", os.path.join(OBJ, "glv_misc.o"), []))
     jobs.append(("glv_api.cpp", os.path.join(OBJ, "glv_api.o"), ["-x", "hip"]))
     jobs.append(("glv_multi.cpp", os.path.join(OBJ, "glv_multi.o"), ["-x", "hip"]))
+    for _, _, extra in jobs:
+        _refuse_experiment_flags(extra)
     if tune:
-        jobs.append(("glv_tune.hip", os.path.join(OBJ, "glv_tune.o"), []))
+        jobs.append(("glv_tune.hip", os.path.join(OBJ, "glv_tune.o"), ["-DGLV_TUNE_BUILD"]))
     with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 2)) as ex:
         objs = list(ex.map(lambda j: _compile(*j), jobs))
     prod = [o for o in objs if not o.endswith("glv_tune.o")]

@@ -57,7 +57,7 @@ int validate(const glv_params* p) {
         return fail(GLV_ERR_INVALID, "avg_frames=%u: must be in [1, %d]", p->avg_frames, GLV_MAX_AVG_FRAMES);
     if (p->avg_window_kind > 1) return fail(GLV_ERR_INVALID, "avg_window_kind=%u: must be 0 or 1", p->avg_window_kind);
     if (p->log_mode > 2) return fail(GLV_ERR_INVALID, "log_mode=%u: must be 0, 1 or 2", p->log_mode);
-    if (p->gl_storage > 1) return fail(GLV_ERR_INVALID, "gl_storage=%u: must be 0 or 1", p->gl_storage);
+    if (p->gl_storage > 2) return fail(GLV_ERR_INVALID, "gl_storage=%u: must be 0, 1 (GL_R16 state, one launch) or 2 (pass by pass, f32 state)", p->gl_storage);
     if (p->ur != p->ur) return fail(GLV_ERR_INVALID, "ur is NaN");   // 0 is legal: render.c:2387 yields it after an interval without updates
     return GLV_OK;
 }
@@ -89,12 +89,14 @@ std::vector<WisdomEntry> g_wisdom;
 std::atomic<uint64_t> g_wisdom_gen{1};      // bumped by every change of the table: invalidates the per-batch caches
 bool g_wisdom_env_loaded = false;
 
+constexpr unsigned kOpGl16 = 1u << 31;     // internal: the chain runs as the fused GL_R16 kernel (gl_storage == 1)
 uint32_t ops_class_of(unsigned ops) {      // the kernel instantiation a chain selects (glv_kernel_tmpl.h launch_variant)
+    if (ops & kOpGl16) return (ops & GLV_OP_BARS) ? 6 : 5;
     if (ops & GLV_OP_BARS) return 2;
     if (ops & (GLV_OP_GRAVITY | GLV_OP_AVERAGE)) return (ops & GLV_OP_R16) ? 4 : 1;
     return (ops & GLV_OP_R16) ? 3 : 0;
 }
-constexpr int kOpsClasses = 5, kInKinds = 5;
+constexpr int kOpsClasses = 7, kInKinds = 5;
 uint32_t log2_round(uint32_t v) { uint32_t l = 0; while ((2u << l) <= v) ++l; return ((v >> l << l) * 3 / 2 <= v && l < 31) ? l + 1 : l; }
 bool same_key(const WisdomKey& a, const WisdomKey& b) {
     return a.n == b.n && a.in_kind == b.in_kind && a.ops_class == b.ops_class && a.log_mode == b.log_mode && a.streams_log2 == b.streams_log2
@@ -233,12 +235,18 @@ struct glv_batch {
     uint32_t ring_pos = 0;       // next write position in the PCM ring, in frames
     int grid_override = 0;
     int variant_override = -1;   // kernel configuration forced by glv_batch_set_variant (-1 = wisdom / default)
+    int last_launches = 0;       // kernels the last process call launched
     int last_grid = 0;           // workgroups of the last frame-kernel launch
     int last_variant = 0;        // kernel configuration of the last frame-kernel launch
     char device_name[48] = "unknown";
     // what the wisdom said the last time it was asked, per (input kind, kernel class): valid while `gen` equals the table's
     // generation -- the launch path takes no lock and scans nothing once an answer is cached
     struct PlanCache { uint64_t gen = 0; int variant = 0, grid = 0; bool hit = false; } plan_cache[kInKinds][kOpsClasses];
+    uint32_t rows = 0;           // channel rows the state arrays and the scratch rows were sized for (streams * 2; 1 for the single-stream drop-ins)
+    bool single_row = false;
+    bool unfused_bars = false;   // GLV_UNFUSED_BARS in the environment at creation (diagnostics: bars always as a second launch)
+    bool state16 = false;        // gl_storage == 1 at creation: d_grav / d_hist hold uint16 texels (2 bytes per value)
+    float grav_g = 0.f; uint32_t grav_sub = 0; bool grav_int = false, grav_known = false;   // the gravity step on texels (glv_tables.h gravity_r16_integer_step)
     float* d_scratch = nullptr;  // [streams*2][n] spectra feeding GLV_OP_BARS
     float* d_ring_f32 = nullptr; // [streams][n][2] interleaved f32 ring (glv_batch_ring_update_f32)
     uint32_t ring_pos_f32 = 0;
@@ -251,9 +259,12 @@ struct glv_batch {
     glv::BarDesc* d_bar_desc = nullptr;   // GLV_OP_BARS tap tables (host generated)
     float* d_bar_w = nullptr;
     glv::BarItem* d_bar_items = nullptr;    // work lists for glv_bars_kernel (32 groups per row)
-    glv::BarItem* d_bar_fitems = nullptr;   // work lists for the fused epilogue (lanes/8 groups per row)
-    uint32_t bar_nsteps = 0, bar_fnsteps = 0; bool bar_fusable = false;
-    uint32_t bar_count = 0; float bar_factor = -1.f, bar_phase = 0.f; int bar_lanes = 0;
+    // work lists for the fused epilogue (lanes / GL groups per row), one per kernel configuration of the size (their lanes per row differ)
+    static constexpr int kMaxVariants = 4;
+    glv::BarItem* d_bar_fitems[kMaxVariants] = {};
+    uint32_t bar_fnsteps[kMaxVariants] = {}; bool bar_fusable[kMaxVariants] = {};
+    uint32_t bar_nsteps = 0;
+    uint32_t bar_count = 0; float bar_factor = -1.f, bar_phase = 0.f;
     // timing
     bool timing = false;
     std::vector<hipEvent_t> ev;  // start/stop pairs
@@ -281,21 +292,22 @@ namespace {
 
 int batch_alloc(glv_batch* b, uint32_t rows) {
     const size_t n = b->p.n;
+    b->state16 = b->p.gl_storage == 1;
+    const size_t esz = b->state16 ? sizeof(uint16_t) : sizeof(float);          // GL_R16 state: texels
     if ((b->ops_mask & GLV_OP_AVERAGE)) {
-        const size_t bytes = sizeof(float) * rows * (size_t) b->p.avg_frames * n;
+        const size_t bytes = esz * rows * (size_t) b->p.avg_frames * n;
         HIP_TRY(hipMalloc(&b->d_hist, bytes));
         HIP_TRY(hipMemset(b->d_hist, 0, bytes));
     }
     if ((b->ops_mask & GLV_OP_GRAVITY)) {
         // kept even when the ring also exists: the single-op glv_gravity() drop-in owns its own
         // `applied` buffer exactly like the reference's separate udata slot (render.c:724)
-        const size_t bytes = sizeof(float) * rows * n;
+        const size_t bytes = esz * rows * n;
         HIP_TRY(hipMalloc(&b->d_grav, bytes));
         HIP_TRY(hipMemset(b->d_grav, 0, bytes));
         b->grav_cur = b->d_grav;
     }
-    // the device rings of the FIFO / PulseAudio modes, when the creation mask announces them (otherwise the first
-    // ring update allocates -- a synchronising hipMalloc inside an otherwise stream-ordered call)
+    // the device rings of the FIFO / PulseAudio modes, when the creation mask announces them
     if (b->ops_mask & GLV_OP_RING_S16) {
         const size_t bytes = sizeof(int16_t) * 2 * n * b->streams;
         HIP_TRY(hipMalloc(&b->d_ring, bytes));
@@ -401,40 +413,99 @@ int ensure_smooth_tables(glv_batch* b) {
     return GLV_OK;
 }
 
-// lanes: lanes per row of the frame-kernel configuration that will consume the fused work lists (0: only glv_bars_kernel runs)
-int ensure_bar_tables(glv_batch* b, int lanes = 0) {
-    if (lanes == 0) lanes = b->bar_lanes ? b->bar_lanes : glv::frame_geometry(b->log_nn, 0).lanes;
-    if (b->d_bar_desc && b->bar_count == b->p.bars && b->bar_factor == b->p.smooth_factor && b->bar_phase == b->p.bar_phase && b->bar_lanes == lanes) return GLV_OK;
+// GLV_OP_BARS tables: taps, weights, the work lists of glv_bars_kernel and one fused work list per kernel configuration of the
+// size (their lanes per row differ).  Host generation + synchronous upload: creation / glv_batch_set_params only.
+int ensure_bar_tables(glv_batch* b) {
+    if (b->d_bar_desc && b->bar_count == b->p.bars && b->bar_factor == b->p.smooth_factor && b->bar_phase == b->p.bar_phase) return GLV_OK;
     if (b->p.bars == 0 || b->p.bars > b->p.n) return fail(GLV_ERR_INVALID, "bars=%u out of range", b->p.bars);
+    if (!(b->p.smooth_factor >= 0.0f && b->p.smooth_factor <= 1.0f))       // also rejects NaN
+        return fail(GLV_ERR_INVALID, "smooth_factor=%g: must be in [0, 1] (a bar would have no taps)", (double) b->p.smooth_factor);
+    if (!(b->p.bar_phase >= 0.0f && b->p.bar_phase < 1.0f)) return fail(GLV_ERR_INVALID, "bar_phase=%g: must be in [0, 1)", (double) b->p.bar_phase);
     std::vector<glv::BarDesc> desc;
     std::vector<float> w;
     glv::make_bar_taps(desc, w, b->p.n, b->p.bars, b->p.smooth_factor, b->p.bar_phase);
     if (!glv::bar_chunks_in_row(desc, b->p.n)) return fail(GLV_ERR_INVALID, "bars: a tap chunk would leave the row (n=%u smooth_factor=%g)", b->p.n, (double) b->p.smooth_factor);
-    if (b->d_bar_desc) { (void) hipFree(b->d_bar_desc); b->d_bar_desc = nullptr; }
-    if (b->d_bar_w) { (void) hipFree(b->d_bar_w); b->d_bar_w = nullptr; }
-    HIP_TRY(hipMalloc(&b->d_bar_desc, sizeof(glv::BarDesc) * desc.size()));
-    // work lists: 256 / GL groups per row for glv_bars_kernel; T / GL groups for the frame kernel of this size (GL = bar_lanes_of(n))
-    // (fused bars: whole waves per row, fewer than 2 * lanes bars).  one chunk of zero weights
-    // appended for padding items.
+    auto drop = [](auto*& ptr) { if (ptr) { (void) hipFree(ptr); ptr = nullptr; } };
+    drop(b->d_bar_desc); drop(b->d_bar_w); drop(b->d_bar_items);
+    for (int v = 0; v < glv_batch::kMaxVariants; ++v) { drop(b->d_bar_fitems[v]); b->bar_fusable[v] = false; b->bar_fnsteps[v] = 0; }
+    b->bar_count = 0;
+    // work lists: 256 / GL groups per row for glv_bars_kernel; T / GL groups for the frame kernel (GL = bar_lanes_of(n); fused bars:
+    // whole waves per row, fewer than 2 * lanes bars).  one chunk of zero weights appended for padding items.
     const uint32_t zero_off = (uint32_t) w.size();
     const uint32_t chunk = glv::bar_chunk_of(b->p.n), gl = (uint32_t) glv::bar_lanes_of(b->p.n);
     w.resize(w.size() + chunk, 0.0f);
-    std::vector<glv::BarItem> items, fitems;
+    std::vector<glv::BarItem> items;
     b->bar_nsteps = glv::make_bar_items(items, desc, 256 / gl, zero_off, chunk);
-    b->bar_fusable = lanes % 64 == 0 && b->p.bars + 1 <= 2 * (uint32_t) lanes;   // bar totals + the dump slot fit the 2 * lanes floats of slack behind the row in LDS
-    if (b->bar_fusable) b->bar_fnsteps = glv::make_bar_items(fitems, desc, (uint32_t) lanes / gl, zero_off, chunk, (uint32_t) glv::frame_geometry(b->log_nn, 0).bar_batch);
-    if (b->d_bar_items) { (void) hipFree(b->d_bar_items); b->d_bar_items = nullptr; }
-    if (b->d_bar_fitems) { (void) hipFree(b->d_bar_fitems); b->d_bar_fitems = nullptr; }
     HIP_TRY(hipMalloc(&b->d_bar_items, sizeof(glv::BarItem) * items.size()));
     HIP_TRY(hipMemcpy(b->d_bar_items, items.data(), sizeof(glv::BarItem) * items.size(), hipMemcpyHostToDevice));
-    if (b->bar_fusable) {
-        HIP_TRY(hipMalloc(&b->d_bar_fitems, sizeof(glv::BarItem) * fitems.size()));
-        HIP_TRY(hipMemcpy(b->d_bar_fitems, fitems.data(), sizeof(glv::BarItem) * fitems.size(), hipMemcpyHostToDevice));
+    const int nv = glv::frame_variants(b->log_nn);
+    for (int v = 0; v < nv && v < glv_batch::kMaxVariants; ++v) {
+        const glv::FrameGeometry geo = glv::frame_geometry(b->log_nn, v);
+        // bar totals + the dump slot fit the 2 * lanes floats of slack behind the row in LDS
+        b->bar_fusable[v] = geo.lanes % 64 == 0 && b->p.bars + 1 <= 2 * (uint32_t) geo.lanes;
+        if (!b->bar_fusable[v]) continue;
+        std::vector<glv::BarItem> fitems;
+        b->bar_fnsteps[v] = glv::make_bar_items(fitems, desc, (uint32_t) geo.lanes / gl, zero_off, chunk, (uint32_t) geo.bar_batch);
+        HIP_TRY(hipMalloc(&b->d_bar_fitems[v], sizeof(glv::BarItem) * fitems.size()));
+        HIP_TRY(hipMemcpy(b->d_bar_fitems[v], fitems.data(), sizeof(glv::BarItem) * fitems.size(), hipMemcpyHostToDevice));
     }
+    HIP_TRY(hipMalloc(&b->d_bar_desc, sizeof(glv::BarDesc) * desc.size()));
     HIP_TRY(hipMalloc(&b->d_bar_w, sizeof(float) * w.size()));
     HIP_TRY(hipMemcpy(b->d_bar_desc, desc.data(), sizeof(glv::BarDesc) * desc.size(), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(b->d_bar_w, w.data(), sizeof(float) * w.size(), hipMemcpyHostToDevice));
-    b->bar_count = b->p.bars; b->bar_factor = b->p.smooth_factor; b->bar_phase = b->p.bar_phase; b->bar_lanes = lanes;
+    b->bar_count = b->p.bars; b->bar_factor = b->p.smooth_factor; b->bar_phase = b->p.bar_phase;
+    return GLV_OK;
+}
+
+// Everything the process calls need besides the state arrays, made from b->p: tilt table, the gravity step on texels, and -- as
+// announced by the creation mask -- bar tables, smooth bounds, the internal spectra rows.  Called by creation and by
+// glv_batch_set_params (and by the single-stream drop-ins when their caller changes a knob): the ONLY place that allocates or
+// copies synchronously; glv_batch_process_* / ring updates never do (tests/test_stream_order.py greps for it).
+int batch_prepare(glv_batch* b) {
+    if (int rc = b->tab.set_tilt(b->p.fft_scale, b->p.fft_cutoff, b->p.log_mode == 1)) return rc;
+    const float g = b->p.gravity_step * (1.0F / b->p.ur);                      // render.c:728
+    if (!b->grav_known || std::memcmp(&g, &b->grav_g, sizeof(g)) != 0) {
+        b->grav_int = glv::gravity_r16_integer_step(g, &b->grav_sub);
+        b->grav_g = g; b->grav_known = true;
+    }
+    // Tables are cheap and always made (an operator the creation mask did not announce only fails to get them when its
+    // parameters are unusable: a later call of that operator is then refused); buffers of spectrum size are made for announced
+    // operators only.
+    {
+        const int rc = ensure_smooth_tables(b);
+        if (rc != GLV_OK && (b->ops_mask & GLV_OP_SMOOTH)) return rc;
+    }
+    {
+        const int rc = ensure_bar_tables(b);
+        if (rc != GLV_OK && (b->ops_mask & GLV_OP_BARS)) return rc;
+    }
+    if (b->ops_mask & GLV_OP_BARS) {
+        // the internal spectra rows: needed whenever bars are not computed inside the transform's launch from a row in LDS
+        // (stateless chains, rows whose bars do not fit the slack behind them, SMOOTH | BARS) and no state array holds the spectra
+        bool all_fused = (b->ops_mask & (GLV_OP_GRAVITY | GLV_OP_AVERAGE)) != 0 && !(b->ops_mask & GLV_OP_SMOOTH) && b->p.gl_storage != 2;
+        for (int v = 0; v < glv::frame_variants(b->log_nn) && v < glv_batch::kMaxVariants; ++v) all_fused = all_fused && b->bar_fusable[v];
+        if (!all_fused && !b->d_scratch) HIP_TRY(hipMalloc(&b->d_scratch, sizeof(float) * (size_t) b->rows * b->p.n));
+    }
+    // function attributes (the > 64 KiB dynamic-LDS opt-in) of every frame kernel this batch can launch: set here, once per device
+    // and instantiation, so that a process call is a plain launch (launch_variant with grid 0 = attribute only; combinations
+    // that are not built answer hipErrorInvalidValue, which is not an error here)
+    {
+        glv::FrameArgs a;
+        std::memset(&a, 0, sizeof(a));
+        const struct { unsigned ops; bool bars; uint32_t gl; } cls[] = {
+            {GLV_OP_FFT, false, 0}, {GLV_OP_FFT | GLV_OP_R16, false, 0}, {GLV_OP_FFT | GLV_OP_GRAVITY, false, 0}, {GLV_OP_FFT | GLV_OP_GRAVITY | GLV_OP_R16, false, 0},
+            {GLV_OP_FFT | GLV_OP_GRAVITY, true, 0}, {GLV_OP_FFT | GLV_OP_GRAVITY, false, 1}, {GLV_OP_FFT | GLV_OP_GRAVITY, true, 1}};
+        for (int in_mode = 0; in_mode < kInKinds; ++in_mode)
+            for (int v = 0; v < glv::frame_variants(b->log_nn); ++v)
+                for (const auto& c : cls) {
+                    a.ops = c.ops; a.gl_storage = c.gl; a.bars_out = c.bars ? reinterpret_cast<float*>(16) : nullptr;
+                    (void) glv::launch_frame(b->log_nn, in_mode, (int) b->p.log_mode, v, a, 0, nullptr);
+                }
+        (void) hipGetLastError();
+    }
+    // the pass-by-pass GL chain parks the transform's f32 spectra when the caller's buffer cannot take them (texel / bar outputs)
+    if (b->p.gl_storage == 2 && (b->ops_mask & (GLV_OP_GRAVITY | GLV_OP_AVERAGE)) && !b->d_scratch && !b->single_row)
+        HIP_TRY(hipMalloc(&b->d_scratch, sizeof(float) * (size_t) b->rows * b->p.n));
     return GLV_OK;
 }
 
@@ -444,26 +515,43 @@ int check_ops(const glv_batch* b, unsigned ops, const float* d_out) {
     // gravity's output IS its new state (render.c:733-734): a chain that ends in gravity can leave the
     // spectra in the state buffer (glv_batch_gravity_state) instead of writing them a second time
     const bool state_is_output = (ops & GLV_OP_GRAVITY) && !(ops & (GLV_OP_AVERAGE | GLV_OP_SMOOTH | GLV_OP_RAW));
-    if (!d_out && !(state_is_output && !(ops & GLV_OP_BARS)))
-        return fail(GLV_ERR_INVALID, "NULL output pointer (allowed only for chains ending in gravity, see glv_batch_gravity_state)");
+    if (!d_out && !(state_is_output && !(ops & GLV_OP_BARS) && !b->state16))
+        return fail(GLV_ERR_INVALID, "NULL output pointer (allowed only for f32-state chains ending in gravity, see glv_batch_gravity_state)");
     const unsigned stateful = ops & (GLV_OP_GRAVITY | GLV_OP_AVERAGE);
     if (stateful & ~b->ops_mask)
         return fail(GLV_ERR_STATE, "ops 0x%x need state the batch was not created with (ops_mask 0x%x)", ops, b->ops_mask);
+    if (stateful && b->state16 != (b->p.gl_storage == 1))
+        return fail(GLV_ERR_STATE, "gl_storage=%u: the state of this batch was created as %s", b->p.gl_storage, b->state16 ? "GL_R16 texels (gl_storage 1)" : "floats (gl_storage 0 / 2)");
     if ((ops & GLV_OP_WRANGE) && (ops & GLV_OP_FFT)) return fail(GLV_ERR_INVALID, "GLV_OP_WRANGE excludes GLV_OP_FFT");
     if ((ops & GLV_OP_RAW) && !(ops & GLV_OP_FFT)) return fail(GLV_ERR_INVALID, "GLV_OP_RAW needs GLV_OP_FFT");
     if ((ops & GLV_OP_MAGNITUDE) && (ops & (GLV_OP_FFT | GLV_OP_WRANGE))) return fail(GLV_ERR_INVALID, "GLV_OP_MAGNITUDE excludes GLV_OP_FFT and GLV_OP_WRANGE");
     if (!(ops & (GLV_OP_FFT | GLV_OP_GRAVITY | GLV_OP_AVERAGE | GLV_OP_WRANGE | GLV_OP_SMOOTH | GLV_OP_MAGNITUDE | GLV_OP_R16))) return fail(GLV_ERR_INVALID, "empty ops");
     if ((ops & GLV_OP_R16) && (ops & (GLV_OP_RAW | GLV_OP_SMOOTH))) return fail(GLV_ERR_INVALID, "GLV_OP_R16 excludes GLV_OP_RAW and GLV_OP_SMOOTH");
     if ((ops & GLV_OP_R16) && !d_out) return fail(GLV_ERR_INVALID, "GLV_OP_R16 needs an output buffer");
-    if ((ops & GLV_OP_BARS) && (b->p.bars == 0 || b->p.bars > b->p.n)) return fail(GLV_ERR_INVALID, "bars=%u out of range", b->p.bars);
-    if ((ops & GLV_OP_BARS) && !(b->p.smooth_factor >= 0.0f && b->p.smooth_factor <= 1.0f))       // also rejects NaN
-        return fail(GLV_ERR_INVALID, "smooth_factor=%g: must be in [0, 1] (a bar would have no taps)", (double) b->p.smooth_factor);
-    if ((ops & GLV_OP_BARS) && !(b->p.bar_phase >= 0.0f && b->p.bar_phase < 1.0f))
-        return fail(GLV_ERR_INVALID, "bar_phase=%g: must be in [0, 1)", (double) b->p.bar_phase);
+    if ((ops & GLV_OP_OUTPUT_IS_STATE) && (!state_is_output || !d_out || (ops & (GLV_OP_BARS | GLV_OP_R16)) || b->p.gl_storage))
+        return fail(GLV_ERR_INVALID, "GLV_OP_OUTPUT_IS_STATE needs a chain that ends in gravity with f32 rows out (no AVERAGE / SMOOTH / RAW / BARS / R16, gl_storage 0)");
+    if ((ops & GLV_OP_BARS) && !b->d_bar_desc)
+        return fail(GLV_ERR_STATE, "GLV_OP_BARS: the batch has no bar tables (bars / smooth_factor / bar_phase were unusable when it was created; tables are built at creation and by glv_batch_set_params, process calls never allocate)");
+    if ((ops & GLV_OP_BARS) && (b->bar_count != b->p.bars || b->bar_factor != b->p.smooth_factor || b->bar_phase != b->p.bar_phase))
+        return fail(GLV_ERR_STATE, "GLV_OP_BARS: bar parameters changed without glv_batch_set_params");
+    if ((ops & GLV_OP_SMOOTH) && (!b->d_smin || b->smooth_d != b->p.smooth_distance || b->smooth_r != b->p.smooth_ratio))
+        return fail(GLV_ERR_STATE, "GLV_OP_SMOOTH: the batch has no window bounds for these parameters (unusable smooth_ratio at creation, or changed without glv_batch_set_params)");
     return GLV_OK;
 }
 
+// does `ops` run as the fused GL_R16 kernel?  (gl_storage 1, an FFT chain with state; RAW / SMOOTH / the audit log take the passes one by one)
+bool gl_fused_chain(const glv_batch* b, unsigned ops) {
+    return b->p.gl_storage == 1 && (ops & GLV_OP_FFT) && (ops & (GLV_OP_GRAVITY | GLV_OP_AVERAGE)) && !(ops & (GLV_OP_RAW | GLV_OP_SMOOTH)) && b->p.log_mode != 2;
+}
+// the chain as the launch plan / wisdom sees it
+unsigned plan_ops(const glv_batch* b, unsigned ops) {
+    if (gl_fused_chain(b, ops)) return ops | kOpGl16;
+    if (b->p.gl_storage && (ops & (GLV_OP_GRAVITY | GLV_OP_AVERAGE))) return GLV_OP_FFT | (ops & GLV_OP_RAW);     // pass by pass: the frame kernel runs the transform alone
+    return ops;
+}
+
 // One update of `units` channel rows through the fused kernel (or the post kernel when no FFT is asked).
+// Stream-ordered: launches and asynchronous device-to-device copies only.
 int process(glv_batch* b, const void* d_in, int in_mode, float* d_out, unsigned ops, uint32_t units,
             uint32_t rot, hipStream_t st) {
     if (!d_in) return fail(GLV_ERR_INVALID, "NULL device pointer");
@@ -478,94 +566,107 @@ int process(glv_batch* b, const void* d_in, int in_mode, float* d_out, unsigned 
             return fail(GLV_ERR_STATE, "gravity was last applied %s average on this batch and is now requested %s it: the two forms keep "
                                        "their state in different buffers (glv_batch_reset, or one batch per chain)",
                         b->grav_mode == 2 ? "fused with" : "without", mode == 2 ? "fused with" : "without");
-        b->grav_mode = mode;
     }
     float* d_final = d_out;
+    b->last_launches = 0;
     HIP_TRY(hipSetDevice(b->device));
+    const bool stateful = (ops & (GLV_OP_GRAVITY | GLV_OP_AVERAGE)) != 0;
+    const bool gl_fused = gl_fused_chain(b, ops);                            // gl_storage 1: the GL passes are the transform's epilogue
+    const bool gl_split = b->p.gl_storage != 0 && stateful && !gl_fused;     // the GL passes one by one (gl_storage 2; RAW / SMOOTH / audit log of 1)
+    // which kernel configuration of this size runs, on how many workgroups (wisdom, overrides, defaults)
+    int variant = 0, grid = 0;
+    if (ops & GLV_OP_FFT) launch_plan(b, units, in_mode, plan_ops(b, ops), &variant, &grid);
     // GLV_OP_BARS: d_out receives the bars.  Stateful FFT chains whose rows are owned by whole waves compute
     // them inside the frame kernel from the finished row in LDS (the spectra never reach HBM, apart from
     // the state the operators keep anyway); otherwise the spectra stay internal -- in the gravity state
-    // when the chain ends in gravity, in a scratch buffer else -- and glv_bars_kernel runs after.
-    const bool gl_split = b->p.gl_storage && (ops & (GLV_OP_GRAVITY | GLV_OP_AVERAGE)) != 0;
-    // which kernel configuration of this size runs, on how many workgroups (wisdom, overrides, defaults)
-    int variant = 0, grid = 0;
-    if (ops & GLV_OP_FFT) launch_plan(b, units, in_mode, gl_split ? (unsigned) GLV_OP_FFT : ops, &variant, &grid);
-    // (bars as GL_R16 texels -- the smooth pass's render target -- leave through glv_bars_kernel)
-    bool fused_bars = (ops & GLV_OP_BARS) && (ops & GLV_OP_FFT) && (ops & (GLV_OP_GRAVITY | GLV_OP_AVERAGE)) && !(ops & (GLV_OP_SMOOTH | GLV_OP_R16)) && !gl_split;
-    if (fused_bars) {
-        if (int rc = ensure_bar_tables(b, glv::frame_geometry(b->log_nn, variant).lanes)) return rc;
-        fused_bars = b->bar_fusable                // whole waves per row, bar totals fit the slack behind the row
-                     && !std::getenv("GLV_UNFUSED_BARS");   // diagnostics: force the two-kernel path
-    }
+    // when the chain ends in gravity, in the scratch rows else -- and glv_bars_kernel runs after.
+    // (the float chain's bars as GL_R16 texels leave through glv_bars_kernel; the GL_R16 chain stores them itself)
+    const bool fused_bars = (ops & GLV_OP_BARS) && (ops & GLV_OP_FFT) && stateful && !(ops & GLV_OP_SMOOTH) && !gl_split
+                            && (gl_fused || !(ops & GLV_OP_R16)) && variant < glv_batch::kMaxVariants && b->bar_fusable[variant]
+                            && !b->unfused_bars;                         // diagnostics: force the two-kernel path
     if (ops & GLV_OP_BARS) {
-        if (fused_bars || state_is_output) d_out = nullptr;
+        if (fused_bars || (state_is_output && !b->p.gl_storage)) d_out = nullptr;
         else {
-            if (!b->d_scratch) HIP_TRY(hipMalloc(&b->d_scratch, sizeof(float) * (size_t) b->streams * 2 * b->p.n));
+            if (!b->d_scratch) return fail(GLV_ERR_STATE, "this GLV_OP_BARS chain needs the internal spectra rows: announce it in glv_batch_create's ops_mask (GLV_OP_BARS together with the chain's other operators)");
             d_out = b->d_scratch;
         }
     }
+    if (b->tab.tilt_scale != b->p.fft_scale || b->tab.tilt_cutoff != b->p.fft_cutoff || b->tab.tilt_fold != (b->p.log_mode == 1))
+        return fail(GLV_ERR_STATE, "fft_scale / fft_cutoff / log_mode changed without glv_batch_set_params");
+    if (ops & GLV_OP_GRAVITY) b->grav_mode = (ops & GLV_OP_AVERAGE) ? 2 : 1;
 
-    if (int rc = b->tab.set_tilt(b->p.fft_scale, b->p.fft_cutoff, b->p.log_mode == 1)) return rc;
     glv::FrameArgs a;
     fill_common(a, b->p, b->tab);
     a.in = d_in; a.out = d_out; a.grav = b->grav_cur; a.grav_w = b->d_grav; a.hist = b->d_hist;
-    a.units = units; a.ops = ops & ~(unsigned) GLV_OP_PRIVATE_STATE; a.head = b->head; a.rot = rot; a.log_mode = b->p.log_mode;
-    if (ops & GLV_OP_BARS) a.ops &= ~(unsigned) GLV_OP_R16;        // with bars the texel conversion applies to the bars, the spectra stay f32
-    // A chain that ends in gravity writes ONE copy of its result (SURVEY 8d row B, 20 N bytes per frame): transform_gravity
-    // stores the same value to its `applied` array and to the buffer (render.c:733-734), so the caller's output buffer IS
-    // the new state and the next update reads it from there.  A private copy in the batch (28 N) is kept when the caller
-    // asks for it (GLV_OP_PRIVATE_STATE), when the transform runs in place on its own input (the next input would overwrite
-    // the state: the reference's calling convention, and the single-stream drop-ins), and when the output is not f32 rows.
+    a.units = units; a.ops = ops & ~(unsigned) (GLV_OP_PRIVATE_STATE | GLV_OP_OUTPUT_IS_STATE); a.head = b->head; a.rot = rot; a.log_mode = b->p.log_mode;
+    a.grav_sub = b->grav_sub; a.grav_int = b->grav_int ? 1u : 0u;
+    if (ops & GLV_OP_BARS) { a.ops &= ~(unsigned) GLV_OP_R16; a.bars_r16 = (ops & GLV_OP_R16) ? 1u : 0u; }   // with bars the texel conversion applies to the bars, the spectra stay f32
+    // GLV_OP_OUTPUT_IS_STATE: a chain that ends in gravity writes ONE copy of its result (SURVEY 8d row B, 20 N bytes per frame) --
+    // transform_gravity stores the same value to its `applied` array and to the buffer (render.c:733-734), so the caller's output
+    // buffer can BE the state the next update reads.  Opt-in: the caller promises to leave the buffer alone until then.
     const bool gravity_only = (ops & GLV_OP_GRAVITY) && !(ops & GLV_OP_AVERAGE);
-    const bool out_is_state = gravity_only && state_is_output && d_out != nullptr && !(ops & (GLV_OP_BARS | GLV_OP_R16 | GLV_OP_PRIVATE_STATE))
-                              && (const void*) d_out != d_in && !b->p.gl_storage;
-    if (out_is_state) { a.grav_w = d_out; a.out = nullptr; }
+    const bool out_is_state = (ops & GLV_OP_OUTPUT_IS_STATE) != 0;           // check_ops vetted the chain
+    if (out_is_state) {
+        if ((const void*) d_out == d_in) return fail(GLV_ERR_INVALID, "GLV_OP_OUTPUT_IS_STATE: the output buffer must not be the input");
+        a.grav_w = d_out; a.out = nullptr;
+    }
     const float* grav_next = gravity_only ? (out_is_state ? d_out : b->d_grav) : b->grav_cur;
     if (fused_bars) {
-        a.bar_desc = b->d_bar_desc; a.bar_items = b->d_bar_fitems; a.bar_nsteps = b->bar_fnsteps; a.bar_w = b->d_bar_w;
+        a.bar_desc = b->d_bar_desc; a.bar_items = b->d_bar_fitems[variant]; a.bar_nsteps = b->bar_fnsteps[variant]; a.bar_w = b->d_bar_w;
         a.bars = b->p.bars; a.bars_out = d_final;
     }
 
-    // glv_params.gl_storage: the GL twin's pass structure (render.c:2188-2265) -- the transform first, then gravity / average
-    // as their own pass over GL_R16-quantised values (glv_frame.h apply_state).  The frame kernel delivers the float spectra
-    // into the caller's buffer when that is what it will hold in the end, else into the batch's scratch rows.
-    // host tables of the follow-up kernels first: nothing is launched (and no state advanced) when they cannot be made
-    if (ops & GLV_OP_SMOOTH) { if (int rc = ensure_smooth_tables(b)) return rc; }
-    if ((ops & GLV_OP_BARS) && !fused_bars) { if (int rc = ensure_bar_tables(b)) return rc; }
     hipError_t e;
+    if (gl_fused) {
+        // render.c:2188-2265 (+ :2277-2303 with bars) in ONE launch on uint16 state.  Bars that do not fit the row's slack in LDS
+        // (bars == n: the pre-smoothing pass) sample the finished rows' floats from the scratch rows in a second launch.
+        a.gl_storage = 1;
+        if (int rc = timed_launch_begin(b, st)) return rc;
+        b->last_grid = grid; b->last_variant = variant;
+        e = glv::launch_frame(b->log_nn, in_mode, (int) b->p.log_mode, variant, a, grid, st); ++b->last_launches;
+        if (e != hipSuccess) return fail(GLV_ERR_HIP, "kernel launch failed: %s", hipGetErrorString(e));
+        b->kernel_name = "glv_frame_kernel";
+        if (ops & GLV_OP_AVERAGE) b->head = (b->head + 1) % b->p.avg_frames;
+        b->grav_cur = grav_next;
+        if ((ops & GLV_OP_BARS) && !fused_bars) {
+            e = glv::launch_bars(d_out, d_final, units, b->p.n, b->p.bars, b->bar_nsteps, b->d_bar_items, b->d_bar_desc, b->d_bar_w, st, (ops & GLV_OP_R16) != 0); ++b->last_launches;
+            if (e != hipSuccess) return fail(GLV_ERR_HIP, "bars launch failed: %s", hipGetErrorString(e));
+        }
+        return timed_launch_end(b, st);
+    }
+    // The GL twin's pass structure (render.c:2188-2265), pass by pass -- the transform first, then gravity / average as their own
+    // pass over GL_R16-quantised values (glv_frame.h apply_state; state as floats with gl_storage 2, as texels with 1).  The frame
+    // kernel delivers the float spectra into the caller's buffer when that is what it will hold in the end, else into the scratch rows.
     if (gl_split && (ops & GLV_OP_FFT)) {
         const bool direct = d_final && !(ops & (GLV_OP_BARS | GLV_OP_R16));
-        float* d_tmp = direct ? d_final : nullptr;
-        if (!direct) {
-            if (!b->d_scratch) HIP_TRY(hipMalloc(&b->d_scratch, sizeof(float) * (size_t) b->streams * 2 * b->p.n));
-            d_tmp = b->d_scratch;
-        }
+        float* d_tmp = direct ? d_final : b->d_scratch;
+        if (!d_tmp) return fail(GLV_ERR_STATE, "this gl_storage chain needs the internal spectra rows (created for gl_storage 2 batches with state, and with GLV_OP_BARS in the ops_mask)");
         glv::FrameArgs a1 = a;
         a1.ops = GLV_OP_FFT | (ops & GLV_OP_RAW); a1.out = d_tmp; a1.bars_out = nullptr;     // GLV_OP_RAW: the passes then run on the raw values
         if (int rc = timed_launch_begin(b, st)) return rc;
         b->last_grid = grid; b->last_variant = variant;
-        e = glv::launch_frame(b->log_nn, in_mode, (int) b->p.log_mode, variant, a1, grid, st);
+        e = glv::launch_frame(b->log_nn, in_mode, (int) b->p.log_mode, variant, a1, grid, st); ++b->last_launches;
         if (e != hipSuccess) return fail(GLV_ERR_HIP, "kernel launch failed: %s", hipGetErrorString(e));
         glv::FrameArgs a2 = a;
-        a2.in = d_tmp; a2.ops = ops & (GLV_OP_GRAVITY | GLV_OP_AVERAGE | ((ops & GLV_OP_BARS) ? 0u : (unsigned) GLV_OP_R16)); a2.gl_storage = 1;
+        a2.in = d_tmp; a2.ops = ops & (GLV_OP_GRAVITY | GLV_OP_AVERAGE | ((ops & GLV_OP_BARS) ? 0u : (unsigned) GLV_OP_R16)); a2.gl_storage = b->p.gl_storage;
         a2.out = (ops & GLV_OP_BARS) ? d_tmp : d_final;            // bars sample the finished rows; NULL = the state is the output
         a2.bars_out = nullptr;
-        e = glv::launch_post(a2, b->p.n, st);
+        e = glv::launch_post(a2, b->p.n, st); ++b->last_launches;
         if (e != hipSuccess) return fail(GLV_ERR_HIP, "GL-storage pass launch failed: %s", hipGetErrorString(e));
         b->kernel_name = "glv_frame_kernel";
         if (ops & GLV_OP_AVERAGE) b->head = (b->head + 1) % b->p.avg_frames;
         b->grav_cur = grav_next;
         if (ops & GLV_OP_SMOOTH) {                 // render.c:694-718 on the finished rows (a SMOOTH chain always has an output buffer)
-            e = glv::launch_smooth(a2.out, units, b->p.n, b->d_smin, b->d_smax, b->smooth_asz, b->smooth_reach, b->smooth_window, st);
+            e = glv::launch_smooth(a2.out, units, b->p.n, b->d_smin, b->d_smax, b->smooth_asz, b->smooth_reach, b->smooth_window, st); ++b->last_launches;
             if (e != hipSuccess) return fail(GLV_ERR_HIP, "smooth launch failed: %s", hipGetErrorString(e));
         }
         if (ops & GLV_OP_BARS) {
-            e = glv::launch_bars(d_tmp, d_final, units, b->p.n, b->p.bars, b->bar_nsteps, b->d_bar_items, b->d_bar_desc, b->d_bar_w, st, (ops & GLV_OP_R16) != 0);
+            e = glv::launch_bars(d_tmp, d_final, units, b->p.n, b->p.bars, b->bar_nsteps, b->d_bar_items, b->d_bar_desc, b->d_bar_w, st, (ops & GLV_OP_R16) != 0); ++b->last_launches;
             if (e != hipSuccess) return fail(GLV_ERR_HIP, "bars launch failed: %s", hipGetErrorString(e));
         }
         return timed_launch_end(b, st);            // the HIP-event window covers every launch of the chain
     }
-    if (gl_split) a.gl_storage = 1;                                  // operators on planar rows: the post kernel models it directly
+    if (gl_split) a.gl_storage = b->p.gl_storage;                    // operators on planar rows: the post kernel models it directly
 
     if (int rc = timed_launch_begin(b, st)) return rc;
     const unsigned core = ops & (GLV_OP_FFT | GLV_OP_GRAVITY | GLV_OP_AVERAGE | GLV_OP_WRANGE | GLV_OP_MAGNITUDE | GLV_OP_R16);
@@ -576,22 +677,22 @@ int process(glv_batch* b, const void* d_in, int in_mode, float* d_out, unsigned 
         b->kernel_name = "glv_smooth_kernel";
     } else if (ops & GLV_OP_FFT) {
         b->last_grid = grid; b->last_variant = variant;
-        e = glv::launch_frame(b->log_nn, in_mode, (int) b->p.log_mode, variant, a, grid, st);
+        e = glv::launch_frame(b->log_nn, in_mode, (int) b->p.log_mode, variant, a, grid, st); ++b->last_launches;
         b->kernel_name = "glv_frame_kernel";
     } else {
         if (in_mode != glv::IN_F32_PLANAR) return fail(GLV_ERR_INVALID, "operators without GLV_OP_FFT take planar f32 input");
-        e = glv::launch_post(a, b->p.n, st);
+        e = glv::launch_post(a, b->p.n, st); ++b->last_launches;
         b->kernel_name = "glv_post_kernel";
     }
     if (e != hipSuccess) return fail(GLV_ERR_HIP, "kernel launch failed: %s", hipGetErrorString(e));
     if (ops & GLV_OP_AVERAGE) b->head = (b->head + 1) % b->p.avg_frames;
     b->grav_cur = grav_next;
     if (ops & GLV_OP_SMOOTH) {                     // render.c:694-718, in place on the finished rows
-        e = glv::launch_smooth(d_out, units, b->p.n, b->d_smin, b->d_smax, b->smooth_asz, b->smooth_reach, b->smooth_window, st);
+        e = glv::launch_smooth(d_out, units, b->p.n, b->d_smin, b->d_smax, b->smooth_asz, b->smooth_reach, b->smooth_window, st); ++b->last_launches;
         if (e != hipSuccess) return fail(GLV_ERR_HIP, "smooth launch failed: %s", hipGetErrorString(e));
     }
     if ((ops & GLV_OP_BARS) && !fused_bars) {
-        e = glv::launch_bars(d_out ? d_out : b->grav_cur, d_final, units, b->p.n, b->p.bars, b->bar_nsteps, b->d_bar_items, b->d_bar_desc, b->d_bar_w, st, (ops & GLV_OP_R16) != 0);
+        e = glv::launch_bars(d_out ? d_out : b->grav_cur, d_final, units, b->p.n, b->p.bars, b->bar_nsteps, b->d_bar_items, b->d_bar_desc, b->d_bar_w, st, (ops & GLV_OP_R16) != 0); ++b->last_launches;
         if (e != hipSuccess) return fail(GLV_ERR_HIP, "bars launch failed: %s", hipGetErrorString(e));
     }
     return timed_launch_end(b, st);
@@ -614,6 +715,8 @@ int batch_create_rows(const glv_params* p, uint32_t streams, unsigned ops_mask, 
     glv_batch* b = new (std::nothrow) glv_batch();
     if (!b) return fail(GLV_ERR_NOMEM, "out of host memory");
     b->p = *p; b->streams = streams; b->ops_mask = ops_mask; b->device = device;
+    b->rows = single_row ? 1u : streams * 2u; b->single_row = single_row;
+    b->unfused_bars = std::getenv("GLV_UNFUSED_BARS") != nullptr;
     b->log_nn = log2_exact(p->n) - 1;
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess) {
@@ -621,10 +724,9 @@ int batch_create_rows(const glv_params* p, uint32_t streams, unsigned ops_mask, 
         std::snprintf(b->device_name, sizeof(b->device_name), "%s", prop.gcnArchName[0] ? prop.gcnArchName : prop.name);
     }
     int rc = b->tab.create(p->n);
-    // the tilt table of the batch's own parameters is uploaded here, so that the stream-ordered calls do not copy
-    // (set_tilt copies again only when fft_scale / fft_cutoff / log_mode change: the single-stream drop-ins allow that)
-    if (rc == GLV_OK) rc = b->tab.set_tilt(p->fft_scale, p->fft_cutoff, p->log_mode == 1);
-    if (rc == GLV_OK) rc = batch_alloc(b, single_row ? 1u : streams * 2u);
+    if (rc == GLV_OK) rc = batch_alloc(b, b->rows);
+    // every table and buffer the announced operators need is made here, so that the stream-ordered calls never allocate or copy
+    if (rc == GLV_OK) rc = batch_prepare(b);
     if (rc != GLV_OK) { glv_batch_destroy(b); return rc; }
     *out = b;
     return GLV_OK;
@@ -671,13 +773,30 @@ int glv_batch_create(const glv_params* p, uint32_t streams, unsigned ops_mask, i
     return batch_create_rows(p, streams, ops_mask, device, false, out);
 }
 
+int glv_batch_set_params(glv_batch* b, const glv_params* p) {
+    if (!b) return fail(GLV_ERR_INVALID, "batch is NULL");
+    if (int rc = validate(p)) return rc;
+    if (p->n != b->p.n || p->avg_frames != b->p.avg_frames)
+        return fail(GLV_ERR_STATE, "params (n=%u, F=%u) do not match the batch (n=%u, F=%u): fixed at creation", p->n, p->avg_frames, b->p.n, b->p.avg_frames);
+    if ((p->gl_storage == 1) != b->state16)
+        return fail(GLV_ERR_STATE, "gl_storage=%u: the state of this batch was created as %s", p->gl_storage, b->state16 ? "GL_R16 texels (gl_storage 1)" : "floats (gl_storage 0 / 2)");
+    HIP_TRY(hipSetDevice(b->device));
+    const glv_params old = b->p;
+    b->p = *p;
+    const int rc = batch_prepare(b);
+    if (rc != GLV_OK) { b->p = old; (void) batch_prepare(b); }              // a rejected change leaves the batch as it was
+    for (auto& row : b->plan_cache) for (auto& pc : row) pc.gen = 0;        // log_mode is part of the wisdom key
+    return rc;
+}
+
 int glv_batch_reset(glv_batch* b) {
     if (!b) return fail(GLV_ERR_INVALID, "batch is NULL");
     HIP_TRY(hipSetDevice(b->device));
     const size_t n = b->p.n;
-    size_t rows = (size_t) b->streams * 2;
-    if (b->d_hist) HIP_TRY(hipMemset(b->d_hist, 0, sizeof(float) * rows * b->p.avg_frames * n));
-    if (b->d_grav) HIP_TRY(hipMemset(b->d_grav, 0, sizeof(float) * rows * n));
+    size_t rows = b->rows;
+    const size_t esz = b->state16 ? sizeof(uint16_t) : sizeof(float);
+    if (b->d_hist) HIP_TRY(hipMemset(b->d_hist, 0, esz * rows * b->p.avg_frames * n));
+    if (b->d_grav) HIP_TRY(hipMemset(b->d_grav, 0, esz * rows * n));
     if (b->d_ring) HIP_TRY(hipMemset(b->d_ring, 0, sizeof(int16_t) * 2 * n * b->streams));
     if (b->d_ring_f32) HIP_TRY(hipMemset(b->d_ring_f32, 0, sizeof(float) * 2 * n * b->streams));
     b->head = 0; b->ring_pos = 0; b->ring_pos_f32 = 0; b->grav_mode = 0; b->grav_cur = b->d_grav;
@@ -698,7 +817,7 @@ int glv_batch_destroy(glv_batch* b) {
     if (b->d_bar_desc) (void) hipFree(b->d_bar_desc);
     if (b->d_bar_w) (void) hipFree(b->d_bar_w);
     if (b->d_bar_items) (void) hipFree(b->d_bar_items);
-    if (b->d_bar_fitems) (void) hipFree(b->d_bar_fitems);
+    for (glv::BarItem* f : b->d_bar_fitems) if (f) (void) hipFree(f);
     for (hipEvent_t e : b->ev) (void) hipEventDestroy(e);
     delete b;
     return GLV_OK;
@@ -737,8 +856,8 @@ static int ring_append(char* d_ring, const char* d_new, uint32_t pos, uint32_t n
     return GLV_OK;
 }
 
-// the append half of a ring update: allocate the ring on first use (unless glv_batch_create did), copy / zero-fill the new
-// frames at the write position and advance it.  *old_pos receives the position before the append.
+// the append half of a ring update: copy / zero-fill the new frames at the write position of the ring glv_batch_create
+// allocated (GLV_OP_RING_S16 / _F32) and advance it.  *old_pos receives the position before the append.
 static int ring_push(glv_batch* b, bool f32, const void* d_new, uint32_t new_frames, hipStream_t st, uint32_t* old_pos) {
     const uint32_t n = b->p.n;
     if (new_frames == 0 || new_frames > n)
@@ -746,12 +865,8 @@ static int ring_push(glv_batch* b, bool f32, const void* d_new, uint32_t new_fra
     const size_t fb = f32 ? 8 : 4;
     void** ring = f32 ? reinterpret_cast<void**>(&b->d_ring_f32) : reinterpret_cast<void**>(&b->d_ring);
     uint32_t* pos = f32 ? &b->ring_pos_f32 : &b->ring_pos;
-    if (!*ring) {
-        const size_t bytes = fb * (size_t) n * b->streams;
-        HIP_TRY(hipMalloc(ring, bytes));
-        HIP_TRY(hipMemsetAsync(*ring, 0, bytes, st));          // == the calloc'd rings of glava.c:487-494
-        *pos = 0;
-    }
+    if (!*ring)
+        return fail(GLV_ERR_STATE, "the batch was created without GLV_OP_RING_%s in its ops_mask (rings are allocated at creation, ring updates never allocate)", f32 ? "F32" : "S16");
     if (int rc = ring_append(static_cast<char*>(*ring), static_cast<const char*>(d_new), *pos, new_frames, n, fb, b->streams, st)) return rc;
     *old_pos = *pos;
     *pos = (*pos + new_frames) % n;                              // the oldest frame now sits here: the window starts there
@@ -819,6 +934,7 @@ int glv_batch_gravity_state(glv_batch* b, const float** d_state) {
     if (b->grav_mode == 2)
         return fail(GLV_ERR_STATE, "gravity runs fused with average on this batch: its state is the newest slot of the history ring "
                                    "(float [rows][F][n], not a [streams][2][n] array); request the chain's output instead");
+    if (b->state16) return fail(GLV_ERR_STATE, "gl_storage 1 keeps the gravity store as uint16 texels, not floats: request the chain's output instead");
     *d_state = b->grav_cur;
     return GLV_OK;
 }
@@ -828,7 +944,7 @@ int glv_batch_bars(glv_batch* b, const float* d_spec, float* d_bars, void* hip_s
     if (!d_spec || !d_bars) return fail(GLV_ERR_INVALID, "NULL device pointer");
     if (b->p.bars == 0 || b->p.bars > b->p.n) return fail(GLV_ERR_INVALID, "bars=%u out of range", b->p.bars);
     HIP_TRY(hipSetDevice(b->device));
-    if (int rc = ensure_bar_tables(b)) return rc;
+    if (!b->d_bar_desc) return fail(GLV_ERR_STATE, "the batch has no bar tables (bars / smooth_factor / bar_phase were unusable when it was created)");
     hipError_t e = glv::launch_bars(d_spec, d_bars, (size_t) b->streams * 2, b->p.n, b->p.bars, b->bar_nsteps, b->d_bar_items, b->d_bar_desc, b->d_bar_w,
                                     (hipStream_t) hip_stream);
     if (e != hipSuccess) return fail(GLV_ERR_HIP, "bars launch failed: %s", hipGetErrorString(e));
@@ -879,24 +995,30 @@ int glv_batch_timing_end(glv_batch* b, double* kernel_ms, uint64_t* launches) {
 uint64_t glv_batch_algorithmic_bytes(const glv_batch* b, unsigned ops, int input_is_s16) {
     if (!b) return 0;
     // SURVEY.md 8d, per stereo frame with N real samples per channel, F = avg_frames:
-    //   in: 4N (s16 x 2ch) or 8N (f32 x 2ch);  out: 8N
-    //   + gravity (no average): 20N in SURVEY 8d row B -- the output doubles as the state (what process() does unless
-    //     GLV_OP_PRIVATE_STATE asks for the batch-owned copy: one more 8N write, 28N)
+    //   in: 4N (s16 x 2ch) or 8N (f32 x 2ch);  out: 8N (f32), 4N (GLV_OP_R16 texels), 8 * bars (GLV_OP_BARS; 4 * bars as texels)
+    //   + gravity (no average): read the state 8N, write it 8N -- and the output besides, unless the output IS the state
+    //     (GLV_OP_OUTPUT_IS_STATE, or d_out == NULL: SURVEY 8d row B's 20N) or only bars leave the chip
     //   + average: read (F-1) ring slots 8N each, write the newest slot 8N (doubles as gravity state)
-    //   GLV_OP_R16: the output is 2 bytes per value: 4N instead of 8N
+    //   gl_storage 1 (GL_R16 state): every state value is a 16-bit texel -- 4N per slot instead of 8N: with F = 5 and texels out
+    //     4N + 16N + 4N + 4N = 28N
+    //   gl_storage 2 (pass by pass): the transform's f32 spectra are written and read back by the gravity / average pass (+16N)
     const uint64_t N = b->p.n, F = b->p.avg_frames;
-    uint64_t per = (input_is_s16 ? 4 * N : 8 * N) + ((ops & GLV_OP_R16) ? 4 * N : 8 * N);
-    if (ops & GLV_OP_AVERAGE) per += 8 * N * (F - 1) + 8 * N;
-    else if (ops & GLV_OP_GRAVITY) per += 8 * N + ((ops & (GLV_OP_PRIVATE_STATE | GLV_OP_R16)) ? 8 * N : 0);   // texel output: the f32 state is written besides
-    // gl_storage: the chain is the reference's pass structure -- the f32 spectra are written by the transform and read
-    // back by the gravity / average pass
-    if (b->p.gl_storage && (ops & GLV_OP_FFT) && (ops & (GLV_OP_GRAVITY | GLV_OP_AVERAGE))) per += 16 * N;
+    const bool stateful = (ops & (GLV_OP_GRAVITY | GLV_OP_AVERAGE)) != 0;
+    const uint64_t sv = (b->state16 && stateful) ? 4 * N : 8 * N;          // one state slot of both channels
+    uint64_t per = input_is_s16 ? 4 * N : 8 * N;
+    const bool bars = (ops & GLV_OP_BARS) != 0;
+    if (bars) per += (uint64_t) ((ops & GLV_OP_R16) ? 4 : 8) * b->p.bars;
+    else if (!((ops & GLV_OP_OUTPUT_IS_STATE) && !(ops & GLV_OP_AVERAGE))) per += (ops & GLV_OP_R16) ? 4 * N : 8 * N;
+    if (ops & GLV_OP_AVERAGE) per += sv * (F - 1) + sv;
+    else if (ops & GLV_OP_GRAVITY) per += 2 * sv;
+    if (b->p.gl_storage == 2 && (ops & GLV_OP_FFT) && stateful) per += 16 * N;
     return per * b->streams;
 }
 
 const char* glv_batch_kernel_name(const glv_batch* b) { return b ? b->kernel_name : ""; }
 
 int glv_batch_last_grid(const glv_batch* b) { return b ? b->last_grid : 0; }
+int glv_batch_last_launches(const glv_batch* b) { return b ? b->last_launches : 0; }
 
 int glv_wisdom_clear(void) {
     std::lock_guard<std::mutex> lock(g_wisdom_mu);
@@ -970,7 +1092,7 @@ int glv_batch_autotune(glv_batch* b, const int16_t* d_pcm, float* d_out, unsigne
     (void) hipEventDestroy(e0); (void) hipEventDestroy(e1);
     if (rc != GLV_OK) return rc;
     if (ops & (GLV_OP_GRAVITY | GLV_OP_AVERAGE)) { if (int r2 = glv_batch_reset(b)) return r2; }
-    wisdom_store(wisdom_key(b, glv::IN_S16_STEREO, ops), best.variant, best.grid, bms);
+    wisdom_store(wisdom_key(b, glv::IN_S16_STEREO, plan_ops(b, ops)), best.variant, best.grid, bms);
     if (best_grid) *best_grid = best.grid;
     if (best_ms) *best_ms = bms;
     return GLV_OK;
@@ -1022,7 +1144,7 @@ int glv_state_create(const glv_params* p, int device, glv_state** out) {
     *out = nullptr;
     glv_state* s = new (std::nothrow) glv_state();
     if (!s) return fail(GLV_ERR_NOMEM, "out of host memory");
-    int rc = batch_create_rows(p, 1, GLV_OP_GRAVITY | GLV_OP_AVERAGE, device, true, &s->b);
+    int rc = batch_create_rows(p, 1, GLV_OP_GRAVITY | GLV_OP_AVERAGE | GLV_OP_SMOOTH, device, true, &s->b);
     if (rc == GLV_OK) {
         const char* mode = std::getenv("GLV_STAGING");
         s->mapped = !(mode && std::strcmp(mode, "copy") == 0);
@@ -1045,8 +1167,9 @@ int glv_state_reset(glv_state* s) {
     glv_batch* b = s->b;
     HIP_TRY(hipSetDevice(b->device));
     const size_t n = b->p.n;
-    HIP_TRY(hipMemset(b->d_hist, 0, sizeof(float) * b->p.avg_frames * n));
-    HIP_TRY(hipMemset(b->d_grav, 0, sizeof(float) * n));
+    const size_t esz = b->state16 ? sizeof(uint16_t) : sizeof(float);
+    HIP_TRY(hipMemset(b->d_hist, 0, esz * b->p.avg_frames * n));
+    HIP_TRY(hipMemset(b->d_grav, 0, esz * n));
     b->head = 0; b->grav_mode = 0; b->grav_cur = b->d_grav;
     return GLV_OK;
 }
@@ -1073,7 +1196,8 @@ static int single(const glv_params* p, glv_state* s, float* buf, unsigned ops) {
     glv_batch* b = s->b;
     if (p->n != b->p.n || p->avg_frames != b->p.avg_frames)
         return fail(GLV_ERR_STATE, "params (n=%u, F=%u) do not match the state (n=%u, F=%u)", p->n, p->avg_frames, b->p.n, b->p.avg_frames);
-    b->p = *p;   // scalar knobs may change between calls, exactly like gl_data fields
+    // scalar knobs may change between calls, exactly like gl_data fields: what depends on them is regenerated when they do
+    if (std::memcmp(&b->p, p, sizeof(*p)) != 0) { if (int rc = glv_batch_set_params(b, p)) return rc; }
     HIP_TRY(hipSetDevice(b->device));
     const size_t bytes = sizeof(float) * p->n;
     if (s->mapped && (ops & GLV_OP_SMOOTH)) {

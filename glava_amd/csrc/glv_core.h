@@ -21,6 +21,20 @@
 #include <math.h>
 #include <stdint.h>
 
+// Experiment macros (timing experiments that produce WRONG results -- no loads, no stores, no barriers -- and A/B knobs) exist
+// for tools/tune.py's A/B libraries only.  They are quarantined behind ONE switch: a translation unit that defines any of them
+// without -DGLV_TUNE_BUILD does not compile, and glava_amd/build.py's build() -- the product -- never passes either
+// (tests/test_abi.py checks the recorded command lines).
+#if !defined(GLV_TUNE_BUILD)
+#if defined(GLV_EXP_BARS_NOLOOP) || defined(GLV_EXP_BARS_NOWLOAD) || defined(GLV_EXP_NOBARRIER) || defined(GLV_EXP_NOCOMPUTE) || \
+    defined(GLV_EXP_NOLOAD) || defined(GLV_EXP_NOSPLIT) || defined(GLV_EXP_NOSTORE) || defined(GLV_EXP_NOTWLOAD) || \
+    defined(GLV_EXP_NOWINLOAD) || defined(GLV_EXP_OLDGROUPS) || defined(GLV_EXP_PHASETIME) || defined(GLV_EXP_STOREPRIO) || \
+    defined(GLV_EXP_SWAP16) || defined(GLV_EXP_WGBARRIER) || defined(GLV_EXP_SHUFFLE) || defined(GLV_EXP_STOREWAVE) || \
+    defined(GLV_R16_SOFT) || defined(GLV_BAR_BATCH_BIG) || defined(GLV_STATE_PAIR_MAX) || defined(GLV_GL16_BLK)
+#error "GLV_EXP_* / tuning macros are for tools/tune.py A/B builds: compile with -DGLV_TUNE_BUILD (glava_amd.build.build_variant does); the product never defines them"
+#endif
+#endif
+
 #if defined(__HIPCC__)
 #define GLV_HD __host__ __device__ __forceinline__
 #else
@@ -332,6 +346,54 @@ GLV_HD float through_r16(float x) { return unorm16_to_float(unorm16(x)); }
 // render.c:730-734
 GLV_HD float gravity(float b, float applied, float g) {
     return (b >= applied ? b : applied) - g;
+}
+
+// ---- GL_R16 state (glv_params.gl_storage == 1) ---------------------------------------------------------------------------
+// Every value the GL passes of render.c:2188-2265 keep between frames lives in a GL_R16 texture (render.c:523, :1718), i.e. IS
+// a 16-bit integer: the gravity store and the ring of averaged frames are kept as what they are -- uint16 texels, two per
+// uint32 (one complex point: low half = the even float of the row) -- instead of the floats c / 65535 they read back as.
+// Lossless by construction (through_r16(x) == unorm16_to_float(unorm16(x))), half the state traffic.
+// the two floats a shader reads back from a packed texel pair (OpenGL 4.6 eq. 2.1: c / 65535, correctly rounded: div_65535)
+GLV_HD cf texels_to_float(uint32_t p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const glv_f2 K = {(float) (p & 0xffffu), (float) (p >> 16)};        // v_cvt_f32_u32 with a word selector each
+    const glv_f2 CH = {0x1.0001p-16f, 0x1.0001p-16f}, CL = {0x1.0001p-48f, 0x1.0001p-48f};
+    glv_f2 t, q;
+    asm("v_pk_mul_f32 %0, %1, %2" : "=v"(t) : "v"(K), "v"(CL));
+    asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(q) : "v"(K), "v"(CH), "v"(t));
+    return cf{q.x, q.y};
+#else
+    return cf{unorm16_to_float(p & 0xffffu), unorm16_to_float(p >> 16)};
+#endif
+}
+// The gravity pass on texels: store' = Q(max(tex, store) - g)  (GL_MAX blend render.c:2199-2210 -- exact on texel values, the
+// float comparison of c / 65535 is the integer comparison of c -- then gravity_pass.frag's subtraction and the write to the
+// GL_R16 target).  For a given g the whole step is a function of ONE 16-bit integer m = max(tex, store), and for almost every g
+// (whenever g * 65535 is not within rounding noise of a half-integer) that function is  m -> max(m - D, 0)  with one integer
+// D: the host checks this for all 65 536 values of m whenever g changes (glv_tables.h gravity_r16_integer_step) and passes
+// `sub` = D | D << 16, `exact_int` = 1; the step is then two packed 16-bit integer instructions per complex point
+// (v_pk_max_u16, v_pk_sub_u16 clamp) instead of two conversions, the two-instruction quotient, the subtraction and the
+// conversion back.  Where the check fails (exact_int = 0) the float operations run as written.
+GLV_HD uint32_t gravity_r16(uint32_t tex, uint32_t store, float g, uint32_t sub, uint32_t exact_int) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    uint32_t m;
+    asm("v_pk_max_u16 %0, %1, %2" : "=v"(m) : "v"(tex), "v"(store));
+    if (exact_int) {                                                    // uniform
+        uint32_t r;
+        asm("v_pk_sub_u16 %0, %1, %2 clamp" : "=v"(r) : "v"(m), "v"(sub));
+        return r;
+    }
+    const cf f = texels_to_float(m);
+    return pack_unorm16(f.x - g, f.y - g);
+#else
+    const uint32_t a0 = tex & 0xffffu, a1 = tex >> 16, b0 = store & 0xffffu, b1 = store >> 16;
+    const uint32_t m0 = a0 > b0 ? a0 : b0, m1 = a1 > b1 ? a1 : b1;
+    if (exact_int) {
+        const uint32_t d = sub & 0xffffu;
+        return (m0 > d ? m0 - d : 0u) | ((m1 > d ? m1 - d : 0u) << 16);
+    }
+    return unorm16(unorm16_to_float(m0) - g) | (unorm16(unorm16_to_float(m1) - g) << 16);
+#endif
 }
 
 // render.c:844: (float)(log((double)y) / 3) with y = |x| + 1.0f already rounded to float (y >= 1).

@@ -58,7 +58,12 @@ struct FrameArgs {
                            // head+1, ..., head+F-1, head  (mod F)
     uint32_t mono;         // fifo.c:98-102
     uint32_t avg_window;
-    uint32_t gl_storage;   // 1: the GL passes' GL_R16 storage is modelled (glv_post_kernel only; see apply_state)
+    uint32_t gl_storage;   // the GL passes' GL_R16 storage is modelled (apply_state / gl16_state_block).  1: the state arrays
+                           // (`grav`, `grav_w`, `hist`) hold uint16 texels -- uint16 [rows][n] / [rows][F][n], the pointers are
+                           // reinterpreted; 2: the same values kept as the floats c / 65535 (the pass-by-pass form: glv_post_kernel only)
+    uint32_t grav_sub;     // gl_storage 1: the gravity step as a packed 16-bit integer subtraction D | D << 16, valid when
+    uint32_t grav_int;     //   grav_int != 0 (glv_core.h gravity_r16, checked on the host for every texel value)
+    uint32_t bars_r16;     // fused bars of the GL_R16 chain: bars_out is uint16 [units][bars] (the smooth pass's render target)
     uint32_t log_mode;     // glv_post_kernel's OP_MAGNITUDE (the frame kernels take it as a template parameter)
     uint32_t rot;          // ring modes (RING kernels): index of the ring's oldest stereo frame = where the window starts
     float inv_n, fft_scale, one_minus_cutoff, g, F_as_float;
@@ -213,7 +218,43 @@ GLV_HD uint32_t ring_slot(uint32_t head, uint32_t f, uint32_t F) {
 // buffer (render.c:521-524), the gravity store after GL_MAX and the in-place subtraction (:2199-2228), the ring copy
 // (exact) and the average (:2230-2265, only when avg_frames > 1).  Consequences the float state machine does not have:
 // gravity's fixed point under silence is 0 (not -g), nothing exceeds 1.
+// ---- GL_R16 state, kept as texels (gl_storage == 1) ------------------------------------------------------------------------
+// The pass structure of apply_state's gl_storage branch below on uint16 state: `tex` = the uploaded point as two packed texels
+// (pack_unorm16 of the transform's output), `off` = the point's byte offset in an f32 row (its texel pair sits at off / 2).
+// Returns the texel pair the chain ends with (gravity store, or the average when F > 1).
+GLV_HD uint32_t weighted_texels(cf& acc, uint32_t p, double w, bool windowed) {
+    const cf f = texels_to_float(p);
+    if (windowed) {                                                       // average_pass.frag:41 as the oracle evaluates it
+        acc.x = (float) ((double) acc.x + w * (double) f.x);
+        acc.y = (float) ((double) acc.y + w * (double) f.y);
+    } else { acc.x = acc.x + f.x; acc.y = acc.y + f.y; }
+    return p;
+}
+GLV_HD uint32_t apply_state_r16(uint32_t tex, uint32_t off, size_t row, uint32_t n, const FrameArgs& a) {
+    const uint32_t F = a.F, o = off / 2u;
+    const bool ring = (a.ops & OP_AVERAGE) != 0;
+    uint16_t* h = ring ? reinterpret_cast<uint16_t*>(a.hist) + row * (size_t) F * n : nullptr;         // uniform
+    if (a.ops & OP_GRAVITY) {
+        const uint16_t* gs = ring ? h + (size_t) (F == 1 ? a.head : ring_slot(a.head, F - 2, F)) * n
+                                  : reinterpret_cast<const uint16_t*>(a.grav) + row * (size_t) n;
+        tex = gravity_r16(tex, ld<uint32_t>(gs, o), a.g, a.grav_sub, a.grav_int);
+        if (!ring) st<uint32_t>(reinterpret_cast<uint16_t*>(a.grav_w) + row * (size_t) n, o, tex);
+    }
+    if (ring) {
+        cf acc = { 0.0f, 0.0f };
+        for (uint32_t f = 0; f + 1 < F; ++f)                               // oldest .. second newest
+            weighted_texels(acc, ld<uint32_t>(h + (size_t) ring_slot(a.head, f, F) * n, o), a.wts[f], a.avg_window != 0);
+        st<uint32_t>(h + (size_t) a.head * n, o, tex);
+        if (F > 1) {                                                       // render.c:2230: no averaging pass for one frame
+            weighted_texels(acc, tex, a.wts[F - 1], a.avg_window != 0);
+            tex = pack_unorm16(acc.x / a.F_as_float, acc.y / a.F_as_float);
+        }
+    }
+    return tex;
+}
+
 GLV_HD cf apply_state(cf val, uint32_t off, size_t row, uint32_t n, const FrameArgs& a) {
+    if (a.gl_storage == 1) return texels_to_float(apply_state_r16(pack_unorm16(val.x, val.y), off, row, n, a));
     if (a.gl_storage) {
         val.x = through_r16(val.x); val.y = through_r16(val.y);              // the upload
         const uint32_t F = a.F;
@@ -358,6 +399,76 @@ GLV_HD void apply_state_block(cf (&val)[NV], const uint32_t (&off)[NV], size_t r
             val[e].x = gravity(val[e].x, st0[e].x, a.g); val[e].y = gravity(val[e].y, st0[e].y, a.g);
             st<cf>(gw, off[e], val[e]);
         }
+    }
+}
+
+// gl_storage == 1 inside the frame kernel: apply_state_r16 for NV complex points of one lane at once, loads first (the shape of
+// apply_state_block; same arithmetic, same order).  PAIRED: points j and j + 1 (j even) are adjacent in the row -- their four
+// texels are one 8-byte access.  TWO: two history frames per trip.
+template <int NV, bool PAIRED, bool TWO>
+GLV_HD void gl16_state_block(uint32_t (&tex)[NV], const uint32_t (&off)[NV], size_t row, uint32_t n, const FrameArgs& a) {
+    auto load = [&](uint32_t (&dst)[NV], const uint16_t* base) {
+        if constexpr (PAIRED) {
+#pragma unroll
+            for (int e = 0; e < NV; e += 2) { const u32x2 t = ld<u32x2>(base, off[e] / 2u); dst[e] = t.x; dst[e + 1] = t.y; }
+        } else {
+#pragma unroll
+            for (int e = 0; e < NV; ++e) dst[e] = ld<uint32_t>(base, off[e] / 2u);
+        }
+    };
+    auto store = [&](uint16_t* base, const uint32_t (&src)[NV]) {
+        if constexpr (PAIRED) {
+#pragma unroll
+            for (int e = 0; e < NV; e += 2) st<u32x2>(base, off[e] / 2u, u32x2{src[e], src[e + 1]});
+        } else {
+#pragma unroll
+            for (int e = 0; e < NV; ++e) st<uint32_t>(base, off[e] / 2u, src[e]);
+        }
+    };
+    const uint32_t F = a.F;
+    const bool windowed = a.avg_window != 0;
+    if (a.ops & OP_AVERAGE) {
+        uint16_t* h = reinterpret_cast<uint16_t*>(a.hist) + row * (size_t) F * n;                      // uniform
+        cf acc[NV];
+        uint32_t prev[NV];
+#pragma unroll
+        for (int e = 0; e < NV; ++e) { acc[e].x = 0.0f; acc[e].y = 0.0f; prev[e] = 0u; }
+        if (F == 1) load(prev, h + (size_t) a.head * n);                     // the gravity store of a one-frame ring is the slot itself
+        uint32_t f = 0;
+        if constexpr (TWO) for (; f + 2 < F; f += 2) {                       // oldest .. second newest, two frames per trip
+            uint32_t p0[NV];
+            load(p0, h + (size_t) ring_slot(a.head, f, F) * n);
+            load(prev, h + (size_t) ring_slot(a.head, f + 1, F) * n);
+            const double w0 = a.wts[f], w1 = a.wts[f + 1];
+#pragma unroll
+            for (int e = 0; e < NV; ++e) { weighted_texels(acc[e], p0[e], w0, windowed); weighted_texels(acc[e], prev[e], w1, windowed); }
+        }
+        for (; f + 1 < F; ++f) {
+            load(prev, h + (size_t) ring_slot(a.head, f, F) * n);
+            const double w = a.wts[f];
+#pragma unroll
+            for (int e = 0; e < NV; ++e) weighted_texels(acc[e], prev[e], w, windowed);
+        }
+        // prev == the previous newest slot == the gravity store (the same texels: render.c:2232-2243 copies it into the ring)
+        if (a.ops & OP_GRAVITY) {
+#pragma unroll
+            for (int e = 0; e < NV; ++e) tex[e] = gravity_r16(tex[e], prev[e], a.g, a.grav_sub, a.grav_int);
+        }
+        store(h + (size_t) a.head * n, tex);
+        if (F > 1) {                                                         // render.c:2230: no averaging pass for one frame
+            const double wl = a.wts[F - 1];
+#pragma unroll
+            for (int e = 0; e < NV; ++e) {
+                weighted_texels(acc[e], tex[e], wl, windowed);
+                tex[e] = pack_unorm16(acc[e].x / a.F_as_float, acc[e].y / a.F_as_float);
+            }
+        }
+    } else if (a.ops & OP_GRAVITY) {
+        uint32_t st0[NV];
+        load(st0, reinterpret_cast<const uint16_t*>(a.grav) + row * (size_t) n);
+#pragma unroll
+        for (int e = 0; e < NV; ++e) tex[e] = gravity_r16(tex[e], st0[e], a.g, a.grav_sub, a.grav_int);
+        store(reinterpret_cast<uint16_t*>(a.grav_w) + row * (size_t) n, tex);
     }
 }
 
@@ -1027,6 +1138,76 @@ struct Frame {
                     } else {
                         store_point(off[j], val[j]);
                     }
+                }
+            }
+        }
+    }
+
+    // ---- epilogue of the GL_R16 chain (glv_params.gl_storage == 1): render.c:2188-2265 inside the transform's launch ------------
+    // magnitude -> upload quantisation (render.c:521-524) -> GL_MAX + gravity pass -> ring copy -> average pass on uint16 state
+    // (gl16_state_block), then the finished texels leave as
+    //   TO_LDS        floats c / 65535 into the slot's LDS region (fused bars: smooth_audio() samples them from there),
+    //   a.ops & R16   GL_R16 texels, out_row = uint16 [n] (what the reference's `av` texture holds): 4 N bytes per frame,
+    //   otherwise     the floats c / 65535, out_row = float [n].
+    // Every stored value is a 16-bit integer by construction, so state and output move 2 bytes per value: with F = 5 a stereo
+    // frame costs 4 N (PCM) + 16 N (four ring slots) + 4 N (newest slot) + 4 N (texels) = 28 N bytes where the pass-by-pass form
+    // (f32 intermediates, three launches) moved ~80 N.
+    static constexpr int GL16_BLK = E <= 16 ? E : E / 2;       // points per block: the whole lane where the registers allow it
+    template <int LOG_MODE, int TILTREG, bool NONFINITE, bool TO_LDS>
+    GLV_HD static void epilogue_gl16(const cf (&v)[E], float* out_row, size_t row, int tid, const FrameArgs& a,
+                                     const LogEntry* logtab, const cf* tl_reg = nullptr) {
+        using PI = PassInfo<P - 1>;
+        static_assert(!SWAP16, "the GL_R16 epilogue keeps the plain last-pass layout");
+        constexpr bool PAIRED = PI::NG >= 2;
+        float tilt_base = 0.0f;
+        if constexpr (TILTREG == 3 && LOG_MODE == 1) {
+            tilt_base = tl_reg[0].x;
+#if defined(__HIP_DEVICE_COMPILE__)
+            asm volatile("" : "+v"(tilt_base));
+#endif
+        }
+        // the uploaded texel pair of register slot (gi, r): abs/log/tilt (render.c:842-846), clamp + quantise (:521-524)
+        auto texels = [&](int gi, int r) -> uint32_t {
+            const cf val = v[gi * PI::R + r];
+            const int q = out_index<P - 1>(tid, gi, r);
+            const float y0 = __builtin_fabsf(val.x) + 1.0f, y1 = __builtin_fabsf(val.y) + 1.0f;
+            cf tl;
+            if constexpr (TILTREG == 1) tl = tl_reg[gi * PI::R + r];
+            else if constexpr (TILTREG == 3 && LOG_MODE == 1) {
+                const int c = 2 * out_index<P - 1>(0, gi, r);
+                const TiltLin tlin = tilt_lin(a.inv_n, a.fft_scale, a.one_minus_cutoff);
+                tl.x = tilt_lin_at(tlin, tilt_base, c);
+                tl.y = tilt_lin_at(tlin, tilt_base, c + 1);
+            } else if constexpr (TILTREG == 2 || TILTREG == 3) {
+                tl.x = tilt_factor<LOG_MODE == 1>(2 * q, a.inv_n, a.fft_scale, a.one_minus_cutoff);
+                tl.y = tilt_factor<LOG_MODE == 1>(2 * q + 1, a.inv_n, a.fft_scale, a.one_minus_cutoff);
+            } else tl = ld<cf>(a.tilt, (uint32_t) q * 8u);
+            return pack_unorm16(log_third_nf<LOG_MODE, NONFINITE>(y0, logtab, log_tab_bits_of(LOG_NN)) * tl.x,
+                                log_third_nf<LOG_MODE, NONFINITE>(y1, logtab, log_tab_bits_of(LOG_NN)) * tl.y);
+        };
+        const bool r16_out = (a.ops & OP_R16) != 0;                                // uniform
+#pragma unroll
+        for (int h0 = 0; h0 < E; h0 += GL16_BLK) {
+            uint32_t tex[GL16_BLK], off[GL16_BLK];
+            // enumeration order: r outer, gi inner => adjacent groups sit next to each other
+#pragma unroll
+            for (int j = 0; j < GL16_BLK; ++j) {
+                const int idx = h0 + j, r = idx / PI::NG, gi = idx % PI::NG;
+                tex[j] = texels(gi, r);
+                off[j] = (uint32_t) out_index<P - 1>(tid, gi, r) * 8u;
+            }
+            gl16_state_block<GL16_BLK, PAIRED, (LOG_NN <= GLV_STATE_PAIR_MAX)>(tex, off, row, (uint32_t) N, a);
+            if (TO_LDS || !r16_out) {
+#pragma unroll
+                for (int j = 0; j < GL16_BLK; j += (PAIRED ? 2 : 1)) {
+                    if constexpr (PAIRED) { cf2 two; two.a = texels_to_float(tex[j]); two.b = texels_to_float(tex[j + 1]); st<cf2>(out_row, off[j], two); }
+                    else st<cf>(out_row, off[j], texels_to_float(tex[j]));
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < GL16_BLK; j += (PAIRED ? 2 : 1)) {
+                    if constexpr (PAIRED) st<u32x2>(out_row, off[j] / 2u, u32x2{tex[j], tex[j + 1]});
+                    else st<uint32_t>(out_row, off[j] / 2u, tex[j]);
                 }
             }
         }

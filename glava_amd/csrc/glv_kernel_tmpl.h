@@ -324,16 +324,25 @@ glv_frame_kernel(const FrameArgs a) {
     // 3: no state, output as GL_R16 texels (GLV_OP_R16: uint16 [units][n], 8N instead of 12N bytes per frame)
     // 4: gravity / average with the output as GL_R16 texels (the state stays f32).  Separate kernels, not a run-time
     // branch: a second copy of the epilogue in the stateful kernel cost N=16384 176 more bytes of scratch per lane.
-    constexpr bool FUSED_BARS = STATEFUL == 2;
-    constexpr bool HAS_STATE = STATEFUL == 1 || STATEFUL == 2 || STATEFUL == 4;
+    // 5: the GL_R16 chain (glv_params.gl_storage == 1): upload quantisation, GL_MAX + gravity pass, ring, average pass on uint16
+    // state (glv_frame.h epilogue_gl16); output GL_R16 texels or their floats (a.ops & OP_R16, uniform).  6: the same with the
+    // bars computed in the kernel (the finished row's floats go to the slot's LDS region), bars as floats or texels (a.bars_r16)
+    constexpr bool FUSED_BARS = STATEFUL == 2 || STATEFUL == 6;
+    constexpr bool GL16 = STATEFUL == 5 || STATEFUL == 6;
+    constexpr bool HAS_STATE = STATEFUL == 1 || STATEFUL == 2 || STATEFUL == 4 || GL16;
     static_assert(!FUSED_BARS || WAVE_SLOT, "fused bars need whole waves per row");
+    static_assert(!GL16 || LOG_MODE != 2, "the GL_R16 chain is built for log modes 0 and 1");
     static_assert(!FUSED_BARS || NBUF == 1, "fused bars park the finished row in exchange region 0: needs the full-size, two-barrier region");
     auto finish = [&](const cf (&v)[E], size_t row, int tid) {
         // a.out == nullptr (gravity without average only): the spectra ARE the gravity state
         // (render.c:733-734 stores the same value to both), so the second copy is not written
         float* out_row = FUSED_BARS ? reinterpret_cast<float*>(xslot)
                                     : (HAS_STATE && a.out == nullptr ? nullptr : a.out + row * N);
-        if constexpr (STATEFUL == 4) {
+        if constexpr (GL16) {
+            float* o = FUSED_BARS ? reinterpret_cast<float*>(xslot)
+                                  : ((a.ops & OP_R16) ? reinterpret_cast<float*>(reinterpret_cast<uint16_t*>(a.out) + row * N) : a.out + row * N);
+            FR::template epilogue_gl16<LOG_MODE, TILTREG, NF, FUSED_BARS>(v, o, row, tid, a, logtab, tilt_reg);
+        } else if constexpr (STATEFUL == 4) {
             float* out16 = reinterpret_cast<float*>(reinterpret_cast<uint16_t*>(a.out) + row * N);
             if (raw_out) FR::template epilogue<LOG_MODE, EPI_RAW_STATE, 0, true, NF>(v, out16, row, tid, a, logtab);
             else FR::template epilogue<LOG_MODE, EPI_MAG_STATE, TILTREG, true, NF>(v, out16, row, tid, a, logtab, tilt_reg);
@@ -403,9 +412,15 @@ glv_frame_kernel(const FrameArgs a) {
             }
             sy.sync();
             if (active) {
+                if (GL16 && a.bars_r16) {                  // uniform: the bars as GL_R16 texels (the smooth pass's render target, render.c:2277-2303)
+                    uint16_t* bo = reinterpret_cast<uint16_t*>(a.bars_out) + row * a.bars;
+                    if ((uint32_t) tid < a.bars) bo[tid] = (uint16_t) unorm16(lres[tid] / bar_wsum);
+                    for (uint32_t k = (uint32_t) tid + T; k < a.bars; k += T) bo[k] = (uint16_t) unorm16(lres[k] / a.bar_desc[k].weight_sum);
+                } else {
                 if ((uint32_t) tid < a.bars) a.bars_out[row * a.bars + (uint32_t) tid] = lres[tid] / bar_wsum;
                 // more bars than lanes (N=1024: 64 lanes, 80 bars): a second trip, its weight sums from L2
                 for (uint32_t k = (uint32_t) tid + T; k < a.bars; k += T) a.bars_out[row * a.bars + k] = lres[k] / a.bar_desc[k].weight_sum;
+                }
             }
             // the next row's first exchange write is preceded by a barrier (NBUF == 1): the bars readers are safe
         } else {
@@ -627,12 +642,26 @@ hipError_t launch_variant(const FrameArgs& a, int grid, hipStream_t st) {
                 if (dev >= 0 && dev < 64) done.dev[dev].store(true, std::memory_order_release);
             }
         }
+        if (grid <= 0) return hipSuccess;             // attribute only: glv_api.cpp batch_prepare readies the kernels a batch may launch, so
+                                                      // that no process call changes a function attribute (a first call can be captured)
         hipLaunchKernelGGL(k, dim3(grid), dim3(FR::T * SLOTS), lds, st, a);
         return hipGetLastError();
     };
     static AttrDone done_plain, done_state, done_r16, done_state_r16;   // per instantiation
     // the stateful epilogue needs the registers a resident last pass (TWREG 3) would occupy
     constexpr int TW_STATEFUL = TWREG == 3 ? 2 : TWREG;
+    // the GL_R16 chain (gl_storage == 1: uint16 state): built for log modes 0 and 1
+    if (a.gl_storage == 1 && (a.ops & (OP_GRAVITY | OP_AVERAGE))) {
+        if constexpr (LOG_MODE != 2) {
+            static AttrDone done_gl16, done_gl16_bars;
+            if (a.bars_out != nullptr) {
+                if constexpr (FR::T % 64 == 0 && NBUF == 1)
+                    return launch(glv_frame_kernel<LOG_NN, IN_MODE, LOG_MODE, SLOTS, NBUF, TW_STATEFUL, WINLDS, OCC, PREFETCH, TILTREG, LOG_E, 6, WPRE_S>, done_gl16_bars);
+                else return hipErrorInvalidValue;
+            }
+            return launch(glv_frame_kernel<LOG_NN, IN_MODE, LOG_MODE, SLOTS, NBUF, TW_STATEFUL, WINLDS, OCC, PREFETCH, TILTREG, LOG_E, 5, WPRE_S>, done_gl16);
+        } else return hipErrorInvalidValue;
+    }
     if (a.bars_out != nullptr) {
         if constexpr (FR::T % 64 == 0 && NBUF == 1) {
             static AttrDone done_bars;

@@ -42,6 +42,20 @@ inline void make_frame_weights(double* w, size_t F, bool use_window, int kind) {
     }
 }
 
+// The gravity pass on GL_R16 texels (glv_core.h gravity_r16): is  m -> unorm16(unorm16_to_float(m) - g)  the integer step
+// m -> max(m - D, 0) for EVERY texel value m?  Checked exhaustively (65 536 evaluations of the float expression the pass is
+// defined by); *sub receives D | D << 16.  False for steps that raise values (g < 0) or where g * 65535 sits so close to a
+// half-integer that float rounding decides texel by texel -- the kernels then evaluate the float expression as written.
+inline bool gravity_r16_integer_step(float g, uint32_t* sub) {
+    const uint32_t top = unorm16(unorm16_to_float(65535u) - g);
+    const uint32_t d = 65535u - top;                    // the only candidate: the step taken from the largest texel
+    *sub = d | (d << 16);
+    if (top > 65535u) return false;
+    for (uint32_t m = 0; m < 65536u; ++m)
+        if (unorm16(unorm16_to_float(m) - g) != (m > d ? m - d : 0u)) return false;
+    return true;
+}
+
 // All radix-2 stages of an nn-point transform: stage with half size L at [L-1, 2L-1).
 inline void make_twiddles(cf* table, size_t nn) {
     for (size_t L = 1; L < nn; L <<= 1) {

@@ -19,7 +19,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("GLV_SPECTRUM_LIB") or os.path.join(HERE, "csrc", "libglvspectrum.so")
 
 OP_FFT, OP_GRAVITY, OP_AVERAGE, OP_RAW, OP_WRANGE, OP_BARS, OP_SMOOTH, OP_MAGNITUDE, OP_R16 = 1, 2, 4, 8, 16, 32, 64, 128, 256
-OP_PRIVATE_STATE, OP_RING_S16, OP_RING_F32 = 512, 1024, 2048
+OP_PRIVATE_STATE, OP_RING_S16, OP_RING_F32, OP_OUTPUT_IS_STATE = 512, 1024, 2048, 4096
 OK, ERR_INVALID, ERR_NO_DEVICE, ERR_HIP, ERR_NOMEM, ERR_STATE = 0, 1, 2, 3, 4, 5
 
 
@@ -77,6 +77,7 @@ def lib() -> C.CDLL:
         L.glv_unpack_s16.argtypes = [C.c_int, vp, C.c_size_t, C.c_int, vp, vp]
         L.glv_batch_create.argtypes = [P, C.c_uint32, C.c_uint, C.c_int, C.POINTER(vp)]
         L.glv_batch_reset.argtypes = [vp]
+        L.glv_batch_set_params.argtypes = [vp, P]
         L.glv_batch_destroy.argtypes = [vp]
         L.glv_batch_process_s16.argtypes = [vp, vp, vp, C.c_uint, vp]
         L.glv_batch_process_f32.argtypes = [vp, vp, vp, C.c_uint, vp]
@@ -97,6 +98,7 @@ def lib() -> C.CDLL:
         L.glv_batch_kernel_name.argtypes = [vp]; L.glv_batch_kernel_name.restype = C.c_char_p
         L.glv_batch_set_grid.argtypes = [vp, C.c_int]
         L.glv_batch_last_grid.argtypes = [vp]
+        L.glv_batch_last_launches.argtypes = [vp]
         L.glv_batch_variants.argtypes = [vp]
         L.glv_batch_set_variant.argtypes = [vp, C.c_int]
         L.glv_batch_last_variant.argtypes = [vp]
@@ -169,7 +171,17 @@ class Batch:
         cp = params.c()
         _check(lib().glv_batch_create(C.byref(cp), streams, ops_mask, device, C.byref(self._h)))
 
+    def set_params(self, params: Params) -> None:
+        """glv_batch_set_params: change scalar knobs (synchronous: tables are regenerated); n, avg_frames and the state's storage
+        class are fixed at creation"""
+        cp = params.c()
+        _check(lib().glv_batch_set_params(self._h, C.byref(cp)))
+        self.params = params
+
     def process_s16(self, d_pcm, d_out, ops: int = OP_FFT, stream: int | None = None) -> None:
+        """one update of every stream; stream-ordered (never allocates, never copies synchronously).  Chains ending in gravity
+        keep their state in a batch-owned buffer; with OP_OUTPUT_IS_STATE d_out itself becomes the state the next update reads
+        (leave it intact until then; see include/glv_spectrum.h)."""
         _check(lib().glv_batch_process_s16(self._h, _ptr(d_pcm), _ptr(d_out), ops, _ptr(stream)))
 
     def process_f32(self, d_in, d_out, ops: int = OP_FFT, stream: int | None = None) -> None:
@@ -225,6 +237,10 @@ class Batch:
 
     def last_grid(self) -> int:
         return int(lib().glv_batch_last_grid(self._h))
+
+    def last_launches(self) -> int:
+        """kernels the last process / ring-update call launched"""
+        return int(lib().glv_batch_last_launches(self._h))
 
     def variants(self) -> int:
         """kernel configurations built for this size (glv_inst.hip Tuned<K, V>)"""

@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define GLV_ABI_VERSION 3
+#define GLV_ABI_VERSION 4
 
 /* status codes (0 = ok).  The reference has no error channel: it prints and calls
  * glava_abort() (glava/glava.h:17, glava/render.c passim); the in-tree shim maps any
@@ -71,16 +71,27 @@ enum {
                                    uint16 [streams][2][bars]; the spectra feeding them stay f32): with gl_storage = 1, bars = n and
                                    bar_phase = 0.5 that is the texture every stock module samples -- upload, gravity, average and
                                    pre-smoothing pass of render.c:2188-2303 in one call.  Excludes GLV_OP_RAW, GLV_OP_SMOOTH. */
-    GLV_OP_PRIVATE_STATE = 1u << 9, /* with a chain that ENDS in gravity (GLV_OP_GRAVITY without AVERAGE / SMOOTH / RAW): keep
-                                   gravity's `applied` array in a buffer owned by the batch, as transform_gravity does
-                                   (render.c:724; :733-734 store every value twice).  Without this flag the output buffer IS the
-                                   state (see glv_batch_process_s16) and the chain moves SURVEY 8d's 20 n bytes per frame
-                                   instead of 28 n */
+    GLV_OP_PRIVATE_STATE = 1u << 9, /* (ABI 3 flag, accepted and ignored since ABI 4: a batch-owned gravity state is the default again) */
     GLV_OP_RING_S16 = 1u << 10, /* glv_batch_create's ops_mask only: allocate (and zero, == the calloc'd rings of
                                    glava.c:487-494) the s16 device ring of glv_batch_ring_update_s16 at creation; without it
                                    the first ring update allocates, i.e. synchronises */
-    GLV_OP_RING_F32 = 1u << 11  /* the same for the interleaved f32 ring of glv_batch_ring_update_f32 */
+    GLV_OP_RING_F32 = 1u << 11, /* the same for the interleaved f32 ring of glv_batch_ring_update_f32 */
+    GLV_OP_OUTPUT_IS_STATE = 1u << 12 /* opt-in, with a chain that ENDS in gravity (GLV_OP_GRAVITY without AVERAGE / SMOOTH / RAW, f32
+                                   rows out, no gl_storage): transform_gravity stores every value twice, to its `applied` array and to
+                                   the buffer (render.c:733-734) -- with this flag ONE array is kept: the call writes the spectra
+                                   once, into d_out, and the NEXT update of the batch reads its `applied` values from there.  The
+                                   caller promises to leave that buffer intact until the next update has been issued (the same
+                                   buffer every time, or several in rotation; stream order is all the synchronisation needed) and
+                                   not to alias it with the input.  The chain then moves SURVEY 8d row B's 20 n bytes per frame
+                                   instead of 28 n.  Without the flag the state lives in a buffer the batch owns (the default: a
+                                   caller may post-process, reuse or free d_out at will) */
 };
+/* Bits glv_batch_create's ops_mask understands: GLV_OP_GRAVITY / GLV_OP_AVERAGE (state arrays), GLV_OP_BARS (tap tables, work
+ * lists and -- where the announced chain cannot compute the bars inside the transform's launch -- the internal spectra rows),
+ * GLV_OP_SMOOTH (window bounds), GLV_OP_RING_S16 / GLV_OP_RING_F32 (device rings).  Everything a process call of those operators
+ * needs is allocated and uploaded at creation (or by glv_batch_set_params): the process calls themselves never allocate, never
+ * copy synchronously and can be captured into a hipGraph from the first one on.  An operator whose tables the batch was not
+ * created with is refused with GLV_ERR_STATE. */
 
 /* Mirrors the fields of the private `struct gl_data` that the path reads
  * (glava/render.c:166-207) and of `struct audio_data` (glava/fifo.h:9-20). */
@@ -115,12 +126,18 @@ typedef struct glv_params {
     float smooth_distance;  /* default 0.01 */
     float smooth_ratio;     /* default 4 */
     uint32_t gl_storage;    /* 0 (default): gravity / average keep float state, like the CPU operators (render.c:720-771).
-                               1: the storage of the GL passes is modelled (render.c:2188-2265 with setaccelfft: every
-                               intermediate is a GL_R16 texture, render.c:523, :1718): the uploaded buffer, the gravity store
-                               after each step and the average are clamped to [0, 1] and quantised to 16 bits; no averaging
-                               pass when avg_frames == 1 (render.c:2230).  Usually combined with avg_window_kind = 1.  The
-                               chain then runs as the reference's does, pass by pass: the frame kernel produces the spectra,
-                               a second kernel applies gravity / average on them. */
+                               1: the storage of the GL passes is modelled (render.c:2188-2265 with setaccelfft, GLava's shipped
+                               default rc.glsl:211: every intermediate is a GL_R16 texture, render.c:523, :1718): the uploaded
+                               buffer, the gravity store after each step and the average are clamped to [0, 1] and quantised to 16
+                               bits; no averaging pass when avg_frames == 1 (render.c:2230).  Usually combined with
+                               avg_window_kind = 1.  The state IS kept as 16-bit texels (uint16 store and ring) and an FFT chain
+                               runs as ONE launch: upload quantisation, GL_MAX + gravity pass, ring copy and average pass are the
+                               transform kernel's epilogue (with GLV_OP_BARS, where a row's bars fit, also the bars); the output is
+                               GL_R16 texels (GLV_OP_R16) or their floats c / 65535.  28 n bytes per frame at avg_frames = 5.
+                               2: the same values, pass by pass as the reference runs them: the transform writes f32 spectra, a
+                               second kernel applies gravity / average on f32 state (every value a float c / 65535).  Bit-identical
+                               to 1 on every input; kept as the checker of 1 and for the chains 1 does not fuse.  The storage
+                               class (1 vs 0 / 2) is fixed when a batch or state is created. */
     float bar_phase;        /* GLV_OP_BARS evaluates smooth_audio() at idx = (k + bar_phase) / bars, k = 0 .. bars-1.
                                0 (default): the bar positions of the modules (radial/1.frag:58-70: pos = k / (NBARS / 2)).
                                0.5 with bars == n: the texel centres of the reference's pre-smoothing pass
@@ -206,28 +223,27 @@ int glv_device_sync(int device, void* hip_stream);
 typedef struct glv_batch glv_batch;
 
 int glv_batch_create(const glv_params* p, uint32_t streams, unsigned ops_mask, int device, glv_batch** out);
+/* Change the scalar knobs of a batch (fft_scale, fft_cutoff, gravity_step, ur, avg_window*, log_mode, channels, bars,
+ * smooth_*, bar_phase, gl_storage 0 <-> 2): regenerates and uploads whatever tables depend on them -- synchronously; this is the
+ * only place besides creation that allocates or copies.  n, avg_frames and the state's storage class (gl_storage == 1 or not)
+ * are fixed at creation (GLV_ERR_STATE).  State (gravity, history, rings) is kept. */
+int glv_batch_set_params(glv_batch* b, const glv_params* p);
 int glv_batch_reset(glv_batch* b);
 int glv_batch_destroy(glv_batch* b);
 
-/* one update of every stream from s16 PCM already resident in HBM.
+/* one update of every stream from s16 PCM already resident in HBM.  Stream-ordered: nothing is allocated, nothing is copied
+ * synchronously; the call can be captured into a hipGraph.
  *
- * OUTPUT == STATE for chains that end in gravity (GLV_OP_GRAVITY without AVERAGE / SMOOTH / RAW): transform_gravity
- * stores every value to its `applied` array AND to the buffer (render.c:733-734) -- one array is enough.  Such a call
- * writes the spectra once, into d_out, and the NEXT update reads its `applied` values from there: the caller must leave
- * that buffer intact until the next update of the batch has been issued (pass the same buffer every time, or alternate
- * between several; ordinary stream order is all the synchronisation needed).  The chain then moves the 20 n bytes per
- * frame of SURVEY 8d row B.  A batch-owned copy of the state (28 n) is kept instead
- *   - when GLV_OP_PRIVATE_STATE is set (callers that post-process d_out in place),
- *   - when the transform runs in place on its own input (d_out == the f32 input: the reference's calling convention,
- *     used by the single-stream drop-ins -- the next input would overwrite the state),
- *   - with GLV_OP_R16 / GLV_OP_BARS outputs and with gl_storage (the state is not what d_out receives).
- * d_out may also be NULL for such a chain: the spectra are then left in the batch-owned state buffer only -- read them
- * through glv_batch_gravity_state.  (With GLV_OP_BARS a chain ending in gravity does this internally.) */
+ * Chains that end in gravity (GLV_OP_GRAVITY without AVERAGE / SMOOTH / RAW): the state lives in a buffer the batch owns and
+ * d_out receives a copy (28 n bytes per frame); d_out may be NULL -- the spectra are then left in the state buffer only, read
+ * them through glv_batch_gravity_state (20 n).  With GLV_OP_OUTPUT_IS_STATE d_out itself becomes the state (20 n; see the flag
+ * for what the caller promises).  (With GLV_OP_BARS a chain ending in gravity keeps the spectra in the state internally.) */
 int glv_batch_process_s16(glv_batch* b, const int16_t* d_pcm, float* d_out, unsigned ops, void* hip_stream);
 /* device pointer to the gravity state float [streams][2][n] == the latest output of a chain ending in gravity: the
- * batch-owned buffer, or the caller's d_out of the latest call when that doubles as the state (above).
- * GLV_ERR_STATE if the batch was created without GLV_OP_GRAVITY, and after fused gravity + average calls (the state is
- * then the newest slot of the history ring, float [rows][F][n] -- not an array of this shape). */
+ * batch-owned buffer, or the caller's d_out of the latest call when that doubles as the state (GLV_OP_OUTPUT_IS_STATE).
+ * GLV_ERR_STATE if the batch was created without GLV_OP_GRAVITY, after fused gravity + average calls (the state is
+ * then the newest slot of the history ring, float [rows][F][n] -- not an array of this shape), and with gl_storage == 1 (the
+ * state is uint16 texels). */
 int glv_batch_gravity_state(glv_batch* b, const float** d_state);
 /* same from planar f32 (the lb/rb snapshot) */
 int glv_batch_process_f32(glv_batch* b, const float* d_f32, float* d_out, unsigned ops, void* hip_stream);
@@ -273,6 +289,8 @@ uint64_t glv_batch_algorithmic_bytes(const glv_batch* b, unsigned ops, int input
 /* Launch-geometry override for tuning (workgroups of the persistent frame kernel; 0 = automatic). */
 int glv_batch_set_grid(glv_batch* b, int grid);
 int glv_batch_last_grid(const glv_batch* b);      /* workgroups the last frame-kernel launch of this batch used */
+int glv_batch_last_launches(const glv_batch* b);  /* kernels the last process / ring-update call of this batch launched (1 for every
+                                                     FFT chain that runs fused; the ring copies of an update are not kernels) */
 /* Kernel configurations of the batch's size: the library carries, per transform size, the configuration that won the
  * build-time sweeps (variant 0) and the runners-up that came close (a different radix split / points per lane, rows per
  * workgroup, placement of the window and twiddle tables); for s16 frame / ring input with log_mode 0 or 1 -- other

@@ -46,6 +46,11 @@ struct Emu {
     template <bool NF>
     static void finish(std::vector<Thread>& th, float* out_row, size_t row, const FrameArgs& a) {
         const bool st = (a.ops & (OP_GRAVITY | OP_AVERAGE)) != 0, raw = (a.ops & OP_RAW) != 0;
+        if (a.gl_storage == 1 && st && !raw) {       // the fused GL_R16 chain (kernel class 5): texels or their floats, as a.ops & OP_R16 says
+            float* o = (a.ops & OP_R16) ? reinterpret_cast<float*>(reinterpret_cast<uint16_t*>(a.out) + row * N) : out_row;
+            for (int tid = 0; tid < T; ++tid) FR::template epilogue_gl16<LOG_MODE, 0, NF, false>(th[tid].v, o, row, tid, a, a.logtab);
+            return;
+        }
         for (int tid = 0; tid < T; ++tid) {
             if (raw && st)       FR::template epilogue<LOG_MODE, EPI_RAW_STATE, 0, false, NF>(th[tid].v, out_row, row, tid, a, a.logtab);
             else if (raw)        FR::template epilogue<LOG_MODE, EPI_RAW, 0, false, NF>(th[tid].v, out_row, row, tid, a, a.logtab);
@@ -114,10 +119,23 @@ extern "C" {
 // n: real samples per channel.  in: s16 [units/2][n][2] (in_mode 0) or f32 [units][n] (in_mode 1);
 // units = channel rows.
 // grav / hist may be NULL when the op is not requested.  Returns 0 on success.
+// gl_storage 1: grav / hist are uint16 arrays (texels), out is uint16 rows when ops has OP_R16; force_float_gravity: evaluate the
+// gravity step with the float expression even where the integer form is proven (both must give the same texels)
+int glvemu_process_gl(int n, int in_mode, const void* in, float* out, float* grav, float* hist,
+                      unsigned units, unsigned ops, unsigned F, unsigned head, int mono, int avg_window,
+                      int avg_kind, int log_mode, float fft_scale, float fft_cutoff, float gravity_step, float ur,
+                      unsigned rot, int log_e, int gl_storage, int force_float_gravity);
 int glvemu_process(int n, int in_mode, const void* in, float* out, float* grav, float* hist,
                    unsigned units, unsigned ops, unsigned F, unsigned head, int mono, int avg_window,
                    int avg_kind, int log_mode, float fft_scale, float fft_cutoff, float gravity_step, float ur,
                    unsigned rot, int log_e) {
+    return glvemu_process_gl(n, in_mode, in, out, grav, hist, units, ops, F, head, mono, avg_window, avg_kind, log_mode, fft_scale, fft_cutoff,
+                             gravity_step, ur, rot, log_e, 0, 0);
+}
+int glvemu_process_gl(int n, int in_mode, const void* in, float* out, float* grav, float* hist,
+                      unsigned units, unsigned ops, unsigned F, unsigned head, int mono, int avg_window,
+                      int avg_kind, int log_mode, float fft_scale, float fft_cutoff, float gravity_step, float ur,
+                      unsigned rot, int log_e, int gl_storage, int force_float_gravity) {
     int log_nn = 0;
     while ((2 << log_nn) < n) ++log_nn;
     if ((2 << log_nn) != n) return 2;
@@ -136,6 +154,8 @@ int glvemu_process(int n, int in_mode, const void* in, float* out, float* grav, 
     a.units = units; a.ops = ops; a.F = F; a.head = head; a.mono = mono; a.avg_window = avg_window; a.rot = rot;
     a.inv_n = 1.0f / (float) n; a.fft_scale = fft_scale; a.one_minus_cutoff = 1.0f - fft_cutoff;
     a.g = gravity_step * (1.0f / ur); a.F_as_float = (float) F;
+    a.gl_storage = (uint32_t) gl_storage;
+    a.grav_int = gravity_r16_integer_step(a.g, &a.grav_sub) && !force_float_gravity ? 1u : 0u;
     if (F > 64) return 3;
     make_frame_weights(a.wts, F, avg_window != 0, avg_kind);
     if (log_e == 5) return log_mode == 0 ? dispatch<0, 5>(log_nn, in_mode, a) : log_mode == 1 ? dispatch<1, 5>(log_nn, in_mode, a) : dispatch<2, 5>(log_nn, in_mode, a);
@@ -144,8 +164,9 @@ int glvemu_process(int n, int in_mode, const void* in, float* out, float* grav, 
 }
 
 
-// glv_post_kernel's loop on the host: gravity / average (optionally with the GL_R16 storage model, glv_params.gl_storage)
-// on planar rows through the same apply_state the kernel calls.  Returns 0 on success.
+// glv_post_kernel's loop on the host: gravity / average (optionally with the GL_R16 storage model, glv_params.gl_storage:
+// 2 = float state, 1 = grav / hist point at uint16 texel arrays) on planar rows through the same apply_state the kernel calls.
+// Returns 0 on success.
 int glvemu_post_state(const float* in, float* out, float* grav, float* hist, int n, unsigned rows, unsigned ops, unsigned F,
                       unsigned head, int avg_window, int avg_kind, int gl_storage, float gravity_step, float ur) {
     if (F == 0 || F > 64) return 3;
@@ -153,6 +174,7 @@ int glvemu_post_state(const float* in, float* out, float* grav, float* hist, int
     std::memset(&a, 0, sizeof(a));
     a.in = in; a.out = out; a.grav = grav; a.grav_w = grav; a.hist = hist; a.units = rows; a.ops = ops; a.F = F; a.head = head;
     a.avg_window = avg_window; a.gl_storage = gl_storage; a.g = gravity_step * (1.0f / ur); a.F_as_float = (float) F;
+    a.grav_int = gravity_r16_integer_step(a.g, &a.grav_sub) ? 1u : 0u;       // gl_storage 1: grav / hist are uint16 arrays
     make_frame_weights(a.wts, F, avg_window != 0, avg_kind);
     for (unsigned r = 0; r < rows; ++r)
         for (int q = 0; q < n / 2; ++q) {
@@ -260,3 +282,13 @@ int glvemu_bar_items_check(int n, int bars, float smooth_factor, int groups) {
     return 0;
 }
 }  // extern "C"
+
+extern "C" {
+// glv_tables.h gravity_r16_integer_step: 1 when the gravity pass on texels is m -> max(m - D, 0) for every texel value (D -> *d)
+int glvemu_gravity_step(float gravity_step, float ur, unsigned* d) {
+    uint32_t sub = 0;
+    const bool ok = glv::gravity_r16_integer_step(gravity_step * (1.0f / ur), &sub);
+    if (d) *d = sub & 0xffffu;
+    return ok ? 1 : 0;
+}
+}

@@ -206,10 +206,11 @@ def _hip_copy_to_host(ptr, count):
 
 @pytest.mark.parametrize("n", [1024, 4096, 16384])
 def test_gravity_output_is_the_state(G, n):
-    """A chain ending in gravity writes its spectra ONCE: the caller's buffer is the `applied` array of the
-    next update (render.c:733-734 store the same value twice).  Same buffer every call, alternating buffers, the explicit
-    private copy and the d_out = NULL form all give the oracle's bits on the raw values and each other's bits on magnitudes;
-    clobbering the output between updates is harmless only with GLV_OP_PRIVATE_STATE."""
+    """With GLV_OP_OUTPUT_IS_STATE (opt-in since ABI 4) a chain ending in gravity writes its spectra ONCE (SURVEY 8d
+    row B): the caller's buffer is the `applied` array of the next update (render.c:733-734 store the same value twice).  Same
+    buffer every call, alternating buffers, the default batch-owned state and the d_out = NULL form all give the oracle's bits on
+    the raw values and each other's bits on magnitudes; clobbering the output between updates is harmless by default and matters
+    only to the caller who opted in."""
     import torch
     streams, updates = 7, 5
     ops = G.OP_FFT | G.OP_GRAVITY
@@ -220,13 +221,14 @@ def test_gravity_output_is_the_state(G, n):
     o_priv, o_raw = torch.empty_like(o_same), torch.empty_like(o_same)
     sos = [StreamOracle(n, average=False) for _ in range(streams)]
     grav_raw = np.zeros((streams * 2, n), np.float32)
-    assert same.algorithmic_bytes(ops) == 20 * n * streams and same.algorithmic_bytes(ops | G.OP_PRIVATE_STATE) == 28 * n * streams
+    OIS = G.OP_OUTPUT_IS_STATE
+    assert same.algorithmic_bytes(ops | OIS) == 20 * n * streams and same.algorithmic_bytes(ops) == 28 * n * streams
     for u in range(updates):
         pcm = lcg_pcm_fast(5100 + 31 * u + n, streams * 2 * n)
         d_pcm = torch.from_numpy(pcm).cuda()
-        same.process_s16(d_pcm, o_same, ops)
-        alt.process_s16(d_pcm, o_alt[u % 3], ops)
-        priv.process_s16(d_pcm, o_priv, ops | G.OP_PRIVATE_STATE)
+        same.process_s16(d_pcm, o_same, ops | OIS)
+        alt.process_s16(d_pcm, o_alt[u % 3], ops | OIS)
+        priv.process_s16(d_pcm, o_priv, ops | (G.OP_PRIVATE_STATE if u % 2 else 0))     # the ABI 3 flag is accepted and means the default
         none_.process_s16(d_pcm, None, ops)
         rawb.process_s16(d_pcm, o_raw, ops | G.OP_RAW)              # RAW chains keep a private state (the output is not the state's meaning)
         torch.cuda.synchronize()
@@ -247,15 +249,19 @@ def test_gravity_output_is_the_state(G, n):
                 row = np.ascontiguousarray(wraw[c]); Oracle.gravity(row, grav_raw[2 * s + c])
                 assert (bits(raw[2 * s + c]) == bits(row)).all(), (u, s, c)
         o_priv.fill_(float("nan"))                                  # the private copy does not care
-    # without the private copy the caller's buffer IS the state: overwrite it and the next update starts from what it holds
+    # opted in, the caller's buffer IS the state: overwrite it and the next update starts from what it holds
     o_same.zero_()
     pcm = lcg_pcm_fast(99, streams * 2 * n); d_pcm = torch.from_numpy(pcm).cuda()
-    same.process_s16(d_pcm, o_same, ops)
+    same.process_s16(d_pcm, o_same, ops | OIS)
     fresh = G.Batch(p, streams, G.OP_GRAVITY)
     o_fresh = torch.empty_like(o_same)
     fresh.process_s16(d_pcm, o_fresh, ops)                          # a fresh batch starts from zeros too
     assert torch.equal(o_same.view(torch.int32), o_fresh.view(torch.int32))
-    priv.process_s16(d_pcm, o_priv, ops | G.OP_PRIVATE_STATE)       # ... whereas this one continues its own history
+    priv.process_s16(d_pcm, o_priv, ops)                            # ... whereas this one continues its own history
+    with pytest.raises(G.GlvError):                                 # the flag is refused where the output is not the state's meaning
+        rawb.process_s16(d_pcm, o_raw, ops | G.OP_RAW | OIS)
+    with pytest.raises(G.GlvError):
+        same.process_s16(d_pcm, None, ops | OIS)
     assert not torch.equal(o_priv.view(torch.int32), o_fresh.view(torch.int32))
     for b in (same, alt, priv, none_, rawb, fresh): b.close()
 
@@ -274,6 +280,8 @@ def test_gravity_state_after_fused_average_is_refused(G):
     assert ei.value.code == G.ERR_STATE
     b.reset()
     b.process_s16(d_pcm, d_out, G.OP_FFT | G.OP_GRAVITY)
+    assert b.gravity_state() not in (0, d_out.data_ptr())           # the batch-owned state (the default since ABI 4)
+    b.process_s16(d_pcm, d_out, G.OP_FFT | G.OP_GRAVITY | G.OP_OUTPUT_IS_STATE)
     assert b.gravity_state() == d_out.data_ptr()
     b.close()
 
@@ -284,7 +292,7 @@ def test_rings_allocated_at_creation(G):
     import torch
     n, streams, nf = 2048, 5, 256
     a = G.Batch(G.Params(n=n), streams, G.OP_FFT | G.OP_RING_S16 | G.OP_RING_F32)
-    b = G.Batch(G.Params(n=n), streams, G.OP_FFT)
+    b = G.Batch(G.Params(n=n), streams, G.OP_FFT | G.OP_RING_S16 | G.OP_RING_F32)
     oa = torch.empty((streams * 2, n), dtype=torch.float32, device="cuda"); ob = torch.empty_like(oa)
     for u in range(3):
         new = torch.from_numpy(lcg_pcm_fast(40 + u, streams * nf * 2)).cuda()
@@ -350,13 +358,13 @@ def test_every_kernel_variant_gives_the_same_bits(G, n):
     nv = None
     for log_mode in (1, 0):
         per_variant = []
-        probe = G.Batch(G.Params(n=n, log_mode=log_mode), streams, G.OP_FFT)
+        probe = G.Batch(G.Params(n=n, log_mode=log_mode), streams, G.OP_FFT | G.OP_BARS | G.OP_RING_S16)
         nv = probe.variants(); probe.close()
         assert nv >= 2, "this size is expected to carry a runner-up configuration"
         for v in range(nv):
             p = G.Params(n=n, log_mode=log_mode, avg_frames=F)
             out = {}
-            b = G.Batch(p, streams, G.OP_FFT | G.OP_RING_S16); b.set_variant(v)
+            b = G.Batch(p, streams, G.OP_FFT | G.OP_RING_S16 | G.OP_BARS); b.set_variant(v)
             assert "variant %d" % v in b.describe_variant(v)
             o = torch.empty((streams * 2, n), dtype=torch.float32, device="cuda")
             b.process_s16(pcm[0], o, G.OP_FFT | G.OP_RAW); out["raw"] = o.clone(); assert b.last_variant() == v
@@ -365,15 +373,15 @@ def test_every_kernel_variant_gives_the_same_bits(G, n):
             b.process_s16(pcm[0], q, G.OP_FFT | G.OP_R16); out["r16"] = q.clone()
             b.ring_update_s16(new, nf, o, G.OP_FFT); out["ring"] = o.clone(); assert b.last_variant() == v
             b.close()
-            bc = G.Batch(p, streams, G.OP_GRAVITY | G.OP_AVERAGE); bc.set_variant(v)
-            bb = G.Batch(p, streams, G.OP_GRAVITY | G.OP_AVERAGE); bb.set_variant(v)
+            bc = G.Batch(p, streams, G.OP_GRAVITY | G.OP_AVERAGE | G.OP_BARS | G.OP_RING_S16); bc.set_variant(v)
+            bb = G.Batch(p, streams, G.OP_GRAVITY | G.OP_AVERAGE | G.OP_BARS | G.OP_RING_S16); bb.set_variant(v)
             d_bars = torch.empty((streams * 2, p.bars), dtype=torch.float32, device="cuda")
             for u in range(3):
                 bc.process_s16(pcm[u], o, G.OP_FFT | G.OP_GRAVITY | G.OP_AVERAGE); out["chain%d" % u] = o.clone()
                 bb.process_s16(pcm[u], d_bars, G.OP_FFT | G.OP_GRAVITY | G.OP_AVERAGE | G.OP_BARS); out["bars%d" % u] = d_bars.clone()
             bc.close(); bb.close()
             # f32 inputs have variant 0 only: a forced variant falls back instead of failing
-            bf = G.Batch(p, streams, G.OP_FFT); bf.set_variant(v)
+            bf = G.Batch(p, streams, G.OP_FFT | G.OP_BARS | G.OP_RING_S16); bf.set_variant(v)
             x = torch.from_numpy((np.random.default_rng(n).standard_normal((streams * 2, n)) * 0.3).astype(np.float32)).cuda()
             bf.process_f32(x, o, G.OP_FFT); out["f32"] = o.clone(); assert bf.last_variant() == 0
             bf.close()
@@ -388,6 +396,6 @@ def test_every_kernel_variant_gives_the_same_bits(G, n):
         _, want = StreamOracle(n, gravity=False, average=False).frame(pcm0[s * 2 * n:(s + 1) * 2 * n], want_raw=True)
         assert (bits(raw[2 * s:2 * s + 2]) == bits(want)).all()
     with pytest.raises(G.GlvError):
-        b = G.Batch(G.Params(n=n), streams, G.OP_FFT)
+        b = G.Batch(G.Params(n=n), streams, G.OP_FFT | G.OP_BARS | G.OP_RING_S16)
         try: b.set_variant(nv)
         finally: b.close()

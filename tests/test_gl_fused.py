@@ -1,0 +1,201 @@
+"""The GL-default pipeline in ONE launch.
+
+GLava ships `setaccelfft true` (shaders/glava/rc.glsl:211): gravity and average run as GL passes on GL_R16 textures
+(glava/render.c:2188-2265, textures :523, :1718), optionally followed by the pre-smoothing pass (:2277-2303).  The library
+has two forms of that chain:
+
+  gl_storage = 2   pass by pass, as the reference runs it: the transform writes f32 spectra, a second kernel applies upload
+                   quantisation / GL_MAX + gravity / ring / average on f32 state (every value a float c / 65535), a third the
+                   bars.  Pinned against the oracle's glvo_gl_chain_r16 and against the reference's own llvmpipe texels
+                   (tests/test_gl_storage.py, tests/test_gl_reference.py).  It is the CHECKER here.
+  gl_storage = 1   the same arithmetic as the transform kernel's epilogue on 16-bit state (uint16 store + ring): one launch,
+                   28 n bytes per frame at F = 5 instead of ~80 n.
+
+This file demands that 1 gives 2's bits -- every output form (texels, floats, bars as floats and as texels, bars == n), every
+input kind, both log modes, every kernel configuration of a size, gravity-only / average-only / F == 1 chains -- and that it
+really is one launch."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from oracle_lib import Oracle, StreamOracle, lcg_pcm_fast
+
+pytestmark = pytest.mark.gpu
+
+
+def _eq(a, b):
+    import torch
+    ia = a.view(torch.int32) if a.dtype == torch.float32 else a
+    ib = b.view(torch.int32) if b.dtype == torch.float32 else b
+    return bool(torch.equal(ia, ib))
+
+
+@pytest.mark.parametrize("n,F,win,log_mode", [(256, 5, True, 1), (512, 5, True, 0), (1024, 5, True, 1), (1024, 6, False, 0), (2048, 2, True, 1),
+                                              (2048, 1, True, 0), (4096, 5, True, 1), (4096, 5, True, 0), (4096, 3, False, 1), (8192, 5, True, 1),
+                                              (8192, 4, True, 0), (16384, 3, True, 1), (16384, 5, True, 0), (32768, 2, True, 1)])
+def test_fused_gl_chain_gives_the_pass_by_pass_bits(glvlib, n, F, win, log_mode):
+    """s16 frames in; `av` texels, their floats, 80 bars as floats and as texels; one launch each for the fused form"""
+    import torch
+    G = glvlib
+    streams = 7 if n <= 8192 else 3
+    mask = G.OP_GRAVITY | G.OP_AVERAGE | G.OP_BARS
+    ops = G.OP_FFT | G.OP_GRAVITY | G.OP_AVERAGE
+    kw = dict(n=n, avg_frames=F, avg_window=win, avg_window_kind=1, log_mode=log_mode, bars=80)
+    forms = [("tex", ops | G.OP_R16, torch.int16, n), ("flt", ops, torch.float32, n), ("bars", ops | G.OP_BARS, torch.float32, 80),
+             ("bars16", ops | G.OP_BARS | G.OP_R16, torch.int16, 80)]
+    fused = {k: G.Batch(G.Params(gl_storage=1, **kw), streams, mask) for k, *_ in forms}
+    split = {k: G.Batch(G.Params(gl_storage=2, **kw), streams, mask) for k, *_ in forms}
+    out_f = {k: torch.zeros((streams * 2, w), dtype=dt, device="cuda") for k, _, dt, w in forms}
+    out_s = {k: torch.zeros((streams * 2, w), dtype=dt, device="cuda") for k, _, dt, w in forms}
+    for fr in range(F + 3):
+        div = (1, 8, 64)[fr % 3]                                       # loud frames saturate texels, quiet ones let gravity show
+        pcm = (lcg_pcm_fast(4200 + fr + n, streams * 2 * n) // div).astype(np.int16)
+        if fr == 2: pcm[:] = 0                                          # silence: the store decays
+        d_pcm = torch.from_numpy(pcm).cuda()
+        for k, o, _, _ in forms:
+            fused[k].process_s16(d_pcm, out_f[k], o)
+            assert fused[k].last_launches() == 1, (k, fused[k].last_launches())
+            split[k].process_s16(d_pcm, out_s[k], o)
+            assert split[k].last_launches() >= 2
+        torch.cuda.synchronize()
+        for k, *_ in forms:
+            assert _eq(out_f[k], out_s[k]), (fr, k)
+        # the floats are the texels' read-back values c / 65535
+        tex_f = torch.from_numpy(out_f["tex"].cpu().numpy().view(np.uint16).astype(np.float32) / np.float32(65535)).cuda()
+        assert _eq(out_f["flt"], tex_f), fr
+    # byte accounting: 16-bit state
+    b = fused["tex"]
+    assert b.algorithmic_bytes(ops | G.OP_R16) == streams * (4 * n + 4 * n * (F - 1) + 4 * n + 4 * n)
+    assert split["tex"].algorithmic_bytes(ops | G.OP_R16) == streams * (4 * n + 8 * n * (F - 1) + 8 * n + 4 * n + 16 * n)
+    for d in (fused, split):
+        for x in d.values(): x.close()
+
+
+@pytest.mark.parametrize("n,F", [(1024, 5), (4096, 5), (16384, 3)])
+def test_fused_gl_chain_equals_the_oracle_model(glvlib, n, F):
+    """independently of the pass-by-pass form: transform_fft (oracle) + glvo_gl_chain_r16, bit for bit with the bit-faithful log"""
+    import torch
+    G = glvlib
+    streams = 5
+    p = G.Params(n=n, avg_frames=F, avg_window_kind=1, gl_storage=1, log_mode=0)
+    b = G.Batch(p, streams, G.OP_GRAVITY | G.OP_AVERAGE)
+    d_q = torch.zeros((streams * 2, n), dtype=torch.int16, device="cuda")
+    store = np.zeros((streams * 2, n), np.float32); hist = np.zeros((streams * 2, F, n), np.float32)
+    heads = [C.c_size_t(0) for _ in range(streams * 2)]
+    ops = G.OP_FFT | G.OP_GRAVITY | G.OP_AVERAGE | G.OP_R16
+    for fr in range(F + 3):
+        pcm = (lcg_pcm_fast(3100 + fr + n, streams * 2 * n) // 16).astype(np.int16)
+        b.process_s16(torch.from_numpy(pcm).cuda(), d_q, ops)
+        gq = d_q.cpu().numpy().view(np.uint16)
+        for u in range(streams):
+            spec = StreamOracle(n, gravity=False, average=False).frame(pcm[u * 2 * n:(u + 1) * 2 * n])
+            for c in range(2):
+                want = np.ascontiguousarray(spec[c])
+                Oracle.lib().glvo_gl_chain_r16(want, store[2 * u + c], hist[2 * u + c], C.byref(heads[2 * u + c]), n, F, 1, 1, 4.2, 86.1328125)
+                assert (gq[2 * u + c] == Oracle.texels_r16(want)).all(), (fr, u, c)
+    b.close()
+
+
+@pytest.mark.parametrize("n", [1024, 4096])
+def test_fused_gl_chain_every_input_kind_and_sub_chain(glvlib, n):
+    """planar f32, interleaved f32, the two device rings; gravity alone, average alone; mono -- fused == pass by pass"""
+    import torch
+    G = glvlib
+    streams, F = 5, 4
+    rng = np.random.default_rng(n)
+    x_pl = (rng.standard_normal((streams * 2, n)) * 0.2).astype(np.float32)
+    x_st = (rng.standard_normal((streams, n, 2)) * 0.2).astype(np.float32)
+    pcm = lcg_pcm_fast(77 + n, streams * 2 * n)
+    d_pl, d_st, d_pcm = torch.from_numpy(x_pl).cuda(), torch.from_numpy(x_st).cuda(), torch.from_numpy(pcm).cuda()
+    for sub in (G.OP_GRAVITY | G.OP_AVERAGE, G.OP_GRAVITY, G.OP_AVERAGE):
+        for ch in (2, 1):
+            mk = lambda gl: G.Batch(G.Params(n=n, avg_frames=F, avg_window_kind=1, gl_storage=gl, channels=ch), streams,     # noqa: E731
+                                    sub | G.OP_RING_S16 | G.OP_RING_F32)
+            for kind in ("s16", "planar", "stereo", "ring16", "ring32"):
+                if ch == 1 and kind == "planar": continue
+                bf, bs = mk(1), mk(2)
+                of = torch.zeros((streams * 2, n), dtype=torch.int16, device="cuda"); os_ = torch.zeros_like(of)
+                for u in range(F + 1):
+                    for b, o in ((bf, of), (bs, os_)):
+                        ops = G.OP_FFT | sub | G.OP_R16
+                        if kind == "s16": b.process_s16(d_pcm, o, ops)
+                        elif kind == "planar": b.process_f32(d_pl, o, ops)
+                        elif kind == "stereo": b.process_f32_stereo(d_st, o, ops)
+                        elif kind == "ring16": b.ring_update_s16(d_pcm[: streams * 2 * 300].reshape(streams, 300, 2).contiguous(), 300, o, ops)
+                        else: b.ring_update_f32(d_st[:, :300].contiguous(), 300, o, ops)
+                    assert bf.last_launches() == 1
+                    assert _eq(of, os_), (sub, ch, kind, u)
+                bf.close(); bs.close()
+
+
+@pytest.mark.parametrize("n", [512, 1024, 2048, 4096, 8192])
+def test_fused_gl_chain_every_kernel_configuration(glvlib, n):
+    import torch
+    G = glvlib
+    streams, F = 9, 5
+    ops = G.OP_FFT | G.OP_GRAVITY | G.OP_AVERAGE
+    outs = []
+    nv = None
+    for v in range(2):
+        b = G.Batch(G.Params(n=n, avg_frames=F, avg_window_kind=1, gl_storage=1), streams, G.OP_GRAVITY | G.OP_AVERAGE | G.OP_BARS)
+        nv = b.variants(); b.set_variant(v)
+        o = torch.zeros((streams * 2, n), dtype=torch.int16, device="cuda")
+        ob = torch.zeros((streams * 2, 80), dtype=torch.float32, device="cuda")
+        got = []
+        for u in range(F + 1):
+            d_pcm = torch.from_numpy((lcg_pcm_fast(910 + u + n, streams * 2 * n) // 4).astype(np.int16)).cuda()
+            b.process_s16(d_pcm, o, ops | G.OP_R16); assert b.last_variant() == v
+            got.append(o.clone())
+        b.reset()
+        for u in range(F + 1):
+            d_pcm = torch.from_numpy((lcg_pcm_fast(910 + u + n, streams * 2 * n) // 4).astype(np.int16)).cuda()
+            b.process_s16(d_pcm, ob, ops | G.OP_BARS)
+            got.append(ob.clone())
+        outs.append(got); b.close()
+    assert nv == 2
+    for x, y in zip(outs[0], outs[1]):
+        assert _eq(x, y)
+
+
+def test_gl_default_pipeline_end_to_end_one_call(glvlib):
+    """PCM in, the texture every stock module samples out: upload -> gravity -> average -> pre-smoothing pass (bars == n,
+    bar_phase 0.5).  The smooth pass's 4096 bars do not fit the slack behind a row in LDS, so this chain is two launches
+    (the fused GL kernel writing the `av` floats, then the bars); its texels equal the pass-by-pass form's."""
+    import torch
+    G = glvlib
+    n, F, streams = 4096, 5, 3
+    kw = dict(n=n, avg_frames=F, avg_window_kind=1, bars=n, bar_phase=0.5)
+    mask = G.OP_GRAVITY | G.OP_AVERAGE | G.OP_BARS
+    bf, bs = G.Batch(G.Params(gl_storage=1, **kw), streams, mask), G.Batch(G.Params(gl_storage=2, **kw), streams, mask)
+    of = torch.zeros((streams * 2, n), dtype=torch.int16, device="cuda"); os_ = torch.zeros_like(of)
+    ops = G.OP_FFT | G.OP_GRAVITY | G.OP_AVERAGE | G.OP_BARS | G.OP_R16
+    for u in range(F + 1):
+        d_pcm = torch.from_numpy((lcg_pcm_fast(31 + u, streams * 2 * n) // 16).astype(np.int16)).cuda()
+        bf.process_s16(d_pcm, of, ops); bs.process_s16(d_pcm, os_, ops)
+        assert bf.last_launches() == 2 and bs.last_launches() == 3
+        assert _eq(of, os_), u
+    bf.close(); bs.close()
+
+
+def test_gl_state_storage_class_is_fixed_at_creation(glvlib):
+    import torch
+    G = glvlib
+    n, streams = 1024, 2
+    p1 = G.Params(n=n, gl_storage=1, avg_window_kind=1)
+    b = G.Batch(p1, streams, G.OP_GRAVITY | G.OP_AVERAGE)
+    with pytest.raises(G.GlvError) as ei:
+        b.set_params(G.Params(n=n, gl_storage=2, avg_window_kind=1))
+    assert ei.value.code == G.ERR_STATE
+    with pytest.raises(G.GlvError) as ei:
+        b.gravity_state()                                           # uint16 texels, not floats
+    assert ei.value.code == G.ERR_STATE
+    b.set_params(G.Params(n=n, gl_storage=1, avg_window_kind=1, gravity_step=1.0))      # a knob: fine
+    b.close()
+    # the single-stream drop-ins keep their class too
+    s = G.State(G.Params(n=n, gl_storage=0))
+    buf = np.zeros(n, np.float32)
+    s.params = G.Params(n=n, gl_storage=1)
+    with pytest.raises(G.GlvError):
+        s.gravity(buf)
+    s.close()

@@ -105,9 +105,9 @@ def test_device_gl_storage_chain_against_the_reference_gl_execution(glvlib, name
     mask = G.OP_GRAVITY | (G.OP_AVERAGE if F > 1 else 0)
     ops = G.OP_FFT | mask
     p = G.Params(n=n, avg_frames=F, avg_window=win, avg_window_kind=1, gl_storage=1, log_mode=0, ur=UR, bars=n, bar_phase=0.5)
-    b = G.Batch(p, 1, mask)
-    bb = G.Batch(p, 1, G.OP_FFT)
-    full = G.Batch(p, 1, mask)              # the whole default pipeline in one call: ... | GLV_OP_BARS | GLV_OP_R16
+    b = G.Batch(p, 1, mask | G.OP_BARS)
+    bb = G.Batch(p, 1, G.OP_FFT | G.OP_BARS)
+    full = G.Batch(p, 1, mask | G.OP_BARS)              # the whole default pipeline in one call: ... | GLV_OP_BARS | GLV_OP_R16
     d_sm = torch.zeros((2, n), dtype=torch.int16, device="cuda")
     d_q = torch.zeros((2, n), dtype=torch.int16, device="cuda")
     d_bars = torch.empty((2, n), dtype=torch.float32, device="cuda")

@@ -314,7 +314,7 @@ def test_gl_twin_average_and_bars(G):
     import torch
     n, streams, F, bars = 16384, 3, 5, 80
     p = G.Params(n=n, avg_frames=F, avg_window_kind=1, bars=bars)
-    b = G.Batch(p, streams, G.OP_FFT | G.OP_GRAVITY | G.OP_AVERAGE)
+    b = G.Batch(p, streams, G.OP_FFT | G.OP_GRAVITY | G.OP_AVERAGE | G.OP_BARS)
     d_bars = torch.empty((streams * 2, bars), dtype=torch.float32, device="cuda")
     d_spec = torch.empty((streams * 2, n), dtype=torch.float32, device="cuda")
     grav = np.zeros((streams * 2, n), np.float32)
@@ -353,7 +353,7 @@ def test_fifo_ring_mode(G, ssz):
     at an odd frame of the device ring), a single frame, the whole window."""
     import torch
     n, streams, nf = 1024, 4, ssz // 4
-    b = G.Batch(G.Params(n=n), streams, G.OP_FFT)
+    b = G.Batch(G.Params(n=n), streams, G.OP_FFT | G.OP_RING_S16)
     rl = np.zeros((streams, n), np.float32); rr = np.zeros((streams, n), np.float32)
     d_out = torch.empty((streams * 2, n), dtype=torch.float32, device="cuda")
     for step in range(7 if nf > 1 else 5):
@@ -372,7 +372,7 @@ def test_fifo_ring_mode(G, ssz):
 
 def test_error_behaviour(G):
     import torch
-    b = G.Batch(G.Params(n=512), 2, G.OP_FFT)
+    b = G.Batch(G.Params(n=512), 2, G.OP_FFT | G.OP_RING_S16)
     d = torch.zeros(2 * 2 * 512, dtype=torch.int16, device="cuda")
     o = torch.zeros((4, 512), dtype=torch.float32, device="cuda")
     with pytest.raises(G.GlvError) as ei:
@@ -393,7 +393,7 @@ def test_error_behaviour(G):
     pcm = lcg_pcm_fast(31, 2 * 128 * 2)
     dn = torch.from_numpy(pcm).cuda()
     b.ring_update_s16(dn, 128, o, G.OP_FFT | G.OP_RAW)
-    b2 = G.Batch(G.Params(n=512), 2, G.OP_FFT)
+    b2 = G.Batch(G.Params(n=512), 2, G.OP_FFT | G.OP_RING_S16)
     o2 = torch.zeros_like(o)
     b2.ring_update_s16(dn, 128, o2, G.OP_FFT | G.OP_RAW)
     torch.cuda.synchronize()
@@ -619,9 +619,9 @@ def test_gravity_state_as_output(G):
     import torch
     n, streams, bars = 2048, 11, 80
     ops = G.OP_FFT | G.OP_GRAVITY
-    a = G.Batch(G.Params(n=n, bars=bars), streams, ops)
-    b = G.Batch(G.Params(n=n, bars=bars), streams, ops)
-    c = G.Batch(G.Params(n=n, bars=bars), streams, ops)
+    a = G.Batch(G.Params(n=n, bars=bars), streams, ops | G.OP_BARS)
+    b = G.Batch(G.Params(n=n, bars=bars), streams, ops | G.OP_BARS)
+    c = G.Batch(G.Params(n=n, bars=bars), streams, ops | G.OP_BARS)
     d_out = torch.empty((streams * 2, n), dtype=torch.float32, device="cuda")
     d_bars = torch.empty((streams * 2, bars), dtype=torch.float32, device="cuda")
     d_bars2 = torch.empty_like(d_bars)
@@ -656,7 +656,7 @@ def test_fused_bars_equal_unfused(G, n, F, bars):
     streams = 5
     ops = G.OP_FFT | G.OP_GRAVITY | (G.OP_AVERAGE if F else 0)
     p = G.Params(n=n, bars=bars, avg_frames=max(F, 1), avg_window_kind=1)
-    a, b = G.Batch(p, streams, ops), G.Batch(p, streams, ops)
+    a, b = G.Batch(p, streams, ops | G.OP_BARS), G.Batch(p, streams, ops | G.OP_BARS)
     d_spec = torch.empty((streams * 2, n), dtype=torch.float32, device="cuda")
     d_b1 = torch.empty((streams * 2, bars), dtype=torch.float32, device="cuda")
     d_b2 = torch.full_like(d_b1, float("nan"))
@@ -729,7 +729,7 @@ def test_ring_mode_full_window_equals_frame_mode(G):
     n, streams, bars = 4096, 5, 80
     ops = G.OP_FFT | G.OP_GRAVITY | G.OP_AVERAGE
     p = G.Params(n=n, bars=bars)
-    a, b = G.Batch(p, streams, ops), G.Batch(p, streams, ops)
+    a, b = G.Batch(p, streams, ops | G.OP_BARS | G.OP_RING_S16), G.Batch(p, streams, ops | G.OP_BARS | G.OP_RING_S16)
     oa = torch.empty((streams * 2, n), dtype=torch.float32, device="cuda"); ob = torch.empty_like(oa)
     ba = torch.empty((streams * 2, bars), dtype=torch.float32, device="cuda"); bb = torch.empty_like(ba)
     for fr in range(4):
@@ -752,7 +752,7 @@ def test_config2_full_size_gravity_bars_subset(G):
     import torch, ctypes
     n, streams, bars = 16384, 8192, 80
     ops = G.OP_FFT | G.OP_GRAVITY
-    b = G.Batch(G.Params(n=n, bars=bars), streams, ops)
+    b = G.Batch(G.Params(n=n, bars=bars), streams, ops | G.OP_BARS)
     d_bars = torch.full((streams * 2, bars), float("nan"), dtype=torch.float32, device="cuda")
     rng = np.random.default_rng(3)
     subset = np.unique(np.concatenate([rng.integers(0, streams, 24), [0, streams - 1]]))
@@ -872,7 +872,7 @@ def test_pulse_ring_mode(G, ch, nf):
     size (odd, not dividing n) as pulse_input.c accepts any sample_sz."""
     import torch
     n, streams = 2048, 4
-    b = G.Batch(G.Params(n=n, channels=ch), streams, G.OP_FFT)
+    b = G.Batch(G.Params(n=n, channels=ch), streams, G.OP_FFT | G.OP_RING_F32)
     rl = np.zeros((streams, n), np.float32); rr = np.zeros((streams, n), np.float32)
     d_out = torch.empty((streams * 2, n), dtype=torch.float32, device="cuda")
     rng = np.random.default_rng(17)
@@ -1052,7 +1052,7 @@ def test_ring_append_and_planar_snapshot(G):
     import torch
     n, streams = 1024, 23
     for ch in (2, 1):
-        b = G.Batch(G.Params(n=n, channels=ch), streams, G.OP_FFT)
+        b = G.Batch(G.Params(n=n, channels=ch), streams, G.OP_FFT | G.OP_RING_S16 | G.OP_RING_F32)
         with pytest.raises(G.GlvError) as ei:
             b.ring_planar(torch.empty((streams, 2, n), dtype=torch.float32, device="cuda"))
         assert ei.value.code == G.ERR_STATE                               # no ring yet
@@ -1091,8 +1091,8 @@ def test_f32_inputs_through_stateful_and_fused_paths(G):
     ops = G.OP_FFT | G.OP_GRAVITY | G.OP_AVERAGE
     p = G.Params(n=n, bars=bars, avg_frames=F)
     rng = np.random.default_rng(5150)
-    chain = {k: G.Batch(p, streams, ops) for k in ("planar", "stereo", "ring", "planar_bars", "stereo_bars")}
-    ref_fft = G.Batch(p, streams, ops)                    # stateless pass, then the operators one by one
+    chain = {k: G.Batch(p, streams, ops | G.OP_BARS | G.OP_RING_F32) for k in ("planar", "stereo", "ring", "planar_bars", "stereo_bars")}
+    ref_fft = G.Batch(p, streams, ops | G.OP_BARS | G.OP_RING_F32)                    # stateless pass, then the operators one by one
     d_spec = torch.empty((streams * 2, n), dtype=torch.float32, device="cuda")
     d_ref = torch.empty_like(d_spec)
     d_bars = torch.empty((streams * 2, bars), dtype=torch.float32, device="cuda")

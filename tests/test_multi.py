@@ -123,13 +123,13 @@ def test_c_multi_driver_several_shards_without_rccl(glvlib, monkeypatch, shards)
         G.Multi(p, 64, G.OP_FFT, devices=[0, 0])
 
 
-def _run_bench_distributed(nproc, port, extra_env=None):
+def _run_bench_distributed(nproc, port, extra_env=None, extra_args=()):
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     env.update(extra_env or {})
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", str(nproc), "--steps", "3", "--warmup", "1",
-           "--streams", "4096", "--no-cpu-baseline", "--no-alt", "--spinup-s", "0.05"]
+           "--streams", "4096", "--no-cpu-baseline", "--no-alt", "--spinup-s", "0.05", "--sustained-s", "0", *extra_args]
     return subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
 
 
@@ -164,3 +164,35 @@ def test_bench_nccl_two_ranks_on_one_gpu_if_rccl_allows(glvlib):
     line = _bench_line(r.stdout)
     assert line["n_gpus"] == 2 and line["value"] > 0
     assert line["config"]["streams_per_gpu"] == 4096
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_with_real_kernels(glvlib, tmp_path):
+    """the world > 1 path of bench.py executed with real kernels before an 8-GPU node ever sees it.  Two ranks
+    share cuda:0 (RCCL refuses that, so the 32-byte stats record and the MAX all-reduce travel over gloo: GLV_BENCH_BACKEND=gloo;
+    the data path has no collective either way).  Checked: both shards' stats records arrive, the line's value is the sum of the
+    ranks' frames over the MAX of their seconds, rank r's shard starts at global stream r * streams, and the FIRST stream of
+    every rank -- dumped by --check-dump -- is what the oracle computes for that PCM (raw FFT bit for bit, magnitudes to 1e-5)."""
+    from oracle_lib import StreamOracle
+    dump = str(tmp_path / "chk")
+    r = _run_bench_distributed(2, 29617, {"GLV_BENCH_BACKEND": "gloo"}, ["--check-dump", dump])
+    assert r.returncode == 0, (r.stderr + r.stdout)[-4000:]
+    line = _bench_line(r.stdout)
+    steps, streams = 3, 4096
+    assert line["n_gpus"] == 2 and line["steps"] == steps and line["scaling"] == "weak"
+    assert line["config"]["collectives"].startswith("gloo") and "2 rank(s)" in line["config"]["collectives"]
+    stats = line["stats"]
+    assert len(stats) == 2 and all(s["frames"] == streams * steps and s["kernel_ms"] > 0 and s["bytes"] == 12 * 4096 * streams * steps for s in stats)
+    secs = max(s["seconds"] for s in stats)
+    assert abs(line["ms_per_step"] * steps * 1e-3 - secs) < 1e-9 * max(1.0, secs) + 1e-12       # MAX over ranks
+    assert abs(line["value"] - sum(s["frames"] for s in stats) / secs) <= 1e-6 * line["value"]
+    pcms = []
+    for rank in range(2):
+        z = np.load(f"{dump}.rank{rank}.npz")
+        assert int(z["rank"]) == rank and int(z["world"]) == 2 and int(z["global_stream"]) == rank * streams
+        pcm = np.ascontiguousarray(z["pcm"]).reshape(-1)                       # int16 [n][2] of the rank's first stream
+        want, wraw = StreamOracle(4096, gravity=False, average=False).frame(pcm, want_raw=True)
+        assert (np.ascontiguousarray(z["raw"]).view(np.uint32) == np.ascontiguousarray(wraw, dtype=np.float32).view(np.uint32)).all(), rank
+        assert np.allclose(z["first_spectrum"], want, rtol=1e-5, atol=2e-6), rank
+        pcms.append(pcm)
+    assert not (pcms[0] == pcms[1]).all()                                      # the shards hold different streams

@@ -11,7 +11,7 @@ n, streams, bars = 4096, 65536, 80
 sync = torch.cuda.synchronize
 ops = G.OP_FFT | G.OP_GRAVITY | G.OP_AVERAGE
 pcm = torch.randint(-32768, 32768, (streams, n, 2), dtype=torch.int16, device="cuda")
-b = G.Batch(G.Params(n=n, bars=bars), streams, ops)
+b = G.Batch(G.Params(n=n, bars=bars), streams, ops | G.OP_BARS)
 spec = torch.empty((streams, 2, n), dtype=torch.float32, device="cuda")
 dbars = torch.empty((streams, 2, bars), dtype=torch.float32, device="cuda")
 dt = timed(lambda: b.process_s16(pcm, spec, ops), sync)

@@ -11,7 +11,7 @@ from configs_bench import timed
 n, streams = 4096, 32768
 sync = torch.cuda.synchronize
 out = torch.empty((streams, 2, n), dtype=torch.float32, device="cuda")
-b = G.Batch(G.Params(n=n), streams, G.OP_FFT)
+b = G.Batch(G.Params(n=n), streams, G.OP_FFT | G.OP_RING_S16)
 x = torch.rand((streams, 2, n), dtype=torch.float32, device="cuda") - 0.5
 dt = timed(lambda: b.process_f32(x, out, G.OP_FFT), sync)
 print(f"planar f32      : {dt*1e3:.3f} ms  {streams/dt/1e6:7.2f} M frames/s  {streams/dt*16*n/8e12*100:5.1f} % of 8 TB/s (16N B/frame)")

@@ -210,6 +210,7 @@ void fill_common(glv::FrameArgs& a, const glv_params& p, const Tables& t) {
     a.one_minus_cutoff = 1.0F - p.fft_cutoff;                  // render.c:845
     a.g = p.gravity_step * (1.0F / p.ur);                      // render.c:728
     a.F_as_float = (float) p.avg_frames;                       // render.c:761
+    a.F_rcp = 1.0F / (float) p.avg_frames;
     glv::make_frame_weights(a.wts, p.avg_frames, p.avg_window != 0, (int) p.avg_window_kind);
 }
 

@@ -30,7 +30,7 @@
     defined(GLV_EXP_NOLOAD) || defined(GLV_EXP_NOSPLIT) || defined(GLV_EXP_NOSTORE) || defined(GLV_EXP_NOTWLOAD) || \
     defined(GLV_EXP_NOWINLOAD) || defined(GLV_EXP_OLDGROUPS) || defined(GLV_EXP_PHASETIME) || defined(GLV_EXP_STOREPRIO) || \
     defined(GLV_EXP_SWAP16) || defined(GLV_EXP_WGBARRIER) || defined(GLV_EXP_SHUFFLE) || defined(GLV_EXP_STOREWAVE) || \
-    defined(GLV_R16_SOFT) || defined(GLV_BAR_BATCH_BIG) || defined(GLV_STATE_PAIR_MAX) || defined(GLV_GL16_BLK)
+    defined(GLV_R16_SOFT) || defined(GLV_BAR_BATCH_BIG) || defined(GLV_STATE_PAIR_MAX) || defined(GLV_GL16_BLK) || defined(GLV_GL16_DIV)
 #error "GLV_EXP_* / tuning macros are for tools/tune.py A/B builds: compile with -DGLV_TUNE_BUILD (glava_amd.build.build_variant does); the product never defines them"
 #endif
 #endif
@@ -346,6 +346,25 @@ GLV_HD float through_r16(float x) { return unorm16_to_float(unorm16(x)); }
 // render.c:730-734
 GLV_HD float gravity(float b, float applied, float g) {
     return (b >= applied ? b : applied) - g;
+}
+
+// x / F for the final division of an averaging pass (average_pass.frag: `/ _AVG_FRAMES`) on GL_R16 values -- x is a weighted sum of
+// at most 64 texel values c / 65535, i.e. 0 or a normal float in [2^-20, 128) -- correctly rounded without the divide expansion
+// (~10 instructions: scale, reciprocal, three refinement steps, fix-up): with r = RN(1 / F), q0 = RN(x r), the remainder
+// rem = x - q0 F is exact in one fused multiply-add and q = RN(q0 + rem r) is the correctly rounded quotient (Markstein).  Checked
+// against the division for every float of that range and every F (tests/test_gl_storage.py through the host emulator).
+#if !defined(GLV_GL16_DIV)
+#define GLV_GL16_DIV 1
+#endif
+GLV_HD float div_frames(float x, float F, float rcpF) {
+#if GLV_GL16_DIV
+    const float q0 = x * rcpF;
+    const float rem = __builtin_fmaf(-q0, F, x);
+    return __builtin_fmaf(rem, rcpF, q0);
+#else
+    (void) rcpF;
+    return x / F;
+#endif
 }
 
 // ---- GL_R16 state (glv_params.gl_storage == 1) ---------------------------------------------------------------------------

@@ -67,6 +67,7 @@ struct FrameArgs {
     uint32_t log_mode;     // glv_post_kernel's OP_MAGNITUDE (the frame kernels take it as a template parameter)
     uint32_t rot;          // ring modes (RING kernels): index of the ring's oldest stereo frame = where the window starts
     float inv_n, fft_scale, one_minus_cutoff, g, F_as_float;
+    float F_rcp;           // RN(1 / F): the GL_R16 chain's final division (glv_core.h div_frames)
     double wts[64];        // window_frame weights, oldest first (render.c:661 as expanded at :766); GLV_MAX_AVG_FRAMES
     // fused GLV_OP_BARS (stateful kernels, lanes-per-row a multiple of 64): the finished row goes to the
     // slot's LDS region instead of HBM and only the bars leave the chip
@@ -247,7 +248,7 @@ GLV_HD uint32_t apply_state_r16(uint32_t tex, uint32_t off, size_t row, uint32_t
         st<uint32_t>(h + (size_t) a.head * n, o, tex);
         if (F > 1) {                                                       // render.c:2230: no averaging pass for one frame
             weighted_texels(acc, tex, a.wts[F - 1], a.avg_window != 0);
-            tex = pack_unorm16(acc.x / a.F_as_float, acc.y / a.F_as_float);
+            tex = pack_unorm16(div_frames(acc.x, a.F_as_float, a.F_rcp), div_frames(acc.y, a.F_as_float, a.F_rcp));
         }
     }
     return tex;
@@ -460,7 +461,7 @@ GLV_HD void gl16_state_block(uint32_t (&tex)[NV], const uint32_t (&off)[NV], siz
 #pragma unroll
             for (int e = 0; e < NV; ++e) {
                 weighted_texels(acc[e], tex[e], wl, windowed);
-                tex[e] = pack_unorm16(acc[e].x / a.F_as_float, acc[e].y / a.F_as_float);
+                tex[e] = pack_unorm16(div_frames(acc[e].x, a.F_as_float, a.F_rcp), div_frames(acc[e].y, a.F_as_float, a.F_rcp));
             }
         }
     } else if (a.ops & OP_GRAVITY) {
@@ -1152,7 +1153,11 @@ struct Frame {
     // Every stored value is a 16-bit integer by construction, so state and output move 2 bytes per value: with F = 5 a stereo
     // frame costs 4 N (PCM) + 16 N (four ring slots) + 4 N (newest slot) + 4 N (texels) = 28 N bytes where the pass-by-pass form
     // (f32 intermediates, three launches) moved ~80 N.
+#if defined(GLV_GL16_BLK)
+    static constexpr int GL16_BLK = (GLV_GL16_BLK) < E ? (GLV_GL16_BLK) : E;      // tools/tune.py A/B
+#else
     static constexpr int GL16_BLK = E <= 16 ? E : E / 2;       // points per block: the whole lane where the registers allow it
+#endif
     template <int LOG_MODE, int TILTREG, bool NONFINITE, bool TO_LDS>
     GLV_HD static void epilogue_gl16(const cf (&v)[E], float* out_row, size_t row, int tid, const FrameArgs& a,
                                      const LogEntry* logtab, const cf* tl_reg = nullptr) {

@@ -153,7 +153,7 @@ int glvemu_process_gl(int n, int in_mode, const void* in, float* out, float* gra
     a.in = in; a.out = out; a.grav = grav; a.grav_w = grav; a.hist = hist; a.tw = tw.data(); a.win = win.data(); a.logtab = lt; a.tilt = tl.data();
     a.units = units; a.ops = ops; a.F = F; a.head = head; a.mono = mono; a.avg_window = avg_window; a.rot = rot;
     a.inv_n = 1.0f / (float) n; a.fft_scale = fft_scale; a.one_minus_cutoff = 1.0f - fft_cutoff;
-    a.g = gravity_step * (1.0f / ur); a.F_as_float = (float) F;
+    a.g = gravity_step * (1.0f / ur); a.F_as_float = (float) F; a.F_rcp = 1.0f / (float) F;
     a.gl_storage = (uint32_t) gl_storage;
     a.grav_int = gravity_r16_integer_step(a.g, &a.grav_sub) && !force_float_gravity ? 1u : 0u;
     if (F > 64) return 3;
@@ -173,7 +173,7 @@ int glvemu_post_state(const float* in, float* out, float* grav, float* hist, int
     FrameArgs a;
     std::memset(&a, 0, sizeof(a));
     a.in = in; a.out = out; a.grav = grav; a.grav_w = grav; a.hist = hist; a.units = rows; a.ops = ops; a.F = F; a.head = head;
-    a.avg_window = avg_window; a.gl_storage = gl_storage; a.g = gravity_step * (1.0f / ur); a.F_as_float = (float) F;
+    a.avg_window = avg_window; a.gl_storage = gl_storage; a.g = gravity_step * (1.0f / ur); a.F_as_float = (float) F; a.F_rcp = 1.0f / (float) F;
     a.grav_int = gravity_r16_integer_step(a.g, &a.grav_sub) ? 1u : 0u;       // gl_storage 1: grav / hist are uint16 arrays
     make_frame_weights(a.wts, F, avg_window != 0, avg_kind);
     for (unsigned r = 0; r < rows; ++r)
@@ -290,5 +290,20 @@ int glvemu_gravity_step(float gravity_step, float ur, unsigned* d) {
     const bool ok = glv::gravity_r16_integer_step(gravity_step * (1.0f / ur), &sub);
     if (d) *d = sub & 0xffffu;
     return ok ? 1 : 0;
+}
+}
+
+extern "C" {
+// glv_core.h div_frames against the division for every float with bits in [lo_bits, hi_bits] (step `stride` in bit space):
+// returns the number of mismatches (first one -> *bad_bits)
+unsigned long long glvemu_div_frames_check(unsigned F, unsigned lo_bits, unsigned hi_bits, unsigned stride, unsigned* bad_bits) {
+    const float Ff = (float) F, r = 1.0f / Ff;
+    unsigned long long bad = 0;
+    for (unsigned long long u = lo_bits; u <= hi_bits; u += stride) {
+        const float x = __builtin_bit_cast(float, (uint32_t) u);
+        const float want = x / Ff, got = glv::div_frames(x, Ff, r);
+        if (__builtin_bit_cast(uint32_t, want) != __builtin_bit_cast(uint32_t, got)) { if (!bad && bad_bits) *bad_bits = (unsigned) u; ++bad; }
+    }
+    return bad;
 }
 }

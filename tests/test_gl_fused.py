@@ -53,9 +53,11 @@ def test_fused_gl_chain_gives_the_pass_by_pass_bits(glvlib, n, F, win, log_mode)
         pcm = (lcg_pcm_fast(4200 + fr + n, streams * 2 * n) // div).astype(np.int16)
         if fr == 2: pcm[:] = 0                                          # silence: the store decays
         d_pcm = torch.from_numpy(pcm).cuda()
+        # bars are computed inside the launch where whole waves own a row (n >= 1024): below that they are a second launch on the
+        # finished rows' floats
         for k, o, _, _ in forms:
             fused[k].process_s16(d_pcm, out_f[k], o)
-            assert fused[k].last_launches() == 1, (k, fused[k].last_launches())
+            assert fused[k].last_launches() == (2 if (o & G.OP_BARS) and n < 1024 else 1), (k, fused[k].last_launches())
             split[k].process_s16(d_pcm, out_s[k], o)
             assert split[k].last_launches() >= 2
         torch.cuda.synchronize()

@@ -110,6 +110,21 @@ def test_emulated_fused_gl_chain_equals_the_oracle_model(emu, n, F, win, log_e):
             assert (st[key][1] == Oracle.texels_r16(ohist)).all(), (fr, key)
 
 
+def test_final_division_of_the_average_is_correctly_rounded(emu):
+    """glv_core.h div_frames (three fused operations instead of the divide expansion) against the IEEE quotient for EVERY float an
+    averaging pass on GL_R16 values can hand it -- [2^-24, 128], all 226 M of them for the frame counts in use, every 61st for
+    all of F = 1 .. 64 -- and for zero"""
+    emu.glvemu_div_frames_check.restype = C.c_ulonglong
+    lo, hi = int(np.float32(2.0 ** -24).view(np.uint32)), int(np.float32(128.0).view(np.uint32))
+    bad = C.c_uint(0)
+    for F in (2, 3, 5, 6):
+        assert emu.glvemu_div_frames_check(F, lo, hi, 1, C.byref(bad)) == 0, (F, hex(bad.value))
+    for F in range(1, 65):
+        assert emu.glvemu_div_frames_check(F, lo, hi, 61, C.byref(bad)) == 0, (F, hex(bad.value))
+        assert emu.glvemu_div_frames_check(F, 0, 0, 1, C.byref(bad)) == 0                      # zero (denormals cannot occur: the
+                                                                                                # smallest nonzero sum is ~1e-6)
+
+
 def test_texel_readback_division_every_texel(emu):
     """through_r16 on k / 65535 + a hair for every k: the device-side division sequence (glv_core.h unorm16_to_float) is the
     correctly rounded c / 65535.0f of the oracle"""

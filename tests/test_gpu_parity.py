@@ -1052,10 +1052,14 @@ def test_ring_append_and_planar_snapshot(G):
     import torch
     n, streams = 1024, 23
     for ch in (2, 1):
+        nob = G.Batch(G.Params(n=n, channels=ch), streams, G.OP_FFT)
+        for call in (lambda: nob.ring_planar(torch.empty((streams, 2, n), dtype=torch.float32, device="cuda")),
+                     lambda: nob.ring_append_s16(None, 4), lambda: nob.ring_planar(torch.empty((streams, 2, n), device="cuda"), f32_ring=True)):
+            with pytest.raises(G.GlvError) as ei:
+                call()
+            assert ei.value.code == G.ERR_STATE                           # rings exist only when the creation mask announced them
+        nob.close()
         b = G.Batch(G.Params(n=n, channels=ch), streams, G.OP_FFT | G.OP_RING_S16 | G.OP_RING_F32)
-        with pytest.raises(G.GlvError) as ei:
-            b.ring_planar(torch.empty((streams, 2, n), dtype=torch.float32, device="cuda"))
-        assert ei.value.code == G.ERR_STATE                               # no ring yet
         rl = np.zeros((streams, n), np.float32); rr = np.zeros((streams, n), np.float32)
         fl = np.zeros((streams, n), np.float32); fr_ = np.zeros((streams, n), np.float32)
         d_pl = torch.empty((streams, 2, n), dtype=torch.float32, device="cuda")

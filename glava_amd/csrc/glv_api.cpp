@@ -212,6 +212,7 @@ void fill_common(glv::FrameArgs& a, const glv_params& p, const Tables& t) {
     a.F_as_float = (float) p.avg_frames;                       // render.c:761
     a.F_rcp = 1.0F / (float) p.avg_frames;
     glv::make_frame_weights(a.wts, p.avg_frames, p.avg_window != 0, (int) p.avg_window_kind);
+    for (uint32_t f = 0; f < p.avg_frames; ++f) a.wts32[f] = (float) a.wts[f];
 }
 
 }  // namespace

@@ -69,6 +69,7 @@ struct FrameArgs {
     float inv_n, fft_scale, one_minus_cutoff, g, F_as_float;
     float F_rcp;           // RN(1 / F): the GL_R16 chain's final division (glv_core.h div_frames)
     double wts[64];        // window_frame weights, oldest first (render.c:661 as expanded at :766); GLV_MAX_AVG_FRAMES
+    float wts32[64];       // the same rounded to float: the GL passes' arithmetic is the shader's, 32-bit (weighted_texels)
     // fused GLV_OP_BARS (stateful kernels, lanes-per-row a multiple of 64): the finished row goes to the
     // slot's LDS region instead of HBM and only the bars leave the chip
     const BarDesc* bar_desc;
@@ -223,14 +224,29 @@ GLV_HD uint32_t ring_slot(uint32_t head, uint32_t f, uint32_t F) {
 // The pass structure of apply_state's gl_storage branch below on uint16 state: `tex` = the uploaded point as two packed texels
 // (pack_unorm16 of the transform's output), `off` = the point's byte offset in an f32 row (its texel pair sits at off / 2).
 // Returns the texel pair the chain ends with (gravity store, or the average when F > 1).
-GLV_HD uint32_t weighted_texels(cf& acc, uint32_t p, double w, bool windowed) {
-    const cf f = texels_to_float(p);
-    if (windowed) {                                                       // average_pass.frag:41 as the oracle evaluates it
-        acc.x = (float) ((double) acc.x + w * (double) f.x);
-        acc.y = (float) ((double) acc.y + w * (double) f.y);
-    } else { acc.x = acc.x + f.x; acc.y = acc.y + f.y; }
-    return p;
+// One term of average_pass.frag's sum,  r += window(I, ...) * texelFetch(tI).r  -- in the shader's own arithmetic: GLSL `float`
+// is 32-bit, the weight is a constant the GLSL compiler folded to a float, product and sum are each rounded to float (no
+// contraction: what a non-fusing implementation such as Mesa's llvmpipe on x86-64 executes).  Rounds 2-3 had borrowed the CPU
+// operator's  float * double -> double -> float  (render.c:759) for this pass too; against the reference's own llvmpipe texels
+// the two are indistinguishable (profiles/r04/gl_average_models.txt: the same texels differ, the exact half-texel ties), the
+// 32-bit form costs two packed instructions per complex point and frame instead of ten.
+GLV_HD void weighted_add(cf& acc, cf f, float w, bool windowed) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const glv_f2 T = {f.x, f.y}, A = {acc.x, acc.y};
+    glv_f2 s;
+    if (windowed) {
+        const glv_f2 W = {w, w};
+        glv_f2 p;
+        asm("v_pk_mul_f32 %0, %1, %2" : "=v"(p) : "v"(T), "v"(W));
+        asm("v_pk_add_f32 %0, %1, %2" : "=v"(s) : "v"(A), "v"(p));
+    } else asm("v_pk_add_f32 %0, %1, %2" : "=v"(s) : "v"(A), "v"(T));
+    acc.x = s.x; acc.y = s.y;
+#else
+    if (windowed) { const float p0 = w * f.x, p1 = w * f.y; acc.x = acc.x + p0; acc.y = acc.y + p1; }
+    else { acc.x = acc.x + f.x; acc.y = acc.y + f.y; }
+#endif
 }
+GLV_HD void weighted_texels(cf& acc, uint32_t p, float w, bool windowed) { weighted_add(acc, texels_to_float(p), w, windowed); }
 GLV_HD uint32_t apply_state_r16(uint32_t tex, uint32_t off, size_t row, uint32_t n, const FrameArgs& a) {
     const uint32_t F = a.F, o = off / 2u;
     const bool ring = (a.ops & OP_AVERAGE) != 0;
@@ -244,10 +260,10 @@ GLV_HD uint32_t apply_state_r16(uint32_t tex, uint32_t off, size_t row, uint32_t
     if (ring) {
         cf acc = { 0.0f, 0.0f };
         for (uint32_t f = 0; f + 1 < F; ++f)                               // oldest .. second newest
-            weighted_texels(acc, ld<uint32_t>(h + (size_t) ring_slot(a.head, f, F) * n, o), a.wts[f], a.avg_window != 0);
+            weighted_texels(acc, ld<uint32_t>(h + (size_t) ring_slot(a.head, f, F) * n, o), a.wts32[f], a.avg_window != 0);
         st<uint32_t>(h + (size_t) a.head * n, o, tex);
         if (F > 1) {                                                       // render.c:2230: no averaging pass for one frame
-            weighted_texels(acc, tex, a.wts[F - 1], a.avg_window != 0);
+            weighted_texels(acc, tex, a.wts32[F - 1], a.avg_window != 0);
             tex = pack_unorm16(div_frames(acc.x, a.F_as_float, a.F_rcp), div_frames(acc.y, a.F_as_float, a.F_rcp));
         }
     }
@@ -269,20 +285,12 @@ GLV_HD cf apply_state(cf val, uint32_t off, size_t row, uint32_t n, const FrameA
         }
         if (ring) {
             cf acc = { 0.0f, 0.0f };
-            for (uint32_t f = 0; f + 1 < F; ++f) {                            // oldest .. second newest
-                const cf prev = ld<cf>(h + (size_t) ring_slot(a.head, f, F) * n, off);
-                if (a.avg_window) {
-                    acc.x = (float) ((double) acc.x + a.wts[f] * (double) prev.x);
-                    acc.y = (float) ((double) acc.y + a.wts[f] * (double) prev.y);
-                } else { acc.x = acc.x + prev.x; acc.y = acc.y + prev.y; }
-            }
+            for (uint32_t f = 0; f + 1 < F; ++f)                              // oldest .. second newest; the shader's 32-bit arithmetic
+                weighted_add(acc, ld<cf>(h + (size_t) ring_slot(a.head, f, F) * n, off), a.wts32[f], a.avg_window != 0);
             st<cf>(h + (size_t) a.head * n, off, val);
             if (F > 1) {                                                      // render.c:2230: no averaging pass for one frame
-                if (a.avg_window) {
-                    acc.x = (float) ((double) acc.x + a.wts[F - 1] * (double) val.x);
-                    acc.y = (float) ((double) acc.y + a.wts[F - 1] * (double) val.y);
-                } else { acc.x = acc.x + val.x; acc.y = acc.y + val.y; }
-                val.x = through_r16(acc.x / a.F_as_float); val.y = through_r16(acc.y / a.F_as_float);
+                weighted_add(acc, val, a.wts32[F - 1], a.avg_window != 0);
+                val.x = through_r16(div_frames(acc.x, a.F_as_float, a.F_rcp)); val.y = through_r16(div_frames(acc.y, a.F_as_float, a.F_rcp));
             }
         }
         return val;
@@ -440,13 +448,13 @@ GLV_HD void gl16_state_block(uint32_t (&tex)[NV], const uint32_t (&off)[NV], siz
             uint32_t p0[NV];
             load(p0, h + (size_t) ring_slot(a.head, f, F) * n);
             load(prev, h + (size_t) ring_slot(a.head, f + 1, F) * n);
-            const double w0 = a.wts[f], w1 = a.wts[f + 1];
+            const float w0 = a.wts32[f], w1 = a.wts32[f + 1];
 #pragma unroll
             for (int e = 0; e < NV; ++e) { weighted_texels(acc[e], p0[e], w0, windowed); weighted_texels(acc[e], prev[e], w1, windowed); }
         }
         for (; f + 1 < F; ++f) {
             load(prev, h + (size_t) ring_slot(a.head, f, F) * n);
-            const double w = a.wts[f];
+            const float w = a.wts32[f];
 #pragma unroll
             for (int e = 0; e < NV; ++e) weighted_texels(acc[e], prev[e], w, windowed);
         }
@@ -457,7 +465,7 @@ GLV_HD void gl16_state_block(uint32_t (&tex)[NV], const uint32_t (&off)[NV], siz
         }
         store(h + (size_t) a.head * n, tex);
         if (F > 1) {                                                         // render.c:2230: no averaging pass for one frame
-            const double wl = a.wts[F - 1];
+            const float wl = a.wts32[F - 1];
 #pragma unroll
             for (int e = 0; e < NV; ++e) {
                 weighted_texels(acc[e], tex[e], wl, windowed);

@@ -362,6 +362,12 @@ void glvo_average_gl(float* b, float* hist, size_t* head, size_t sz, size_t F, i
  * values, then the in-place gravity pass :2219-2228, gravity_pass.frag);  ring[head] = store (pass.frag copy :2232-2243);
  * row = Q(sum_I window(I) * t_I / F) (average_pass.frag, t_0 = newest) -- only when F > 1 (:2230), else row = store.
  * store is the previous newest ring slot (the same texels).  Q() as glvo_unorm16 / glvo_unorm16_to_float above.
+ * The average is evaluated in the shader's own arithmetic: GLSL `float` is 32 bits -- `float r = 0; r += window(I) * tI; ...
+ * r / _AVG_FRAMES` -- the weight a compile-time constant folded to float, every product, sum and the quotient rounded to float,
+ * nothing contracted (what Mesa's llvmpipe executes on x86-64).  (Rounds 2-3 restated this pass with the CPU operator's
+ * float * double products, render.c:759; against the reference's llvmpipe texels the two forms are indistinguishable --
+ * profiles/r04/gl_average_models.txt -- and which neighbour an exact half-texel tie takes is the driver's choice either way:
+ * tests/test_gl_reference.py compares tie-aware.)
  * Restatement (no GL here); the shader arithmetic itself is checked against tests/glsl_eval.py. */
 static float glvo_q16(float x) { return glvo_unorm16_to_float(glvo_unorm16(x)); }
 void glvo_gl_chain_r16(float* row, float* store, float* hist, size_t* head, size_t sz, size_t F, int use_window, int do_average,
@@ -381,7 +387,9 @@ void glvo_gl_chain_r16(float* row, float* store, float* hist, size_t* head, size
             float v = 0.0F;
             for (size_t f = 0; f < F; ++f) {
                 size_t slot = (*head + 1 + f) % F;
-                v = (float) ((double) v + glvo_gl_frame_weight(f, F, use_window) * (double) hist[slot * sz + t]);
+                float w = (float) glvo_gl_frame_weight(f, F, use_window);
+                float p = (use_window && F != 2) ? w * hist[slot * sz + t] : hist[slot * sz + t];
+                v = v + p;
             }
             row[t] = glvo_q16(v / (float) F);
         }
@@ -463,6 +471,39 @@ void glvo_bars_chunked_at(const float* tex, size_t sz, float* bars_out, size_t b
         bars_out[k] = total / weight;
     }
     free(x); free(w);
+}
+
+/* smooth_audio() once more, for the tie-aware comparisons of tests/test_gl_reference.py: the same taps -- selected by the shader's
+ * float bounds smin / smax exactly as in glvo_bars_at -- but weights, products, sums and the quotient in float64, so that
+ * exact[k] is (to ~1e-15) the real number a float implementation approximates; ntaps[k] = taps of bar k (the float error of
+ * an implementation's sum grows with it); fragile[k] = 1 when the tap SET itself hangs on the last bits of the math library:
+ * the count floor(smax - smin) + 1 or the rounding of every tap position round(smin + j) would change if smin / smax moved by
+ * `ulps` units in the last place (log() of two libraries may differ by that) -- such a bar gains or loses a whole tap between
+ * implementations and is compared with no tolerance claim at all. */
+void glvo_bars_at_exact(const float* tex, size_t sz, double* exact, int* ntaps, int* fragile, size_t bars, float smooth_factor, float phase, int ulps) {
+    for (size_t k = 0; k < bars; ++k) {
+        float idx = phase == 0.0F ? (float) k / (float) bars : ((float) k + phase) / (float) bars;
+        float smin = glvo_scale_audio(glvo_clamp01(idx - smooth_factor)) * sz;
+        float smax = glvo_scale_audio(glvo_clamp01(idx + smooth_factor)) * sz;
+        float m = (smax - smin) / 2.0F, rm = smin + m;
+        double avg = 0, weight = 0;
+        int cnt = 0;
+        for (float s = smin; s <= smax; s += 1.0F) {
+            double x = ((double) m - fabs((double) rm - (double) s)) / (double) m;
+            x = x < 0 ? 0 : (x > 1 ? 1 : x);
+            double w = 0.5 * sin(3.14159265358979323846 * x - 3.14159265358979323846 / 2) + 0.5;
+            double tv = tex[(int) roundf(s)];
+            tv = tv > 0 ? (tv < 1 ? tv : 1) : 0;
+            avg += tv * w; weight += w; ++cnt;
+        }
+        exact[k] = weight > 0 ? avg / weight : 0.0;
+        ntaps[k] = cnt;
+        /* scale_audio() = log, a product and a quotient in float: `ulps` units of the larger bound, four times over for the chain */
+        double big = fabs((double) smax) > 1 ? fabs((double) smax) : 1;
+        double eps = 4.0 * ulps * (nextafterf((float) big, INFINITY) - (float) big);
+        double d = (double) smax - (double) smin, fm = (double) smin - floor((double) smin);
+        fragile[k] = fabs(d - rint(d)) <= 2 * eps || fabs(fm - 0.5) <= eps;
+    }
 }
 
 /* The library's s16 window product (glava_amd/csrc/glv_core.h apply_window_split): for every window position of size n the

@@ -158,6 +158,7 @@ int glvemu_process_gl(int n, int in_mode, const void* in, float* out, float* gra
     a.grav_int = gravity_r16_integer_step(a.g, &a.grav_sub) && !force_float_gravity ? 1u : 0u;
     if (F > 64) return 3;
     make_frame_weights(a.wts, F, avg_window != 0, avg_kind);
+    for (unsigned f = 0; f < F; ++f) a.wts32[f] = (float) a.wts[f];
     if (log_e == 5) return log_mode == 0 ? dispatch<0, 5>(log_nn, in_mode, a) : log_mode == 1 ? dispatch<1, 5>(log_nn, in_mode, a) : dispatch<2, 5>(log_nn, in_mode, a);
     if (log_e == 3) return log_mode == 0 ? dispatch<0, 3>(log_nn, in_mode, a) : log_mode == 1 ? dispatch<1, 3>(log_nn, in_mode, a) : dispatch<2, 3>(log_nn, in_mode, a);
     return log_mode == 0 ? dispatch<0, 4>(log_nn, in_mode, a) : log_mode == 1 ? dispatch<1, 4>(log_nn, in_mode, a) : dispatch<2, 4>(log_nn, in_mode, a);
@@ -176,6 +177,7 @@ int glvemu_post_state(const float* in, float* out, float* grav, float* hist, int
     a.avg_window = avg_window; a.gl_storage = gl_storage; a.g = gravity_step * (1.0f / ur); a.F_as_float = (float) F; a.F_rcp = 1.0f / (float) F;
     a.grav_int = gravity_r16_integer_step(a.g, &a.grav_sub) ? 1u : 0u;       // gl_storage 1: grav / hist are uint16 arrays
     make_frame_weights(a.wts, F, avg_window != 0, avg_kind);
+    for (unsigned f = 0; f < F; ++f) a.wts32[f] = (float) a.wts[f];
     for (unsigned r = 0; r < rows; ++r)
         for (int q = 0; q < n / 2; ++q) {
             const uint32_t off = (uint32_t) q * 8u;

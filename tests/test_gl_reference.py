@@ -11,10 +11,14 @@ Generator: tests/golden/make_gl_golden.py (committed; needs /root/reference).
   GPU   the HIP path's gl_storage chain (avg_window_kind 1) and GLV_OP_BARS at the pre-smoothing pass's texel centres
         (bar_phase 0.5, bars == n) against the same texels.
 
-Tolerances are what separates two conforming GL implementations, nothing more: a float -> UNORM16 conversion may take either
-neighbour at a tie (OpenGL 4.6 section 2.3.5; exact ties are common in the unwindowed average: a sum of F integers over F),
-and log() / sin() of the shader compiler's math library may differ from glibc's in the last ulp, which can move ONE tap in or
-out of ONE bar's window.  Hence: every texel within 1 step, mismatches counted, outliers (the tap-count case) bounded."""
+Comparisons are TIE-AWARE: every pass's output texel is the rounding of a real number that can be computed
+exactly from the pass's integer inputs -- the upload x * 65535, the average sum_I w_I c_I / F of the ring's integer texels, the
+weighted mean of smooth_audio()'s taps.  A float implementation may land on either neighbour only where that real number lies
+within its own arithmetic error of a half-integer (a genuine tie: which way it goes is the implementation's business, OpenGL 4.6
+section 2.3.5); everywhere else the texel is determined, and EQUALITY is demanded -- of the reference's llvmpipe texels, of the
+oracle's, of the MI355X's.  The one thing no arithmetic decides is smooth_audio()'s tap SET where a bound computed through log()
+sits within a few ulps of admitting one more tap (glvo_bars_at_exact flags those bars, ~0.5 % at n = 4096): they are excluded
+from the claim, and nothing else is.  No mismatch fractions, no outlier budgets."""
 import ctypes as C
 import os
 
@@ -35,41 +39,90 @@ def texel_float(t):
     return (t.astype(np.float32) / np.float32(65535)).copy()        # what a shader reads back: c / 65535 (OpenGL 4.6 eq. 2.1), correctly rounded
 
 
-def diff_stats(a, b):
-    d = np.abs(a.astype(np.int64) - b.astype(np.int64))
-    return int(d.max()), float((d != 0).mean()), int((d > 1).sum())
+U = 2.0 ** -24          # unit roundoff of the float arithmetic the passes run in
+
+
+def gl_weights(F, win):
+    """average_pass.frag's weights by AGE (0 = oldest): window(I, ...) of common.glsl:13 with I = F - 1 - age; none for two frames"""
+    return np.array([1.0 if (not win or F == 2) else 0.53836 - (0.46164 * np.cos(6.28318530718 * (F - 1 - a) / F - 1)) for a in range(F)])
+
+
+def assert_tie_aware(got, exact, delta, what, skip=None):
+    """got: integer texels; exact: the real value in texel units; delta: the arithmetic error an implementation may have there.
+    Outside |frac(exact) - 0.5| <= delta the texel must be rint(exact); inside, one of the two neighbours."""
+    got = got.astype(np.int64)
+    exact = np.clip(exact, 0.0, 65535.0)
+    lo = np.floor(exact)
+    near = np.abs(exact - lo - 0.5) <= delta
+    keep = np.ones(got.shape, bool) if skip is None else ~skip
+    far_bad = (got != np.rint(exact)) & ~near & keep
+    near_bad = (got != lo) & (got != lo + 1) & near & keep
+    assert not far_bad.any() and not near_bad.any(), (what, int(far_bad.sum()), int(near_bad.sum()), np.flatnonzero(far_bad | near_bad)[:5])
+    return int((near & keep).sum()), int(((got != np.rint(exact)) & keep).sum())
+
+
+def exact_upload(spec):
+    return np.clip(spec.astype(np.float64), 0.0, 1.0) * 65535.0
+
+
+def exact_average(ring, F, win):
+    """ring: F integer texel rows, oldest first"""
+    w = gl_weights(F, win)
+    return sum(w[a] * ring[a].astype(np.float64) for a in range(F)) / F
+
+
+def exact_smooth(av_texels, n):
+    exact = np.empty(n, np.float64); nt = np.empty(n, np.int32); frag = np.empty(n, np.int32)
+    Oracle.lib().glvo_bars_at_exact(texel_float(av_texels), n, exact, nt, frag, n, 0.025, 0.5, 4)
+    return exact * 65535.0, nt, frag.astype(bool)
+
+
+def d_upload(ex): return U * np.maximum(ex, 1.0) + 1e-9                      # one rounding (Mesa multiplies in float before converting)
+def d_average(ex, F): return (F + 8) * U * np.maximum(ex, 1.0)               # F products, F sums, the quotient, the folded weights
+# worst case of an nt-term float sum (numerator and weight sum) + the weights themselves: they are sin() values, GLSL promises no
+# accuracy for sin() and Mesa's llvmpipe evaluates it with a polynomial good to ~2^-20, which a weighted mean inherits
+def d_smooth(ex, nt): return ((nt + 16) * U + 2.0 ** -18) * np.maximum(ex, 1.0)
 
 
 @pytest.mark.parametrize("name,n,F,win", CASES)
-def test_oracle_gl_passes_against_the_reference_gl_execution(name, n, F, win):
-    """gravity store: EXACT; average: within one texel step (ties); upload: within one step; pre-smoothing pass: within one step
-    except where a bar gains / loses a tap to the math library (at most 2 texels per row)."""
+def test_gl_passes_tie_aware_reference_and_oracle(name, n, F, win):
+    """Pass by pass, each fed with the reference's own input texels: the REFERENCE's llvmpipe texels and the ORACLE's restatement
+    against the exact value of the pass -- gravity store exact; upload, average and pre-smoothing pass equal to the rounded exact
+    value except at genuine ties (either neighbour), fragile tap sets of the smooth pass excluded."""
     pcm, tex = GOLD[name + "_pcm"], GOLD[name + "_tex"]
     store = np.zeros((2, n), np.float32); hist = np.zeros((2, F, n), np.float32)
     heads = [C.c_size_t(0), C.c_size_t(0)]
-    worst = {"up": 0.0, "av": 0.0, "sm": 0.0}
+    ring = [[np.zeros(n, np.int64) for _ in range(F)] for _ in range(2)]
+    seen = {"up": [0, 0], "av": [0, 0], "sm": [0, 0], "fragile": 0}
     for f in range(pcm.shape[0]):
         for ch in range(2):
             x = pcm[f, :, ch].astype(np.float32) / np.float32(65535)                       # fifo.c:105-106
-            mx, frac, out = diff_stats(Oracle.texels_r16(Oracle.transform_fft(x)), tex[f, ch, UP])
-            assert mx <= 1 and frac < 5e-3, ("upload", f, ch, mx, frac)
-            worst["up"] = max(worst["up"], frac)
+            spec = Oracle.transform_fft(x)
+            ex = exact_upload(spec)
+            for who, got in (("reference", tex[f, ch, UP]), ("oracle", Oracle.texels_r16(spec))):
+                nn, nd = assert_tie_aware(got, ex, d_upload(ex), ("upload", who, f, ch))
+            seen["up"][0] += nn; seen["up"][1] += nd
             # the passes, fed with the reference's own upload so that each comparison isolates one pass
             row = texel_float(tex[f, ch, UP])
             Oracle.lib().glvo_gl_chain_r16(row, store[ch], hist[ch], C.byref(heads[ch]), n, F, int(win), 1, 4.2, UR)
             assert (Oracle.texels_r16(store[ch]) == tex[f, ch, GR]).all(), ("gravity store", f, ch)
-            mx, frac, out = diff_stats(Oracle.texels_r16(row), tex[f, ch, AV])
-            assert mx <= 1 and frac < (0.55 if not win or F == 2 else 5e-3), ("average", f, ch, mx, frac)   # unweighted sums: exact half-texel ties
-            worst["av"] = max(worst["av"], frac)
-            # keep the model's state on the reference's texels (a one-step difference must not propagate into later frames)
-            store[ch] = texel_float(tex[f, ch, GR])
-            hist[ch][(heads[ch].value + F - 1) % F] = store[ch]
+            ring[ch] = ring[ch][1:] + [tex[f, ch, GR].astype(np.int64)]
+            if F > 1:
+                ex = exact_average(ring[ch], F, win)
+                for who, got in (("reference", tex[f, ch, AV]), ("oracle", Oracle.texels_r16(row))):
+                    nn, nd = assert_tie_aware(got, ex, d_average(ex, F), ("average", who, f, ch))
+                seen["av"][0] += nn; seen["av"][1] += nd
+            else:
+                assert (tex[f, ch, AV] == tex[f, ch, GR]).all() and (Oracle.texels_r16(row) == tex[f, ch, GR]).all()     # render.c:2230
+            # (the model's state IS the reference's: the gravity store matched exactly)
             sm = np.empty(n, np.float32)
             Oracle.lib().glvo_bars_at(texel_float(tex[f, ch, AV]), n, sm, n, 0.025, 0.5)
-            mx, frac, out = diff_stats(Oracle.texels_r16(sm), tex[f, ch, SM])
-            assert out <= 2 and frac < 2e-2, ("smooth pass", f, ch, mx, frac, out)
-            worst["sm"] = max(worst["sm"], frac)
-    print(name, worst)
+            ex, nt, frag = exact_smooth(tex[f, ch, AV], n)
+            for who, got in (("reference", tex[f, ch, SM]), ("oracle", Oracle.texels_r16(sm))):
+                nn, nd = assert_tie_aware(got, ex, d_smooth(ex, nt), ("smooth pass", who, f, ch), skip=frag)
+            seen["sm"][0] += nn; seen["sm"][1] += nd; seen["fragile"] = int(frag.sum())
+    assert seen["fragile"] <= 0.01 * n                                      # the excluded bars are a handful
+    print(name, "near-tie texels / texels the reference rounds the other way:", seen)
 
 
 def test_gl_golden_file_is_reproducible(tmp_path):
@@ -94,42 +147,64 @@ def test_gl_golden_file_is_reproducible(tmp_path):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("name,n,F,win", CASES)
-def test_device_gl_storage_chain_against_the_reference_gl_execution(glvlib, name, n, F, win):
-    """The HIP path with gl_storage = 1 (GL_R16 storage of every pass) and the GL twin's window (avg_window_kind 1), from the
-    same s16 PCM the reference's renderer was fed: its GL_R16 texels against the reference's own `av` texture, frame by frame;
-    then GLV_OP_BARS at the pre-smoothing pass's positions (bar_phase 0.5, bars = n) on the reference's `av` texels against
-    its `sm` texture."""
+def test_device_gl_passes_tie_aware(glvlib, name, n, F, win):
+    """The HIP path (gl_storage 1: the fused GL_R16 chain; avg_window_kind 1; GLV_OP_BARS at the pre-smoothing pass's texel centres)
+    held to the same standard.  Pass by pass, fed with the reference's own texels: upload (GLV_OP_R16 of the transform), gravity +
+    average (the operators on planar rows), smooth pass (glv_batch_bars) -- each equal to the rounded exact value except at genuine
+    ties.  End to end from the PCM the reference's renderer was fed, in ONE call (upload -> gravity -> average -> pre-smoothing
+    pass, all GL_R16): within one texel step of the reference's `av` and `sm` textures (an upload texel that took the other
+    neighbour at a tie travels through max and average as at most that one step), fragile tap sets excluded."""
     import torch
     G = glvlib
     pcm, tex = GOLD[name + "_pcm"], GOLD[name + "_tex"]
     mask = G.OP_GRAVITY | (G.OP_AVERAGE if F > 1 else 0)
     ops = G.OP_FFT | mask
     p = G.Params(n=n, avg_frames=F, avg_window=win, avg_window_kind=1, gl_storage=1, log_mode=0, ur=UR, bars=n, bar_phase=0.5)
-    b = G.Batch(p, 1, mask | G.OP_BARS)
+    up = G.Batch(p, 1, G.OP_FFT)            # the transform with the texel upload
+    passes = G.Batch(p, 1, mask)            # gravity / average passes on the reference's upload texels (planar rows in)
     bb = G.Batch(p, 1, G.OP_FFT | G.OP_BARS)
-    full = G.Batch(p, 1, mask | G.OP_BARS)              # the whole default pipeline in one call: ... | GLV_OP_BARS | GLV_OP_R16
+    full = G.Batch(p, 1, mask | G.OP_BARS)  # the whole default pipeline in one call: ... | GLV_OP_BARS | GLV_OP_R16
+    chain = G.Batch(p, 1, mask)
     d_sm = torch.zeros((2, n), dtype=torch.int16, device="cuda")
     d_q = torch.zeros((2, n), dtype=torch.int16, device="cuda")
     d_bars = torch.empty((2, n), dtype=torch.float32, device="cuda")
+    ring = [[np.zeros(n, np.int64) for _ in range(F)] for _ in range(2)]
     for f in range(pcm.shape[0]):
         d_pcm = torch.from_numpy(np.ascontiguousarray(pcm[f])).cuda()
-        b.process_s16(d_pcm, d_q, ops | G.OP_R16)
+        # upload
+        up.process_s16(d_pcm, d_q, G.OP_FFT | G.OP_R16)
         got = d_q.cpu().numpy().view(np.uint16)
-        # PCM in, the texture the stock modules sample out (upload -> gravity -> average -> pre-smoothing pass, every one GL_R16)
-        full.process_s16(d_pcm, d_sm, ops | G.OP_BARS | G.OP_R16)
-        got_sm = d_sm.cpu().numpy().view(np.uint16)
         for ch in range(2):
-            mx, frac, out = diff_stats(got_sm[ch], tex[f, ch, SM])
-            assert out <= 2 and frac < (0.6 if not win or F == 2 else 5e-2), ("end to end", f, ch, mx, frac, out)
+            x = pcm[f, :, ch].astype(np.float32) / np.float32(65535)
+            ex = exact_upload(Oracle.transform_fft(x))
+            assert_tie_aware(got[ch], ex, d_upload(ex), ("upload", f, ch))
+        # gravity + average passes on the reference's upload
+        rows = np.stack([texel_float(tex[f, ch, UP]) for ch in range(2)])
+        passes.process_f32(torch.from_numpy(rows).cuda(), d_q, mask | G.OP_R16)
+        got = d_q.cpu().numpy().view(np.uint16)
         for ch in range(2):
-            mx, frac, out = diff_stats(got[ch], tex[f, ch, AV])
-            # one-step differences of the upload (0.1 % of texels) travel through max / average: a little more slack than the
-            # per-pass comparison of the CPU test, still within one texel step
-            assert mx <= 1 and frac < (0.55 if not win or F == 2 else 2e-2), ("chain", f, ch, mx, frac)
+            ring[ch] = ring[ch][1:] + [tex[f, ch, GR].astype(np.int64)]
+            if F > 1:
+                ex = exact_average(ring[ch], F, win)
+                assert_tie_aware(got[ch], ex, d_average(ex, F), ("average", f, ch))
+            else:
+                assert (got[ch] == tex[f, ch, GR]).all()
+        # smooth pass on the reference's `av`
         av = np.stack([texel_float(tex[f, ch, AV]) for ch in range(2)])
         bb.bars(torch.from_numpy(av).cuda(), d_bars)
         sm = Oracle.texels_r16(d_bars.cpu().numpy())
+        frags = []
         for ch in range(2):
-            mx, frac, out = diff_stats(sm[ch], tex[f, ch, SM])
-            assert out <= 2 and frac < 2e-2, ("smooth pass", f, ch, mx, frac, out)
-    b.close(); bb.close(); full.close()
+            ex, nt, frag = exact_smooth(tex[f, ch, AV], n)
+            assert_tie_aware(sm[ch], ex, d_smooth(ex, nt), ("smooth pass", f, ch), skip=frag)
+            frags.append(frag)
+        # end to end from PCM
+        chain.process_s16(d_pcm, d_q, ops | G.OP_R16)
+        full.process_s16(d_pcm, d_sm, ops | G.OP_BARS | G.OP_R16)
+        got_av = d_q.cpu().numpy().view(np.uint16); got_sm = d_sm.cpu().numpy().view(np.uint16)
+        for ch in range(2):
+            assert np.abs(got_av[ch].astype(np.int64) - tex[f, ch, AV].astype(np.int64)).max() <= 1, ("chain", f, ch)
+            d = np.abs(got_sm[ch].astype(np.int64) - tex[f, ch, SM].astype(np.int64))
+            # a one-step difference of `av` can move a tap of the smooth pass by one step too: one step, outside the fragile sets
+            assert d[~frags[ch]].max() <= 1, ("end to end", f, ch, int(d[~frags[ch]].max()))
+    for b in (up, passes, bb, full, chain): b.close()

@@ -24,6 +24,13 @@ ARCH = "gfx950"
 HIPFLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC",
             "-fno-fast-math", "-Wall", "-Wno-unused-function"]
 SIZES = (7, 8, 9, 10, 11, 12, 13, 14)
+PARTS = (0, 1, 2)        # glv_inst.hip is compiled per (size, part): s16 inputs / f32 inputs / the runner-up configuration
+
+
+def _inst_jobs(obj_dir: str, sizes, extra: list[str]):
+    """largest sizes first: they compile slowest, the pool should not end on them"""
+    return [("glv_inst.hip", os.path.join(obj_dir, f"glv_inst_{k}_{p}.o"), [f"-DGLV_LOG_NN={k}", f"-DGLV_INST_PART={p}", *extra])
+            for k in sorted(sizes, reverse=True) for p in PARTS]
 HEADERS = ["glv_core.h", "glv_frame.h", "glv_kernel_tmpl.h", "glv_launch.h", "glv_tables.h", "glv_winsplit.h",
            os.path.join("..", "..", "include", "glv_spectrum.h")]
 
@@ -61,7 +68,7 @@ def _compile(src: str, obj: str, extra: list[str]) -> str:
 def _refuse_experiment_flags(flags: list[str]) -> None:
     """the product is compiled with HIPFLAGS + the size only: experiment / tuning macros (glv_core.h) must not reach it"""
     env = " ".join(os.environ.get(k, "") for k in ("HIPCC_COMPILE_FLAGS_APPEND", "HIPFLAGS", "CXXFLAGS", "CPPFLAGS"))
-    bad = [f for f in flags if f.startswith("-D") and not f.startswith("-DGLV_LOG_NN=")]
+    bad = [f for f in flags if f.startswith("-D") and not f.startswith(("-DGLV_LOG_NN=", "-DGLV_INST_PART="))]
     if bad or "-DGLV_" in env:
         raise RuntimeError(f"product build refuses extra macro definitions: {bad or env!r} (use build_variant for A/B libraries)")
 
@@ -91,10 +98,10 @@ def build_variant(name: str, extra_flags: list[str], sizes=SIZES, kernels_only: 
     obj_dir = os.path.join(OBJ, name)
     os.makedirs(obj_dir, exist_ok=True)
     extra_flags = ["-DGLV_TUNE_BUILD", *[f for f in extra_flags if f != "-DGLV_TUNE_BUILD"]]      # the experiment macros' switch (glv_core.h)
-    jobs = [("glv_inst.hip", os.path.join(obj_dir, f"glv_inst_{k}.o"), [f"-DGLV_LOG_NN={k}", *extra_flags]) for k in sizes]
+    jobs = _inst_jobs(obj_dir, sizes, extra_flags)
     reused = []
     if kernels_only:
-        reused = [os.path.join(OBJ, f"glv_inst_{k}.o") for k in SIZES if k not in sizes]
+        reused = [os.path.join(OBJ, f"glv_inst_{k}_{p}.o") for k in SIZES if k not in sizes for p in PARTS]
         reused += [os.path.join(OBJ, o) for o in ("glv_misc.o", "glv_api.o", "glv_multi.o")]
     else:
         jobs.append(("glv_misc.hip", os.path.join(obj_dir, "glv_misc.o"), list(extra_flags)))
@@ -119,7 +126,7 @@ def build(tune: bool = False, verbose: bool = False) -> str:
             print("up to date", lib)
         return lib
     os.makedirs(OBJ, exist_ok=True)
-    jobs = [("glv_inst.hip", os.path.join(OBJ, f"glv_inst_{k}.o"), [f"-DGLV_LOG_NN={k}"]) for k in SIZES]
+    jobs = _inst_jobs(OBJ, SIZES, [])
     jobs.append(("glv_misc.hip", os.path.join(OBJ, "glv_misc.o"), []))
     jobs.append(("glv_api.cpp", os.path.join(OBJ, "glv_api.o"), ["-x", "hip"]))
     jobs.append(("glv_multi.cpp", os.path.join(OBJ, "glv_multi.o"), ["-x", "hip"]))

@@ -120,11 +120,14 @@ void wisdom_store(const WisdomKey& k, int variant, int grid, float ms) {
     for (WisdomEntry& e : g_wisdom) if (same_key(e.k, k)) { e.variant = variant; e.grid = grid; e.ms = ms; return; }
     g_wisdom.push_back(WisdomEntry{k, variant, grid, ms});
 }
-int wisdom_load_file(const char* path) {
+// Returns the number of entries loaded, -1 when the file cannot be opened.  Lines that are not entries of the current (v2,
+// 11-field) format are counted: *skipped, of which *v1 look like the 7-field format of round 2 (n input_kind ops_class log_mode
+// log2(streams) workgroups ms) -- a tuned deployment must not fall back to defaults unnoticed.
+int wisdom_load_file(const char* path, int* skipped = nullptr, int* v1 = nullptr) {
     FILE* f = std::fopen(path, "r");
     if (!f) { (void) fail(GLV_ERR_INVALID, "cannot open wisdom file %s", path); return -1; }
     char line[320];
-    int n_loaded = 0;
+    int n_loaded = 0, n_skipped = 0, n_v1 = 0;
     while (std::fgets(line, sizeof(line), f)) {
         if (line[0] == '#' || line[0] == '\n') continue;
         WisdomKey k; int variant, grid; float ms; char dev[48];
@@ -133,9 +136,15 @@ int wisdom_load_file(const char* path) {
                         &k.avg_frames, &variant, &grid, &ms) == 11 && grid > 0 && variant >= 0) {
             key_set_device(k, dev, k.cus);
             wisdom_store(k, variant, grid, ms); ++n_loaded;
+        } else {
+            ++n_skipped;
+            unsigned a[5]; int g1; float m1; char tail[8];
+            if (std::sscanf(line, "%u %u %u %u %u %d %f %7s", &a[0], &a[1], &a[2], &a[3], &a[4], &g1, &m1, tail) == 7) ++n_v1;
         }
     }
     std::fclose(f);
+    if (skipped) *skipped = n_skipped;
+    if (v1) *v1 = n_v1;
     return n_loaded;
 }
 
@@ -444,7 +453,7 @@ int ensure_bar_tables(glv_batch* b) {
     for (int v = 0; v < nv && v < glv_batch::kMaxVariants; ++v) {
         const glv::FrameGeometry geo = glv::frame_geometry(b->log_nn, v);
         // bar totals + the dump slot fit the 2 * lanes floats of slack behind the row in LDS
-        b->bar_fusable[v] = geo.lanes % 64 == 0 && b->p.bars + 1 <= 2 * (uint32_t) geo.lanes;
+        b->bar_fusable[v] = geo.lanes % 64 == 0 && geo.nbuf == 1 && b->p.bars + 1 <= 2 * (uint32_t) geo.lanes;
         if (!b->bar_fusable[v]) continue;
         std::vector<glv::BarItem> fitems;
         b->bar_fnsteps[v] = glv::make_bar_items(fitems, desc, (uint32_t) geo.lanes / gl, zero_off, chunk, (uint32_t) geo.bar_batch);
@@ -712,7 +721,12 @@ int batch_create_rows(const glv_params* p, uint32_t streams, unsigned ops_mask, 
         const bool first = !g_wisdom_env_loaded;
         g_wisdom_env_loaded = true;
         lock.unlock();
-        if (first) if (const char* w = std::getenv("GLV_WISDOM")) (void) wisdom_load_file(w);      // a missing file is not an error
+        if (first) if (const char* w = std::getenv("GLV_WISDOM")) {                                    // a missing file is not an error
+            int skipped = 0, v1 = 0;
+            const int nl = wisdom_load_file(w, &skipped, &v1);
+            if (nl >= 0 && skipped > 0)
+                std::fprintf(stderr, "glv: GLV_WISDOM=%s: %d entries loaded, %d line(s) skipped%s\n", w, nl, skipped, v1 ? " (7-field v1 format: re-tune)" : "");
+        }
     }
     glv_batch* b = new (std::nothrow) glv_batch();
     if (!b) return fail(GLV_ERR_NOMEM, "out of host memory");
@@ -1031,8 +1045,18 @@ int glv_wisdom_clear(void) {
 int glv_wisdom_count(void) { std::lock_guard<std::mutex> lock(g_wisdom_mu); return (int) g_wisdom.size(); }
 int glv_wisdom_load(const char* path) {
     if (!path) return fail(GLV_ERR_INVALID, "path is NULL");
-    const int n = wisdom_load_file(path);
-    return n < 0 ? GLV_ERR_INVALID : GLV_OK;
+    int skipped = 0, v1 = 0;
+    const int n = wisdom_load_file(path, &skipped, &v1);
+    if (n < 0) return GLV_ERR_INVALID;
+    if (skipped > 0) {
+        // a file that yields nothing is an error; a partly usable one loads, with the count left in glv_last_error()
+        const int code = n == 0 ? GLV_ERR_INVALID : GLV_OK;
+        (void) fail(code, "wisdom file %s: %d entr%s loaded, %d line(s) skipped%s", path, n, n == 1 ? "y" : "ies", skipped,
+                    v1 ? " (some are in the 7-field v1 format of an older library: re-tune with glv_batch_autotune and save again)" : " (not in the 11-field v2 format)");
+        return code;
+    }
+    g_err = "";
+    return GLV_OK;
 }
 int glv_wisdom_save(const char* path) {
     if (!path) return fail(GLV_ERR_INVALID, "path is NULL");
@@ -1135,7 +1159,7 @@ int glv_batch_describe_variant(const glv_batch* b, int variant, char* buf, size_
     const glv::FrameGeometry g = glv::frame_geometry(b->log_nn, variant);
     std::snprintf(buf, len, "n=%u variant %d: %d points per lane, %d lanes per row, %d row(s) per workgroup, %d workgroup(s) per CU, "
                             "%d KiB LDS, twiddles %s, window %s", b->p.n, variant, 1 << g.log_e, g.lanes, g.slots, g.resident, (g.lds_bytes + 1023) / 1024,
-                  g.twreg == 1 ? "in VGPRs" : g.twreg == 0 ? "through L2" : g.twreg == 4 ? "in LDS" : "middle passes in LDS, last pass through L2",
+                  g.twreg == 1 ? "in VGPRs" : g.twreg == 0 ? "through L2" : g.twreg == 4 ? (g.nbuf == 0 ? "in LDS (split exchange)" : "in LDS") : "middle passes in LDS, last pass through L2",
                   g.winlds ? "in LDS" : "through L2");
     return GLV_OK;
 }

@@ -867,6 +867,51 @@ struct Frame {
         }
     }
 
+    // ---- the last exchange as wavefront shuffles (north_star: "wavefront shuffles for the small-stage butterflies"; A/B knob
+    // GLV_EXP_SHUFFLE, tools/tune.py builds only) -----------------------------------------------------------------------------
+    // Where ONE wave owns a row and a lane holds 8 points (N=1024: T = 64, E = 8, passes 3+3+3) the exchange between the last two
+    // passes is a pure 8 x 8 transpose between the register index and lane bits 3..5: slot r of lane (a, l) -- a = lane >> 3,
+    // l = lane & 7 -- holds element a*64 + bitrev(r)*8 + l, and the last pass wants element i*64 + lane in slot i, i.e. slot
+    // bitrev(h) of lane (i, l) in slot i of lane (h, l).  Three butterfly stages of 2 x 2 block swaps do it without LDS:
+    //   lane bit 5 <-> register bit 2   v_permlane32_swap_b32  (the two 32-lane halves trade registers)     8 instructions
+    //   lane bit 4 <-> register bit 1   v_permlane16_swap_b32  (rows of 16)                                8
+    //   lane bit 3 <-> register bit 0   v_mov_b32 ... row_ror:8 under a bank mask: no 8-lane swap exists,  24 (a copy and two
+    //                                   masked moves per dword pair)
+    // 40 vector-ALU instructions in place of 8 ds_write_b64 + 8 ds_read_b64 and their round trip.  Pure data movement: same bits.
+    static constexpr bool SHUFFLE_LAST = T == 64 && E == 8 && P >= 2 && PL::rb(P - 1) == 3 && PL::log_l0(P - 1) == LOG_NN - 3 && LOG_NN == 9;
+#if defined(__HIPCC__)
+    __device__ __forceinline__ static void shuffle_last(cf (&v)[E]) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        float w[8][2];                                   // w[b] = the slot holding element ... + b*8 + l: slot bitrev(b)
+#pragma unroll
+        for (int b = 0; b < 8; ++b) { w[b][0] = v[bitrev(b, 3)].x; w[b][1] = v[bitrev(b, 3)].y; }
+        // register bit 2 <-> lane bit 5
+        asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %8\n\tv_permlane32_swap_b32 %1, %9\n\tv_permlane32_swap_b32 %2, %10\n\tv_permlane32_swap_b32 %3, %11\n\t"
+                     "v_permlane32_swap_b32 %4, %12\n\tv_permlane32_swap_b32 %5, %13\n\tv_permlane32_swap_b32 %6, %14\n\tv_permlane32_swap_b32 %7, %15\n\ts_nop 1"
+                     : "+v"(w[0][0]), "+v"(w[0][1]), "+v"(w[1][0]), "+v"(w[1][1]), "+v"(w[2][0]), "+v"(w[2][1]), "+v"(w[3][0]), "+v"(w[3][1]),
+                       "+v"(w[4][0]), "+v"(w[4][1]), "+v"(w[5][0]), "+v"(w[5][1]), "+v"(w[6][0]), "+v"(w[6][1]), "+v"(w[7][0]), "+v"(w[7][1]));
+        // register bit 1 <-> lane bit 4
+        asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %8\n\tv_permlane16_swap_b32 %1, %9\n\tv_permlane16_swap_b32 %2, %10\n\tv_permlane16_swap_b32 %3, %11\n\t"
+                     "v_permlane16_swap_b32 %4, %12\n\tv_permlane16_swap_b32 %5, %13\n\tv_permlane16_swap_b32 %6, %14\n\tv_permlane16_swap_b32 %7, %15\n\ts_nop 1"
+                     : "+v"(w[0][0]), "+v"(w[0][1]), "+v"(w[1][0]), "+v"(w[1][1]), "+v"(w[4][0]), "+v"(w[4][1]), "+v"(w[5][0]), "+v"(w[5][1]),
+                       "+v"(w[2][0]), "+v"(w[2][1]), "+v"(w[3][0]), "+v"(w[3][1]), "+v"(w[6][0]), "+v"(w[6][1]), "+v"(w[7][0]), "+v"(w[7][1]));
+        // register bit 0 <-> lane bit 3: lanes 0-7 of every row of 16 keep A and take the partner's A into B, lanes 8-15 take the
+        // partner's B into A and keep B (row_ror:8 reads lane ^ 8 inside a row; bank mask 0x3 = lanes 0-7, 0xC = lanes 8-15)
+#pragma unroll
+        for (int b = 0; b < 8; b += 2)
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                const int A = __builtin_bit_cast(int, w[b][c]), B = __builtin_bit_cast(int, w[b + 1][c]);
+                const int nB = __builtin_amdgcn_update_dpp(B, A, 0x128, 0xF, 0x3, false);
+                const int nA = __builtin_amdgcn_update_dpp(A, B, 0x128, 0xF, 0xC, false);
+                w[b][c] = __builtin_bit_cast(float, nA); w[b + 1][c] = __builtin_bit_cast(float, nB);
+            }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { v[i].x = w[i][0]; v[i].y = w[i][1]; }
+#endif
+    }
+#endif
+
     // ---- split exchange (kernel knob NBUF = 0): the row crosses LDS one float component at a time -- all real parts
     // (write, barrier, read), then all imaginary parts -- so the exchange region is XREGION floats instead of XREGION complex
     // points: half the LDS per row in flight, at the price of two more barriers per exchange and 4-byte LDS accesses.  The

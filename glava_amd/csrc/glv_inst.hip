@@ -1,12 +1,19 @@
 // glv_inst.hip -- production instantiations of glv_frame_kernel for ONE transform size.
-// Compiled once per size with -DGLV_LOG_NN=k (k = log2(nn) = log2(N) - 1, 7..14) so the eight
-// sizes build in parallel.  The knob set per size is the measured best of tools/tune.py
+// Compiled per size with -DGLV_LOG_NN=k (k = log2(nn) = log2(N) - 1, 7..14) and per PART with -DGLV_INST_PART=p so that the
+// 24 translation units build in parallel and balance over the cores (the large sizes compile slowest):
+//   part 0  s16 frames and the s16 ring, configuration 0; the size's dispatcher and geometry functions
+//   part 1  the f32 inputs (planar rows, interleaved stereo, the f32 ring), configuration 0
+//   part 2  configuration 1 (the runner-up plan of the size), every input
+// The knob set per size is the measured best of tools/tune.py
 // (profiles/tune_r01_final.txt, earlier sweeps in profiles/tune_r01.txt); see DESIGN.md "Kernel configuration".
 #include "glv_kernel_tmpl.h"
 #include "glv_launch.h"
 
 #ifndef GLV_LOG_NN
 #error "compile with -DGLV_LOG_NN=<7..14>"
+#endif
+#ifndef GLV_INST_PART
+#error "compile with -DGLV_INST_PART=<0..2>"
 #endif
 
 namespace glv {
@@ -38,8 +45,11 @@ GLV_TUNED(12,   0, 4,    2,    1,   true,  true,  2,  1,       true,   0,   0,  
 GLV_TUNED(12,   1, 4,    1,    1,   true,  false, 2,  1,       true,   0,   0,   2)    //          one row per workgroup, two workgroups per CU, window through L2 (tie with log_mode 0 in the r01 sweep)
 GLV_TUNED(13,   0, 5,    1,    1,   2,     false, 2,  1,       3,      0,   0,   2)    // N=16384  E=32: 5+5+3; pass-1 twiddles from an 8 KiB LDS table, tilt computed (log_mode 1: two fused ops per value)
                                                                                        //          (WPRE, the window prefetch ahead of the stores, measured no gain: profiles/r02)
+GLV_TUNED(13,   1, 5,    2,    0,   4,     false, 2,  1,       3,      0,   0,   2)    //          split exchange (the row crosses LDS one float component at a time): two rows per 512-thread workgroup and
+                                                                                       //          EVERY twiddle in LDS, no L2 gather (tied the production plan in r03 sweep_xsplit; fused bars fall back to two launches)
 GLV_TUNED(14,   0, 5,    1,    1,   2,     false, 2,  1,       3,      0,   0,   1)    // N=32768  E=32: 5+5+4, one 512-lane row per CU (135 KiB exchange region), pass-1 twiddles from LDS (sweep_13)
-GLV_NVARIANTS(8, 2) GLV_NVARIANTS(9, 2) GLV_NVARIANTS(10, 2) GLV_NVARIANTS(11, 2) GLV_NVARIANTS(12, 2)
+GLV_TUNED(14,   1, 5,    1,    1,   0,     false, 2,  1,       3,      0,   0,   1)    //          every pass's per-lane twiddles gathered from the L2-resident table (no LDS copy: 8 KiB more for the exchange)
+GLV_NVARIANTS(8, 2) GLV_NVARIANTS(9, 2) GLV_NVARIANTS(10, 2) GLV_NVARIANTS(11, 2) GLV_NVARIANTS(12, 2) GLV_NVARIANTS(13, 2) GLV_NVARIANTS(14, 2)
 #undef GLV_TUNED
 #undef GLV_NVARIANTS
 
@@ -48,11 +58,11 @@ GLV_NVARIANTS(8, 2) GLV_NVARIANTS(9, 2) GLV_NVARIANTS(10, 2) GLV_NVARIANTS(11, 2
 
 constexpr int kNV = NumVariants<GLV_LOG_NN>::value;
 
-// The runners-up are built for the inputs and log modes a tuned deployment runs (s16 frames and the s16 ring, log_mode 0 / 1):
-// every other combination has variant 0 only (frame_variant_ok), which keeps the library at ~1.3x the single-variant build.
+// The runner-up is built for every input and the log modes a deployment runs (0 and 1); log_mode 2 (audit) has configuration 0 only.
 static bool variant_built(int in_mode, int log_mode, int variant) {
+    (void) in_mode;
     if (variant == 0) return true;
-    return variant > 0 && variant < kNV && (in_mode == IN_S16_STEREO || in_mode == IN_S16_RING) && (log_mode == 0 || log_mode == 1);
+    return variant > 0 && variant < kNV && (log_mode == 0 || log_mode == 1);
 }
 
 template <int IN_MODE, int LOG_MODE, int V>
@@ -61,32 +71,59 @@ static hipError_t launch_one(const FrameArgs& a, int grid, hipStream_t st) {
     return launch_variant<GLV_LOG_NN, IN_MODE, LOG_MODE, TU::slots, TU::nbuf, TU::twreg, TU::winlds, TU::occ, TU::prefetch, TU::tiltreg, TU::log_e, TU::wpre, TU::wpre_s>(a, grid, st);
 }
 
-template <int IN_MODE>
-static hipError_t launch_log(int log_mode, int variant, const FrameArgs& a, int grid, hipStream_t st) {
-    if constexpr (kNV > 1 && (IN_MODE == IN_S16_STEREO || IN_MODE == IN_S16_RING)) {
-        if (variant == 1) {
-            if (log_mode == 0) return launch_one<IN_MODE, 0, 1>(a, grid, st);
-            if (log_mode == 1) return launch_one<IN_MODE, 1, 1>(a, grid, st);
-        }
-    }
-    if (variant != 0) return hipErrorInvalidValue;
+// the three parts' entry points (each defined by the translation unit compiled with that GLV_INST_PART)
+hipError_t GLV_CAT(GLV_CAT(launch_frame_, GLV_LOG_NN), _part0)(int in_mode, int log_mode, const FrameArgs& a, int grid, hipStream_t st);
+hipError_t GLV_CAT(GLV_CAT(launch_frame_, GLV_LOG_NN), _part1)(int in_mode, int log_mode, const FrameArgs& a, int grid, hipStream_t st);
+hipError_t GLV_CAT(GLV_CAT(launch_frame_, GLV_LOG_NN), _part2)(int in_mode, int log_mode, const FrameArgs& a, int grid, hipStream_t st);
+
+template <int IN_MODE, int V>
+static hipError_t launch_log(int log_mode, const FrameArgs& a, int grid, hipStream_t st) {
     switch (log_mode) {
-        case 0: return launch_one<IN_MODE, 0, 0>(a, grid, st);
-        case 1: return launch_one<IN_MODE, 1, 0>(a, grid, st);
-        case 2: return launch_one<IN_MODE, 2, 0>(a, grid, st);
+        case 0: return launch_one<IN_MODE, 0, V>(a, grid, st);
+        case 1: return launch_one<IN_MODE, 1, V>(a, grid, st);
+        case 2: if constexpr (V == 0) return launch_one<IN_MODE, 2, 0>(a, grid, st); else return hipErrorInvalidValue;
     }
     return hipErrorInvalidValue;
 }
 
-hipError_t GLV_CAT(launch_frame_, GLV_LOG_NN)(int in_mode, int log_mode, int variant, const FrameArgs& a, int grid, hipStream_t st) {
+#if GLV_INST_PART == 0
+hipError_t GLV_CAT(GLV_CAT(launch_frame_, GLV_LOG_NN), _part0)(int in_mode, int log_mode, const FrameArgs& a, int grid, hipStream_t st) {
     switch (in_mode) {
-        case IN_S16_STEREO: return launch_log<IN_S16_STEREO>(log_mode, variant, a, grid, st);
-        case IN_S16_RING:   return launch_log<IN_S16_RING>(log_mode, variant, a, grid, st);
-        case IN_F32_PLANAR: return launch_log<IN_F32_PLANAR>(log_mode, variant, a, grid, st);
-        case IN_F32_STEREO: return launch_log<IN_F32_STEREO>(log_mode, variant, a, grid, st);
-        case IN_F32_RING:   return launch_log<IN_F32_RING>(log_mode, variant, a, grid, st);
+        case IN_S16_STEREO: return launch_log<IN_S16_STEREO, 0>(log_mode, a, grid, st);
+        case IN_S16_RING:   return launch_log<IN_S16_RING, 0>(log_mode, a, grid, st);
     }
     return hipErrorInvalidValue;
+}
+#elif GLV_INST_PART == 1
+hipError_t GLV_CAT(GLV_CAT(launch_frame_, GLV_LOG_NN), _part1)(int in_mode, int log_mode, const FrameArgs& a, int grid, hipStream_t st) {
+    switch (in_mode) {
+        case IN_F32_PLANAR: return launch_log<IN_F32_PLANAR, 0>(log_mode, a, grid, st);
+        case IN_F32_STEREO: return launch_log<IN_F32_STEREO, 0>(log_mode, a, grid, st);
+        case IN_F32_RING:   return launch_log<IN_F32_RING, 0>(log_mode, a, grid, st);
+    }
+    return hipErrorInvalidValue;
+}
+#else
+hipError_t GLV_CAT(GLV_CAT(launch_frame_, GLV_LOG_NN), _part2)(int in_mode, int log_mode, const FrameArgs& a, int grid, hipStream_t st) {
+    if constexpr (kNV > 1) {
+        switch (in_mode) {
+            case IN_S16_STEREO: return launch_log<IN_S16_STEREO, 1>(log_mode, a, grid, st);
+            case IN_S16_RING:   return launch_log<IN_S16_RING, 1>(log_mode, a, grid, st);
+            case IN_F32_PLANAR: return launch_log<IN_F32_PLANAR, 1>(log_mode, a, grid, st);
+            case IN_F32_STEREO: return launch_log<IN_F32_STEREO, 1>(log_mode, a, grid, st);
+            case IN_F32_RING:   return launch_log<IN_F32_RING, 1>(log_mode, a, grid, st);
+        }
+    }
+    return hipErrorInvalidValue;
+}
+#endif
+
+#if GLV_INST_PART == 0
+hipError_t GLV_CAT(launch_frame_, GLV_LOG_NN)(int in_mode, int log_mode, int variant, const FrameArgs& a, int grid, hipStream_t st) {
+    if (variant == 1) return GLV_CAT(GLV_CAT(launch_frame_, GLV_LOG_NN), _part2)(in_mode, log_mode, a, grid, st);
+    if (variant != 0) return hipErrorInvalidValue;
+    if (in_mode == IN_S16_STEREO || in_mode == IN_S16_RING) return GLV_CAT(GLV_CAT(launch_frame_, GLV_LOG_NN), _part0)(in_mode, log_mode, a, grid, st);
+    return GLV_CAT(GLV_CAT(launch_frame_, GLV_LOG_NN), _part1)(in_mode, log_mode, a, grid, st);
 }
 
 // what the host needs to know about configuration `variant` of this size (glv_launch.h FrameGeometry)
@@ -113,7 +150,7 @@ static FrameGeometry geometry_of() {
     // the grid slightly smaller than strictly necessary.
     g.rows_per_trip = (TU::prefetch == 1 || TU::slots == 1) ? 2 * TU::slots : TU::slots;
     g.lds_bytes = (int) lds;
-    g.log_e = TU::log_e; g.slots = TU::slots; g.twreg = TU::twreg; g.winlds = TU::winlds ? 1 : 0;
+    g.log_e = TU::log_e; g.slots = TU::slots; g.twreg = TU::twreg; g.winlds = TU::winlds ? 1 : 0; g.nbuf = TU::nbuf;
     return g;
 }
 
@@ -123,5 +160,7 @@ FrameGeometry GLV_CAT(frame_geometry_, GLV_LOG_NN)(int variant) {
     if constexpr (kNV > 1) { if (variant == 1) return geometry_of<1>(); }
     return geometry_of<0>();
 }
+
+#endif   // GLV_INST_PART == 0
 
 }  // namespace glv

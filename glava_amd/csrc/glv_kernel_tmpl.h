@@ -185,6 +185,11 @@ struct Body {
         if constexpr (PASS + 1 < P) {
             char* xb = xslot + (NBUF == 2 ? (size_t) (xcount & 1u) * FR::XREGION * sizeof(cf) : 0);
             GLV_SCHED_FENCE();
+#if defined(GLV_EXP_SHUFFLE)          /* tools/tune.py A/B: the last exchange as wavefront shuffles (glv_frame.h shuffle_last) */
+            if constexpr (PASS + 1 == P - 1 && FR::SHUFFLE_LAST) {
+                FR::shuffle_last(v);
+            } else
+#endif
             if constexpr (NBUF == 0) {
                 // split exchange: real parts, then imaginary parts, through the one half-size region
                 sy.sync();                                  // previous readers of the region are done

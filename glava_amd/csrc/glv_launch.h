@@ -15,6 +15,7 @@ struct FrameGeometry {
     int rows_per_trip;  // channel rows one workgroup takes per trip of its persistent loop
     int bar_batch;      // steps per batch of the fused GLV_OP_BARS loop: its work lists are padded to multiples of this
     int lds_bytes, log_e, slots, twreg, winlds;   // for diagnostics / the wisdom file's comments
+    int nbuf;           // exchange regions per row (0: split exchange -- no room to park a finished row: bars are a second launch)
 };
 
 // per-size production launchers, one translation unit each (glv_inst.hip -DGLV_LOG_NN=k)

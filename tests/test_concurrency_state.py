@@ -345,13 +345,14 @@ def test_gl_storage_chain_with_smooth_and_raw(G, n, F):
 
 
 # ---- kernel configurations (f4) -----------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("n", [512, 1024, 2048, 4096, 8192])
+@pytest.mark.parametrize("n", [512, 1024, 2048, 4096, 8192, 16384, 32768])
 def test_every_kernel_variant_gives_the_same_bits(G, n):
     """glv_inst.hip builds more than one kernel configuration for these sizes (a different radix split / rows per workgroup /
-    table placement).  Whatever the wisdom picks, the spectra are the same: raw FFT, magnitudes (both log modes), the
-    stateful chain, GL_R16 texels, fused bars and the ring mode of every variant equal variant 0 bit for bit."""
+    table placement; since round 4 also for N = 16384 -- the split exchange with every twiddle in LDS -- and N = 32768, and for
+    the f32 inputs).  Whatever the wisdom picks, the spectra are the same: raw FFT, magnitudes (both log modes), the stateful
+    chain, GL_R16 texels, fused bars, the ring mode and the f32 inputs of every variant equal variant 0 bit for bit."""
     import torch
-    streams, F, nf = 37, 5, 256
+    streams, F, nf = (37 if n <= 8192 else 9), 5, 256
     pcm = [torch.from_numpy(lcg_pcm_fast(8200 + n + u, streams * 2 * n)).cuda() for u in range(3)]
     new = torch.from_numpy(lcg_pcm_fast(8300 + n, streams * nf * 2)).cuda()
     results = []
@@ -380,11 +381,18 @@ def test_every_kernel_variant_gives_the_same_bits(G, n):
                 bc.process_s16(pcm[u], o, G.OP_FFT | G.OP_GRAVITY | G.OP_AVERAGE); out["chain%d" % u] = o.clone()
                 bb.process_s16(pcm[u], d_bars, G.OP_FFT | G.OP_GRAVITY | G.OP_AVERAGE | G.OP_BARS); out["bars%d" % u] = d_bars.clone()
             bc.close(); bb.close()
-            # f32 inputs have variant 0 only: a forced variant falls back instead of failing
-            bf = G.Batch(p, streams, G.OP_FFT | G.OP_BARS | G.OP_RING_S16); bf.set_variant(v)
+            # the f32 inputs carry the runner-up too (round 4); the audit log mode has configuration 0 only: a forced variant falls
+            # back there instead of failing
+            bf = G.Batch(p, streams, G.OP_FFT | G.OP_GRAVITY | G.OP_AVERAGE); bf.set_variant(v)
             x = torch.from_numpy((np.random.default_rng(n).standard_normal((streams * 2, n)) * 0.3).astype(np.float32)).cuda()
-            bf.process_f32(x, o, G.OP_FFT); out["f32"] = o.clone(); assert bf.last_variant() == 0
+            xs = torch.from_numpy((np.random.default_rng(n + 1).standard_normal((streams, n, 2)) * 0.3).astype(np.float32)).cuda()
+            bf.process_f32(x, o, G.OP_FFT); out["f32"] = o.clone(); assert bf.last_variant() == v
+            bf.process_f32_stereo(xs, o, G.OP_FFT | G.OP_GRAVITY | G.OP_AVERAGE); out["f32s_chain"] = o.clone(); assert bf.last_variant() == v
             bf.close()
+            if log_mode == 1:
+                ba = G.Batch(G.Params(n=n, log_mode=2), streams, G.OP_FFT); ba.set_variant(v)
+                ba.process_s16(pcm[0], o, G.OP_FFT); assert ba.last_variant() == 0
+                ba.close()
             per_variant.append(out)
         for v in range(1, nv):
             for k, t in per_variant[0].items():

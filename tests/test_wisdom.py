@@ -15,7 +15,14 @@ def test_wisdom_file_roundtrip(glvlib, tmp_path):
     p.write_text("# comment\ngfx950:sramecc+:xnack- 256 8192 0 0 1 15 0 1 256 0.697000\ngfx950:sramecc+:xnack- 256 16384 0 1 1 14 5 0 512 1.270000\nnot an entry\n"
                  "gfx950 256 4096 0 0 1 16 0 0 0 0.5\n8192 0 0 1 15 256 0.697000\ngfx942 304 8192 0 0 1 15 0 0 304 0.9\n")
     G.wisdom_load(str(p))
-    assert G.wisdom_count() == 3                      # the malformed line, the grid-0 line and the round-2 (v1) line are ignored
+    assert G.wisdom_count() == 3                      # the malformed line, the grid-0 line and the round-2 (v1) line are ignored ...
+    msg = G.lib().glv_last_error().decode()           # ... but not silently
+    assert "3 entries loaded" in msg and "3 line(s) skipped" in msg and "v1" in msg, msg
+    old = tmp_path / "v1.txt"
+    old.write_text("# glv launch wisdom v1\n8192 0 0 1 15 256 0.697000\n4096 0 0 1 16 512 0.650000\n")
+    with pytest.raises(G.GlvError) as ei:             # a file that yields nothing is an error
+        G.wisdom_load(str(old))
+    assert ei.value.code == G.ERR_INVALID and "v1" in str(ei.value)
     q = tmp_path / "out.txt"
     G.wisdom_save(str(q))
     lines = [l.split() for l in q.read_text().splitlines() if not l.startswith("#")]
@@ -75,7 +82,7 @@ def test_autotune_measures_records_and_is_used(glvlib, tmp_path):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("n,streams", [(4096, 8192), (8192, 4096), (1024, 32768)])
+@pytest.mark.parametrize("n,streams", [(4096, 8192), (8192, 4096), (1024, 32768), (16384, 2048), (32768, 1024)])
 def test_wisdom_selects_the_kernel_variant(glvlib, tmp_path, n, streams):
     """f4: the wisdom chooses WHICH kernel configuration runs (radix split / rows per workgroup / table placement), not only the
     grid.  autotune times every configuration built for the size and records the winner; the entry is keyed on the device, so a

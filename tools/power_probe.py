@@ -23,16 +23,22 @@ def sample():
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--seconds", type=float, default=6.0)
+    ap.add_argument("--n", type=int, default=4096)
+    ap.add_argument("--streams", type=int, default=0, help="default: 65536 * 4096 / n (equal bytes)")
+    ap.add_argument("--only", default="", help="comma list of pass names to run: f32,r16,strict (default all)")
     a = ap.parse_args()
     import statistics
     import torch
     from glava_amd import build as B, spectrum as G
     B.build()
-    n, streams = 4096, 65536
+    n = a.n
+    streams = a.streams or 65536 * 4096 // n
+    only = set(a.only.split(",")) if a.only else None
     pcm = torch.randint(-32768, 32768, (streams, n, 2), dtype=torch.int16, device="cuda")
     out = torch.empty((streams, 2, n), dtype=torch.float32, device="cuda")
-    print("idle:", sample())
-    for name, ops, lm in (("window+FFT+magnitude -> f32", G.OP_FFT, 1), ("... -> GL_R16 texels", G.OP_FFT | G.OP_R16, 1), ("bit-faithful log -> f32", G.OP_FFT, 0)):
+    print(f"N={n} x {streams} streams, library {os.environ.get('GLV_SPECTRUM_LIB', 'product')}; idle:", sample())
+    for key, name, ops, lm in (("f32", "window+FFT+magnitude -> f32", G.OP_FFT, 1), ("r16", "... -> GL_R16 texels", G.OP_FFT | G.OP_R16, 1), ("strict", "bit-faithful log -> f32", G.OP_FFT, 0)):
+        if only and key not in only: continue
         b = G.Batch(G.Params(n=n, log_mode=lm), streams, G.OP_FFT)
         stop = False
         samples = []

@@ -148,8 +148,21 @@ int wisdom_load_file(const char* path, int* skipped = nullptr, int* v1 = nullptr
     return n_loaded;
 }
 
-// Device-resident constants of one transform size.
+// Device-resident constants of one transform size.  The size-only tables -- twiddles, the window in both forms (the float-pair
+// form is SEARCHED on the device: n workgroups trying 65 536 sample values per position), the log table -- are made once per
+// (device, n) and shared by every batch of that size with a reference count (glv_multi shards, the five configs[4]
+// batches and the audio backends used to repeat the search and its synchronisation points); the tilt factors depend on a batch's
+// parameters and stay per batch.
+struct SharedTables {
+    int device = 0; uint32_t n = 0; int refs = 0;
+    glv::cf* d_tw = nullptr; double* d_win = nullptr; float* d_win_split = nullptr; glv::LogEntry* d_log = nullptr;
+    int win_shifted = 0;
+};
+std::mutex g_tab_mu;
+std::vector<SharedTables*> g_tabs;
+
 struct Tables {
+    SharedTables* shared = nullptr;
     glv::cf* d_tw = nullptr;
     double* d_win = nullptr;
     float* d_win_split = nullptr;      // the same window as float pairs, for s16 samples (glv_core.h WinSplit; made on the device)
@@ -170,43 +183,70 @@ struct Tables {
         tilt_scale = fft_scale; tilt_cutoff = fft_cutoff;
         return GLV_OK;
     }
-    int create(uint32_t n) {
-        n_ = n;
-        const uint32_t nn = n / 2;
+    static void free_shared(SharedTables* t) {
+        if (t->d_tw) (void) hipFree(t->d_tw);
+        if (t->d_win) (void) hipFree(t->d_win);
+        if (t->d_win_split) (void) hipFree(t->d_win_split);
+        if (t->d_log) (void) hipFree(t->d_log);
+        delete t;
+    }
+    static int make_shared(SharedTables* t) {
+        const uint32_t n = t->n, nn = n / 2;
         std::vector<glv::cf> tw(nn, glv::cf{0.0f, 0.0f});
         std::vector<double> win(n);
         glv::make_twiddles(tw.data(), nn);
         glv::make_window(win.data(), n);
-        HIP_TRY(hipMalloc(&d_tw, sizeof(glv::cf) * nn));
-        HIP_TRY(hipMalloc(&d_win, sizeof(double) * n));
-        HIP_TRY(hipMemcpy(d_tw, tw.data(), sizeof(glv::cf) * nn, hipMemcpyHostToDevice));
-        HIP_TRY(hipMemcpy(d_win, win.data(), sizeof(double) * n, hipMemcpyHostToDevice));
+        HIP_TRY(hipMalloc(&t->d_tw, sizeof(glv::cf) * nn));
+        HIP_TRY(hipMalloc(&t->d_win, sizeof(double) * n));
+        HIP_TRY(hipMemcpy(t->d_tw, tw.data(), sizeof(glv::cf) * nn, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(t->d_win, win.data(), sizeof(double) * n, hipMemcpyHostToDevice));
         {   // the split window: searched and proven on the device for every s16 sample value (glv_misc.hip)
             int* d_fs = nullptr;
-            HIP_TRY(hipMalloc(&d_win_split, sizeof(float) * 2 * n));
+            HIP_TRY(hipMalloc(&t->d_win_split, sizeof(float) * 2 * n));
             HIP_TRY(hipMalloc(&d_fs, 2 * sizeof(int)));
             HIP_TRY(hipMemset(d_fs, 0, 2 * sizeof(int)));
-            hipError_t e = glv::launch_window_split(d_win, d_win_split, n, d_fs, nullptr);
+            hipError_t e = glv::launch_window_split(t->d_win, t->d_win_split, n, d_fs, nullptr);
             int fs[2] = {0, 0};
             if (e == hipSuccess) e = hipMemcpy(fs, d_fs, sizeof(fs), hipMemcpyDeviceToHost);
             (void) hipFree(d_fs);
             HIP_TRY(e);
             if (fs[0]) return fail(GLV_ERR_HIP, "window table of n=%u has no exact float-pair form on this host's cos()", n);
-            win_shifted = fs[1];
+            t->win_shifted = fs[1];
         }
         glv::LogEntry lt[glv::kLogTabMaxSize];
         glv::make_log_table(lt);
-        HIP_TRY(hipMalloc(&d_log, sizeof(lt)));
-        HIP_TRY(hipMemcpy(d_log, lt, sizeof(lt), hipMemcpyHostToDevice));
+        HIP_TRY(hipMalloc(&t->d_log, sizeof(lt)));
+        HIP_TRY(hipMemcpy(t->d_log, lt, sizeof(lt), hipMemcpyHostToDevice));
+        return GLV_OK;
+    }
+    int create(uint32_t n, int device) {
+        n_ = n;
+        std::lock_guard<std::mutex> lock(g_tab_mu);       // held across the creation: a second batch of the size waits instead of searching too
+        for (SharedTables* t : g_tabs) if (t->device == device && t->n == n) { shared = t; break; }
+        if (!shared) {
+            SharedTables* t = new (std::nothrow) SharedTables();
+            if (!t) return fail(GLV_ERR_NOMEM, "out of host memory");
+            t->device = device; t->n = n;
+            if (int rc = make_shared(t)) { free_shared(t); return rc; }
+            g_tabs.push_back(t);
+            shared = t;
+        }
+        ++shared->refs;
+        d_tw = shared->d_tw; d_win = shared->d_win; d_win_split = shared->d_win_split; d_log = shared->d_log; win_shifted = shared->win_shifted;
         return GLV_OK;
     }
     void destroy() {
-        if (d_tw) (void) hipFree(d_tw);
-        if (d_win) (void) hipFree(d_win);
-        if (d_win_split) (void) hipFree(d_win_split);
-        if (d_log) (void) hipFree(d_log);
         if (d_tilt) (void) hipFree(d_tilt);
-        d_tw = nullptr; d_win = nullptr; d_win_split = nullptr; d_log = nullptr; d_tilt = nullptr;
+        d_tilt = nullptr;
+        if (shared) {
+            std::lock_guard<std::mutex> lock(g_tab_mu);
+            if (--shared->refs == 0) {
+                for (size_t i = 0; i < g_tabs.size(); ++i) if (g_tabs[i] == shared) { g_tabs.erase(g_tabs.begin() + (long) i); break; }
+                free_shared(shared);
+            }
+            shared = nullptr;
+        }
+        d_tw = nullptr; d_win = nullptr; d_win_split = nullptr; d_log = nullptr;
     }
 };
 
@@ -739,7 +779,7 @@ int batch_create_rows(const glv_params* p, uint32_t streams, unsigned ops_mask, 
         b->num_cus = prop.multiProcessorCount;
         std::snprintf(b->device_name, sizeof(b->device_name), "%s", prop.gcnArchName[0] ? prop.gcnArchName : prop.name);
     }
-    int rc = b->tab.create(p->n);
+    int rc = b->tab.create(p->n, device);
     if (rc == GLV_OK) rc = batch_alloc(b, b->rows);
     // every table and buffer the announced operators need is made here, so that the stream-ordered calls never allocate or copy
     if (rc == GLV_OK) rc = batch_prepare(b);

@@ -76,6 +76,38 @@ struct SlotSync {
     static constexpr uint32_t WAVES = T / 64 > 0 ? T / 64 : 1;
     uint32_t* counter = nullptr;     // LDS, one per slot (COUNTER mode)
     uint32_t expected = 0;
+    // GLV_EXP_STOREWAVE (tools/tune.py A/B builds): the handshake with the slot's store wave -- counter[1] counts the compute
+    // waves that have parked their part of a finished row in the slot's LDS region ("ready"), counter[2] the rows the store wave
+    // has taken out of it ("free").  Every wait is bounded: a protocol error ends in wrong results, never in a hung GPU.
+    uint32_t rows_done = 0;
+    bool dead = false;
+    static constexpr uint32_t SPIN_LIMIT = 1u << 22;
+    __device__ __forceinline__ void signal_ready() {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        if ((threadIdx.x & 63) == 0) __hip_atomic_fetch_add(counter + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        ++rows_done;
+    }
+    __device__ __forceinline__ void wait_free() {          // the store wave has read every row parked so far
+        uint32_t spins = 0;
+        if (rows_done == 0) return;                         // nothing parked yet (and kernels without store waves never park)
+        while (!dead && __hip_atomic_load(counter + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < rows_done) {
+            __builtin_amdgcn_s_sleep(1);
+            if (++spins == SPIN_LIMIT) dead = true;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    }
+    __device__ __forceinline__ void wait_ready(uint32_t rows) {   // store wave: all WAVES compute waves parked row number `rows`
+        uint32_t spins = 0;
+        while (!dead && __hip_atomic_load(counter + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < rows * WAVES) {
+            __builtin_amdgcn_s_sleep(1);
+            if (++spins == SPIN_LIMIT) dead = true;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    }
+    __device__ __forceinline__ void signal_free(uint32_t rows) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        if ((threadIdx.x & 63) == 0) __hip_atomic_store(counter + 2, rows, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
 
     __device__ __forceinline__ void sync() {
         if constexpr (WAVE_LOCAL) {
@@ -203,6 +235,9 @@ struct Body {
                 sy.sync();
                 FR::template exchange_read_half<PASS + 1, 1>(v, xb, tid);
             } else {
+#if defined(GLV_EXP_STOREWAVE)
+            if constexpr (PASS == 0) sy.wait_free();    // the store wave has taken the previous row out of the region
+#endif
 #if !defined(GLV_EXP_NOBARRIER)      /* tools/tune.py timing experiment only: wrong results without the barriers */
             if constexpr (NBUF == 1) sy.sync();         // previous readers of the region are done
 #endif
@@ -240,9 +275,27 @@ static __device__ __forceinline__ uint32_t maybe_scalar(uint32_t v) {
     else return v;
 }
 
+// GLV_EXP_STOREWAVE (tools/tune.py A/B builds only): store-wave specialisation.  vmcnt is per WAVE and counts
+// loads and stores on one in-order counter, so a table / PCM load a compute wave issues behind a row's stores waits for all of
+// them.  With this knob the compute waves of a slot park the finished row in the slot's LDS exchange region (idle between a
+// row's last exchange and the next row's first) and one extra wave per slot streams it to HBM: the compute waves never have a
+// store in flight.  Built for the stateless s16 pipeline (f32 and GL_R16 output) of configurations with at least two slots.
+// The catch is in the occupancy: registers are allocated per KERNEL, the store wave gets the compute waves' budget, so a CU
+// must have a free wave slot at that budget -- the production plans (210-250 VGPRs, exactly two waves per SIMD) have none.
+template <int LOG_NN, int LOG_E, int SLOTS, int IN_MODE, int PREFETCH, int STATEFUL>
+constexpr bool frame_store_waves() {
+#if defined(GLV_EXP_STOREWAVE)
+    return (IN_MODE == IN_S16_STEREO || IN_MODE == IN_S16_RING) && PREFETCH == 1 && (STATEFUL == 0 || STATEFUL == 3) && (Frame<LOG_NN, LOG_E>::T % 64) == 0 && SLOTS >= 2;
+#else
+    return false;
+#endif
+}
+template <int LOG_NN, int LOG_E, int SLOTS, int IN_MODE, int PREFETCH, int STATEFUL>
+constexpr int frame_threads() { return Frame<LOG_NN, LOG_E>::T * SLOTS + (frame_store_waves<LOG_NN, LOG_E, SLOTS, IN_MODE, PREFETCH, STATEFUL>() ? 64 * SLOTS : 0); }
+
 template <int LOG_NN, int IN_MODE, int LOG_MODE, int SLOTS, int NBUF, int TWREG, bool WINLDS, int OCC, int PREFETCH, int TILTREG,
           int LOG_E, int STATEFUL, int WPRE = 0>
-__global__ void __launch_bounds__((Frame<LOG_NN, LOG_E>::T * SLOTS), OCC)
+__global__ void __launch_bounds__((frame_threads<LOG_NN, LOG_E, SLOTS, IN_MODE, PREFETCH, STATEFUL>()), OCC)
 glv_frame_kernel(const FrameArgs a) {
     using FR = Frame<LOG_NN, LOG_E>;
     constexpr int E = FR::E;
@@ -262,15 +315,18 @@ glv_frame_kernel(const FrameArgs a) {
     constexpr int NREG = NBUF == 0 ? 1 : NBUF;                                                         // regions per slot
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const uint32_t slot = maybe_scalar<WAVE_SLOT>(threadIdx.x / T);
-    const int tid = threadIdx.x % T;
+    constexpr bool SWAVE = frame_store_waves<LOG_NN, LOG_E, SLOTS, IN_MODE, PREFETCH, STATEFUL>();
+    constexpr int NCOMPUTE = T * SLOTS, NTHREADS = frame_threads<LOG_NN, LOG_E, SLOTS, IN_MODE, PREFETCH, STATEFUL>();
+    const bool store_wave = SWAVE && threadIdx.x >= (uint32_t) NCOMPUTE;          // wave-uniform: NCOMPUTE is a multiple of 64
+    const uint32_t slot = maybe_scalar<WAVE_SLOT>(store_wave ? (threadIdx.x - NCOMPUTE) / 64 : threadIdx.x / T);
+    const int tid = store_wave ? (int) (threadIdx.x & 63u) : (int) (threadIdx.x % T);
     char* xslot = smem + (size_t) slot * NREG * XBYTES;
 
     const void* gwin = WSPLIT ? a.win_split : static_cast<const void*>(a.win);     // 16 bytes per complex point either way
     const void* win = gwin;
     if constexpr (WINLDS) {
         char* lwin = smem + (size_t) SLOTS * NREG * XBYTES;
-        for (int i = threadIdx.x; i < N / 2; i += T * SLOTS) st<d2>(lwin, (uint32_t) i * 16u, ld<d2>(gwin, (uint32_t) i * 16u));
+        for (int i = threadIdx.x; i < N / 2; i += NTHREADS) st<d2>(lwin, (uint32_t) i * 16u, ld<d2>(gwin, (uint32_t) i * 16u));
         __syncthreads();
         win = lwin;
     }
@@ -281,7 +337,7 @@ glv_frame_kernel(const FrameArgs a) {
     if constexpr (LOG_MODE == 0) {
         char* llog = smem + (size_t) SLOTS * NREG * XBYTES + (WINLDS ? (size_t) N * sizeof(double) : 0);
         constexpr int LB = log_tab_bits_of(LOG_NN);             // entries this size uses: every 2^(9 - LB)-th of the table in HBM
-        for (int i = threadIdx.x; i < (1 << LB); i += T * SLOTS) st<d2>(llog, (uint32_t) i * 16u, ld<d2>(a.logtab, (uint32_t) (i << (kLogTabMaxBits - LB)) * 16u));
+        for (int i = threadIdx.x; i < (1 << LB); i += NTHREADS) st<d2>(llog, (uint32_t) i * 16u, ld<d2>(a.logtab, (uint32_t) (i << (kLogTabMaxBits - LB)) * 16u));
         __syncthreads();
         logtab = reinterpret_cast<const LogEntry*>(llog);
     }
@@ -290,7 +346,7 @@ glv_frame_kernel(const FrameArgs a) {
     const cf* lds_tw = nullptr;
     if constexpr (BD::TW_LDS_MODE) {
         char* ltw = smem + (size_t) SLOTS * NREG * XBYTES + (WINLDS ? (size_t) N * sizeof(double) : 0) + ((size_t) sizeof(LogEntry) << log_tab_bits_of(LOG_NN));
-        for (int i = threadIdx.x; i < BD::LDS_ENTRIES; i += T * SLOTS) st<cf>(ltw, (uint32_t) i * 8u, ld<cf>(a.tw, (uint32_t) (BD::LDS_BIAS + i) * 8u));
+        for (int i = threadIdx.x; i < BD::LDS_ENTRIES; i += NTHREADS) st<cf>(ltw, (uint32_t) i * 8u, ld<cf>(a.tw, (uint32_t) (BD::LDS_BIAS + i) * 8u));
         __syncthreads();
         lds_tw = reinterpret_cast<const cf*>(ltw);
     }
@@ -299,11 +355,41 @@ glv_frame_kernel(const FrameArgs a) {
     SlotSync<T, SLOTS> sy;
     if constexpr (SlotSync<T, SLOTS>::COUNTER) {
         uint32_t* ctr = reinterpret_cast<uint32_t*>(smem + frame_lds_bytes<LOG_NN, LOG_E, SLOTS, NBUF, WINLDS, TWREG>() - 16 * SLOTS) + 4 * slot;
-        if (tid == 0) *ctr = 0;
+        if (tid == 0 && !store_wave) { ctr[0] = 0; ctr[1] = 0; ctr[2] = 0; }
         __syncthreads();
         sy.counter = ctr;
     }
 
+    if constexpr (SWAVE) {
+        static_assert(SlotSync<T, SLOTS>::COUNTER, "store waves need the slot-scoped counter barrier (the workgroup barrier would include them)");
+        if (store_wave) {
+            // one wave per slot: take each finished row out of the slot's region (1 KiB per wave instruction) and stream it to HBM
+            constexpr bool R16OUT = STATEFUL == 3;
+            constexpr uint32_t ROWBYTES = R16OUT ? N * 2u : N * 4u, PIECES = ROWBYTES / 1024u;
+            const uint32_t nframes = a.units / 2, fstride = gridDim.x * SLOTS;
+            const uint32_t nfs = nframes == 0 ? 0 : (nframes - 1) / fstride + 1;
+            uint32_t k = 0;
+            for (uint32_t r = 0; r < 2 * nfs; ++r) {
+                const uint32_t m = r >> 1, ch = r & 1u;
+                if (blockIdx.x * SLOTS + m * fstride >= nframes) break;
+                const uint32_t fraw = blockIdx.x * SLOTS + m * fstride + slot;
+                const bool active = fraw < nframes;
+                const size_t row = (size_t) (active ? fraw : nframes - 1) * 2 + ch;
+                ++k;
+                sy.wait_ready(k);
+                cf2 piece[PIECES];
+#pragma unroll
+                for (uint32_t j = 0; j < PIECES; ++j) piece[j] = ld<cf2>(xslot, j * 1024u + (uint32_t) tid * 16u);
+                sy.signal_free(k);                          // (the release fence waits for the reads)
+                char* dst = reinterpret_cast<char*>(a.out) + row * (size_t) ROWBYTES;
+                if (active) {
+#pragma unroll
+                    for (uint32_t j = 0; j < PIECES; ++j) st<cf2>(dst, j * 1024u + (uint32_t) tid * 16u, piece[j]);
+                }
+            }
+            return;
+        }
+    }
     PhaseClock clk;
     clk.start();
     cf tw_all[BD::TW_TOTAL];
@@ -341,8 +427,8 @@ glv_frame_kernel(const FrameArgs a) {
     auto finish = [&](const cf (&v)[E], size_t row, int tid) {
         // a.out == nullptr (gravity without average only): the spectra ARE the gravity state
         // (render.c:733-734 stores the same value to both), so the second copy is not written
-        float* out_row = FUSED_BARS ? reinterpret_cast<float*>(xslot)
-                                    : (HAS_STATE && a.out == nullptr ? nullptr : a.out + row * N);
+        float* out_row = (FUSED_BARS || SWAVE) ? reinterpret_cast<float*>(xslot)
+                                               : (HAS_STATE && a.out == nullptr ? nullptr : a.out + row * N);
         if constexpr (GL16) {
             float* o = FUSED_BARS ? reinterpret_cast<float*>(xslot)
                                   : ((a.ops & OP_R16) ? reinterpret_cast<float*>(reinterpret_cast<uint16_t*>(a.out) + row * N) : a.out + row * N);
@@ -355,7 +441,7 @@ glv_frame_kernel(const FrameArgs a) {
             if (raw_out) FR::template epilogue<LOG_MODE, EPI_RAW_STATE, 0, false, NF>(v, out_row, row, tid, a, logtab);
             else FR::template epilogue<LOG_MODE, EPI_MAG_STATE, TILTREG, false, NF>(v, out_row, row, tid, a, logtab, tilt_reg);
         } else if constexpr (STATEFUL == 3) {
-            float* out16 = reinterpret_cast<float*>(reinterpret_cast<uint16_t*>(a.out) + row * N);
+            float* out16 = SWAVE ? reinterpret_cast<float*>(xslot) : reinterpret_cast<float*>(reinterpret_cast<uint16_t*>(a.out) + row * N);
             if (raw_out) FR::template epilogue<LOG_MODE, EPI_RAW, 0, true, NF>(v, out16, row, tid, a, logtab);
             else FR::template epilogue<LOG_MODE, EPI_MAG, TILTREG, true, NF>(v, out16, row, tid, a, logtab, tilt_reg);
         } else {
@@ -428,6 +514,10 @@ glv_frame_kernel(const FrameArgs a) {
                 }
             }
             // the next row's first exchange write is preceded by a barrier (NBUF == 1): the bars readers are safe
+        } else if constexpr (SWAVE) {
+            sy.sync();                                     // every reader of the row's last exchange is done: the region is ours
+            if (active) finish(v, row, tid);               // finished row -> LDS, natural order
+            sy.signal_ready();                             // the store wave takes it from here
         } else {
 #if defined(GLV_EXP_STOREPRIO)       /* tools/tune.py A/B: the epilogue (stores) at raised wave priority */
             __builtin_amdgcn_s_setprio(GLV_EXP_STOREPRIO);
@@ -636,7 +726,7 @@ hipError_t launch_variant(const FrameArgs& a, int grid, hipStream_t st) {
     // (several host threads may drive several devices through the same instantiation -- glv_multi_*: the flags are
     // atomics; two threads racing on one device at worst both set the attribute, which is idempotent)
     struct AttrDone { std::atomic<bool> dev[64] = {}; };
-    auto launch = [&](auto k, AttrDone& done) -> hipError_t {
+    auto launch = [&](auto k, AttrDone& done, int threads = FR::T * SLOTS) -> hipError_t {
         if (lds > 64 * 1024) {
             int dev = 0;
             (void) hipGetDevice(&dev);
@@ -649,7 +739,7 @@ hipError_t launch_variant(const FrameArgs& a, int grid, hipStream_t st) {
         }
         if (grid <= 0) return hipSuccess;             // attribute only: glv_api.cpp batch_prepare readies the kernels a batch may launch, so
                                                       // that no process call changes a function attribute (a first call can be captured)
-        hipLaunchKernelGGL(k, dim3(grid), dim3(FR::T * SLOTS), lds, st, a);
+        hipLaunchKernelGGL(k, dim3(grid), dim3(threads), lds, st, a);
         return hipGetLastError();
     };
     static AttrDone done_plain, done_state, done_r16, done_state_r16;   // per instantiation
@@ -679,8 +769,10 @@ hipError_t launch_variant(const FrameArgs& a, int grid, hipStream_t st) {
     if (a.ops & (OP_GRAVITY | OP_AVERAGE))
         return launch(glv_frame_kernel<LOG_NN, IN_MODE, LOG_MODE, SLOTS, NBUF, TW_STATEFUL, WINLDS, OCC, PREFETCH, TILTREG, LOG_E, 1, WPRE_S>, done_state);
     if (a.ops & OP_R16)
-        return launch(glv_frame_kernel<LOG_NN, IN_MODE, LOG_MODE, SLOTS, NBUF, TWREG, WINLDS, OCC, PREFETCH, TILTREG, LOG_E, 3, WPRE>, done_r16);
-    return launch(glv_frame_kernel<LOG_NN, IN_MODE, LOG_MODE, SLOTS, NBUF, TWREG, WINLDS, OCC, PREFETCH, TILTREG, LOG_E, 0, WPRE>, done_plain);
+        return launch(glv_frame_kernel<LOG_NN, IN_MODE, LOG_MODE, SLOTS, NBUF, TWREG, WINLDS, OCC, PREFETCH, TILTREG, LOG_E, 3, WPRE>, done_r16,
+                      frame_threads<LOG_NN, LOG_E, SLOTS, IN_MODE, PREFETCH, 3>());
+    return launch(glv_frame_kernel<LOG_NN, IN_MODE, LOG_MODE, SLOTS, NBUF, TWREG, WINLDS, OCC, PREFETCH, TILTREG, LOG_E, 0, WPRE>, done_plain,
+                  frame_threads<LOG_NN, LOG_E, SLOTS, IN_MODE, PREFETCH, 0>());
 }
 
 }  // namespace glv

@@ -50,9 +50,9 @@ volatile int glv_hipfifo_timeout_ms = 50;
 float glv_hipfifo_fft_scale = 10.2f, glv_hipfifo_fft_cutoff = 0.3f;
 /* what is published: 0 (default) the sample rings struct audio_data defines, 1 finished spectra; -1 = take it from the
  * environment (GLAVA_HIPFIFO_SPECTRA) when the thread starts */
-volatile int glv_hipfifo_spectra = -1;
+volatile int glv_hipfifo_spectra __attribute__((weak)) = -1;     /* weak: integration/hippulse.c carries the same definition */
 /* read by the patched handle_audio (integration/render_hip.patch): non-zero while a backend publishes spectra */
-volatile int glv_audio_publishes_spectra = 0;
+volatile int glv_audio_publishes_spectra __attribute__((weak)) = 0;
 
 static void glv_hipfifo_die(const char* what) {
     fprintf(stderr, "hipfifo backend: %s: %s\n", what, glv_last_error());

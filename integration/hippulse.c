@@ -33,8 +33,10 @@
 #include <pulse/error.h>
 #endif
 
-extern volatile int glv_hipfifo_spectra;              /* integration/hipfifo.c: what the hip backends publish */
-extern volatile int glv_audio_publishes_spectra;      /* read by the patched handle_audio */
+/* shared with integration/hipfifo.c: what the hip backends publish (-1: GLAVA_HIPFIFO_SPECTRA decides) and the flag the patched
+ * handle_audio reads.  Weak definitions in BOTH backends, so that either links alone and both link together */
+volatile int glv_hipfifo_spectra __attribute__((weak)) = -1;
+volatile int glv_audio_publishes_spectra __attribute__((weak)) = 0;
 
 static void glv_hippulse_die(const char* what) {
     fprintf(stderr, "hippulse backend: %s: %s\n", what, glv_last_error());

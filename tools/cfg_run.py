@@ -1,22 +1,45 @@
 #!/usr/bin/env python3
-"""A few launches of one configuration, for rocprofv3:  cfg_run.py configs2 | chain | n1024bars"""
-import os, sys
+"""One configuration, warmed up and launched back to back, for rocprofv3 (tools/profile_cmd.sh):
+    cfg_run.py configs2 | chain | n1024bars | gl_default | gl_bars | ring  [calls]
+0.3 s of spin-up launches first (the first dozens of launches after idle run ~20 % slower), then `calls` launches (default 150):
+the kernel-trace average then describes the warm kernel (the r03 summaries averaged 6 cold calls)."""
+import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch
 from glava_amd import spectrum as G
 which = sys.argv[1] if len(sys.argv) > 1 else "configs2"
+calls = int(sys.argv[2]) if len(sys.argv) > 2 else 150
+kw, mask, dt, width = {}, 0, torch.float32, None
 if which == "configs2":
     n, streams, ops, bars = 16384, 8192, G.OP_FFT | G.OP_GRAVITY | G.OP_BARS, 80
 elif which == "chain":
-    n, streams, ops, bars = 4096, 32768, G.OP_FFT | G.OP_GRAVITY | G.OP_AVERAGE, 0
-else:
+    n, streams, ops, bars = 4096, 65536, G.OP_FFT | G.OP_GRAVITY | G.OP_AVERAGE, 0
+elif which == "n1024bars":
     n, streams, ops, bars = 1024, 131072, G.OP_FFT | G.OP_GRAVITY | G.OP_AVERAGE | G.OP_BARS, 80
-pcm = torch.randint(-32768, 32768, (streams, n, 2), dtype=torch.int16, device="cuda")
-out = torch.empty((streams, 2, bars if bars else n), dtype=torch.float32, device="cuda")
-b = G.Batch(G.Params(n=n, bars=max(bars, 1)), streams, ops & ~G.OP_BARS)
-for _ in range(6):
-    b.process_s16(pcm, out, ops)
+elif which == "gl_default":
+    n, streams, ops, bars = 4096, 65536, G.OP_FFT | G.OP_GRAVITY | G.OP_AVERAGE | G.OP_R16, 0
+    kw, dt = dict(avg_window_kind=1, gl_storage=1), torch.int16
+elif which == "gl_bars":
+    n, streams, ops, bars = 4096, 65536, G.OP_FFT | G.OP_GRAVITY | G.OP_AVERAGE | G.OP_BARS | G.OP_R16, 80
+    kw, dt = dict(avg_window_kind=1, gl_storage=1), torch.int16
+elif which == "ring":
+    n, streams, ops, bars = 4096, 65536, G.OP_FFT, 0
+    mask = G.OP_RING_S16
+else:
+    raise SystemExit("unknown configuration " + which)
+pcm = torch.randint(-32768, 32768, (streams, 256 if which == "ring" else n, 2), dtype=torch.int16, device="cuda")
+out = torch.empty((streams, 2, bars if bars else n), dtype=dt, device="cuda")
+b = G.Batch(G.Params(n=n, bars=max(bars, 1), **kw), streams, (ops & (G.OP_GRAVITY | G.OP_AVERAGE)) | mask)
+call = (lambda: b.ring_update_s16(pcm, 256, out, ops)) if which == "ring" else (lambda: b.process_s16(pcm, out, ops))
+t_end = time.perf_counter() + 0.3
+while time.perf_counter() < t_end:
+    for _ in range(4): call()
+    torch.cuda.synchronize()
+t0 = time.perf_counter()
+for _ in range(calls): call()
 torch.cuda.synchronize()
-print(which, "n", n, "streams", streams, "algorithmic bytes per launch", b.algorithmic_bytes(ops) if hasattr(b, "algorithmic_bytes") else "-")
+dt_ = (time.perf_counter() - t0) / calls
+print(which, "n", n, "streams", streams, "algorithmic bytes per launch", b.algorithmic_bytes(ops), f"wall ms per call {dt_ * 1e3:.4f} over {calls} calls after spin-up",
+      f"=> {b.algorithmic_bytes(ops) / dt_ / 8e12:.4f} of 8 TB/s", "launches per call", b.last_launches())
 b.close()

@@ -221,6 +221,19 @@ def extra_configs(G, torch, device, a, peak_gbs):
                            f"stored as GL_R16 texels: 24 N + {4 * bars} B/frame", s, b.algorithmic_bytes(glops | G.OP_BARS | G.OP_R16), dt, kms)
     gl["bars_out"]["launches_per_step"] = b.last_launches()
     b.close()
+    # ... and with the pre-smoothing pass of render.c:2277-2303 behind it (bars == n at the texel centres: the texture every stock
+    # module samples under setsmoothpass): 4096 bars do not fit the slack behind a row in LDS, so this is the fused GL kernel
+    # writing the `av` floats + the bars kernel; that pass is ~57 weighted taps per OUTPUT texel (233 K multiply-adds per row) --
+    # compute-bound, not memory-bound: reported as frames/s with its (meaningless here) byte fraction, on 1/16 of the streams
+    s3 = max(s // 16, 1)
+    qs = torch.empty((s3, 2, n), dtype=torch.int16, device="cuda")
+    b3 = G.Batch(G.Params(n=n, log_mode=a.log_mode, avg_frames=F, avg_window_kind=1, gl_storage=1, bars=n, bar_phase=0.5), s3,
+                 G.OP_GRAVITY | G.OP_AVERAGE | G.OP_BARS, device=device)
+    dt, kms = run(b3, lambda: b3.process_s16(pcm, qs, glops | G.OP_BARS | G.OP_R16, st0))
+    gl["sm_out"] = entry(f"same chain + the pre-smoothing pass (bars = n = {n}, bar_phase 0.5) -> `sm` GL_R16 texels, {s3} streams, two launches; "
+                         f"the pass is ~57 weighted taps per output texel: compute-bound", s3, b3.algorithmic_bytes(glops | G.OP_R16) + 12 * n * s3, dt, kms)
+    gl["sm_out"]["launches_per_step"] = b3.last_launches()
+    b3.close(); del qs
     # the pass-by-pass form of the same chain (the checker: f32 intermediates, three launches), for the record
     s2 = s // 4
     b2 = G.Batch(G.Params(n=n, log_mode=a.log_mode, avg_frames=F, avg_window_kind=1, gl_storage=2), s2, G.OP_GRAVITY | G.OP_AVERAGE, device=device)

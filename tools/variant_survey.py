@@ -20,18 +20,19 @@ def main():
     from glava_amd import build as B, spectrum as G
     B.build()
     lines = []
-    cases = [("fft", G.OP_FFT, G.OP_FFT, 1, 12), ("fft->R16", G.OP_FFT | G.OP_R16, G.OP_FFT, 1, 8), ("fft log_mode 0", G.OP_FFT, G.OP_FFT, 0, 12),
-             ("fft->gravity->average", G.OP_FFT | G.OP_GRAVITY | G.OP_AVERAGE, G.OP_GRAVITY | G.OP_AVERAGE, 1, 52)]
-    for n in (512, 1024, 2048, 4096, 8192):
+    cases = [("fft", G.OP_FFT, G.OP_FFT, 1, 12, {}), ("fft->R16", G.OP_FFT | G.OP_R16, G.OP_FFT, 1, 8, {}), ("fft log_mode 0", G.OP_FFT, G.OP_FFT, 0, 12, {}),
+             ("fft->gravity->average", G.OP_FFT | G.OP_GRAVITY | G.OP_AVERAGE, G.OP_GRAVITY | G.OP_AVERAGE, 1, 52, {}),
+             ("GL_R16 chain (gl_storage 1)", G.OP_FFT | G.OP_GRAVITY | G.OP_AVERAGE | G.OP_R16, G.OP_GRAVITY | G.OP_AVERAGE, 1, 28, dict(gl_storage=1, avg_window_kind=1))]
+    for n in (512, 1024, 2048, 4096, 8192, 16384, 32768):
         streams = 65536 * 4096 // n
         pcm = torch.randint(-32768, 32768, (streams, n, 2), dtype=torch.int16, device="cuda")
         out = torch.empty((streams, 2, n), dtype=torch.float32, device="cuda")
-        for name, ops, mask, lm, bpn in cases:
+        for name, ops, mask, lm, bpn, kw in cases:
             if mask != G.OP_FFT and n > 4096:
                 s2 = streams // 4                              # the history ring of the chain: keep it at a few GiB
             else:
                 s2 = streams
-            b = G.Batch(G.Params(n=n, log_mode=lm), s2, mask)
+            b = G.Batch(G.Params(n=n, log_mode=lm, **kw), s2, mask)
             res = []
             for v in range(b.variants()):
                 b.set_variant(v)

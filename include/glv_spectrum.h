@@ -73,8 +73,8 @@ enum {
                                    pre-smoothing pass of render.c:2188-2303 in one call.  Excludes GLV_OP_RAW, GLV_OP_SMOOTH. */
     GLV_OP_PRIVATE_STATE = 1u << 9, /* (ABI 3 flag, accepted and ignored since ABI 4: a batch-owned gravity state is the default again) */
     GLV_OP_RING_S16 = 1u << 10, /* glv_batch_create's ops_mask only: allocate (and zero, == the calloc'd rings of
-                                   glava.c:487-494) the s16 device ring of glv_batch_ring_update_s16 at creation; without it
-                                   the first ring update allocates, i.e. synchronises */
+                                   glava.c:487-494) the s16 device ring of glv_batch_ring_update_s16 / _append_s16; ring calls on
+                                   a batch created without it are refused (GLV_ERR_STATE: nothing is allocated after creation) */
     GLV_OP_RING_F32 = 1u << 11, /* the same for the interleaved f32 ring of glv_batch_ring_update_f32 */
     GLV_OP_OUTPUT_IS_STATE = 1u << 12 /* opt-in, with a chain that ENDS in gravity (GLV_OP_GRAVITY without AVERAGE / SMOOTH / RAW, f32
                                    rows out, no gl_storage): transform_gravity stores every value twice, to its `applied` array and to
@@ -86,11 +86,12 @@ enum {
                                    instead of 28 n.  Without the flag the state lives in a buffer the batch owns (the default: a
                                    caller may post-process, reuse or free d_out at will) */
 };
-/* Bits glv_batch_create's ops_mask understands: GLV_OP_GRAVITY / GLV_OP_AVERAGE (state arrays), GLV_OP_BARS (tap tables, work
- * lists and -- where the announced chain cannot compute the bars inside the transform's launch -- the internal spectra rows),
- * GLV_OP_SMOOTH (window bounds), GLV_OP_RING_S16 / GLV_OP_RING_F32 (device rings).  Everything a process call of those operators
- * needs is allocated and uploaded at creation (or by glv_batch_set_params): the process calls themselves never allocate, never
- * copy synchronously and can be captured into a hipGraph from the first one on.  An operator whose tables the batch was not
+/* Bits glv_batch_create's ops_mask understands: GLV_OP_GRAVITY / GLV_OP_AVERAGE (state arrays), GLV_OP_BARS (the internal
+ * spectra rows, where the announced chain cannot compute its bars inside the transform's launch), GLV_OP_SMOOTH, GLV_OP_RING_S16 /
+ * GLV_OP_RING_F32 (device rings).  The tables are cheap and always made at creation (tilt, bar taps and work lists, smooth
+ * bounds: an operator the mask did not announce only goes without them when its parameters are unusable); buffers of spectrum
+ * size are made for announced operators only.  The process calls themselves never allocate, never copy synchronously, change no
+ * function attribute, and can be captured into a hipGraph from the first one on; an operator whose buffers the batch was not
  * created with is refused with GLV_ERR_STATE. */
 
 /* Mirrors the fields of the private `struct gl_data` that the path reads

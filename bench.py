@@ -225,7 +225,7 @@ def extra_configs(G, torch, device, a, peak_gbs):
     # module samples under setsmoothpass): 4096 bars do not fit the slack behind a row in LDS, so this is the fused GL kernel
     # writing the `av` floats + the bars kernel; that pass is ~57 weighted taps per OUTPUT texel (233 K multiply-adds per row) --
     # compute-bound, not memory-bound: reported as frames/s with its (meaningless here) byte fraction, on 1/16 of the streams
-    s3 = max(s // 16, 1)
+    s3 = max(s // 4, 1)
     qs = torch.empty((s3, 2, n), dtype=torch.int16, device="cuda")
     b3 = G.Batch(G.Params(n=n, log_mode=a.log_mode, avg_frames=F, avg_window_kind=1, gl_storage=1, bars=n, bar_phase=0.5), s3,
                  G.OP_GRAVITY | G.OP_AVERAGE | G.OP_BARS, device=device)

@@ -37,6 +37,9 @@ struct BarDesc { uint32_t first_bin, count, tap_offset; float weight_sum; };
 // completes, or `bars` (a dump slot) when it does not, keep = 0.0f when the chunk opens a bar (the running total
 // restarts), 1.0f otherwise.
 struct alignas(16) BarItem { uint32_t w_byte, tex_byte, res; float keep; };
+// One tile of glv_bars_rows_kernel (many bars of many rows): bars [k0, k1) whose taps -- rounded up to whole octets -- lie in the
+// bins [origin, end) of the row, origin and end multiples of 4, end - origin <= the kernel's LDS window.
+struct alignas(16) BarTile { uint32_t k0, k1, origin, end; };
 
 struct FrameArgs {
     const void* in;        // s16: int16 [units/2][n][2] (a unit is one channel row of a frame);  f32 planar: float [units][n];

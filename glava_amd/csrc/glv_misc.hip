@@ -6,6 +6,9 @@
 //   glv_unpack_kernel  s16 interleaved -> planar f32 (glv_unpack_s16; glava/fifo.c:94-110)
 #include <hip/hip_runtime.h>
 
+#include <atomic>
+#include <type_traits>
+
 #include "glv_frame.h"
 #include "glv_launch.h"
 #include "glv_winsplit.h"
@@ -364,6 +367,161 @@ __global__ void __launch_bounds__(256) glv_bars_short_kernel(const float* __rest
     }
 }
 
+// The same bars for MANY bars and MANY rows (the pre-smoothing pass of render.c:2277-2303: bars == n, one output per texel, ~57
+// taps each at n = 4096: 233 K multiply-adds per row): ONE LANE PER ROW.  The taps and weights of bar k do not depend on the row,
+// so with 64 rows side by side in a wave every weight is wave-uniform -- a scalar register operand, fetched once per 64 rows
+// through the scalar cache -- and a tap is ONE vector instruction for 64 rows (v_pk_fma_f32: one link of the even and the odd
+// chain).  A workgroup is four waves on the SAME 64 rows: the rows' texels live in LDS as a linear window [bin][row] (S bins x
+// 64 rows: conflict-free, a tap pair is one ds_read2st64_b32 at an immediate offset) that serves one TILE of bars -- up to 64
+// consecutive bars whose taps fit the window (host table, glv_tables.h make_bar_tiles: bars' first bins are monotone) -- the
+// waves take the tile's bars in turn, park their results in LDS, and the tile leaves as contiguous row segments.  Two workgroups
+// per CU = two waves per SIMD: the scalar and LDS latencies of one wave's bar are covered by the other's.  The summation order is
+// the documented one (glv_frame.h "GLV_OP_BARS arithmetic": chunks of 16 / 32 / 64 taps, per chunk 2 / 4 / 8 partial sums of eight
+// consecutive taps, each the sum of two fused-multiply-add chains, combined pairwise, chunk totals in order) walked sequentially by
+// the lane: the same bits as glv_bars_kernel and the fused epilogue.  glv_bars_kernel spends ~32 vector instructions per 8 taps
+// of ONE row (and pads every bar to whole 64-tap chunks); this one ~14 per 8 taps of 64 rows.
+constexpr int kRowsWaves = 4, kRowsTileBars = 32, kRowsStagePitch = 65;     // 32 bars per tile: 2 x (64 KiB window + 8 KiB stage) fit a CU's 160 KiB
+template <int S, int GL>
+__global__ void __launch_bounds__(64 * kRowsWaves) glv_bars_rows_kernel(const float* __restrict__ spec, void* __restrict__ bars_out, size_t nrows, uint32_t n,
+                                                                        uint32_t bars, const BarTile* __restrict__ tiles, uint32_t ntiles, uint32_t tiles_per_wg,
+                                                                        const BarDesc* __restrict__ desc, const float* __restrict__ tap_w, int r16) {
+#if defined(__HIP_DEVICE_COMPILE__)                     /* packed-f32 inline assembly: the host pass sees an empty stub */
+    extern __shared__ float rows_lds[];                 // [S][64] texel window | [32][65] finished outputs of the tile
+    float* win = rows_lds;
+    float* stage = rows_lds + (size_t) S * 64;
+    constexpr uint32_t CHUNK = 8u * GL;
+    static_assert(kRowsTileBars / kRowsWaves <= 64 && CHUNK <= 64, "a wave's bars of a tile / a chunk's weights ride in one register, one per lane");
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave = (uint32_t) __builtin_amdgcn_readfirstlane((int) (threadIdx.x >> 6));
+    const size_t row0 = (size_t) blockIdx.x * 64;
+    if (row0 >= nrows) return;
+    const uint32_t R = (uint32_t) (nrows - row0 < 64 ? nrows - row0 : 64);
+    const float* src = spec + (row0 + (lane < R ? lane : R - 1)) * (size_t) n;
+    const uint32_t t_begin = blockIdx.y * tiles_per_wg, t_end = t_begin + tiles_per_wg < ntiles ? t_begin + tiles_per_wg : ntiles;
+    const glv_f2 ones = {1.0f, 1.0f};
+    // Weights and bar descriptors are wave-uniform.  Through the scalar cache (s_load) they cost a dependent L2 round trip per bar that
+    // nothing covers (desc -> tap_offset -> weights, ~1000 cycles before the first multiply) and 64 SGPRs that cannot be double
+    // buffered; instead lane l of the wave LOADS weight l of the chunk (one coalesced 256-byte vector load per 64 taps, issued one
+    // chunk ahead) and lane j the descriptor of the wave's j-th bar of the tile, and the uniform values are taken out of those
+    // registers with v_readlane_b32 when they are used.
+    auto lane_of = [](uint32_t v, uint32_t l) { return (uint32_t) __builtin_amdgcn_readlane((int) v, (int) l); };
+    // A chunk's weights as CHUNK / 4 registers: register g holds weights 4g .. 4g+3 of the chunk, one per lane of every quad, so that a
+    // tap's weight reaches all 64 lanes through the multiply-add's own DPP operand (quad_perm:[k,k,k,k]) -- no broadcast instruction
+    struct ChunkW { float g[CHUNK / 4]; };
+    auto chunk_weights = [&](uint32_t tap_offset, uint32_t c0) {
+        ChunkW cw;
+#pragma unroll
+        for (uint32_t g = 0; g < CHUNK / 4; ++g) cw.g[g] = ld<float>(tap_w, (tap_offset + c0 + 4u * g + (lane & 3u)) * 4u);
+        return cw;
+    };
+    for (uint32_t t = t_begin; t < t_end; ++t) {
+        const BarTile T = tiles[t];                                             // uniform: scalar loads
+        const uint32_t nb = T.k1 > T.k0 + wave ? (T.k1 - T.k0 - wave + kRowsWaves - 1) / kRowsWaves : 0u;    // this wave's bars: k0 + wave, + 4, ...
+        BarDesc dv = {0u, 0u, 0u, 1.0f};
+        if (lane < nb) dv = desc[T.k0 + wave + kRowsWaves * lane];
+        __syncthreads();                                                        // the previous tile has left the window and the stage
+        // 4 bins of every row per load; four loads of a wave are issued before the first is parked
+        const uint32_t ncol = (T.end - T.origin) / 4u;
+        for (uint32_t cb = wave; cb < ncol; cb += kRowsWaves * 4) {
+            BarW4 v4[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const uint32_t c = cb + (uint32_t) q * kRowsWaves;
+                v4[q] = ld<BarW4>(src, (T.origin + 4u * (c < ncol ? c : cb)) * 4u);
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const uint32_t c = cb + (uint32_t) q * kRowsWaves;
+                if (c < ncol) {                                                     // uniform
+                    // clamped here, once per texel, instead of once per tap: [0, 1] like the GL_R16 texel the shader samples, NaN -> 0
+                    // (v_pk_mul_f32 x, 1.0 clamp -- the operation bar_item_lane_sum applies to every tap: same bits)
+                    glv_f2 lo = {v4[q].w[0], v4[q].w[1]}, hi = {v4[q].w[2], v4[q].w[3]};
+                    asm("v_pk_mul_f32 %0, %1, %2 clamp" : "=v"(lo) : "v"(lo), "v"(ones));
+                    asm("v_pk_mul_f32 %0, %1, %2 clamp" : "=v"(hi) : "v"(hi), "v"(ones));
+                    win[(size_t) (4u * c + 0) * 64 + lane] = lo.x; win[(size_t) (4u * c + 1) * 64 + lane] = lo.y;
+                    win[(size_t) (4u * c + 2) * 64 + lane] = hi.x; win[(size_t) (4u * c + 3) * 64 + lane] = hi.y;
+                }
+            }
+        }
+        ChunkW wnext = chunk_weights(nb ? lane_of(dv.tap_offset, 0) : 0u, 0u);
+        __syncthreads();
+        for (uint32_t j = 0; j < nb; ++j) {
+            const uint32_t first_bin = lane_of(dv.first_bin, j), count = lane_of(dv.count, j), tap_offset = lane_of(dv.tap_offset, j);
+            const float wsum = __builtin_bit_cast(float, lane_of(__builtin_bit_cast(uint32_t, dv.weight_sum), j));
+            const float* x = win + (size_t) (first_bin - T.origin) * 64 + lane;
+            float total = 0.0f;
+            for (uint32_t c0 = 0; c0 < count; c0 += CHUNK) {
+                const ChunkW wv = wnext;
+                // one chunk ahead: the bar's next chunk, else the first chunk of the wave's next bar
+                if (c0 + CHUNK < count) wnext = chunk_weights(tap_offset, c0 + CHUNK);
+                else if (j + 1 < nb) wnext = chunk_weights(lane_of(dv.tap_offset, j + 1), 0u);
+                const float* xc = x + (size_t) c0 * 64;
+                float sl[GL];
+                // the chunk's octets of taps are independent chains: step them together.  Octets past the bar's end hold nothing but
+                // zero weights and sum to +0 exactly, so only the first ceil(rest / 8) are computed -- one unrolled body per count
+                const uint32_t rest = count - c0;
+                const uint32_t noct = rest >= CHUNK ? (uint32_t) GL : (rest + 7u) / 8u;
+                auto octets = [&](auto NO) {
+                    constexpr int NOCT = decltype(NO)::value;
+                    float ev[NOCT], od[NOCT];                       // the even and the odd chain of every octet
+                    // first link of every chain: fma(x, w, +0) == x * w (both factors are >= +0: no -0 can arise)
+#pragma unroll
+                    for (int l = 0; l < NOCT; ++l) {
+                        const int t0 = 8 * l;
+                        const float x0 = xc[(size_t) t0 * 64], x1 = xc[(size_t) (t0 + 1) * 64];
+                        asm("v_mul_f32_dpp %0, %1, %2 quad_perm:[0,0,0,0] row_mask:0xf bank_mask:0xf" : "=v"(ev[l]) : "v"(wv.g[t0 / 4]), "v"(x0));
+                        asm("v_mul_f32_dpp %0, %1, %2 quad_perm:[1,1,1,1] row_mask:0xf bank_mask:0xf" : "=v"(od[l]) : "v"(wv.g[t0 / 4]), "v"(x1));
+                    }
+#pragma unroll
+                    for (int i = 2; i < kBarTaps; i += 2)
+#pragma unroll
+                        for (int l = 0; l < NOCT; ++l) {
+                            const int t0 = 8 * l + i;                   // taps t0 (even chain), t0 + 1 (odd chain): weights in register t0 / 4, quad lanes t0 % 4, + 1
+                            const float x0 = xc[(size_t) t0 * 64], x1 = xc[(size_t) (t0 + 1) * 64];       // already clamped
+                            if ((t0 & 3) == 0) {
+                                asm("v_fmac_f32_dpp %0, %1, %2 quad_perm:[0,0,0,0] row_mask:0xf bank_mask:0xf" : "+v"(ev[l]) : "v"(wv.g[t0 / 4]), "v"(x0));
+                                asm("v_fmac_f32_dpp %0, %1, %2 quad_perm:[1,1,1,1] row_mask:0xf bank_mask:0xf" : "+v"(od[l]) : "v"(wv.g[t0 / 4]), "v"(x1));
+                            } else {
+                                asm("v_fmac_f32_dpp %0, %1, %2 quad_perm:[2,2,2,2] row_mask:0xf bank_mask:0xf" : "+v"(ev[l]) : "v"(wv.g[t0 / 4]), "v"(x0));
+                                asm("v_fmac_f32_dpp %0, %1, %2 quad_perm:[3,3,3,3] row_mask:0xf bank_mask:0xf" : "+v"(od[l]) : "v"(wv.g[t0 / 4]), "v"(x1));
+                            }
+                        }
+#pragma unroll
+                    for (int l = 0; l < GL; ++l) sl[l] = l < NOCT ? ev[l < NOCT ? l : 0] + od[l < NOCT ? l : 0] : 0.0f;
+                };
+                switch (noct) {
+                    case 1: octets(std::integral_constant<int, 1>{}); break;
+                    case 2: octets(std::integral_constant<int, GL >= 2 ? 2 : GL>{}); break;
+                    case 3: octets(std::integral_constant<int, GL >= 3 ? 3 : GL>{}); break;
+                    case 4: octets(std::integral_constant<int, GL >= 4 ? 4 : GL>{}); break;
+                    case 5: octets(std::integral_constant<int, GL >= 5 ? 5 : GL>{}); break;
+                    case 6: octets(std::integral_constant<int, GL >= 6 ? 6 : GL>{}); break;
+                    case 7: octets(std::integral_constant<int, GL >= 7 ? 7 : GL>{}); break;
+                    default: octets(std::integral_constant<int, GL>{}); break;
+                }
+                float sum = sl[0] + sl[1];                                     // group_sum's order: neighbours, pairs of pairs, the two quads
+                if constexpr (GL >= 4) sum = sum + (sl[2] + sl[3]);
+                if constexpr (GL >= 8) sum = sum + ((sl[4] + sl[5]) + (sl[6] + sl[7]));
+                total = c0 == 0 ? sum : total + sum;                           // fma(total, keep, sum) with keep = 0 / 1
+            }
+            stage[(size_t) (wave + kRowsWaves * j) * kRowsStagePitch + lane] = total / wsum;
+        }
+        __syncthreads();
+        // the tile's m bars of R rows: every row's m values are one contiguous segment of the output
+        const uint32_t m = T.k1 - T.k0;
+        static_assert(kRowsTileBars == 32, "the flush below maps 32 threads to a row's segment");
+        for (uint32_t e = threadIdx.x; e < 64u * kRowsTileBars; e += 64 * kRowsWaves) {
+            const uint32_t jr = e >> 5, kk = e & 31u;
+            if (jr < R && kk < m) {
+                const float v = stage[(size_t) kk * kRowsStagePitch + jr];
+                if (r16) reinterpret_cast<uint16_t*>(bars_out)[(row0 + jr) * bars + T.k0 + kk] = (uint16_t) unorm16(v);
+                else reinterpret_cast<float*>(bars_out)[(row0 + jr) * bars + T.k0 + kk] = v;
+            }
+        }
+    }
+#endif
+}
+
 // the s16 window as float pairs: glv_winsplit.h (shared with the knob-sweep harness glv_tune.hip)
 hipError_t launch_window_split(const double* w_tab, float* split, uint32_t n, int* d_fail_shifted, hipStream_t st) {
     return launch_window_split_impl(w_tab, split, n, d_fail_shifted, st);
@@ -448,9 +606,47 @@ static void launch_bars_gl(const float* spec, float* bars_out, size_t nrows, uin
     else if (nsteps == 4) hipLaunchKernelGGL((glv_bars_short_kernel<4, 2, GL>), grid((nrows + 1) / 2), dim3(256), 0, st, spec, bars_out, nrows, n, bars, items, desc, tap_w, r);
     else hipLaunchKernelGGL((glv_bars_kernel<GL>), grid(nrows), dim3(256), 0, st, spec, bars_out, nrows, n, bars, nsteps, items, desc, tap_w, r);
 }
+template <int S, int GL>
+static hipError_t launch_bars_rows(const float* spec, float* bars_out, size_t nrows, uint32_t n, uint32_t bars, const BarTile* tiles, uint32_t ntiles,
+                                   const BarDesc* desc, const float* tap_w, hipStream_t st, int r) {
+    const size_t lds = sizeof(float) * ((size_t) 64 * S + (size_t) kRowsTileBars * kRowsStagePitch);
+    static std::atomic<bool> done[64] = {};
+    if (lds > 64 * 1024) {
+        int dev = 0;
+        (void) hipGetDevice(&dev);
+        if (dev < 0 || dev >= 64 || !done[dev].load(std::memory_order_acquire)) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(glv_bars_rows_kernel<S, GL>), hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
+            if (e != hipSuccess) return e;
+            if (dev >= 0 && dev < 64) done[dev].store(true, std::memory_order_release);
+        }
+    }
+    // 64 rows per workgroup in x, ranges of tiles in y: enough workgroups to fill the chip a few times over
+    const uint32_t xb = (uint32_t) ((nrows + 63) / 64);
+    uint32_t yb = xb >= 2048 ? 1 : (2048 + xb - 1) / xb;
+    if (yb > ntiles) yb = ntiles;
+    const uint32_t tpw = (ntiles + yb - 1) / yb;
+    yb = (ntiles + tpw - 1) / tpw;
+    hipLaunchKernelGGL((glv_bars_rows_kernel<S, GL>), dim3(xb, yb), dim3(64 * kRowsWaves), lds, st, spec, static_cast<void*>(bars_out), nrows, n, bars, tiles,
+                       ntiles, tpw, desc, tap_w, r);
+    return hipGetLastError();
+}
+
 hipError_t launch_bars(const float* spec, float* bars_out, size_t nrows, uint32_t n, uint32_t bars, uint32_t nsteps,
-                       const BarItem* items, const BarDesc* desc, const float* tap_w, hipStream_t st, bool r16) {
+                       const BarItem* items, const BarDesc* desc, const float* tap_w, hipStream_t st, bool r16, const BarTile* tiles, uint32_t ntiles,
+                       uint32_t tile_bins) {
     const int r = r16 ? 1 : 0;
+    // many bars of many rows (the pre-smoothing pass): one lane per row, weights as scalars (glv_bars_rows_kernel), when the host
+    // could cut the bars into tiles that fit an LDS window of tile_bins bins (glv_tables.h make_bar_tiles)
+    if (tiles != nullptr && ntiles != 0 && bars >= 256 && nrows >= 256) {
+        switch (bar_lanes_of(n)) {
+            case 2: if (tile_bins == 128) return launch_bars_rows<128, 2>(spec, bars_out, nrows, n, bars, tiles, ntiles, desc, tap_w, st, r); break;
+            case 4: if (tile_bins == 128) return launch_bars_rows<128, 4>(spec, bars_out, nrows, n, bars, tiles, ntiles, desc, tap_w, st, r); break;
+            default:
+                if (tile_bins == 128) return launch_bars_rows<128, 8>(spec, bars_out, nrows, n, bars, tiles, ntiles, desc, tap_w, st, r);
+                if (tile_bins == 256) return launch_bars_rows<256, 8>(spec, bars_out, nrows, n, bars, tiles, ntiles, desc, tap_w, st, r);
+                break;
+        }
+    }
     switch (bar_lanes_of(n)) {                                   // the work lists were made for 256 / bar_lanes_of(n) groups
         case 2: launch_bars_gl<2>(spec, bars_out, nrows, n, bars, nsteps, items, desc, tap_w, st, r); break;
         case 4: launch_bars_gl<4>(spec, bars_out, nrows, n, bars, nsteps, items, desc, tap_w, st, r); break;

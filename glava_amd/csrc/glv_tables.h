@@ -180,6 +180,34 @@ inline uint32_t make_bar_items(std::vector<BarItem>& items, const std::vector<Ba
     return nsteps;
 }
 
+// Tiles for glv_bars_rows_kernel: consecutive bars (at most max_bars) whose taps, rounded up to whole octets, fit a window of
+// `bins` bins that starts on a multiple of 4.  Needs monotone first bins (smooth_audio()'s are) and every bar to fit alone;
+// returns false otherwise (the kernel is then not used).
+inline bool make_bar_tiles(std::vector<BarTile>& tiles, const std::vector<BarDesc>& desc, uint32_t n, uint32_t bins, uint32_t max_bars) {
+    tiles.clear();
+    uint32_t k = 0;
+    const uint32_t nb = (uint32_t) desc.size();
+    auto oct_end = [&](uint32_t i) { return desc[i].first_bin + ((desc[i].count + 7u) & ~7u); };
+    while (k < nb) {
+        BarTile t{k, k, desc[k].first_bin & ~3u, 0};
+        uint32_t end = 0;
+        while (t.k1 < nb && t.k1 - t.k0 < max_bars) {
+            const BarDesc& d = desc[t.k1];
+            if (d.first_bin < t.origin || (t.k1 > t.k0 && d.first_bin < desc[t.k1 - 1].first_bin)) return false;     // not monotone
+            const uint32_t e = (oct_end(t.k1) + 3u) & ~3u;
+            if (e > n) return false;
+            if (e - t.origin > bins) break;
+            end = e > end ? e : end;
+            ++t.k1;
+        }
+        if (t.k1 == t.k0) return false;                                          // a single bar does not fit the window
+        t.end = end;
+        tiles.push_back(t);
+        k = t.k1;
+    }
+    return true;
+}
+
 // log_mode 0 table (glv_core.h log_third_table): c_j = 1 + j / 2^bits, { 2^-23 / c_j, log(c_j)/3 }.
 inline void make_log_table(LogEntry* t, int bits = kLogTabMaxBits) {
     for (int j = 0; j < (1 << bits); ++j) {

@@ -201,3 +201,45 @@ def test_gl_state_storage_class_is_fixed_at_creation(glvlib):
     with pytest.raises(G.GlvError):
         s.gravity(buf)
     s.close()
+
+
+@pytest.mark.parametrize("n,streams", [(1024, 150), (2048, 129), (4096, 165), (4096, 128)])
+def test_many_bars_of_many_rows_kernel_gives_the_documented_bits(glvlib, n, streams):
+    """The pre-smoothing pass at scale (bars == n, bar_phase 0.5; >= 256 rows): glv_bars_rows_kernel -- one lane per row, weights as
+    wave-uniform scalars, the rows' window in LDS -- walks the documented summation order sequentially, so its bars equal the
+    oracle's glvo_bars_chunked_at and the small-batch kernel's (glv_bars_kernel, fewer than 256 rows) bit for bit; texel output
+    likewise.  Rows include values outside [0, 1], NaN and Inf (clamped like a GL_R16 texel)."""
+    import torch
+    G = glvlib
+    rows = streams * 2
+    rng = np.random.default_rng(n + streams)
+    spec = (rng.random((rows, n), dtype=np.float32) ** 2 * np.float32(1.3) - np.float32(0.05)).astype(np.float32)
+    spec[3, 100:140] = np.nan; spec[5, 7] = np.inf; spec[6, 300:310] = -np.inf
+    p = G.Params(n=n, bars=n, bar_phase=0.5)
+    big = G.Batch(p, streams, G.OP_FFT | G.OP_BARS)
+    small = G.Batch(p, 8, G.OP_FFT | G.OP_BARS)
+    d_spec = torch.from_numpy(spec).cuda()
+    d_big = torch.empty((rows, n), dtype=torch.float32, device="cuda")
+    big.bars(d_spec, d_big)
+    got = d_big.cpu().numpy()
+    d_small = torch.empty((16, n), dtype=torch.float32, device="cuda")
+    for r0 in (0, rows - 16):
+        small.bars(d_spec[r0:r0 + 16].contiguous(), d_small)
+        assert _eq(d_small, d_big[r0:r0 + 16].contiguous()), r0
+    for r in (0, 3, 5, 6, rows - 1):
+        want = np.empty(n, np.float32)
+        Oracle.lib().glvo_bars_chunked_at(np.ascontiguousarray(spec[r]), n, want, n, 0.025, 0.5)
+        assert (got[r].view(np.uint32) == want.view(np.uint32)).all(), r
+    # the whole GL-default pipeline with the pre-smoothing pass, texels out: many streams (rows kernel) == few streams (bars kernel)
+    kw = dict(n=n, avg_frames=3, avg_window_kind=1, gl_storage=1, bars=n, bar_phase=0.5)
+    mask = G.OP_GRAVITY | G.OP_AVERAGE | G.OP_BARS
+    ops = G.OP_FFT | mask | G.OP_R16
+    fb, fs = G.Batch(G.Params(**kw), streams, mask), G.Batch(G.Params(**kw), 8, mask)
+    ob = torch.zeros((rows, n), dtype=torch.int16, device="cuda"); os_ = torch.zeros((16, n), dtype=torch.int16, device="cuda")
+    for u in range(4):
+        pcm = (lcg_pcm_fast(555 + u + n, streams * 2 * n) // 8).astype(np.int16)
+        d_pcm = torch.from_numpy(pcm).cuda()
+        fb.process_s16(d_pcm, ob, ops); fs.process_s16(d_pcm[: 8 * 2 * n], os_, ops)
+        assert fb.last_launches() == 2
+        assert _eq(ob[:16].contiguous(), os_), u
+    for b in (big, small, fb, fs): b.close()

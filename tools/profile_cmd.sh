@@ -12,6 +12,7 @@ rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -o bench --
 i=0
 for set in \
   "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU" \
+  ${GLV_PMC_EXTRA:+"$GLV_PMC_EXTRA"} \
   "FETCH_SIZE GRBM_GUI_ACTIVE" \
   "WRITE_SIZE GRBM_COUNT"; do
   i=$((i+1))

@@ -384,7 +384,7 @@ constexpr int kRowsWaves = 4, kRowsTileBars = 32, kRowsStagePitch = 65;     // 3
 template <int S, int GL>
 __global__ void __launch_bounds__(64 * kRowsWaves) glv_bars_rows_kernel(const float* __restrict__ spec, void* __restrict__ bars_out, size_t nrows, uint32_t n,
                                                                         uint32_t bars, const BarTile* __restrict__ tiles, uint32_t ntiles, uint32_t tiles_per_wg,
-                                                                        const BarDesc* __restrict__ desc, const float* __restrict__ tap_w, int r16) {
+                                                                        const BarDesc* __restrict__ desc, const float* __restrict__ tap_wq, int r16) {
 #if defined(__HIP_DEVICE_COMPILE__)                     /* packed-f32 inline assembly: the host pass sees an empty stub */
     extern __shared__ float rows_lds[];                 // [S][64] texel window | [32][65] finished outputs of the tile
     float* win = rows_lds;
@@ -408,10 +408,18 @@ __global__ void __launch_bounds__(64 * kRowsWaves) glv_bars_rows_kernel(const fl
     // A chunk's weights as CHUNK / 4 registers: register g holds weights 4g .. 4g+3 of the chunk, one per lane of every quad, so that a
     // tap's weight reaches all 64 lanes through the multiply-add's own DPP operand (quad_perm:[k,k,k,k]) -- no broadcast instruction
     struct ChunkW { float g[CHUNK / 4]; };
+    // tap_wq: the same weights, every chunk regrouped per quad lane -- [chunk][q][g] = w[chunk * CHUNK + 4 g + q] -- so that lane q of a
+    // quad reads its CHUNK / 4 registers as CHUNK / 16 contiguous 16-byte loads (one per register from the plain table was 16 loads and
+    // their address arithmetic per 64 taps)
     auto chunk_weights = [&](uint32_t tap_offset, uint32_t c0) {
         ChunkW cw;
+        const uint32_t base = (tap_offset + c0 + (lane & 3u) * (CHUNK / 4u)) * 4u;       // tap_offset and c0 are multiples of CHUNK
 #pragma unroll
-        for (uint32_t g = 0; g < CHUNK / 4; ++g) cw.g[g] = ld<float>(tap_w, (tap_offset + c0 + 4u * g + (lane & 3u)) * 4u);
+        for (uint32_t h = 0; h < CHUNK / 16u; ++h) {
+            const BarW4 v4 = ld<BarW4>(tap_wq, base + 16u * h);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) cw.g[4 * h + i] = v4.w[i];
+        }
         return cw;
     };
     for (uint32_t t = t_begin; t < t_end; ++t) {
@@ -608,7 +616,7 @@ static void launch_bars_gl(const float* spec, float* bars_out, size_t nrows, uin
 }
 template <int S, int GL>
 static hipError_t launch_bars_rows(const float* spec, float* bars_out, size_t nrows, uint32_t n, uint32_t bars, const BarTile* tiles, uint32_t ntiles,
-                                   const BarDesc* desc, const float* tap_w, hipStream_t st, int r) {
+                                   const BarDesc* desc, const float* tap_wq, hipStream_t st, int r) {
     const size_t lds = sizeof(float) * ((size_t) 64 * S + (size_t) kRowsTileBars * kRowsStagePitch);
     static std::atomic<bool> done[64] = {};
     if (lds > 64 * 1024) {
@@ -627,23 +635,23 @@ static hipError_t launch_bars_rows(const float* spec, float* bars_out, size_t nr
     const uint32_t tpw = (ntiles + yb - 1) / yb;
     yb = (ntiles + tpw - 1) / tpw;
     hipLaunchKernelGGL((glv_bars_rows_kernel<S, GL>), dim3(xb, yb), dim3(64 * kRowsWaves), lds, st, spec, static_cast<void*>(bars_out), nrows, n, bars, tiles,
-                       ntiles, tpw, desc, tap_w, r);
+                       ntiles, tpw, desc, tap_wq, r);
     return hipGetLastError();
 }
 
 hipError_t launch_bars(const float* spec, float* bars_out, size_t nrows, uint32_t n, uint32_t bars, uint32_t nsteps,
                        const BarItem* items, const BarDesc* desc, const float* tap_w, hipStream_t st, bool r16, const BarTile* tiles, uint32_t ntiles,
-                       uint32_t tile_bins) {
+                       uint32_t tile_bins, const float* tap_wq) {
     const int r = r16 ? 1 : 0;
     // many bars of many rows (the pre-smoothing pass): one lane per row, weights as scalars (glv_bars_rows_kernel), when the host
     // could cut the bars into tiles that fit an LDS window of tile_bins bins (glv_tables.h make_bar_tiles)
-    if (tiles != nullptr && ntiles != 0 && bars >= 256 && nrows >= 256) {
+    if (tiles != nullptr && tap_wq != nullptr && ntiles != 0 && bars >= 256 && nrows >= 256) {
         switch (bar_lanes_of(n)) {
-            case 2: if (tile_bins == 128) return launch_bars_rows<128, 2>(spec, bars_out, nrows, n, bars, tiles, ntiles, desc, tap_w, st, r); break;
-            case 4: if (tile_bins == 128) return launch_bars_rows<128, 4>(spec, bars_out, nrows, n, bars, tiles, ntiles, desc, tap_w, st, r); break;
+            case 2: if (tile_bins == 128) return launch_bars_rows<128, 2>(spec, bars_out, nrows, n, bars, tiles, ntiles, desc, tap_wq, st, r); break;
+            case 4: if (tile_bins == 128) return launch_bars_rows<128, 4>(spec, bars_out, nrows, n, bars, tiles, ntiles, desc, tap_wq, st, r); break;
             default:
-                if (tile_bins == 128) return launch_bars_rows<128, 8>(spec, bars_out, nrows, n, bars, tiles, ntiles, desc, tap_w, st, r);
-                if (tile_bins == 256) return launch_bars_rows<256, 8>(spec, bars_out, nrows, n, bars, tiles, ntiles, desc, tap_w, st, r);
+                if (tile_bins == 128) return launch_bars_rows<128, 8>(spec, bars_out, nrows, n, bars, tiles, ntiles, desc, tap_wq, st, r);
+                if (tile_bins == 256) return launch_bars_rows<256, 8>(spec, bars_out, nrows, n, bars, tiles, ntiles, desc, tap_wq, st, r);
                 break;
         }
     }

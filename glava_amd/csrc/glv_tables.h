@@ -208,6 +208,15 @@ inline bool make_bar_tiles(std::vector<BarTile>& tiles, const std::vector<BarDes
     return true;
 }
 
+// The weights regrouped for glv_bars_rows_kernel: every chunk of `chunk` taps as [q][g] = w[4 g + q], q = 0..3 (the lane of a quad
+// that holds the weight), g = 0 .. chunk / 4 - 1 (the register).  tap_w is a whole number of chunks long.
+inline void make_bar_quad_weights(std::vector<float>& wq, const std::vector<float>& tap_w, uint32_t chunk) {
+    wq.assign(tap_w.size(), 0.0f);
+    for (size_t c = 0; c + chunk <= tap_w.size(); c += chunk)
+        for (uint32_t q = 0; q < 4; ++q)
+            for (uint32_t g = 0; g < chunk / 4; ++g) wq[c + q * (chunk / 4) + g] = tap_w[c + 4 * g + q];
+}
+
 // log_mode 0 table (glv_core.h log_third_table): c_j = 1 + j / 2^bits, { 2^-23 / c_j, log(c_j)/3 }.
 inline void make_log_table(LogEntry* t, int bits = kLogTabMaxBits) {
     for (int j = 0; j < (1 << bits); ++j) {

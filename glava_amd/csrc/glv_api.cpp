@@ -286,6 +286,7 @@ struct glv_batch {
     uint32_t ring_pos = 0;       // next write position in the PCM ring, in frames
     int grid_override = 0;
     int variant_override = -1;   // kernel configuration forced by glv_batch_set_variant (-1 = wisdom / default)
+    int attr_log_mode = -1;      // log mode whose kernels had their function attributes set (batch_prepare)
     int last_launches = 0;       // kernels the last process call launched
     int last_grid = 0;           // workgroups of the last frame-kernel launch
     int last_variant = 0;        // kernel configuration of the last frame-kernel launch
@@ -536,7 +537,9 @@ int ensure_bar_tables(glv_batch* b) {
 int batch_prepare(glv_batch* b) {
     if (int rc = b->tab.set_tilt(b->p.fft_scale, b->p.fft_cutoff, b->p.log_mode == 1)) return rc;
     const float g = b->p.gravity_step * (1.0F / b->p.ur);                      // render.c:728
-    if (!b->grav_known || std::memcmp(&g, &b->grav_g, sizeof(g)) != 0) {
+    // (only the GL_R16 state needs it: 65 536 evaluations on the host -- the single-stream drop-ins come through here whenever the
+    // host's measured `ur` changes, i.e. every frame)
+    if (b->state16 && (!b->grav_known || std::memcmp(&g, &b->grav_g, sizeof(g)) != 0)) {
         b->grav_int = glv::gravity_r16_integer_step(g, &b->grav_sub);
         b->grav_g = g; b->grav_known = true;
     }
@@ -561,7 +564,8 @@ int batch_prepare(glv_batch* b) {
     // function attributes (the > 64 KiB dynamic-LDS opt-in) of every frame kernel this batch can launch: set here, once per device
     // and instantiation, so that a process call is a plain launch (launch_variant with grid 0 = attribute only; combinations
     // that are not built answer hipErrorInvalidValue, which is not an error here)
-    {
+    if (b->attr_log_mode != (int) b->p.log_mode) {
+        b->attr_log_mode = (int) b->p.log_mode;
         glv::FrameArgs a;
         std::memset(&a, 0, sizeof(a));
         const struct { unsigned ops; bool bars; uint32_t gl; } cls[] = {

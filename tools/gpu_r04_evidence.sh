@@ -10,7 +10,7 @@ python bench.py > $O/bench_line.json 2> $O/bench.err
 TRAFFIC_ARGS="--traffic-json $O/hbm_traffic.json --n 4096 --streams 65536 --ops fft --kernel glv_frame_kernel<11,~0,~1,~2,~1,~1,~true,~2,~1,~1,~4,~0,~0>" bash tools/profile.sh r04 --no-alt --no-configs --sustained-s 0 > $O/prof_r04.txt 2>&1
 bash tools/profile.sh r04_n8192 --n 8192 --streams 32768 --no-alt --no-configs --sustained-s 0 > /dev/null 2>&1
 bash tools/profile.sh r04_n16384 --n 16384 --streams 16384 --no-alt --no-configs --sustained-s 0 > /dev/null 2>&1
-for c in gl_default gl_bars configs2 chain n1024bars ring; do
+for c in gl_default gl_bars gl_sm configs2 chain n1024bars ring; do
   bash tools/profile_cmd.sh r04_$c python $GRAFT_REPO_ROOT/tools/cfg_run.py $c 150 > $O/prof_$c.txt 2>&1
 done
 python tools/power_probe.py --seconds 5 > $O/power.txt 2>/dev/null

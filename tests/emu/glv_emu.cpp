@@ -309,3 +309,42 @@ unsigned long long glvemu_div_frames_check(unsigned F, unsigned lo_bits, unsigne
     return bad;
 }
 }
+
+extern "C" {
+// glv_tables.h make_bar_tiles / make_bar_quad_weights (the host tables of glv_bars_rows_kernel): 0 when the tiles cover every bar
+// exactly once in order, hold at most max_bars bars, start on a multiple of 4 bins, span at most `bins` bins, contain every tap
+// of their bars rounded up to whole octets, and the regrouped weights are a permutation of the plain ones chunk by chunk.
+// -1: the bars cannot be tiled for this window (the kernel is then not used).
+int glvemu_bar_tiles_check(int n, int bars, float smooth_factor, float phase, int bins, int max_bars, unsigned* ntiles_out, unsigned* max_count_out) {
+    using namespace glv;
+    std::vector<BarDesc> desc;
+    std::vector<float> w;
+    make_bar_taps(desc, w, (uint32_t) n, (uint32_t) bars, smooth_factor, phase);
+    const uint32_t chunk = bar_chunk_of((uint32_t) n);
+    w.resize(w.size() + chunk, 0.0f);
+    uint32_t mc = 0;
+    for (const BarDesc& d : desc) mc = d.count > mc ? d.count : mc;
+    if (max_count_out) *max_count_out = mc;
+    std::vector<BarTile> tiles;
+    if (!make_bar_tiles(tiles, desc, (uint32_t) n, (uint32_t) bins, (uint32_t) max_bars)) return -1;
+    if (ntiles_out) *ntiles_out = (unsigned) tiles.size();
+    uint32_t next = 0;
+    for (const BarTile& t : tiles) {
+        if (t.k0 != next || t.k1 <= t.k0 || t.k1 - t.k0 > (uint32_t) max_bars) return 1;
+        if ((t.origin & 3u) || (t.end & 3u) || t.end <= t.origin || t.end - t.origin > (uint32_t) bins || t.end > (uint32_t) n) return 2;
+        for (uint32_t k = t.k0; k < t.k1; ++k) {
+            const uint32_t e = desc[k].first_bin + ((desc[k].count + 7u) & ~7u);
+            if (desc[k].first_bin < t.origin || e > t.end) return 3;
+        }
+        next = t.k1;
+    }
+    if (next != (uint32_t) bars) return 4;
+    std::vector<float> wq;
+    make_bar_quad_weights(wq, w, chunk);
+    if (wq.size() != w.size() || w.size() % chunk) return 5;
+    for (size_t c = 0; c < w.size(); c += chunk)
+        for (uint32_t t = 0; t < chunk; ++t)
+            if (wq[c + (t & 3u) * (chunk / 4) + t / 4] != w[c + t]) return 6;
+    return 0;
+}
+}

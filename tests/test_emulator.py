@@ -302,3 +302,21 @@ def test_fused_tilt_formula_is_within_its_bound(n):
             exact = np.maximum(t, f(1.0)).astype(np.float64) * np.float64(k)
             worst = max(worst, float(np.nanmax(np.abs(got.astype(np.float64) - exact) / exact)))
         assert worst <= 4.5e-7, (n, scale, cutoff, worst)
+
+
+@pytest.mark.parametrize("n,bins", [(1024, 128), (2048, 128), (4096, 128), (4096, 256), (8192, 256)])
+def test_tile_and_quad_weight_tables_of_the_many_rows_bars_kernel(emu, n, bins):
+    """glv_bars_rows_kernel (the pre-smoothing pass at scale: bars == n, one lane per row) runs off two host tables: tiles of at
+    most 32 consecutive bars whose taps fit an LDS window of `bins` bins, and the weights regrouped per quad lane.  Invariants of
+    both, and which sizes can be tiled at all: n <= 2048 with 128 bins, n = 4096 only with 256 (its longest bar has 191 taps),
+    n >= 8192 not (the library then keeps glv_bars_kernel)."""
+    import ctypes as C
+    nt, mc = C.c_uint(0), C.c_uint(0)
+    rc = emu.glvemu_bar_tiles_check(n, n, C.c_float(0.025), C.c_float(0.5), bins, 32, C.byref(nt), C.byref(mc))
+    fits = ((mc.value + 7) & ~7) + 3 <= bins
+    if n >= 8192 or (n == 4096 and bins == 128):
+        assert rc == -1 and not fits, (rc, mc.value)
+    else:
+        assert rc == 0 and fits and nt.value >= n // 32, (rc, nt.value, mc.value)
+    # the modules' 80 bars tile too (the kernel is only used from 256 bars up, but the table logic is size-agnostic)
+    assert emu.glvemu_bar_tiles_check(4096, 80, C.c_float(0.025), C.c_float(0.0), 256, 32, C.byref(nt), C.byref(mc)) == 0

@@ -390,13 +390,17 @@ WisdomKey wisdom_key(const glv_batch* b, int in_mode, unsigned ops) {
 int default_grid(const glv_batch* b, uint32_t units, int variant) {
     const glv::FrameGeometry g = glv::frame_geometry(b->log_nn, variant);
     const uint32_t wgs = (units + g.rows_per_trip - 1) / g.rows_per_trip;
-    // persistent workgroups: two rounds of what fits the chip (the second round evens out CU-to-CU
-    // differences), one round when that would leave a slot fewer than 8 trips -- every workgroup pays a
-    // prologue (window / table staging, pipeline fill) that short-lived workgroups cannot amortise
-    // (N=8192, 8192 streams: 0.194 ms with 256-512 workgroups, 0.224 ms with 2048)
+    // persistent workgroups: up to g.rounds rounds of what fits the chip (N=8192, 8192 streams: 0.194 ms with 256-512
+    // workgroups, 0.224 ms with 2048; N<=4096, 65536 streams: eight rounds beat two by 1-4 %, profiles/r04/grid_ab.txt)
     const uint32_t round = (uint32_t) b->num_cus * (uint32_t) g.resident;
-    const uint32_t cap = wgs >= 16u * round ? (uint32_t) g.rounds * round : round;
-    return (int) (wgs < cap ? wgs : cap);
+    if (wgs <= round) return (int) wgs;
+    // more rounds than one even out the tail (the hardware dispatches the next workgroup to whichever CU is free), as long as a
+    // workgroup still makes at least eight trips: every workgroup pays a prologue (window / table staging, pipeline fill) --
+    // N=4096, 16384 streams: 0.168 ms with 512-1024 workgroups, 0.173 with 2048, 0.183 with 4096
+    uint32_t grid = wgs / 8u;
+    if (grid < round) grid = round;
+    if (grid > (uint32_t) g.rounds * round) grid = (uint32_t) g.rounds * round;
+    return (int) grid;
 }
 
 // (kernel configuration, workgroups) of the next frame-kernel launch: explicit overrides, else the wisdom, else the defaults

@@ -31,21 +31,23 @@ template <int LOG_NN> struct NumVariants { static constexpr int value = 1; };
     template <> struct Tuned<K, V> { static constexpr int log_e = LE, slots = S, nbuf = NB, occ = OC; \
                                      static constexpr bool winlds = WL; static constexpr int twreg = TR, tiltreg = TL, prefetch = PF, wpre = WP, wpre_s = WPS, rounds = RD; };
 #define GLV_NVARIANTS(K, NV) template <> struct NumVariants<K> { static constexpr int value = NV; };
-//     log2(nn) V  LOG_E SLOTS NBUF TWREG  WINLDS OCC PREFETCH TILTREG WPRE WPRE_S ROUNDS   (knob values: glv_kernel_tmpl.h; ROUNDS: persistent workgroups launched = ROUNDS x what fits the chip)
-GLV_TUNED(7,    0, 3,    16,   1,   true,  true,  4,  1,       true,   0,   0,   2)    // N=256    E=8:  3+3+1 (16 lanes per row; not tuned: coverage of setbufsize 256)
-GLV_TUNED(8,    0, 3,    16,   1,   true,  true,  4,  1,       true,   0,   0,   2)    // N=512    E=8:  3+3+2
-GLV_TUNED(8,    1, 4,    16,   1,   true,  true,  2,  1,       true,   0,   0,   2)    //          E=16: 4+4, one exchange less (0.629 vs 0.598 ms in the r01 sweep; equal with log_mode 0)
-GLV_TUNED(9,    0, 3,    4,    1,   true,  true,  4,  1,       true,   0,   0,   2)    // N=1024   E=8:  3+3+3
-GLV_TUNED(9,    1, 3,    2,    1,   true,  true,  4,  1,       true,   0,   0,   2)    //          two rows per workgroup instead of four (smaller workgroups, more of them)
-GLV_TUNED(10,   0, 4,    4,    1,   true,  true,  2,  1,       true,   0,   0,   2)    // N=2048   E=16: 4+4+3, four 128-lane rows (r02 sweep_13: 0.627 vs 0.668 ms for E=8)
-GLV_TUNED(10,   1, 3,    4,    1,   true,  true,  4,  1,       true,   0,   0,   2)    //          E=8:  3+3+3+1, four 256-lane rows, 4 waves per SIMD (production until round 2)
-GLV_TUNED(11,   0, 4,    2,    1,   true,  true,  2,  1,       true,   0,   0,   2)    // N=4096   E=16: 4+4+3
-GLV_TUNED(11,   1, 3,    2,    1,   true,  true,  3,  1,       true,   0,   0,   2)    //          E=8:  3+3+3+2, 3 waves per SIMD (0.672 vs 0.647 ms; 0.917 vs 0.909 with log_mode 0)
+//     log2(nn) V  LOG_E SLOTS NBUF TWREG  WINLDS OCC PREFETCH TILTREG WPRE WPRE_S ROUNDS   (knob values: glv_kernel_tmpl.h; ROUNDS: persistent workgroups launched = up to ROUNDS x what fits the chip.
+//     Round 4 (tools/grid_ab.py, profiles/r04/grid_ab.txt): N <= 4096 runs 1-4 % faster in EVERY kernel class with eight rounds than with two -- the hardware hands the next
+//     workgroup to whichever CU finishes first, which evens out the tail a two-round launch ends on; N = 8192 / 32768 keep one round (a 64 KiB window staging prologue per workgroup))
+GLV_TUNED(7,    0, 3,    16,   1,   true,  true,  4,  1,       true,   0,   0,   8)    // N=256    E=8:  3+3+1 (16 lanes per row; not tuned: coverage of setbufsize 256)
+GLV_TUNED(8,    0, 3,    16,   1,   true,  true,  4,  1,       true,   0,   0,   8)    // N=512    E=8:  3+3+2
+GLV_TUNED(8,    1, 4,    16,   1,   true,  true,  2,  1,       true,   0,   0,   8)    //          E=16: 4+4, one exchange less (0.629 vs 0.598 ms in the r01 sweep; equal with log_mode 0)
+GLV_TUNED(9,    0, 3,    4,    1,   true,  true,  4,  1,       true,   0,   0,   8)    // N=1024   E=8:  3+3+3
+GLV_TUNED(9,    1, 3,    2,    1,   true,  true,  4,  1,       true,   0,   0,   8)    //          two rows per workgroup instead of four (smaller workgroups, more of them)
+GLV_TUNED(10,   0, 4,    4,    1,   true,  true,  2,  1,       true,   0,   0,   8)    // N=2048   E=16: 4+4+3, four 128-lane rows (r02 sweep_13: 0.627 vs 0.668 ms for E=8)
+GLV_TUNED(10,   1, 3,    4,    1,   true,  true,  4,  1,       true,   0,   0,   8)    //          E=8:  3+3+3+1, four 256-lane rows, 4 waves per SIMD (production until round 2)
+GLV_TUNED(11,   0, 4,    2,    1,   true,  true,  2,  1,       true,   0,   0,   8)    // N=4096   E=16: 4+4+3
+GLV_TUNED(11,   1, 3,    2,    1,   true,  true,  3,  1,       true,   0,   0,   8)    //          E=8:  3+3+3+2, 3 waves per SIMD (0.672 vs 0.647 ms; 0.917 vs 0.909 with log_mode 0)
 GLV_TUNED(12,   0, 4,    2,    1,   true,  true,  2,  1,       true,   0,   0,   1)    // N=8192   E=16: 4+4+4; two slots share the 64 KiB LDS window
 GLV_TUNED(12,   1, 4,    1,    1,   true,  false, 2,  1,       true,   0,   0,   2)    //          one row per workgroup, two workgroups per CU, window through L2 (tie with log_mode 0 in the r01 sweep)
-GLV_TUNED(13,   0, 5,    1,    1,   2,     false, 2,  1,       3,      0,   0,   2)    // N=16384  E=32: 5+5+3; pass-1 twiddles from an 8 KiB LDS table, tilt computed (log_mode 1: two fused ops per value)
+GLV_TUNED(13,   0, 5,    1,    1,   2,     false, 2,  1,       3,      0,   0,   4)    // N=16384  E=32: 5+5+3; pass-1 twiddles from an 8 KiB LDS table, tilt computed (log_mode 1: two fused ops per value)
                                                                                        //          (WPRE, the window prefetch ahead of the stores, measured no gain: profiles/r02)
-GLV_TUNED(13,   1, 5,    2,    0,   4,     false, 2,  1,       3,      0,   0,   2)    //          split exchange (the row crosses LDS one float component at a time): two rows per 512-thread workgroup and
+GLV_TUNED(13,   1, 5,    2,    0,   4,     false, 2,  1,       3,      0,   0,   4)    //          split exchange (the row crosses LDS one float component at a time): two rows per 512-thread workgroup and
                                                                                        //          EVERY twiddle in LDS, no L2 gather (tied the production plan in r03 sweep_xsplit; fused bars fall back to two launches)
 GLV_TUNED(14,   0, 5,    1,    1,   2,     false, 2,  1,       3,      0,   0,   1)    // N=32768  E=32: 5+5+4, one 512-lane row per CU (135 KiB exchange region), pass-1 twiddles from LDS (sweep_13)
 GLV_TUNED(14,   1, 5,    1,    1,   0,     false, 2,  1,       3,      0,   0,   1)    //          every pass's per-lane twiddles gathered from the L2-resident table (no LDS copy: 8 KiB more for the exchange)

@@ -90,7 +90,7 @@ def build_tune_variant(name: str, extra_flags: list[str], variants: str | None =
     return lib
 
 
-def build_variant(name: str, extra_flags: list[str], sizes=SIZES, kernels_only: bool = False) -> str:
+def build_variant(name: str, extra_flags: list[str], sizes=SIZES, kernels_only: bool = False, misc: bool = False) -> str:
     """A/B copy of the product library, glava_amd/csrc/libglvspectrum_<name>.so, compiled with extra flags
     (experiment macros); loaded instead of the product with GLV_SPECTRUM_LIB=<path> (tools/ab_bench.sh).
     kernels_only: the flags touch nothing but the frame kernels of `sizes` -- only those objects are compiled, everything
@@ -102,7 +102,11 @@ def build_variant(name: str, extra_flags: list[str], sizes=SIZES, kernels_only: 
     reused = []
     if kernels_only:
         reused = [os.path.join(OBJ, f"glv_inst_{k}_{p}.o") for k in SIZES if k not in sizes for p in PARTS]
-        reused += [os.path.join(OBJ, o) for o in ("glv_misc.o", "glv_api.o", "glv_multi.o")]
+        reused += [os.path.join(OBJ, o) for o in ("glv_api.o", "glv_multi.o")]
+        if misc:        # the flags (also) touch the kernels of glv_misc.hip: sizes=() compiles nothing else
+            jobs.append(("glv_misc.hip", os.path.join(obj_dir, "glv_misc.o"), list(extra_flags)))
+        else:
+            reused.append(os.path.join(OBJ, "glv_misc.o"))
     else:
         jobs.append(("glv_misc.hip", os.path.join(obj_dir, "glv_misc.o"), list(extra_flags)))
         jobs.append(("glv_api.cpp", os.path.join(obj_dir, "glv_api.o"), ["-x", "hip", *extra_flags]))

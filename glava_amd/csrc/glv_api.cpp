@@ -319,7 +319,10 @@ struct glv_batch {
     uint32_t bar_count = 0; float bar_factor = -1.f, bar_phase = 0.f;
     glv::BarTile* d_bar_tiles = nullptr;   // tiles of the many-bars x many-rows kernel (glv_misc.hip glv_bars_rows_kernel), when the bars allow them
     uint32_t bar_ntiles = 0, bar_tile_bins = 0;
-    float* d_bar_wq = nullptr;             // the weights regrouped per quad lane for that kernel (glv_tables.h make_bar_quad_weights)
+    glv::BarGroupDesc* d_bar_groups = nullptr;   // its groups of eight bars, their weight stream and the bars' weight sums (glv_tables.h make_bar_groups)
+    float* d_bar_wg = nullptr;
+    float* d_bar_wsum = nullptr;
+    glv::BarRowsTables rows_tables() const { return glv::BarRowsTables{d_bar_tiles, bar_ntiles, bar_tile_bins, d_bar_groups, d_bar_wg, d_bar_wsum}; }
     // timing
     bool timing = false;
     std::vector<hipEvent_t> ev;  // start/stop pairs
@@ -485,7 +488,7 @@ int ensure_bar_tables(glv_batch* b) {
     glv::make_bar_taps(desc, w, b->p.n, b->p.bars, b->p.smooth_factor, b->p.bar_phase);
     if (!glv::bar_chunks_in_row(desc, b->p.n)) return fail(GLV_ERR_INVALID, "bars: a tap chunk would leave the row (n=%u smooth_factor=%g)", b->p.n, (double) b->p.smooth_factor);
     auto drop = [](auto*& ptr) { if (ptr) { (void) hipFree(ptr); ptr = nullptr; } };
-    drop(b->d_bar_desc); drop(b->d_bar_w); drop(b->d_bar_items); drop(b->d_bar_tiles); drop(b->d_bar_wq);
+    drop(b->d_bar_desc); drop(b->d_bar_w); drop(b->d_bar_items); drop(b->d_bar_tiles); drop(b->d_bar_groups); drop(b->d_bar_wg); drop(b->d_bar_wsum);
     for (int v = 0; v < glv_batch::kMaxVariants; ++v) { drop(b->d_bar_fitems[v]); b->bar_fusable[v] = false; b->bar_fnsteps[v] = 0; }
     b->bar_count = 0;
     // work lists: 256 / GL groups per row for glv_bars_kernel; T / GL groups for the frame kernel (GL = bar_lanes_of(n); fused bars:
@@ -513,19 +516,23 @@ int ensure_bar_tables(glv_batch* b) {
     HIP_TRY(hipMemcpy(b->d_bar_desc, desc.data(), sizeof(glv::BarDesc) * desc.size(), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(b->d_bar_w, w.data(), sizeof(float) * w.size(), hipMemcpyHostToDevice));
     b->bar_count = b->p.bars; b->bar_factor = b->p.smooth_factor; b->bar_phase = b->p.bar_phase;
-    // many bars (the pre-smoothing pass): the tile table of the lane-per-row kernel, for the smallest LDS window that takes every bar
+    // many bars (the pre-smoothing pass): the tables of the lane-per-row kernel, for the smallest LDS window that takes every group
     b->bar_ntiles = 0; b->bar_tile_bins = 0;
-    if (b->p.bars >= 256 && !std::getenv("GLV_NO_BARS_ROWS")) {                    // (diagnostics: keep the small-batch kernel for every row count)
+    if (b->p.bars >= glv::kBarGroupMin && !std::getenv("GLV_NO_BARS_ROWS")) {      // (diagnostics: keep the small-batch kernel for every row count)
         std::vector<glv::BarTile> tiles;
-        for (uint32_t bins : {128u, 256u}) {
-            if (bins == 256u && glv::bar_lanes_of(b->p.n) != 8) break;             // (built for the 64-tap chunks only)
-            if (glv::make_bar_tiles(tiles, desc, b->p.n, bins, 32u)) {            // 32 = glv_misc.hip kRowsTileBars
+        std::vector<glv::BarGroupDesc> groups;
+        std::vector<float> wg, wsum;
+        for (uint32_t bins : {128u, 240u}) {
+            if (bins == 240u && glv::bar_lanes_of(b->p.n) != 8) break;             // (built for the 64-tap chunks only)
+            if (glv::make_bar_groups(groups, wg, wsum, tiles, desc, w, b->p.n, bins, 64u)) {      // 64 = glv_misc.hip kRowsTileBars
                 HIP_TRY(hipMalloc(&b->d_bar_tiles, sizeof(glv::BarTile) * tiles.size()));
                 HIP_TRY(hipMemcpy(b->d_bar_tiles, tiles.data(), sizeof(glv::BarTile) * tiles.size(), hipMemcpyHostToDevice));
-                std::vector<float> wq;
-                glv::make_bar_quad_weights(wq, w, chunk);
-                HIP_TRY(hipMalloc(&b->d_bar_wq, sizeof(float) * wq.size()));
-                HIP_TRY(hipMemcpy(b->d_bar_wq, wq.data(), sizeof(float) * wq.size(), hipMemcpyHostToDevice));
+                HIP_TRY(hipMalloc(&b->d_bar_groups, sizeof(glv::BarGroupDesc) * groups.size()));
+                HIP_TRY(hipMemcpy(b->d_bar_groups, groups.data(), sizeof(glv::BarGroupDesc) * groups.size(), hipMemcpyHostToDevice));
+                HIP_TRY(hipMalloc(&b->d_bar_wg, sizeof(float) * wg.size()));
+                HIP_TRY(hipMemcpy(b->d_bar_wg, wg.data(), sizeof(float) * wg.size(), hipMemcpyHostToDevice));
+                HIP_TRY(hipMalloc(&b->d_bar_wsum, sizeof(float) * wsum.size()));
+                HIP_TRY(hipMemcpy(b->d_bar_wsum, wsum.data(), sizeof(float) * wsum.size(), hipMemcpyHostToDevice));
                 b->bar_ntiles = (uint32_t) tiles.size(); b->bar_tile_bins = bins;
                 break;
             }
@@ -709,7 +716,8 @@ int process(glv_batch* b, const void* d_in, int in_mode, float* d_out, unsigned 
         if (ops & GLV_OP_AVERAGE) b->head = (b->head + 1) % b->p.avg_frames;
         b->grav_cur = grav_next;
         if ((ops & GLV_OP_BARS) && !fused_bars) {
-            e = glv::launch_bars(d_out, d_final, units, b->p.n, b->p.bars, b->bar_nsteps, b->d_bar_items, b->d_bar_desc, b->d_bar_w, st, (ops & GLV_OP_R16) != 0, b->d_bar_tiles, b->bar_ntiles, b->bar_tile_bins, b->d_bar_wq); ++b->last_launches;
+            const glv::BarRowsTables rt = b->rows_tables();
+            e = glv::launch_bars(d_out, d_final, units, b->p.n, b->p.bars, b->bar_nsteps, b->d_bar_items, b->d_bar_desc, b->d_bar_w, st, (ops & GLV_OP_R16) != 0, &rt); ++b->last_launches;
             if (e != hipSuccess) return fail(GLV_ERR_HIP, "bars launch failed: %s", hipGetErrorString(e));
         }
         return timed_launch_end(b, st);
@@ -741,7 +749,8 @@ int process(glv_batch* b, const void* d_in, int in_mode, float* d_out, unsigned 
             if (e != hipSuccess) return fail(GLV_ERR_HIP, "smooth launch failed: %s", hipGetErrorString(e));
         }
         if (ops & GLV_OP_BARS) {
-            e = glv::launch_bars(d_tmp, d_final, units, b->p.n, b->p.bars, b->bar_nsteps, b->d_bar_items, b->d_bar_desc, b->d_bar_w, st, (ops & GLV_OP_R16) != 0, b->d_bar_tiles, b->bar_ntiles, b->bar_tile_bins, b->d_bar_wq); ++b->last_launches;
+            const glv::BarRowsTables rt = b->rows_tables();
+            e = glv::launch_bars(d_tmp, d_final, units, b->p.n, b->p.bars, b->bar_nsteps, b->d_bar_items, b->d_bar_desc, b->d_bar_w, st, (ops & GLV_OP_R16) != 0, &rt); ++b->last_launches;
             if (e != hipSuccess) return fail(GLV_ERR_HIP, "bars launch failed: %s", hipGetErrorString(e));
         }
         return timed_launch_end(b, st);            // the HIP-event window covers every launch of the chain
@@ -772,7 +781,8 @@ int process(glv_batch* b, const void* d_in, int in_mode, float* d_out, unsigned 
         if (e != hipSuccess) return fail(GLV_ERR_HIP, "smooth launch failed: %s", hipGetErrorString(e));
     }
     if ((ops & GLV_OP_BARS) && !fused_bars) {
-        e = glv::launch_bars(d_out ? d_out : b->grav_cur, d_final, units, b->p.n, b->p.bars, b->bar_nsteps, b->d_bar_items, b->d_bar_desc, b->d_bar_w, st, (ops & GLV_OP_R16) != 0, b->d_bar_tiles, b->bar_ntiles, b->bar_tile_bins, b->d_bar_wq); ++b->last_launches;
+        const glv::BarRowsTables rt = b->rows_tables();
+        e = glv::launch_bars(d_out ? d_out : b->grav_cur, d_final, units, b->p.n, b->p.bars, b->bar_nsteps, b->d_bar_items, b->d_bar_desc, b->d_bar_w, st, (ops & GLV_OP_R16) != 0, &rt); ++b->last_launches;
         if (e != hipSuccess) return fail(GLV_ERR_HIP, "bars launch failed: %s", hipGetErrorString(e));
     }
     return timed_launch_end(b, st);
@@ -904,7 +914,9 @@ int glv_batch_destroy(glv_batch* b) {
     if (b->d_bar_items) (void) hipFree(b->d_bar_items);
     for (glv::BarItem* f : b->d_bar_fitems) if (f) (void) hipFree(f);
     if (b->d_bar_tiles) (void) hipFree(b->d_bar_tiles);
-    if (b->d_bar_wq) (void) hipFree(b->d_bar_wq);
+    if (b->d_bar_groups) (void) hipFree(b->d_bar_groups);
+    if (b->d_bar_wg) (void) hipFree(b->d_bar_wg);
+    if (b->d_bar_wsum) (void) hipFree(b->d_bar_wsum);
     for (hipEvent_t e : b->ev) (void) hipEventDestroy(e);
     delete b;
     return GLV_OK;
@@ -1032,8 +1044,9 @@ int glv_batch_bars(glv_batch* b, const float* d_spec, float* d_bars, void* hip_s
     if (b->p.bars == 0 || b->p.bars > b->p.n) return fail(GLV_ERR_INVALID, "bars=%u out of range", b->p.bars);
     HIP_TRY(hipSetDevice(b->device));
     if (!b->d_bar_desc) return fail(GLV_ERR_STATE, "the batch has no bar tables (bars / smooth_factor / bar_phase were unusable when it was created)");
+    const glv::BarRowsTables rt = b->rows_tables();
     hipError_t e = glv::launch_bars(d_spec, d_bars, (size_t) b->streams * 2, b->p.n, b->p.bars, b->bar_nsteps, b->d_bar_items, b->d_bar_desc, b->d_bar_w,
-                                    (hipStream_t) hip_stream, false, b->d_bar_tiles, b->bar_ntiles, b->bar_tile_bins, b->d_bar_wq);
+                                    (hipStream_t) hip_stream, false, &rt);
     if (e != hipSuccess) return fail(GLV_ERR_HIP, "bars launch failed: %s", hipGetErrorString(e));
     return GLV_OK;
 }

@@ -40,11 +40,13 @@ hipError_t launch_smooth(float* rows, size_t nrows, uint32_t n, const int* smin,
 // the s16 window table as float pairs (glv_core.h WinSplit): split = float [n/2][4]; d_fail_shifted = int [2], zeroed by the caller
 hipError_t launch_window_split(const double* w_tab, float* split, uint32_t n, int* d_fail_shifted, hipStream_t st);
 hipError_t launch_window_split_check(const double* w_tab, const float* split, uint32_t n, unsigned long long* d_mismatches, hipStream_t st);
-// tiles / ntiles / tile_bins / tap_wq: the tile table and the per-quad weight table of the many-bars x many-rows kernel
-// (glv_tables.h make_bar_tiles, make_bar_quad_weights; nullptr: not considered)
+// rt: the tables of the many-bars x many-rows kernel (glv_tables.h make_bar_groups; nullptr: not considered)
+struct BarRowsTables {
+    const BarTile* tiles; uint32_t ntiles, tile_bins;     // tile_bins: the LDS window the tiles were cut for (128 or 240 bins)
+    const BarGroupDesc* groups; const float* wg; const float* wsum;
+};
 hipError_t launch_bars(const float* spec, float* bars_out, size_t nrows, uint32_t n, uint32_t bars, uint32_t nsteps,
-                       const BarItem* items, const BarDesc* desc, const float* tap_w, hipStream_t st, bool r16 = false,
-                       const BarTile* tiles = nullptr, uint32_t ntiles = 0, uint32_t tile_bins = 0, const float* tap_wq = nullptr);
+                       const BarItem* items, const BarDesc* desc, const float* tap_w, hipStream_t st, bool r16 = false, const BarRowsTables* rt = nullptr);
 hipError_t launch_ring_planar(const void* ring, int is_f32, uint32_t n, uint32_t rot, int mono, size_t streams, float* out, hipStream_t st);
 hipError_t launch_unpack(const int16_t* pcm, size_t frames, int mono, float* l, float* r, hipStream_t st);
 

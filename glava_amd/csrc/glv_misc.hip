@@ -367,30 +367,34 @@ __global__ void __launch_bounds__(256) glv_bars_short_kernel(const float* __rest
     }
 }
 
-// The same bars for MANY bars and MANY rows (the pre-smoothing pass of render.c:2277-2303: bars == n, one output per texel, ~57
-// taps each at n = 4096: 233 K multiply-adds per row): ONE LANE PER ROW.  The taps and weights of bar k do not depend on the row,
-// so with 64 rows side by side in a wave every weight is wave-uniform -- a scalar register operand, fetched once per 64 rows
-// through the scalar cache -- and a tap is ONE vector instruction for 64 rows (v_pk_fma_f32: one link of the even and the odd
-// chain).  A workgroup is four waves on the SAME 64 rows: the rows' texels live in LDS as a linear window [bin][row] (S bins x
-// 64 rows: conflict-free, a tap pair is one ds_read2st64_b32 at an immediate offset) that serves one TILE of bars -- up to 64
-// consecutive bars whose taps fit the window (host table, glv_tables.h make_bar_tiles: bars' first bins are monotone) -- the
-// waves take the tile's bars in turn, park their results in LDS, and the tile leaves as contiguous row segments.  Two workgroups
-// per CU = two waves per SIMD: the scalar and LDS latencies of one wave's bar are covered by the other's.  The summation order is
-// the documented one (glv_frame.h "GLV_OP_BARS arithmetic": chunks of 16 / 32 / 64 taps, per chunk 2 / 4 / 8 partial sums of eight
-// consecutive taps, each the sum of two fused-multiply-add chains, combined pairwise, chunk totals in order) walked sequentially by
-// the lane: the same bits as glv_bars_kernel and the fused epilogue.  glv_bars_kernel spends ~32 vector instructions per 8 taps
-// of ONE row (and pads every bar to whole 64-tap chunks); this one ~14 per 8 taps of 64 rows.
-constexpr int kRowsWaves = 4, kRowsTileBars = 32, kRowsStagePitch = 65;     // 32 bars per tile: 2 x (64 KiB window + 8 KiB stage) fit a CU's 160 KiB
+// The same bars for MANY bars and MANY rows (the pre-smoothing pass of render.c:2277-2303: bars == n, one output per texel, ~58
+// taps each at n = 4096: 237 K multiply-adds per row): ONE LANE PER ROW, EIGHT BARS PER WAVE AT A TIME.
+//   * The taps and weights of a bar do not depend on the row, so with 64 rows side by side in a wave every weight is wave-uniform: a
+//     SCALAR register, streamed through the scalar cache (s_load_dwordx16) -- no vector register, no vector load, no broadcast.
+//   * The eight bars of a group start at one bin (glv_tables.h make_bar_taps, "group rule"), so they walk the same texels in the same
+//     octets: the lane reads an octet of its row ONCE from LDS (two ds_read_b128) and uses it for eight bars.
+//   * A tap pair is one v_pk_fma_f32 for 64 rows: {even chain, odd chain} += {x[2i], x[2i+1]} * {w[2i], w[2i+1]} with the weight pair as
+//     an SGPR-pair operand -- 4 packed instructions per octet and bar, + 1 add for the octet sum, + the tree.
+//     (Round 4's first version took one bar per wave, one v_fmac_f32_dpp and half a ds_read2st64_b32 per tap and row: LDS-bandwidth
+//     bound at 1.33 ms for 32 K rows of N = 4096 -- profiles/r04/rows_parts.txt: 1.18 ms of it with no HBM traffic at all.)
+// A workgroup is eight waves on the SAME 64 rows: the rows' texels live in LDS as a window [bin / 4][row][4] (conflict-free b128
+// accesses both ways: the fill's global loads deliver exactly one such slot) that serves one TILE -- up to eight groups whose taps fit
+// the window (host table, glv_tables.h make_bar_groups) --, wave w takes group w, results are parked in LDS and the tile leaves as
+// contiguous row segments of 64 values.  Two workgroups per CU = four waves per SIMD cover the scalar and LDS latencies.
+// The summation order is the documented one (glv_frame.h "GLV_OP_BARS arithmetic": chunks of 16 / 32 / 64 taps, per chunk 2 / 4 / 8
+// octet sums, each the sum of two fused-multiply-add chains, combined pairwise, chunk totals in order), walked octet by octet with a
+// three-deep stack of partial sums: the same bits as glv_bars_kernel and the fused epilogue.
+constexpr int kRowsWaves = 8, kRowsTileBars = 64, kRowsStagePitch = 65;     // N = 4096: 2 x (60 KiB window + 16.3 KiB stage) fit a CU's 160 KiB
 template <int S, int GL>
 __global__ void __launch_bounds__(64 * kRowsWaves) glv_bars_rows_kernel(const float* __restrict__ spec, void* __restrict__ bars_out, size_t nrows, uint32_t n,
                                                                         uint32_t bars, const BarTile* __restrict__ tiles, uint32_t ntiles, uint32_t tiles_per_wg,
-                                                                        const BarDesc* __restrict__ desc, const float* __restrict__ tap_wq, int r16) {
+                                                                        const BarGroupDesc* __restrict__ groups, const float* __restrict__ wg,
+                                                                        const float* __restrict__ wsum, int r16) {
 #if defined(__HIP_DEVICE_COMPILE__)                     /* packed-f32 inline assembly: the host pass sees an empty stub */
-    extern __shared__ float rows_lds[];                 // [S][64] texel window | [32][65] finished outputs of the tile
-    float* win = rows_lds;
+    extern __shared__ float rows_lds[];                 // [S / 4][64] x 4 texels: the window | [64][65] finished outputs of the tile
+    static_assert(S % 8 == 0 && kRowsTileBars == 8 * kRowsWaves, "a wave per group of eight bars");
+    BarW4* win = reinterpret_cast<BarW4*>(rows_lds);
     float* stage = rows_lds + (size_t) S * 64;
-    constexpr uint32_t CHUNK = 8u * GL;
-    static_assert(kRowsTileBars / kRowsWaves <= 64 && CHUNK <= 64, "a wave's bars of a tile / a chunk's weights ride in one register, one per lane");
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = (uint32_t) __builtin_amdgcn_readfirstlane((int) (threadIdx.x >> 6));
     const size_t row0 = (size_t) blockIdx.x * 64;
@@ -399,43 +403,31 @@ __global__ void __launch_bounds__(64 * kRowsWaves) glv_bars_rows_kernel(const fl
     const float* src = spec + (row0 + (lane < R ? lane : R - 1)) * (size_t) n;
     const uint32_t t_begin = blockIdx.y * tiles_per_wg, t_end = t_begin + tiles_per_wg < ntiles ? t_begin + tiles_per_wg : ntiles;
     const glv_f2 ones = {1.0f, 1.0f};
-    // Weights and bar descriptors are wave-uniform.  Through the scalar cache (s_load) they cost a dependent L2 round trip per bar that
-    // nothing covers (desc -> tap_offset -> weights, ~1000 cycles before the first multiply) and 64 SGPRs that cannot be double
-    // buffered; instead lane l of the wave LOADS weight l of the chunk (one coalesced 256-byte vector load per 64 taps, issued one
-    // chunk ahead) and lane j the descriptor of the wave's j-th bar of the tile, and the uniform values are taken out of those
-    // registers with v_readlane_b32 when they are used.
-    auto lane_of = [](uint32_t v, uint32_t l) { return (uint32_t) __builtin_amdgcn_readlane((int) v, (int) l); };
-    // A chunk's weights as CHUNK / 4 registers: register g holds weights 4g .. 4g+3 of the chunk, one per lane of every quad, so that a
-    // tap's weight reaches all 64 lanes through the multiply-add's own DPP operand (quad_perm:[k,k,k,k]) -- no broadcast instruction
-    struct ChunkW { float g[CHUNK / 4]; };
-    // tap_wq: the same weights, every chunk regrouped per quad lane -- [chunk][q][g] = w[chunk * CHUNK + 4 g + q] -- so that lane q of a
-    // quad reads its CHUNK / 4 registers as CHUNK / 16 contiguous 16-byte loads (one per register from the plain table was 16 loads and
-    // their address arithmetic per 64 taps)
-    auto chunk_weights = [&](uint32_t tap_offset, uint32_t c0) {
-        ChunkW cw;
-        const uint32_t base = (tap_offset + c0 + (lane & 3u) * (CHUNK / 4u)) * 4u;       // tap_offset and c0 are multiples of CHUNK
+    struct HalfW { glv_f2 w[16]; };                     // a half step: bars 4 h .. 4 h + 3 of the group x 4 tap pairs, 32 SGPRs
+    auto load_half = [&](const float* wp, uint32_t i) {
+        HalfW h;
+        const glv_f2* p = reinterpret_cast<const glv_f2*>(wp + (size_t) i * 32u);
 #pragma unroll
-        for (uint32_t h = 0; h < CHUNK / 16u; ++h) {
-            const BarW4 v4 = ld<BarW4>(tap_wq, base + 16u * h);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) cw.g[4 * h + i] = v4.w[i];
-        }
-        return cw;
+        for (int q = 0; q < 16; ++q) h.w[q] = p[q];
+        return h;
     };
     for (uint32_t t = t_begin; t < t_end; ++t) {
         const BarTile T = tiles[t];                                             // uniform: scalar loads
-        const uint32_t nb = T.k1 > T.k0 + wave ? (T.k1 - T.k0 - wave + kRowsWaves - 1) / kRowsWaves : 0u;    // this wave's bars: k0 + wave, + 4, ...
-        BarDesc dv = {0u, 0u, 0u, 1.0f};
-        if (lane < nb) dv = desc[T.k0 + wave + kRowsWaves * lane];
+        const bool valid = T.k0 + 8u * wave < T.k1;
+        const BarGroupDesc g = groups[valid ? T.k0 / 8u + wave : T.k0 / 8u];
         __syncthreads();                                                        // the previous tile has left the window and the stage
-        // 4 bins of every row per load; four loads of a wave are issued before the first is parked
+        // 4 bins of every row per load = one window slot; four loads of a wave are issued before the first is parked
         const uint32_t ncol = (T.end - T.origin) / 4u;
         for (uint32_t cb = wave; cb < ncol; cb += kRowsWaves * 4) {
             BarW4 v4[4];
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const uint32_t c = cb + (uint32_t) q * kRowsWaves;
+#if defined(GLV_EXP_ROWS_NOFILL)        /* timing experiment (wrong results): no row loads */
+                v4[q] = BarW4{{(float) c, 0.5f, 0.25f, (float) lane}};
+#else
                 v4[q] = ld<BarW4>(src, (T.origin + 4u * (c < ncol ? c : cb)) * 4u);
+#endif
             }
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
@@ -446,81 +438,123 @@ __global__ void __launch_bounds__(64 * kRowsWaves) glv_bars_rows_kernel(const fl
                     glv_f2 lo = {v4[q].w[0], v4[q].w[1]}, hi = {v4[q].w[2], v4[q].w[3]};
                     asm("v_pk_mul_f32 %0, %1, %2 clamp" : "=v"(lo) : "v"(lo), "v"(ones));
                     asm("v_pk_mul_f32 %0, %1, %2 clamp" : "=v"(hi) : "v"(hi), "v"(ones));
-                    win[(size_t) (4u * c + 0) * 64 + lane] = lo.x; win[(size_t) (4u * c + 1) * 64 + lane] = lo.y;
-                    win[(size_t) (4u * c + 2) * 64 + lane] = hi.x; win[(size_t) (4u * c + 3) * 64 + lane] = hi.y;
+                    win[(size_t) c * 64 + lane] = BarW4{{lo.x, lo.y, hi.x, hi.y}};
                 }
             }
         }
-        ChunkW wnext = chunk_weights(nb ? lane_of(dv.tap_offset, 0) : 0u, 0u);
         __syncthreads();
-        for (uint32_t j = 0; j < nb; ++j) {
-            const uint32_t first_bin = lane_of(dv.first_bin, j), count = lane_of(dv.count, j), tap_offset = lane_of(dv.tap_offset, j);
-            const float wsum = __builtin_bit_cast(float, lane_of(__builtin_bit_cast(uint32_t, dv.weight_sum), j));
-            const float* x = win + (size_t) (first_bin - T.origin) * 64 + lane;
-            float total = 0.0f;
-            for (uint32_t c0 = 0; c0 < count; c0 += CHUNK) {
-                const ChunkW wv = wnext;
-                // one chunk ahead: the bar's next chunk, else the first chunk of the wave's next bar
-                if (c0 + CHUNK < count) wnext = chunk_weights(tap_offset, c0 + CHUNK);
-                else if (j + 1 < nb) wnext = chunk_weights(lane_of(dv.tap_offset, j + 1), 0u);
-                const float* xc = x + (size_t) c0 * 64;
-                float sl[GL];
-                // the chunk's octets of taps are independent chains: step them together.  Octets past the bar's end hold nothing but
-                // zero weights and sum to +0 exactly, so only the first ceil(rest / 8) are computed -- one unrolled body per count
-                const uint32_t rest = count - c0;
-                const uint32_t noct = rest >= CHUNK ? (uint32_t) GL : (rest + 7u) / 8u;
-                auto octets = [&](auto NO) {
-                    constexpr int NOCT = decltype(NO)::value;
-                    float ev[NOCT], od[NOCT];                       // the even and the odd chain of every octet
-                    // first link of every chain: fma(x, w, +0) == x * w (both factors are >= +0: no -0 can arise)
+#if !defined(GLV_EXP_ROWS_NOCOMPUTE)
+        if (valid) {
+            const uint32_t steps = (uint32_t) __builtin_amdgcn_readfirstlane((int) g.steps);
+            const float* wp = wg + (uint32_t) __builtin_amdgcn_readfirstlane((int) g.w_off);
+            const BarW4* xb = win + (size_t) ((g.first_bin - T.origin) / 4u) * 64 + lane;      // step s: slots 2 s, 2 s + 1 (one past the last step is read and dropped: the stage follows the window)
+            // per pair of bars {2 i, 2 i + 1}: the running total and the stack of partial sums of the chunk under way
+            glv_f2 tot[4], p0[4], p1[4], p2[4];
 #pragma unroll
-                    for (int l = 0; l < NOCT; ++l) {
-                        const int t0 = 8 * l;
-                        const float x0 = xc[(size_t) t0 * 64], x1 = xc[(size_t) (t0 + 1) * 64];
-                        asm("v_mul_f32_dpp %0, %1, %2 quad_perm:[0,0,0,0] row_mask:0xf bank_mask:0xf" : "=v"(ev[l]) : "v"(wv.g[t0 / 4]), "v"(x0));
-                        asm("v_mul_f32_dpp %0, %1, %2 quad_perm:[1,1,1,1] row_mask:0xf bank_mask:0xf" : "=v"(od[l]) : "v"(wv.g[t0 / 4]), "v"(x1));
+            for (int i = 0; i < 4; ++i) tot[i] = p0[i] = p1[i] = p2[i] = glv_f2{0.0f, 0.0f};
+            HalfW wcur = load_half(wp, 0u);
+            const float* wnext = wp + 32;                                       // the weight stream, one half step ahead: a running scalar pointer
+            const BarW4* xnext = xb + 128;                                      // the texels, one step ahead
+            BarW4 xa = xb[0], xc = xb[64];
+            auto pk_add = [](glv_f2 a, glv_f2 b2) { glv_f2 r; asm("v_pk_add_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b2)); return r; };
+            // one octet of texels x eight bars; L = the octet's place in its chunk (compile time: the tree of partial sums --
+            // group_sum's order: neighbours, pairs of pairs, the two quads -- built as the octets arrive)
+            auto step = [&](auto LC) {
+                constexpr int L = decltype(LC)::value;
+                const BarW4 na = xnext[0], nc = xnext[64];                       // the next step's texels
+                xnext += 128;
+                const glv_f2 x01 = {xa.w[0], xa.w[1]}, x23 = {xa.w[2], xa.w[3]}, x45 = {xc.w[0], xc.w[1]}, x67 = {xc.w[2], xc.w[3]};
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const HalfW wn = load_half(wnext, 0u);                        // one half step ahead (64 floats of slack follow the table)
+                    wnext += 32;
+                    // {even chain, odd chain} of the half step's four bars, interleaved (a dependent packed op two slots later costs a wait
+                    // state); first link: fma(x, w, +0) == x * w (both >= +0)
+                    glv_f2 ac[4], o[2];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) asm("v_pk_mul_f32 %0, %1, %2" : "=v"(ac[q]) : "v"(x01), "s"(wcur.w[4 * q + 0]));
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) asm("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(ac[q]) : "v"(x23), "s"(wcur.w[4 * q + 1]));
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) asm("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(ac[q]) : "v"(x45), "s"(wcur.w[4 * q + 2]));
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) asm("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(ac[q]) : "v"(x67), "s"(wcur.w[4 * q + 3]));
+                    asm("v_add_f32 %0, %1, %2" : "=v"(o[0].x) : "v"(ac[0].x), "v"(ac[0].y));
+                    asm("v_add_f32 %0, %1, %2" : "=v"(o[0].y) : "v"(ac[1].x), "v"(ac[1].y));
+                    asm("v_add_f32 %0, %1, %2" : "=v"(o[1].x) : "v"(ac[2].x), "v"(ac[2].y));
+                    asm("v_add_f32 %0, %1, %2" : "=v"(o[1].y) : "v"(ac[3].x), "v"(ac[3].y));
+#pragma unroll
+                    for (int bp = 0; bp < 2; ++bp) {
+                        const int i = 2 * h + bp;
+                        if constexpr (L == 0) p0[i] = o[bp];
+                        else if constexpr (L == 1) p0[i] = pk_add(p0[i], o[bp]);
+                        else if constexpr (L == 2 || L == 4) p1[i] = o[bp];
+                        else if constexpr (L == 5) p1[i] = pk_add(p1[i], o[bp]);
+                        else if constexpr (L == 3) p0[i] = pk_add(p0[i], pk_add(p1[i], o[bp]));
+                        else if constexpr (L == 6) p2[i] = o[bp];
+                        else p0[i] = pk_add(p0[i], pk_add(p1[i], pk_add(p2[i], o[bp])));
                     }
-#pragma unroll
-                    for (int i = 2; i < kBarTaps; i += 2)
-#pragma unroll
-                        for (int l = 0; l < NOCT; ++l) {
-                            const int t0 = 8 * l + i;                   // taps t0 (even chain), t0 + 1 (odd chain): weights in register t0 / 4, quad lanes t0 % 4, + 1
-                            const float x0 = xc[(size_t) t0 * 64], x1 = xc[(size_t) (t0 + 1) * 64];       // already clamped
-                            if ((t0 & 3) == 0) {
-                                asm("v_fmac_f32_dpp %0, %1, %2 quad_perm:[0,0,0,0] row_mask:0xf bank_mask:0xf" : "+v"(ev[l]) : "v"(wv.g[t0 / 4]), "v"(x0));
-                                asm("v_fmac_f32_dpp %0, %1, %2 quad_perm:[1,1,1,1] row_mask:0xf bank_mask:0xf" : "+v"(od[l]) : "v"(wv.g[t0 / 4]), "v"(x1));
-                            } else {
-                                asm("v_fmac_f32_dpp %0, %1, %2 quad_perm:[2,2,2,2] row_mask:0xf bank_mask:0xf" : "+v"(ev[l]) : "v"(wv.g[t0 / 4]), "v"(x0));
-                                asm("v_fmac_f32_dpp %0, %1, %2 quad_perm:[3,3,3,3] row_mask:0xf bank_mask:0xf" : "+v"(od[l]) : "v"(wv.g[t0 / 4]), "v"(x1));
-                            }
-                        }
-#pragma unroll
-                    for (int l = 0; l < GL; ++l) sl[l] = l < NOCT ? ev[l < NOCT ? l : 0] + od[l < NOCT ? l : 0] : 0.0f;
-                };
-                switch (noct) {
-                    case 1: octets(std::integral_constant<int, 1>{}); break;
-                    case 2: octets(std::integral_constant<int, GL >= 2 ? 2 : GL>{}); break;
-                    case 3: octets(std::integral_constant<int, GL >= 3 ? 3 : GL>{}); break;
-                    case 4: octets(std::integral_constant<int, GL >= 4 ? 4 : GL>{}); break;
-                    case 5: octets(std::integral_constant<int, GL >= 5 ? 5 : GL>{}); break;
-                    case 6: octets(std::integral_constant<int, GL >= 6 ? 6 : GL>{}); break;
-                    case 7: octets(std::integral_constant<int, GL >= 7 ? 7 : GL>{}); break;
-                    default: octets(std::integral_constant<int, GL>{}); break;
+                    wcur = wn;
                 }
-                float sum = sl[0] + sl[1];                                     // group_sum's order: neighbours, pairs of pairs, the two quads
-                if constexpr (GL >= 4) sum = sum + (sl[2] + sl[3]);
-                if constexpr (GL >= 8) sum = sum + ((sl[4] + sl[5]) + (sl[6] + sl[7]));
-                total = c0 == 0 ? sum : total + sum;                           // fma(total, keep, sum) with keep = 0 / 1
+                xa = na; xc = nc;
+                GLV_SCHED_FENCE();
+            };
+            // whole chunks: after the last octet everything is folded into p0
+            const uint32_t full = steps / (uint32_t) GL, rem = steps % (uint32_t) GL;
+            for (uint32_t c = 0; c < full; ++c) {
+                step(std::integral_constant<int, 0>{});
+                step(std::integral_constant<int, 1>{});
+                if constexpr (GL >= 4) { step(std::integral_constant<int, 2>{}); step(std::integral_constant<int, 3>{}); }
+                if constexpr (GL >= 8) {
+                    step(std::integral_constant<int, 4>{}); step(std::integral_constant<int, 5>{});
+                    step(std::integral_constant<int, 6>{}); step(std::integral_constant<int, 7>{});
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) tot[i] = pk_add(tot[i], p0[i]);
             }
-            stage[(size_t) (wave + kRowsWaves * j) * kRowsStagePitch + lane] = total / wsum;
+            // the last, partial chunk: the octets the bars do not have are +0 and x + 0 == x for x >= +0, so what is parked is added
+            // in the tree's order and nothing else: rem = 1, 2, 4: p0;  3, 5, 6: p0 + p1;  7: p0 + (p1 + p2)
+            if (rem) {
+                for (uint32_t r = 0; r < rem; ++r) {
+                    switch (r) {
+                        case 0: step(std::integral_constant<int, 0>{}); break;
+                        case 1: step(std::integral_constant<int, 1>{}); break;
+                        case 2: step(std::integral_constant<int, GL >= 4 ? 2 : 0>{}); break;
+                        case 3: step(std::integral_constant<int, GL >= 4 ? 3 : 0>{}); break;
+                        case 4: step(std::integral_constant<int, GL >= 8 ? 4 : 0>{}); break;
+                        case 5: step(std::integral_constant<int, GL >= 8 ? 5 : 0>{}); break;
+                        default: step(std::integral_constant<int, GL >= 8 ? 6 : 0>{}); break;
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    glv_f2 sum = p0[i];
+                    if (rem == 7) sum = pk_add(sum, pk_add(p1[i], p2[i]));
+                    else if (rem == 3 || rem == 5 || rem == 6) sum = pk_add(sum, p1[i]);
+                    tot[i] = pk_add(tot[i], sum);
+                }
+            }
+            float totf[8];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { totf[2 * i] = tot[i].x; totf[2 * i + 1] = tot[i].y; }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) stage[(size_t) (8u * wave + (uint32_t) j) * kRowsStagePitch + lane] = totf[j] / wsum[T.k0 + 8u * wave + (uint32_t) j];
         }
+#else
+        if (valid)
+            for (int j = 0; j < 8; ++j) stage[(size_t) (8u * wave + (uint32_t) j) * kRowsStagePitch + lane] = win[(size_t) j * 64 + lane].w[0] + wg[g.w_off];
+#endif
         __syncthreads();
         // the tile's m bars of R rows: every row's m values are one contiguous segment of the output
         const uint32_t m = T.k1 - T.k0;
-        static_assert(kRowsTileBars == 32, "the flush below maps 32 threads to a row's segment");
+#pragma unroll
         for (uint32_t e = threadIdx.x; e < 64u * kRowsTileBars; e += 64 * kRowsWaves) {
-            const uint32_t jr = e >> 5, kk = e & 31u;
+            const uint32_t jr = e >> 6, kk = e & 63u;
+#if defined(GLV_EXP_ROWS_NOFLUSH)       /* timing experiment (wrong results): one store in 64 */
+            if (jr < R && kk < m && kk == 0) {
+#else
             if (jr < R && kk < m) {
+#endif
                 const float v = stage[(size_t) kk * kRowsStagePitch + jr];
                 if (r16) reinterpret_cast<uint16_t*>(bars_out)[(row0 + jr) * bars + T.k0 + kk] = (uint16_t) unorm16(v);
                 else reinterpret_cast<float*>(bars_out)[(row0 + jr) * bars + T.k0 + kk] = v;
@@ -616,7 +650,7 @@ static void launch_bars_gl(const float* spec, float* bars_out, size_t nrows, uin
 }
 template <int S, int GL>
 static hipError_t launch_bars_rows(const float* spec, float* bars_out, size_t nrows, uint32_t n, uint32_t bars, const BarTile* tiles, uint32_t ntiles,
-                                   const BarDesc* desc, const float* tap_wq, hipStream_t st, int r) {
+                                   const BarGroupDesc* groups, const float* wg, const float* wsum, hipStream_t st, int r) {
     const size_t lds = sizeof(float) * ((size_t) 64 * S + (size_t) kRowsTileBars * kRowsStagePitch);
     static std::atomic<bool> done[64] = {};
     if (lds > 64 * 1024) {
@@ -635,25 +669,26 @@ static hipError_t launch_bars_rows(const float* spec, float* bars_out, size_t nr
     const uint32_t tpw = (ntiles + yb - 1) / yb;
     yb = (ntiles + tpw - 1) / tpw;
     hipLaunchKernelGGL((glv_bars_rows_kernel<S, GL>), dim3(xb, yb), dim3(64 * kRowsWaves), lds, st, spec, static_cast<void*>(bars_out), nrows, n, bars, tiles,
-                       ntiles, tpw, desc, tap_wq, r);
+                       ntiles, tpw, groups, wg, wsum, r);
     return hipGetLastError();
 }
 
 hipError_t launch_bars(const float* spec, float* bars_out, size_t nrows, uint32_t n, uint32_t bars, uint32_t nsteps,
-                       const BarItem* items, const BarDesc* desc, const float* tap_w, hipStream_t st, bool r16, const BarTile* tiles, uint32_t ntiles,
-                       uint32_t tile_bins, const float* tap_wq) {
+                       const BarItem* items, const BarDesc* desc, const float* tap_w, hipStream_t st, bool r16, const BarRowsTables* rt) {
     const int r = r16 ? 1 : 0;
-    // many bars of many rows (the pre-smoothing pass): one lane per row, weights as scalars (glv_bars_rows_kernel), when the host
-    // could cut the bars into tiles that fit an LDS window of tile_bins bins (glv_tables.h make_bar_tiles)
-    if (tiles != nullptr && tap_wq != nullptr && ntiles != 0 && bars >= 256 && nrows >= 256) {
+    // many bars of many rows (the pre-smoothing pass): one lane per row, eight bars per wave, weights as scalars (glv_bars_rows_kernel),
+    // when the host could cut the bars into tiles that fit an LDS window of rt->tile_bins bins (glv_tables.h make_bar_groups)
+    if (rt != nullptr && rt->tiles != nullptr && rt->ntiles != 0 && bars >= 256 && nrows >= 256) {
+#define GLV_ROWS(SS, GG) launch_bars_rows<SS, GG>(spec, bars_out, nrows, n, bars, rt->tiles, rt->ntiles, rt->groups, rt->wg, rt->wsum, st, r)
         switch (bar_lanes_of(n)) {
-            case 2: if (tile_bins == 128) return launch_bars_rows<128, 2>(spec, bars_out, nrows, n, bars, tiles, ntiles, desc, tap_wq, st, r); break;
-            case 4: if (tile_bins == 128) return launch_bars_rows<128, 4>(spec, bars_out, nrows, n, bars, tiles, ntiles, desc, tap_wq, st, r); break;
+            case 2: if (rt->tile_bins == 128) return GLV_ROWS(128, 2); break;
+            case 4: if (rt->tile_bins == 128) return GLV_ROWS(128, 4); break;
             default:
-                if (tile_bins == 128) return launch_bars_rows<128, 8>(spec, bars_out, nrows, n, bars, tiles, ntiles, desc, tap_wq, st, r);
-                if (tile_bins == 256) return launch_bars_rows<256, 8>(spec, bars_out, nrows, n, bars, tiles, ntiles, desc, tap_wq, st, r);
+                if (rt->tile_bins == 128) return GLV_ROWS(128, 8);
+                if (rt->tile_bins == 240) return GLV_ROWS(240, 8);
                 break;
         }
+#undef GLV_ROWS
     }
     switch (bar_lanes_of(n)) {                                   // the work lists were made for 256 / bar_lanes_of(n) groups
         case 2: launch_bars_gl<2>(spec, bars_out, nrows, n, bars, nsteps, items, desc, tap_w, st, r); break;

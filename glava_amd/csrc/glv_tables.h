@@ -110,19 +110,26 @@ inline size_t make_smooth_bounds(int* smin, int* smax, size_t sz, float smooth_d
 //   smin/smax = scale_audio(clamp(idx -/+ factor)) * n,  scale_audio(u) = -log(1 - 0.9u)/8
 //   m = (smax - smin)/2, rm = smin + m;  for s = smin; s <= smax; s += 1:  w = sinusoidal(clamp((m - |rm - s|)/m))
 //   sample bin int(round(s)).  Consecutive s round to consecutive bins, so a bar is a contiguous bin range.
+// Group rule (round 4): with bars >= kBarGroupMin (the pre-smoothing pass and other many-bar uses) the bars come in GROUPS of
+// kBarGroup = 8 consecutive bars that all start at the group's bin A = (smallest first bin of the group) & ~7: a bar whose own first
+// tap is d bins further right gets d leading taps of weight +0 (count and the chunk structure include them; weight_sum does not
+// change -- it is the tap-order sum and 0 + w == w).  Every value is what smooth_audio() defines, the SUMMATION is regrouped:
+// the eight bars of a group walk the same bins in the same octets, which is what lets one lane of glv_bars_rows_kernel load an octet
+// of texels once for eight bars (glv_misc.hip); the test suite's CPU restatement applies the same rule.
+constexpr uint32_t kBarGroup = 8, kBarGroupMin = 256;
 inline void make_bar_taps(std::vector<BarDesc>& desc, std::vector<float>& tap_w, uint32_t n, uint32_t bars, float smooth_factor, float phase = 0.0f) {
     const uint32_t chunk = bar_chunk_of(n);
     auto scale = [](float u) { return -logf((-0.9f * u) + 1.0f) / 8.0f; };
     auto clamp01 = [](float x) { return x < 0.0f ? 0.0f : (x > 1.0f ? 1.0f : x); };
     desc.resize(bars);
     tap_w.clear();
+    std::vector<std::vector<float>> w_of(bars);
     for (uint32_t k = 0; k < bars; ++k) {
         const float idx = phase == 0.0f ? (float) k / (float) bars : ((float) k + phase) / (float) bars;   // gl_FragCoord.x / w
         const float smin = scale(clamp01(idx - smooth_factor)) * (float) n;
         const float smax = scale(clamp01(idx + smooth_factor)) * (float) n;
         const float m = (smax - smin) / 2.0f, rm = smin + m;
         BarDesc d{};
-        d.tap_offset = (uint32_t) tap_w.size();
         float weight = 0.0f;
         bool first = true;
         uint32_t prev_bin = 0;
@@ -131,17 +138,35 @@ inline void make_bar_taps(std::vector<BarDesc>& desc, std::vector<float>& tap_w,
             const uint32_t bin = (uint32_t) (int) roundf(sx);
             if (first) { d.first_bin = bin; first = false; }
             else if (bin != prev_bin + 1) {          // (never for step 1.0; keep the range contiguous regardless)
-                for (uint32_t g = prev_bin + 1; g < bin; ++g) tap_w.push_back(0.0f);
+                for (uint32_t g = prev_bin + 1; g < bin; ++g) w_of[k].push_back(0.0f);
             }
             prev_bin = bin;
             weight += w;
-            tap_w.push_back(w);
+            w_of[k].push_back(w);
         }
-        d.count = (uint32_t) tap_w.size() - d.tap_offset;
         d.weight_sum = weight;
+        desc[k] = d;
+    }
+    for (uint32_t k = 0; k < bars; ++k) {
+        BarDesc& d = desc[k];
+        uint32_t lead = 0;
+        if (bars >= kBarGroupMin) {
+            const uint32_t g0 = k / kBarGroup * kBarGroup, g1 = g0 + kBarGroup < bars ? g0 + kBarGroup : bars;
+            uint32_t a = 0xffffffffu;
+            for (uint32_t j = g0; j < g1; ++j) {        // bars before k already carry the group's start, which is <= their own first bin
+                const uint32_t fb = desc[j].first_bin;
+                a = fb < a ? fb : a;
+            }
+            a &= ~7u;
+            lead = d.first_bin - a;
+            d.first_bin = a;
+        }
+        d.tap_offset = (uint32_t) tap_w.size();
+        tap_w.insert(tap_w.end(), lead, 0.0f);
+        tap_w.insert(tap_w.end(), w_of[k].begin(), w_of[k].end());
+        d.count = (uint32_t) tap_w.size() - d.tap_offset;
         // zero-pad to whole chunks: the kernels load a chunk's weights unconditionally
         while ((tap_w.size() - d.tap_offset) % chunk) tap_w.push_back(0.0f);
-        desc[k] = d;
     }
 }
 
@@ -180,41 +205,57 @@ inline uint32_t make_bar_items(std::vector<BarItem>& items, const std::vector<Ba
     return nsteps;
 }
 
-// Tiles for glv_bars_rows_kernel: consecutive bars (at most max_bars) whose taps, rounded up to whole octets, fit a window of
-// `bins` bins that starts on a multiple of 4.  Needs monotone first bins (smooth_audio()'s are) and every bar to fit alone;
-// returns false otherwise (the kernel is then not used).
-inline bool make_bar_tiles(std::vector<BarTile>& tiles, const std::vector<BarDesc>& desc, uint32_t n, uint32_t bins, uint32_t max_bars) {
-    tiles.clear();
-    uint32_t k = 0;
-    const uint32_t nb = (uint32_t) desc.size();
-    auto oct_end = [&](uint32_t i) { return desc[i].first_bin + ((desc[i].count + 7u) & ~7u); };
-    while (k < nb) {
-        BarTile t{k, k, desc[k].first_bin & ~3u, 0};
-        uint32_t end = 0;
-        while (t.k1 < nb && t.k1 - t.k0 < max_bars) {
-            const BarDesc& d = desc[t.k1];
-            if (d.first_bin < t.origin || (t.k1 > t.k0 && d.first_bin < desc[t.k1 - 1].first_bin)) return false;     // not monotone
-            const uint32_t e = (oct_end(t.k1) + 3u) & ~3u;
-            if (e > n) return false;
-            if (e - t.origin > bins) break;
-            end = e > end ? e : end;
-            ++t.k1;
+// Tables of glv_bars_rows_kernel (bars >= kBarGroupMin: every group of kBarGroup bars starts at one bin, make_bar_taps).
+//   groups[G]: the group's first bin (a multiple of 8), the octet steps that cover its longest bar, where its weights start in wg
+//   wg:        per group and step 64 floats -- [bar of the group 0..7][tap 8 s .. 8 s + 7] -- +0 past a bar's end / for bars past the
+//              last one; the kernel streams them through the scalar cache one half step (4 bars) ahead, so 64 floats of slack follow
+//   wsum:      weight_sum per bar, padded with 1.0 to whole groups
+//   tiles:     consecutive groups (at most max_bars / 8) whose bins [origin, end) fit a window of `bins` bins
+// false when a group does not fit the window alone or the groups' first bins are not monotone (the kernel is then not used).
+inline bool make_bar_groups(std::vector<BarGroupDesc>& groups, std::vector<float>& wg, std::vector<float>& wsum, std::vector<BarTile>& tiles,
+                            const std::vector<BarDesc>& desc, const std::vector<float>& tap_w, uint32_t n, uint32_t bins, uint32_t max_bars) {
+    groups.clear(); wg.clear(); wsum.clear(); tiles.clear();
+    const uint32_t bars = (uint32_t) desc.size();
+    if (bars < kBarGroupMin || max_bars % kBarGroup) return false;
+    const uint32_t ng = (bars + kBarGroup - 1) / kBarGroup;
+    for (uint32_t G = 0; G < ng; ++G) {
+        const uint32_t k0 = G * kBarGroup, k1 = k0 + kBarGroup < bars ? k0 + kBarGroup : bars;
+        BarGroupDesc g{desc[k0].first_bin, 0u, (uint32_t) wg.size(), k1 - k0};
+        if (g.first_bin % 8u) return false;
+        for (uint32_t k = k0; k < k1; ++k) {
+            if (desc[k].first_bin != g.first_bin) return false;                 // not the grouped tables
+            const uint32_t st = (desc[k].count + 7u) / 8u;
+            g.steps = st > g.steps ? st : g.steps;
         }
-        if (t.k1 == t.k0) return false;                                          // a single bar does not fit the window
-        t.end = end;
+        if (g.first_bin + 8u * g.steps > n) return false;
+        if (G && g.first_bin < groups[G - 1].first_bin) return false;           // not monotone
+        for (uint32_t s = 0; s < g.steps; ++s)
+            for (uint32_t j = 0; j < kBarGroup; ++j)
+                for (uint32_t t = 0; t < 8u; ++t) {
+                    const uint32_t k = k0 + j, p = 8u * s + t;
+                    wg.push_back(k < k1 && p < desc[k].count ? tap_w[desc[k].tap_offset + p] : 0.0f);
+                }
+        for (uint32_t j = 0; j < kBarGroup; ++j) wsum.push_back(k0 + j < k1 ? desc[k0 + j].weight_sum : 1.0f);
+        groups.push_back(g);
+    }
+    wg.insert(wg.end(), 64, 0.0f);
+    uint32_t G = 0;
+    while (G < ng) {
+        BarTile t{G * kBarGroup, G * kBarGroup, groups[G].first_bin, 0u};
+        uint32_t H = G;
+        while (H < ng && (H - G) * kBarGroup < max_bars) {
+            const uint32_t e = groups[H].first_bin + 8u * groups[H].steps;
+            const uint32_t end = e > t.end ? e : t.end;
+            if (end - t.origin > bins) break;
+            t.end = end;
+            ++H;
+        }
+        if (H == G) return false;                                                // a single group does not fit the window
+        t.k1 = H * kBarGroup < bars ? H * kBarGroup : bars;
         tiles.push_back(t);
-        k = t.k1;
+        G = H;
     }
     return true;
-}
-
-// The weights regrouped for glv_bars_rows_kernel: every chunk of `chunk` taps as [q][g] = w[4 g + q], q = 0..3 (the lane of a quad
-// that holds the weight), g = 0 .. chunk / 4 - 1 (the register).  tap_w is a whole number of chunks long.
-inline void make_bar_quad_weights(std::vector<float>& wq, const std::vector<float>& tap_w, uint32_t chunk) {
-    wq.assign(tap_w.size(), 0.0f);
-    for (size_t c = 0; c + chunk <= tap_w.size(); c += chunk)
-        for (uint32_t q = 0; q < 4; ++q)
-            for (uint32_t g = 0; g < chunk / 4; ++g) wq[c + q * (chunk / 4) + g] = tap_w[c + 4 * g + q];
 }
 
 // log_mode 0 table (glv_core.h log_third_table): c_j = 1 + j / 2^bits, { 2^-23 / c_j, log(c_j)/3 }.

@@ -311,40 +311,91 @@ unsigned long long glvemu_div_frames_check(unsigned F, unsigned lo_bits, unsigne
 }
 
 extern "C" {
-// glv_tables.h make_bar_tiles / make_bar_quad_weights (the host tables of glv_bars_rows_kernel): 0 when the tiles cover every bar
-// exactly once in order, hold at most max_bars bars, start on a multiple of 4 bins, span at most `bins` bins, contain every tap
-// of their bars rounded up to whole octets, and the regrouped weights are a permutation of the plain ones chunk by chunk.
-// -1: the bars cannot be tiled for this window (the kernel is then not used).
+// glv_tables.h make_bar_taps (group rule) / make_bar_groups (the host tables of glv_bars_rows_kernel): 0 when every group of eight
+// bars starts at one multiple of 8, the tiles cover every bar exactly once in order in whole groups, hold at most max_bars bars, span
+// at most `bins` bins and contain every octet step of their groups, and the weight stream holds exactly the bars' weights (+0 past
+// a bar's end).  -1: the groups cannot be tiled for this window (the kernel is then not used).
 int glvemu_bar_tiles_check(int n, int bars, float smooth_factor, float phase, int bins, int max_bars, unsigned* ntiles_out, unsigned* max_count_out) {
     using namespace glv;
     std::vector<BarDesc> desc;
     std::vector<float> w;
     make_bar_taps(desc, w, (uint32_t) n, (uint32_t) bars, smooth_factor, phase);
-    const uint32_t chunk = bar_chunk_of((uint32_t) n);
-    w.resize(w.size() + chunk, 0.0f);
     uint32_t mc = 0;
     for (const BarDesc& d : desc) mc = d.count > mc ? d.count : mc;
     if (max_count_out) *max_count_out = mc;
     std::vector<BarTile> tiles;
-    if (!make_bar_tiles(tiles, desc, (uint32_t) n, (uint32_t) bins, (uint32_t) max_bars)) return -1;
+    std::vector<BarGroupDesc> groups;
+    std::vector<float> wg, wsum;
+    if (!make_bar_groups(groups, wg, wsum, tiles, desc, w, (uint32_t) n, (uint32_t) bins, (uint32_t) max_bars)) return -1;
     if (ntiles_out) *ntiles_out = (unsigned) tiles.size();
+    if (groups.size() != ((size_t) bars + 7) / 8 || wsum.size() != groups.size() * 8) return 7;
     uint32_t next = 0;
     for (const BarTile& t : tiles) {
-        if (t.k0 != next || t.k1 <= t.k0 || t.k1 - t.k0 > (uint32_t) max_bars) return 1;
-        if ((t.origin & 3u) || (t.end & 3u) || t.end <= t.origin || t.end - t.origin > (uint32_t) bins || t.end > (uint32_t) n) return 2;
+        if (t.k0 != next || t.k1 <= t.k0 || t.k1 - t.k0 > (uint32_t) max_bars || t.k0 % 8u) return 1;
+        if ((t.origin & 7u) || (t.end & 7u) || t.end <= t.origin || t.end - t.origin > (uint32_t) bins || t.end > (uint32_t) n) return 2;
         for (uint32_t k = t.k0; k < t.k1; ++k) {
-            const uint32_t e = desc[k].first_bin + ((desc[k].count + 7u) & ~7u);
-            if (desc[k].first_bin < t.origin || e > t.end) return 3;
+            const BarGroupDesc& g = groups[k / 8];
+            if (desc[k].first_bin != g.first_bin || (desc[k].count + 7u) / 8u > g.steps) return 3;
+            if (g.first_bin < t.origin || g.first_bin + 8u * g.steps > t.end) return 3;
+            for (uint32_t p = 0; p < 8u * g.steps; ++p) {
+                const float want = p < desc[k].count ? w[desc[k].tap_offset + p] : 0.0f;
+                if (__builtin_bit_cast(uint32_t, wg[g.w_off + (p / 8u) * 64u + (k % 8u) * 8u + p % 8u]) != __builtin_bit_cast(uint32_t, want)) return 6;
+            }
+            if (wsum[k] != desc[k].weight_sum) return 5;
         }
         next = t.k1;
     }
     if (next != (uint32_t) bars) return 4;
-    std::vector<float> wq;
-    make_bar_quad_weights(wq, w, chunk);
-    if (wq.size() != w.size() || w.size() % chunk) return 5;
-    for (size_t c = 0; c < w.size(); c += chunk)
-        for (uint32_t t = 0; t < chunk; ++t)
-            if (wq[c + (t & 3u) * (chunk / 4) + t / 4] != w[c + t]) return 6;
+    return 0;
+}
+
+// glv_bars_rows_kernel's arithmetic on the host, off the same tables: per group the octet steps in order, eight bars side by side,
+// {even, odd} chains as a product and three fused multiply-adds each, the octet sum, the three-deep stack of partial sums per chunk
+// of GL octets (glv_misc.hip), one division.  out: bars floats.  Returns 0, or -1 when the tables cannot be made.
+int glvemu_bars_rows(const float* tex, int n, int bars, float smooth_factor, float phase, int bins, float* out) {
+    using namespace glv;
+    std::vector<BarDesc> desc;
+    std::vector<float> w;
+    make_bar_taps(desc, w, (uint32_t) n, (uint32_t) bars, smooth_factor, phase);
+    std::vector<BarTile> tiles;
+    std::vector<BarGroupDesc> groups;
+    std::vector<float> wg, wsum;
+    if (!make_bar_groups(groups, wg, wsum, tiles, desc, w, (uint32_t) n, (uint32_t) bins, 64u)) return -1;
+    const int GL = bar_lanes_of((uint32_t) n);
+    auto clamp01 = [](float v) { return v > 0.0f ? (v < 1.0f ? v : 1.0f) : 0.0f; };      // NaN -> 0
+    for (const BarTile& t : tiles)
+        for (uint32_t G = t.k0 / 8; 8 * G < t.k1; ++G) {
+            const BarGroupDesc& g = groups[G];
+            float tot[8] = {}, p0[8] = {}, p1[8] = {}, p2[8] = {};
+            uint32_t s = 0;
+            while (s < g.steps) {
+                for (int L = 0; L < GL && s < g.steps; ++L, ++s) {
+                    float x[8];
+                    for (int i = 0; i < 8; ++i) x[i] = clamp01(tex[g.first_bin + 8u * s + (uint32_t) i]);
+                    for (int j = 0; j < 8; ++j) {
+                        const float* ww = &wg[g.w_off + s * 64u + (uint32_t) j * 8u];
+                        float e = x[0] * ww[0], o = x[1] * ww[1];
+                        for (int i = 2; i < 8; i += 2) { e = fmaf(x[i], ww[i], e); o = fmaf(x[i + 1], ww[i + 1], o); }
+                        const float oc = e + o;
+                        if (L == 0) p0[j] = oc;
+                        else if (L == 1) p0[j] = p0[j] + oc;
+                        else if (L == 2 || L == 4) p1[j] = oc;
+                        else if (L == 5) p1[j] = p1[j] + oc;
+                        else if (L == 3) { p0[j] = p0[j] + (p1[j] + oc); p1[j] = 0.0f; }
+                        else if (L == 6) p2[j] = oc;
+                        else { p0[j] = p0[j] + (p1[j] + (p2[j] + oc)); p1[j] = 0.0f; p2[j] = 0.0f; }
+                    }
+                }
+                for (int j = 0; j < 8; ++j) {
+                    float sum = p0[j];
+                    if (GL >= 8) sum = sum + (p1[j] + p2[j]);
+                    else if (GL >= 4) sum = sum + p1[j];
+                    tot[j] = tot[j] + sum;
+                    p1[j] = p2[j] = 0.0f;
+                }
+            }
+            for (uint32_t j = 0; j < g.nbars; ++j) out[8 * G + j] = tot[j] / wsum[8 * G + j];
+        }
     return 0;
 }
 }

@@ -304,19 +304,47 @@ def test_fused_tilt_formula_is_within_its_bound(n):
         assert worst <= 4.5e-7, (n, scale, cutoff, worst)
 
 
-@pytest.mark.parametrize("n,bins", [(1024, 128), (2048, 128), (4096, 128), (4096, 256), (8192, 256)])
-def test_tile_and_quad_weight_tables_of_the_many_rows_bars_kernel(emu, n, bins):
-    """glv_bars_rows_kernel (the pre-smoothing pass at scale: bars == n, one lane per row) runs off two host tables: tiles of at
-    most 32 consecutive bars whose taps fit an LDS window of `bins` bins, and the weights regrouped per quad lane.  Invariants of
-    both, and which sizes can be tiled at all: n <= 2048 with 128 bins, n = 4096 only with 256 (its longest bar has 191 taps),
+@pytest.mark.parametrize("n,bins", [(256, 128), (1024, 128), (2048, 128), (4096, 128), (4096, 240), (8192, 240)])
+def test_group_tables_of_the_many_rows_bars_kernel(emu, n, bins):
+    """glv_bars_rows_kernel (the pre-smoothing pass at scale: bars == n, one lane per row, eight bars per wave) runs off host tables:
+    the bars in groups of eight that start at one bin (make_bar_taps' group rule: leading +0 taps), per group a stream of 64 weights
+    per octet step, tiles of at most 64 consecutive bars whose steps fit an LDS window of `bins` bins.  Invariants of all of them,
+    and which sizes can be tiled at all: n <= 2048 with 128 bins, n = 4096 only with 240 (its longest bar has 191 taps + the lead),
     n >= 8192 not (the library then keeps glv_bars_kernel)."""
     import ctypes as C
     nt, mc = C.c_uint(0), C.c_uint(0)
-    rc = emu.glvemu_bar_tiles_check(n, n, C.c_float(0.025), C.c_float(0.5), bins, 32, C.byref(nt), C.byref(mc))
-    fits = ((mc.value + 7) & ~7) + 3 <= bins
+    rc = emu.glvemu_bar_tiles_check(n, n, C.c_float(0.025), C.c_float(0.5), bins, 64, C.byref(nt), C.byref(mc))
     if n >= 8192 or (n == 4096 and bins == 128):
-        assert rc == -1 and not fits, (rc, mc.value)
+        assert rc == -1 and ((mc.value + 7) & ~7) > bins, (rc, mc.value)
     else:
-        assert rc == 0 and fits and nt.value >= n // 32, (rc, nt.value, mc.value)
-    # the modules' 80 bars tile too (the kernel is only used from 256 bars up, but the table logic is size-agnostic)
-    assert emu.glvemu_bar_tiles_check(4096, 80, C.c_float(0.025), C.c_float(0.0), 256, 32, C.byref(nt), C.byref(mc)) == 0
+        assert rc == 0 and ((mc.value + 7) & ~7) <= bins and nt.value >= n // 64, (rc, nt.value, mc.value)
+    # fewer bars than a power of two, a last group that is not full, wide gaps between the bars
+    assert emu.glvemu_bar_tiles_check(4096, 1001, C.c_float(0.025), C.c_float(0.0), 240, 64, C.byref(nt), C.byref(mc)) == 0
+    assert emu.glvemu_bar_tiles_check(1024, 259, C.c_float(0.025), C.c_float(0.5), 128, 64, C.byref(nt), C.byref(mc)) == 0
+    assert emu.glvemu_bar_tiles_check(4096, 259, C.c_float(0.025), C.c_float(0.5), 240, 64, C.byref(nt), C.byref(mc)) == -1      # 191 taps + a spread of 35 bins
+    # below 256 bars there are no groups (the modules' 80 bars keep their own first bins)
+    assert emu.glvemu_bar_tiles_check(4096, 80, C.c_float(0.025), C.c_float(0.0), 240, 64, C.byref(nt), C.byref(mc)) == -1
+
+
+@pytest.mark.parametrize("n,bars,bins,phase", [(256, 256, 128, 0.5), (512, 512, 128, 0.5), (1024, 1024, 128, 0.5), (2048, 2048, 128, 0.5), (4096, 4096, 240, 0.5),
+                                               (4096, 1001, 240, 0.0), (1024, 259, 128, 0.5)])
+def test_rows_kernel_arithmetic_is_the_documented_one(emu, oracle, n, bars, bins, phase):
+    """The lane-per-row kernel walks a group's octets with a three-deep stack of partial sums and eight bars side by side
+    (glvemu_bars_rows restates it off the same host tables); the oracle sums every bar on its own in the documented order
+    (glvo_bars_chunked_at: chunks, octets, two chains, pairwise, chunk totals in order, with the group rule's leading +0 taps).
+    Bit for bit the same -- for noise, for texels outside [0, 1] and NaN (clamped), for an all-zero and an all-one row."""
+    import ctypes as C
+    rng = np.random.default_rng(n + bars)
+    rows = [rng.random(n, dtype=np.float32), (rng.standard_normal(n) * 2).astype(np.float32), np.zeros(n, np.float32), np.ones(n, np.float32)]
+    rows += [(rng.random(n, dtype=np.float32) ** 2 * np.float32(1.3) - np.float32(0.05)).astype(np.float32) for _ in range(24)]
+    rows[1][::7] = np.nan
+    rows[1][3::11] = np.inf
+    fp = C.POINTER(C.c_float)
+    emu.glvemu_bars_rows.argtypes = [fp, C.c_int, C.c_int, C.c_float, C.c_float, C.c_int, fp]
+    emu.glvemu_bars_rows.restype = C.c_int
+    for tex in rows:
+        got = np.full(bars, -1, np.float32)
+        assert emu.glvemu_bars_rows(tex.ctypes.data_as(fp), n, bars, 0.025, phase, bins, got.ctypes.data_as(fp)) == 0
+        want = np.zeros(bars, np.float32)
+        oracle.lib().glvo_bars_chunked_at(np.ascontiguousarray(tex), n, want, bars, 0.025, phase)
+        assert (got.view(np.uint32) == want.view(np.uint32)).all(), (n, bars, int((got.view(np.uint32) != want.view(np.uint32)).sum()))

@@ -226,7 +226,7 @@ def test_many_bars_of_many_rows_kernel_gives_the_documented_bits(glvlib, n, stre
     for r0 in (0, rows - 16):
         small.bars(d_spec[r0:r0 + 16].contiguous(), d_small)
         assert _eq(d_small, d_big[r0:r0 + 16].contiguous()), r0
-    for r in (0, 3, 5, 6, rows - 1):
+    for r in range(rows):                   # every row (round 4: n = 4096, bar 2848 has a skipped bin -- one ulp apart on one row in seven)
         want = np.empty(n, np.float32)
         Oracle.lib().glvo_bars_chunked_at(np.ascontiguousarray(spec[r]), n, want, n, 0.025, 0.5)
         assert (got[r].view(np.uint32) == want.view(np.uint32)).all(), r

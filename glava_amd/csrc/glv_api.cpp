@@ -522,7 +522,7 @@ int ensure_bar_tables(glv_batch* b) {
         std::vector<glv::BarTile> tiles;
         std::vector<glv::BarGroupDesc> groups;
         std::vector<float> wg, wsum;
-        for (uint32_t bins : {128u, 240u}) {
+        for (uint32_t bins : {160u, 240u}) {
             if (bins == 240u && glv::bar_lanes_of(b->p.n) != 8) break;             // (built for the 64-tap chunks only)
             if (glv::make_bar_groups(groups, wg, wsum, tiles, desc, w, b->p.n, bins, 64u)) {      // 64 = glv_misc.hip kRowsTileBars
                 HIP_TRY(hipMalloc(&b->d_bar_tiles, sizeof(glv::BarTile) * tiles.size()));

@@ -41,7 +41,7 @@ struct alignas(16) BarItem { uint32_t w_byte, tex_byte, res; float keep; };
 // taps, rounded up to whole octets, lie in the bins [origin, end) of the row, origin and end multiples of 8, end - origin <= the
 // kernel's LDS window.  One group: its first bin, its octet steps, where its 64 weights per step start (glv_tables.h make_bar_groups).
 struct alignas(16) BarTile { uint32_t k0, k1, origin, end; };
-struct alignas(16) BarGroupDesc { uint32_t first_bin, steps, w_off, nbars; };
+struct alignas(16) BarGroupDesc { uint32_t first_bin, steps, w_off, slot0; };      // slot0: (first_bin / 4) mod (window bins / 4), the group's first slot of the LDS ring
 
 struct FrameArgs {
     const void* in;        // s16: int16 [units/2][n][2] (a unit is one channel row of a frame);  f32 planar: float [units][n];

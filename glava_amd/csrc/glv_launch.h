@@ -42,7 +42,7 @@ hipError_t launch_window_split(const double* w_tab, float* split, uint32_t n, in
 hipError_t launch_window_split_check(const double* w_tab, const float* split, uint32_t n, unsigned long long* d_mismatches, hipStream_t st);
 // rt: the tables of the many-bars x many-rows kernel (glv_tables.h make_bar_groups; nullptr: not considered)
 struct BarRowsTables {
-    const BarTile* tiles; uint32_t ntiles, tile_bins;     // tile_bins: the LDS window the tiles were cut for (128 or 240 bins)
+    const BarTile* tiles; uint32_t ntiles, tile_bins;     // tile_bins: the LDS ring the rounds were cut for (160 or 240 bins)
     const BarGroupDesc* groups; const float* wg; const float* wsum;
 };
 hipError_t launch_bars(const float* spec, float* bars_out, size_t nrows, uint32_t n, uint32_t bars, uint32_t nsteps,

@@ -7,6 +7,7 @@
 #include <hip/hip_runtime.h>
 
 #include <atomic>
+#include <cstdlib>
 #include <type_traits>
 
 #include "glv_frame.h"
@@ -377,22 +378,31 @@ __global__ void __launch_bounds__(256) glv_bars_short_kernel(const float* __rest
 //     an SGPR-pair operand -- 4 packed instructions per octet and bar, + 1 add for the octet sum, + the tree.
 //     (Round 4's first version took one bar per wave, one v_fmac_f32_dpp and half a ds_read2st64_b32 per tap and row: LDS-bandwidth
 //     bound at 1.33 ms for 32 K rows of N = 4096 -- profiles/r04/rows_parts.txt: 1.18 ms of it with no HBM traffic at all.)
-// A workgroup is eight waves on the SAME 64 rows: the rows' texels live in LDS as a window [bin / 4][row][4] (conflict-free b128
-// accesses both ways: the fill's global loads deliver exactly one such slot) that serves one TILE -- up to eight groups whose taps fit
-// the window (host table, glv_tables.h make_bar_groups) --, wave w takes group w, results are parked in LDS and the tile leaves as
-// contiguous row segments of 64 values.  Two workgroups per CU = four waves per SIMD cover the scalar and LDS latencies.
+// A workgroup is eight waves on the SAME 64 rows.  The rows' texels live in LDS as a RING of S bins, [bin / 4 mod S / 4][row][4]
+// (conflict-free b128 accesses both ways: the fill's global loads deliver exactly one such slot).  The bars' first bins grow slowly
+// (4096 bars cover 1250 bins), so a ROUND -- eight groups, wave w takes group w (host table, glv_tables.h make_bar_groups) -- needs
+// only a few bins the previous round did not have: they are requested before the round's arithmetic and written behind it, into
+// slots no wave of the round reads (the table guarantees end(t + 1) - origin(t) <= S).  Every texel is read from HBM / L2 once per
+// range of rounds.  The round's 64 results per row are parked in LDS and leave as contiguous row segments (measured: storing a
+// group's eight results per row straight from the registers -- 64 lines per store instruction, rows a power of two apart -- costs
+// 0.79 instead of 0.61 ms at N = 4096).  Two workgroups per CU = four waves per SIMD cover the scalar and LDS latencies (an s_load
+// result needs lgkmcnt(0): the prefetch distance is half a step, the rest is the other waves).  What bounds the kernel is that
+// scalar stream: 256 B per octet step and wave, 0.56 GB per launch at N = 4096 x 32 K rows, ~1 TB/s through the scalar caches
+// (profiles/r04/rows_kernel.txt: the vector ALU is busy 40 % of the time, waves wait on lgkmcnt).
 // The summation order is the documented one (glv_frame.h "GLV_OP_BARS arithmetic": chunks of 16 / 32 / 64 taps, per chunk 2 / 4 / 8
 // octet sums, each the sum of two fused-multiply-add chains, combined pairwise, chunk totals in order), walked octet by octet with a
-// three-deep stack of partial sums: the same bits as glv_bars_kernel and the fused epilogue.
-constexpr int kRowsWaves = 8, kRowsTileBars = 64, kRowsStagePitch = 65;     // N = 4096: 2 x (60 KiB window + 16.3 KiB stage) fit a CU's 160 KiB
+// three-deep stack of partial sums: the same bits as glv_bars_kernel and the fused epilogue.  The final division by the bar's weight
+// sum is three instructions with the host's reciprocal (glv_tables.h bar_rcp_division_ok: the correctly rounded quotient).
+constexpr int kRowsWaves = 8, kRowsTileBars = 64, kRowsStagePitch = 65;     // N = 4096: 2 x (60 KiB ring + 16.3 KiB stage) fit a CU's 160 KiB
 template <int S, int GL>
 __global__ void __launch_bounds__(64 * kRowsWaves) glv_bars_rows_kernel(const float* __restrict__ spec, void* __restrict__ bars_out, size_t nrows, uint32_t n,
                                                                         uint32_t bars, const BarTile* __restrict__ tiles, uint32_t ntiles, uint32_t tiles_per_wg,
                                                                         const BarGroupDesc* __restrict__ groups, const float* __restrict__ wg,
                                                                         const float* __restrict__ wsum, int r16) {
 #if defined(__HIP_DEVICE_COMPILE__)                     /* packed-f32 inline assembly: the host pass sees an empty stub */
-    extern __shared__ float rows_lds[];                 // [S / 4][64] x 4 texels: the window | [64][65] finished outputs of the tile
-    static_assert(S % 8 == 0 && kRowsTileBars == 8 * kRowsWaves, "a wave per group of eight bars");
+    extern __shared__ float rows_lds[];                 // [S / 4][64] x 4 texels: the ring | [64][65] finished outputs of the round
+    constexpr uint32_t NS = S / 4;                      // slots
+    static_assert(S % 8 == 0 && kRowsTileBars == 8 * kRowsWaves, "a wave per group of eight bars; a step's two slots never straddle the ring's end");
     BarW4* win = reinterpret_cast<BarW4*>(rows_lds);
     float* stage = rows_lds + (size_t) S * 64;
     const uint32_t lane = threadIdx.x & 63u;
@@ -403,70 +413,92 @@ __global__ void __launch_bounds__(64 * kRowsWaves) glv_bars_rows_kernel(const fl
     const float* src = spec + (row0 + (lane < R ? lane : R - 1)) * (size_t) n;
     const uint32_t t_begin = blockIdx.y * tiles_per_wg, t_end = t_begin + tiles_per_wg < ntiles ? t_begin + tiles_per_wg : ntiles;
     const glv_f2 ones = {1.0f, 1.0f};
+    BarW4* win_lane = win + lane;
     struct HalfW { glv_f2 w[16]; };                     // a half step: bars 4 h .. 4 h + 3 of the group x 4 tap pairs, 32 SGPRs
-    auto load_half = [&](const float* wp, uint32_t i) {
+    auto load_half = [&](const float* wp) {
         HalfW h;
-        const glv_f2* p = reinterpret_cast<const glv_f2*>(wp + (size_t) i * 32u);
+        const glv_f2* p = reinterpret_cast<const glv_f2*>(wp);
 #pragma unroll
         for (int q = 0; q < 16; ++q) h.w[q] = p[q];
         return h;
     };
+    // 4 bins of this lane's row: one slot of the ring; clamped here, once per texel, instead of once per tap: [0, 1] like the GL_R16
+    // texel the shader samples, NaN -> 0 (v_pk_mul_f32 x, 1.0 clamp -- the operation bar_item_lane_sum applies to every tap: same bits)
+    auto fetch = [&](uint32_t bin) {
+#if defined(GLV_EXP_ROWS_NOFILL)        /* timing experiment (wrong results): no row loads */
+        return BarW4{{(float) bin, 0.5f, 0.25f, (float) lane}};
+#else
+        return ld<BarW4>(src, bin * 4u);
+#endif
+    };
+    auto park = [&](const BarW4& v, uint32_t bin) {
+        glv_f2 lo = {v.w[0], v.w[1]}, hi = {v.w[2], v.w[3]};
+        asm("v_pk_mul_f32 %0, %1, %2 clamp" : "=v"(lo) : "v"(lo), "v"(ones));
+        asm("v_pk_mul_f32 %0, %1, %2 clamp" : "=v"(hi) : "v"(hi), "v"(ones));
+        win_lane[(size_t) ((bin / 4u) % NS) * 64] = BarW4{{lo.x, lo.y, hi.x, hi.y}};
+    };
+    if (t_begin >= t_end) return;
+    // the first round's whole window: four loads of a wave are in flight before the first is parked
+    uint32_t filled_to;
+    {
+        const BarTile T = tiles[t_begin];
+        const uint32_t ncol = (T.end - T.origin) / 4u;
+        for (uint32_t cb = wave * 4u; cb < ncol; cb += kRowsWaves * 4) {
+            BarW4 v4[4];
+#pragma unroll
+            for (uint32_t q = 0; q < 4; ++q) v4[q] = fetch(T.origin + 4u * (cb + q < ncol ? cb + q : cb));
+#pragma unroll
+            for (uint32_t q = 0; q < 4; ++q)
+                if (cb + q < ncol) park(v4[q], T.origin + 4u * (cb + q));
+        }
+        filled_to = T.end;
+    }
+    __syncthreads();
     for (uint32_t t = t_begin; t < t_end; ++t) {
         const BarTile T = tiles[t];                                             // uniform: scalar loads
         const bool valid = T.k0 + 8u * wave < T.k1;
         const BarGroupDesc g = groups[valid ? T.k0 / 8u + wave : T.k0 / 8u];
-        __syncthreads();                                                        // the previous tile has left the window and the stage
-        // 4 bins of every row per load = one window slot; four loads of a wave are issued before the first is parked
-        const uint32_t ncol = (T.end - T.origin) / 4u;
-        for (uint32_t cb = wave; cb < ncol; cb += kRowsWaves * 4) {
-            BarW4 v4[4];
+        // what the next round adds to the ring: requested now, parked behind this round's arithmetic (up to two slots per wave in
+        // registers, which is what a round adds at most in practice; the rest after them)
+        const uint32_t next_end = t + 1 < t_end ? tiles[t + 1].end : filled_to;
+        const uint32_t nnew = next_end > filled_to ? (next_end - filled_to) / 4u : 0u;
+        BarW4 pre[2];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const uint32_t c = cb + (uint32_t) q * kRowsWaves;
-#if defined(GLV_EXP_ROWS_NOFILL)        /* timing experiment (wrong results): no row loads */
-                v4[q] = BarW4{{(float) c, 0.5f, 0.25f, (float) lane}};
+        for (uint32_t q = 0; q < 2; ++q) pre[q] = fetch(filled_to + 4u * (wave + kRowsWaves * q < nnew ? wave + kRowsWaves * q : 0u));
+        // the next round's new slots, none of which this round's groups read.  Parked BEFORE this round's stores are issued: vmcnt
+        // retires in order, so a wait for these loads behind the stores would wait for the stores (which take microseconds)
+        auto park_new = [&]() {
+#pragma unroll
+            for (uint32_t q = 0; q < 2; ++q)
+                if (wave + kRowsWaves * q < nnew) park(pre[q], filled_to + 4u * (wave + kRowsWaves * q));
+            for (uint32_t c = wave + 2u * kRowsWaves; c < nnew; c += kRowsWaves) park(fetch(filled_to + 4u * c), filled_to + 4u * c);
+        };
+#if defined(GLV_EXP_ROWS_NOCOMPUTE)
+        if (valid) park_new();
 #else
-                v4[q] = ld<BarW4>(src, (T.origin + 4u * (c < ncol ? c : cb)) * 4u);
-#endif
-            }
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const uint32_t c = cb + (uint32_t) q * kRowsWaves;
-                if (c < ncol) {                                                     // uniform
-                    // clamped here, once per texel, instead of once per tap: [0, 1] like the GL_R16 texel the shader samples, NaN -> 0
-                    // (v_pk_mul_f32 x, 1.0 clamp -- the operation bar_item_lane_sum applies to every tap: same bits)
-                    glv_f2 lo = {v4[q].w[0], v4[q].w[1]}, hi = {v4[q].w[2], v4[q].w[3]};
-                    asm("v_pk_mul_f32 %0, %1, %2 clamp" : "=v"(lo) : "v"(lo), "v"(ones));
-                    asm("v_pk_mul_f32 %0, %1, %2 clamp" : "=v"(hi) : "v"(hi), "v"(ones));
-                    win[(size_t) c * 64 + lane] = BarW4{{lo.x, lo.y, hi.x, hi.y}};
-                }
-            }
-        }
-        __syncthreads();
-#if !defined(GLV_EXP_ROWS_NOCOMPUTE)
         if (valid) {
             const uint32_t steps = (uint32_t) __builtin_amdgcn_readfirstlane((int) g.steps);
             const float* wp = wg + (uint32_t) __builtin_amdgcn_readfirstlane((int) g.w_off);
-            const BarW4* xb = win + (size_t) ((g.first_bin - T.origin) / 4u) * 64 + lane;      // step s: slots 2 s, 2 s + 1 (one past the last step is read and dropped: the stage follows the window)
+            uint32_t slot = (uint32_t) __builtin_amdgcn_readfirstlane((int) g.slot0);       // even; a step reads slots slot, slot + 1, then moves on two (wrapping)
             // per pair of bars {2 i, 2 i + 1}: the running total and the stack of partial sums of the chunk under way
             glv_f2 tot[4], p0[4], p1[4], p2[4];
 #pragma unroll
             for (int i = 0; i < 4; ++i) tot[i] = p0[i] = p1[i] = p2[i] = glv_f2{0.0f, 0.0f};
-            HalfW wcur = load_half(wp, 0u);
+            HalfW wcur = load_half(wp);
             const float* wnext = wp + 32;                                       // the weight stream, one half step ahead: a running scalar pointer
-            const BarW4* xnext = xb + 128;                                      // the texels, one step ahead
-            BarW4 xa = xb[0], xc = xb[64];
-            auto pk_add = [](glv_f2 a, glv_f2 b2) { glv_f2 r; asm("v_pk_add_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b2)); return r; };
+            BarW4 xa = win_lane[(size_t) slot * 64], xc = win_lane[(size_t) slot * 64 + 64];
+            slot = slot + 2u == NS ? 0u : slot + 2u;
+            auto pk_add = [](glv_f2 a2, glv_f2 b2) { glv_f2 r; asm("v_pk_add_f32 %0, %1, %2" : "=v"(r) : "v"(a2), "v"(b2)); return r; };
             // one octet of texels x eight bars; L = the octet's place in its chunk (compile time: the tree of partial sums --
             // group_sum's order: neighbours, pairs of pairs, the two quads -- built as the octets arrive)
             auto step = [&](auto LC) {
                 constexpr int L = decltype(LC)::value;
-                const BarW4 na = xnext[0], nc = xnext[64];                       // the next step's texels
-                xnext += 128;
+                const BarW4 na = win_lane[(size_t) slot * 64], nc = win_lane[(size_t) slot * 64 + 64];       // the next step's texels (one step past the group's end is read and dropped)
+                slot = slot + 2u == NS ? 0u : slot + 2u;
                 const glv_f2 x01 = {xa.w[0], xa.w[1]}, x23 = {xa.w[2], xa.w[3]}, x45 = {xc.w[0], xc.w[1]}, x67 = {xc.w[2], xc.w[3]};
 #pragma unroll
                 for (int h = 0; h < 2; ++h) {
-                    const HalfW wn = load_half(wnext, 0u);                        // one half step ahead (64 floats of slack follow the table)
+                    const HalfW wn = load_half(wnext);                            // one half step ahead (64 floats of slack follow the table)
                     wnext += 32;
                     // {even chain, odd chain} of the half step's four bars, interleaved (a dependent packed op two slots later costs a wait
                     // state); first link: fma(x, w, +0) == x * w (both >= +0)
@@ -534,32 +566,66 @@ __global__ void __launch_bounds__(64 * kRowsWaves) glv_bars_rows_kernel(const fl
                     tot[i] = pk_add(tot[i], sum);
                 }
             }
-            float totf[8];
+            park_new();
+            // total / weight sum: with the host's reciprocal where that is the correctly rounded quotient (glv_tables.h
+            // bar_rcp_division_ok; not for a total so small that the remainder below would be inexact), else the long way
+            const uint32_t kg = T.k0 + 8u * wave;
+            struct WS { glv_f2 v[8]; };                                         // {weight sum, its reciprocal or 0} of the eight bars: scalar loads
+            const WS ws = *reinterpret_cast<const WS*>(wsum + 2u * kg);
+            float q[8];
+            bool fast = true;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) { totf[2 * i] = tot[i].x; totf[2 * i + 1] = tot[i].y; }
+            for (int j = 0; j < 8; ++j) fast = fast && ws.v[j].y != 0.0f;
+            float tmax = 0.0f;                                                  // is some total in (0, 2^-90)?  (totals are >= +0)
 #pragma unroll
-            for (int j = 0; j < 8; ++j) stage[(size_t) (8u * wave + (uint32_t) j) * kRowsStagePitch + lane] = totf[j] / wsum[T.k0 + 8u * wave + (uint32_t) j];
+            for (int i = 0; i < 4; ++i) {
+                const float a0 = tot[i].x == 0.0f ? 1.0f : tot[i].x, a1 = tot[i].y == 0.0f ? 1.0f : tot[i].y;
+                const float mn = a0 < a1 ? a0 : a1;
+                tmax = i == 0 ? mn : (mn < tmax ? mn : tmax);
+            }
+            fast = fast && !__builtin_amdgcn_readfirstlane((int) (__ballot(tmax < 0x1p-90f) != 0ull));
+            if (fast) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float a = j & 1 ? tot[j / 2].y : tot[j / 2].x, bsum = ws.v[j].x, r = ws.v[j].y;
+                    const float q0 = a * r;
+                    const float rm = __builtin_fmaf(-q0, bsum, a);
+                    q[j] = __builtin_fmaf(rm, r, q0);
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) q[j] = (j & 1 ? tot[j / 2].y : tot[j / 2].x) / ws.v[j].x;
+            }
+            // parked for the round's flush: scattered 16 / 32-byte stores straight from here (one line per lane and instruction) cost more
+            // than the arithmetic -- every later wait for a load then waits for their acknowledgements (vmcnt retires in order)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) stage[(size_t) (8u * wave + (uint32_t) j) * kRowsStagePitch + lane] = q[j];
         }
-#else
-        if (valid)
-            for (int j = 0; j < 8; ++j) stage[(size_t) (8u * wave + (uint32_t) j) * kRowsStagePitch + lane] = win[(size_t) j * 64 + lane].w[0] + wg[g.w_off];
 #endif
+        if (!valid) park_new();
+        filled_to = next_end > filled_to ? next_end : filled_to;
         __syncthreads();
-        // the tile's m bars of R rows: every row's m values are one contiguous segment of the output
-        const uint32_t m = T.k1 - T.k0;
+        // the round's m bars of R rows: every row's m values are one contiguous segment of the output; wave w takes rows w, w + 8, ...
+        {
+            const uint32_t m = T.k1 - T.k0;
+            const float* sp = stage + (size_t) lane * kRowsStagePitch;
+            const size_t at0 = (row0 + wave) * (size_t) bars + T.k0 + lane;
 #pragma unroll
-        for (uint32_t e = threadIdx.x; e < 64u * kRowsTileBars; e += 64 * kRowsWaves) {
-            const uint32_t jr = e >> 6, kk = e & 63u;
+            for (uint32_t i = 0; i < 64u / kRowsWaves; ++i) {
+                const uint32_t jr = wave + kRowsWaves * i;
 #if defined(GLV_EXP_ROWS_NOFLUSH)       /* timing experiment (wrong results): one store in 64 */
-            if (jr < R && kk < m && kk == 0) {
+                if (jr < R && lane < m && lane == 0) {
 #else
-            if (jr < R && kk < m) {
+                if (jr < R && lane < m) {
 #endif
-                const float v = stage[(size_t) kk * kRowsStagePitch + jr];
-                if (r16) reinterpret_cast<uint16_t*>(bars_out)[(row0 + jr) * bars + T.k0 + kk] = (uint16_t) unorm16(v);
-                else reinterpret_cast<float*>(bars_out)[(row0 + jr) * bars + T.k0 + kk] = v;
+                    const float v = sp[jr];
+                    const size_t at = at0 + (size_t) (kRowsWaves * i) * bars;
+                    if (r16) reinterpret_cast<uint16_t*>(bars_out)[at] = (uint16_t) pack_unorm16(v, 0.0f);
+                    else reinterpret_cast<float*>(bars_out)[at] = v;
+                }
             }
         }
+        __syncthreads();                                                        // the stage is free for the next round
     }
 #endif
 }
@@ -662,9 +728,13 @@ static hipError_t launch_bars_rows(const float* spec, float* bars_out, size_t nr
             if (dev >= 0 && dev < 64) done[dev].store(true, std::memory_order_release);
         }
     }
-    // 64 rows per workgroup in x, ranges of tiles in y: enough workgroups to fill the chip a few times over
+    // 64 rows per workgroup in x, ranges of rounds in y: two resident workgroups per CU, twice over (a range start refills the whole
+    // ring; N = 4096: 32 K rows 0.60 / 0.61 / 0.62 ms with 1 / 2 / 4 ranges, 8 K rows 0.48 / 0.19 / 0.18 ms with 1 / 4 / 16)
     const uint32_t xb = (uint32_t) ((nrows + 63) / 64);
-    uint32_t yb = xb >= 2048 ? 1 : (2048 + xb - 1) / xb;
+    uint32_t yb = xb >= 1024 ? 1 : (1024 + xb - 1) / xb;
+#if defined(GLV_TUNE_BUILD)
+    if (const char* o = std::getenv("GLV_ROWS_YB")) yb = (uint32_t) atoi(o);       // tools/rows_bench: the split of the rounds over blockIdx.y
+#endif
     if (yb > ntiles) yb = ntiles;
     const uint32_t tpw = (ntiles + yb - 1) / yb;
     yb = (ntiles + tpw - 1) / tpw;
@@ -681,10 +751,10 @@ hipError_t launch_bars(const float* spec, float* bars_out, size_t nrows, uint32_
     if (rt != nullptr && rt->tiles != nullptr && rt->ntiles != 0 && bars >= 256 && nrows >= 256) {
 #define GLV_ROWS(SS, GG) launch_bars_rows<SS, GG>(spec, bars_out, nrows, n, bars, rt->tiles, rt->ntiles, rt->groups, rt->wg, rt->wsum, st, r)
         switch (bar_lanes_of(n)) {
-            case 2: if (rt->tile_bins == 128) return GLV_ROWS(128, 2); break;
-            case 4: if (rt->tile_bins == 128) return GLV_ROWS(128, 4); break;
+            case 2: if (rt->tile_bins == 160) return GLV_ROWS(160, 2); break;
+            case 4: if (rt->tile_bins == 160) return GLV_ROWS(160, 4); break;
             default:
-                if (rt->tile_bins == 128) return GLV_ROWS(128, 8);
+                if (rt->tile_bins == 160) return GLV_ROWS(160, 8);
                 if (rt->tile_bins == 240) return GLV_ROWS(240, 8);
                 break;
         }

@@ -206,22 +206,36 @@ inline uint32_t make_bar_items(std::vector<BarItem>& items, const std::vector<Ba
 }
 
 // Tables of glv_bars_rows_kernel (bars >= kBarGroupMin: every group of kBarGroup bars starts at one bin, make_bar_taps).
-//   groups[G]: the group's first bin (a multiple of 8), the octet steps that cover its longest bar, where its weights start in wg
+//   groups[G]: the group's first bin (a multiple of 8), the octet steps that cover its longest bar, where its weights start in wg,
+//              its first slot in the kernel's LDS ring of `bins` bins
 //   wg:        per group and step 64 floats -- [bar of the group 0..7][tap 8 s .. 8 s + 7] -- +0 past a bar's end / for bars past the
 //              last one; the kernel streams them through the scalar cache one half step (4 bars) ahead, so 64 floats of slack follow
-//   wsum:      weight_sum per bar, padded with 1.0 to whole groups
-//   tiles:     consecutive groups (at most max_bars / 8) whose bins [origin, end) fit a window of `bins` bins
-// false when a group does not fit the window alone or the groups' first bins are not monotone (the kernel is then not used).
+//   wsum:      per bar {weight_sum, 1 / weight_sum}, padded with {1, 1} to whole groups.  The reciprocal is 0 where the kernel must
+//              divide the long way (bar_rcp_division_ok)
+//   tiles:     ROUNDS of the kernel: consecutive groups (at most max_bars / 8, one per wave) whose bins [origin, end) fit the ring
+//              together with what the NEXT round adds to it (its new bins are written while this round still reads its own):
+//              end(t) - origin(t) <= bins and end(t + 1) - origin(t) <= bins; origins and ends are monotone
+// false when a group does not fit alone or the groups' first bins are not monotone (the kernel is then not used).
+//
+// bar_rcp_division_ok: a / b as q0 = a * r, rem = fma(-q0, b, a), q = fma(rem, r, q0) with r = RN(1 / b) is the correctly rounded
+// quotient (Markstein 1990) unless b's significand is all ones; a is a sum of [0, 1] texels times the weights, b their sum:
+// no overflow, and the kernel takes the long way itself for 0 < a < 2^-90 (where rem would not be exact).  tests/test_emulator.py
+// checks every significand of a against every b of the shipped sizes.
+inline bool bar_rcp_division_ok(float b) {
+    const uint32_t u = __builtin_bit_cast(uint32_t, b);
+    return b >= 0x1p-60f && b <= 0x1p60f && (u & 0x7fffffu) != 0x7fffffu;
+}
 inline bool make_bar_groups(std::vector<BarGroupDesc>& groups, std::vector<float>& wg, std::vector<float>& wsum, std::vector<BarTile>& tiles,
                             const std::vector<BarDesc>& desc, const std::vector<float>& tap_w, uint32_t n, uint32_t bins, uint32_t max_bars) {
     groups.clear(); wg.clear(); wsum.clear(); tiles.clear();
     const uint32_t bars = (uint32_t) desc.size();
-    if (bars < kBarGroupMin || max_bars % kBarGroup) return false;
+    if (bars < kBarGroupMin || max_bars % kBarGroup || bins % 8u) return false;
     const uint32_t ng = (bars + kBarGroup - 1) / kBarGroup;
     for (uint32_t G = 0; G < ng; ++G) {
         const uint32_t k0 = G * kBarGroup, k1 = k0 + kBarGroup < bars ? k0 + kBarGroup : bars;
-        BarGroupDesc g{desc[k0].first_bin, 0u, (uint32_t) wg.size(), k1 - k0};
+        BarGroupDesc g{desc[k0].first_bin, 0u, (uint32_t) wg.size(), 0u};
         if (g.first_bin % 8u) return false;
+        g.slot0 = (g.first_bin / 4u) % (bins / 4u);
         for (uint32_t k = k0; k < k1; ++k) {
             if (desc[k].first_bin != g.first_bin) return false;                 // not the grouped tables
             const uint32_t st = (desc[k].count + 7u) / 8u;
@@ -235,24 +249,29 @@ inline bool make_bar_groups(std::vector<BarGroupDesc>& groups, std::vector<float
                     const uint32_t k = k0 + j, p = 8u * s + t;
                     wg.push_back(k < k1 && p < desc[k].count ? tap_w[desc[k].tap_offset + p] : 0.0f);
                 }
-        for (uint32_t j = 0; j < kBarGroup; ++j) wsum.push_back(k0 + j < k1 ? desc[k0 + j].weight_sum : 1.0f);
+        for (uint32_t j = 0; j < kBarGroup; ++j) {
+            const float ws = k0 + j < k1 ? desc[k0 + j].weight_sum : 1.0f;
+            wsum.push_back(ws);
+            wsum.push_back(bar_rcp_division_ok(ws) ? 1.0f / ws : 0.0f);
+        }
         groups.push_back(g);
     }
     wg.insert(wg.end(), 64, 0.0f);
-    uint32_t G = 0;
+    uint32_t G = 0, prev_origin = 0;
     while (G < ng) {
-        BarTile t{G * kBarGroup, G * kBarGroup, groups[G].first_bin, 0u};
+        BarTile t{G * kBarGroup, G * kBarGroup, groups[G].first_bin, tiles.empty() ? 0u : tiles.back().end};      // ends are kept monotone
         uint32_t H = G;
         while (H < ng && (H - G) * kBarGroup < max_bars) {
             const uint32_t e = groups[H].first_bin + 8u * groups[H].steps;
             const uint32_t end = e > t.end ? e : t.end;
-            if (end - t.origin > bins) break;
+            if (end - t.origin > bins || (!tiles.empty() && end - prev_origin > bins)) break;
             t.end = end;
             ++H;
         }
-        if (H == G) return false;                                                // a single group does not fit the window
+        if (H == G) return false;                                                // a single group does not fit
         t.k1 = H * kBarGroup < bars ? H * kBarGroup : bars;
         tiles.push_back(t);
+        prev_origin = t.origin;
         G = H;
     }
     return true;

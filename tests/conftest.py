@@ -57,7 +57,7 @@ def emu():
     so = os.path.join(ROOT, "tests", "emu", "libglvemu.so")
     deps = [src] + [os.path.join(ROOT, "glava_amd", "csrc", h) for h in ("glv_core.h", "glv_frame.h", "glv_tables.h")]
     if not os.path.exists(so) or any(os.path.getmtime(d) > os.path.getmtime(so) for d in deps):
-        subprocess.run(["g++", "-O2", "-std=c++17", "-ffp-contract=off", "-shared", "-fPIC", "-o", so, src], check=True)
+        subprocess.run(["g++", "-O2", "-std=c++17", "-ffp-contract=off", "-pthread", "-shared", "-fPIC", "-o", so, src], check=True)
     return C.CDLL(so)
 
 

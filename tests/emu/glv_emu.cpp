@@ -11,6 +11,8 @@
 #include <cstdlib>
 #include <cstring>
 #include <vector>
+#include <thread>
+#include <algorithm>
 
 #include "../../glava_amd/csrc/glv_frame.h"
 #include "../../glava_amd/csrc/glv_tables.h"
@@ -328,7 +330,7 @@ int glvemu_bar_tiles_check(int n, int bars, float smooth_factor, float phase, in
     std::vector<float> wg, wsum;
     if (!make_bar_groups(groups, wg, wsum, tiles, desc, w, (uint32_t) n, (uint32_t) bins, (uint32_t) max_bars)) return -1;
     if (ntiles_out) *ntiles_out = (unsigned) tiles.size();
-    if (groups.size() != ((size_t) bars + 7) / 8 || wsum.size() != groups.size() * 8) return 7;
+    if (groups.size() != ((size_t) bars + 7) / 8 || wsum.size() != groups.size() * 16) return 7;
     uint32_t next = 0;
     for (const BarTile& t : tiles) {
         if (t.k0 != next || t.k1 <= t.k0 || t.k1 - t.k0 > (uint32_t) max_bars || t.k0 % 8u) return 1;
@@ -341,12 +343,56 @@ int glvemu_bar_tiles_check(int n, int bars, float smooth_factor, float phase, in
                 const float want = p < desc[k].count ? w[desc[k].tap_offset + p] : 0.0f;
                 if (__builtin_bit_cast(uint32_t, wg[g.w_off + (p / 8u) * 64u + (k % 8u) * 8u + p % 8u]) != __builtin_bit_cast(uint32_t, want)) return 6;
             }
-            if (wsum[k] != desc[k].weight_sum) return 5;
+            if (wsum[2 * k] != desc[k].weight_sum || wsum[2 * k + 1] != (bar_rcp_division_ok(desc[k].weight_sum) ? 1.0f / desc[k].weight_sum : 0.0f)) return 5;
+            if (g.slot0 != (g.first_bin / 4u) % ((uint32_t) bins / 4u)) return 8;
         }
         next = t.k1;
     }
     if (next != (uint32_t) bars) return 4;
+    // the ring: what round t + 1 adds must not land on what round t reads; origins and ends monotone
+    for (size_t i = 1; i < tiles.size(); ++i)
+        if (tiles[i].end < tiles[i - 1].end || tiles[i].origin < tiles[i - 1].origin || tiles[i].end - tiles[i - 1].origin > (uint32_t) bins) return 9;
     return 0;
+}
+
+// The rows kernel's three-instruction division by a bar's weight sum (glv_tables.h bar_rcp_division_ok; glv_misc.hip): for every bar
+// of the table, q0 = a * r, rem = fma(-q0, b, a), q = fma(rem, r, q0) against a / b for EVERY significand of a in two binades around
+// b -- every b_stride-th distinct weight sum -- (scaling a by a power of two scales everything exactly while nothing leaves the normal range, which the kernel's 2^-90 guard and
+// totals <= 2^8 ensure), and at the guard's edge.  Returns the number of mismatches; *checked = quotients compared.
+unsigned long long glvemu_div_rcp_check(int n, int bars, float smooth_factor, float phase, int nthreads, int b_stride, unsigned long long* checked) {
+    using namespace glv;
+    std::vector<BarDesc> desc;
+    std::vector<float> w;
+    make_bar_taps(desc, w, (uint32_t) n, (uint32_t) bars, smooth_factor, phase);
+    std::vector<float> bs;
+    for (const BarDesc& d : desc) bs.push_back(d.weight_sum);
+    std::sort(bs.begin(), bs.end());
+    bs.erase(std::unique(bs.begin(), bs.end()), bs.end());
+    std::vector<unsigned long long> bad((size_t) nthreads, 0ull), cnt((size_t) nthreads, 0ull);
+    std::vector<std::thread> th;
+    for (int ti = 0; ti < nthreads; ++ti)
+        th.emplace_back([&, ti]() {
+            for (size_t i = (size_t) ti * (size_t) b_stride; i < bs.size(); i += (size_t) nthreads * (size_t) b_stride) {
+                const float b = bs[i];
+                if (!bar_rcp_division_ok(b)) continue;
+                const float r = 1.0f / b;
+                int eb; (void) frexpf(b, &eb);
+                for (int e : {eb - 1, eb, -89 + eb, 7}) {                            // a in [2^(e-1), 2^e) ... incl. the smallest and largest totals the fast path sees
+                    const uint32_t base = __builtin_bit_cast(uint32_t, ldexpf(0.5f, e));
+                    for (uint32_t m = 0; m < (1u << 23); ++m) {
+                        const float a = __builtin_bit_cast(float, base + m);
+                        const float q0 = a * r, rm = fmaf(-q0, b, a), q = fmaf(rm, r, q0);
+                        if (__builtin_bit_cast(uint32_t, q) != __builtin_bit_cast(uint32_t, a / b)) ++bad[(size_t) ti];
+                    }
+                    cnt[(size_t) ti] += 1ull << 23;
+                }
+            }
+        });
+    for (auto& t : th) t.join();
+    unsigned long long nb = 0, nc = 0;
+    for (int ti = 0; ti < nthreads; ++ti) { nb += bad[(size_t) ti]; nc += cnt[(size_t) ti]; }
+    if (checked) *checked = nc;
+    return nb;
 }
 
 // glv_bars_rows_kernel's arithmetic on the host, off the same tables: per group the octet steps in order, eight bars side by side,
@@ -394,7 +440,7 @@ int glvemu_bars_rows(const float* tex, int n, int bars, float smooth_factor, flo
                     p1[j] = p2[j] = 0.0f;
                 }
             }
-            for (uint32_t j = 0; j < g.nbars; ++j) out[8 * G + j] = tot[j] / wsum[8 * G + j];
+            for (uint32_t j = 0; j < 8u && 8 * G + j < (uint32_t) bars; ++j) out[8 * G + j] = tot[j] / wsum[2 * (8 * G + j)];
         }
     return 0;
 }

@@ -2,6 +2,8 @@
 emulator (tests/emu/glv_emu.cpp) must reproduce the oracle bit for bit -- this is where the
 Stockham index maps, the pass plan for every size, the LDS swizzle, the twiddle gather and the
 gravity/average state machine are debugged without a GPU."""
+import os
+
 import numpy as np
 import pytest
 
@@ -304,30 +306,30 @@ def test_fused_tilt_formula_is_within_its_bound(n):
         assert worst <= 4.5e-7, (n, scale, cutoff, worst)
 
 
-@pytest.mark.parametrize("n,bins", [(256, 128), (1024, 128), (2048, 128), (4096, 128), (4096, 240), (8192, 240)])
+@pytest.mark.parametrize("n,bins", [(256, 160), (1024, 160), (2048, 160), (4096, 160), (4096, 240), (8192, 240)])
 def test_group_tables_of_the_many_rows_bars_kernel(emu, n, bins):
     """glv_bars_rows_kernel (the pre-smoothing pass at scale: bars == n, one lane per row, eight bars per wave) runs off host tables:
     the bars in groups of eight that start at one bin (make_bar_taps' group rule: leading +0 taps), per group a stream of 64 weights
-    per octet step, tiles of at most 64 consecutive bars whose steps fit an LDS window of `bins` bins.  Invariants of all of them,
-    and which sizes can be tiled at all: n <= 2048 with 128 bins, n = 4096 only with 240 (its longest bar has 191 taps + the lead),
-    n >= 8192 not (the library then keeps glv_bars_kernel)."""
+    per octet step, rounds of at most 64 consecutive bars whose steps -- and what the next round adds -- fit an LDS ring of `bins`
+    bins.  Invariants of all of them, and which sizes can be cut into rounds at all: n <= 2048 with 160 bins, n = 4096 only with 240
+    (its longest bar has 191 taps + the lead), n >= 8192 not (the library then keeps glv_bars_kernel)."""
     import ctypes as C
     nt, mc = C.c_uint(0), C.c_uint(0)
     rc = emu.glvemu_bar_tiles_check(n, n, C.c_float(0.025), C.c_float(0.5), bins, 64, C.byref(nt), C.byref(mc))
-    if n >= 8192 or (n == 4096 and bins == 128):
+    if n >= 8192 or (n == 4096 and bins == 160):
         assert rc == -1 and ((mc.value + 7) & ~7) > bins, (rc, mc.value)
     else:
         assert rc == 0 and ((mc.value + 7) & ~7) <= bins and nt.value >= n // 64, (rc, nt.value, mc.value)
     # fewer bars than a power of two, a last group that is not full, wide gaps between the bars
-    assert emu.glvemu_bar_tiles_check(4096, 1001, C.c_float(0.025), C.c_float(0.0), 240, 64, C.byref(nt), C.byref(mc)) == 0
-    assert emu.glvemu_bar_tiles_check(1024, 259, C.c_float(0.025), C.c_float(0.5), 128, 64, C.byref(nt), C.byref(mc)) == 0
-    assert emu.glvemu_bar_tiles_check(4096, 259, C.c_float(0.025), C.c_float(0.5), 240, 64, C.byref(nt), C.byref(mc)) == -1      # 191 taps + a spread of 35 bins
+    assert emu.glvemu_bar_tiles_check(2048, 1001, C.c_float(0.025), C.c_float(0.0), 160, 64, C.byref(nt), C.byref(mc)) == 0
+    assert emu.glvemu_bar_tiles_check(1024, 259, C.c_float(0.025), C.c_float(0.5), 160, 64, C.byref(nt), C.byref(mc)) == 0
+    assert emu.glvemu_bar_tiles_check(4096, 259, C.c_float(0.025), C.c_float(0.5), 160, 64, C.byref(nt), C.byref(mc)) == -1      # 191 taps + a spread of 35 bins
     # below 256 bars there are no groups (the modules' 80 bars keep their own first bins)
     assert emu.glvemu_bar_tiles_check(4096, 80, C.c_float(0.025), C.c_float(0.0), 240, 64, C.byref(nt), C.byref(mc)) == -1
 
 
-@pytest.mark.parametrize("n,bars,bins,phase", [(256, 256, 128, 0.5), (512, 512, 128, 0.5), (1024, 1024, 128, 0.5), (2048, 2048, 128, 0.5), (4096, 4096, 240, 0.5),
-                                               (4096, 1001, 240, 0.0), (1024, 259, 128, 0.5)])
+@pytest.mark.parametrize("n,bars,bins,phase", [(256, 256, 160, 0.5), (512, 512, 160, 0.5), (1024, 1024, 160, 0.5), (2048, 2048, 160, 0.5), (4096, 4096, 240, 0.5),
+                                               (2048, 1001, 160, 0.0), (1024, 259, 160, 0.5)])
 def test_rows_kernel_arithmetic_is_the_documented_one(emu, oracle, n, bars, bins, phase):
     """The lane-per-row kernel walks a group's octets with a three-deep stack of partial sums and eight bars side by side
     (glvemu_bars_rows restates it off the same host tables); the oracle sums every bar on its own in the documented order
@@ -348,3 +350,20 @@ def test_rows_kernel_arithmetic_is_the_documented_one(emu, oracle, n, bars, bins
         want = np.zeros(bars, np.float32)
         oracle.lib().glvo_bars_chunked_at(np.ascontiguousarray(tex), n, want, bars, 0.025, phase)
         assert (got.view(np.uint32) == want.view(np.uint32)).all(), (n, bars, int((got.view(np.uint32) != want.view(np.uint32)).sum()))
+
+
+@pytest.mark.parametrize("n,b_stride", [(1024, 16), (4096, 64)])
+def test_rows_kernel_division_by_reciprocal_is_the_quotient(emu, n, b_stride):
+    """The lane-per-row kernel divides a bar's total by its weight sum in three instructions -- q0 = a * r, rem = fma(-q0, b, a),
+    q = fma(rem, r, q0) with the host's r = RN(1 / b) (Markstein) -- where the table says that is exact.  Checked for the weight
+    sums of the pre-smoothing pass against a / b over EVERY significand of a in four binades (the two around b, the smallest and the
+    largest totals the fast path sees): 2^25 quotients per bar, no mismatch.  By default every 16th / 64th distinct weight sum (the CPU
+    suite stays short); GLV_FULL_CHECKS=1 takes them all (round 4: 1.3e11 quotients for n = 4096, none differs)."""
+    import ctypes as C
+    emu.glvemu_div_rcp_check.restype = C.c_ulonglong
+    emu.glvemu_div_rcp_check.argtypes = [C.c_int, C.c_int, C.c_float, C.c_float, C.c_int, C.c_int, C.POINTER(C.c_ulonglong)]
+    if os.environ.get("GLV_FULL_CHECKS"):
+        b_stride = 1
+    checked = C.c_ulonglong(0)
+    bad = emu.glvemu_div_rcp_check(n, n, 0.025, 0.5, min(16, os.cpu_count() or 2), b_stride, C.byref(checked))
+    assert bad == 0 and checked.value >= (n // (2 * b_stride) - 16) * (1 << 25), (bad, checked.value)

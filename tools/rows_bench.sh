@@ -1,0 +1,8 @@
+#!/bin/bash
+# build tools/bin/rows_bench[_<name>] (name = "": the kernel as shipped; otherwise with the given -D switches)
+#   tools/rows_bench.sh            -> tools/bin/rows_bench
+#   tools/rows_bench.sh nofill -DGLV_EXP_ROWS_NOFILL
+cd "$(dirname "$0")/.." || exit 1
+name=${1:+_$1}; shift
+mkdir -p tools/bin
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fno-fast-math -Wno-unused-function -DGLV_TUNE_BUILD "$@" tools/rows_bench.hip -o tools/bin/rows_bench$name

@@ -243,3 +243,30 @@ def test_many_bars_of_many_rows_kernel_gives_the_documented_bits(glvlib, n, stre
         assert fb.last_launches() == 2
         assert _eq(ob[:16].contiguous(), os_), u
     for b in (big, small, fb, fs): b.close()
+
+
+@pytest.mark.parametrize("n,bars,phase,rows", [(2048, 1001, 0.0, 300), (1024, 259, 0.5, 257), (4096, 4096, 0.5, 70 * 64 + 3), (512, 512, 0.5, 1024)])
+def test_many_rows_kernel_with_ragged_tables(glvlib, n, bars, phase, rows):
+    """The lane-per-row kernel away from the round numbers: a bar count that is not a multiple of eight (a last group of one bar, a
+    last round of fewer than 64 bars), bars further apart than in the pre-smoothing pass (wider leads), a row count that leaves a last
+    workgroup of 3 rows, more row blocks than resident workgroups -- every bar of every row against the oracle's documented order,
+    floats and texels."""
+    import torch
+    G = glvlib
+    assert rows % 2 == 1 or rows >= 256
+    streams = (rows + 1) // 2
+    rng = np.random.default_rng(n * 7 + bars)
+    spec = (rng.random((streams * 2, n), dtype=np.float32) ** 3 * np.float32(1.2) - np.float32(0.02)).astype(np.float32)
+    spec[1, : n // 3] = 0.0
+    p = G.Params(n=n, bars=bars, bar_phase=phase)
+    b = G.Batch(p, streams, G.OP_FFT | G.OP_BARS)
+    d_spec = torch.from_numpy(spec).cuda()
+    d_out = torch.full((streams * 2, bars), -1.0, dtype=torch.float32, device="cuda")
+    b.bars(d_spec, d_out)
+    got = d_out.cpu().numpy()
+    want = np.empty((streams * 2, bars), np.float32)
+    for r in range(streams * 2):
+        Oracle.lib().glvo_bars_chunked_at(np.ascontiguousarray(spec[r]), n, want[r], bars, 0.025, phase)
+    same = (got.view(np.uint32) == want.view(np.uint32)) | (np.isnan(got) & np.isnan(want))
+    assert same.all(), (int((~same).sum()), np.argwhere(~same)[:4].tolist())
+    b.close()

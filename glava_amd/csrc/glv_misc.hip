@@ -387,8 +387,9 @@ __global__ void __launch_bounds__(256) glv_bars_short_kernel(const float* __rest
 // group's eight results per row straight from the registers -- 64 lines per store instruction, rows a power of two apart -- costs
 // 0.79 instead of 0.61 ms at N = 4096).  Two workgroups per CU = four waves per SIMD cover the scalar and LDS latencies (an s_load
 // result needs lgkmcnt(0): the prefetch distance is half a step, the rest is the other waves).  What bounds the kernel is that
-// scalar stream: 256 B per octet step and wave, 0.56 GB per launch at N = 4096 x 32 K rows, ~1 TB/s through the scalar caches
-// (profiles/r04/rows_kernel.txt: the vector ALU is busy 40 % of the time, waves wait on lgkmcnt).
+// scalar stream: 256 B per octet step and wave, 0.56 GB per launch at N = 4096 x 32 K rows, every half step an L2 round trip of
+// ~1300 cycles (profiles/r04/rows_kernel.txt: the vector ALU is busy 40 % of the time, waves wait on lgkmcnt; the loads do not
+// hit in the scalar cache -- made to read one address they queue at one L2 channel and the kernel is twice as slow).
 // The summation order is the documented one (glv_frame.h "GLV_OP_BARS arithmetic": chunks of 16 / 32 / 64 taps, per chunk 2 / 4 / 8
 // octet sums, each the sum of two fused-multiply-add chains, combined pairwise, chunk totals in order), walked octet by octet with a
 // three-deep stack of partial sums: the same bits as glv_bars_kernel and the fused epilogue.  The final division by the bar's weight
@@ -478,7 +479,11 @@ __global__ void __launch_bounds__(64 * kRowsWaves) glv_bars_rows_kernel(const fl
 #else
         if (valid) {
             const uint32_t steps = (uint32_t) __builtin_amdgcn_readfirstlane((int) g.steps);
+#if defined(GLV_EXP_ROWS_SAMEW)
+            const float* wp = wg;
+#else
             const float* wp = wg + (uint32_t) __builtin_amdgcn_readfirstlane((int) g.w_off);
+#endif
             uint32_t slot = (uint32_t) __builtin_amdgcn_readfirstlane((int) g.slot0);       // even; a step reads slots slot, slot + 1, then moves on two (wrapping)
             // per pair of bars {2 i, 2 i + 1}: the running total and the stack of partial sums of the chunk under way
             glv_f2 tot[4], p0[4], p1[4], p2[4];
@@ -499,7 +504,11 @@ __global__ void __launch_bounds__(64 * kRowsWaves) glv_bars_rows_kernel(const fl
 #pragma unroll
                 for (int h = 0; h < 2; ++h) {
                     const HalfW wn = load_half(wnext);                            // one half step ahead (64 floats of slack follow the table)
+#if defined(GLV_EXP_ROWS_SAMEW)         /* timing experiment (wrong results): every half step reads the same 128 bytes -- scalar-cache hits */
+                    wnext = wp + (((wnext - wp) + 32) & 32);
+#else
                     wnext += 32;
+#endif
                     // {even chain, odd chain} of the half step's four bars, interleaved (a dependent packed op two slots later costs a wait
                     // state); first link: fma(x, w, +0) == x * w (both >= +0)
                     glv_f2 ac[4], o[2];

@@ -534,6 +534,8 @@ int ensure_bar_tables(glv_batch* b) {
                 HIP_TRY(hipMalloc(&b->d_bar_wsum, sizeof(float) * wsum.size()));
                 HIP_TRY(hipMemcpy(b->d_bar_wsum, wsum.data(), sizeof(float) * wsum.size(), hipMemcpyHostToDevice));
                 b->bar_ntiles = (uint32_t) tiles.size(); b->bar_tile_bins = bins;
+                const glv::BarRowsTables rt = b->rows_tables();
+                HIP_TRY(glv::prepare_bars_rows(b->p.n, &rt));
                 break;
             }
         }

@@ -47,6 +47,7 @@ struct BarRowsTables {
 };
 hipError_t launch_bars(const float* spec, float* bars_out, size_t nrows, uint32_t n, uint32_t bars, uint32_t nsteps,
                        const BarItem* items, const BarDesc* desc, const float* tap_w, hipStream_t st, bool r16 = false, const BarRowsTables* rt = nullptr);
+hipError_t prepare_bars_rows(uint32_t n, const BarRowsTables* rt);      // function attributes of the kernel launch_bars would pick
 hipError_t launch_ring_planar(const void* ring, int is_f32, uint32_t n, uint32_t rot, int mono, size_t streams, float* out, hipStream_t st);
 hipError_t launch_unpack(const int16_t* pcm, size_t frames, int mono, float* l, float* r, hipStream_t st);
 

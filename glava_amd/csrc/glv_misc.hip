@@ -737,6 +737,7 @@ static hipError_t launch_bars_rows(const float* spec, float* bars_out, size_t nr
             if (dev >= 0 && dev < 64) done[dev].store(true, std::memory_order_release);
         }
     }
+    if (nrows == 0) return hipSuccess;                                          // prepare_bars_rows: the attribute only
     // 64 rows per workgroup in x, ranges of rounds in y: two resident workgroups per CU, twice over (a range start refills the whole
     // ring; N = 4096: 32 K rows 0.60 / 0.61 / 0.62 ms with 1 / 2 / 4 ranges, 8 K rows 0.48 / 0.19 / 0.18 ms with 1 / 4 / 16)
     const uint32_t xb = (uint32_t) ((nrows + 63) / 64);
@@ -750,6 +751,23 @@ static hipError_t launch_bars_rows(const float* spec, float* bars_out, size_t nr
     hipLaunchKernelGGL((glv_bars_rows_kernel<S, GL>), dim3(xb, yb), dim3(64 * kRowsWaves), lds, st, spec, static_cast<void*>(bars_out), nrows, n, bars, tiles,
                        ntiles, tpw, groups, wg, wsum, r);
     return hipGetLastError();
+}
+
+// the > 64 KiB dynamic-LDS opt-in of the rows kernel that launch_bars would pick for (n, rt), set ahead of the first launch (a
+// process call is then a plain launch)
+hipError_t prepare_bars_rows(uint32_t n, const BarRowsTables* rt) {
+    if (rt == nullptr || rt->tiles == nullptr || rt->ntiles == 0) return hipSuccess;
+#define GLV_ROWS(SS, GG) launch_bars_rows<SS, GG>(nullptr, nullptr, 0, n, 0, rt->tiles, rt->ntiles, rt->groups, rt->wg, rt->wsum, nullptr, 0)
+    switch (bar_lanes_of(n)) {
+        case 2: if (rt->tile_bins == 160) return GLV_ROWS(160, 2); break;
+        case 4: if (rt->tile_bins == 160) return GLV_ROWS(160, 4); break;
+        default:
+            if (rt->tile_bins == 160) return GLV_ROWS(160, 8);
+            if (rt->tile_bins == 240) return GLV_ROWS(240, 8);
+            break;
+    }
+#undef GLV_ROWS
+    return hipSuccess;
 }
 
 hipError_t launch_bars(const float* spec, float* bars_out, size_t nrows, uint32_t n, uint32_t bars, uint32_t nsteps,

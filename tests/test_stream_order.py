@@ -93,7 +93,7 @@ def _bits_equal(a, b):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("case", ["configs1", "chain_F5", "fused_bars", "gl_default", "gravity_out_is_state", "unfused_bars"])
+@pytest.mark.parametrize("case", ["configs1", "chain_F5", "fused_bars", "gl_default", "gl_default_sm", "gravity_out_is_state", "unfused_bars"])
 def test_first_process_call_can_be_captured_and_replayed(glvlib, case):
     """capture the FIRST call(s) after glv_batch_create into a hipGraph, replay, compare with an eagerly driven twin batch"""
     import torch
@@ -108,6 +108,9 @@ def test_first_process_call_can_be_captured_and_replayed(glvlib, case):
                            ops=G.OP_FFT | G.OP_GRAVITY | G.OP_AVERAGE | G.OP_BARS, dt=torch.float32, w=80, per_graph=F),
         "gl_default": dict(p=G.Params(n=n, avg_frames=F, avg_window_kind=1, gl_storage=1), mask=G.OP_GRAVITY | G.OP_AVERAGE,
                            ops=G.OP_FFT | G.OP_GRAVITY | G.OP_AVERAGE | G.OP_R16, dt=torch.int16, w=n, per_graph=F),
+        # + the pre-smoothing pass (two launches; 256 rows: the lane-per-row kernel with its > 64 KiB LDS opt-in set at creation)
+        "gl_default_sm": dict(p=G.Params(n=n, avg_frames=F, avg_window_kind=1, gl_storage=1, bars=n, bar_phase=0.5), mask=G.OP_GRAVITY | G.OP_AVERAGE | G.OP_BARS,
+                              ops=G.OP_FFT | G.OP_GRAVITY | G.OP_AVERAGE | G.OP_BARS | G.OP_R16, dt=torch.int16, w=n, per_graph=F, streams=128),
         "gravity_out_is_state": dict(p=G.Params(n=n), mask=G.OP_GRAVITY, ops=G.OP_FFT | G.OP_GRAVITY | G.OP_OUTPUT_IS_STATE,
                                      dt=torch.float32, w=n, per_graph=1),
         "unfused_bars": dict(p=G.Params(n=512, avg_frames=F), mask=G.OP_GRAVITY | G.OP_AVERAGE | G.OP_BARS,
@@ -115,6 +118,7 @@ def test_first_process_call_can_be_captured_and_replayed(glvlib, case):
     }[case]
     p = spec["p"]
     nn = p.n
+    streams = spec.get("streams", streams)
     pcm = [torch.from_numpy((lcg_pcm_fast(7300 + u, streams * 2 * nn) // 4).astype(np.int16)).cuda() for u in range(spec["per_graph"])]
     graph_b, eager_b = G.Batch(p, streams, spec["mask"]), G.Batch(p, streams, spec["mask"])
     o_graph = [torch.zeros((streams * 2, spec["w"]), dtype=spec["dt"], device="cuda") for _ in range(spec["per_graph"])]

@@ -317,12 +317,12 @@ struct glv_batch {
     uint32_t bar_fnsteps[kMaxVariants] = {}; bool bar_fusable[kMaxVariants] = {};
     uint32_t bar_nsteps = 0;
     uint32_t bar_count = 0; float bar_factor = -1.f, bar_phase = 0.f;
-    glv::BarTile* d_bar_tiles = nullptr;   // tiles of the many-bars x many-rows kernel (glv_misc.hip glv_bars_rows_kernel), when the bars allow them
-    uint32_t bar_ntiles = 0, bar_tile_bins = 0;
-    glv::BarGroupDesc* d_bar_groups = nullptr;   // its groups of eight bars, their weight stream and the bars' weight sums (glv_tables.h make_bar_groups)
-    float* d_bar_wg = nullptr;
+    glv::BarMTile* d_bar_mtiles = nullptr;  // >= 256 bars (glv_tables.h make_bar_mtiles): tiles of 32 bars, their weights in MFMA operand layout, the bars'
+    float* d_bar_wt = nullptr;              // {weight sum, reciprocal}, and -- when they could be cut -- the rounds of glv_bars_rows_kernel for its LDS ring
     float* d_bar_wsum = nullptr;
-    glv::BarRowsTables rows_tables() const { return glv::BarRowsTables{d_bar_tiles, bar_ntiles, bar_tile_bins, d_bar_groups, d_bar_wg, d_bar_wsum}; }
+    glv::BarTile* d_bar_rounds = nullptr;
+    uint32_t bar_ntiles = 0, bar_nrounds = 0, bar_ring_bins = 0;
+    glv::BarRowsTables rows_tables() const { return glv::BarRowsTables{d_bar_mtiles, bar_ntiles, d_bar_wt, d_bar_wsum, d_bar_rounds, bar_nrounds, bar_ring_bins}; }
     // timing
     bool timing = false;
     std::vector<hipEvent_t> ev;  // start/stop pairs
@@ -488,7 +488,7 @@ int ensure_bar_tables(glv_batch* b) {
     glv::make_bar_taps(desc, w, b->p.n, b->p.bars, b->p.smooth_factor, b->p.bar_phase);
     if (!glv::bar_chunks_in_row(desc, b->p.n)) return fail(GLV_ERR_INVALID, "bars: a tap chunk would leave the row (n=%u smooth_factor=%g)", b->p.n, (double) b->p.smooth_factor);
     auto drop = [](auto*& ptr) { if (ptr) { (void) hipFree(ptr); ptr = nullptr; } };
-    drop(b->d_bar_desc); drop(b->d_bar_w); drop(b->d_bar_items); drop(b->d_bar_tiles); drop(b->d_bar_groups); drop(b->d_bar_wg); drop(b->d_bar_wsum);
+    drop(b->d_bar_desc); drop(b->d_bar_w); drop(b->d_bar_items); drop(b->d_bar_mtiles); drop(b->d_bar_wt); drop(b->d_bar_wsum); drop(b->d_bar_rounds);
     for (int v = 0; v < glv_batch::kMaxVariants; ++v) { drop(b->d_bar_fitems[v]); b->bar_fusable[v] = false; b->bar_fnsteps[v] = 0; }
     b->bar_count = 0;
     // work lists: 256 / GL groups per row for glv_bars_kernel; T / GL groups for the frame kernel (GL = bar_lanes_of(n); fused bars:
@@ -504,7 +504,8 @@ int ensure_bar_tables(glv_batch* b) {
     for (int v = 0; v < nv && v < glv_batch::kMaxVariants; ++v) {
         const glv::FrameGeometry geo = glv::frame_geometry(b->log_nn, v);
         // bar totals + the dump slot fit the 2 * lanes floats of slack behind the row in LDS
-        b->bar_fusable[v] = geo.lanes % 64 == 0 && geo.nbuf == 1 && b->p.bars + 1 <= 2 * (uint32_t) geo.lanes;
+        // (from 256 bars up a bar is one fma chain, glv_tables.h make_bar_mtiles: the chunked loop of the epilogue does not apply)
+        b->bar_fusable[v] = geo.lanes % 64 == 0 && geo.nbuf == 1 && b->p.bars + 1 <= 2 * (uint32_t) geo.lanes && b->p.bars < glv::kBarSeqMin;
         if (!b->bar_fusable[v]) continue;
         std::vector<glv::BarItem> fitems;
         b->bar_fnsteps[v] = glv::make_bar_items(fitems, desc, (uint32_t) geo.lanes / gl, zero_off, chunk, (uint32_t) geo.bar_batch);
@@ -516,28 +517,31 @@ int ensure_bar_tables(glv_batch* b) {
     HIP_TRY(hipMemcpy(b->d_bar_desc, desc.data(), sizeof(glv::BarDesc) * desc.size(), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(b->d_bar_w, w.data(), sizeof(float) * w.size(), hipMemcpyHostToDevice));
     b->bar_count = b->p.bars; b->bar_factor = b->p.smooth_factor; b->bar_phase = b->p.bar_phase;
-    // many bars (the pre-smoothing pass): the tables of the lane-per-row kernel, for the smallest LDS window that takes every group
-    b->bar_ntiles = 0; b->bar_tile_bins = 0;
-    if (b->p.bars >= glv::kBarGroupMin && !std::getenv("GLV_NO_BARS_ROWS")) {      // (diagnostics: keep the small-batch kernel for every row count)
-        std::vector<glv::BarTile> tiles;
-        std::vector<glv::BarGroupDesc> groups;
-        std::vector<float> wg, wsum;
-        for (uint32_t bins : {160u, 240u}) {
-            if (bins == 240u && glv::bar_lanes_of(b->p.n) != 8) break;             // (built for the 64-tap chunks only)
-            if (glv::make_bar_groups(groups, wg, wsum, tiles, desc, w, b->p.n, bins, 64u)) {      // 64 = glv_misc.hip kRowsTileBars
-                HIP_TRY(hipMalloc(&b->d_bar_tiles, sizeof(glv::BarTile) * tiles.size()));
-                HIP_TRY(hipMemcpy(b->d_bar_tiles, tiles.data(), sizeof(glv::BarTile) * tiles.size(), hipMemcpyHostToDevice));
-                HIP_TRY(hipMalloc(&b->d_bar_groups, sizeof(glv::BarGroupDesc) * groups.size()));
-                HIP_TRY(hipMemcpy(b->d_bar_groups, groups.data(), sizeof(glv::BarGroupDesc) * groups.size(), hipMemcpyHostToDevice));
-                HIP_TRY(hipMalloc(&b->d_bar_wg, sizeof(float) * wg.size()));
-                HIP_TRY(hipMemcpy(b->d_bar_wg, wg.data(), sizeof(float) * wg.size(), hipMemcpyHostToDevice));
-                HIP_TRY(hipMalloc(&b->d_bar_wsum, sizeof(float) * wsum.size()));
-                HIP_TRY(hipMemcpy(b->d_bar_wsum, wsum.data(), sizeof(float) * wsum.size(), hipMemcpyHostToDevice));
-                b->bar_ntiles = (uint32_t) tiles.size(); b->bar_tile_bins = bins;
-                const glv::BarRowsTables rt = b->rows_tables();
-                HIP_TRY(glv::prepare_bars_rows(b->p.n, &rt));
-                break;
-            }
+    // many bars (the pre-smoothing pass): tiles of 32 bars for the chain kernels; rounds for the smallest LDS ring that takes them
+    b->bar_ntiles = 0; b->bar_nrounds = 0; b->bar_ring_bins = 0;
+    if (b->p.bars >= glv::kBarSeqMin) {
+        std::vector<glv::BarMTile> mtiles;
+        std::vector<glv::BarTile> rounds;
+        std::vector<float> wt, wsum;
+        for (uint32_t bins : {160u, 288u}) {
+            if (!glv::make_bar_mtiles(mtiles, wt, wsum, rounds, desc, w, b->p.n, bins, 4u))       // 4 = glv_misc.hip kRowsWaves
+                return fail(GLV_ERR_INVALID, "bars: no tile table (bars=%u)", b->p.bars);
+            if (!rounds.empty()) { b->bar_ring_bins = bins; break; }
+        }
+        if (std::getenv("GLV_NO_BARS_ROWS")) rounds.clear();                        // (diagnostics: the one-lane-per-bar kernel for every row count)
+        HIP_TRY(hipMalloc(&b->d_bar_mtiles, sizeof(glv::BarMTile) * mtiles.size()));
+        HIP_TRY(hipMemcpy(b->d_bar_mtiles, mtiles.data(), sizeof(glv::BarMTile) * mtiles.size(), hipMemcpyHostToDevice));
+        HIP_TRY(hipMalloc(&b->d_bar_wt, sizeof(float) * wt.size()));
+        HIP_TRY(hipMemcpy(b->d_bar_wt, wt.data(), sizeof(float) * wt.size(), hipMemcpyHostToDevice));
+        HIP_TRY(hipMalloc(&b->d_bar_wsum, sizeof(float) * wsum.size()));
+        HIP_TRY(hipMemcpy(b->d_bar_wsum, wsum.data(), sizeof(float) * wsum.size(), hipMemcpyHostToDevice));
+        b->bar_ntiles = (uint32_t) mtiles.size();
+        if (!rounds.empty()) {
+            HIP_TRY(hipMalloc(&b->d_bar_rounds, sizeof(glv::BarTile) * rounds.size()));
+            HIP_TRY(hipMemcpy(b->d_bar_rounds, rounds.data(), sizeof(glv::BarTile) * rounds.size(), hipMemcpyHostToDevice));
+            b->bar_nrounds = (uint32_t) rounds.size();
+            const glv::BarRowsTables rt = b->rows_tables();
+            HIP_TRY(glv::prepare_bars_rows(b->p.n, &rt));
         }
     }
     return GLV_OK;
@@ -915,10 +919,10 @@ int glv_batch_destroy(glv_batch* b) {
     if (b->d_bar_w) (void) hipFree(b->d_bar_w);
     if (b->d_bar_items) (void) hipFree(b->d_bar_items);
     for (glv::BarItem* f : b->d_bar_fitems) if (f) (void) hipFree(f);
-    if (b->d_bar_tiles) (void) hipFree(b->d_bar_tiles);
-    if (b->d_bar_groups) (void) hipFree(b->d_bar_groups);
-    if (b->d_bar_wg) (void) hipFree(b->d_bar_wg);
+    if (b->d_bar_mtiles) (void) hipFree(b->d_bar_mtiles);
+    if (b->d_bar_wt) (void) hipFree(b->d_bar_wt);
     if (b->d_bar_wsum) (void) hipFree(b->d_bar_wsum);
+    if (b->d_bar_rounds) (void) hipFree(b->d_bar_rounds);
     for (hipEvent_t e : b->ev) (void) hipEventDestroy(e);
     delete b;
     return GLV_OK;

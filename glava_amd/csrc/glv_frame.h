@@ -37,11 +37,10 @@ struct BarDesc { uint32_t first_bin, count, tap_offset; float weight_sum; };
 // completes, or `bars` (a dump slot) when it does not, keep = 0.0f when the chunk opens a bar (the running total
 // restarts), 1.0f otherwise.
 struct alignas(16) BarItem { uint32_t w_byte, tex_byte, res; float keep; };
-// One tile of glv_bars_rows_kernel (many bars of many rows): bars [k0, k1) -- whole groups of 8, glv_tables.h make_bar_taps -- whose
-// taps, rounded up to whole octets, lie in the bins [origin, end) of the row, origin and end multiples of 8, end - origin <= the
-// kernel's LDS window.  One group: its first bin, its octet steps, where its 64 weights per step start (glv_tables.h make_bar_groups).
+// Many bars (>= 256; glv_tables.h make_bar_mtiles): one tile of 32 consecutive bars -- first bin, pairs of bins, where its 64
+// weights per pair start -- and one round of glv_bars_rows_kernel: tiles [k0, k1) whose bins [origin, end) sit in the LDS ring.
 struct alignas(16) BarTile { uint32_t k0, k1, origin, end; };
-struct alignas(16) BarGroupDesc { uint32_t first_bin, steps, w_off, slot0; };      // slot0: (first_bin / 4) mod (window bins / 4), the group's first slot of the LDS ring
+struct alignas(16) BarMTile { uint32_t k0, origin, steps, w_off; };
 
 struct FrameArgs {
     const void* in;        // s16: int16 [units/2][n][2] (a unit is one channel row of a frame);  f32 planar: float [units][n];

@@ -40,10 +40,11 @@ hipError_t launch_smooth(float* rows, size_t nrows, uint32_t n, const int* smin,
 // the s16 window table as float pairs (glv_core.h WinSplit): split = float [n/2][4]; d_fail_shifted = int [2], zeroed by the caller
 hipError_t launch_window_split(const double* w_tab, float* split, uint32_t n, int* d_fail_shifted, hipStream_t st);
 hipError_t launch_window_split_check(const double* w_tab, const float* split, uint32_t n, unsigned long long* d_mismatches, hipStream_t st);
-// rt: the tables of the many-bars x many-rows kernel (glv_tables.h make_bar_groups; nullptr: not considered)
+// rt: the tables of the many-bars kernels (>= 256 bars; glv_tables.h make_bar_mtiles): tiles of 32 bars with their weights, the bars'
+// weight sums, and -- when they could be cut -- the rounds of the matrix-core kernel for an LDS ring of ring_bins (160 or 288) bins
 struct BarRowsTables {
-    const BarTile* tiles; uint32_t ntiles, tile_bins;     // tile_bins: the LDS ring the rounds were cut for (160 or 240 bins)
-    const BarGroupDesc* groups; const float* wg; const float* wsum;
+    const BarMTile* mtiles; uint32_t ntiles; const float* wt; const float* wsum;
+    const BarTile* rounds; uint32_t nrounds, ring_bins;
 };
 hipError_t launch_bars(const float* spec, float* bars_out, size_t nrows, uint32_t n, uint32_t bars, uint32_t nsteps,
                        const BarItem* items, const BarDesc* desc, const float* tap_w, hipStream_t st, bool r16 = false, const BarRowsTables* rt = nullptr);

@@ -368,63 +368,49 @@ __global__ void __launch_bounds__(256) glv_bars_short_kernel(const float* __rest
     }
 }
 
-// The same bars for MANY bars and MANY rows (the pre-smoothing pass of render.c:2277-2303: bars == n, one output per texel, ~58
-// taps each at n = 4096: 237 K multiply-adds per row): ONE LANE PER ROW, EIGHT BARS PER WAVE AT A TIME.
-//   * The taps and weights of a bar do not depend on the row, so with 64 rows side by side in a wave every weight is wave-uniform: a
-//     SCALAR register, streamed through the scalar cache (s_load_dwordx16) -- no vector register, no vector load, no broadcast.
-//   * The eight bars of a group start at one bin (glv_tables.h make_bar_taps, "group rule"), so they walk the same texels in the same
-//     octets: the lane reads an octet of its row ONCE from LDS (two ds_read_b128) and uses it for eight bars.
-//   * A tap pair is one v_pk_fma_f32 for 64 rows: {even chain, odd chain} += {x[2i], x[2i+1]} * {w[2i], w[2i+1]} with the weight pair as
-//     an SGPR-pair operand -- 4 packed instructions per octet and bar, + 1 add for the octet sum, + the tree.
-//     (Round 4's first version took one bar per wave, one v_fmac_f32_dpp and half a ds_read2st64_b32 per tap and row: LDS-bandwidth
-//     bound at 1.33 ms for 32 K rows of N = 4096 -- profiles/r04/rows_parts.txt: 1.18 ms of it with no HBM traffic at all.)
-// A workgroup is eight waves on the SAME 64 rows.  The rows' texels live in LDS as a RING of S bins, [bin / 4 mod S / 4][row][4]
-// (conflict-free b128 accesses both ways: the fill's global loads deliver exactly one such slot).  The bars' first bins grow slowly
-// (4096 bars cover 1250 bins), so a ROUND -- eight groups, wave w takes group w (host table, glv_tables.h make_bar_groups) -- needs
-// only a few bins the previous round did not have: they are requested before the round's arithmetic and written behind it, into
-// slots no wave of the round reads (the table guarantees end(t + 1) - origin(t) <= S).  Every texel is read from HBM / L2 once per
-// range of rounds.  The round's 64 results per row are parked in LDS and leave as contiguous row segments (measured: storing a
-// group's eight results per row straight from the registers -- 64 lines per store instruction, rows a power of two apart -- costs
-// 0.79 instead of 0.61 ms at N = 4096).  Two workgroups per CU = four waves per SIMD cover the scalar and LDS latencies (an s_load
-// result needs lgkmcnt(0): the prefetch distance is half a step, the rest is the other waves).  What bounds the kernel is that
-// scalar stream: 256 B per octet step and wave, 0.56 GB per launch at N = 4096 x 32 K rows, every half step an L2 round trip of
-// ~1300 cycles (profiles/r04/rows_kernel.txt: the vector ALU is busy 40 % of the time, waves wait on lgkmcnt; the loads do not
-// hit in the scalar cache -- made to read one address they queue at one L2 channel and the kernel is twice as slow).
-// The summation order is the documented one (glv_frame.h "GLV_OP_BARS arithmetic": chunks of 16 / 32 / 64 taps, per chunk 2 / 4 / 8
-// octet sums, each the sum of two fused-multiply-add chains, combined pairwise, chunk totals in order), walked octet by octet with a
-// three-deep stack of partial sums: the same bits as glv_bars_kernel and the fused epilogue.  The final division by the bar's weight
-// sum is three instructions with the host's reciprocal (glv_tables.h bar_rcp_division_ok: the correctly rounded quotient).
-constexpr int kRowsWaves = 8, kRowsTileBars = 64, kRowsStagePitch = 65;     // N = 4096: 2 x (60 KiB ring + 16.3 KiB stage) fit a CU's 160 KiB
-template <int S, int GL>
+// MANY bars (>= 256: the pre-smoothing pass of render.c:2277-2303, bars == n -- one output per texel, ~58 taps each at n = 4096,
+// 237 K multiply-adds per row).  From 256 bars up a bar is one fused-multiply-add chain over its taps in bin order (glv_frame.h
+// "GLV_OP_BARS arithmetic", glv_tables.h make_bar_mtiles), and a tap of weight +0 leaves a chain untouched -- so the 32 chains of a
+// tile of consecutive bars can all run over the tile's common bin range, which makes the pass a banded matrix product:
+//     out[row][bar] = sum over bins of x[row][bin] * w[bin][bar]          (then / weight_sum[bar])
+//
+// glv_bars_rows_kernel (>= 256 rows): the matrix cores.  One v_mfma_f32_32x32x2_f32 is 32 rows x 32 bars x 2 bins, and on gfx950 it
+// IS the k-ordered fmaf chain (tools/mfma_probe.hip: bit for bit, subnormals and zeros included) -- the documented arithmetic, at the
+// f32 matrix rate.  A workgroup is four waves on the SAME 64 rows.  The rows' texels live in LDS as a RING of S bins, [bin mod S][row]
+// (the a-operand of a step -- lane l: row l % 32 of the half, bin 2 s + l / 32 -- is one conflict-free ds_read_b32), clamped to
+// [0, 1] (NaN -> 0) once when they are parked; the weights of a step are one coalesced 256-byte load in b-operand layout, requested
+// eight steps ahead.  The bars' first bins grow slowly (4096 bars cover 1250 bins), so a ROUND -- four tiles, wave w takes tile w
+// (host table) -- needs only a few bins the previous round did not have: requested before the round's arithmetic, written behind it
+// into slots no wave of the round reads (the table guarantees end(t + 1) - origin(t) <= S); one barrier per round.  With rows as the
+// result's rows a result register holds, across lanes 0..31 / 32..63, 32 consecutive bars of ONE row: every store instruction is two
+// whole 128-byte (texels: 64-byte) row segments, straight from the accumulators, and a lane's 32 results all belong to one bar --
+// one weight sum, one reciprocal (glv_tables.h bar_rcp_division_ok: three instructions give the correctly rounded quotient).
+// Round 4's earlier versions, for the record (profiles/r04/rows_kernel.txt; N = 4096 x 32 K rows): one lane per row and one bar
+// per wave with v_fmac_f32_dpp, LDS-bandwidth-bound, 1.33 ms; eight bars per wave sharing the texels with the weights as SGPR pairs
+// for v_pk_fma_f32 (chunked summation, groups of bars padded to one first bin), bound by the L2 round trips of its scalar weight
+// stream, 0.60 ms.
+constexpr int kRowsWaves = 4;
+typedef float glv_f16v __attribute__((ext_vector_type(16)));
+template <int S>
 __global__ void __launch_bounds__(64 * kRowsWaves) glv_bars_rows_kernel(const float* __restrict__ spec, void* __restrict__ bars_out, size_t nrows, uint32_t n,
-                                                                        uint32_t bars, const BarTile* __restrict__ tiles, uint32_t ntiles, uint32_t tiles_per_wg,
-                                                                        const BarGroupDesc* __restrict__ groups, const float* __restrict__ wg,
+                                                                        uint32_t bars, const BarTile* __restrict__ rounds, uint32_t nrounds, uint32_t rounds_per_wg,
+                                                                        const BarMTile* __restrict__ mtiles, const float* __restrict__ wt,
                                                                         const float* __restrict__ wsum, int r16) {
-#if defined(__HIP_DEVICE_COMPILE__)                     /* packed-f32 inline assembly: the host pass sees an empty stub */
-    extern __shared__ float rows_lds[];                 // [S / 4][64] x 4 texels: the ring | [64][65] finished outputs of the round
-    constexpr uint32_t NS = S / 4;                      // slots
-    static_assert(S % 8 == 0 && kRowsTileBars == 8 * kRowsWaves, "a wave per group of eight bars; a step's two slots never straddle the ring's end");
-    BarW4* win = reinterpret_cast<BarW4*>(rows_lds);
-    float* stage = rows_lds + (size_t) S * 64;
+#if defined(__HIP_DEVICE_COMPILE__)
+    extern __shared__ float rows_lds[];                 // [S][64]: the ring
+    static_assert(S % 4 == 0, "a parked slot of four bins never straddles the ring's end");
+    constexpr int PF = 8;                               // steps of weights in flight
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = (uint32_t) __builtin_amdgcn_readfirstlane((int) (threadIdx.x >> 6));
     const size_t row0 = (size_t) blockIdx.x * 64;
     if (row0 >= nrows) return;
     const uint32_t R = (uint32_t) (nrows - row0 < 64 ? nrows - row0 : 64);
     const float* src = spec + (row0 + (lane < R ? lane : R - 1)) * (size_t) n;
-    const uint32_t t_begin = blockIdx.y * tiles_per_wg, t_end = t_begin + tiles_per_wg < ntiles ? t_begin + tiles_per_wg : ntiles;
+    const uint32_t t_begin = blockIdx.y * rounds_per_wg, t_end = t_begin + rounds_per_wg < nrounds ? t_begin + rounds_per_wg : nrounds;
+    if (t_begin >= t_end) return;
     const glv_f2 ones = {1.0f, 1.0f};
-    BarW4* win_lane = win + lane;
-    struct HalfW { glv_f2 w[16]; };                     // a half step: bars 4 h .. 4 h + 3 of the group x 4 tap pairs, 32 SGPRs
-    auto load_half = [&](const float* wp) {
-        HalfW h;
-        const glv_f2* p = reinterpret_cast<const glv_f2*>(wp);
-#pragma unroll
-        for (int q = 0; q < 16; ++q) h.w[q] = p[q];
-        return h;
-    };
-    // 4 bins of this lane's row: one slot of the ring; clamped here, once per texel, instead of once per tap: [0, 1] like the GL_R16
-    // texel the shader samples, NaN -> 0 (v_pk_mul_f32 x, 1.0 clamp -- the operation bar_item_lane_sum applies to every tap: same bits)
+    // 4 bins of this lane's row; clamped here, once per texel: [0, 1] like the GL_R16 texel the shader samples, NaN -> 0 (v_pk_mul_f32
+    // x, 1.0 clamp -- the operation bar_item_lane_sum applies to every tap)
     auto fetch = [&](uint32_t bin) {
 #if defined(GLV_EXP_ROWS_NOFILL)        /* timing experiment (wrong results): no row loads */
         return BarW4{{(float) bin, 0.5f, 0.25f, (float) lane}};
@@ -436,13 +422,16 @@ __global__ void __launch_bounds__(64 * kRowsWaves) glv_bars_rows_kernel(const fl
         glv_f2 lo = {v.w[0], v.w[1]}, hi = {v.w[2], v.w[3]};
         asm("v_pk_mul_f32 %0, %1, %2 clamp" : "=v"(lo) : "v"(lo), "v"(ones));
         asm("v_pk_mul_f32 %0, %1, %2 clamp" : "=v"(hi) : "v"(hi), "v"(ones));
-        win_lane[(size_t) ((bin / 4u) % NS) * 64] = BarW4{{lo.x, lo.y, hi.x, hi.y}};
+        float* at = rows_lds + (size_t) (bin % (uint32_t) S) * 64 + lane;
+        at[0] = lo.x; at[64] = lo.y; at[128] = hi.x; at[192] = hi.y;
     };
-    if (t_begin >= t_end) return;
+    // the ring starts as zeros: the padded steps of a tile read slots nothing was parked in yet, with weight +0 -- 0 * x must be +0
+    for (uint32_t i = threadIdx.x; i < (uint32_t) S * 64u; i += 64 * kRowsWaves) rows_lds[i] = 0.0f;
+    __syncthreads();
     // the first round's whole window: four loads of a wave are in flight before the first is parked
     uint32_t filled_to;
     {
-        const BarTile T = tiles[t_begin];
+        const BarTile T = rounds[t_begin];
         const uint32_t ncol = (T.end - T.origin) / 4u;
         for (uint32_t cb = wave * 4u; cb < ncol; cb += kRowsWaves * 4) {
             BarW4 v4[4];
@@ -455,19 +444,19 @@ __global__ void __launch_bounds__(64 * kRowsWaves) glv_bars_rows_kernel(const fl
         filled_to = T.end;
     }
     __syncthreads();
+    // lane part of an a-operand address: row (lane % 32) of a half, the odd bin of the pair for lanes 32..63
+    const float* xlane = rows_lds + (lane >> 5) * 64u + (lane & 31u);
     for (uint32_t t = t_begin; t < t_end; ++t) {
-        const BarTile T = tiles[t];                                             // uniform: scalar loads
-        const bool valid = T.k0 + 8u * wave < T.k1;
-        const BarGroupDesc g = groups[valid ? T.k0 / 8u + wave : T.k0 / 8u];
+        const BarTile T = rounds[t];                                            // uniform: scalar loads
+        const bool valid = T.k0 + wave < T.k1;
+        const BarMTile M = mtiles[valid ? T.k0 + wave : T.k0];
         // what the next round adds to the ring: requested now, parked behind this round's arithmetic (up to two slots per wave in
-        // registers, which is what a round adds at most in practice; the rest after them)
-        const uint32_t next_end = t + 1 < t_end ? tiles[t + 1].end : filled_to;
+        // registers -- what a round adds at most in practice --, the rest after them)
+        const uint32_t next_end = t + 1 < t_end ? rounds[t + 1].end : filled_to;
         const uint32_t nnew = next_end > filled_to ? (next_end - filled_to) / 4u : 0u;
         BarW4 pre[2];
 #pragma unroll
         for (uint32_t q = 0; q < 2; ++q) pre[q] = fetch(filled_to + 4u * (wave + kRowsWaves * q < nnew ? wave + kRowsWaves * q : 0u));
-        // the next round's new slots, none of which this round's groups read.  Parked BEFORE this round's stores are issued: vmcnt
-        // retires in order, so a wait for these loads behind the stores would wait for the stores (which take microseconds)
         auto park_new = [&]() {
 #pragma unroll
             for (uint32_t q = 0; q < 2; ++q)
@@ -475,168 +464,122 @@ __global__ void __launch_bounds__(64 * kRowsWaves) glv_bars_rows_kernel(const fl
             for (uint32_t c = wave + 2u * kRowsWaves; c < nnew; c += kRowsWaves) park(fetch(filled_to + 4u * c), filled_to + 4u * c);
         };
 #if defined(GLV_EXP_ROWS_NOCOMPUTE)
-        if (valid) park_new();
+        park_new();
 #else
         if (valid) {
-            const uint32_t steps = (uint32_t) __builtin_amdgcn_readfirstlane((int) g.steps);
-#if defined(GLV_EXP_ROWS_SAMEW)
-            const float* wp = wg;
-#else
-            const float* wp = wg + (uint32_t) __builtin_amdgcn_readfirstlane((int) g.w_off);
-#endif
-            uint32_t slot = (uint32_t) __builtin_amdgcn_readfirstlane((int) g.slot0);       // even; a step reads slots slot, slot + 1, then moves on two (wrapping)
-            // per pair of bars {2 i, 2 i + 1}: the running total and the stack of partial sums of the chunk under way
-            glv_f2 tot[4], p0[4], p1[4], p2[4];
+            const uint32_t steps = (uint32_t) __builtin_amdgcn_readfirstlane((int) M.steps);        // a multiple of 4 (glv_tables.h kBarStepPad)
+            const float* wp = wt + (uint32_t) __builtin_amdgcn_readfirstlane((int) M.w_off) + lane;
+            uint32_t sb = (uint32_t) __builtin_amdgcn_readfirstlane((int) (M.origin % (uint32_t) S));   // ring slot of the step's even bin
+            glv_f16v acc0 = {0}, acc1 = {0};                                    // rows 0..31 / 32..63 of the block x the tile's 32 bars
+            // software pipeline: the weights eight steps ahead (PF registers, each reloaded as soon as its step has used it), the texels
+            // one step ahead; a step is two MFMAs (rows 0..31 and 32..63 of the block) on the same weights
+            float w[PF];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) tot[i] = p0[i] = p1[i] = p2[i] = glv_f2{0.0f, 0.0f};
-            HalfW wcur = load_half(wp);
-            const float* wnext = wp + 32;                                       // the weight stream, one half step ahead: a running scalar pointer
-            BarW4 xa = win_lane[(size_t) slot * 64], xc = win_lane[(size_t) slot * 64 + 64];
-            slot = slot + 2u == NS ? 0u : slot + 2u;
-            auto pk_add = [](glv_f2 a2, glv_f2 b2) { glv_f2 r; asm("v_pk_add_f32 %0, %1, %2" : "=v"(r) : "v"(a2), "v"(b2)); return r; };
-            // one octet of texels x eight bars; L = the octet's place in its chunk (compile time: the tree of partial sums --
-            // group_sum's order: neighbours, pairs of pairs, the two quads -- built as the octets arrive)
-            auto step = [&](auto LC) {
-                constexpr int L = decltype(LC)::value;
-                const BarW4 na = win_lane[(size_t) slot * 64], nc = win_lane[(size_t) slot * 64 + 64];       // the next step's texels (one step past the group's end is read and dropped)
-                slot = slot + 2u == NS ? 0u : slot + 2u;
-                const glv_f2 x01 = {xa.w[0], xa.w[1]}, x23 = {xa.w[2], xa.w[3]}, x45 = {xc.w[0], xc.w[1]}, x67 = {xc.w[2], xc.w[3]};
-#pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                    const HalfW wn = load_half(wnext);                            // one half step ahead (64 floats of slack follow the table)
-#if defined(GLV_EXP_ROWS_SAMEW)         /* timing experiment (wrong results): every half step reads the same 128 bytes -- scalar-cache hits */
-                    wnext = wp + (((wnext - wp) + 32) & 32);
-#else
-                    wnext += 32;
-#endif
-                    // {even chain, odd chain} of the half step's four bars, interleaved (a dependent packed op two slots later costs a wait
-                    // state); first link: fma(x, w, +0) == x * w (both >= +0)
-                    glv_f2 ac[4], o[2];
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) asm("v_pk_mul_f32 %0, %1, %2" : "=v"(ac[q]) : "v"(x01), "s"(wcur.w[4 * q + 0]));
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) asm("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(ac[q]) : "v"(x23), "s"(wcur.w[4 * q + 1]));
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) asm("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(ac[q]) : "v"(x45), "s"(wcur.w[4 * q + 2]));
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) asm("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(ac[q]) : "v"(x67), "s"(wcur.w[4 * q + 3]));
-                    asm("v_add_f32 %0, %1, %2" : "=v"(o[0].x) : "v"(ac[0].x), "v"(ac[0].y));
-                    asm("v_add_f32 %0, %1, %2" : "=v"(o[0].y) : "v"(ac[1].x), "v"(ac[1].y));
-                    asm("v_add_f32 %0, %1, %2" : "=v"(o[1].x) : "v"(ac[2].x), "v"(ac[2].y));
-                    asm("v_add_f32 %0, %1, %2" : "=v"(o[1].y) : "v"(ac[3].x), "v"(ac[3].y));
-#pragma unroll
-                    for (int bp = 0; bp < 2; ++bp) {
-                        const int i = 2 * h + bp;
-                        if constexpr (L == 0) p0[i] = o[bp];
-                        else if constexpr (L == 1) p0[i] = pk_add(p0[i], o[bp]);
-                        else if constexpr (L == 2 || L == 4) p1[i] = o[bp];
-                        else if constexpr (L == 5) p1[i] = pk_add(p1[i], o[bp]);
-                        else if constexpr (L == 3) p0[i] = pk_add(p0[i], pk_add(p1[i], o[bp]));
-                        else if constexpr (L == 6) p2[i] = o[bp];
-                        else p0[i] = pk_add(p0[i], pk_add(p1[i], pk_add(p2[i], o[bp])));
-                    }
-                    wcur = wn;
-                }
-                xa = na; xc = nc;
-                GLV_SCHED_FENCE();
+            for (int i = 0; i < PF; ++i) w[i] = wp[(size_t) i * 64];            // (64 * 2 * kBarStepPad floats of slack follow the table)
+            wp += (size_t) PF * 64;
+            float xa = xlane[(size_t) sb * 64], xb = xlane[(size_t) sb * 64 + 32];
+            sb = sb + 2u == (uint32_t) S ? 0u : sb + 2u;
+            auto step = [&](int u) {
+                const float na = xlane[(size_t) sb * 64], nb = xlane[(size_t) sb * 64 + 32];      // (one step past the tile's end is read and dropped)
+                sb = sb + 2u == (uint32_t) S ? 0u : sb + 2u;
+                const float wcur = w[u];
+                w[u] = wp[0];
+                wp += 64;
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(xa, wcur, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(xb, wcur, acc1, 0, 0, 0);
+                xa = na; xb = nb;
             };
-            // whole chunks: after the last octet everything is folded into p0
-            const uint32_t full = steps / (uint32_t) GL, rem = steps % (uint32_t) GL;
-            for (uint32_t c = 0; c < full; ++c) {
-                step(std::integral_constant<int, 0>{});
-                step(std::integral_constant<int, 1>{});
-                if constexpr (GL >= 4) { step(std::integral_constant<int, 2>{}); step(std::integral_constant<int, 3>{}); }
-                if constexpr (GL >= 8) {
-                    step(std::integral_constant<int, 4>{}); step(std::integral_constant<int, 5>{});
-                    step(std::integral_constant<int, 6>{}); step(std::integral_constant<int, 7>{});
-                }
+            uint32_t s = 0;
+            for (; s + 8u <= steps; s += 8u) {
 #pragma unroll
-                for (int i = 0; i < 4; ++i) tot[i] = pk_add(tot[i], p0[i]);
+                for (int u = 0; u < 8; ++u) step(u);
             }
-            // the last, partial chunk: the octets the bars do not have are +0 and x + 0 == x for x >= +0, so what is parked is added
-            // in the tree's order and nothing else: rem = 1, 2, 4: p0;  3, 5, 6: p0 + p1;  7: p0 + (p1 + p2)
-            if (rem) {
-                for (uint32_t r = 0; r < rem; ++r) {
-                    switch (r) {
-                        case 0: step(std::integral_constant<int, 0>{}); break;
-                        case 1: step(std::integral_constant<int, 1>{}); break;
-                        case 2: step(std::integral_constant<int, GL >= 4 ? 2 : 0>{}); break;
-                        case 3: step(std::integral_constant<int, GL >= 4 ? 3 : 0>{}); break;
-                        case 4: step(std::integral_constant<int, GL >= 8 ? 4 : 0>{}); break;
-                        case 5: step(std::integral_constant<int, GL >= 8 ? 5 : 0>{}); break;
-                        default: step(std::integral_constant<int, GL >= 8 ? 6 : 0>{}); break;
-                    }
-                }
+            if (s < steps) {                                                    // steps is a multiple of 4: one half turn is left
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    glv_f2 sum = p0[i];
-                    if (rem == 7) sum = pk_add(sum, pk_add(p1[i], p2[i]));
-                    else if (rem == 3 || rem == 5 || rem == 6) sum = pk_add(sum, p1[i]);
-                    tot[i] = pk_add(tot[i], sum);
-                }
+                for (int u = 0; u < 4; ++u) step(u);
             }
             park_new();
-            // total / weight sum: with the host's reciprocal where that is the correctly rounded quotient (glv_tables.h
-            // bar_rcp_division_ok; not for a total so small that the remainder below would be inexact), else the long way
-            const uint32_t kg = T.k0 + 8u * wave;
-            struct WS { glv_f2 v[8]; };                                         // {weight sum, its reciprocal or 0} of the eight bars: scalar loads
-            const WS ws = *reinterpret_cast<const WS*>(wsum + 2u * kg);
-            float q[8];
-            bool fast = true;
+            // a lane's 32 results are one bar (k0 + lane % 32) of the rows 8 (r / 4) + 4 (lane / 32) + r % 4 (+ 32 for acc1)
+            const uint32_t kb = M.k0 + (lane & 31u);
+            const glv_f2 ws = *reinterpret_cast<const glv_f2*>(wsum + 2u * (size_t) kb);       // {weight sum, its reciprocal or 0} (padded to whole tiles)
+            float q[32];
+            float tmin = 1.0f;                                                  // is some total in (0, 2^-90)?  (totals are >= +0)
 #pragma unroll
-            for (int j = 0; j < 8; ++j) fast = fast && ws.v[j].y != 0.0f;
-            float tmax = 0.0f;                                                  // is some total in (0, 2^-90)?  (totals are >= +0)
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const float a0 = tot[i].x == 0.0f ? 1.0f : tot[i].x, a1 = tot[i].y == 0.0f ? 1.0f : tot[i].y;
+            for (int r = 0; r < 16; ++r) {
+                const float a0 = acc0[r] == 0.0f ? 1.0f : acc0[r], a1 = acc1[r] == 0.0f ? 1.0f : acc1[r];
                 const float mn = a0 < a1 ? a0 : a1;
-                tmax = i == 0 ? mn : (mn < tmax ? mn : tmax);
+                tmin = mn < tmin ? mn : tmin;
             }
-            fast = fast && !__builtin_amdgcn_readfirstlane((int) (__ballot(tmax < 0x1p-90f) != 0ull));
+            const bool fast = __ballot(ws.y == 0.0f || tmin < 0x1p-90f) == 0ull;
             if (fast) {
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const float a = j & 1 ? tot[j / 2].y : tot[j / 2].x, bsum = ws.v[j].x, r = ws.v[j].y;
-                    const float q0 = a * r;
-                    const float rm = __builtin_fmaf(-q0, bsum, a);
-                    q[j] = __builtin_fmaf(rm, r, q0);
+                for (int r = 0; r < 32; ++r) {
+                    const float a = r < 16 ? acc0[r & 15] : acc1[r & 15];
+                    const float q0 = a * ws.y;
+                    const float rm = __builtin_fmaf(-q0, ws.x, a);
+                    q[r] = __builtin_fmaf(rm, ws.y, q0);
                 }
             } else {
 #pragma unroll
-                for (int j = 0; j < 8; ++j) q[j] = (j & 1 ? tot[j / 2].y : tot[j / 2].x) / ws.v[j].x;
+                for (int r = 0; r < 32; ++r) q[r] = (r < 16 ? acc0[r & 15] : acc1[r & 15]) / ws.x;
             }
-            // parked for the round's flush: scattered 16 / 32-byte stores straight from here (one line per lane and instruction) cost more
-            // than the arithmetic -- every later wait for a load then waits for their acknowledgements (vmcnt retires in order)
+            if (kb < bars) {
 #pragma unroll
-            for (int j = 0; j < 8; ++j) stage[(size_t) (8u * wave + (uint32_t) j) * kRowsStagePitch + lane] = q[j];
-        }
-#endif
-        if (!valid) park_new();
-        filled_to = next_end > filled_to ? next_end : filled_to;
-        __syncthreads();
-        // the round's m bars of R rows: every row's m values are one contiguous segment of the output; wave w takes rows w, w + 8, ...
-        {
-            const uint32_t m = T.k1 - T.k0;
-            const float* sp = stage + (size_t) lane * kRowsStagePitch;
-            const size_t at0 = (row0 + wave) * (size_t) bars + T.k0 + lane;
-#pragma unroll
-            for (uint32_t i = 0; i < 64u / kRowsWaves; ++i) {
-                const uint32_t jr = wave + kRowsWaves * i;
-#if defined(GLV_EXP_ROWS_NOFLUSH)       /* timing experiment (wrong results): one store in 64 */
-                if (jr < R && lane < m && lane == 0) {
+                for (int r = 0; r < 32; ++r) {
+                    const uint32_t jr = 32u * (uint32_t) (r / 16) + 8u * (uint32_t) ((r & 15) / 4) + 4u * (lane >> 5) + (uint32_t) (r & 3);
+#if defined(GLV_EXP_ROWS_NOFLUSH)       /* timing experiment (wrong results): one store in 32 */
+                    if (jr < R && r == 0) {
 #else
-                if (jr < R && lane < m) {
+                    if (jr < R) {
 #endif
-                    const float v = sp[jr];
-                    const size_t at = at0 + (size_t) (kRowsWaves * i) * bars;
-                    if (r16) reinterpret_cast<uint16_t*>(bars_out)[at] = (uint16_t) pack_unorm16(v, 0.0f);
-                    else reinterpret_cast<float*>(bars_out)[at] = v;
+                        const size_t at = (row0 + jr) * (size_t) bars + kb;
+                        if (r16) reinterpret_cast<uint16_t*>(bars_out)[at] = (uint16_t) pack_unorm16(q[r], 0.0f);
+                        else reinterpret_cast<float*>(bars_out)[at] = q[r];
+                    }
                 }
             }
+        } else {
+            park_new();
         }
-        __syncthreads();                                                        // the stage is free for the next round
+#endif
+        filled_to = next_end > filled_to ? next_end : filled_to;
+        __syncthreads();
     }
 #endif
+}
+
+// The same arithmetic with one lane per bar, off the same tables: few rows (a single GLava instance has two), or bars whose taps do
+// not fit the LDS ring (n >= 8192).  A wave = two tiles of one row; the row is read through L1 (32 lanes share a texel).
+__global__ void __launch_bounds__(256) glv_bars_seq_kernel(const float* __restrict__ spec, void* __restrict__ bars_out, size_t nrows, uint32_t n, uint32_t bars,
+                                                          const BarMTile* __restrict__ mtiles, uint32_t ntiles, const float* __restrict__ wt,
+                                                          const float* __restrict__ wsum, int r16) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const size_t units = nrows * (size_t) ((ntiles + 1u) / 2u);
+    for (size_t u = (size_t) blockIdx.x * (blockDim.x / 64) + (threadIdx.x >> 6); u < units; u += (size_t) gridDim.x * (blockDim.x / 64)) {
+        const size_t row = u / ((ntiles + 1u) / 2u);
+        const uint32_t T = 2u * (uint32_t) (u % ((ntiles + 1u) / 2u)) + (lane >> 5);
+        if (T >= ntiles) continue;
+        const BarMTile M = mtiles[T];
+        const float* x = spec + row * (size_t) n;
+        const float* wp = wt + M.w_off + (lane & 31u);
+        float acc = 0.0f;
+        for (uint32_t i = 0; i < 2u * M.steps; ++i) {
+            const uint32_t bin = M.origin + i;
+            float xv = x[bin < n ? bin : n - 1u];                               // (padded steps: weight +0)
+#if defined(__HIP_DEVICE_COMPILE__)
+            asm("v_mul_f32 %0, 1.0, %1 clamp" : "=v"(xv) : "v"(xv));            // [0, 1], NaN -> 0: what the rows kernel parks
+#else
+            xv = xv > 0.0f ? (xv < 1.0f ? xv : 1.0f) : 0.0f;
+#endif
+            acc = __builtin_fmaf(xv, wp[(size_t) i * 32], acc);
+        }
+        const uint32_t kb = M.k0 + (lane & 31u);
+        if (kb < bars) {
+            const float v = acc / wsum[2u * (size_t) kb];
+            if (r16) reinterpret_cast<uint16_t*>(bars_out)[row * bars + kb] = (uint16_t) unorm16(v);
+            else reinterpret_cast<float*>(bars_out)[row * bars + kb] = v;
+        }
+    }
 }
 
 // the s16 window as float pairs: glv_winsplit.h (shared with the knob-sweep harness glv_tune.hip)
@@ -723,69 +666,59 @@ static void launch_bars_gl(const float* spec, float* bars_out, size_t nrows, uin
     else if (nsteps == 4) hipLaunchKernelGGL((glv_bars_short_kernel<4, 2, GL>), grid((nrows + 1) / 2), dim3(256), 0, st, spec, bars_out, nrows, n, bars, items, desc, tap_w, r);
     else hipLaunchKernelGGL((glv_bars_kernel<GL>), grid(nrows), dim3(256), 0, st, spec, bars_out, nrows, n, bars, nsteps, items, desc, tap_w, r);
 }
-template <int S, int GL>
-static hipError_t launch_bars_rows(const float* spec, float* bars_out, size_t nrows, uint32_t n, uint32_t bars, const BarTile* tiles, uint32_t ntiles,
-                                   const BarGroupDesc* groups, const float* wg, const float* wsum, hipStream_t st, int r) {
-    const size_t lds = sizeof(float) * ((size_t) 64 * S + (size_t) kRowsTileBars * kRowsStagePitch);
+template <int S>
+static hipError_t launch_bars_rows(const float* spec, float* bars_out, size_t nrows, uint32_t n, uint32_t bars, const BarRowsTables& rt, hipStream_t st, int r) {
+    const size_t lds = sizeof(float) * (size_t) 64 * S;
     static std::atomic<bool> done[64] = {};
     if (lds > 64 * 1024) {
         int dev = 0;
         (void) hipGetDevice(&dev);
         if (dev < 0 || dev >= 64 || !done[dev].load(std::memory_order_acquire)) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(glv_bars_rows_kernel<S, GL>), hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(glv_bars_rows_kernel<S>), hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
             if (e != hipSuccess) return e;
             if (dev >= 0 && dev < 64) done[dev].store(true, std::memory_order_release);
         }
     }
     if (nrows == 0) return hipSuccess;                                          // prepare_bars_rows: the attribute only
-    // 64 rows per workgroup in x, ranges of rounds in y: two resident workgroups per CU, twice over (a range start refills the whole
-    // ring; N = 4096: 32 K rows 0.60 / 0.61 / 0.62 ms with 1 / 2 / 4 ranges, 8 K rows 0.48 / 0.19 / 0.18 ms with 1 / 4 / 16)
+    // 64 rows per workgroup in x, ranges of rounds in y: two resident workgroups per CU, twice over (a range start refills the whole ring)
     const uint32_t xb = (uint32_t) ((nrows + 63) / 64);
     uint32_t yb = xb >= 1024 ? 1 : (1024 + xb - 1) / xb;
 #if defined(GLV_TUNE_BUILD)
     if (const char* o = std::getenv("GLV_ROWS_YB")) yb = (uint32_t) atoi(o);       // tools/rows_bench: the split of the rounds over blockIdx.y
 #endif
-    if (yb > ntiles) yb = ntiles;
-    const uint32_t tpw = (ntiles + yb - 1) / yb;
-    yb = (ntiles + tpw - 1) / tpw;
-    hipLaunchKernelGGL((glv_bars_rows_kernel<S, GL>), dim3(xb, yb), dim3(64 * kRowsWaves), lds, st, spec, static_cast<void*>(bars_out), nrows, n, bars, tiles,
-                       ntiles, tpw, groups, wg, wsum, r);
+    if (yb > rt.nrounds) yb = rt.nrounds;
+    const uint32_t rpw = (rt.nrounds + yb - 1) / yb;
+    yb = (rt.nrounds + rpw - 1) / rpw;
+    hipLaunchKernelGGL((glv_bars_rows_kernel<S>), dim3(xb, yb), dim3(64 * kRowsWaves), lds, st, spec, static_cast<void*>(bars_out), nrows, n, bars, rt.rounds,
+                       rt.nrounds, rpw, rt.mtiles, rt.wt, rt.wsum, r);
     return hipGetLastError();
 }
 
-// the > 64 KiB dynamic-LDS opt-in of the rows kernel that launch_bars would pick for (n, rt), set ahead of the first launch (a
-// process call is then a plain launch)
+// the > 64 KiB dynamic-LDS opt-in of the rows kernel that launch_bars would pick for rt, set ahead of the first launch (a process call
+// is then a plain launch)
 hipError_t prepare_bars_rows(uint32_t n, const BarRowsTables* rt) {
-    if (rt == nullptr || rt->tiles == nullptr || rt->ntiles == 0) return hipSuccess;
-#define GLV_ROWS(SS, GG) launch_bars_rows<SS, GG>(nullptr, nullptr, 0, n, 0, rt->tiles, rt->ntiles, rt->groups, rt->wg, rt->wsum, nullptr, 0)
-    switch (bar_lanes_of(n)) {
-        case 2: if (rt->tile_bins == 160) return GLV_ROWS(160, 2); break;
-        case 4: if (rt->tile_bins == 160) return GLV_ROWS(160, 4); break;
-        default:
-            if (rt->tile_bins == 160) return GLV_ROWS(160, 8);
-            if (rt->tile_bins == 240) return GLV_ROWS(240, 8);
-            break;
-    }
-#undef GLV_ROWS
+    if (rt == nullptr || rt->rounds == nullptr || rt->nrounds == 0) return hipSuccess;
+    if (rt->ring_bins == 160) return launch_bars_rows<160>(nullptr, nullptr, 0, n, 0, *rt, nullptr, 0);
+    if (rt->ring_bins == 288) return launch_bars_rows<288>(nullptr, nullptr, 0, n, 0, *rt, nullptr, 0);
     return hipSuccess;
 }
 
 hipError_t launch_bars(const float* spec, float* bars_out, size_t nrows, uint32_t n, uint32_t bars, uint32_t nsteps,
                        const BarItem* items, const BarDesc* desc, const float* tap_w, hipStream_t st, bool r16, const BarRowsTables* rt) {
     const int r = r16 ? 1 : 0;
-    // many bars of many rows (the pre-smoothing pass): one lane per row, eight bars per wave, weights as scalars (glv_bars_rows_kernel),
-    // when the host could cut the bars into tiles that fit an LDS window of rt->tile_bins bins (glv_tables.h make_bar_groups)
-    if (rt != nullptr && rt->tiles != nullptr && rt->ntiles != 0 && bars >= 256 && nrows >= 256) {
-#define GLV_ROWS(SS, GG) launch_bars_rows<SS, GG>(spec, bars_out, nrows, n, bars, rt->tiles, rt->ntiles, rt->groups, rt->wg, rt->wsum, st, r)
-        switch (bar_lanes_of(n)) {
-            case 2: if (rt->tile_bins == 160) return GLV_ROWS(160, 2); break;
-            case 4: if (rt->tile_bins == 160) return GLV_ROWS(160, 4); break;
-            default:
-                if (rt->tile_bins == 160) return GLV_ROWS(160, 8);
-                if (rt->tile_bins == 240) return GLV_ROWS(240, 8);
-                break;
+    // many bars: one fma chain per bar (glv_tables.h make_bar_mtiles) -- on the matrix cores when there are rows to fill them and the
+    // host could cut the tiles into rounds for the LDS ring, one lane per bar otherwise
+    if (bars >= 256) {
+        if (rt == nullptr || rt->mtiles == nullptr || rt->ntiles == 0) return hipErrorInvalidValue;
+        if (rt->rounds != nullptr && rt->nrounds != 0 && nrows >= 256) {
+            if (rt->ring_bins == 160) return launch_bars_rows<160>(spec, bars_out, nrows, n, bars, *rt, st, r);
+            if (rt->ring_bins == 288) return launch_bars_rows<288>(spec, bars_out, nrows, n, bars, *rt, st, r);
         }
-#undef GLV_ROWS
+        const size_t units = nrows * (size_t) ((rt->ntiles + 1u) / 2u);
+        const size_t wgs = (units + 3) / 4;
+        hipLaunchKernelGGL(glv_bars_seq_kernel, dim3((unsigned) (wgs < 256 * 16 ? (wgs ? wgs : 1) : 256 * 16)), dim3(256), 0, st, spec, static_cast<void*>(bars_out),
+                           nrows, n, bars, rt->mtiles, rt->ntiles, rt->wt, rt->wsum, r);
+        return hipGetLastError();
     }
     switch (bar_lanes_of(n)) {                                   // the work lists were made for 256 / bar_lanes_of(n) groups
         case 2: launch_bars_gl<2>(spec, bars_out, nrows, n, bars, nsteps, items, desc, tap_w, st, r); break;

@@ -110,26 +110,19 @@ inline size_t make_smooth_bounds(int* smin, int* smax, size_t sz, float smooth_d
 //   smin/smax = scale_audio(clamp(idx -/+ factor)) * n,  scale_audio(u) = -log(1 - 0.9u)/8
 //   m = (smax - smin)/2, rm = smin + m;  for s = smin; s <= smax; s += 1:  w = sinusoidal(clamp((m - |rm - s|)/m))
 //   sample bin int(round(s)).  Consecutive s round to consecutive bins, so a bar is a contiguous bin range.
-// Group rule (round 4): with bars >= kBarGroupMin (the pre-smoothing pass and other many-bar uses) the bars come in GROUPS of
-// kBarGroup = 8 consecutive bars that all start at the group's bin A = (smallest first bin of the group) & ~7: a bar whose own first
-// tap is d bins further right gets d leading taps of weight +0 (count and the chunk structure include them; weight_sum does not
-// change -- it is the tap-order sum and 0 + w == w).  Every value is what smooth_audio() defines, the SUMMATION is regrouped:
-// the eight bars of a group walk the same bins in the same octets, which is what lets one lane of glv_bars_rows_kernel load an octet
-// of texels once for eight bars (glv_misc.hip); the test suite's CPU restatement applies the same rule.
-constexpr uint32_t kBarGroup = 8, kBarGroupMin = 256;
 inline void make_bar_taps(std::vector<BarDesc>& desc, std::vector<float>& tap_w, uint32_t n, uint32_t bars, float smooth_factor, float phase = 0.0f) {
     const uint32_t chunk = bar_chunk_of(n);
     auto scale = [](float u) { return -logf((-0.9f * u) + 1.0f) / 8.0f; };
     auto clamp01 = [](float x) { return x < 0.0f ? 0.0f : (x > 1.0f ? 1.0f : x); };
     desc.resize(bars);
     tap_w.clear();
-    std::vector<std::vector<float>> w_of(bars);
     for (uint32_t k = 0; k < bars; ++k) {
         const float idx = phase == 0.0f ? (float) k / (float) bars : ((float) k + phase) / (float) bars;   // gl_FragCoord.x / w
         const float smin = scale(clamp01(idx - smooth_factor)) * (float) n;
         const float smax = scale(clamp01(idx + smooth_factor)) * (float) n;
         const float m = (smax - smin) / 2.0f, rm = smin + m;
         BarDesc d{};
+        d.tap_offset = (uint32_t) tap_w.size();
         float weight = 0.0f;
         bool first = true;
         uint32_t prev_bin = 0;
@@ -138,35 +131,17 @@ inline void make_bar_taps(std::vector<BarDesc>& desc, std::vector<float>& tap_w,
             const uint32_t bin = (uint32_t) (int) roundf(sx);
             if (first) { d.first_bin = bin; first = false; }
             else if (bin != prev_bin + 1) {          // (never for step 1.0; keep the range contiguous regardless)
-                for (uint32_t g = prev_bin + 1; g < bin; ++g) w_of[k].push_back(0.0f);
+                for (uint32_t g = prev_bin + 1; g < bin; ++g) tap_w.push_back(0.0f);
             }
             prev_bin = bin;
             weight += w;
-            w_of[k].push_back(w);
+            tap_w.push_back(w);
         }
-        d.weight_sum = weight;
-        desc[k] = d;
-    }
-    for (uint32_t k = 0; k < bars; ++k) {
-        BarDesc& d = desc[k];
-        uint32_t lead = 0;
-        if (bars >= kBarGroupMin) {
-            const uint32_t g0 = k / kBarGroup * kBarGroup, g1 = g0 + kBarGroup < bars ? g0 + kBarGroup : bars;
-            uint32_t a = 0xffffffffu;
-            for (uint32_t j = g0; j < g1; ++j) {        // bars before k already carry the group's start, which is <= their own first bin
-                const uint32_t fb = desc[j].first_bin;
-                a = fb < a ? fb : a;
-            }
-            a &= ~7u;
-            lead = d.first_bin - a;
-            d.first_bin = a;
-        }
-        d.tap_offset = (uint32_t) tap_w.size();
-        tap_w.insert(tap_w.end(), lead, 0.0f);
-        tap_w.insert(tap_w.end(), w_of[k].begin(), w_of[k].end());
         d.count = (uint32_t) tap_w.size() - d.tap_offset;
+        d.weight_sum = weight;
         // zero-pad to whole chunks: the kernels load a chunk's weights unconditionally
         while ((tap_w.size() - d.tap_offset) % chunk) tap_w.push_back(0.0f);
+        desc[k] = d;
     }
 }
 
@@ -205,75 +180,93 @@ inline uint32_t make_bar_items(std::vector<BarItem>& items, const std::vector<Ba
     return nsteps;
 }
 
-// Tables of glv_bars_rows_kernel (bars >= kBarGroupMin: every group of kBarGroup bars starts at one bin, make_bar_taps).
-//   groups[G]: the group's first bin (a multiple of 8), the octet steps that cover its longest bar, where its weights start in wg,
-//              its first slot in the kernel's LDS ring of `bins` bins
-//   wg:        per group and step 64 floats -- [bar of the group 0..7][tap 8 s .. 8 s + 7] -- +0 past a bar's end / for bars past the
-//              last one; the kernel streams them through the scalar cache one half step (4 bars) ahead, so 64 floats of slack follow
-//   wsum:      per bar {weight_sum, 1 / weight_sum}, padded with {1, 1} to whole groups.  The reciprocal is 0 where the kernel must
+// ---- many bars (bars >= kBarSeqMin: the pre-smoothing pass, bars == n) ------------------------------------------------------------
+// From 256 bars up a bar is ONE fused-multiply-add chain over its taps in bin order, from +0:
+//     acc = fma(w[b], x[b], acc),  b = first_bin .. first_bin + count - 1;   bar = acc / weight_sum
+// (glv_frame.h "GLV_OP_BARS arithmetic").  A tap of weight +0 leaves the chain untouched (x is clamped to [0, 1]: 0 * x = +0,
+// acc + 0 = acc), so a tile of 32 bars can run all its chains over ONE common bin range -- 32 bars x 64 rows x 2 bins are one
+// v_mfma_f32_32x32x2_f32 pair (bit for bit a k-ordered fmaf chain on gfx950: tools/mfma_probe.hip), which is what
+// glv_bars_rows_kernel does; glv_bars_seq_kernel walks the same tables with one lane per bar (few rows, or bars too long for the
+// LDS ring).
+//   mtiles[T]: bars [32 T, 32 T + 32): first bin `origin` (a multiple of 4), `steps` pairs of bins (a multiple of kBarStepPad: the
+//              kernels run whole groups of steps; the padding weighs +0), where its weights start in wt
+//   wt:        per tile and step 64 floats -- [bin of the pair 0..1][bar of the tile 0..31] -- exactly the b-operand of the MFMA,
+//              one coalesced load per step; +0 outside a bar's own taps / for bars past the last one
+//   wsum:      per bar {weight_sum, 1 / weight_sum}, padded with {1, 1} to whole tiles.  The reciprocal is 0 where the kernels must
 //              divide the long way (bar_rcp_division_ok)
-//   tiles:     ROUNDS of the kernel: consecutive groups (at most max_bars / 8, one per wave) whose bins [origin, end) fit the ring
-//              together with what the NEXT round adds to it (its new bins are written while this round still reads its own):
-//              end(t) - origin(t) <= bins and end(t + 1) - origin(t) <= bins; origins and ends are monotone
-// false when a group does not fit alone or the groups' first bins are not monotone (the kernel is then not used).
+//   rounds:    consecutive tiles (at most tiles_per_round, one per wave) whose bins [origin, end) fit an LDS ring of `bins` bins
+//              together with what the NEXT round adds to it: end(t) - origin(t) <= bins and end(t + 1) - origin(t) <= bins; empty
+//              when some tile does not fit or the first bins are not monotone (glv_bars_rows_kernel is then not used)
 //
 // bar_rcp_division_ok: a / b as q0 = a * r, rem = fma(-q0, b, a), q = fma(rem, r, q0) with r = RN(1 / b) is the correctly rounded
 // quotient (Markstein 1990) unless b's significand is all ones; a is a sum of [0, 1] texels times the weights, b their sum:
-// no overflow, and the kernel takes the long way itself for 0 < a < 2^-90 (where rem would not be exact).  tests/test_emulator.py
-// checks every significand of a against every b of the shipped sizes.
+// no overflow, and the kernels take the long way themselves for 0 < a < 2^-90 (where rem would not be exact).  tests/test_emulator.py
+// checks every significand of a against the weight sums of the shipped sizes.
+constexpr uint32_t kBarSeqMin = 256, kBarTileBars = 32, kBarStepPad = 4;      // (the kernels prefetch 8 steps of weights: 64 * 2 * kBarStepPad floats of slack)
 inline bool bar_rcp_division_ok(float b) {
     const uint32_t u = __builtin_bit_cast(uint32_t, b);
     return b >= 0x1p-60f && b <= 0x1p60f && (u & 0x7fffffu) != 0x7fffffu;
 }
-inline bool make_bar_groups(std::vector<BarGroupDesc>& groups, std::vector<float>& wg, std::vector<float>& wsum, std::vector<BarTile>& tiles,
-                            const std::vector<BarDesc>& desc, const std::vector<float>& tap_w, uint32_t n, uint32_t bins, uint32_t max_bars) {
-    groups.clear(); wg.clear(); wsum.clear(); tiles.clear();
+inline bool make_bar_mtiles(std::vector<BarMTile>& mtiles, std::vector<float>& wt, std::vector<float>& wsum, std::vector<BarTile>& rounds,
+                            const std::vector<BarDesc>& desc, const std::vector<float>& tap_w, uint32_t n, uint32_t bins, uint32_t tiles_per_round) {
+    mtiles.clear(); wt.clear(); wsum.clear(); rounds.clear();
     const uint32_t bars = (uint32_t) desc.size();
-    if (bars < kBarGroupMin || max_bars % kBarGroup || bins % 8u) return false;
-    const uint32_t ng = (bars + kBarGroup - 1) / kBarGroup;
-    for (uint32_t G = 0; G < ng; ++G) {
-        const uint32_t k0 = G * kBarGroup, k1 = k0 + kBarGroup < bars ? k0 + kBarGroup : bars;
-        BarGroupDesc g{desc[k0].first_bin, 0u, (uint32_t) wg.size(), 0u};
-        if (g.first_bin % 8u) return false;
-        g.slot0 = (g.first_bin / 4u) % (bins / 4u);
+    if (bars < kBarSeqMin) return false;
+    const uint32_t nt = (bars + kBarTileBars - 1) / kBarTileBars;
+    bool monotone = true;
+    for (uint32_t T = 0; T < nt; ++T) {
+        const uint32_t k0 = T * kBarTileBars, k1 = k0 + kBarTileBars < bars ? k0 + kBarTileBars : bars;
+        uint32_t lo = 0xffffffffu, hi = 0;
         for (uint32_t k = k0; k < k1; ++k) {
-            if (desc[k].first_bin != g.first_bin) return false;                 // not the grouped tables
-            const uint32_t st = (desc[k].count + 7u) / 8u;
-            g.steps = st > g.steps ? st : g.steps;
+            lo = desc[k].first_bin < lo ? desc[k].first_bin : lo;
+            hi = desc[k].first_bin + desc[k].count > hi ? desc[k].first_bin + desc[k].count : hi;
         }
-        if (g.first_bin + 8u * g.steps > n) return false;
-        if (G && g.first_bin < groups[G - 1].first_bin) return false;           // not monotone
-        for (uint32_t s = 0; s < g.steps; ++s)
-            for (uint32_t j = 0; j < kBarGroup; ++j)
-                for (uint32_t t = 0; t < 8u; ++t) {
-                    const uint32_t k = k0 + j, p = 8u * s + t;
-                    wg.push_back(k < k1 && p < desc[k].count ? tap_w[desc[k].tap_offset + p] : 0.0f);
-                }
-        for (uint32_t j = 0; j < kBarGroup; ++j) {
+        BarMTile t{k0, lo & ~3u, 0u, (uint32_t) wt.size()};
+        t.steps = (hi - t.origin + 1u) / 2u;
+        t.steps = (t.steps + kBarStepPad - 1u) / kBarStepPad * kBarStepPad;
+        if (T && t.origin < mtiles[T - 1].origin) monotone = false;
+        for (uint32_t i = 0; i < 2u * t.steps; ++i)
+            for (uint32_t j = 0; j < kBarTileBars; ++j) {
+                const uint32_t k = k0 + j, bin = t.origin + i;
+                wt.push_back(k < k1 && bin >= desc[k].first_bin && bin < desc[k].first_bin + desc[k].count ? tap_w[desc[k].tap_offset + bin - desc[k].first_bin] : 0.0f);
+            }
+        for (uint32_t j = 0; j < kBarTileBars; ++j) {
             const float ws = k0 + j < k1 ? desc[k0 + j].weight_sum : 1.0f;
             wsum.push_back(ws);
             wsum.push_back(bar_rcp_division_ok(ws) ? 1.0f / ws : 0.0f);
         }
-        groups.push_back(g);
+        mtiles.push_back(t);
     }
-    wg.insert(wg.end(), 64, 0.0f);
-    uint32_t G = 0, prev_origin = 0;
-    while (G < ng) {
-        BarTile t{G * kBarGroup, G * kBarGroup, groups[G].first_bin, tiles.empty() ? 0u : tiles.back().end};      // ends are kept monotone
-        uint32_t H = G;
-        while (H < ng && (H - G) * kBarGroup < max_bars) {
-            const uint32_t e = groups[H].first_bin + 8u * groups[H].steps;
-            const uint32_t end = e > t.end ? e : t.end;
-            if (end - t.origin > bins || (!tiles.empty() && end - prev_origin > bins)) break;
-            t.end = end;
+    wt.insert(wt.end(), 64u * 2u * kBarStepPad, 0.0f);                          // what the kernels' look-ahead reads past the last tile
+    // rounds for the LDS ring (the padded steps read, with weight +0, whatever the ring holds there: only its own bins must fit)
+    uint32_t T = 0, prev_origin = 0;
+    bool fits = monotone && bins % 4u == 0;
+    while (fits && T < nt) {
+        BarTile r{T, T, mtiles[T].origin, rounds.empty() ? 0u : rounds.back().end};       // k0, k1: TILE indices here; ends are kept monotone
+        auto tile_end = [&](uint32_t H) {                                       // last bin + 1 of the tile's own taps, rounded up to a slot
+            uint32_t e = 0;
+            const uint32_t k1 = (H + 1) * kBarTileBars < bars ? (H + 1) * kBarTileBars : bars;
+            for (uint32_t k = H * kBarTileBars; k < k1; ++k) e = desc[k].first_bin + desc[k].count > e ? desc[k].first_bin + desc[k].count : e;
+            return (e + 3u) & ~3u;
+        };
+        uint32_t H = T;
+        while (H < nt && H - T < tiles_per_round) {
+            const uint32_t e = tile_end(H);
+            if (e > n) { fits = false; break; }
+            const uint32_t end = e > r.end ? e : r.end;
+            if (end - r.origin > bins || (!rounds.empty() && end - prev_origin > bins)) break;
+            // the tile after this one must be able to open the next round: its bins are added while this round still reads from r.origin
+            if (H > T && H + 1 < nt && tile_end(H + 1) - r.origin > bins) break;
+            r.end = end;
             ++H;
         }
-        if (H == G) return false;                                                // a single group does not fit
-        t.k1 = H * kBarGroup < bars ? H * kBarGroup : bars;
-        tiles.push_back(t);
-        prev_origin = t.origin;
-        G = H;
+        if (H == T) fits = false;                                                // a single tile does not fit
+        r.k1 = H;
+        rounds.push_back(r);
+        prev_origin = r.origin;
+        T = H;
     }
+    if (!fits) rounds.clear();
     return true;
 }
 

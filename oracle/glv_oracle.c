@@ -430,21 +430,15 @@ void glvo_bars_at(const float* tex, size_t sz, float* bars_out, size_t bars, flo
  * the bar's end), combined pairwise (neighbours, pairs of pairs, the two quads); chunk totals added in chunk order; one
  * division by the tap-order sum of the weights.  glava_amd/csrc/glv_frame.h "GLV_OP_BARS arithmetic" is what this restates;
  * the GPU tests demand these bits, tests/test_glsl_twins.py bounds the distance to glvo_bars (summation rounding only).
- * With 256 bars or more (the pre-smoothing pass: bars == sz) the library lets every group of eight consecutive bars start at one
- * bin -- the smallest first bin of the group rounded down to a multiple of 8 -- by giving a bar `lead` leading taps of weight +0
- * (glava_amd/csrc/glv_tables.h make_bar_taps, "group rule"): the taps and weights are smooth_audio()'s, the chunks / octets they
- * fall into are counted from the group's bin. */
+ * With 256 bars or more (the pre-smoothing pass: bars == sz) the library's order is simpler: ONE fused-multiply-add chain over the
+ * bar's taps in bin order from +0, acc = fmaf(w, x, acc) -- what a tile of v_mfma_f32_32x32x2_f32 computes for 32 bars x 64 rows at
+ * a time (a k-ordered fmaf chain, bit for bit; taps of weight +0 -- the other bars' bins of the tile -- leave it untouched). */
 void glvo_bars_chunked_at(const float* tex, size_t sz, float* bars_out, size_t bars, float smooth_factor, float phase);
 void glvo_bars_chunked(const float* tex, size_t sz, float* bars_out, size_t bars, float smooth_factor) { glvo_bars_chunked_at(tex, sz, bars_out, bars, smooth_factor, 0.0F); }
 void glvo_bars_chunked_at(const float* tex, size_t sz, float* bars_out, size_t bars, float smooth_factor, float phase) {
     float* x = malloc(sizeof(float) * (sz + 128));
     float* w = malloc(sizeof(float) * (sz + 128));
     const size_t C = sz <= 1024 ? 16 : (sz == 2048 ? 32 : 64);
-    long* first = malloc(sizeof(long) * (bars + 1));
-    for (size_t k = 0; k < bars; ++k) {
-        float idx = phase == 0.0F ? (float) k / (float) bars : ((float) k + phase) / (float) bars;
-        first[k] = (long) (int) roundf(glvo_scale_audio(glvo_clamp01(idx - smooth_factor)) * sz);
-    }
     for (size_t k = 0; k < bars; ++k) {
         float idx = phase == 0.0F ? (float) k / (float) bars : ((float) k + phase) / (float) bars;
         float smin = glvo_scale_audio(glvo_clamp01(idx - smooth_factor)) * sz;
@@ -452,20 +446,13 @@ void glvo_bars_chunked_at(const float* tex, size_t sz, float* bars_out, size_t b
         float m = (smax - smin) / 2.0F, rm = smin + m;
         float weight = 0;
         size_t cnt = 0;
-        if (bars >= 256) {                                    /* the group rule: leading +0 taps up to the group's first bin */
-            size_t g0 = k / 8 * 8, g1 = g0 + 8 < bars ? g0 + 8 : bars;
-            long a = first[g0];
-            for (size_t j = g0; j < g1; ++j) a = first[j] < a ? first[j] : a;
-            a -= a % 8;
-            for (long q = a; q < first[k]; ++q) { w[cnt] = 0; x[cnt] = 0; ++cnt; }
-        }
         long prev = -1;
         for (float s = smin; s <= smax; s += 1.0F) {
             float wt = glvo_sinusoidal(glvo_clamp01((m - fabsf(rm - s)) / m));
             weight += wt;
             /* the library counts a bar's taps by BIN: where s += 1.0F rounds up across a binade boundary (x.49997 + 1 -> (x+1).5) round(s)
              * skips a bin -- the shader has no tap there, the library a tap of weight +0 (glv_tables.h make_bar_taps), which moves the
-             * taps behind it one place further in their chunk (n = 4096, bar 2848: bin 512) */
+             * taps behind it one place further in their chunk (n = 4096, bar 2848: bin 512; only the chunked order notices) */
             long bin = (long) (int) roundf(s);
             for (long q = prev + 1; prev >= 0 && q < bin; ++q) { w[cnt] = 0; x[cnt] = 0; ++cnt; }
             prev = bin;
@@ -476,6 +463,11 @@ void glvo_bars_chunked_at(const float* tex, size_t sz, float* bars_out, size_t b
         }
         for (size_t p = cnt; p < ((cnt + C - 1) / C) * C; ++p) { w[p] = 0; x[p] = 0; }
         float total = 0;
+        if (bars >= 256) {                                    /* one chain in bin order */
+            for (size_t p = 0; p < cnt; ++p) total = fmaf(w[p], x[p], total);
+            bars_out[k] = total / weight;
+            continue;
+        }
         for (size_t c0 = 0; c0 < cnt; c0 += C) {
             float lane[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
             for (size_t l = 0; l < C / 8; ++l) {
@@ -493,7 +485,7 @@ void glvo_bars_chunked_at(const float* tex, size_t sz, float* bars_out, size_t b
         }
         bars_out[k] = total / weight;
     }
-    free(x); free(w); free(first);
+    free(x); free(w);
 }
 
 /* smooth_audio() once more, for the tie-aware comparisons of tests/test_gl_reference.py: the same taps -- selected by the shader's

@@ -216,7 +216,14 @@ void glvemu_div_65535(int lo, int hi, float* out) {
 extern "C" {
 // bars of `nrows` rows of n floats through work lists for `groups` groups of bar_lanes_of(n) lanes.  steps_out (may be NULL)
 // receives the step count; returns 0 on success.
+int glvemu_bars_rows(const float* tex, int n, int bars, float smooth_factor, float phase, int bins, float* out);
 int glvemu_bars(const float* spec, size_t nrows, int n, int bars, float smooth_factor, int groups, float* out, unsigned* steps_out, float phase) {
+    if ((uint32_t) bars >= glv::kBarSeqMin) {              // like launch_bars: from 256 bars up the chain kernels and their tile tables
+        for (size_t r = 0; r < nrows; ++r)
+            if (glvemu_bars_rows(spec + r * (size_t) n, n, bars, smooth_factor, phase, 288, out + r * (size_t) bars)) return -1;
+        if (steps_out) *steps_out = 0;
+        return 0;
+    }
     using namespace glv;
     std::vector<BarDesc> desc;
     std::vector<float> w;
@@ -313,11 +320,12 @@ unsigned long long glvemu_div_frames_check(unsigned F, unsigned lo_bits, unsigne
 }
 
 extern "C" {
-// glv_tables.h make_bar_taps (group rule) / make_bar_groups (the host tables of glv_bars_rows_kernel): 0 when every group of eight
-// bars starts at one multiple of 8, the tiles cover every bar exactly once in order in whole groups, hold at most max_bars bars, span
-// at most `bins` bins and contain every octet step of their groups, and the weight stream holds exactly the bars' weights (+0 past
-// a bar's end).  -1: the groups cannot be tiled for this window (the kernel is then not used).
-int glvemu_bar_tiles_check(int n, int bars, float smooth_factor, float phase, int bins, int max_bars, unsigned* ntiles_out, unsigned* max_count_out) {
+// glv_tables.h make_bar_mtiles (the host tables of the many-bars kernels): 0 when the tiles cover every bar once in order, 32 at a
+// time, from a first bin that is a multiple of 4 over a whole number of step groups; the weights in MFMA operand layout hold exactly
+// the bars' weights at the bars' bins and +0 elsewhere; the rounds cover every tile once in order, at most tiles_per_round at a time,
+// fit the ring (their own bins and what the next round adds), and are monotone.  -1: no rounds for this ring (the matrix-core
+// kernel is then not used); -2: no tables at all (fewer than 256 bars).
+int glvemu_bar_tiles_check(int n, int bars, float smooth_factor, float phase, int bins, int tiles_per_round, unsigned* nrounds_out, unsigned* max_count_out) {
     using namespace glv;
     std::vector<BarDesc> desc;
     std::vector<float> w;
@@ -325,33 +333,65 @@ int glvemu_bar_tiles_check(int n, int bars, float smooth_factor, float phase, in
     uint32_t mc = 0;
     for (const BarDesc& d : desc) mc = d.count > mc ? d.count : mc;
     if (max_count_out) *max_count_out = mc;
-    std::vector<BarTile> tiles;
-    std::vector<BarGroupDesc> groups;
-    std::vector<float> wg, wsum;
-    if (!make_bar_groups(groups, wg, wsum, tiles, desc, w, (uint32_t) n, (uint32_t) bins, (uint32_t) max_bars)) return -1;
-    if (ntiles_out) *ntiles_out = (unsigned) tiles.size();
-    if (groups.size() != ((size_t) bars + 7) / 8 || wsum.size() != groups.size() * 16) return 7;
-    uint32_t next = 0;
-    for (const BarTile& t : tiles) {
-        if (t.k0 != next || t.k1 <= t.k0 || t.k1 - t.k0 > (uint32_t) max_bars || t.k0 % 8u) return 1;
-        if ((t.origin & 7u) || (t.end & 7u) || t.end <= t.origin || t.end - t.origin > (uint32_t) bins || t.end > (uint32_t) n) return 2;
-        for (uint32_t k = t.k0; k < t.k1; ++k) {
-            const BarGroupDesc& g = groups[k / 8];
-            if (desc[k].first_bin != g.first_bin || (desc[k].count + 7u) / 8u > g.steps) return 3;
-            if (g.first_bin < t.origin || g.first_bin + 8u * g.steps > t.end) return 3;
-            for (uint32_t p = 0; p < 8u * g.steps; ++p) {
-                const float want = p < desc[k].count ? w[desc[k].tap_offset + p] : 0.0f;
-                if (__builtin_bit_cast(uint32_t, wg[g.w_off + (p / 8u) * 64u + (k % 8u) * 8u + p % 8u]) != __builtin_bit_cast(uint32_t, want)) return 6;
+    std::vector<BarMTile> mt;
+    std::vector<BarTile> rounds;
+    std::vector<float> wt, wsum;
+    if (!make_bar_mtiles(mt, wt, wsum, rounds, desc, w, (uint32_t) n, (uint32_t) bins, (uint32_t) tiles_per_round)) return -2;
+    if (mt.size() != ((size_t) bars + 31) / 32 || wsum.size() != mt.size() * 64) return 7;
+    for (size_t T = 0; T < mt.size(); ++T) {
+        const BarMTile& t = mt[T];
+        if (t.k0 != 32 * T || (t.origin & 3u) || t.steps == 0 || t.steps % kBarStepPad) return 1;
+        for (uint32_t j = 0; j < 32; ++j) {
+            const uint32_t k = t.k0 + j;
+            if (k < (uint32_t) bars && (desc[k].first_bin < t.origin || desc[k].first_bin + desc[k].count > t.origin + 2 * t.steps)) return 3;
+            for (uint32_t i = 0; i < 2 * t.steps; ++i) {
+                const uint32_t bin = t.origin + i;
+                const float want = k < (uint32_t) bars && bin >= desc[k].first_bin && bin < desc[k].first_bin + desc[k].count ? w[desc[k].tap_offset + bin - desc[k].first_bin] : 0.0f;
+                if (__builtin_bit_cast(uint32_t, wt[t.w_off + i * 32 + j]) != __builtin_bit_cast(uint32_t, want)) return 6;
             }
-            if (wsum[2 * k] != desc[k].weight_sum || wsum[2 * k + 1] != (bar_rcp_division_ok(desc[k].weight_sum) ? 1.0f / desc[k].weight_sum : 0.0f)) return 5;
-            if (g.slot0 != (g.first_bin / 4u) % ((uint32_t) bins / 4u)) return 8;
+            const float ws = k < (uint32_t) bars ? desc[k].weight_sum : 1.0f;
+            if (wsum[2 * k] != ws || wsum[2 * k + 1] != (bar_rcp_division_ok(ws) ? 1.0f / ws : 0.0f)) return 5;
         }
-        next = t.k1;
     }
-    if (next != (uint32_t) bars) return 4;
-    // the ring: what round t + 1 adds must not land on what round t reads; origins and ends monotone
-    for (size_t i = 1; i < tiles.size(); ++i)
-        if (tiles[i].end < tiles[i - 1].end || tiles[i].origin < tiles[i - 1].origin || tiles[i].end - tiles[i - 1].origin > (uint32_t) bins) return 9;
+    if (rounds.empty()) return -1;
+    if (nrounds_out) *nrounds_out = (unsigned) rounds.size();
+    uint32_t next = 0;
+    for (size_t i = 0; i < rounds.size(); ++i) {
+        const BarTile& r = rounds[i];
+        if (r.k0 != next || r.k1 <= r.k0 || r.k1 - r.k0 > (uint32_t) tiles_per_round) return 2;
+        if ((r.origin & 3u) || (r.end & 3u) || r.end <= r.origin || r.end - r.origin > (uint32_t) bins || r.end > (uint32_t) n) return 4;
+        for (uint32_t T = r.k0; T < r.k1; ++T)
+            for (uint32_t k = mt[T].k0; k < mt[T].k0 + 32 && k < (uint32_t) bars; ++k)
+                if (desc[k].first_bin < r.origin || desc[k].first_bin + desc[k].count > r.end) return 8;
+        if (i && (r.end < rounds[i - 1].end || r.origin < rounds[i - 1].origin || r.end - rounds[i - 1].origin > (uint32_t) bins)) return 9;
+        next = r.k1;
+    }
+    if (next != mt.size()) return 10;
+    return 0;
+}
+
+// The many-bars kernels' arithmetic on the host, off the same tables: per tile and bar ONE fmaf chain over the tile's whole (padded)
+// bin range, the other bars' bins and the padding weighing +0 -- what the MFMA computes.  Texels past the row (padding) read as the
+// row's last one.  out: bars floats.  Returns 0, or -2 when there are no tables.
+int glvemu_bars_rows(const float* tex, int n, int bars, float smooth_factor, float phase, int bins, float* out) {
+    using namespace glv;
+    std::vector<BarDesc> desc;
+    std::vector<float> w;
+    make_bar_taps(desc, w, (uint32_t) n, (uint32_t) bars, smooth_factor, phase);
+    std::vector<BarMTile> mt;
+    std::vector<BarTile> rounds;
+    std::vector<float> wt, wsum;
+    if (!make_bar_mtiles(mt, wt, wsum, rounds, desc, w, (uint32_t) n, (uint32_t) bins, 4u)) return -2;
+    auto clamp01 = [](float v) { return v > 0.0f ? (v < 1.0f ? v : 1.0f) : 0.0f; };      // NaN -> 0
+    for (const BarMTile& t : mt)
+        for (uint32_t j = 0; j < 32 && t.k0 + j < (uint32_t) bars; ++j) {
+            float acc = 0.0f;
+            for (uint32_t i = 0; i < 2 * t.steps; ++i) {
+                const uint32_t bin = t.origin + i;
+                acc = fmaf(clamp01(tex[bin < (uint32_t) n ? bin : (uint32_t) n - 1]), wt[t.w_off + i * 32 + j], acc);
+            }
+            out[t.k0 + j] = acc / wsum[2 * (t.k0 + j)];
+        }
     return 0;
 }
 
@@ -395,53 +435,4 @@ unsigned long long glvemu_div_rcp_check(int n, int bars, float smooth_factor, fl
     return nb;
 }
 
-// glv_bars_rows_kernel's arithmetic on the host, off the same tables: per group the octet steps in order, eight bars side by side,
-// {even, odd} chains as a product and three fused multiply-adds each, the octet sum, the three-deep stack of partial sums per chunk
-// of GL octets (glv_misc.hip), one division.  out: bars floats.  Returns 0, or -1 when the tables cannot be made.
-int glvemu_bars_rows(const float* tex, int n, int bars, float smooth_factor, float phase, int bins, float* out) {
-    using namespace glv;
-    std::vector<BarDesc> desc;
-    std::vector<float> w;
-    make_bar_taps(desc, w, (uint32_t) n, (uint32_t) bars, smooth_factor, phase);
-    std::vector<BarTile> tiles;
-    std::vector<BarGroupDesc> groups;
-    std::vector<float> wg, wsum;
-    if (!make_bar_groups(groups, wg, wsum, tiles, desc, w, (uint32_t) n, (uint32_t) bins, 64u)) return -1;
-    const int GL = bar_lanes_of((uint32_t) n);
-    auto clamp01 = [](float v) { return v > 0.0f ? (v < 1.0f ? v : 1.0f) : 0.0f; };      // NaN -> 0
-    for (const BarTile& t : tiles)
-        for (uint32_t G = t.k0 / 8; 8 * G < t.k1; ++G) {
-            const BarGroupDesc& g = groups[G];
-            float tot[8] = {}, p0[8] = {}, p1[8] = {}, p2[8] = {};
-            uint32_t s = 0;
-            while (s < g.steps) {
-                for (int L = 0; L < GL && s < g.steps; ++L, ++s) {
-                    float x[8];
-                    for (int i = 0; i < 8; ++i) x[i] = clamp01(tex[g.first_bin + 8u * s + (uint32_t) i]);
-                    for (int j = 0; j < 8; ++j) {
-                        const float* ww = &wg[g.w_off + s * 64u + (uint32_t) j * 8u];
-                        float e = x[0] * ww[0], o = x[1] * ww[1];
-                        for (int i = 2; i < 8; i += 2) { e = fmaf(x[i], ww[i], e); o = fmaf(x[i + 1], ww[i + 1], o); }
-                        const float oc = e + o;
-                        if (L == 0) p0[j] = oc;
-                        else if (L == 1) p0[j] = p0[j] + oc;
-                        else if (L == 2 || L == 4) p1[j] = oc;
-                        else if (L == 5) p1[j] = p1[j] + oc;
-                        else if (L == 3) { p0[j] = p0[j] + (p1[j] + oc); p1[j] = 0.0f; }
-                        else if (L == 6) p2[j] = oc;
-                        else { p0[j] = p0[j] + (p1[j] + (p2[j] + oc)); p1[j] = 0.0f; p2[j] = 0.0f; }
-                    }
-                }
-                for (int j = 0; j < 8; ++j) {
-                    float sum = p0[j];
-                    if (GL >= 8) sum = sum + (p1[j] + p2[j]);
-                    else if (GL >= 4) sum = sum + p1[j];
-                    tot[j] = tot[j] + sum;
-                    p1[j] = p2[j] = 0.0f;
-                }
-            }
-            for (uint32_t j = 0; j < 8u && 8 * G + j < (uint32_t) bars; ++j) out[8 * G + j] = tot[j] / wsum[2 * (8 * G + j)];
-        }
-    return 0;
-}
 }

@@ -23,35 +23,32 @@ int main(int argc, char** argv) {
     using namespace glv;
     const uint32_t n = argc > 1 ? (uint32_t) atoi(argv[1]) : 4096u;
     const size_t rows = argc > 2 ? (size_t) atol(argv[2]) : (size_t) 32768 * 4096 / n;
-    const uint32_t bins = argc > 3 ? (uint32_t) atoi(argv[3]) : (n >= 4096 ? 240u : 160u);
+    const uint32_t bins = argc > 3 ? (uint32_t) atoi(argv[3]) : (n >= 4096 ? 288u : 160u);
     const int reps = argc > 4 ? atoi(argv[4]) : 20;
     std::vector<BarDesc> desc; std::vector<float> w;
     make_bar_taps(desc, w, n, n, 0.025f, 0.5f);
-    std::vector<BarTile> tiles; std::vector<BarGroupDesc> groups; std::vector<float> wg, wsum;
-    if (!make_bar_groups(groups, wg, wsum, tiles, desc, w, n, bins, 64u)) { fprintf(stderr, "no tiles for n=%u bins=%u\n", n, bins); return 2; }
-    size_t steps = 0; for (auto& g : groups) steps += g.steps;
+    std::vector<BarMTile> mt; std::vector<BarTile> rounds; std::vector<float> wt, wsum;
+    if (!make_bar_mtiles(mt, wt, wsum, rounds, desc, w, n, bins, 4u) || rounds.empty()) { fprintf(stderr, "no rounds for n=%u ring=%u\n", n, bins); return 2; }
+    size_t steps = 0; for (auto& t : mt) steps += t.steps;
     std::vector<float> spec(rows * n);
     uint32_t lcg = 12345u;
     for (auto& v : spec) { lcg = lcg * 1664525u + 1013904223u; v = (float) (lcg >> 8) * (1.0f / 16777216.0f); }
-    float *d_spec, *d_out, *d_wg, *d_wsum; BarTile* d_tiles; BarGroupDesc* d_groups;
+    float *d_spec, *d_out, *d_wt, *d_wsum; BarTile* d_rounds; BarMTile* d_mt;
     CK(hipMalloc(&d_spec, sizeof(float) * rows * n)); CK(hipMalloc(&d_out, sizeof(float) * rows * n));
-    CK(hipMalloc(&d_wg, sizeof(float) * wg.size())); CK(hipMalloc(&d_wsum, sizeof(float) * wsum.size()));
-    CK(hipMalloc(&d_tiles, sizeof(BarTile) * tiles.size())); CK(hipMalloc(&d_groups, sizeof(BarGroupDesc) * groups.size()));
+    CK(hipMalloc(&d_wt, sizeof(float) * wt.size())); CK(hipMalloc(&d_wsum, sizeof(float) * wsum.size()));
+    CK(hipMalloc(&d_rounds, sizeof(BarTile) * rounds.size())); CK(hipMalloc(&d_mt, sizeof(BarMTile) * mt.size()));
     CK(hipMemcpy(d_spec, spec.data(), sizeof(float) * rows * n, hipMemcpyHostToDevice));
-    CK(hipMemcpy(d_wg, wg.data(), sizeof(float) * wg.size(), hipMemcpyHostToDevice)); CK(hipMemcpy(d_wsum, wsum.data(), sizeof(float) * wsum.size(), hipMemcpyHostToDevice));
-    CK(hipMemcpy(d_tiles, tiles.data(), sizeof(BarTile) * tiles.size(), hipMemcpyHostToDevice));
-    CK(hipMemcpy(d_groups, groups.data(), sizeof(BarGroupDesc) * groups.size(), hipMemcpyHostToDevice));
-    const BarRowsTables rt{d_tiles, (uint32_t) tiles.size(), bins, d_groups, d_wg, d_wsum};
+    CK(hipMemcpy(d_wt, wt.data(), sizeof(float) * wt.size(), hipMemcpyHostToDevice)); CK(hipMemcpy(d_wsum, wsum.data(), sizeof(float) * wsum.size(), hipMemcpyHostToDevice));
+    CK(hipMemcpy(d_rounds, rounds.data(), sizeof(BarTile) * rounds.size(), hipMemcpyHostToDevice));
+    CK(hipMemcpy(d_mt, mt.data(), sizeof(BarMTile) * mt.size(), hipMemcpyHostToDevice));
+    const BarRowsTables rt{d_mt, (uint32_t) mt.size(), d_wt, d_wsum, d_rounds, (uint32_t) rounds.size(), bins};
+    CK(prepare_bars_rows(n, &rt));
     {
         int nb = -1;
-        const size_t lds = sizeof(float) * ((size_t) 64 * bins + (size_t) kRowsTileBars * kRowsStagePitch);
-        hipError_t e = hipErrorUnknown;
-        if (bins == 240) { (void) hipFuncSetAttribute(reinterpret_cast<const void*>(glv_bars_rows_kernel<240, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
-                           e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, glv_bars_rows_kernel<240, 8>, 512, lds); }
-        else if (bins == 160 && n >= 4096) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, glv_bars_rows_kernel<160, 8>, 512, lds);
-        else if (bins == 160 && n == 2048) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, glv_bars_rows_kernel<160, 4>, 512, lds);
-        else if (bins == 160) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, glv_bars_rows_kernel<160, 2>, 512, lds);
-        printf("occupancy: %d workgroups of 512 per CU with %zu B of LDS (%s)\n", nb, lds, hipGetErrorString(e));
+        const size_t lds = sizeof(float) * (size_t) 64 * bins;
+        hipError_t e = bins == 288 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, glv_bars_rows_kernel<288>, 256, lds)
+                                   : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, glv_bars_rows_kernel<160>, 256, lds);
+        printf("occupancy: %d workgroups of 256 per CU with %zu B of LDS (%s)\n", nb, lds, hipGetErrorString(e));
     }
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     for (int r16 = 0; r16 < 2; ++r16) {
@@ -65,8 +62,8 @@ int main(int argc, char** argv) {
             float ms; CK(hipEventElapsedTime(&ms, e0, e1)); ms /= reps;
             best = ms < best ? ms : best; sum += ms;
         }
-        printf("n=%u rows=%zu bins=%u tiles=%zu steps/row-block=%zu %s: %.4f ms (best %.4f)  %.1f G tap-slots/s\n", n, rows, bins, tiles.size(), steps, r16 ? "r16" : "f32",
-               sum / 3, best, (double) steps * 512.0 * (double) ((rows + 63) / 64) / (sum / 3 * 1e-3) * 1e-9);
+        printf("n=%u rows=%zu ring=%u rounds=%zu steps/row-block=%zu %s: %.4f ms (best %.4f)  %.1f TFLOP/s on the matrix cores\n", n, rows, bins, rounds.size(), steps, r16 ? "r16" : "f32",
+               sum / 3, best, (double) steps * 2.0 * 2048.0 * 2.0 * (double) ((rows + 63) / 64) / (sum / 3 * 1e-3) * 1e-12);
     }
     return 0;
 }

@@ -399,7 +399,11 @@ __global__ void __launch_bounds__(64 * kRowsWaves) glv_bars_rows_kernel(const fl
 #if defined(__HIP_DEVICE_COMPILE__)
     extern __shared__ float rows_lds[];                 // [S][64]: the ring
     static_assert(S % 4 == 0, "a parked slot of four bins never straddles the ring's end");
-    constexpr int PF = 8;                               // steps of weights in flight
+#if defined(GLV_ROWS_NB)                /* tools/rows_bench A/B builds */
+    constexpr int NB = GLV_ROWS_NB, PF = 8 * NB;
+#else
+    constexpr int NB = 1, PF = 8 * NB;                  // steps of weights in flight: NB banks of 8 registers (tiles are whole banks: glv_tables.h kBarStepPad)
+#endif
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = (uint32_t) __builtin_amdgcn_readfirstlane((int) (threadIdx.x >> 6));
     const size_t row0 = (size_t) blockIdx.x * 64;
@@ -446,6 +450,13 @@ __global__ void __launch_bounds__(64 * kRowsWaves) glv_bars_rows_kernel(const fl
     __syncthreads();
     // lane part of an a-operand address: row (lane % 32) of a half, the odd bin of the pair for lanes 32..63
     const float* xlane = rows_lds + (lane >> 5) * 64u + (lane & 31u);
+    // The weights: wave w takes tile k0 + w of every round and the host laid those tiles out one behind the other (glv_tables.h
+    // make_bar_mtiles), so the wave reads ONE stream, PF steps ahead, straight across tile boundaries -- a register is reloaded as soon
+    // as its step has used it, and the loads a tile's first steps need were issued before the previous tile's stores (vmcnt retires in
+    // order: a load behind the stores waits for them).  bank: which of the NB banks of 8 registers the next 8 steps use.
+    float w[PF];
+    const float* wp = nullptr;                          // stream position of the NEXT load (lane-offset)
+    uint32_t bank = 0;
     for (uint32_t t = t_begin; t < t_end; ++t) {
         const BarTile T = rounds[t];                                            // uniform: scalar loads
         const bool valid = T.k0 + wave < T.k1;
@@ -467,42 +478,54 @@ __global__ void __launch_bounds__(64 * kRowsWaves) glv_bars_rows_kernel(const fl
         park_new();
 #else
         if (valid) {
-            const uint32_t steps = (uint32_t) __builtin_amdgcn_readfirstlane((int) M.steps);        // a multiple of 4 (glv_tables.h kBarStepPad)
-            const float* wp = wt + (uint32_t) __builtin_amdgcn_readfirstlane((int) M.w_off) + lane;
+            const uint32_t steps = (uint32_t) __builtin_amdgcn_readfirstlane((int) M.steps);        // a multiple of 8 (glv_tables.h kBarStepPad)
             uint32_t sb = (uint32_t) __builtin_amdgcn_readfirstlane((int) (M.origin % (uint32_t) S));   // ring slot of the step's even bin
             glv_f16v acc0 = {0}, acc1 = {0};                                    // rows 0..31 / 32..63 of the block x the tile's 32 bars
-            // software pipeline: the weights eight steps ahead (PF registers, each reloaded as soon as its step has used it), the texels
-            // one step ahead; a step is two MFMAs (rows 0..31 and 32..63 of the block) on the same weights
-            float w[PF];
+            if (wp == nullptr) {                                                // the wave's first tile: fill the pipeline
+                wp = wt + (uint32_t) __builtin_amdgcn_readfirstlane((int) M.w_off) + lane;
 #pragma unroll
-            for (int i = 0; i < PF; ++i) w[i] = wp[(size_t) i * 64];            // (64 * 2 * kBarStepPad floats of slack follow the table)
-            wp += (size_t) PF * 64;
-            float xa = xlane[(size_t) sb * 64], xb = xlane[(size_t) sb * 64 + 32];
-            sb = sb + 2u == (uint32_t) S ? 0u : sb + 2u;
-            auto step = [&](int u) {
-                const float na = xlane[(size_t) sb * 64], nb = xlane[(size_t) sb * 64 + 32];      // (one step past the tile's end is read and dropped)
-                sb = sb + 2u == (uint32_t) S ? 0u : sb + 2u;
-                const float wcur = w[u];
-                w[u] = wp[0];
-                wp += 64;
-                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(xa, wcur, acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(xb, wcur, acc1, 0, 0, 0);
-                xa = na; xb = nb;
-            };
-            uint32_t s = 0;
-            for (; s + 8u <= steps; s += 8u) {
-#pragma unroll
-                for (int u = 0; u < 8; ++u) step(u);
+                for (int i = 0; i < PF; ++i) w[i] = wp[(size_t) i * 64];
+                wp += (size_t) PF * 64;
+                bank = 0;
             }
-            if (s < steps) {                                                    // steps is a multiple of 4: one half turn is left
+            // the texels two steps ahead; a step is two MFMAs (rows 0..31 and 32..63 of the block) on the same weights
+            float xa0 = xlane[(size_t) sb * 64], xb0 = xlane[(size_t) sb * 64 + 32];
+            sb = sb + 2u == (uint32_t) S ? 0u : sb + 2u;
+            float xa1 = xlane[(size_t) sb * 64], xb1 = xlane[(size_t) sb * 64 + 32];
+            sb = sb + 2u == (uint32_t) S ? 0u : sb + 2u;
+            auto eight = [&](auto BC) {                                         // eight steps on bank B
+                constexpr int B = decltype(BC)::value;
 #pragma unroll
-                for (int u = 0; u < 4; ++u) step(u);
+                for (int u = 0; u < 8; ++u) {
+#if defined(GLV_EXP_ROWS_NOLDS)         /* timing experiment (wrong results): no texel reads */
+                    const float na = xa0 + 1.0f, nb = xb0 + 1.0f;
+#else
+                    const float na = xlane[(size_t) sb * 64], nb = xlane[(size_t) sb * 64 + 32];      // (up to two steps past the tile's end are read and dropped)
+#endif
+                    sb = sb + 2u == (uint32_t) S ? 0u : sb + 2u;
+                    const float wcur = w[8 * B + u];
+#if defined(GLV_EXP_ROWS_NOWLOAD)       /* timing experiment (wrong results): no weight loads */
+                    w[8 * B + u] = wcur + 1.0f;
+#else
+                    w[8 * B + u] = wp[(size_t) u * 64];
+#endif
+                    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(xa0, wcur, acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(xb0, wcur, acc1, 0, 0, 0);
+                    xa0 = xa1; xb0 = xb1; xa1 = na; xb1 = nb;
+                }
+                wp += (size_t) 8 * 64;
+            };
+            for (uint32_t s8 = 0; s8 < steps; s8 += 8u) {
+                if (bank == 0) eight(std::integral_constant<int, 0>{});
+                else if (bank == 1) eight(std::integral_constant<int, (NB > 1 ? 1 : 0)>{});
+                else if (bank == 2) eight(std::integral_constant<int, (NB > 2 ? 2 : 0)>{});
+                else eight(std::integral_constant<int, (NB > 3 ? 3 : 0)>{});
+                bank = bank + 1u == (uint32_t) NB ? 0u : bank + 1u;
             }
             park_new();
             // a lane's 32 results are one bar (k0 + lane % 32) of the rows 8 (r / 4) + 4 (lane / 32) + r % 4 (+ 32 for acc1)
             const uint32_t kb = M.k0 + (lane & 31u);
             const glv_f2 ws = *reinterpret_cast<const glv_f2*>(wsum + 2u * (size_t) kb);       // {weight sum, its reciprocal or 0} (padded to whole tiles)
-            float q[32];
             float tmin = 1.0f;                                                  // is some total in (0, 2^-90)?  (totals are >= +0)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
@@ -510,40 +533,42 @@ __global__ void __launch_bounds__(64 * kRowsWaves) glv_bars_rows_kernel(const fl
                 const float mn = a0 < a1 ? a0 : a1;
                 tmin = mn < tmin ? mn : tmin;
             }
+            // total / weight sum: with the host's reciprocal where that is the correctly rounded quotient (glv_tables.h bar_rcp_division_ok;
+            // not for a total so small that the remainder would be inexact), else the long way -- the whole wave one way or the other
             const bool fast = __ballot(ws.y == 0.0f || tmin < 0x1p-90f) == 0ull;
+            const size_t at0 = (row0 + 4u * (lane >> 5)) * (size_t) bars + kb;
+            auto put = [&](int r, float v) {
+                const uint32_t jr = 32u * (uint32_t) (r / 16) + 8u * (uint32_t) ((r & 15) / 4) + 4u * (lane >> 5) + (uint32_t) (r & 3);
+#if defined(GLV_EXP_ROWS_NOFLUSH)       /* timing experiment (wrong results): one store in 32 */
+                if (jr < R && kb < bars && r == 0) {
+#else
+                if (jr < R && kb < bars) {
+#endif
+                    const size_t at = at0 + (size_t) (32u * (uint32_t) (r / 16) + 8u * (uint32_t) ((r & 15) / 4) + (uint32_t) (r & 3)) * bars;
+                    if (r16) reinterpret_cast<uint16_t*>(bars_out)[at] = (uint16_t) pack_unorm16(v, 0.0f);
+                    else reinterpret_cast<float*>(bars_out)[at] = v;
+                }
+            };
             if (fast) {
 #pragma unroll
                 for (int r = 0; r < 32; ++r) {
                     const float a = r < 16 ? acc0[r & 15] : acc1[r & 15];
                     const float q0 = a * ws.y;
                     const float rm = __builtin_fmaf(-q0, ws.x, a);
-                    q[r] = __builtin_fmaf(rm, ws.y, q0);
+                    put(r, __builtin_fmaf(rm, ws.y, q0));
                 }
             } else {
 #pragma unroll
-                for (int r = 0; r < 32; ++r) q[r] = (r < 16 ? acc0[r & 15] : acc1[r & 15]) / ws.x;
-            }
-            if (kb < bars) {
-#pragma unroll
-                for (int r = 0; r < 32; ++r) {
-                    const uint32_t jr = 32u * (uint32_t) (r / 16) + 8u * (uint32_t) ((r & 15) / 4) + 4u * (lane >> 5) + (uint32_t) (r & 3);
-#if defined(GLV_EXP_ROWS_NOFLUSH)       /* timing experiment (wrong results): one store in 32 */
-                    if (jr < R && r == 0) {
-#else
-                    if (jr < R) {
-#endif
-                        const size_t at = (row0 + jr) * (size_t) bars + kb;
-                        if (r16) reinterpret_cast<uint16_t*>(bars_out)[at] = (uint16_t) pack_unorm16(q[r], 0.0f);
-                        else reinterpret_cast<float*>(bars_out)[at] = q[r];
-                    }
-                }
+                for (int r = 0; r < 32; ++r) put(r, (r < 16 ? acc0[r & 15] : acc1[r & 15]) / ws.x);
             }
         } else {
             park_new();
         }
 #endif
         filled_to = next_end > filled_to ? next_end : filled_to;
+#if !defined(GLV_EXP_ROWS_NOBARRIER)     /* timing experiment (wrong results): rounds not synchronised */
         __syncthreads();
+#endif
     }
 #endif
 }

@@ -202,7 +202,7 @@ inline uint32_t make_bar_items(std::vector<BarItem>& items, const std::vector<Ba
 // quotient (Markstein 1990) unless b's significand is all ones; a is a sum of [0, 1] texels times the weights, b their sum:
 // no overflow, and the kernels take the long way themselves for 0 < a < 2^-90 (where rem would not be exact).  tests/test_emulator.py
 // checks every significand of a against the weight sums of the shipped sizes.
-constexpr uint32_t kBarSeqMin = 256, kBarTileBars = 32, kBarStepPad = 4;      // (the kernels prefetch 8 steps of weights: 64 * 2 * kBarStepPad floats of slack)
+constexpr uint32_t kBarSeqMin = 256, kBarTileBars = 32, kBarStepPad = 8, kBarLookAhead = 32;      // (steps; the rows kernel's weight look-ahead is at most kBarLookAhead)
 inline bool bar_rcp_division_ok(float b) {
     const uint32_t u = __builtin_bit_cast(uint32_t, b);
     return b >= 0x1p-60f && b <= 0x1p60f && (u & 0x7fffffu) != 0x7fffffu;
@@ -211,25 +211,23 @@ inline bool make_bar_mtiles(std::vector<BarMTile>& mtiles, std::vector<float>& w
                             const std::vector<BarDesc>& desc, const std::vector<float>& tap_w, uint32_t n, uint32_t bins, uint32_t tiles_per_round) {
     mtiles.clear(); wt.clear(); wsum.clear(); rounds.clear();
     const uint32_t bars = (uint32_t) desc.size();
-    if (bars < kBarSeqMin) return false;
+    if (bars < kBarSeqMin || tiles_per_round == 0) return false;
     const uint32_t nt = (bars + kBarTileBars - 1) / kBarTileBars;
     bool monotone = true;
+    auto tile_end = [&](uint32_t H) {                                           // last bin + 1 of the tile's own taps, rounded up to a slot
+        uint32_t e = 0;
+        const uint32_t k1 = (H + 1) * kBarTileBars < bars ? (H + 1) * kBarTileBars : bars;
+        for (uint32_t k = H * kBarTileBars; k < k1; ++k) e = desc[k].first_bin + desc[k].count > e ? desc[k].first_bin + desc[k].count : e;
+        return (e + 3u) & ~3u;
+    };
     for (uint32_t T = 0; T < nt; ++T) {
         const uint32_t k0 = T * kBarTileBars, k1 = k0 + kBarTileBars < bars ? k0 + kBarTileBars : bars;
-        uint32_t lo = 0xffffffffu, hi = 0;
-        for (uint32_t k = k0; k < k1; ++k) {
-            lo = desc[k].first_bin < lo ? desc[k].first_bin : lo;
-            hi = desc[k].first_bin + desc[k].count > hi ? desc[k].first_bin + desc[k].count : hi;
-        }
-        BarMTile t{k0, lo & ~3u, 0u, (uint32_t) wt.size()};
-        t.steps = (hi - t.origin + 1u) / 2u;
+        uint32_t lo = 0xffffffffu;
+        for (uint32_t k = k0; k < k1; ++k) lo = desc[k].first_bin < lo ? desc[k].first_bin : lo;
+        BarMTile t{k0, lo & ~3u, 0u, 0u};
+        t.steps = (tile_end(T) - t.origin + 1u) / 2u;
         t.steps = (t.steps + kBarStepPad - 1u) / kBarStepPad * kBarStepPad;
         if (T && t.origin < mtiles[T - 1].origin) monotone = false;
-        for (uint32_t i = 0; i < 2u * t.steps; ++i)
-            for (uint32_t j = 0; j < kBarTileBars; ++j) {
-                const uint32_t k = k0 + j, bin = t.origin + i;
-                wt.push_back(k < k1 && bin >= desc[k].first_bin && bin < desc[k].first_bin + desc[k].count ? tap_w[desc[k].tap_offset + bin - desc[k].first_bin] : 0.0f);
-            }
         for (uint32_t j = 0; j < kBarTileBars; ++j) {
             const float ws = k0 + j < k1 ? desc[k0 + j].weight_sum : 1.0f;
             wsum.push_back(ws);
@@ -237,18 +235,11 @@ inline bool make_bar_mtiles(std::vector<BarMTile>& mtiles, std::vector<float>& w
         }
         mtiles.push_back(t);
     }
-    wt.insert(wt.end(), 64u * 2u * kBarStepPad, 0.0f);                          // what the kernels' look-ahead reads past the last tile
-    // rounds for the LDS ring (the padded steps read, with weight +0, whatever the ring holds there: only its own bins must fit)
+    // rounds for the LDS ring (the padded steps read, with weight +0, whatever the ring holds there: only a tile's own bins must fit)
     uint32_t T = 0, prev_origin = 0;
     bool fits = monotone && bins % 4u == 0;
     while (fits && T < nt) {
         BarTile r{T, T, mtiles[T].origin, rounds.empty() ? 0u : rounds.back().end};       // k0, k1: TILE indices here; ends are kept monotone
-        auto tile_end = [&](uint32_t H) {                                       // last bin + 1 of the tile's own taps, rounded up to a slot
-            uint32_t e = 0;
-            const uint32_t k1 = (H + 1) * kBarTileBars < bars ? (H + 1) * kBarTileBars : bars;
-            for (uint32_t k = H * kBarTileBars; k < k1; ++k) e = desc[k].first_bin + desc[k].count > e ? desc[k].first_bin + desc[k].count : e;
-            return (e + 3u) & ~3u;
-        };
         uint32_t H = T;
         while (H < nt && H - T < tiles_per_round) {
             const uint32_t e = tile_end(H);
@@ -267,6 +258,28 @@ inline bool make_bar_mtiles(std::vector<BarMTile>& mtiles, std::vector<float>& w
         T = H;
     }
     if (!fits) rounds.clear();
+    // the weights, laid out as the rows kernel consumes them: wave w of a workgroup takes tile k0 + w of every round, so its tiles
+    // follow one another in memory -- ONE stream per wave, which the kernel reads a fixed number of steps ahead straight across tile
+    // boundaries (without rounds: tile order)
+    std::vector<uint32_t> order;
+    if (!rounds.empty()) {
+        for (uint32_t wv = 0; wv < tiles_per_round; ++wv)
+            for (const BarTile& r : rounds)
+                if (r.k0 + wv < r.k1) order.push_back(r.k0 + wv);
+    } else {
+        for (uint32_t i = 0; i < nt; ++i) order.push_back(i);
+    }
+    for (uint32_t Ti : order) {
+        BarMTile& t = mtiles[Ti];
+        const uint32_t k0 = t.k0, k1 = k0 + kBarTileBars < bars ? k0 + kBarTileBars : bars;
+        t.w_off = (uint32_t) wt.size();
+        for (uint32_t i = 0; i < 2u * t.steps; ++i)
+            for (uint32_t j = 0; j < kBarTileBars; ++j) {
+                const uint32_t k = k0 + j, bin = t.origin + i;
+                wt.push_back(k < k1 && bin >= desc[k].first_bin && bin < desc[k].first_bin + desc[k].count ? tap_w[desc[k].tap_offset + bin - desc[k].first_bin] : 0.0f);
+            }
+    }
+    wt.insert(wt.end(), 64u * kBarLookAhead, 0.0f);                             // what the look-ahead reads past the last tile
     return true;
 }
 

@@ -30,7 +30,7 @@
     defined(GLV_EXP_NOLOAD) || defined(GLV_EXP_NOSPLIT) || defined(GLV_EXP_NOSTORE) || defined(GLV_EXP_NOTWLOAD) || \
     defined(GLV_EXP_NOWINLOAD) || defined(GLV_EXP_OLDGROUPS) || defined(GLV_EXP_PHASETIME) || defined(GLV_EXP_STOREPRIO) || \
     defined(GLV_EXP_SWAP16) || defined(GLV_EXP_WGBARRIER) || defined(GLV_EXP_SHUFFLE) || defined(GLV_EXP_STOREWAVE) || \
-    defined(GLV_EXP_ROWS_NOFILL) || defined(GLV_EXP_ROWS_NOFLUSH) || defined(GLV_EXP_ROWS_NOCOMPUTE) || defined(GLV_ROWS_NB) || defined(GLV_EXP_ROWS_NOWLOAD) || defined(GLV_EXP_ROWS_NOLDS) || defined(GLV_EXP_ROWS_NOBARRIER) || \
+    defined(GLV_EXP_ROWS_NOFILL) || defined(GLV_EXP_ROWS_NOFLUSH) || defined(GLV_EXP_ROWS_NOCOMPUTE) || defined(GLV_ROWS_NB) || defined(GLV_ROWS_RB) || defined(GLV_EXP_ROWS_NOWLOAD) || defined(GLV_EXP_ROWS_NOLDS) || defined(GLV_EXP_ROWS_NOBARRIER) || \
     defined(GLV_R16_SOFT) || defined(GLV_BAR_BATCH_BIG) || defined(GLV_STATE_PAIR_MAX) || defined(GLV_GL16_BLK) || defined(GLV_GL16_DIV)
 #error "GLV_EXP_* / tuning macros are for tools/tune.py A/B builds: compile with -DGLV_TUNE_BUILD (glava_amd.build.build_variant does); the product never defines them"
 #endif

@@ -390,15 +390,19 @@ __global__ void __launch_bounds__(256) glv_bars_short_kernel(const float* __rest
 // for v_pk_fma_f32 (chunked summation, groups of bars padded to one first bin), bound by the L2 round trips of its scalar weight
 // stream, 0.60 ms.
 constexpr int kRowsWaves = 4;
+#if !defined(GLV_ROWS_RB)               /* rows per workgroup: 64 (two MFMAs per step on the same weights) or 32; tools/rows_bench A/B builds override */
+#define GLV_ROWS_RB 64
+#endif
 typedef float glv_f16v __attribute__((ext_vector_type(16)));
-template <int S>
+template <int S, int RB>
 __global__ void __launch_bounds__(64 * kRowsWaves) glv_bars_rows_kernel(const float* __restrict__ spec, void* __restrict__ bars_out, size_t nrows, uint32_t n,
                                                                         uint32_t bars, const BarTile* __restrict__ rounds, uint32_t nrounds, uint32_t rounds_per_wg,
                                                                         const BarMTile* __restrict__ mtiles, const float* __restrict__ wt,
                                                                         const float* __restrict__ wsum, int r16) {
 #if defined(__HIP_DEVICE_COMPILE__)
-    extern __shared__ float rows_lds[];                 // [S][64]: the ring
-    static_assert(S % 4 == 0, "a parked slot of four bins never straddles the ring's end");
+    extern __shared__ float rows_lds[];                 // [S][RB]: the ring
+    static_assert(S % 8 == 0 && (RB == 64 || RB == 32), "a parked slot of four bins never straddles the ring's end; one or two MFMAs per step");
+    constexpr uint32_t CPI = 64 / RB;                   // columns of four bins one fetch instruction covers (the lanes beyond RB rows take the next column)
 #if defined(GLV_ROWS_NB)                /* tools/rows_bench A/B builds */
     constexpr int NB = GLV_ROWS_NB, PF = 8 * NB;
 #else
@@ -406,14 +410,15 @@ __global__ void __launch_bounds__(64 * kRowsWaves) glv_bars_rows_kernel(const fl
 #endif
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = (uint32_t) __builtin_amdgcn_readfirstlane((int) (threadIdx.x >> 6));
-    const size_t row0 = (size_t) blockIdx.x * 64;
+    const size_t row0 = (size_t) blockIdx.x * RB;
     if (row0 >= nrows) return;
-    const uint32_t R = (uint32_t) (nrows - row0 < 64 ? nrows - row0 : 64);
-    const float* src = spec + (row0 + (lane < R ? lane : R - 1)) * (size_t) n;
+    const uint32_t R = (uint32_t) (nrows - row0 < RB ? nrows - row0 : RB);
+    const uint32_t frow = lane % (uint32_t) RB, fcol = lane / (uint32_t) RB;      // fill: this lane's row and which column of the instruction
+    const float* src = spec + (row0 + (frow < R ? frow : R - 1)) * (size_t) n;
     const uint32_t t_begin = blockIdx.y * rounds_per_wg, t_end = t_begin + rounds_per_wg < nrounds ? t_begin + rounds_per_wg : nrounds;
     if (t_begin >= t_end) return;
     const glv_f2 ones = {1.0f, 1.0f};
-    // 4 bins of this lane's row; clamped here, once per texel: [0, 1] like the GL_R16 texel the shader samples, NaN -> 0 (v_pk_mul_f32
+    // 4 bins of this lane's row (column `col` of four bins from bin0); clamped here, once per texel: [0, 1] like the GL_R16 texel the shader samples, NaN -> 0 (v_pk_mul_f32
     // x, 1.0 clamp -- the operation bar_item_lane_sum applies to every tap)
     auto fetch = [&](uint32_t bin) {
 #if defined(GLV_EXP_ROWS_NOFILL)        /* timing experiment (wrong results): no row loads */
@@ -426,30 +431,32 @@ __global__ void __launch_bounds__(64 * kRowsWaves) glv_bars_rows_kernel(const fl
         glv_f2 lo = {v.w[0], v.w[1]}, hi = {v.w[2], v.w[3]};
         asm("v_pk_mul_f32 %0, %1, %2 clamp" : "=v"(lo) : "v"(lo), "v"(ones));
         asm("v_pk_mul_f32 %0, %1, %2 clamp" : "=v"(hi) : "v"(hi), "v"(ones));
-        float* at = rows_lds + (size_t) (bin % (uint32_t) S) * 64 + lane;
-        at[0] = lo.x; at[64] = lo.y; at[128] = hi.x; at[192] = hi.y;
+        float* at = rows_lds + (size_t) (bin % (uint32_t) S) * RB + frow;
+        at[0] = lo.x; at[RB] = lo.y; at[2 * RB] = hi.x; at[3 * RB] = hi.y;
     };
+    // instruction i of a run of `ncol` columns starting at bin0: this lane's column, clamped for the load, and whether it exists
+    auto col_of = [&](uint32_t i) { return i * CPI + fcol; };
     // the ring starts as zeros: the padded steps of a tile read slots nothing was parked in yet, with weight +0 -- 0 * x must be +0
-    for (uint32_t i = threadIdx.x; i < (uint32_t) S * 64u; i += 64 * kRowsWaves) rows_lds[i] = 0.0f;
+    for (uint32_t i = threadIdx.x; i < (uint32_t) S * RB; i += 64 * kRowsWaves) rows_lds[i] = 0.0f;
     __syncthreads();
     // the first round's whole window: four loads of a wave are in flight before the first is parked
     uint32_t filled_to;
     {
         const BarTile T = rounds[t_begin];
-        const uint32_t ncol = (T.end - T.origin) / 4u;
-        for (uint32_t cb = wave * 4u; cb < ncol; cb += kRowsWaves * 4) {
+        const uint32_t ncol = (T.end - T.origin) / 4u, ninst = (ncol + CPI - 1u) / CPI;
+        for (uint32_t ib = wave * 4u; ib < ninst; ib += kRowsWaves * 4) {
             BarW4 v4[4];
 #pragma unroll
-            for (uint32_t q = 0; q < 4; ++q) v4[q] = fetch(T.origin + 4u * (cb + q < ncol ? cb + q : cb));
+            for (uint32_t q = 0; q < 4; ++q) v4[q] = fetch(T.origin + 4u * (col_of(ib + q) < ncol ? col_of(ib + q) : 0u));
 #pragma unroll
             for (uint32_t q = 0; q < 4; ++q)
-                if (cb + q < ncol) park(v4[q], T.origin + 4u * (cb + q));
+                if (col_of(ib + q) < ncol) park(v4[q], T.origin + 4u * col_of(ib + q));
         }
         filled_to = T.end;
     }
     __syncthreads();
     // lane part of an a-operand address: row (lane % 32) of a half, the odd bin of the pair for lanes 32..63
-    const float* xlane = rows_lds + (lane >> 5) * 64u + (lane & 31u);
+    const float* xlane = rows_lds + (lane >> 5) * (uint32_t) RB + (lane & 31u);
     // The weights: wave w takes tile k0 + w of every round and the host laid those tiles out one behind the other (glv_tables.h
     // make_bar_mtiles), so the wave reads ONE stream, PF steps ahead, straight across tile boundaries -- a register is reloaded as soon
     // as its step has used it, and the loads a tile's first steps need were issued before the previous tile's stores (vmcnt retires in
@@ -467,12 +474,13 @@ __global__ void __launch_bounds__(64 * kRowsWaves) glv_bars_rows_kernel(const fl
         const uint32_t nnew = next_end > filled_to ? (next_end - filled_to) / 4u : 0u;
         BarW4 pre[2];
 #pragma unroll
-        for (uint32_t q = 0; q < 2; ++q) pre[q] = fetch(filled_to + 4u * (wave + kRowsWaves * q < nnew ? wave + kRowsWaves * q : 0u));
+        for (uint32_t q = 0; q < 2; ++q) pre[q] = fetch(filled_to + 4u * (col_of(wave + kRowsWaves * q) < nnew ? col_of(wave + kRowsWaves * q) : 0u));
         auto park_new = [&]() {
 #pragma unroll
             for (uint32_t q = 0; q < 2; ++q)
-                if (wave + kRowsWaves * q < nnew) park(pre[q], filled_to + 4u * (wave + kRowsWaves * q));
-            for (uint32_t c = wave + 2u * kRowsWaves; c < nnew; c += kRowsWaves) park(fetch(filled_to + 4u * c), filled_to + 4u * c);
+                if (col_of(wave + kRowsWaves * q) < nnew) park(pre[q], filled_to + 4u * col_of(wave + kRowsWaves * q));
+            for (uint32_t i = wave + 2u * kRowsWaves; i * CPI < nnew; i += kRowsWaves)
+                if (col_of(i) < nnew) park(fetch(filled_to + 4u * col_of(i)), filled_to + 4u * col_of(i));
         };
 #if defined(GLV_EXP_ROWS_NOCOMPUTE)
         park_new();
@@ -480,7 +488,7 @@ __global__ void __launch_bounds__(64 * kRowsWaves) glv_bars_rows_kernel(const fl
         if (valid) {
             const uint32_t steps = (uint32_t) __builtin_amdgcn_readfirstlane((int) M.steps);        // a multiple of 8 (glv_tables.h kBarStepPad)
             uint32_t sb = (uint32_t) __builtin_amdgcn_readfirstlane((int) (M.origin % (uint32_t) S));   // ring slot of the step's even bin
-            glv_f16v acc0 = {0}, acc1 = {0};                                    // rows 0..31 / 32..63 of the block x the tile's 32 bars
+            glv_f16v acc0 = {0}, acc1 = {0};                                    // rows 0..31 / 32..63 of the block (RB == 64) x the tile's 32 bars
             if (wp == nullptr) {                                                // the wave's first tile: fill the pipeline
                 wp = wt + (uint32_t) __builtin_amdgcn_readfirstlane((int) M.w_off) + lane;
 #pragma unroll
@@ -489,9 +497,9 @@ __global__ void __launch_bounds__(64 * kRowsWaves) glv_bars_rows_kernel(const fl
                 bank = 0;
             }
             // the texels two steps ahead; a step is two MFMAs (rows 0..31 and 32..63 of the block) on the same weights
-            float xa0 = xlane[(size_t) sb * 64], xb0 = xlane[(size_t) sb * 64 + 32];
+            float xa0 = xlane[(size_t) sb * RB], xb0 = RB == 64 ? xlane[(size_t) sb * RB + 32] : 0.0f;
             sb = sb + 2u == (uint32_t) S ? 0u : sb + 2u;
-            float xa1 = xlane[(size_t) sb * 64], xb1 = xlane[(size_t) sb * 64 + 32];
+            float xa1 = xlane[(size_t) sb * RB], xb1 = RB == 64 ? xlane[(size_t) sb * RB + 32] : 0.0f;
             sb = sb + 2u == (uint32_t) S ? 0u : sb + 2u;
             auto eight = [&](auto BC) {                                         // eight steps on bank B
                 constexpr int B = decltype(BC)::value;
@@ -500,7 +508,7 @@ __global__ void __launch_bounds__(64 * kRowsWaves) glv_bars_rows_kernel(const fl
 #if defined(GLV_EXP_ROWS_NOLDS)         /* timing experiment (wrong results): no texel reads */
                     const float na = xa0 + 1.0f, nb = xb0 + 1.0f;
 #else
-                    const float na = xlane[(size_t) sb * 64], nb = xlane[(size_t) sb * 64 + 32];      // (up to two steps past the tile's end are read and dropped)
+                    const float na = xlane[(size_t) sb * RB], nb = RB == 64 ? xlane[(size_t) sb * RB + 32] : 0.0f;      // (up to two steps past the tile's end are read and dropped)
 #endif
                     sb = sb + 2u == (uint32_t) S ? 0u : sb + 2u;
                     const float wcur = w[8 * B + u];
@@ -510,7 +518,7 @@ __global__ void __launch_bounds__(64 * kRowsWaves) glv_bars_rows_kernel(const fl
                     w[8 * B + u] = wp[(size_t) u * 64];
 #endif
                     acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(xa0, wcur, acc0, 0, 0, 0);
-                    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(xb0, wcur, acc1, 0, 0, 0);
+                    if constexpr (RB == 64) acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(xb0, wcur, acc1, 0, 0, 0);
                     xa0 = xa1; xb0 = xb1; xa1 = na; xb1 = nb;
                 }
                 wp += (size_t) 8 * 64;
@@ -529,7 +537,7 @@ __global__ void __launch_bounds__(64 * kRowsWaves) glv_bars_rows_kernel(const fl
             float tmin = 1.0f;                                                  // is some total in (0, 2^-90)?  (totals are >= +0)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const float a0 = acc0[r] == 0.0f ? 1.0f : acc0[r], a1 = acc1[r] == 0.0f ? 1.0f : acc1[r];
+                const float a0 = acc0[r] == 0.0f ? 1.0f : acc0[r], a1 = RB == 32 || acc1[r] == 0.0f ? 1.0f : acc1[r];
                 const float mn = a0 < a1 ? a0 : a1;
                 tmin = mn < tmin ? mn : tmin;
             }
@@ -551,7 +559,7 @@ __global__ void __launch_bounds__(64 * kRowsWaves) glv_bars_rows_kernel(const fl
             };
             if (fast) {
 #pragma unroll
-                for (int r = 0; r < 32; ++r) {
+                for (int r = 0; r < RB / 2; ++r) {
                     const float a = r < 16 ? acc0[r & 15] : acc1[r & 15];
                     const float q0 = a * ws.y;
                     const float rm = __builtin_fmaf(-q0, ws.x, a);
@@ -559,7 +567,7 @@ __global__ void __launch_bounds__(64 * kRowsWaves) glv_bars_rows_kernel(const fl
                 }
             } else {
 #pragma unroll
-                for (int r = 0; r < 32; ++r) put(r, (r < 16 ? acc0[r & 15] : acc1[r & 15]) / ws.x);
+                for (int r = 0; r < RB / 2; ++r) put(r, (r < 16 ? acc0[r & 15] : acc1[r & 15]) / ws.x);
             }
         } else {
             park_new();
@@ -691,22 +699,22 @@ static void launch_bars_gl(const float* spec, float* bars_out, size_t nrows, uin
     else if (nsteps == 4) hipLaunchKernelGGL((glv_bars_short_kernel<4, 2, GL>), grid((nrows + 1) / 2), dim3(256), 0, st, spec, bars_out, nrows, n, bars, items, desc, tap_w, r);
     else hipLaunchKernelGGL((glv_bars_kernel<GL>), grid(nrows), dim3(256), 0, st, spec, bars_out, nrows, n, bars, nsteps, items, desc, tap_w, r);
 }
-template <int S>
+template <int S, int RB>
 static hipError_t launch_bars_rows(const float* spec, float* bars_out, size_t nrows, uint32_t n, uint32_t bars, const BarRowsTables& rt, hipStream_t st, int r) {
-    const size_t lds = sizeof(float) * (size_t) 64 * S;
+    const size_t lds = sizeof(float) * (size_t) RB * S;
     static std::atomic<bool> done[64] = {};
     if (lds > 64 * 1024) {
         int dev = 0;
         (void) hipGetDevice(&dev);
         if (dev < 0 || dev >= 64 || !done[dev].load(std::memory_order_acquire)) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(glv_bars_rows_kernel<S>), hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(glv_bars_rows_kernel<S, RB>), hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
             if (e != hipSuccess) return e;
             if (dev >= 0 && dev < 64) done[dev].store(true, std::memory_order_release);
         }
     }
     if (nrows == 0) return hipSuccess;                                          // prepare_bars_rows: the attribute only
     // 64 rows per workgroup in x, ranges of rounds in y: two resident workgroups per CU, twice over (a range start refills the whole ring)
-    const uint32_t xb = (uint32_t) ((nrows + 63) / 64);
+    const uint32_t xb = (uint32_t) ((nrows + RB - 1) / RB);
     uint32_t yb = xb >= 1024 ? 1 : (1024 + xb - 1) / xb;
 #if defined(GLV_TUNE_BUILD)
     if (const char* o = std::getenv("GLV_ROWS_YB")) yb = (uint32_t) atoi(o);       // tools/rows_bench: the split of the rounds over blockIdx.y
@@ -714,7 +722,7 @@ static hipError_t launch_bars_rows(const float* spec, float* bars_out, size_t nr
     if (yb > rt.nrounds) yb = rt.nrounds;
     const uint32_t rpw = (rt.nrounds + yb - 1) / yb;
     yb = (rt.nrounds + rpw - 1) / rpw;
-    hipLaunchKernelGGL((glv_bars_rows_kernel<S>), dim3(xb, yb), dim3(64 * kRowsWaves), lds, st, spec, static_cast<void*>(bars_out), nrows, n, bars, rt.rounds,
+    hipLaunchKernelGGL((glv_bars_rows_kernel<S, RB>), dim3(xb, yb), dim3(64 * kRowsWaves), lds, st, spec, static_cast<void*>(bars_out), nrows, n, bars, rt.rounds,
                        rt.nrounds, rpw, rt.mtiles, rt.wt, rt.wsum, r);
     return hipGetLastError();
 }
@@ -723,8 +731,8 @@ static hipError_t launch_bars_rows(const float* spec, float* bars_out, size_t nr
 // is then a plain launch)
 hipError_t prepare_bars_rows(uint32_t n, const BarRowsTables* rt) {
     if (rt == nullptr || rt->rounds == nullptr || rt->nrounds == 0) return hipSuccess;
-    if (rt->ring_bins == 160) return launch_bars_rows<160>(nullptr, nullptr, 0, n, 0, *rt, nullptr, 0);
-    if (rt->ring_bins == 288) return launch_bars_rows<288>(nullptr, nullptr, 0, n, 0, *rt, nullptr, 0);
+    if (rt->ring_bins == 160) return launch_bars_rows<160, GLV_ROWS_RB>(nullptr, nullptr, 0, n, 0, *rt, nullptr, 0);
+    if (rt->ring_bins == 288) return launch_bars_rows<288, GLV_ROWS_RB>(nullptr, nullptr, 0, n, 0, *rt, nullptr, 0);
     return hipSuccess;
 }
 
@@ -736,8 +744,8 @@ hipError_t launch_bars(const float* spec, float* bars_out, size_t nrows, uint32_
     if (bars >= 256) {
         if (rt == nullptr || rt->mtiles == nullptr || rt->ntiles == 0) return hipErrorInvalidValue;
         if (rt->rounds != nullptr && rt->nrounds != 0 && nrows >= 256) {
-            if (rt->ring_bins == 160) return launch_bars_rows<160>(spec, bars_out, nrows, n, bars, *rt, st, r);
-            if (rt->ring_bins == 288) return launch_bars_rows<288>(spec, bars_out, nrows, n, bars, *rt, st, r);
+            if (rt->ring_bins == 160) return launch_bars_rows<160, GLV_ROWS_RB>(spec, bars_out, nrows, n, bars, *rt, st, r);
+            if (rt->ring_bins == 288) return launch_bars_rows<288, GLV_ROWS_RB>(spec, bars_out, nrows, n, bars, *rt, st, r);
         }
         const size_t units = nrows * (size_t) ((rt->ntiles + 1u) / 2u);
         const size_t wgs = (units + 3) / 4;

@@ -45,9 +45,9 @@ int main(int argc, char** argv) {
     CK(prepare_bars_rows(n, &rt));
     {
         int nb = -1;
-        const size_t lds = sizeof(float) * (size_t) 64 * bins;
-        hipError_t e = bins == 288 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, glv_bars_rows_kernel<288>, 256, lds)
-                                   : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, glv_bars_rows_kernel<160>, 256, lds);
+        const size_t lds = sizeof(float) * (size_t) GLV_ROWS_RB * bins;
+        hipError_t e = bins == 288 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, glv_bars_rows_kernel<288, GLV_ROWS_RB>, 256, lds)
+                                   : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, glv_bars_rows_kernel<160, GLV_ROWS_RB>, 256, lds);
         printf("occupancy: %d workgroups of 256 per CU with %zu B of LDS (%s)\n", nb, lds, hipGetErrorString(e));
     }
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
@@ -63,7 +63,7 @@ int main(int argc, char** argv) {
             best = ms < best ? ms : best; sum += ms;
         }
         printf("n=%u rows=%zu ring=%u rounds=%zu steps/row-block=%zu %s: %.4f ms (best %.4f)  %.1f TFLOP/s on the matrix cores\n", n, rows, bins, rounds.size(), steps, r16 ? "r16" : "f32",
-               sum / 3, best, (double) steps * 2.0 * 2048.0 * 2.0 * (double) ((rows + 63) / 64) / (sum / 3 * 1e-3) * 1e-12);
+               sum / 3, best, (double) steps * 2.0 * 2048.0 * 2.0 * (double) ((rows + 63) / 64) / (sum / 3 * 1e-3) * 1e-12);      // (64-row blocks: two MFMAs per step)
     }
     return 0;
 }

@@ -97,9 +97,10 @@ struct FrameArgs {
 // tests/test_glsl_twins.py).  Which group of which wave takes a chunk does not enter the arithmetic, so the fused epilogue
 // (row in LDS, T/8 groups per row) and glv_bars_kernel (row in HBM, 32 groups per row) give the same bits.
 // A bar's taps are counted by BIN: its range is contiguous, a bin that round(s) skips (s += 1.0 rounding up across a binade
-// boundary) is a tap of weight +0; and from 256 bars up every group of eight consecutive bars starts at one bin, the leading taps
-// of the later ones weighing +0 (glv_tables.h make_bar_taps: values untouched, the chunks counted from the group's bin) -- which is
-// what lets glv_bars_rows_kernel (glv_misc.hip: one lane per row) read an octet of texels once for eight bars.
+// boundary) is a tap of weight +0.
+// FROM 256 BARS UP (the pre-smoothing pass, bars == n) the contract is simpler: ONE fused-multiply-add chain over the bar's taps in
+// bin order from +0, acc = fma(w, x, acc), then / weight_sum -- what the matrix cores compute for 32 bars x 64 rows at a time
+// (glv_tables.h make_bar_mtiles, glv_misc.hip glv_bars_rows_kernel / glv_bars_seq_kernel; never fused into the frame kernel).
 // Why this shape: the loop is VALU-issue bound (the chip runs at its power limit, time follows the instruction count).
 // Round 2's version (16 lanes x 4 taps, mul + add, flags unpacked from a bit field) spent 41 instructions per 4 taps;
 // this one spends ~32 per 8: per-step bookkeeping is amortised over twice the taps, one DPP level is gone, multiplies

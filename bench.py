@@ -231,7 +231,7 @@ def extra_configs(G, torch, device, a, peak_gbs):
                  G.OP_GRAVITY | G.OP_AVERAGE | G.OP_BARS, device=device)
     dt, kms = run(b3, lambda: b3.process_s16(pcm, qs, glops | G.OP_BARS | G.OP_R16, st0))
     gl["sm_out"] = entry(f"same chain + the pre-smoothing pass (bars = n = {n}, bar_phase 0.5) -> `sm` GL_R16 texels, {s3} streams, two launches; "
-                         f"the pass is ~58 weighted taps per output texel (eight bars per wave share the texels, weights stream through the scalar cache): bound by that stream, not HBM", s3, b3.algorithmic_bytes(glops | G.OP_R16) + 12 * n * s3, dt, kms)
+                         f"the pass is ~58 weighted taps per output texel, a banded matrix product on the matrix cores (v_mfma_f32_32x32x2_f32 = the documented fma chain): bound by them and the output, not HBM", s3, b3.algorithmic_bytes(glops | G.OP_R16) + 12 * n * s3, dt, kms)
     gl["sm_out"]["launches_per_step"] = b3.last_launches()
     b3.close(); del qs
     # the pass-by-pass form of the same chain (the checker: f32 intermediates, three launches), for the record

@@ -245,15 +245,15 @@ def test_many_bars_of_many_rows_kernel_gives_the_documented_bits(glvlib, n, stre
     for b in (big, small, fb, fs): b.close()
 
 
-@pytest.mark.parametrize("n,bars,phase,rows", [(2048, 1001, 0.0, 300), (1024, 259, 0.5, 257), (4096, 4096, 0.5, 70 * 64 + 3), (512, 512, 0.5, 1024)])
+@pytest.mark.parametrize("n,bars,phase,rows", [(2048, 1001, 0.0, 300), (1024, 259, 0.5, 257), (4096, 4096, 0.5, 70 * 64 + 3), (512, 512, 0.5, 1024),
+                                                (8192, 8192, 0.5, 258), (16384, 256, 0.0, 300), (4096, 4096, 0.5, 6)])
 def test_many_rows_kernel_with_ragged_tables(glvlib, n, bars, phase, rows):
-    """The lane-per-row kernel away from the round numbers: a bar count that is not a multiple of eight (a last group of one bar, a
-    last round of fewer than 64 bars), bars further apart than in the pre-smoothing pass (wider leads), a row count that leaves a last
-    workgroup of 3 rows, more row blocks than resident workgroups -- every bar of every row against the oracle's documented order,
-    floats and texels."""
+    """The many-bars kernels away from the round numbers: a bar count that is not a multiple of 32 (a last tile of a few bars, a last
+    round of fewer than four tiles), bars further apart than in the pre-smoothing pass, a row count that leaves a last workgroup of
+    3 rows, more row blocks than resident workgroups (the matrix-core kernel); bars longer than the LDS ring (n = 8192, 16384) and
+    few rows (the one-lane-per-bar kernel) -- every bar of every row against the oracle's chain, floats."""
     import torch
     G = glvlib
-    assert rows % 2 == 1 or rows >= 256
     streams = (rows + 1) // 2
     rng = np.random.default_rng(n * 7 + bars)
     spec = (rng.random((streams * 2, n), dtype=np.float32) ** 3 * np.float32(1.2) - np.float32(0.02)).astype(np.float32)

@@ -523,7 +523,7 @@ int ensure_bar_tables(glv_batch* b) {
         std::vector<glv::BarMTile> mtiles;
         std::vector<glv::BarTile> rounds;
         std::vector<float> wt, wsum;
-        for (uint32_t bins : {160u, 288u}) {
+        for (uint32_t bins : {160u, 288u, 448u, 832u}) {                          // glv_misc.hip launch_bars: the ring sizes the kernel is built for
             if (!glv::make_bar_mtiles(mtiles, wt, wsum, rounds, desc, w, b->p.n, bins, 4u))       // 4 = glv_misc.hip kRowsWaves
                 return fail(GLV_ERR_INVALID, "bars: no tile table (bars=%u)", b->p.bars);
             if (!rounds.empty()) { b->bar_ring_bins = bins; break; }

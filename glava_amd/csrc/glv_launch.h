@@ -41,7 +41,7 @@ hipError_t launch_smooth(float* rows, size_t nrows, uint32_t n, const int* smin,
 hipError_t launch_window_split(const double* w_tab, float* split, uint32_t n, int* d_fail_shifted, hipStream_t st);
 hipError_t launch_window_split_check(const double* w_tab, const float* split, uint32_t n, unsigned long long* d_mismatches, hipStream_t st);
 // rt: the tables of the many-bars kernels (>= 256 bars; glv_tables.h make_bar_mtiles): tiles of 32 bars with their weights, the bars'
-// weight sums, and -- when they could be cut -- the rounds of the matrix-core kernel for an LDS ring of ring_bins (160 or 288) bins
+// weight sums, and -- when they could be cut -- the rounds of the matrix-core kernel for an LDS ring of ring_bins (160, 288, 448 or 832) bins
 struct BarRowsTables {
     const BarMTile* mtiles; uint32_t ntiles; const float* wt; const float* wsum;
     const BarTile* rounds; uint32_t nrounds, ring_bins;

@@ -733,6 +733,8 @@ hipError_t prepare_bars_rows(uint32_t n, const BarRowsTables* rt) {
     if (rt == nullptr || rt->rounds == nullptr || rt->nrounds == 0) return hipSuccess;
     if (rt->ring_bins == 160) return launch_bars_rows<160, GLV_ROWS_RB>(nullptr, nullptr, 0, n, 0, *rt, nullptr, 0);
     if (rt->ring_bins == 288) return launch_bars_rows<288, GLV_ROWS_RB>(nullptr, nullptr, 0, n, 0, *rt, nullptr, 0);
+    if (rt->ring_bins == 448) return launch_bars_rows<448, 32>(nullptr, nullptr, 0, n, 0, *rt, nullptr, 0);
+    if (rt->ring_bins == 832) return launch_bars_rows<832, 32>(nullptr, nullptr, 0, n, 0, *rt, nullptr, 0);
     return hipSuccess;
 }
 
@@ -744,8 +746,11 @@ hipError_t launch_bars(const float* spec, float* bars_out, size_t nrows, uint32_
     if (bars >= 256) {
         if (rt == nullptr || rt->mtiles == nullptr || rt->ntiles == 0) return hipErrorInvalidValue;
         if (rt->rounds != nullptr && rt->nrounds != 0 && nrows >= 256) {
+            // (the long bars of n = 8192 / 16384 need a longer ring: 32 rows per workgroup there, one MFMA per step)
             if (rt->ring_bins == 160) return launch_bars_rows<160, GLV_ROWS_RB>(spec, bars_out, nrows, n, bars, *rt, st, r);
             if (rt->ring_bins == 288) return launch_bars_rows<288, GLV_ROWS_RB>(spec, bars_out, nrows, n, bars, *rt, st, r);
+            if (rt->ring_bins == 448) return launch_bars_rows<448, 32>(spec, bars_out, nrows, n, bars, *rt, st, r);
+            if (rt->ring_bins == 832) return launch_bars_rows<832, 32>(spec, bars_out, nrows, n, bars, *rt, st, r);
         }
         const size_t units = nrows * (size_t) ((rt->ntiles + 1u) / 2u);
         const size_t wgs = (units + 3) / 4;

@@ -246,12 +246,12 @@ def test_many_bars_of_many_rows_kernel_gives_the_documented_bits(glvlib, n, stre
 
 
 @pytest.mark.parametrize("n,bars,phase,rows", [(2048, 1001, 0.0, 300), (1024, 259, 0.5, 257), (4096, 4096, 0.5, 70 * 64 + 3), (512, 512, 0.5, 1024),
-                                                (8192, 8192, 0.5, 258), (16384, 256, 0.0, 300), (4096, 4096, 0.5, 6)])
+                                                (8192, 8192, 0.5, 258), (16384, 16384, 0.5, 258), (16384, 256, 0.0, 300), (4096, 4096, 0.5, 6)])
 def test_many_rows_kernel_with_ragged_tables(glvlib, n, bars, phase, rows):
     """The many-bars kernels away from the round numbers: a bar count that is not a multiple of 32 (a last tile of a few bars, a last
     round of fewer than four tiles), bars further apart than in the pre-smoothing pass, a row count that leaves a last workgroup of
-    3 rows, more row blocks than resident workgroups (the matrix-core kernel); bars longer than the LDS ring (n = 8192, 16384) and
-    few rows (the one-lane-per-bar kernel) -- every bar of every row against the oracle's chain, floats."""
+    3 rows, more row blocks than resident workgroups, the long rings of n = 8192 / 16384 with 32 rows per workgroup (the matrix-core
+    kernel); tiles too wide for any ring (256 bars at n = 16384) and few rows (the one-lane-per-bar kernel) -- every bar of every row against the oracle's chain, floats."""
     import torch
     G = glvlib
     streams = (rows + 1) // 2

@@ -14,7 +14,6 @@ for n in [int(x) for x in sys.argv[1:]] or [1024, 2048, 4096]:
     out = torch.empty((streams * 2, n), dtype=torch.float32, device="cuda")
     b = G.Batch(G.Params(n=n, bars=n, bar_phase=0.5), streams, G.OP_FFT | G.OP_BARS)
     dt = timed(lambda: b.bars(spec, out), sync, steps=10)
-    taps = {1024: None, 2048: None, 4096: None}
-    tag = "glv_bars_kernel (GLV_NO_BARS_ROWS)" if os.environ.get("GLV_NO_BARS_ROWS") else "glv_bars_rows_kernel"
+    tag = "glv_bars_seq_kernel (GLV_NO_BARS_ROWS)" if os.environ.get("GLV_NO_BARS_ROWS") else "glv_bars_rows_kernel"
     print(f"{tag}: N={n} bars=n, {streams * 2} rows: {dt * 1e3:.3f} ms  -> {streams / dt / 1e6:.2f} M stereo frames/s  ({dt * 1e9 / (streams * 2):.1f} ns per row)")
     b.close()

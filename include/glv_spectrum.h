@@ -50,11 +50,13 @@ enum {
                                    smooth.glsl:13-64, radial/1.frag:58-70): emit `bars` values per
                                    channel instead of n bins; d_out is float [streams][2][bars].
                                    Inputs are clamped to [0, 1] (NaN -> 0) like the GL_R16 texels the shader
-                                   samples; the taps' products are summed in a documented, fixed order (chunks
-                                   of 16 / 32 / 64 taps by n, fused multiply-add chains: glava_amd/csrc/glv_frame.h "GLV_OP_BARS
-                                   arithmetic"; oracle/glv_oracle.c glvo_bars_chunked restates it) -- within
-                                   2e-4 relative of the shader's tap-by-tap loop, identical bits on every
-                                   device path.  A bar whose weights sum to 0 is 0 / 0 as in the shader */
+                                   samples; the taps' products are summed in a documented, fixed order (below 256
+                                   bars: chunks of 16 / 32 / 64 taps by n, fused multiply-add chains; from 256 bars up -- the
+                                   pre-smoothing pass, bars = n -- ONE fused multiply-add chain per bar in bin order, which the
+                                   matrix cores compute: glava_amd/csrc/glv_frame.h "GLV_OP_BARS arithmetic";
+                                   oracle/glv_oracle.c glvo_bars_chunked restates both) -- within 2e-4 relative of the
+                                   shader's tap-by-tap loop, identical bits on every device path.  A bar whose weights
+                                   sum to 0 is 0 / 0 as in the shader */
     GLV_OP_SMOOTH   = 1u << 6,  /* CPU-path log-window mean  == transform_smooth   render.c:694-718;
                                    applied last, in place on each row (after fft/gravity/average) */
     GLV_OP_MAGNITUDE = 1u << 7, /* the magnitude stage alone: b = (float)(log(|b| + 1.0f) / 3) * tilt(i),

@@ -234,6 +234,32 @@ def extra_configs(G, torch, device, a, peak_gbs):
                          f"the pass is ~58 weighted taps per output texel, a banded matrix product on the matrix cores (v_mfma_f32_32x32x2_f32 = the documented fma chain): bound by them and the output, not HBM", s3, b3.algorithmic_bytes(glops | G.OP_R16) + 12 * n * s3, dt, kms)
     gl["sm_out"]["launches_per_step"] = b3.last_launches()
     b3.close(); del qs
+    # the pre-smoothing kernel by itself on rows already in HBM: its roofline is the f32 matrix rate (157.3 TFLOP/s dense at nominal
+    # clock, MI355X_MICROARCH.md), counted on the USEFUL multiply-adds (smooth_audio()'s own taps; the tiles' padding is not counted)
+    try:
+        import numpy as np
+        f32 = np.float32
+        k = (np.arange(n, dtype=f32) + f32(0.5)) / f32(n)
+        sc = lambda u: (-np.log((f32(-0.9) * u + f32(1.0)).astype(f32)).astype(f32) / f32(8.0)).astype(f32)
+        smin = (sc(np.clip(k - f32(0.025), f32(0), f32(1)).astype(f32)) * f32(n)).astype(f32)
+        smax = (sc(np.clip(k + f32(0.025), f32(0), f32(1)).astype(f32)) * f32(n)).astype(f32)
+        taps = int(np.sum(np.floor((smax - smin).astype(np.float64)) + 1))
+        rows_in = torch.rand((s3 * 2, n), dtype=torch.float32, device="cuda")
+        b4 = G.Batch(G.Params(n=n, bars=n, bar_phase=0.5), s3, G.OP_FFT | G.OP_BARS, device=device)
+        sync = torch.cuda.synchronize
+        for _ in range(10): b4.bars(rows_in, qs4 := torch.empty((s3 * 2, n), dtype=torch.float32, device="cuda"))
+        sync()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(20): b4.bars(rows_in, qs4)
+        e1.record(); sync()
+        ms = e0.elapsed_time(e1) / 20
+        tf = 2.0 * taps * s3 * 2 / (ms * 1e-3) * 1e-12
+        gl["sm_out"]["pass_alone"] = {"note": f"glv_bars_rows_kernel alone, {s3 * 2} float rows in HBM -> floats: {taps} useful multiply-adds per row on v_mfma_f32_32x32x2_f32",
+                                      "ms": ms, "roofline": {"bound": "mfma", "achieved": tf, "peak": 157.3, "unit": "TFLOP/s", "frac": tf / 157.3}}
+        b4.close(); del rows_in, qs4
+    except Exception as ex:                                   # never fails the bench line
+        gl["sm_out"]["pass_alone"] = {"note": f"not measured: {ex}"}
     # the pass-by-pass form of the same chain (the checker: f32 intermediates, three launches), for the record
     s2 = s // 4
     b2 = G.Batch(G.Params(n=n, log_mode=a.log_mode, avg_frames=F, avg_window_kind=1, gl_storage=2), s2, G.OP_GRAVITY | G.OP_AVERAGE, device=device)

@@ -523,12 +523,19 @@ __global__ void __launch_bounds__(64 * kRowsWaves) glv_bars_rows_kernel(const fl
                 }
                 wp += (size_t) 8 * 64;
             };
-            for (uint32_t s8 = 0; s8 < steps; s8 += 8u) {
-                if (bank == 0) eight(std::integral_constant<int, 0>{});
-                else if (bank == 1) eight(std::integral_constant<int, (NB > 1 ? 1 : 0)>{});
-                else if (bank == 2) eight(std::integral_constant<int, (NB > 2 ? 2 : 0)>{});
-                else eight(std::integral_constant<int, (NB > 3 ? 3 : 0)>{});
-                bank = bank + 1u == (uint32_t) NB ? 0u : bank + 1u;
+            if constexpr (NB == 1) {
+                // (a taken branch between MFMAs is dear -- four-step blocks: 0.41 instead of 0.33 ms --, so two blocks per trip where there are two)
+                uint32_t s8 = 0;
+                for (; s8 + 16u <= steps; s8 += 16u) { eight(std::integral_constant<int, 0>{}); eight(std::integral_constant<int, 0>{}); }
+                if (s8 < steps) eight(std::integral_constant<int, 0>{});
+            } else {
+                for (uint32_t s8 = 0; s8 < steps; s8 += 8u) {
+                    if (bank == 0) eight(std::integral_constant<int, 0>{});
+                    else if (bank == 1) eight(std::integral_constant<int, (NB > 1 ? 1 : 0)>{});
+                    else if (bank == 2) eight(std::integral_constant<int, (NB > 2 ? 2 : 0)>{});
+                    else eight(std::integral_constant<int, (NB > 3 ? 3 : 0)>{});
+                    bank = bank + 1u == (uint32_t) NB ? 0u : bank + 1u;
+                }
             }
             park_new();
             // a lane's 32 results are one bar (k0 + lane % 32) of the rows 8 (r / 4) + 4 (lane / 32) + r % 4 (+ 32 for acc1)

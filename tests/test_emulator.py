@@ -356,7 +356,7 @@ def test_many_bars_arithmetic_is_the_documented_one(emu, oracle, n, bars, bins, 
 
 @pytest.mark.parametrize("n,b_stride", [(1024, 16), (4096, 64)])
 def test_rows_kernel_division_by_reciprocal_is_the_quotient(emu, n, b_stride):
-    """The lane-per-row kernel divides a bar's total by its weight sum in three instructions -- q0 = a * r, rem = fma(-q0, b, a),
+    """The many-bars kernels divide a bar's total by its weight sum in three instructions -- q0 = a * r, rem = fma(-q0, b, a),
     q = fma(rem, r, q0) with the host's r = RN(1 / b) (Markstein) -- where the table says that is exact.  Checked for the weight
     sums of the pre-smoothing pass against a / b over EVERY significand of a in four binades (the two around b, the smallest and the
     largest totals the fast path sees): 2^25 quotients per bar, no mismatch.  By default every 16th / 64th distinct weight sum (the CPU

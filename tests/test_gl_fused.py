@@ -205,10 +205,11 @@ def test_gl_state_storage_class_is_fixed_at_creation(glvlib):
 
 @pytest.mark.parametrize("n,streams", [(1024, 150), (2048, 129), (4096, 165), (4096, 128)])
 def test_many_bars_of_many_rows_kernel_gives_the_documented_bits(glvlib, n, streams):
-    """The pre-smoothing pass at scale (bars == n, bar_phase 0.5; >= 256 rows): glv_bars_rows_kernel -- one lane per row, weights as
-    wave-uniform scalars, the rows' window in LDS -- walks the documented summation order sequentially, so its bars equal the
-    oracle's glvo_bars_chunked_at and the small-batch kernel's (glv_bars_kernel, fewer than 256 rows) bit for bit; texel output
-    likewise.  Rows include values outside [0, 1], NaN and Inf (clamped like a GL_R16 texel)."""
+    """The pre-smoothing pass at scale (bars == n, bar_phase 0.5; >= 256 rows): glv_bars_rows_kernel -- a banded matrix product on the
+    matrix cores, 32 bars x 64 rows x 2 bins per v_mfma_f32_32x32x2_f32, the rows' texels in an LDS ring -- computes the documented
+    order (from 256 bars up: one fma chain per bar in bin order), so its bars equal the oracle's glvo_bars_chunked_at and the
+    one-lane-per-bar kernel's (glv_bars_seq_kernel, fewer than 256 rows) bit for bit, on EVERY row; texel output likewise.  Rows
+    include values outside [0, 1], NaN and Inf (clamped like a GL_R16 texel)."""
     import torch
     G = glvlib
     rows = streams * 2

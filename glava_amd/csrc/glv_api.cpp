@@ -321,7 +321,7 @@ struct glv_batch {
     float* d_bar_wt = nullptr;              // {weight sum, reciprocal}, and -- when they could be cut -- the rounds of glv_bars_rows_kernel for its LDS ring
     float* d_bar_wsum = nullptr;
     glv::BarTile* d_bar_rounds = nullptr;
-    uint32_t bar_ntiles = 0, bar_nrounds = 0, bar_ring_bins = 0;
+    uint32_t bar_ntiles = 0, bar_nrounds = 0, bar_ring_bins = 0, bar_bins_needed = 0;      // bar_bins_needed: bins of a row the many-bars kernels sample (0: all)
     glv::BarRowsTables rows_tables() const { return glv::BarRowsTables{d_bar_mtiles, bar_ntiles, d_bar_wt, d_bar_wsum, d_bar_rounds, bar_nrounds, bar_ring_bins}; }
     // timing
     bool timing = false;
@@ -518,7 +518,7 @@ int ensure_bar_tables(glv_batch* b) {
     HIP_TRY(hipMemcpy(b->d_bar_w, w.data(), sizeof(float) * w.size(), hipMemcpyHostToDevice));
     b->bar_count = b->p.bars; b->bar_factor = b->p.smooth_factor; b->bar_phase = b->p.bar_phase;
     // many bars (the pre-smoothing pass): tiles of 32 bars for the chain kernels; rounds for the smallest LDS ring that takes them
-    b->bar_ntiles = 0; b->bar_nrounds = 0; b->bar_ring_bins = 0;
+    b->bar_ntiles = 0; b->bar_nrounds = 0; b->bar_ring_bins = 0; b->bar_bins_needed = 0;
     if (b->p.bars >= glv::kBarSeqMin) {
         std::vector<glv::BarMTile> mtiles;
         std::vector<glv::BarTile> rounds;
@@ -536,6 +536,9 @@ int ensure_bar_tables(glv_batch* b) {
         HIP_TRY(hipMalloc(&b->d_bar_wsum, sizeof(float) * wsum.size()));
         HIP_TRY(hipMemcpy(b->d_bar_wsum, wsum.data(), sizeof(float) * wsum.size(), hipMemcpyHostToDevice));
         b->bar_ntiles = (uint32_t) mtiles.size();
+        b->bar_bins_needed = 0;
+        for (const glv::BarDesc& d : desc) b->bar_bins_needed = d.first_bin + d.count > b->bar_bins_needed ? d.first_bin + d.count : b->bar_bins_needed;
+        b->bar_bins_needed = (b->bar_bins_needed + 63u) & ~63u;                     // whole store instructions (and slack for the fill's 16-byte loads)
         if (!rounds.empty()) {
             HIP_TRY(hipMalloc(&b->d_bar_rounds, sizeof(glv::BarTile) * rounds.size()));
             HIP_TRY(hipMemcpy(b->d_bar_rounds, rounds.data(), sizeof(glv::BarTile) * rounds.size(), hipMemcpyHostToDevice));
@@ -714,6 +717,9 @@ int process(glv_batch* b, const void* d_in, int in_mode, float* d_out, unsigned 
         // render.c:2188-2265 (+ :2277-2303 with bars) in ONE launch on uint16 state.  Bars that do not fit the row's slack in LDS
         // (bars == n: the pre-smoothing pass) sample the finished rows' floats from the scratch rows in a second launch.
         a.gl_storage = 1;
+        // the rows go to the bars of a second launch and nowhere else (the scratch rows): what those bars do not sample is not stored
+        if ((ops & GLV_OP_BARS) && !fused_bars && d_out == b->d_scratch && b->bar_bins_needed != 0 && b->bar_bins_needed < b->p.n)
+            a.out_limit = b->bar_bins_needed * 4u;
         if (int rc = timed_launch_begin(b, st)) return rc;
         b->last_grid = grid; b->last_variant = variant;
         e = glv::launch_frame(b->log_nn, in_mode, (int) b->p.log_mode, variant, a, grid, st); ++b->last_launches;

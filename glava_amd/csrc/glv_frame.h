@@ -72,6 +72,8 @@ struct FrameArgs {
     uint32_t rot;          // ring modes (RING kernels): index of the ring's oldest stereo frame = where the window starts
     float inv_n, fft_scale, one_minus_cutoff, g, F_as_float;
     float F_rcp;           // RN(1 / F): the GL_R16 chain's final division (glv_core.h div_frames)
+    uint32_t out_limit;    // gl_storage 1, rows handed to a later kernel only (the bars of a second launch): bytes of a float row that are
+                           // written at all -- the pre-smoothing pass samples bins below 0.31 n, the rest of the row is not stored (0: no limit)
     double wts[64];        // window_frame weights, oldest first (render.c:661 as expanded at :766); GLV_MAX_AVG_FRAMES
     float wts32[64];       // the same rounded to float: the GL passes' arithmetic is the shader's, 32-bit (weighted_texels)
     // fused GLV_OP_BARS (stateful kernels, lanes-per-row a multiple of 64): the finished row goes to the
@@ -1267,6 +1269,8 @@ struct Frame {
             if (TO_LDS || !r16_out) {
 #pragma unroll
                 for (int j = 0; j < GL16_BLK; j += (PAIRED ? 2 : 1)) {
+                    // (out_limit: a store instruction covers consecutive points across its lanes, so whole instructions fall away)
+                    if (!TO_LDS && a.out_limit != 0u && off[j] >= a.out_limit) continue;
                     if constexpr (PAIRED) { cf2 two; two.a = texels_to_float(tex[j]); two.b = texels_to_float(tex[j + 1]); st<cf2>(out_row, off[j], two); }
                     else st<cf>(out_row, off[j], texels_to_float(tex[j]));
                 }

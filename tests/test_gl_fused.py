@@ -271,3 +271,45 @@ def test_many_rows_kernel_with_ragged_tables(glvlib, n, bars, phase, rows):
     same = (got.view(np.uint32) == want.view(np.uint32)) | (np.isnan(got) & np.isnan(want))
     assert same.all(), (int((~same).sum()), np.argwhere(~same)[:4].tolist())
     b.close()
+
+
+def test_many_bars_kernels_agree_over_random_parameters(glvlib, monkeypatch):
+    """The matrix-core kernel against the one-lane-per-bar kernel (GLV_NO_BARS_ROWS at table creation) over a seeded sweep of sizes,
+    bar counts, smoothing widths and phases -- wide bars (smooth_factor up to 0.12: hundreds of taps), bar counts that leave ragged
+    tiles and rounds, rings of every size the kernel is built for, parameter sets no ring takes (both batches then run the same
+    kernel) -- bit for bit, floats and texels; and one row of each against the oracle's chain."""
+    import torch
+    G = glvlib
+    rng = np.random.default_rng(2024)
+    seen_rings = 0
+    for trial in range(24):
+        n = int(rng.choice([256, 512, 1024, 2048, 4096, 8192]))
+        bars = int(rng.choice([256, 300, 333, 512, 1000, n])) if n >= 512 else 256
+        bars = min(bars, n)
+        factor = float(rng.choice([0.005, 0.025, 0.05, 0.12]))
+        phase = float(rng.choice([0.0, 0.5, 0.25]))
+        rows = 256 + 2 * int(rng.integers(0, 40))
+        streams = rows // 2
+        spec = (rng.random((rows, n), dtype=np.float32) ** 2 * np.float32(1.25) - np.float32(0.04)).astype(np.float32)
+        spec[2, ::9] = np.nan
+        p = G.Params(n=n, bars=bars, bar_phase=phase, smooth_factor=factor)
+        d_spec = torch.from_numpy(spec).cuda()
+        try:
+            fast = G.Batch(p, streams, G.OP_FFT | G.OP_BARS)
+        except G.GlvError:
+            continue                                                        # (a tap chunk would leave the row: refused at creation)
+        monkeypatch.setenv("GLV_NO_BARS_ROWS", "1")
+        slow = G.Batch(p, streams, G.OP_FFT | G.OP_BARS)
+        monkeypatch.delenv("GLV_NO_BARS_ROWS")
+        a = torch.full((rows, bars), -1.0, dtype=torch.float32, device="cuda"); b2 = torch.full_like(a, -2.0)
+        fast.bars(d_spec, a); slow.bars(d_spec, b2)
+        ga, gb = a.cpu().numpy(), b2.cpu().numpy()
+        same = (ga.view(np.uint32) == gb.view(np.uint32)) | (np.isnan(ga) & np.isnan(gb))
+        assert same.all(), (trial, n, bars, factor, phase, int((~same).sum()))
+        want = np.empty(bars, np.float32)
+        Oracle.lib().glvo_bars_chunked_at(np.ascontiguousarray(spec[rows - 1]), n, want, bars, factor, phase)
+        ok = (ga[rows - 1].view(np.uint32) == want.view(np.uint32)) | (np.isnan(ga[rows - 1]) & np.isnan(want))
+        assert ok.all(), (trial, n, bars, factor, phase)
+        seen_rings += 1
+        fast.close(); slow.close()
+    assert seen_rings >= 12

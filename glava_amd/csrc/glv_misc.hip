@@ -720,9 +720,11 @@ static hipError_t launch_bars_rows(const float* spec, float* bars_out, size_t nr
         }
     }
     if (nrows == 0) return hipSuccess;                                          // prepare_bars_rows: the attribute only
-    // 64 rows per workgroup in x, ranges of rounds in y: two resident workgroups per CU, twice over (a range start refills the whole ring)
+    // RB rows per workgroup in x, ranges of rounds in y: 512 workgroups = two per CU, once (a range start refills the whole ring; N = 4096,
+    // ms with 1 / 2 / 4 / 8 / 16 ranges: 32 K rows 0.321 / 0.328 / 0.337 / 0.351 / 0.370, 8 K rows 0.213 / 0.137 / 0.093 / 0.099 / 0.102,
+    // 2 K rows 0.206 / 0.131 / 0.072 / 0.048 / 0.045)
     const uint32_t xb = (uint32_t) ((nrows + RB - 1) / RB);
-    uint32_t yb = xb >= 1024 ? 1 : (1024 + xb - 1) / xb;
+    uint32_t yb = xb >= 512 ? 1 : (512 + xb - 1) / xb;
 #if defined(GLV_TUNE_BUILD)
     if (const char* o = std::getenv("GLV_ROWS_YB")) yb = (uint32_t) atoi(o);       // tools/rows_bench: the split of the rounds over blockIdx.y
 #endif

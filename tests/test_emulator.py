@@ -369,3 +369,33 @@ def test_rows_kernel_division_by_reciprocal_is_the_quotient(emu, n, b_stride):
     checked = C.c_ulonglong(0)
     bad = emu.glvemu_div_rcp_check(n, n, 0.025, 0.5, min(16, os.cpu_count() or 2), b_stride, C.byref(checked))
     assert bad == 0 and checked.value >= (n // (2 * b_stride) - 16) * (1 << 25), (bad, checked.value)
+
+
+def test_tile_tables_over_random_parameters(emu, oracle):
+    """A seeded sweep of sizes, bar counts (>= 256), smoothing widths, phases and ring sizes: the tile / round tables always pass their
+    invariants (or report that no rounds exist: -1), and the chains walked off them equal the oracle's per-bar chains bit for bit."""
+    import ctypes as C
+    rng = np.random.default_rng(77)
+    fp = C.POINTER(C.c_float)
+    emu.glvemu_bars_rows.argtypes = [fp, C.c_int, C.c_int, C.c_float, C.c_float, C.c_int, fp]
+    emu.glvemu_bars_rows.restype = C.c_int
+    with_rounds = 0
+    for trial in range(40):
+        n = int(rng.choice([256, 512, 1024, 2048, 4096]))
+        bars = int(rng.integers(256, n + 1))
+        factor = float(rng.choice([0.004, 0.0125, 0.025, 0.06, 0.11]))
+        phase = float(rng.choice([0.0, 0.5, 0.3]))
+        bins = int(rng.choice([160, 288, 448, 832]))
+        nr, mc = C.c_uint(0), C.c_uint(0)
+        rc = emu.glvemu_bar_tiles_check(n, bars, C.c_float(factor), C.c_float(phase), bins, 4, C.byref(nr), C.byref(mc))
+        assert rc in (0, -1), (trial, n, bars, factor, phase, bins, rc)
+        with_rounds += rc == 0
+        if trial % 4 == 0:
+            tex = (rng.random(n, dtype=np.float32) * np.float32(1.1) - np.float32(0.03)).astype(np.float32)
+            got = np.full(bars, -1, np.float32)
+            assert emu.glvemu_bars_rows(tex.ctypes.data_as(fp), n, bars, factor, phase, bins, got.ctypes.data_as(fp)) == 0
+            want = np.zeros(bars, np.float32)
+            oracle.lib().glvo_bars_chunked_at(np.ascontiguousarray(tex), n, want, bars, factor, phase)
+            same = (got.view(np.uint32) == want.view(np.uint32)) | (np.isnan(got) & np.isnan(want))
+            assert same.all(), (trial, n, bars, factor, phase)
+    assert with_rounds >= 10

@@ -374,7 +374,7 @@ __global__ void __launch_bounds__(256) glv_bars_short_kernel(const float* __rest
 // tile of consecutive bars can all run over the tile's common bin range, which makes the pass a banded matrix product:
 //     out[row][bar] = sum over bins of x[row][bin] * w[bin][bar]          (then / weight_sum[bar])
 //
-// glv_bars_rows_kernel (>= 256 rows): the matrix cores.  One v_mfma_f32_32x32x2_f32 is 32 rows x 32 bars x 2 bins, and on gfx950 it
+// glv_bars_rows_kernel (whenever the host could cut rounds for an LDS ring): the matrix cores.  One v_mfma_f32_32x32x2_f32 is 32 rows x 32 bars x 2 bins, and on gfx950 it
 // IS the k-ordered fmaf chain (tools/mfma_probe.hip: bit for bit, subnormals and zeros included) -- the documented arithmetic, at the
 // f32 matrix rate.  A workgroup is four waves on the SAME 64 rows.  The rows' texels live in LDS as a RING of S bins, [bin mod S][row]
 // (the a-operand of a step -- lane l: row l % 32 of the half, bin 2 s + l / 32 -- is one conflict-free ds_read_b32), clamped to
@@ -390,6 +390,7 @@ __global__ void __launch_bounds__(256) glv_bars_short_kernel(const float* __rest
 // for v_pk_fma_f32 (chunked summation, groups of bars padded to one first bin), bound by the L2 round trips of its scalar weight
 // stream, 0.60 ms.
 constexpr int kRowsWaves = 4;
+constexpr size_t kRowsMin = 1;           // rows from which the matrix-core kernel is used: any (tools/sm_small.py)
 #if !defined(GLV_ROWS_RB)               /* rows per workgroup: 64 (two MFMAs per step on the same weights) or 32; tools/rows_bench A/B builds override */
 #define GLV_ROWS_RB 64
 #endif
@@ -588,8 +589,9 @@ __global__ void __launch_bounds__(64 * kRowsWaves) glv_bars_rows_kernel(const fl
 #endif
 }
 
-// The same arithmetic with one lane per bar, off the same tables: few rows (a single GLava instance has two), or bars whose taps do
-// not fit the LDS ring (n >= 8192).  A wave = two tiles of one row; the row is read through L1 (32 lanes share a texel).
+// The same arithmetic with one lane per bar, off the same tables: tiles no LDS ring takes (n = 32768; a few hundred bars spread over a
+// long row).  A wave = two tiles of one row; the row is read through L1 (32 lanes share a texel).  (Even two rows -- a single GLava
+// instance -- are quicker on the matrix cores where rounds exist: N = 4096 14.9 us against 27.1 us, tools/sm_small.py.)
 __global__ void __launch_bounds__(256) glv_bars_seq_kernel(const float* __restrict__ spec, void* __restrict__ bars_out, size_t nrows, uint32_t n, uint32_t bars,
                                                           const BarMTile* __restrict__ mtiles, uint32_t ntiles, const float* __restrict__ wt,
                                                           const float* __restrict__ wsum, int r16) {
@@ -750,11 +752,11 @@ hipError_t prepare_bars_rows(uint32_t n, const BarRowsTables* rt) {
 hipError_t launch_bars(const float* spec, float* bars_out, size_t nrows, uint32_t n, uint32_t bars, uint32_t nsteps,
                        const BarItem* items, const BarDesc* desc, const float* tap_w, hipStream_t st, bool r16, const BarRowsTables* rt) {
     const int r = r16 ? 1 : 0;
-    // many bars: one fma chain per bar (glv_tables.h make_bar_mtiles) -- on the matrix cores when there are rows to fill them and the
-    // host could cut the tiles into rounds for the LDS ring, one lane per bar otherwise
+    // many bars: one fma chain per bar (glv_tables.h make_bar_mtiles) -- on the matrix cores when the host could cut the tiles into
+    // rounds for the LDS ring, one lane per bar otherwise
     if (bars >= 256) {
         if (rt == nullptr || rt->mtiles == nullptr || rt->ntiles == 0) return hipErrorInvalidValue;
-        if (rt->rounds != nullptr && rt->nrounds != 0 && nrows >= 256) {
+        if (rt->rounds != nullptr && rt->nrounds != 0 && nrows >= kRowsMin) {
             // (the long bars of n = 8192 / 16384 need a longer ring: 32 rows per workgroup there, one MFMA per step)
             if (rt->ring_bins == 160) return launch_bars_rows<160, GLV_ROWS_RB>(spec, bars_out, nrows, n, bars, *rt, st, r);
             if (rt->ring_bins == 288) return launch_bars_rows<288, GLV_ROWS_RB>(spec, bars_out, nrows, n, bars, *rt, st, r);

@@ -205,10 +205,11 @@ def test_gl_state_storage_class_is_fixed_at_creation(glvlib):
 
 @pytest.mark.parametrize("n,streams", [(1024, 150), (2048, 129), (4096, 165), (4096, 128)])
 def test_many_bars_of_many_rows_kernel_gives_the_documented_bits(glvlib, n, streams):
-    """The pre-smoothing pass at scale (bars == n, bar_phase 0.5; >= 256 rows): glv_bars_rows_kernel -- a banded matrix product on the
+    """The pre-smoothing pass at scale (bars == n, bar_phase 0.5): glv_bars_rows_kernel -- a banded matrix product on the
     matrix cores, 32 bars x 64 rows x 2 bins per v_mfma_f32_32x32x2_f32, the rows' texels in an LDS ring -- computes the documented
-    order (from 256 bars up: one fma chain per bar in bin order), so its bars equal the oracle's glvo_bars_chunked_at and the
-    one-lane-per-bar kernel's (glv_bars_seq_kernel, fewer than 256 rows) bit for bit, on EVERY row; texel output likewise.  Rows
+    order (from 256 bars up: one fma chain per bar in bin order), so its bars equal the oracle's glvo_bars_chunked_at bit for bit on
+    EVERY row, whether a batch has hundreds of rows or sixteen (partial row blocks); texel output likewise (the one-lane-per-bar
+    kernel: test_many_bars_kernels_agree_over_random_parameters).  Rows
     include values outside [0, 1], NaN and Inf (clamped like a GL_R16 texel)."""
     import torch
     G = glvlib
@@ -247,7 +248,7 @@ def test_many_bars_of_many_rows_kernel_gives_the_documented_bits(glvlib, n, stre
 
 
 @pytest.mark.parametrize("n,bars,phase,rows", [(2048, 1001, 0.0, 300), (1024, 259, 0.5, 257), (4096, 4096, 0.5, 70 * 64 + 3), (512, 512, 0.5, 1024),
-                                                (8192, 8192, 0.5, 258), (16384, 16384, 0.5, 258), (16384, 256, 0.0, 300), (4096, 4096, 0.5, 6)])
+                                                (8192, 8192, 0.5, 258), (16384, 16384, 0.5, 258), (16384, 256, 0.0, 300), (4096, 4096, 0.5, 6), (4096, 4096, 0.5, 70), (2048, 2048, 0.5, 64)])
 def test_many_rows_kernel_with_ragged_tables(glvlib, n, bars, phase, rows):
     """The many-bars kernels away from the round numbers: a bar count that is not a multiple of 32 (a last tile of a few bars, a last
     round of fewer than four tiles), bars further apart than in the pre-smoothing pass, a row count that leaves a last workgroup of

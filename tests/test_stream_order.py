@@ -108,7 +108,7 @@ def test_first_process_call_can_be_captured_and_replayed(glvlib, case):
                            ops=G.OP_FFT | G.OP_GRAVITY | G.OP_AVERAGE | G.OP_BARS, dt=torch.float32, w=80, per_graph=F),
         "gl_default": dict(p=G.Params(n=n, avg_frames=F, avg_window_kind=1, gl_storage=1), mask=G.OP_GRAVITY | G.OP_AVERAGE,
                            ops=G.OP_FFT | G.OP_GRAVITY | G.OP_AVERAGE | G.OP_R16, dt=torch.int16, w=n, per_graph=F),
-        # + the pre-smoothing pass (two launches; 256 rows: the matrix-core kernel with its > 64 KiB LDS opt-in set at creation)
+        # + the pre-smoothing pass (two launches; the matrix-core kernel with its > 64 KiB LDS opt-in set at creation)
         "gl_default_sm": dict(p=G.Params(n=n, avg_frames=F, avg_window_kind=1, gl_storage=1, bars=n, bar_phase=0.5), mask=G.OP_GRAVITY | G.OP_AVERAGE | G.OP_BARS,
                               ops=G.OP_FFT | G.OP_GRAVITY | G.OP_AVERAGE | G.OP_BARS | G.OP_R16, dt=torch.int16, w=n, per_graph=F, streams=128),
         "gravity_out_is_state": dict(p=G.Params(n=n), mask=G.OP_GRAVITY, ops=G.OP_FFT | G.OP_GRAVITY | G.OP_OUTPUT_IS_STATE,

@@ -323,6 +323,13 @@ struct glv_batch {
     glv::BarTile* d_bar_rounds = nullptr;
     uint32_t bar_ntiles = 0, bar_nrounds = 0, bar_ring_bins = 0, bar_bins_needed = 0;      // bar_bins_needed: bins of a row the many-bars kernels sample (0: all)
     glv::BarRowsTables rows_tables() const { return glv::BarRowsTables{d_bar_mtiles, bar_ntiles, d_bar_wt, d_bar_wsum, d_bar_rounds, bar_nrounds, bar_ring_bins}; }
+    // the same pass over TEXEL rows (the GL chains, gl_storage != 0): exact integer arithmetic on the i8 matrix cores (glv_tables.h make_bar_itiles)
+    glv::BarMTile* d_bar_itiles = nullptr; int8_t* d_bar_wq = nullptr; glv::BarIFin* d_bar_fin = nullptr; glv::BarTile* d_bar_irounds = nullptr;
+    uint32_t bar_intiles = 0, bar_inrounds = 0, bar_iring_bins = 0;
+    bool bar_i8_none = false;    // the integer tables could not be made for these parameters (a bar wider than any ring / P > 31): the f32 chain serves
+    bool bar_i8_off = false;     // GLV_NO_BARS_I8 in the environment at creation (diagnostics: the f32 matrix-core kernel on texel rows too)
+    glv::BarIRowsTables irows_tables() const { return glv::BarIRowsTables{d_bar_itiles, bar_intiles, d_bar_wq, d_bar_fin, d_bar_irounds, bar_inrounds, bar_iring_bins}; }
+    bool bars_i8() const { return d_bar_irounds != nullptr && bar_inrounds != 0; }
     // timing
     bool timing = false;
     std::vector<hipEvent_t> ev;  // start/stop pairs
@@ -478,7 +485,8 @@ int ensure_smooth_tables(glv_batch* b) {
 // GLV_OP_BARS tables: taps, weights, the work lists of glv_bars_kernel and one fused work list per kernel configuration of the
 // size (their lanes per row differ).  Host generation + synchronous upload: creation / glv_batch_set_params only.
 int ensure_bar_tables(glv_batch* b) {
-    if (b->d_bar_desc && b->bar_count == b->p.bars && b->bar_factor == b->p.smooth_factor && b->bar_phase == b->p.bar_phase) return GLV_OK;
+    const bool want_i8 = b->p.gl_storage != 0 && b->p.bars >= glv::kBarSeqMin && !b->bar_i8_off;      // chains whose rows are texels
+    if (b->d_bar_desc && b->bar_count == b->p.bars && b->bar_factor == b->p.smooth_factor && b->bar_phase == b->p.bar_phase && (want_i8 == (b->d_bar_itiles != nullptr) || b->bar_i8_none)) return GLV_OK;
     if (b->p.bars == 0 || b->p.bars > b->p.n) return fail(GLV_ERR_INVALID, "bars=%u out of range", b->p.bars);
     if (!(b->p.smooth_factor >= 0.0f && b->p.smooth_factor <= 1.0f))       // also rejects NaN
         return fail(GLV_ERR_INVALID, "smooth_factor=%g: must be in [0, 1] (a bar would have no taps)", (double) b->p.smooth_factor);
@@ -489,6 +497,8 @@ int ensure_bar_tables(glv_batch* b) {
     if (!glv::bar_chunks_in_row(desc, b->p.n)) return fail(GLV_ERR_INVALID, "bars: a tap chunk would leave the row (n=%u smooth_factor=%g)", b->p.n, (double) b->p.smooth_factor);
     auto drop = [](auto*& ptr) { if (ptr) { (void) hipFree(ptr); ptr = nullptr; } };
     drop(b->d_bar_desc); drop(b->d_bar_w); drop(b->d_bar_items); drop(b->d_bar_mtiles); drop(b->d_bar_wt); drop(b->d_bar_wsum); drop(b->d_bar_rounds);
+    drop(b->d_bar_itiles); drop(b->d_bar_wq); drop(b->d_bar_fin); drop(b->d_bar_irounds);
+    b->bar_intiles = 0; b->bar_inrounds = 0; b->bar_iring_bins = 0; b->bar_i8_none = false;
     for (int v = 0; v < glv_batch::kMaxVariants; ++v) { drop(b->d_bar_fitems[v]); b->bar_fusable[v] = false; b->bar_fnsteps[v] = 0; }
     b->bar_count = 0;
     // work lists: 256 / GL groups per row for glv_bars_kernel; T / GL groups for the frame kernel (GL = bar_lanes_of(n); fused bars:
@@ -546,8 +556,52 @@ int ensure_bar_tables(glv_batch* b) {
             const glv::BarRowsTables rt = b->rows_tables();
             HIP_TRY(glv::prepare_bars_rows(b->p.n, &rt));
         }
+        // texel rows: the integer tables, for the smallest ring that takes them (glv_misc.hip launch_bars_i8: the rings the kernel is built for)
+        if (want_i8) {
+            std::vector<glv::BarMTile> itiles;
+            std::vector<glv::BarTile> irounds;
+            std::vector<int8_t> wq;
+            std::vector<glv::BarIFin> fin;
+            for (uint32_t bins : {160u, 288u, 448u, 832u, 1600u}) {
+                if (!glv::make_bar_itiles(itiles, wq, fin, irounds, desc, w, b->p.n, bins, 4u)) { irounds.clear(); break; }
+                if (!irounds.empty()) { b->bar_iring_bins = bins; break; }
+            }
+            if (irounds.empty()) b->bar_i8_none = true;
+            else {
+                HIP_TRY(hipMalloc(&b->d_bar_itiles, sizeof(glv::BarMTile) * itiles.size()));
+                HIP_TRY(hipMemcpy(b->d_bar_itiles, itiles.data(), sizeof(glv::BarMTile) * itiles.size(), hipMemcpyHostToDevice));
+                HIP_TRY(hipMalloc(&b->d_bar_wq, wq.size()));
+                HIP_TRY(hipMemcpy(b->d_bar_wq, wq.data(), wq.size(), hipMemcpyHostToDevice));
+                HIP_TRY(hipMalloc(&b->d_bar_fin, sizeof(glv::BarIFin) * fin.size()));
+                HIP_TRY(hipMemcpy(b->d_bar_fin, fin.data(), sizeof(glv::BarIFin) * fin.size(), hipMemcpyHostToDevice));
+                HIP_TRY(hipMalloc(&b->d_bar_irounds, sizeof(glv::BarTile) * irounds.size()));
+                HIP_TRY(hipMemcpy(b->d_bar_irounds, irounds.data(), sizeof(glv::BarTile) * irounds.size(), hipMemcpyHostToDevice));
+                b->bar_intiles = (uint32_t) itiles.size(); b->bar_inrounds = (uint32_t) irounds.size();
+                const glv::BarIRowsTables irt = b->irows_tables();
+                HIP_TRY(glv::prepare_bars_i8(b->p.n, &irt));
+            }
+        }
     }
     return GLV_OK;
+}
+
+// the gravity step on texels (only the GL_R16 state needs it: 65 536 evaluations on the host whenever g changes -- for the
+// single-stream drop-ins that is whenever the host's measured `ur` changes, i.e. every frame)
+void update_gravity_step(glv_batch* b) {
+    const float g = b->p.gravity_step * (1.0F / b->p.ur);                      // render.c:728
+    if (b->state16 && (!b->grav_known || std::memcmp(&g, &b->grav_g, sizeof(g)) != 0)) {
+        b->grav_int = glv::gravity_r16_integer_step(g, &b->grav_sub);
+        b->grav_g = g; b->grav_known = true;
+    }
+}
+
+bool same_bits(float a, float b) { return std::memcmp(&a, &b, sizeof(a)) == 0; }
+bool same_params(const glv_params& a, const glv_params& b) {
+    return a.n == b.n && a.channels == b.channels && same_bits(a.fft_scale, b.fft_scale) && same_bits(a.fft_cutoff, b.fft_cutoff)
+           && same_bits(a.gravity_step, b.gravity_step) && same_bits(a.ur, b.ur) && a.avg_frames == b.avg_frames && a.avg_window == b.avg_window
+           && a.avg_window_kind == b.avg_window_kind && a.log_mode == b.log_mode && a.bars == b.bars && same_bits(a.smooth_factor, b.smooth_factor)
+           && same_bits(a.smooth_distance, b.smooth_distance) && same_bits(a.smooth_ratio, b.smooth_ratio) && a.gl_storage == b.gl_storage
+           && same_bits(a.bar_phase, b.bar_phase);
 }
 
 // Everything the process calls need besides the state arrays, made from b->p: tilt table, the gravity step on texels, and -- as
@@ -556,28 +610,29 @@ int ensure_bar_tables(glv_batch* b) {
 // copies synchronously; glv_batch_process_* / ring updates never do (tests/test_stream_order.py greps for it).
 int batch_prepare(glv_batch* b) {
     if (int rc = b->tab.set_tilt(b->p.fft_scale, b->p.fft_cutoff, b->p.log_mode == 1)) return rc;
-    const float g = b->p.gravity_step * (1.0F / b->p.ur);                      // render.c:728
-    // (only the GL_R16 state needs it: 65 536 evaluations on the host -- the single-stream drop-ins come through here whenever the
-    // host's measured `ur` changes, i.e. every frame)
-    if (b->state16 && (!b->grav_known || std::memcmp(&g, &b->grav_g, sizeof(g)) != 0)) {
-        b->grav_int = glv::gravity_r16_integer_step(g, &b->grav_sub);
-        b->grav_g = g; b->grav_known = true;
-    }
+    update_gravity_step(b);
     // Tables are cheap and always made (an operator the creation mask did not announce only fails to get them when its
     // parameters are unusable: a later call of that operator is then refused); buffers of spectrum size are made for announced
     // operators only.
+    // (an unannounced operator's unusable parameters are not this call's error: glv_last_error keeps what it said before)
     {
+        const std::string said = g_err;
         const int rc = ensure_smooth_tables(b);
-        if (rc != GLV_OK && (b->ops_mask & GLV_OP_SMOOTH)) return rc;
+        if (rc != GLV_OK) { if (b->ops_mask & GLV_OP_SMOOTH) return rc; g_err = said; }
     }
     {
+        const std::string said = g_err;
         const int rc = ensure_bar_tables(b);
-        if (rc != GLV_OK && (b->ops_mask & GLV_OP_BARS)) return rc;
+        if (rc != GLV_OK) { if (b->ops_mask & GLV_OP_BARS) return rc; g_err = said; }
     }
     if (b->ops_mask & GLV_OP_BARS) {
         // the internal spectra rows: needed whenever bars are not computed inside the transform's launch from a row in LDS
         // (stateless chains, rows whose bars do not fit the slack behind them, SMOOTH | BARS) and no state array holds the spectra
-        bool all_fused = (b->ops_mask & (GLV_OP_GRAVITY | GLV_OP_AVERAGE)) != 0 && !(b->ops_mask & GLV_OP_SMOOTH) && b->p.gl_storage != 2;
+        // -- the test must cover EVERY chain process() would run unfused (its `fused_bars`): the float chain's bars as texels
+        // (BARS | R16 with gl_storage 0) leave through glv_bars_kernel, the audit log (log_mode 2) takes the GL passes one by one, and
+        // GLV_UNFUSED_BARS forces two launches; only the GL_R16 chain whose every kernel configuration takes the bars goes without
+        bool all_fused = (b->ops_mask & (GLV_OP_GRAVITY | GLV_OP_AVERAGE)) != 0 && !(b->ops_mask & GLV_OP_SMOOTH) && b->p.gl_storage == 1
+                         && b->p.log_mode != 2 && !b->unfused_bars;
         for (int v = 0; v < glv::frame_variants(b->log_nn) && v < glv_batch::kMaxVariants; ++v) all_fused = all_fused && b->bar_fusable[v];
         if (!all_fused && !b->d_scratch) HIP_TRY(hipMalloc(&b->d_scratch, sizeof(float) * (size_t) b->rows * b->p.n));
     }
@@ -720,6 +775,10 @@ int process(glv_batch* b, const void* d_in, int in_mode, float* d_out, unsigned 
         // the rows go to the bars of a second launch and nowhere else (the scratch rows): what those bars do not sample is not stored
         if ((ops & GLV_OP_BARS) && !fused_bars && d_out == b->d_scratch && b->bar_bins_needed != 0 && b->bar_bins_needed < b->p.n)
             a.out_limit = b->bar_bins_needed * 4u;
+        // ... and they go there as what they are, 16-bit texels (uint16 [rows][n] in the scratch rows), when the second launch is the
+        // integer matrix-core pass (many bars: the pre-smoothing pass)
+        const bool bars_i8 = (ops & GLV_OP_BARS) && !fused_bars && b->p.bars >= glv::kBarSeqMin && b->bars_i8();
+        if (bars_i8) a.ops |= glv::OP_R16;
         if (int rc = timed_launch_begin(b, st)) return rc;
         b->last_grid = grid; b->last_variant = variant;
         e = glv::launch_frame(b->log_nn, in_mode, (int) b->p.log_mode, variant, a, grid, st); ++b->last_launches;
@@ -727,13 +786,24 @@ int process(glv_batch* b, const void* d_in, int in_mode, float* d_out, unsigned 
         b->kernel_name = "glv_frame_kernel";
         if (ops & GLV_OP_AVERAGE) b->head = (b->head + 1) % b->p.avg_frames;
         b->grav_cur = grav_next;
-        if ((ops & GLV_OP_BARS) && !fused_bars) {
+        if (bars_i8) {
+            const glv::BarIRowsTables irt = b->irows_tables();
+            e = glv::launch_bars_i8(d_out, false, d_final, units, b->p.n, b->p.bars, &irt, st, (ops & GLV_OP_R16) != 0); ++b->last_launches;
+            if (e != hipSuccess) return fail(GLV_ERR_HIP, "bars launch failed: %s", hipGetErrorString(e));
+        } else if ((ops & GLV_OP_BARS) && !fused_bars) {
             const glv::BarRowsTables rt = b->rows_tables();
             e = glv::launch_bars(d_out, d_final, units, b->p.n, b->p.bars, b->bar_nsteps, b->d_bar_items, b->d_bar_desc, b->d_bar_w, st, (ops & GLV_OP_R16) != 0, &rt); ++b->last_launches;
             if (e != hipSuccess) return fail(GLV_ERR_HIP, "bars launch failed: %s", hipGetErrorString(e));
         }
         return timed_launch_end(b, st);
     }
+    // many bars of rows that hold texel values as floats c / 65535 (the GL passes one by one): the same integer pass, converting back
+    auto bars_of_texel_floats = [&](const float* rows) -> int {
+        const glv::BarIRowsTables irt = b->irows_tables();
+        const hipError_t e2 = glv::launch_bars_i8(rows, true, d_final, units, b->p.n, b->p.bars, &irt, st, (ops & GLV_OP_R16) != 0); ++b->last_launches;
+        return e2 == hipSuccess ? GLV_OK : fail(GLV_ERR_HIP, "bars launch failed: %s", hipGetErrorString(e2));
+    };
+    const bool texel_bars_i8 = gl_split && (ops & GLV_OP_BARS) && !(ops & GLV_OP_SMOOTH) && b->p.bars >= glv::kBarSeqMin && b->bars_i8();
     // The GL twin's pass structure (render.c:2188-2265), pass by pass -- the transform first, then gravity / average as their own
     // pass over GL_R16-quantised values (glv_frame.h apply_state; state as floats with gl_storage 2, as texels with 1).  The frame
     // kernel delivers the float spectra into the caller's buffer when that is what it will hold in the end, else into the scratch rows.
@@ -760,7 +830,9 @@ int process(glv_batch* b, const void* d_in, int in_mode, float* d_out, unsigned 
             e = glv::launch_smooth(a2.out, units, b->p.n, b->d_smin, b->d_smax, b->smooth_asz, b->smooth_reach, b->smooth_window, st); ++b->last_launches;
             if (e != hipSuccess) return fail(GLV_ERR_HIP, "smooth launch failed: %s", hipGetErrorString(e));
         }
-        if (ops & GLV_OP_BARS) {
+        if (texel_bars_i8) {
+            if (int rc = bars_of_texel_floats(d_tmp)) return rc;
+        } else if (ops & GLV_OP_BARS) {
             const glv::BarRowsTables rt = b->rows_tables();
             e = glv::launch_bars(d_tmp, d_final, units, b->p.n, b->p.bars, b->bar_nsteps, b->d_bar_items, b->d_bar_desc, b->d_bar_w, st, (ops & GLV_OP_R16) != 0, &rt); ++b->last_launches;
             if (e != hipSuccess) return fail(GLV_ERR_HIP, "bars launch failed: %s", hipGetErrorString(e));
@@ -792,7 +864,9 @@ int process(glv_batch* b, const void* d_in, int in_mode, float* d_out, unsigned 
         e = glv::launch_smooth(d_out, units, b->p.n, b->d_smin, b->d_smax, b->smooth_asz, b->smooth_reach, b->smooth_window, st); ++b->last_launches;
         if (e != hipSuccess) return fail(GLV_ERR_HIP, "smooth launch failed: %s", hipGetErrorString(e));
     }
-    if ((ops & GLV_OP_BARS) && !fused_bars) {
+    if (texel_bars_i8 && !(ops & GLV_OP_FFT) && d_out != nullptr) {      // gravity / average on planar rows with the GL storage, then many bars: texel values
+        if (int rc = bars_of_texel_floats(d_out)) return rc;
+    } else if ((ops & GLV_OP_BARS) && !fused_bars) {
         const glv::BarRowsTables rt = b->rows_tables();
         e = glv::launch_bars(d_out ? d_out : b->grav_cur, d_final, units, b->p.n, b->p.bars, b->bar_nsteps, b->d_bar_items, b->d_bar_desc, b->d_bar_w, st, (ops & GLV_OP_R16) != 0, &rt); ++b->last_launches;
         if (e != hipSuccess) return fail(GLV_ERR_HIP, "bars launch failed: %s", hipGetErrorString(e));
@@ -824,6 +898,7 @@ int batch_create_rows(const glv_params* p, uint32_t streams, unsigned ops_mask, 
     b->p = *p; b->streams = streams; b->ops_mask = ops_mask; b->device = device;
     b->rows = single_row ? 1u : streams * 2u; b->single_row = single_row;
     b->unfused_bars = std::getenv("GLV_UNFUSED_BARS") != nullptr;
+    b->bar_i8_off = std::getenv("GLV_NO_BARS_I8") != nullptr;
     b->log_nn = log2_exact(p->n) - 1;
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess) {
@@ -888,6 +963,9 @@ int glv_batch_set_params(glv_batch* b, const glv_params* p) {
     if ((p->gl_storage == 1) != b->state16)
         return fail(GLV_ERR_STATE, "gl_storage=%u: the state of this batch was created as %s", p->gl_storage, b->state16 ? "GL_R16 texels (gl_storage 1)" : "floats (gl_storage 0 / 2)");
     HIP_TRY(hipSetDevice(b->device));
+    // the tables are rewritten in place: every kernel already queued on any stream of the device must have read them first (a
+    // blocking copy from pageable memory does not order against a caller's non-blocking stream)
+    HIP_TRY(hipDeviceSynchronize());
     const glv_params old = b->p;
     b->p = *p;
     const int rc = batch_prepare(b);
@@ -929,6 +1007,10 @@ int glv_batch_destroy(glv_batch* b) {
     if (b->d_bar_wt) (void) hipFree(b->d_bar_wt);
     if (b->d_bar_wsum) (void) hipFree(b->d_bar_wsum);
     if (b->d_bar_rounds) (void) hipFree(b->d_bar_rounds);
+    if (b->d_bar_itiles) (void) hipFree(b->d_bar_itiles);
+    if (b->d_bar_wq) (void) hipFree(b->d_bar_wq);
+    if (b->d_bar_fin) (void) hipFree(b->d_bar_fin);
+    if (b->d_bar_irounds) (void) hipFree(b->d_bar_irounds);
     for (hipEvent_t e : b->ev) (void) hipEventDestroy(e);
     delete b;
     return GLV_OK;
@@ -1319,7 +1401,16 @@ static int single(const glv_params* p, glv_state* s, float* buf, unsigned ops) {
     if (p->n != b->p.n || p->avg_frames != b->p.avg_frames)
         return fail(GLV_ERR_STATE, "params (n=%u, F=%u) do not match the state (n=%u, F=%u)", p->n, p->avg_frames, b->p.n, b->p.avg_frames);
     // scalar knobs may change between calls, exactly like gl_data fields: what depends on them is regenerated when they do
-    if (std::memcmp(&b->p, p, sizeof(*p)) != 0) { if (int rc = glv_batch_set_params(b, p)) return rc; }
+    // (compared field by field: padding bytes of a caller's struct mean nothing.  GLava's measured `ur` changes every frame
+    // (render.c:2387): that touches nothing but the gravity step -- no table, no launch plan)
+    if (!same_params(b->p, *p)) {
+        glv_params rest = *p;
+        rest.ur = b->p.ur; rest.gravity_step = b->p.gravity_step;
+        if (same_params(b->p, rest)) {
+            b->p.ur = p->ur; b->p.gravity_step = p->gravity_step;
+            update_gravity_step(b);
+        } else if (int rc = glv_batch_set_params(b, p)) return rc;
+    }
     HIP_TRY(hipSetDevice(b->device));
     const size_t bytes = sizeof(float) * p->n;
     if (s->mapped && (ops & GLV_OP_SMOOTH)) {

@@ -41,6 +41,8 @@ struct alignas(16) BarItem { uint32_t w_byte, tex_byte, res; float keep; };
 // weights per pair start -- and one round of glv_bars_rows_kernel: tiles [k0, k1) whose bins [origin, end) sit in the LDS ring.
 struct alignas(16) BarTile { uint32_t k0, k1, origin, end; };
 struct alignas(16) BarMTile { uint32_t k0, origin, steps, w_off; };
+// texel rows (glv_tables.h make_bar_itiles): per bar the epilogue's rounding constant and shift, texel = (floor(T / 2^16) + c) >> s; s == 0: weights sum to 0
+struct alignas(8) BarIFin { uint32_t c, s; };
 
 struct FrameArgs {
     const void* in;        // s16: int16 [units/2][n][2] (a unit is one channel row of a frame);  f32 planar: float [units][n];
@@ -73,7 +75,8 @@ struct FrameArgs {
     float inv_n, fft_scale, one_minus_cutoff, g, F_as_float;
     float F_rcp;           // RN(1 / F): the GL_R16 chain's final division (glv_core.h div_frames)
     uint32_t out_limit;    // gl_storage 1, rows handed to a later kernel only (the bars of a second launch): bytes of a float row that are
-                           // written at all -- the pre-smoothing pass samples bins below 0.31 n, the rest of the row is not stored (0: no limit)
+                           // written at all -- the pre-smoothing pass samples bins below 0.31 n, the rest of the row is not stored (0: no limit);
+                           // texel rows (OP_R16: what the i8 matrix-core pass reads) stop at the same bin, i.e. at half as many bytes
     double wts[64];        // window_frame weights, oldest first (render.c:661 as expanded at :766); GLV_MAX_AVG_FRAMES
     float wts32[64];       // the same rounded to float: the GL passes' arithmetic is the shader's, 32-bit (weighted_texels)
     // fused GLV_OP_BARS (stateful kernels, lanes-per-row a multiple of 64): the finished row goes to the
@@ -1277,6 +1280,7 @@ struct Frame {
             } else {
 #pragma unroll
                 for (int j = 0; j < GL16_BLK; j += (PAIRED ? 2 : 1)) {
+                    if (a.out_limit != 0u && off[j] >= a.out_limit) continue;      // (out_limit counts bytes of a FLOAT row: off[j] is that offset)
                     if constexpr (PAIRED) st<u32x2>(out_row, off[j] / 2u, u32x2{tex[j], tex[j + 1]});
                     else st<uint32_t>(out_row, off[j] / 2u, tex[j]);
                 }

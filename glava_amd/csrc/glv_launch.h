@@ -49,6 +49,14 @@ struct BarRowsTables {
 hipError_t launch_bars(const float* spec, float* bars_out, size_t nrows, uint32_t n, uint32_t bars, uint32_t nsteps,
                        const BarItem* items, const BarDesc* desc, const float* tap_w, hipStream_t st, bool r16 = false, const BarRowsTables* rt = nullptr);
 hipError_t prepare_bars_rows(uint32_t n, const BarRowsTables* rt);      // function attributes of the kernel launch_bars would pick
+// the tables of the i8 matrix-core kernel for texel rows (glv_tables.h make_bar_itiles): tiles (origin a multiple of 16 bins, steps of 32),
+// the digit planes of the integer weights in operand layout, per bar the rounding constant and shift, the rounds for a ring of ring_bins bins
+struct BarIRowsTables {
+    const BarMTile* tiles; uint32_t ntiles; const void* wq; const BarIFin* fin;
+    const BarTile* rounds; uint32_t nrounds, ring_bins;
+};
+hipError_t launch_bars_i8(const void* rows, bool rows_f32, void* bars_out, size_t nrows, uint32_t n, uint32_t bars, const BarIRowsTables* rt, hipStream_t st, bool r16);
+hipError_t prepare_bars_i8(uint32_t n, const BarIRowsTables* rt);     // function attributes of the kernels launch_bars_i8 would pick
 hipError_t launch_ring_planar(const void* ring, int is_f32, uint32_t n, uint32_t rot, int mono, size_t streams, float* out, hipStream_t st);
 hipError_t launch_unpack(const int16_t* pcm, size_t frames, int mono, float* l, float* r, hipStream_t st);
 

@@ -624,6 +624,200 @@ __global__ void __launch_bounds__(256) glv_bars_seq_kernel(const float* __restri
     }
 }
 
+// MANY bars over TEXEL rows (the library's GL chains, gl_storage != 0: the pre-smoothing pass of render.c:2277-2303 samples a GL_R16
+// texture) -- EXACT integer arithmetic on the i8 matrix cores (glv_tables.h make_bar_itiles has the contract; the tests' CPU checker restates
+// it as glvo_bars_int_at).  The texels are 16-bit integers; with the bar's weights as integers W that sum to 2^P the weighted mean
+// is sum W c / 2^P exactly.  c - 32896 = 256 h + l and W = 65536 w2 + 256 w1 + w0 in balanced signed bytes: one step is 32 rows x 32 bars
+// x 32 bins as six v_mfma_i32_32x32x32_i8 (h w2 | h w1 + l w2 | h w0 + l w1 | l w0: four int32 accumulator tiles, nothing rounds) -- 28 x
+// the multiply-add rate of the f32 form, which this kernel replaces wherever the rows are texels.  Same shape as glv_bars_rows_kernel
+// otherwise: four waves on the same RB rows, wave w takes tile w of every round, the rows' texels in an LDS ring of S bins -- here as two
+// planes of signed bytes [row][bin] (row pitch S + 16 bytes: the a-operand, 16 consecutive bins of one row per lane, is a conflict-free
+// ds_read_b128), split and biased ONCE when they are parked, 8 texels = one 16-byte load at a time; the weights one coalesced 1 KiB line per
+// digit and step, one step ahead, one stream per wave straight across tile boundaries.  A slot nothing was parked in yet, or that the next
+// round is overwriting, only ever meets weight 0, and 0 x anything is 0 here -- no clearing, no clamping, no NaN.  The epilogue is five
+// integer instructions per texel: floor(T / 2^16) = (a3 << 8) + a2 + ((a1 + (a0 >> 8)) >> 8), texel = (that + c) >> s with the host's
+// c = 32896 2^s + 2^(s - 1), s = P - 16 (round to nearest, an exact half up).
+typedef int glv_i4v __attribute__((ext_vector_type(4)));
+typedef int glv_i16v __attribute__((ext_vector_type(16)));
+template <int S, int RB, bool F32IN, bool R16>
+__global__ void __launch_bounds__(64 * kRowsWaves, 2) glv_bars_rows_i8_kernel(const void* __restrict__ rows_in, void* __restrict__ bars_out, size_t nrows, uint32_t n,
+                                                                              uint32_t bars, const BarTile* __restrict__ rounds, uint32_t nrounds, uint32_t rounds_per_wg,
+                                                                              const BarMTile* __restrict__ tiles, const glv_i4v* __restrict__ wq,
+                                                                              const BarIFin* __restrict__ fin) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    static_assert(S % 32 == 0 && (RB == 64 || RB == 32), "16-bin chunks never straddle the ring's end and (S + 16) / 16 is odd; one or two row groups");
+    extern __shared__ __attribute__((aligned(16))) char i8_lds[];       // [2 planes][RB rows][S + 16 bytes]
+    constexpr uint32_t PITCH = S + 16, S16 = S / 16, G = RB / 32, CPI = 64 * kRowsWaves / RB;       // CPI: columns of 8 bins one sweep of the workgroup fetches
+    char* plane_h = i8_lds;
+    char* plane_l = i8_lds + (size_t) RB * PITCH;
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave = (uint32_t) __builtin_amdgcn_readfirstlane((int) (threadIdx.x >> 6));
+    const size_t row0 = (size_t) blockIdx.x * RB;
+    if (row0 >= nrows) return;
+    const uint32_t R = (uint32_t) (nrows - row0 < RB ? nrows - row0 : RB);
+    const uint32_t t_begin = blockIdx.y * rounds_per_wg, t_end = t_begin + rounds_per_wg < nrounds ? t_begin + rounds_per_wg : nrounds;
+    if (t_begin >= t_end) return;
+    const uint32_t frow = threadIdx.x % (uint32_t) RB, fcol = threadIdx.x / (uint32_t) RB;
+    const size_t srow = row0 + (frow < R ? frow : R - 1);                 // (a partial row block repeats its last row; its stores are masked)
+    const char* src = static_cast<const char*>(rows_in) + srow * (size_t) n * (F32IN ? 4u : 2u);
+    struct Tex8 { uint32_t d[4]; };                                     // 8 texels, two per dword
+    auto fetch = [&](uint32_t bin) -> Tex8 {
+        Tex8 v;
+        if constexpr (F32IN) {                                          // rows of floats c / 65535 (the pass-by-pass chain): back to the texels, exactly
+            const BarW4 a = ld<BarW4>(src, bin * 4u), b = ld<BarW4>(src, bin * 4u + 16u);
+            v.d[0] = pack_unorm16(a.w[0], a.w[1]); v.d[1] = pack_unorm16(a.w[2], a.w[3]);
+            v.d[2] = pack_unorm16(b.w[0], b.w[1]); v.d[3] = pack_unorm16(b.w[2], b.w[3]);
+        } else {
+            const glv_i4v a = *reinterpret_cast<const glv_i4v*>(src + bin * 2u);
+            v.d[0] = (uint32_t) a.x; v.d[1] = (uint32_t) a.y; v.d[2] = (uint32_t) a.z; v.d[3] = (uint32_t) a.w;
+        }
+        return v;
+    };
+    auto park = [&](const Tex8& v, uint32_t bin) {                       // low bytes / high bytes of the 8 texels, biased to signed (c ^ 0x8080)
+        const uint32_t l0 = __builtin_amdgcn_perm(v.d[1], v.d[0], 0x06040200u) ^ 0x80808080u, l1 = __builtin_amdgcn_perm(v.d[3], v.d[2], 0x06040200u) ^ 0x80808080u;
+        const uint32_t h0 = __builtin_amdgcn_perm(v.d[1], v.d[0], 0x07050301u) ^ 0x80808080u, h1 = __builtin_amdgcn_perm(v.d[3], v.d[2], 0x07050301u) ^ 0x80808080u;
+        const uint32_t at = frow * PITCH + bin % (uint32_t) S;
+        *reinterpret_cast<uint2*>(plane_l + at) = make_uint2(l0, l1);
+        *reinterpret_cast<uint2*>(plane_h + at) = make_uint2(h0, h1);
+    };
+    // the first round's whole window
+    uint32_t filled_to;
+    {
+        const BarTile T = rounds[t_begin];
+        const uint32_t ncol = (T.end - T.origin) / 8u;
+        for (uint32_t c0 = fcol; c0 < ncol; c0 += 4u * CPI) {
+            Tex8 v4[4];
+#pragma unroll
+            for (uint32_t q = 0; q < 4; ++q) v4[q] = fetch(T.origin + 8u * (c0 + q * CPI < ncol ? c0 + q * CPI : 0u));
+#pragma unroll
+            for (uint32_t q = 0; q < 4; ++q)
+                if (c0 + q * CPI < ncol) park(v4[q], T.origin + 8u * (c0 + q * CPI));
+        }
+        filled_to = T.end;
+    }
+    __syncthreads();
+    // a-operand: lane l reads 16 consecutive bins (one half of the step's 32) of row l % 32 of a group
+    const uint32_t arow = (lane & 31u) * PITCH, ahalf = lane >> 5;
+    // The weights: wave w takes tile k0 + w of every round and the host laid those tiles out one behind the other, so the wave reads ONE
+    // stream of steps straight across tile boundaries, PF steps ahead: a step's three digit fragments sit in bank (step mod PF), and the bank
+    // is reloaded as soon as its step has used it (the stream ends in PF steps of zeros).  Register banks mean an unrolled loop, and a tile may
+    // end after any step: the loop below runs over the wave's STREAM, and what a tile's last step is followed by -- parking the next round's
+    // bins, the epilogue, the round's barrier, the next tile's set-up -- hangs off each of the PF steps as a side block.
+    constexpr int PF = 3;
+    const glv_i4v* wp = nullptr;                                        // stream position of the NEXT load (lane-offset)
+    glv_i4v wb[PF][3];
+    glv_i16v acc[G][4];
+    uint32_t t = t_begin, left = 0, ck = 0, next_end = filled_to, nnew = 0;
+    BarMTile M = tiles[0];
+    Tex8 pre[2];
+    auto park_new = [&]() {
+#pragma unroll
+        for (uint32_t q = 0; q < 2; ++q)
+            if (fcol + q * CPI < nnew) park(pre[q], filled_to + 8u * (fcol + q * CPI));
+        for (uint32_t c = fcol + 2u * CPI; c < nnew; c += CPI) park(fetch(filled_to + 8u * c), filled_to + 8u * c);
+        filled_to = next_end > filled_to ? next_end : filled_to;
+    };
+    // opens round t: requests what the NEXT round adds to the ring (parked behind this round's arithmetic), sets up the wave's tile.
+    // false: the wave has no tile in this round
+    auto open_round = [&]() -> bool {
+        const BarTile T = rounds[t];                                            // uniform: scalar loads
+        const bool valid = T.k0 + wave < T.k1;
+        next_end = t + 1 < t_end ? rounds[t + 1].end : filled_to;
+        nnew = next_end > filled_to ? (next_end - filled_to) / 8u : 0u;
+#pragma unroll
+        for (uint32_t q = 0; q < 2; ++q) pre[q] = fetch(filled_to + 8u * (fcol + q * CPI < nnew ? fcol + q * CPI : 0u));
+        if (!valid) return false;
+        M = tiles[T.k0 + wave];
+        left = (uint32_t) __builtin_amdgcn_readfirstlane((int) M.steps);
+        ck = ((uint32_t) __builtin_amdgcn_readfirstlane((int) (M.origin >> 4)) + ahalf) % S16;      // this lane's 16-bin chunk of the step, in the ring
+#pragma unroll
+        for (uint32_t g = 0; g < G; ++g)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) acc[g][q] = glv_i16v{0};
+        return true;
+    };
+    // rounds without a tile for this wave: park, join the barrier, go on.  false: no round is left
+    auto next_tile = [&]() -> bool {
+        while (t < t_end) {
+            if (open_round()) return true;
+            park_new();
+            __syncthreads();
+            ++t;
+        }
+        return false;
+    };
+    // behind a tile's last step
+    auto close_tile = [&]() {
+        park_new();
+        // a lane's 16 results of a group are one bar (k0 + lane % 32) of the rows 32 g + 8 (r / 4) + 4 (lane / 32) + r % 4
+        const uint32_t kb = M.k0 + (lane & 31u);
+        const BarIFin f = fin[kb];                                              // (padded to whole tiles)
+        const size_t at0 = (row0 + 4u * (lane >> 5)) * (size_t) bars + kb;
+#pragma unroll
+        for (uint32_t g = 0; g < G; ++g)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const uint32_t jr = 32u * g + 8u * (uint32_t) (r / 4) + 4u * (lane >> 5) + (uint32_t) (r & 3);
+                if (jr >= R || kb >= bars) continue;
+                const size_t at = at0 + (size_t) (32u * g + 8u * (uint32_t) (r / 4) + (uint32_t) (r & 3)) * bars;
+                const int a0 = acc[g][0][r], a1 = acc[g][1][r], a2 = acc[g][2][r], a3 = acc[g][3][r];
+                if constexpr (R16) {
+                    const uint32_t t16 = (uint32_t) ((a3 << 8) + a2 + ((a1 + (a0 >> 8)) >> 8));
+                    reinterpret_cast<uint16_t*>(bars_out)[at] = f.s == 0u ? (uint16_t) 0 : (uint16_t) ((t16 + f.c) >> f.s);
+                } else {
+                    const int P = (int) f.s + 16;
+                    const long long tot = ((long long) a3 << 24) + ((long long) a2 << 16) + ((long long) a1 << 8) + a0 + ((long long) 32896 << P);
+                    reinterpret_cast<float*>(bars_out)[at] = f.s == 0u ? __builtin_nanf("") : (float) (__builtin_ldexp((double) tot, -P) / 65535.0);
+                }
+            }
+        __syncthreads();
+        ++t;
+    };
+    auto step = [&](auto BC) {                                                  // one step of 32 bins on bank B
+        constexpr int B = decltype(BC)::value;
+        glv_i4v ah[G], al[G];
+#pragma unroll
+        for (uint32_t g = 0; g < G; ++g) {
+            ah[g] = *reinterpret_cast<const glv_i4v*>(plane_h + g * 32u * PITCH + arow + ck * 16u);
+            al[g] = *reinterpret_cast<const glv_i4v*>(plane_l + g * 32u * PITCH + arow + ck * 16u);
+        }
+        ck = ck + 2u >= S16 ? ck + 2u - S16 : ck + 2u;
+        const glv_i4v w0 = wb[B][0], w1 = wb[B][1], w2 = wb[B][2];
+#pragma unroll
+        for (int d = 0; d < 3; ++d) wb[B][d] = wp[(size_t) d * 64];             // the bank's next step, PF steps on
+        wp += 3 * 64;
+#pragma unroll
+        for (uint32_t g = 0; g < G; ++g) {
+            acc[g][3] = __builtin_amdgcn_mfma_i32_32x32x32_i8(ah[g], w2, acc[g][3], 0, 0, 0);
+            acc[g][2] = __builtin_amdgcn_mfma_i32_32x32x32_i8(ah[g], w1, acc[g][2], 0, 0, 0);
+            acc[g][1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(ah[g], w0, acc[g][1], 0, 0, 0);
+            acc[g][0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(al[g], w0, acc[g][0], 0, 0, 0);
+        }
+#pragma unroll
+        for (uint32_t g = 0; g < G; ++g) {
+            acc[g][2] = __builtin_amdgcn_mfma_i32_32x32x32_i8(al[g], w2, acc[g][2], 0, 0, 0);
+            acc[g][1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(al[g], w1, acc[g][1], 0, 0, 0);
+        }
+    };
+    if (!next_tile()) return;
+    // the wave's first tile: fill the pipeline
+    wp = wq + (uint32_t) __builtin_amdgcn_readfirstlane((int) M.w_off) + lane;
+#pragma unroll
+    for (int b = 0; b < PF; ++b)
+#pragma unroll
+        for (int d = 0; d < 3; ++d) wb[b][d] = wp[(size_t) (3 * b + d) * 64];
+    wp += (size_t) PF * 3 * 64;
+    for (;;) {
+        step(std::integral_constant<int, 0>{});
+        if (--left == 0) { close_tile(); if (!next_tile()) break; }
+        step(std::integral_constant<int, 1>{});
+        if (--left == 0) { close_tile(); if (!next_tile()) break; }
+        step(std::integral_constant<int, 2>{});
+        if (--left == 0) { close_tile(); if (!next_tile()) break; }
+    }
+#endif
+}
+
 // the s16 window as float pairs: glv_winsplit.h (shared with the knob-sweep harness glv_tune.hip)
 hipError_t launch_window_split(const double* w_tab, float* split, uint32_t n, int* d_fail_shifted, hipStream_t st) {
     return launch_window_split_impl(w_tab, split, n, d_fail_shifted, st);
@@ -747,6 +941,61 @@ hipError_t prepare_bars_rows(uint32_t n, const BarRowsTables* rt) {
     if (rt->ring_bins == 448) return launch_bars_rows<448, 32>(nullptr, nullptr, 0, n, 0, *rt, nullptr, 0);
     if (rt->ring_bins == 832) return launch_bars_rows<832, 32>(nullptr, nullptr, 0, n, 0, *rt, nullptr, 0);
     return hipSuccess;
+}
+
+// the i8 kernel for ring_bins in {160, 288, 448, 832} (64 rows per workgroup) or 1600 (32 rows: the bars of n = 32768); nrows == 0: the
+// dynamic-LDS attribute only
+template <int S, int RB, bool F32IN, bool R16>
+static hipError_t launch_bars_i8_one(const void* rows, void* bars_out, size_t nrows, uint32_t n, uint32_t bars, const BarIRowsTables& rt, hipStream_t st) {
+    const size_t lds = (size_t) 2 * RB * (S + 16);
+    static std::atomic<bool> done[64] = {};
+    if (lds > 64 * 1024) {
+        int dev = 0;
+        (void) hipGetDevice(&dev);
+        if (dev < 0 || dev >= 64 || !done[dev].load(std::memory_order_acquire)) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(glv_bars_rows_i8_kernel<S, RB, F32IN, R16>), hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
+            if (e != hipSuccess) return e;
+            if (dev >= 0 && dev < 64) done[dev].store(true, std::memory_order_release);
+        }
+    }
+    if (nrows == 0) return hipSuccess;
+    // RB rows per workgroup in x, ranges of rounds in y (512 workgroups, as glv_bars_rows_kernel)
+    const uint32_t xb = (uint32_t) ((nrows + RB - 1) / RB);
+    uint32_t yb = xb >= 512 ? 1 : (512 + xb - 1) / xb;
+#if defined(GLV_TUNE_BUILD)
+    if (const char* o = std::getenv("GLV_ROWS_YB")) yb = (uint32_t) atoi(o);
+#endif
+    if (yb > rt.nrounds) yb = rt.nrounds;
+    const uint32_t rpw = (rt.nrounds + yb - 1) / yb;
+    yb = (rt.nrounds + rpw - 1) / rpw;
+    hipLaunchKernelGGL((glv_bars_rows_i8_kernel<S, RB, F32IN, R16>), dim3(xb, yb), dim3(64 * kRowsWaves), lds, st, rows, bars_out, nrows, n, bars, rt.rounds, rt.nrounds, rpw,
+                       rt.tiles, reinterpret_cast<const glv_i4v*>(rt.wq), rt.fin);
+    return hipGetLastError();
+}
+template <bool F32IN, bool R16>
+static hipError_t launch_bars_i8_in(const void* rows, void* bars_out, size_t nrows, uint32_t n, uint32_t bars, const BarIRowsTables& rt, hipStream_t st) {
+    switch (rt.ring_bins) {
+        case 160: return launch_bars_i8_one<160, 64, F32IN, R16>(rows, bars_out, nrows, n, bars, rt, st);
+        case 288: return launch_bars_i8_one<288, 64, F32IN, R16>(rows, bars_out, nrows, n, bars, rt, st);
+        case 448: return launch_bars_i8_one<448, 64, F32IN, R16>(rows, bars_out, nrows, n, bars, rt, st);
+        case 832: return launch_bars_i8_one<832, 64, F32IN, R16>(rows, bars_out, nrows, n, bars, rt, st);
+        case 1600: return launch_bars_i8_one<1600, 32, F32IN, R16>(rows, bars_out, nrows, n, bars, rt, st);
+    }
+    return hipErrorInvalidValue;
+}
+// rows: uint16 [nrows][n] texels (rows_f32 false) or float [nrows][n] holding texel values c / 65535 (true)
+hipError_t launch_bars_i8(const void* rows, bool rows_f32, void* bars_out, size_t nrows, uint32_t n, uint32_t bars, const BarIRowsTables* rt, hipStream_t st, bool r16) {
+    if (rt == nullptr || rt->tiles == nullptr || rt->rounds == nullptr || rt->nrounds == 0) return hipErrorInvalidValue;
+    if (rows_f32) return r16 ? launch_bars_i8_in<true, true>(rows, bars_out, nrows, n, bars, *rt, st) : launch_bars_i8_in<true, false>(rows, bars_out, nrows, n, bars, *rt, st);
+    return r16 ? launch_bars_i8_in<false, true>(rows, bars_out, nrows, n, bars, *rt, st) : launch_bars_i8_in<false, false>(rows, bars_out, nrows, n, bars, *rt, st);
+}
+hipError_t prepare_bars_i8(uint32_t n, const BarIRowsTables* rt) {
+    if (rt == nullptr || rt->rounds == nullptr || rt->nrounds == 0) return hipSuccess;
+    hipError_t e = launch_bars_i8_in<false, true>(nullptr, nullptr, 0, n, 0, *rt, nullptr);
+    if (e == hipSuccess) e = launch_bars_i8_in<false, false>(nullptr, nullptr, 0, n, 0, *rt, nullptr);
+    if (e == hipSuccess) e = launch_bars_i8_in<true, true>(nullptr, nullptr, 0, n, 0, *rt, nullptr);
+    if (e == hipSuccess) e = launch_bars_i8_in<true, false>(nullptr, nullptr, 0, n, 0, *rt, nullptr);
+    return e;
 }
 
 hipError_t launch_bars(const float* spec, float* bars_out, size_t nrows, uint32_t n, uint32_t bars, uint32_t nsteps,

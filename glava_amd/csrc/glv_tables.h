@@ -207,6 +207,34 @@ inline bool bar_rcp_division_ok(float b) {
     const uint32_t u = __builtin_bit_cast(uint32_t, b);
     return b >= 0x1p-60f && b <= 0x1p60f && (u & 0x7fffffu) != 0x7fffffu;
 }
+// rounds of consecutive tiles for an LDS ring of `bins` bins (shared by make_bar_mtiles and make_bar_itiles): see make_bar_mtiles
+template <class OriginOf, class EndOf>
+inline bool cut_bar_rounds(std::vector<BarTile>& rounds, uint32_t nt, OriginOf origin_of, EndOf end_of, uint32_t n, uint32_t bins, uint32_t tiles_per_round) {
+    rounds.clear();
+    uint32_t T = 0, prev_origin = 0;
+    bool fits = true;
+    while (fits && T < nt) {
+        BarTile r{T, T, origin_of(T), rounds.empty() ? 0u : rounds.back().end};       // k0, k1: TILE indices here; ends are kept monotone
+        uint32_t H = T;
+        while (H < nt && H - T < tiles_per_round) {
+            const uint32_t e = end_of(H);
+            if (e > n) { fits = false; break; }
+            const uint32_t end = e > r.end ? e : r.end;
+            if (end - r.origin > bins || (!rounds.empty() && end - prev_origin > bins)) break;
+            // the tile after this one must be able to open the next round: its bins are added while this round still reads from r.origin
+            if (H > T && H + 1 < nt && end_of(H + 1) - r.origin > bins) break;
+            r.end = end;
+            ++H;
+        }
+        if (H == T) fits = false;                                                // a single tile does not fit
+        r.k1 = H;
+        rounds.push_back(r);
+        prev_origin = r.origin;
+        T = H;
+    }
+    if (!fits) rounds.clear();
+    return fits;
+}
 inline bool make_bar_mtiles(std::vector<BarMTile>& mtiles, std::vector<float>& wt, std::vector<float>& wsum, std::vector<BarTile>& rounds,
                             const std::vector<BarDesc>& desc, const std::vector<float>& tap_w, uint32_t n, uint32_t bins, uint32_t tiles_per_round) {
     mtiles.clear(); wt.clear(); wsum.clear(); rounds.clear();
@@ -236,28 +264,7 @@ inline bool make_bar_mtiles(std::vector<BarMTile>& mtiles, std::vector<float>& w
         mtiles.push_back(t);
     }
     // rounds for the LDS ring (the padded steps read, with weight +0, whatever the ring holds there: only a tile's own bins must fit)
-    uint32_t T = 0, prev_origin = 0;
-    bool fits = monotone && bins % 4u == 0;
-    while (fits && T < nt) {
-        BarTile r{T, T, mtiles[T].origin, rounds.empty() ? 0u : rounds.back().end};       // k0, k1: TILE indices here; ends are kept monotone
-        uint32_t H = T;
-        while (H < nt && H - T < tiles_per_round) {
-            const uint32_t e = tile_end(H);
-            if (e > n) { fits = false; break; }
-            const uint32_t end = e > r.end ? e : r.end;
-            if (end - r.origin > bins || (!rounds.empty() && end - prev_origin > bins)) break;
-            // the tile after this one must be able to open the next round: its bins are added while this round still reads from r.origin
-            if (H > T && H + 1 < nt && tile_end(H + 1) - r.origin > bins) break;
-            r.end = end;
-            ++H;
-        }
-        if (H == T) fits = false;                                                // a single tile does not fit
-        r.k1 = H;
-        rounds.push_back(r);
-        prev_origin = r.origin;
-        T = H;
-    }
-    if (!fits) rounds.clear();
+    if (monotone && bins % 4u == 0) cut_bar_rounds(rounds, nt, [&](uint32_t T) { return mtiles[T].origin; }, tile_end, n, bins, tiles_per_round);
     // the weights, laid out as the rows kernel consumes them: wave w of a workgroup takes tile k0 + w of every round, so its tiles
     // follow one another in memory -- ONE stream per wave, which the kernel reads a fixed number of steps ahead straight across tile
     // boundaries (without rounds: tile order)
@@ -280,6 +287,109 @@ inline bool make_bar_mtiles(std::vector<BarMTile>& mtiles, std::vector<float>& w
             }
     }
     wt.insert(wt.end(), 64u * kBarLookAhead, 0.0f);                             // what the look-ahead reads past the last tile
+    return true;
+}
+
+// ---- many bars over TEXEL rows (the GL chains, gl_storage != 0: what the reference's pre-smoothing pass samples is a GL_R16 texture,
+// render.c:2277-2303) -- exact integer arithmetic on the i8 matrix cores (glv_misc.hip glv_bars_rows_i8_kernel) ----------------------
+// The texels c_j are 16-bit integers, so the weighted mean  sum w_j c_j / sum w_j  can be computed EXACTLY once the weights are integers:
+//     ws = sum_j (double) w_j (tap order);   P = max(17, 21 + ceil(log2 ws))   (so that every W_j <= 2^22)
+//     W_j = llrint(ldexp((double) w_j, P) / ws);   the first largest W_j takes the residue 2^P - sum W_j   =>  sum_j W_j == 2^P exactly
+//     texel = floor(sum_j W_j c_j / 2^P + 1/2)          (round to nearest, a tie -- an exact half -- goes up; OpenGL 4.6 2.3.5 leaves it open)
+//     float form (bars not as texels): (float) ((double) sum_j W_j c_j * 2^-P / 65535.0)
+// w_j are the shader's float weights (make_bar_taps).  The integer weights are within 2^-P (relative to their sum: <= 2^-22 of the largest)
+// of the float ones, so the result lies within 65535 / 2^21 = 0.03 texel steps of the mean with the float weights in exact arithmetic
+// (typically 0.002) -- closer to it than any float summation order is (tests/test_gl_reference.py holds it to the reference's own
+// llvmpipe texels tie-aware, like every other form).  A bar whose weights sum to 0 (0 / 0 in the shader) is texel 0 / float NaN.
+// On the device c - 32896 = 256 h + l and W = 65536 w2 + 256 w1 + w0 in balanced signed bytes: six v_mfma_i32_32x32x32_i8 per
+// 32 rows x 32 bars x 32 bins into four accumulators (2^24: h w2; 2^16: h w1 + l w2; 2^8: h w0 + l w1; 2^0: l w0), all exact.
+//   itiles[T]: bars [32 T, 32 T + 32): origin (a multiple of 16 bins), steps of 32 bins, w_off = first 16-byte vector of its weights in wq
+//   wq:        per tile and step [digit 0..2][lane 0..63][16 bytes]: lane l, byte j = digit of W for bar k0 + l % 32 at bin
+//              origin + 32 step + 16 (l / 32) + j (0 outside the bar's own taps) -- the b-operand of the MFMA, one coalesced load per digit
+//   fin[k]:    {c, s}: texel = (uint32) (floor(T / 2^16) + c) >> s with s = P - 16 in [1, 15] and c = 32896 * 2^s + 2^(s-1); s == 0: weights sum to 0
+//   rounds:    as make_bar_mtiles (tile ends rounded up to 8 bins: the ring is filled 8 texels = 16 bytes at a time)
+constexpr uint32_t kBarIStepBins = 32, kBarILookAhead = 2;       // bins per step; steps of zeros behind the last tile (the kernel's weight look-ahead)
+// the integer weights of one bar (W: count values); returns P, or -1 when the float weights sum to 0 / NaN, or -2 when P would exceed 31
+inline int bar_int_weights(const float* w, uint32_t count, std::vector<int32_t>& W) {
+    W.assign(count, 0);
+    double ws = 0.0;
+    for (uint32_t j = 0; j < count; ++j) ws += (double) w[j];
+    if (!(ws > 0.0) || !(ws < 1e30)) return -1;
+    int ex = 0;
+    const double f = frexp(ws, &ex);                       // ws = f 2^ex, f in [0.5, 1)
+    int P = 21 + (f == 0.5 ? ex - 1 : ex);                 // 21 + ceil(log2 ws)
+    if (P < 17) P = 17;
+    if (P > 31) return -2;
+    int64_t sum = 0;
+    uint32_t jmax = 0;
+    for (uint32_t j = 0; j < count; ++j) {
+        W[j] = (int32_t) llrint(ldexp((double) w[j], P) / ws);
+        sum += W[j];
+        if (W[j] > W[jmax]) jmax = j;
+    }
+    W[jmax] += (int32_t) (((int64_t) 1 << P) - sum);
+    return P;
+}
+inline void bar_int_digits(int32_t W, int8_t d[3]) {       // W = 65536 d2 + 256 d1 + d0, every digit in [-128, 127]
+    const int32_t d0 = ((W + 128) & 255) - 128, W1 = (W - d0) >> 8, d1 = ((W1 + 128) & 255) - 128, d2 = (W1 - d1) >> 8;
+    d[0] = (int8_t) d0; d[1] = (int8_t) d1; d[2] = (int8_t) d2;
+}
+inline bool make_bar_itiles(std::vector<BarMTile>& itiles, std::vector<int8_t>& wq, std::vector<BarIFin>& fin, std::vector<BarTile>& rounds,
+                            const std::vector<BarDesc>& desc, const std::vector<float>& tap_w, uint32_t n, uint32_t bins, uint32_t tiles_per_round) {
+    itiles.clear(); wq.clear(); fin.clear(); rounds.clear();
+    const uint32_t bars = (uint32_t) desc.size();
+    if (bars < kBarSeqMin || tiles_per_round == 0 || bins % 32u) return false;
+    const uint32_t nt = (bars + kBarTileBars - 1) / kBarTileBars;
+    // the integer weights of every bar
+    std::vector<std::vector<int32_t>> W(bars);
+    fin.assign((size_t) nt * kBarTileBars, BarIFin{0u, 0u});
+    for (uint32_t k = 0; k < bars; ++k) {
+        const int P = bar_int_weights(tap_w.data() + desc[k].tap_offset, desc[k].count, W[k]);
+        if (P == -2) return false;
+        if (P < 0) continue;                                                    // weights sum to 0: s stays 0
+        const uint32_t s = (uint32_t) P - 16u;
+        fin[k] = BarIFin{(32896u << s) + (1u << (s - 1u)), s};
+    }
+    bool monotone = true;
+    auto tile_end = [&](uint32_t H) {                                           // last bin + 1 of the tile's own taps, rounded up to a fill unit
+        uint32_t e = 0;
+        const uint32_t k1 = (H + 1) * kBarTileBars < bars ? (H + 1) * kBarTileBars : bars;
+        for (uint32_t k = H * kBarTileBars; k < k1; ++k) e = desc[k].first_bin + desc[k].count > e ? desc[k].first_bin + desc[k].count : e;
+        return (e + 7u) & ~7u;
+    };
+    for (uint32_t T = 0; T < nt; ++T) {
+        const uint32_t k0 = T * kBarTileBars, k1 = k0 + kBarTileBars < bars ? k0 + kBarTileBars : bars;
+        uint32_t lo = 0xffffffffu;
+        for (uint32_t k = k0; k < k1; ++k) lo = desc[k].first_bin < lo ? desc[k].first_bin : lo;
+        BarMTile t{k0, lo & ~15u, 0u, 0u};
+        t.steps = (tile_end(T) - t.origin + kBarIStepBins - 1u) / kBarIStepBins;
+        if (T && t.origin < itiles[T - 1].origin) monotone = false;
+        itiles.push_back(t);
+    }
+    if (monotone) cut_bar_rounds(rounds, nt, [&](uint32_t T) { return itiles[T].origin; }, tile_end, n, bins, tiles_per_round);
+    std::vector<uint32_t> order;                                                // one stream per wave, as make_bar_mtiles
+    if (!rounds.empty()) {
+        for (uint32_t wv = 0; wv < tiles_per_round; ++wv)
+            for (const BarTile& r : rounds)
+                if (r.k0 + wv < r.k1) order.push_back(r.k0 + wv);
+    } else {
+        for (uint32_t i = 0; i < nt; ++i) order.push_back(i);
+    }
+    for (uint32_t Ti : order) {
+        BarMTile& t = itiles[Ti];
+        const uint32_t k0 = t.k0, k1 = k0 + kBarTileBars < bars ? k0 + kBarTileBars : bars;
+        t.w_off = (uint32_t) (wq.size() / 16u);
+        wq.resize(wq.size() + (size_t) t.steps * 3u * 64u * 16u, 0);
+        int8_t* base = wq.data() + (size_t) t.w_off * 16u;
+        for (uint32_t k = k0; k < k1; ++k)
+            for (uint32_t i = 0; i < desc[k].count; ++i) {
+                const uint32_t rel = desc[k].first_bin + i - t.origin, step = rel / kBarIStepBins, half = (rel % kBarIStepBins) / 16u, j = rel % 16u;
+                int8_t d[3];
+                bar_int_digits(W[k][i], d);
+                for (uint32_t q = 0; q < 3; ++q) base[(((size_t) step * 3u + q) * 64u + half * 32u + (k - k0)) * 16u + j] = d[q];
+            }
+    }
+    wq.resize(wq.size() + (size_t) kBarILookAhead * 3u * 64u * 16u, 0);         // what the look-ahead reads past the last tile
     return true;
 }
 

@@ -488,6 +488,63 @@ void glvo_bars_chunked_at(const float* tex, size_t sz, float* bars_out, size_t b
     free(x); free(w);
 }
 
+/* GLV_OP_BARS over TEXEL rows with 256 bars or more -- the pre-smoothing pass inside the library's GL chains (gl_storage != 0:
+ * render.c:2277-2303 samples a GL_R16 texture, so every input is a 16-bit integer c).  There the library computes the weighted mean
+ * of smooth.glsl:25-40 in EXACT integer arithmetic (glava_amd/csrc/glv_tables.h "many bars over TEXEL rows" is what this restates):
+ *   w_j   the shader's float weights, taps counted by bin as above (a skipped bin is a tap of weight 0)
+ *   ws    = sum_j (double) w_j in tap order;  P = max(17, 21 + ceil(log2 ws))
+ *   W_j   = llrint(ldexp((double) w_j, P) / ws); the first largest W_j takes the residue, so that sum_j W_j == 2^P
+ *   texel = floor(sum_j W_j c_j / 2^P + 1/2);   float = (float) ((double) sum_j W_j c_j * 2^-P / 65535.0)
+ * A bar whose float weights sum to 0 (0 / 0 in the shader) is texel 0 / float NaN.  Either output may be NULL.
+ * Returns 0, or -1 when some bar would need P > 31 (the library then keeps its float chain). */
+int glvo_bars_int_at(const uint16_t* tex, size_t sz, uint16_t* texels_out, float* floats_out, size_t bars, float smooth_factor, float phase) {
+    float* w = malloc(sizeof(float) * (sz + 128));
+    long* bin_of = malloc(sizeof(long) * (sz + 128));
+    long long* W = malloc(sizeof(long long) * (sz + 128));
+    int rc = 0;
+    for (size_t k = 0; k < bars && rc == 0; ++k) {
+        float idx = phase == 0.0F ? (float) k / (float) bars : ((float) k + phase) / (float) bars;
+        float smin = glvo_scale_audio(glvo_clamp01(idx - smooth_factor)) * sz;
+        float smax = glvo_scale_audio(glvo_clamp01(idx + smooth_factor)) * sz;
+        float m = (smax - smin) / 2.0F, rm = smin + m;
+        size_t cnt = 0;
+        long prev = -1;
+        for (float s = smin; s <= smax; s += 1.0F) {
+            float wt = glvo_sinusoidal(glvo_clamp01((m - fabsf(rm - s)) / m));
+            long bin = (long) (int) roundf(s);
+            for (long q = prev + 1; prev >= 0 && q < bin; ++q) { w[cnt] = 0; bin_of[cnt] = q; ++cnt; }
+            prev = bin;
+            w[cnt] = wt; bin_of[cnt] = bin; ++cnt;
+        }
+        double ws = 0;
+        for (size_t j = 0; j < cnt; ++j) ws += (double) w[j];
+        if (!(ws > 0) || !(ws < 1e30)) {
+            if (texels_out) texels_out[k] = 0;
+            if (floats_out) floats_out[k] = NAN;
+            continue;
+        }
+        int ex = 0;
+        double f = frexp(ws, &ex);
+        int P = 21 + (f == 0.5 ? ex - 1 : ex);
+        if (P < 17) P = 17;
+        if (P > 31) { rc = -1; break; }
+        long long sum = 0;
+        size_t jmax = 0;
+        for (size_t j = 0; j < cnt; ++j) {
+            W[j] = llrint(ldexp((double) w[j], P) / ws);
+            sum += W[j];
+            if (W[j] > W[jmax]) jmax = j;
+        }
+        W[jmax] += (1LL << P) - sum;
+        long long total = 0;
+        for (size_t j = 0; j < cnt; ++j) total += W[j] * (long long) tex[bin_of[j]];
+        if (texels_out) texels_out[k] = (uint16_t) ((total + (1LL << (P - 1))) >> P);
+        if (floats_out) floats_out[k] = (float) (ldexp((double) total, -P) / 65535.0);
+    }
+    free(w); free(bin_of); free(W);
+    return rc;
+}
+
 /* smooth_audio() once more, for the tie-aware comparisons of tests/test_gl_reference.py: the same taps -- selected by the shader's
  * float bounds smin / smax exactly as in glvo_bars_at -- but weights, products, sums and the quotient in float64, so that
  * exact[k] is (to ~1e-15) the real number a float implementation approximates; ntaps[k] = taps of bar k (the float error of

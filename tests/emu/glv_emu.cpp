@@ -395,6 +395,70 @@ int glvemu_bars_rows(const float* tex, int n, int bars, float smooth_factor, flo
     return 0;
 }
 
+// The i8 matrix-core form of the many-bars pass over TEXEL rows (glv_tables.h make_bar_itiles, glv_misc.hip glv_bars_rows_i8_kernel) on the
+// host, off the same tables, the way the kernel consumes them: the ring of `bins` bins per row as two planes of signed bytes (c ^ 0x8080),
+// filled round by round (a slot is OVERWRITTEN when the ring wraps, exactly as on the device: a table whose rounds let a wave read a bin
+// that is gone shows up here), per tile / step / digit the 64 x 16 bytes of the b-operand against the 16 bytes per lane of the a-operand,
+// four int32 accumulators, and the kernel's epilogue  texel = (uint32) ((a3 << 8) + a2 + ((a1 + (a0 >> 8)) >> 8) + c) >> s.
+// out16 / outf: bars values (either may be NULL).  Returns 0, -2 without tables, -3 without rounds for this ring.
+int glvemu_bars_int(const uint16_t* tex, int n, int bars, float smooth_factor, float phase, int bins, uint16_t* out16, float* outf) {
+    using namespace glv;
+    std::vector<BarDesc> desc;
+    std::vector<float> w;
+    make_bar_taps(desc, w, (uint32_t) n, (uint32_t) bars, smooth_factor, phase);
+    std::vector<BarMTile> it;
+    std::vector<BarTile> rounds;
+    std::vector<int8_t> wq;
+    std::vector<BarIFin> fin;
+    if (!make_bar_itiles(it, wq, fin, rounds, desc, w, (uint32_t) n, (uint32_t) bins, 4u)) return -2;
+    if (rounds.empty()) return -3;
+    const uint32_t S = (uint32_t) bins;
+    std::vector<int8_t> ph(S, 99), pl(S, -77);                                   // garbage where nothing was parked: must meet weight 0 only
+    auto park = [&](uint32_t b0, uint32_t b1) {
+        for (uint32_t b = b0; b < b1; ++b) {
+            const uint16_t c = tex[b < (uint32_t) n ? b : (uint32_t) n - 1];
+            ph[b % S] = (int8_t) ((c >> 8) ^ 0x80); pl[b % S] = (int8_t) ((c & 255) ^ 0x80);
+        }
+    };
+    uint32_t filled_to = rounds[0].end;
+    park(rounds[0].origin, rounds[0].end);
+    std::vector<long long> before;
+    for (size_t t = 0; t < rounds.size(); ++t) {
+        const BarTile& R = rounds[t];
+        const uint32_t next_end = t + 1 < rounds.size() ? rounds[t + 1].end : filled_to;
+        // the round's tiles are evaluated TWICE -- before and after the next round's bins are parked: on the device the other waves park
+        // them while this one still reads, so a table is only right if nothing a tile reads with a non-zero weight changes
+        for (int pass = 0; pass < 2; ++pass) {
+            size_t at = 0;
+            for (uint32_t Ti = R.k0; Ti < R.k1; ++Ti) {
+                const BarMTile& T = it[Ti];
+                if (T.origin % 16u) return 1;
+                for (uint32_t j = 0; j < 32 && T.k0 + j < (uint32_t) bars; ++j) {
+                    int32_t a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+                    for (uint32_t s = 0; s < T.steps; ++s)
+                        for (uint32_t half = 0; half < 2; ++half)
+                            for (uint32_t q = 0; q < 16; ++q) {
+                                const uint32_t slot = (T.origin + 32 * s + 16 * half + q) % S;
+                                const int32_t h = ph[slot], l = pl[slot];
+                                const int8_t* wb = wq.data() + (size_t) T.w_off * 16u + (((size_t) s * 3u) * 64u + half * 32u + j) * 16u + q;
+                                const int32_t w0 = wb[0], w1 = wb[(size_t) 64 * 16], w2 = wb[(size_t) 2 * 64 * 16];
+                                a3 += h * w2; a2 += h * w1 + l * w2; a1 += h * w0 + l * w1; a0 += l * w0;
+                            }
+                    const BarIFin f = fin[T.k0 + j];
+                    const int P = (int) f.s + 16;
+                    const long long tot = ((long long) a3 << 24) + ((long long) a2 << 16) + ((long long) a1 << 8) + a0 + ((long long) 32896 << P);
+                    if (pass == 0) before.push_back(tot); else if (before[at++] != tot) return 2;
+                    if (out16) out16[T.k0 + j] = f.s == 0 ? 0 : (uint16_t) (((uint32_t) ((a3 << 8) + a2 + ((a1 + (a0 >> 8)) >> 8)) + f.c) >> f.s);
+                    if (outf) outf[T.k0 + j] = f.s == 0 ? __builtin_nanf("") : (float) (ldexp((double) tot, -P) / 65535.0);
+                }
+            }
+            if (pass == 0 && next_end > filled_to) { park(filled_to, next_end); filled_to = next_end; }
+        }
+        before.clear();
+    }
+    return 0;
+}
+
 // The rows kernel's three-instruction division by a bar's weight sum (glv_tables.h bar_rcp_division_ok; glv_misc.hip): for every bar
 // of the table, q0 = a * r, rem = fma(-q0, b, a), q = fma(rem, r, q0) against a / b for EVERY significand of a in two binades around
 // b -- every b_stride-th distinct weight sum -- (scaling a by a power of two scales everything exactly while nothing leaves the normal range, which the kernel's 2^-90 guard and

@@ -106,6 +106,9 @@ class Oracle:
             L.glvo_bars_chunked.argtypes = [_f32p, C.c_size_t, _f32p, C.c_size_t, C.c_float]
             L.glvo_bars_at.argtypes = [_f32p, C.c_size_t, _f32p, C.c_size_t, C.c_float, C.c_float]
             L.glvo_bars_chunked_at.argtypes = [_f32p, C.c_size_t, _f32p, C.c_size_t, C.c_float, C.c_float]
+            _u16p = np.ctypeslib.ndpointer(np.uint16, flags="C_CONTIGUOUS")
+            L.glvo_bars_int_at.argtypes = [_u16p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_size_t, C.c_float, C.c_float]
+            L.glvo_bars_int_at.restype = C.c_int
             L.glvo_texels_r16.argtypes = [_f32p, C.c_size_t, np.ctypeslib.ndpointer(np.uint16, flags="C_CONTIGUOUS")]
             L.glvo_bars_at_exact.argtypes = [_f32p, C.c_size_t, np.ctypeslib.ndpointer(np.float64, flags="C_CONTIGUOUS"),
                                              np.ctypeslib.ndpointer(np.int32, flags="C_CONTIGUOUS"), np.ctypeslib.ndpointer(np.int32, flags="C_CONTIGUOUS"),
@@ -132,6 +135,15 @@ class Oracle:
         out = np.empty(b.size, np.uint16)
         cls.lib().glvo_texels_r16(b, b.size, out)
         return out.reshape(np.shape(buf))
+
+    @classmethod
+    def bars_int(cls, texels: np.ndarray, bars: int, smooth_factor=0.025, phase=0.5):
+        """glvo_bars_int_at: the exact integer weighted mean of the many-bars pass over one row of GL_R16 texels -> (texels, floats)"""
+        texels = np.ascontiguousarray(texels, dtype=np.uint16)
+        t = np.zeros(bars, np.uint16); f = np.zeros(bars, np.float32)
+        rc = cls.lib().glvo_bars_int_at(texels, texels.size, t.ctypes.data, f.ctypes.data, bars, smooth_factor, phase)
+        assert rc == 0, rc
+        return t, f
 
     @classmethod
     def window_table(cls, n: int) -> np.ndarray:

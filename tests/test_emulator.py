@@ -354,6 +354,39 @@ def test_many_bars_arithmetic_is_the_documented_one(emu, oracle, n, bars, bins, 
         assert same.all(), (n, bars, int((~same).sum()))
 
 
+@pytest.mark.parametrize("n,bars,bins,factor,phase", [(512, 512, 160, 0.025, 0.5), (1024, 1024, 160, 0.025, 0.5), (2048, 2048, 160, 0.025, 0.5), (4096, 4096, 288, 0.025, 0.5),
+                                                      (8192, 8192, 448, 0.025, 0.5), (16384, 16384, 832, 0.025, 0.5), (32768, 32768, 1600, 0.025, 0.5),
+                                                      (2048, 1001, 288, 0.025, 0.0), (1024, 259, 288, 0.025, 0.5), (4096, 4096, 832, 0.12, 0.25), (4096, 300, 832, 0.005, 0.0)])
+def test_integer_tables_of_the_texel_rows_pass(emu, oracle, n, bars, bins, factor, phase):
+    """Many bars over TEXEL rows (the library's GL chains): exact integer arithmetic on the i8 matrix cores off host tables -- per bar
+    integer weights that sum to 2^P, as balanced signed byte digits in MFMA operand layout, the texels as two planes of signed bytes in an
+    LDS ring (glv_tables.h make_bar_itiles).  glvemu_bars_int walks those tables the way the kernel does -- ring slots overwritten as the
+    ring wraps, every tile evaluated before AND after the next round's bins are parked, the kernel's five-instruction epilogue -- and must
+    give the oracle's independent restatement (glvo_bars_int_at: the bars' own taps, 64-bit integers): the same texels, the same float
+    bits.  Saturated, zero and random rows; and the result lies within 0.03 texel steps of the weighted mean with the shader's weights
+    in float64 (glvo_bars_at_exact) -- closer than any float summation order."""
+    import ctypes as C
+    rng = np.random.default_rng(n * 3 + bars)
+    u16p = np.ctypeslib.ndpointer(np.uint16, flags="C_CONTIGUOUS"); f32p = np.ctypeslib.ndpointer(np.float32, flags="C_CONTIGUOUS")
+    emu.glvemu_bars_int.argtypes = [u16p, C.c_int, C.c_int, C.c_float, C.c_float, C.c_int, u16p, f32p]
+    emu.glvemu_bars_int.restype = C.c_int
+    rows = [(rng.random(n) ** 2 * 65535.99).astype(np.uint16), np.full(n, 65535, np.uint16), np.zeros(n, np.uint16), rng.integers(0, 65536, n).astype(np.uint16),
+            (rng.random(n) < 0.5).astype(np.uint16) * np.uint16(65535)]
+    for tex in rows:
+        g16 = np.full(bars, 7, np.uint16); gf = np.full(bars, -1, np.float32)
+        assert emu.glvemu_bars_int(tex, n, bars, factor, phase, bins, g16, gf) == 0
+        w16, wf = oracle.bars_int(tex, bars, factor, phase)
+        assert (g16 == w16).all(), (n, bars, int((g16 != w16).sum()))
+        assert ((gf.view(np.uint32) == wf.view(np.uint32)) | (np.isnan(gf) & np.isnan(wf))).all()
+        ex = np.empty(bars, np.float64); nt = np.empty(bars, np.int32); frag = np.empty(bars, np.int32)
+        oracle.lib().glvo_bars_at_exact((tex.astype(np.float32) / np.float32(65535)).copy(), n, ex, nt, frag, bars, factor, phase, 4)
+        ok = ~np.isnan(wf)
+        assert np.abs(wf[ok].astype(np.float64) * 65535 - ex[ok] * 65535).max() <= 0.03 + 65535 * 2.0 ** -23
+    if (n, bins) == (4096, 288):
+        # a ring too small for the tiles gives no rounds (the library then falls back to the float chain's kernels), never wrong numbers
+        assert emu.glvemu_bars_int(rows[0], n, bars, factor, phase, 160, g16, gf) == -3
+
+
 @pytest.mark.parametrize("n,b_stride", [(1024, 16), (4096, 64)])
 def test_rows_kernel_division_by_reciprocal_is_the_quotient(emu, n, b_stride):
     """The many-bars kernels divide a bar's total by its weight sum in three instructions -- q0 = a * r, rem = fma(-q0, b, a),

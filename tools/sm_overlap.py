@@ -1,0 +1,43 @@
+#!/usr/bin/env python3
+"""the GL-default pipeline with the pre-smoothing pass as TWO batches of half the streams on two HIP streams, so that
+transform(k+1) and the many-bars pass (k) can be in flight together -- against one batch of all the streams on one stream.
+    sm_overlap.py [streams] [calls]"""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+from glava_amd import spectrum as G
+streams = int(sys.argv[1]) if len(sys.argv) > 1 else 16384
+calls = int(sys.argv[2]) if len(sys.argv) > 2 else 60
+n, F = 4096, 5
+ops = G.OP_FFT | G.OP_GRAVITY | G.OP_AVERAGE | G.OP_BARS | G.OP_R16
+mask = G.OP_GRAVITY | G.OP_AVERAGE | G.OP_BARS
+p = G.Params(n=n, avg_frames=F, avg_window_kind=1, gl_storage=1, bars=n, bar_phase=0.5)
+
+
+def timed(fn):
+    t_end = time.perf_counter() + 0.3
+    while time.perf_counter() < t_end:
+        fn(); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(calls): fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / calls * 1e3
+
+
+pcm = torch.randint(-32768, 32768, (streams, n, 2), dtype=torch.int16, device="cuda")
+out = torch.empty((streams, 2, n), dtype=torch.int16, device="cuda")
+one = G.Batch(p, streams, mask)
+ms1 = timed(lambda: one.process_s16(pcm, out, ops))
+one.close()
+for parts in (2, 4):
+    sub = streams // parts
+    bs = [G.Batch(p, sub, mask) for _ in range(parts)]
+    sts = [torch.cuda.Stream() for _ in range(parts)]
+
+    def split():
+        for i, (b, st) in enumerate(zip(bs, sts)):
+            b.process_s16(pcm[i * sub:(i + 1) * sub], out[i * sub:(i + 1) * sub], ops, st.cuda_stream)
+    ms = timed(split)
+    print(f"sm chain N={n} x {streams} streams: one batch, one stream {ms1:.4f} ms = {streams / ms1 / 1e3:.2f} M frames/s; {parts} batches on {parts} streams {ms:.4f} ms = {streams / ms / 1e3:.2f} M frames/s")
+    for b in bs: b.close()

@@ -41,8 +41,10 @@ struct alignas(16) BarItem { uint32_t w_byte, tex_byte, res; float keep; };
 // weights per pair start -- and one round of glv_bars_rows_kernel: tiles [k0, k1) whose bins [origin, end) sit in the LDS ring.
 struct alignas(16) BarTile { uint32_t k0, k1, origin, end; };
 struct alignas(16) BarMTile { uint32_t k0, origin, steps, w_off; };
-// texel rows (glv_tables.h make_bar_itiles): per bar the epilogue's rounding constant and shift, texel = (floor(T / 2^16) + c) >> s; s == 0: weights sum to 0
+// texel rows (glv_tables.h make_bar_itiles): per bar the epilogue's rounding constant and shift, texel = (floor(T / 2^16) + c) >> s, s = P - 16 in [1, 15];
+// a bar whose weights sum to 0 has every digit 0, c = 0 and s = kBarIFinNone (the same expression then gives texel 0; the float form NaN)
 struct alignas(8) BarIFin { uint32_t c, s; };
+constexpr uint32_t kBarIFinNone = 16;
 
 struct FrameArgs {
     const void* in;        // s16: int16 [units/2][n][2] (a unit is one channel row of a frame);  f32 planar: float [units][n];

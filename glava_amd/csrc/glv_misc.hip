@@ -708,7 +708,7 @@ __global__ void __launch_bounds__(64 * kRowsWaves, 2) glv_bars_rows_i8_kernel(co
     glv_i4v wb[PF][3];
     glv_i16v acc[G][4];
     uint32_t t = t_begin, left = 0, ck = 0, next_end = filled_to, nnew = 0;
-    BarMTile M = tiles[0];
+    BarMTile M = tiles[0];                                              // (overwritten before use)
     Tex8 pre[2];
     auto park_new = [&]() {
 #pragma unroll
@@ -717,24 +717,32 @@ __global__ void __launch_bounds__(64 * kRowsWaves, 2) glv_bars_rows_i8_kernel(co
         for (uint32_t c = fcol + 2u * CPI; c < nnew; c += CPI) park(fetch(filled_to + 8u * c), filled_to + 8u * c);
         filled_to = next_end > filled_to ? next_end : filled_to;
     };
-    // opens round t: requests what the NEXT round adds to the ring (parked behind this round's arithmetic), sets up the wave's tile.
-    // false: the wave has no tile in this round
+    // opens round t: sets up the wave's tile, requests what the NEXT round adds to the ring (parked behind this round's arithmetic) and the
+    // tile's epilogue constants.  false: the wave has no tile in this round
+    BarIFin fpre = BarIFin{0u, 0u};
+    // (the descriptors of round t + 1 -- uniform scalar loads, the tile's dependent on the round's -- are requested while round t runs)
+    BarTile Tn = rounds[t_begin];
+    BarMTile Mn = tiles[Tn.k0 + wave < Tn.k1 ? Tn.k0 + wave : Tn.k0];
     auto open_round = [&]() -> bool {
-        const BarTile T = rounds[t];                                            // uniform: scalar loads
+        const BarTile T = Tn;
         const bool valid = T.k0 + wave < T.k1;
-        next_end = t + 1 < t_end ? rounds[t + 1].end : filled_to;
+        if (valid) M = Mn;
+        Tn = rounds[t + 1 < t_end ? t + 1 : t];
+        Mn = tiles[Tn.k0 + wave < Tn.k1 ? Tn.k0 + wave : Tn.k0];
+        next_end = t + 1 < t_end ? Tn.end : filled_to;
         nnew = next_end > filled_to ? (next_end - filled_to) / 8u : 0u;
+        if (valid) {
+            left = (uint32_t) __builtin_amdgcn_readfirstlane((int) M.steps);
+            ck = ((uint32_t) __builtin_amdgcn_readfirstlane((int) (M.origin >> 4)) + ahalf) % S16;      // this lane's 16-bin chunk of the step, in the ring
+#pragma unroll
+            for (uint32_t g = 0; g < G; ++g)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) acc[g][q] = glv_i16v{0};
+        }
 #pragma unroll
         for (uint32_t q = 0; q < 2; ++q) pre[q] = fetch(filled_to + 8u * (fcol + q * CPI < nnew ? fcol + q * CPI : 0u));
-        if (!valid) return false;
-        M = tiles[T.k0 + wave];
-        left = (uint32_t) __builtin_amdgcn_readfirstlane((int) M.steps);
-        ck = ((uint32_t) __builtin_amdgcn_readfirstlane((int) (M.origin >> 4)) + ahalf) % S16;      // this lane's 16-bin chunk of the step, in the ring
-#pragma unroll
-        for (uint32_t g = 0; g < G; ++g)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) acc[g][q] = glv_i16v{0};
-        return true;
+        if (valid) fpre = fin[M.k0 + (lane & 31u)];                             // (padded to whole tiles)
+        return valid;
     };
     // rounds without a tile for this wave: park, join the barrier, go on.  false: no round is left
     auto next_tile = [&]() -> bool {
@@ -747,31 +755,79 @@ __global__ void __launch_bounds__(64 * kRowsWaves, 2) glv_bars_rows_i8_kernel(co
         return false;
     };
     // behind a tile's last step
+    // Loads and stores retire on ONE counter and out of order with respect to each other, so behind a tile's 32 result stores a wait for a
+    // weight fragment is in effect a wait for the stores as well (vmcnt(6) below stays CORRECT -- loads retire in order among themselves, six
+    // younger ones outstanding mean the awaited one is back -- it just lasts until the stores have left too).  Hence: every load is awaited
+    // BEFORE the stores are issued -- the fragments of the next PF steps are then in their registers and those steps (most tiles have no
+    // more) wait for nothing while the stores drain behind the round's barrier.  `fresh` counts the steps that still need no wait.
+    uint32_t fresh = 0;
     auto close_tile = [&]() {
+        __builtin_amdgcn_s_waitcnt(0x0F70);                                     // vmcnt(0): the ring's new texels, the weight stream
+        fresh = PF;
         park_new();
         // a lane's 16 results of a group are one bar (k0 + lane % 32) of the rows 32 g + 8 (r / 4) + 4 (lane / 32) + r % 4
         const uint32_t kb = M.k0 + (lane & 31u);
-        const BarIFin f = fin[kb];                                              // (padded to whole tiles)
-        const size_t at0 = (row0 + 4u * (lane >> 5)) * (size_t) bars + kb;
-#pragma unroll
-        for (uint32_t g = 0; g < G; ++g)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const uint32_t jr = 32u * g + 8u * (uint32_t) (r / 4) + 4u * (lane >> 5) + (uint32_t) (r & 3);
-                if (jr >= R || kb >= bars) continue;
-                const size_t at = at0 + (size_t) (32u * g + 8u * (uint32_t) (r / 4) + (uint32_t) (r & 3)) * bars;
-                const int a0 = acc[g][0][r], a1 = acc[g][1][r], a2 = acc[g][2][r], a3 = acc[g][3][r];
-                if constexpr (R16) {
-                    const uint32_t t16 = (uint32_t) ((a3 << 8) + a2 + ((a1 + (a0 >> 8)) >> 8));
-                    reinterpret_cast<uint16_t*>(bars_out)[at] = f.s == 0u ? (uint16_t) 0 : (uint16_t) ((t16 + f.c) >> f.s);
-                } else {
-                    const int P = (int) f.s + 16;
-                    const long long tot = ((long long) a3 << 24) + ((long long) a2 << 16) + ((long long) a1 << 8) + a0 + ((long long) 32896 << P);
-                    reinterpret_cast<float*>(bars_out)[at] = f.s == 0u ? __builtin_nanf("") : (float) (__builtin_ldexp((double) tot, -P) / 65535.0);
-                }
+        const BarIFin f = fpre;
+        using OutT = std::conditional_t<R16, uint16_t, float>;
+        // the lane's first row of the block at its bar; the compiler must not keep 32 per-lane addresses alive across the tile loop
+        // (it did: spilled, and every store then waited for a scratch reload with vmcnt(0) -- i.e. for the store before it)
+        // (the OFFSET is what is made opaque: a pointer that went through an asm statement loses its address space and the stores become FLAT ones)
+        size_t base_at = (row0 + 4u * (lane >> 5)) * (size_t) bars + kb;
+        asm volatile("" : "+v"(base_at));
+        OutT* base = static_cast<OutT*>(bars_out) + base_at;
+        auto result = [&](uint32_t g, int r) -> OutT {
+            const int a0 = acc[g][0][r], a1 = acc[g][1][r], a2 = acc[g][2][r], a3 = acc[g][3][r];
+            if constexpr (R16) {
+                // (a bar whose weights sum to 0 has c = 0, s = 16 and all-zero digits: 0 >> 16 -- no branch)
+                const uint32_t t16 = (uint32_t) ((a3 << 8) + a2 + ((a1 + (a0 >> 8)) >> 8));
+                return (uint16_t) ((t16 + f.c) >> f.s);
+            } else {
+                const int P = (int) f.s + 16;
+                const long long tot = ((long long) a3 << 24) + ((long long) a2 << 16) + ((long long) a1 << 8) + a0 + ((long long) 32896 << P);
+                return f.s == kBarIFinNone ? __builtin_nanf("") : (float) (__builtin_ldexp((double) tot, -P) / 65535.0);
             }
+        };
+        // register r of a group is row 8 (r / 4) + r % 4 (+ 4 for the upper lanes: in `base`) of its 32: four row pointers, each moved on by
+        // eight rows per quad of registers -- no table of 32 row offsets in scalar registers
+        OutT* rp[4] = {base, base + bars, base + 2 * (size_t) bars, base + 3 * (size_t) bars};
+        const size_t eight = 8 * (size_t) bars;
+        // a partial last block: rows of the group this lane may store (made opaque: 32 hoisted row masks would not fit the scalar registers)
+        uint32_t rlim = R > 4u * (lane >> 5) ? R - 4u * (lane >> 5) : 0u;
+        asm volatile("" : "+v"(rlim));
+        if (kb < bars) {
+            if (R == (uint32_t) RB) {                                           // whole block (uniform): no row checks
+#pragma unroll
+                for (uint32_t g = 0; g < G; ++g)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) { *rp[i] = result(g, 4 * q + i); rp[i] += eight; }
+                    }
+            } else {
+#pragma unroll
+                for (uint32_t g = 0; g < G; ++g)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            if (32u * g + 8u * (uint32_t) q + (uint32_t) i < rlim) *rp[i] = result(g, 4 * q + i);
+                            rp[i] += eight;
+                        }
+                    }
+            }
+        }
         __syncthreads();
         ++t;
+    };
+    // The weight stream is requested and awaited by hand: behind a bank's three requests at least the other two banks' six have been issued
+    // by the time the bank is used, and loads retire in order: vmcnt(6).  (Left to the compiler, every control-flow merge behind a tile's end
+    // made the next wait a wait for everything, the fragments requested a moment ago included: an L2 round trip per tile.)  The compiler does
+    // not know these loads are in flight: its own waits (for the ring's texels, the epilogue's constants) can only come out stricter than
+    // necessary, never too lax.
+    auto wload = [&](glv_i4v& d0, glv_i4v& d1, glv_i4v& d2) {
+        asm volatile("global_load_dwordx4 %0, %3, off\n\tglobal_load_dwordx4 %1, %3, off offset:1024\n\tglobal_load_dwordx4 %2, %3, off offset:2048"
+                     : "=&v"(d0), "=&v"(d1), "=&v"(d2) : "v"(wp) : "memory");
+        wp += 3 * 64;
     };
     auto step = [&](auto BC) {                                                  // one step of 32 bins on bank B
         constexpr int B = decltype(BC)::value;
@@ -782,10 +838,9 @@ __global__ void __launch_bounds__(64 * kRowsWaves, 2) glv_bars_rows_i8_kernel(co
             al[g] = *reinterpret_cast<const glv_i4v*>(plane_l + g * 32u * PITCH + arow + ck * 16u);
         }
         ck = ck + 2u >= S16 ? ck + 2u - S16 : ck + 2u;
+        if (fresh != 0) --fresh;
+        else asm volatile("s_waitcnt vmcnt(6)" : "+v"(wb[B][0]), "+v"(wb[B][1]), "+v"(wb[B][2]) : : "memory");
         const glv_i4v w0 = wb[B][0], w1 = wb[B][1], w2 = wb[B][2];
-#pragma unroll
-        for (int d = 0; d < 3; ++d) wb[B][d] = wp[(size_t) d * 64];             // the bank's next step, PF steps on
-        wp += 3 * 64;
 #pragma unroll
         for (uint32_t g = 0; g < G; ++g) {
             acc[g][3] = __builtin_amdgcn_mfma_i32_32x32x32_i8(ah[g], w2, acc[g][3], 0, 0, 0);
@@ -798,15 +853,15 @@ __global__ void __launch_bounds__(64 * kRowsWaves, 2) glv_bars_rows_i8_kernel(co
             acc[g][2] = __builtin_amdgcn_mfma_i32_32x32x32_i8(al[g], w2, acc[g][2], 0, 0, 0);
             acc[g][1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(al[g], w1, acc[g][1], 0, 0, 0);
         }
+        // the bank's next step, PF steps on: requested once its MFMAs have been issued (they read the registers when they issue)
+        asm volatile("" : : "v"(acc[0][1]) : "memory");
+        wload(wb[B][0], wb[B][1], wb[B][2]);
     };
     if (!next_tile()) return;
     // the wave's first tile: fill the pipeline
     wp = wq + (uint32_t) __builtin_amdgcn_readfirstlane((int) M.w_off) + lane;
 #pragma unroll
-    for (int b = 0; b < PF; ++b)
-#pragma unroll
-        for (int d = 0; d < 3; ++d) wb[b][d] = wp[(size_t) (3 * b + d) * 64];
-    wp += (size_t) PF * 3 * 64;
+    for (int b = 0; b < PF; ++b) wload(wb[b][0], wb[b][1], wb[b][2]);
     for (;;) {
         step(std::integral_constant<int, 0>{});
         if (--left == 0) { close_tile(); if (!next_tile()) break; }

@@ -306,7 +306,7 @@ inline bool make_bar_mtiles(std::vector<BarMTile>& mtiles, std::vector<float>& w
 //   itiles[T]: bars [32 T, 32 T + 32): origin (a multiple of 16 bins), steps of 32 bins, w_off = first 16-byte vector of its weights in wq
 //   wq:        per tile and step [digit 0..2][lane 0..63][16 bytes]: lane l, byte j = digit of W for bar k0 + l % 32 at bin
 //              origin + 32 step + 16 (l / 32) + j (0 outside the bar's own taps) -- the b-operand of the MFMA, one coalesced load per digit
-//   fin[k]:    {c, s}: texel = (uint32) (floor(T / 2^16) + c) >> s with s = P - 16 in [1, 15] and c = 32896 * 2^s + 2^(s-1); s == 0: weights sum to 0
+//   fin[k]:    {c, s}: texel = (uint32) (floor(T / 2^16) + c) >> s with s = P - 16 in [1, 15] and c = 32896 * 2^s + 2^(s-1); weights that sum to 0: {0, kBarIFinNone}, every digit 0
 //   rounds:    as make_bar_mtiles (tile ends rounded up to 8 bins: the ring is filled 8 texels = 16 bytes at a time)
 constexpr uint32_t kBarIStepBins = 32, kBarILookAhead = 2;       // bins per step; steps of zeros behind the last tile (the kernel's weight look-ahead)
 // the integer weights of one bar (W: count values); returns P, or -1 when the float weights sum to 0 / NaN, or -2 when P would exceed 31
@@ -342,11 +342,11 @@ inline bool make_bar_itiles(std::vector<BarMTile>& itiles, std::vector<int8_t>& 
     const uint32_t nt = (bars + kBarTileBars - 1) / kBarTileBars;
     // the integer weights of every bar
     std::vector<std::vector<int32_t>> W(bars);
-    fin.assign((size_t) nt * kBarTileBars, BarIFin{0u, 0u});
+    fin.assign((size_t) nt * kBarTileBars, BarIFin{0u, kBarIFinNone});
     for (uint32_t k = 0; k < bars; ++k) {
         const int P = bar_int_weights(tap_w.data() + desc[k].tap_offset, desc[k].count, W[k]);
         if (P == -2) return false;
-        if (P < 0) continue;                                                    // weights sum to 0: s stays 0
+        if (P < 0) continue;                                                    // weights sum to 0: {0, kBarIFinNone}, every digit 0
         const uint32_t s = (uint32_t) P - 16u;
         fin[k] = BarIFin{(32896u << s) + (1u << (s - 1u)), s};
     }

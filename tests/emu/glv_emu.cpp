@@ -448,8 +448,8 @@ int glvemu_bars_int(const uint16_t* tex, int n, int bars, float smooth_factor, f
                     const int P = (int) f.s + 16;
                     const long long tot = ((long long) a3 << 24) + ((long long) a2 << 16) + ((long long) a1 << 8) + a0 + ((long long) 32896 << P);
                     if (pass == 0) before.push_back(tot); else if (before[at++] != tot) return 2;
-                    if (out16) out16[T.k0 + j] = f.s == 0 ? 0 : (uint16_t) (((uint32_t) ((a3 << 8) + a2 + ((a1 + (a0 >> 8)) >> 8)) + f.c) >> f.s);
-                    if (outf) outf[T.k0 + j] = f.s == 0 ? __builtin_nanf("") : (float) (ldexp((double) tot, -P) / 65535.0);
+                    if (out16) out16[T.k0 + j] = (uint16_t) (((uint32_t) ((a3 << 8) + a2 + ((a1 + (a0 >> 8)) >> 8)) + f.c) >> f.s);      // (weights that sum to 0: 0 >> 16)
+                    if (outf) outf[T.k0 + j] = f.s == kBarIFinNone ? __builtin_nanf("") : (float) (ldexp((double) tot, -P) / 65535.0);
                 }
             }
             if (pass == 0 && next_end > filled_to) { park(filled_to, next_end); filled_to = next_end; }

@@ -1348,7 +1348,9 @@ int glv_state_create(const glv_params* p, int device, glv_state** out) {
     *out = nullptr;
     glv_state* s = new (std::nothrow) glv_state();
     if (!s) return fail(GLV_ERR_NOMEM, "out of host memory");
-    int rc = batch_create_rows(p, 1, GLV_OP_GRAVITY | GLV_OP_AVERAGE | GLV_OP_SMOOTH, device, true, &s->b);
+    // (GL_R16 state -- the accel path of handle_audio, glv_gl_texture -- also announces the pre-smoothing pass: one scratch row)
+    const unsigned mask = GLV_OP_GRAVITY | GLV_OP_AVERAGE | GLV_OP_SMOOTH | (p && p->gl_storage == 1 && p->bars >= 1 && p->bars <= p->n ? (unsigned) GLV_OP_BARS : 0u);
+    int rc = batch_create_rows(p, 1, mask, device, true, &s->b);
     if (rc == GLV_OK) {
         const char* mode = std::getenv("GLV_STAGING");
         s->mapped = !(mode && std::strcmp(mode, "copy") == 0);
@@ -1468,6 +1470,46 @@ int glv_texels_r16(const glv_params* p, glv_state* s, const float* buf, uint16_t
     HIP_TRY(hipMemcpyAsync(s->d_io, buf, sizeof(float) * p->n, hipMemcpyHostToDevice, nullptr));
     if (int rc = process(b, s->d_io, glv::IN_F32_PLANAR, reinterpret_cast<float*>(s->d_tex), GLV_OP_R16, 1, 0, nullptr)) return rc;
     HIP_TRY(hipMemcpyAsync(texels, s->d_tex, sizeof(uint16_t) * p->n, hipMemcpyDeviceToHost, nullptr));
+    HIP_TRY(hipStreamSynchronize(nullptr));
+    return GLV_OK;
+}
+
+int glv_gl_texture(const glv_params* p, glv_state* s, const float* buf, int smooth_pass, uint16_t* texels) {
+    if (!s || !s->b) return fail(GLV_ERR_INVALID, "state is NULL");
+    if (!buf || !texels) return fail(GLV_ERR_INVALID, "NULL buffer");
+    if (int rc = validate(p)) return rc;
+    glv_batch* b = s->b;
+    if (p->n != b->p.n || p->avg_frames != b->p.avg_frames)
+        return fail(GLV_ERR_STATE, "params (n=%u, F=%u) do not match the state (n=%u, F=%u)", p->n, p->avg_frames, b->p.n, b->p.avg_frames);
+    if (p->gl_storage != 1 || !b->state16) return fail(GLV_ERR_STATE, "glv_gl_texture needs a state created with gl_storage = 1 (the GL passes' GL_R16 storage)");
+    if (smooth_pass && (p->bars != p->n || !(b->ops_mask & GLV_OP_BARS)))
+        return fail(GLV_ERR_INVALID, "glv_gl_texture with the pre-smoothing pass: bars must equal n (bar_phase 0.5: the pass's texel centres) when the state is created");
+    if (!same_params(b->p, *p)) {
+        glv_params rest = *p;
+        rest.ur = b->p.ur; rest.gravity_step = b->p.gravity_step;
+        if (same_params(b->p, rest)) { b->p.ur = p->ur; b->p.gravity_step = p->gravity_step; update_gravity_step(b); }
+        else if (int rc = glv_batch_set_params(b, p)) return rc;
+    }
+    HIP_TRY(hipSetDevice(b->device));
+    // render.c:2230: no averaging pass with a single frame; the chain then ends in the gravity store
+    const unsigned ops = GLV_OP_FFT | GLV_OP_GRAVITY | (p->avg_frames > 1 ? (unsigned) GLV_OP_AVERAGE : 0u) | (smooth_pass ? (unsigned) GLV_OP_BARS : 0u) | GLV_OP_R16;
+    const size_t in_bytes = sizeof(float) * p->n, out_bytes = sizeof(uint16_t) * p->n;
+    if (s->mapped) {
+        if (!s->h_tex) {
+            HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&s->h_tex), out_bytes, hipHostMallocMapped));
+            HIP_TRY(hipHostGetDevicePointer(reinterpret_cast<void**>(&s->d_tex), s->h_tex, 0));
+        }
+        std::memcpy(s->h_io, buf, in_bytes);
+        const int rc = process(b, s->d_io, glv::IN_F32_PLANAR, reinterpret_cast<float*>(s->d_tex), ops, 1, 0, nullptr);
+        HIP_TRY(hipStreamSynchronize(nullptr));
+        if (rc) return rc;
+        std::memcpy(texels, s->h_tex, out_bytes);
+        return GLV_OK;
+    }
+    if (!s->d_tex) HIP_TRY(hipMalloc(&s->d_tex, out_bytes));
+    HIP_TRY(hipMemcpyAsync(s->d_io, buf, in_bytes, hipMemcpyHostToDevice, nullptr));
+    if (int rc = process(b, s->d_io, glv::IN_F32_PLANAR, reinterpret_cast<float*>(s->d_tex), ops, 1, 0, nullptr)) return rc;
+    HIP_TRY(hipMemcpyAsync(texels, s->d_tex, out_bytes, hipMemcpyDeviceToHost, nullptr));
     HIP_TRY(hipStreamSynchronize(nullptr));
     return GLV_OK;
 }

@@ -74,6 +74,7 @@ def lib() -> C.CDLL:
         for name in ("glv_fft", "glv_gravity", "glv_average", "glv_wrange", "glv_smooth", "glv_magnitude", "glv_fft_gravity_average"):
             getattr(L, name).argtypes = [P, vp, vp]
         L.glv_texels_r16.argtypes = [P, vp, vp, vp]
+        L.glv_gl_texture.argtypes = [P, vp, vp, C.c_int, vp]
         L.glv_unpack_s16.argtypes = [C.c_int, vp, C.c_size_t, C.c_int, vp, vp]
         L.glv_batch_create.argtypes = [P, C.c_uint32, C.c_uint, C.c_int, C.POINTER(vp)]
         L.glv_batch_reset.argtypes = [vp]
@@ -354,6 +355,12 @@ class State:
         """the GL_R16 texels handle_audio's upload stores for buf (render.c:521-524); host buffers"""
         cp = self.params.c()
         _check(lib().glv_texels_r16(C.byref(cp), self._h, _ptr(buf), _ptr(texels)))
+
+    def gl_texture(self, buf, texels, smooth_pass: bool = True) -> None:
+        """handle_audio's accel_fft branch from the per-frame transform_fft to the texture the module samples (render.c:2176-2303);
+        host buffers: n float samples in (not modified), n GL_R16 texels out; the state must have gl_storage = 1"""
+        cp = self.params.c()
+        _check(lib().glv_gl_texture(C.byref(cp), self._h, _ptr(buf), 1 if smooth_pass else 0, _ptr(texels)))
 
     def reset(self) -> None:
         _check(lib().glv_state_reset(self._h))

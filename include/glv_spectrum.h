@@ -190,6 +190,15 @@ int glv_fft_gravity_average(const glv_params* p, glv_state* s, float* buf);
 /* the GL_R16 texels glTexImage1D(..., GL_R16, ..., GL_FLOAT, buf) stores for buf[0..n) (render.c:521-524):
  * texels[i] = round_to_nearest_even(clamp(buf[i], 0, 1) * 65535); buf is not modified */
 int glv_texels_r16(const glv_params* p, glv_state* s, const float* buf, uint16_t* texels);
+/* == the accel_fft branch of handle_audio, from the per-frame transform_fft to the texture the module samples (glava/render.c:2176-2303,
+ * GLava's shipped configuration: rc.glsl:211 setaccelfft true, smooth_parameters.glsl:78 setsmoothpass true): transform_fft of the n samples
+ * in buf (not modified), the GL_R16 upload (:521-524), GL_MAX store + gravity pass (:2199-2228), ring copy + average pass (:2230-2265; none
+ * when avg_frames == 1) and -- smooth_pass != 0 -- the pre-smoothing pass (:2277-2303, util/smooth_pass.frag) on 16-bit state: one launch
+ * (+ one for the pre-smoothing pass).  texels: the n GL_R16 texels the last pass's render target holds -- upload them with
+ * glTexImage1D(GL_TEXTURE_1D, 0, GL_R16, n, 0, GL_RED, GL_UNSIGNED_SHORT, texels).  The state must have been created with gl_storage = 1
+ * (normally avg_window_kind = 1; for the pre-smoothing pass bars = n and bar_phase = 0.5); it holds the gravity store and the ring like
+ * the reference's gr_store / gr.out textures do.  integration/render_hip.patch binds this into handle_audio. */
+int glv_gl_texture(const glv_params* p, glv_state* s, const float* buf, int smooth_pass, uint16_t* texels);
 
 /* == the unpack loop of the FIFO backend, glava/fifo.c:94-110 (and :67-79 when pcm == NULL):
  * `frames` interleaved stereo s16 frames -> planar f32.  Runs on the device (the bit-exactness

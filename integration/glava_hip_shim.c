@@ -11,6 +11,8 @@
  *     transform_average_hip  == transform_average  render.c:738-771
  *     transform_wrange_hip   == transform_wrange   render.c:773-781
  *     transform_fga_hip      == the fft,gravity,average triple of handle_audio (render.c:2149-2153), one launch
+ *     transform_gl_hip       == the accel_fft branch behind the transform list (render.c:2176-2303): FFT, upload, GL_MAX store,
+ *                               gravity / average / pre-smoothing passes -- GLava's shipped configuration -- as one call
  * plus glv_hip_release(slot), to be called from rd_destroy before it free()s the slot (render.c:2463-2469).
  *
  * integration/shim_harness.c compiles it against the unmodified reference sources (oracle/Makefile ->
@@ -25,7 +27,26 @@
 struct glv_box { unsigned long long magic; glv_state* st; };
 #define GLV_BOX_MAGIC 0x676c765f626f7821ULL   /* "glv_box!": tells a box from a slot the stock operators filled (float state) */
 
-static unsigned glv_hip_log_mode = 1;      /* glv_params.log_mode for new boxes (tests flip it) */
+/* Run-time knobs (environment, read once):
+ *   GLAVA_HIP_DEVICE=<ordinal>     the HIP device the states live on (default 0)
+ *   GLAVA_HIP_LOG_MODE=0|1|2       glv_params.log_mode: 1 (default) the hardware log2, <= 1.8e-7 relative on every input of the stage;
+ *                                  0 the bit-faithful fp64 table log -- the reference's floats, bit for bit; 2 the audit form
+ *   GLAVA_HIP_GL=0                 keep the accel path's GL passes on the GL (only the per-frame FFT runs on the MI355X)
+ *   GLAVA_HIP_SMOOTH_FACTOR=<f>    SMOOTH_FACTOR of the pre-smoothing pass when the user's smooth_parameters.glsl changes it
+ *                                  (a GLSL #define: struct gl_data does not carry it; default 0.025, smooth_parameters.glsl:72) */
+static unsigned glv_hip_log_mode = 1;      /* glv_params.log_mode for new boxes (GLAVA_HIP_LOG_MODE; tests flip it) */
+static int glv_hip_env_done = 0, glv_hip_dev = 0, glv_hip_gl = 1;
+static float glv_hip_smooth_factor = 0.025f;
+static void glv_hip_env(void) {
+    if (glv_hip_env_done) return;
+    glv_hip_env_done = 1;
+    const char* e;
+    if ((e = getenv("GLAVA_HIP_DEVICE")) && e[0]) glv_hip_dev = atoi(e);
+    if ((e = getenv("GLAVA_HIP_LOG_MODE")) && e[0] >= '0' && e[0] <= '2' && !e[1]) glv_hip_log_mode = (unsigned) (e[0] - '0');
+    if ((e = getenv("GLAVA_HIP_GL")) && e[0] == '0') glv_hip_gl = 0;
+    if ((e = getenv("GLAVA_HIP_SMOOTH_FACTOR")) && e[0]) glv_hip_smooth_factor = (float) atof(e);
+}
+static bool glv_hip_gl_on(void) { glv_hip_env(); return glv_hip_gl != 0; }
 
 static void glv_hip_fill(const struct gl_data* d, size_t sz, glv_params* p) {
     glv_params_default(p);
@@ -36,7 +57,15 @@ static void glv_hip_fill(const struct gl_data* d, size_t sz, glv_params* p) {
     p->ur           = d->ur;                  /* measured updates/s, render.c:2387 */
     p->avg_frames   = (uint32_t) d->avg_frames;
     p->avg_window   = d->avg_window;
+    glv_hip_env();
     p->log_mode     = glv_hip_log_mode;
+}
+/* the accel path's GL passes (render.c:2188-2303) with their GL_R16 storage: the shaders' Hamming window, newest frame first
+   (average_pass.frag:19-45), the pre-smoothing pass at the texel centres (util/smooth_pass.frag) */
+static void glv_hip_fill_gl(const struct gl_data* d, size_t sz, glv_params* p) {
+    glv_hip_fill(d, sz, p);
+    p->gl_storage = 1; p->avg_window_kind = 1;
+    p->bars = (uint32_t) sz; p->bar_phase = 0.5f; p->smooth_factor = glv_hip_smooth_factor;
 }
 
 /* Parameters outside what the library takes -- a window that is not a power of two in [256, 32768] (setbufsize is
@@ -54,7 +83,7 @@ static glv_state* glv_hip_slot(struct gl_data* d, void** udata, size_t sz) {
         b = calloc(1, sizeof(*b));
         if (!b) { fprintf(stderr, "glv: out of memory\n"); glava_abort(); }
         b->magic = GLV_BOX_MAGIC;
-        if (glv_state_create(&p, /*device*/ 0, &b->st) != GLV_OK) {
+        if (glv_state_create(&p, glv_hip_dev, &b->st) != GLV_OK) {
             fprintf(stderr, "glv: %s\n", glv_last_error());
             glava_abort();                     /* the reference's error convention (glava.h:17) */
         }
@@ -76,6 +105,24 @@ GLV_HIP_OPERATOR(transform_gravity_hip, glv_gravity)
 GLV_HIP_OPERATOR(transform_average_hip, glv_average)
 GLV_HIP_OPERATOR(transform_wrange_hip,  glv_wrange)
 GLV_HIP_OPERATOR(transform_fga_hip,     glv_fft_gravity_average)
+
+/* The whole accel path of handle_audio behind the transform list (render.c:2176-2303: per-frame transform_fft, GL_R16 upload, GL_MAX
+   store + gravity pass, ring + average pass, pre-smoothing pass) as one call: buf holds the bind's n samples (left as they are), *texels
+   (malloc'd here, free()d by rd_destroy) receives the n GL_R16 texels of the texture the module samples.  The state slot holds the gravity
+   store and the ring, as the reference's gr_store / gr.out textures do. */
+void transform_gl_hip(struct gl_data* d, void** udata, unsigned short** texels, float* buf, size_t sz, bool smooth_pass) {
+    struct glv_box* b = *udata;
+    glv_params p; glv_hip_fill_gl(d, sz, &p);
+    if (!b) {
+        b = calloc(1, sizeof(*b));
+        if (!b) { fprintf(stderr, "glv: out of memory\n"); glava_abort(); }
+        b->magic = GLV_BOX_MAGIC;
+        if (glv_state_create(&p, glv_hip_dev, &b->st) != GLV_OK) { fprintf(stderr, "glv: %s\n", glv_last_error()); glava_abort(); }
+        *udata = b;
+    }
+    if (!*texels && !(*texels = calloc(sz, sizeof(unsigned short)))) { fprintf(stderr, "glv: out of memory\n"); glava_abort(); }
+    if (glv_gl_texture(&p, b->st, buf, smooth_pass ? 1 : 0, *texels) != GLV_OK) { fprintf(stderr, "glv: %s\n", glv_last_error()); glava_abort(); }
+}
 
 /* rd_destroy hook: release the device state of a *_hip slot; the box itself is free()d by rd_destroy.  Slots that the
    stock operators filled (parameters the library does not take fall back to them) hold the reference's own float state --

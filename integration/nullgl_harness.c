@@ -27,7 +27,7 @@ bool xwin_should_render(struct gl_wcb* a, void* b) { (void) a; (void) b; return 
 void xwin_wait_for_wm(void) {}
 
 /* ---- a GL that does nothing ------------------------------------------------------------------------------------ */
-typedef struct { int unit; size_t width; float* data; } ng_upload;
+typedef struct { int unit; size_t width; float* data; unsigned short* texels; } ng_upload;      /* data: a GL_FLOAT upload; texels: a GL_UNSIGNED_SHORT one */
 static ng_upload ng_log[64];
 static size_t ng_n = 0;
 static int ng_unit = 0;
@@ -42,11 +42,16 @@ static void ng_ActiveTexture(GLenum t) { ng_unit = (int) (t - GL_TEXTURE0); }
 static void ng_GenObjects(GLsizei n, GLuint* ids) { for (GLsizei i = 0; i < n; ++i) ids[i] = ++ng_ids; }
 static void ng_TexImage1D(GLenum target, GLint level, GLint ifmt, GLsizei w, GLint border, GLenum fmt, GLenum type, const void* data) {
     (void) target; (void) level; (void) border; (void) fmt;
-    if (!data || ifmt != GL_R16 || type != GL_FLOAT || ng_n >= sizeof(ng_log) / sizeof(ng_log[0])) return;
+    if (!data || ifmt != GL_R16 || (type != GL_FLOAT && type != GL_UNSIGNED_SHORT) || ng_n >= sizeof(ng_log) / sizeof(ng_log[0])) return;
     ng_upload* u = &ng_log[ng_n++];
-    u->unit = ng_unit; u->width = (size_t) w;
-    u->data = malloc(sizeof(float) * (size_t) w);
-    memcpy(u->data, data, sizeof(float) * (size_t) w);
+    u->unit = ng_unit; u->width = (size_t) w; u->data = NULL; u->texels = NULL;
+    if (type == GL_FLOAT) {
+        u->data = malloc(sizeof(float) * (size_t) w);
+        memcpy(u->data, data, sizeof(float) * (size_t) w);
+    } else {                                    /* the patched accel path: the finished GL_R16 texels of the MI355X chain */
+        u->texels = malloc(sizeof(unsigned short) * (size_t) w);
+        memcpy(u->texels, data, sizeof(unsigned short) * (size_t) w);
+    }
 }
 static void* ng_loader(const char* name) {
     if (!strcmp(name, "glGetString")) return (void*) ng_GetString;
@@ -85,6 +90,8 @@ typedef struct {
     unsigned avg_frames; int avg_window;
     float fft_scale, fft_cutoff, gravity_step, ur, fr;
     unsigned hip_log_mode;      /* patched build only: glv_params.log_mode of the *_hip operators */
+    int smooth_pass;            /* setsmoothpass (render.c:2277) */
+    int hip_gl;                 /* patched build only: the accel path's GL passes on the MI355X too (GLAVA_HIP_GL) */
 } nullgl_cfg;
 
 typedef struct { struct glava_renderer* r; size_t isz; } nullgl;
@@ -113,7 +120,9 @@ void* nullgl_create(const nullgl_cfg* c) {
         loaded = true;
     }
 #ifdef GLV_NULLGL_HIP
+    glv_hip_env();
     glv_hip_log_mode = c->hip_log_mode;
+    glv_hip_gl = c->hip_gl;
 #endif
     nullgl* h = calloc(1, sizeof(*h));
     struct glava_renderer* r = calloc(1, sizeof(*r));
@@ -124,7 +133,7 @@ void* nullgl_create(const nullgl_cfg* c) {
     gl->bufscale = c->bufscale ? c->bufscale : 1; gl->interpolate = c->interpolate != 0; gl->accel_fft = c->accel_fft != 0;
     gl->avg_frames = c->avg_frames; gl->avg_window = c->avg_window != 0;
     gl->fft_scale = c->fft_scale; gl->fft_cutoff = c->fft_cutoff; gl->gravity_step = c->gravity_step;
-    gl->ur = c->ur; gl->fr = c->fr;
+    gl->ur = c->ur; gl->fr = c->fr; gl->smooth_pass = c->smooth_pass != 0;
     gl->audio_tex_l = 11; gl->audio_tex_r = 12;
     gl->av_utex = calloc(c->avg_frames ? c->avg_frames : 1, sizeof(GLuint));   /* uniform locations of the averaging pass (render.c:1655-1660) */
     gl->stages_sz = 1;
@@ -158,8 +167,26 @@ int nullgl_update(void* hv, float* lb, float* rb, size_t bsz, int modified, floa
     *up_n = 0;
     for (size_t i = 0; i < ng_n; ++i) {
         float* dst = ng_log[i].unit == 1 ? up_l : ng_log[i].unit == 2 ? up_r : NULL;
-        if (dst) { memcpy(dst, ng_log[i].data, sizeof(float) * ng_log[i].width); *up_n = ng_log[i].width; ++got; }
-        free(ng_log[i].data);
+        if (dst && ng_log[i].data) { memcpy(dst, ng_log[i].data, sizeof(float) * ng_log[i].width); *up_n = ng_log[i].width; ++got; }
+        free(ng_log[i].data); free(ng_log[i].texels);
+    }
+    ng_n = 0;
+    return got;
+}
+/* the same for the patched accel path with the GL passes on the MI355X: tex_l / tex_r receive the GL_R16 texels handle_audio uploaded
+ * (GL_UNSIGNED_SHORT) to the left / right audio texture -- the texture the module samples; returns how many such uploads the update made
+ * (0 on a frame without new audio: the textures keep the last result), *float_uploads the GL_FLOAT uploads it made besides (none) */
+int nullgl_update_texels(void* hv, float* lb, float* rb, size_t bsz, int modified, unsigned short* tex_l, unsigned short* tex_r, int* float_uploads) {
+    nullgl* h = hv;
+    ng_n = 0;
+    if (!rd_update(h->r, lb, rb, bsz, modified != 0)) return -1;
+    int got = 0;
+    *float_uploads = 0;
+    for (size_t i = 0; i < ng_n; ++i) {
+        unsigned short* dst = ng_log[i].unit == 1 ? tex_l : ng_log[i].unit == 2 ? tex_r : NULL;
+        if (dst && ng_log[i].texels) { memcpy(dst, ng_log[i].texels, sizeof(unsigned short) * ng_log[i].width); ++got; }
+        if (ng_log[i].data) ++*float_uploads;
+        free(ng_log[i].data); free(ng_log[i].texels);
     }
     ng_n = 0;
     return got;

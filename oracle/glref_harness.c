@@ -21,7 +21,13 @@
 #include <dlfcn.h>
 #include <GL/internal/dri_interface.h>
 
-#include "/root/reference/glava/render.c"
+/* GLV_RENDER_C: the untouched reference (default), or the copy oracle/Makefile produces by applying integration/render_hip.patch to it
+ * (-> oracle/_ref/libglvglref_hip.so, linked against the product library: the reference host WITH the MI355X binding, over the same
+ * software GL -- tests/test_gl_reference.py compares the texture its modules sample with the unpatched run's) */
+#ifndef GLV_RENDER_C
+#define GLV_RENDER_C "/root/reference/glava/render.c"
+#endif
+#include GLV_RENDER_C
 
 /* ---- symbols rd_new()/rd_update() reference from the X11 window code ------------------------------------------------ */
 void xwin_assign_icon_bmp(struct gl_wcb* a, void* b, const char* c) { (void) a; (void) b; (void) c; }
@@ -158,3 +164,8 @@ int glref_update(void* h, float* lb, float* rb, size_t bsz, int modified, uint16
 }
 
 void glref_destroy(void* h) { rd_destroy((struct glava_renderer*) h); }
+#ifdef GLV_GLREF_HIP
+/* patched build: the accel path's GL passes on the MI355X (GLAVA_HIP_GL) or on the GL, and the log mode of the operators */
+void glref_hip(int gl_passes_on_hip, unsigned log_mode) { glv_hip_env(); glv_hip_gl = gl_passes_on_hip; glv_hip_log_mode = log_mode; }
+volatile int glv_audio_publishes_spectra = 0;
+#endif

@@ -66,5 +66,13 @@ def glvlib():
     """The product library; built in-tree if missing (hipcc cross-compiles without a GPU)."""
     from glava_amd import build as B
     B.build()
+    # torch ships its own HIP runtime: it must be the first one the process initialises -- a harness library that pulls in the
+    # system's libamdhip64 first (oracle/_ref/libglvnullgl_hip.so) leaves torch with "No HIP GPUs are available"
+    try:
+        import torch
+        if torch.cuda.is_available():
+            torch.cuda.init()
+    except ImportError:
+        pass
     from glava_amd import spectrum
     return spectrum

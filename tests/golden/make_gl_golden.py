@@ -25,7 +25,9 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 from oracle_lib import lcg_pcm_fast  # noqa: E402
 
 SO = os.path.join(ROOT, "oracle", "_ref", "libglvglref.so")
-SHADERS = "/root/reference/shaders/glava"
+# the installed shader tree: the reference's, or (GPU box: no /root/reference) the files of the bars module oracle/Makefile put under oracle/_ref/shaders
+SHADERS = os.environ.get("GLV_SHADERS") or ("/root/reference/shaders/glava" if os.path.exists("/root/reference/shaders/glava/rc.glsl")
+                                             else os.path.join(ROOT, "oracle", "_ref", "shaders"))
 UR = 86.1328125
 
 # name, n, avg_frames, avg_window, frames, pcm shift (>> keeps magnitudes inside [0, 1] where GL_R16 does not saturate)
@@ -61,9 +63,13 @@ def config_dir(tmp, F, win):
     return d
 
 
-def run_case(n, F, win, pcm, tmp):
-    """one renderer per case; rd_new can be called repeatedly in one process (every call makes its own context)"""
-    L = C.CDLL(SO)
+def run_case(n, F, win, pcm, tmp, so=SO, hip=None):
+    """one renderer per case; rd_new can be called repeatedly in one process (every call makes its own context).
+    so / hip: the patched build (oracle/_ref/libglvglref_hip.so) with hip = (GL passes on the MI355X?, log_mode)"""
+    L = C.CDLL(so)
+    if hip is not None:
+        L.glref_hip.argtypes = [C.c_int, C.c_uint]
+        L.glref_hip(int(hip[0]), int(hip[1]))
     L.glref_create.restype = C.c_void_p
     L.glref_create.argtypes = [C.c_char_p, C.c_char_p, C.POINTER(C.c_char_p), C.c_float]
     L.glref_avg_frames.argtypes = [C.c_void_p]

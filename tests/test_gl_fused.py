@@ -382,3 +382,30 @@ def test_float_chain_with_bars_as_texels_after_creation_time_allocation(glvlib):
         assert (ot.cpu().numpy().view(np.uint16) == Oracle.texels_r16(of.cpu().numpy())).all(), u
     bt.close(); bf.close()
 
+
+
+def test_single_stream_gl_texture_is_the_batched_chain(glvlib):
+    """glv_gl_texture (the drop-in integration/render_hip.patch binds into handle_audio's accel path: host samples in, the module's GL_R16
+    texels out) against the batched GL-default chain on planar rows: the same texels, with and without the pre-smoothing pass, a silent
+    update in between, the samples left untouched."""
+    import torch
+    G = glvlib
+    n, F = 4096, 5
+    kw = dict(n=n, avg_frames=F, avg_window_kind=1, gl_storage=1, bars=n, bar_phase=0.5)
+    mask = G.OP_GRAVITY | G.OP_AVERAGE | G.OP_BARS
+    for smooth in (True, False):
+        st = [G.State(G.Params(**kw)) for _ in range(2)]
+        b = G.Batch(G.Params(**kw), 1, mask)
+        ops = G.OP_FFT | G.OP_GRAVITY | G.OP_AVERAGE | G.OP_R16 | (G.OP_BARS if smooth else 0)
+        out = torch.zeros((2, n), dtype=torch.int16, device="cuda")
+        for u in range(F + 2):
+            x = (lcg_pcm_fast(606 + u, 2 * n).reshape(n, 2).T.astype(np.float32) / np.float32(65535 * (1, 8)[u % 2])).copy()
+            if u == 3: x[:] = 0
+            b.process_f32(torch.from_numpy(x).cuda(), out, ops)
+            want = out.cpu().numpy().view(np.uint16)
+            for ch in range(2):
+                row = x[ch].copy(); tex = np.zeros(n, np.uint16)
+                st[ch].gl_texture(row, tex, smooth)
+                assert (row == x[ch]).all() and (tex == want[ch]).all(), (smooth, u, ch)
+        for s in st: s.close()
+        b.close()

@@ -208,3 +208,39 @@ def test_device_gl_passes_tie_aware(glvlib, name, n, F, win):
             # a one-step difference of `av` can move a tap of the smooth pass by one step too: one step, outside the fragile sets
             assert d[~frags[ch]].max() <= 1, ("end to end", f, ch, int(d[~frags[ch]].max()))
     for b in (up, passes, bb, full, chain): b.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,n,F,win", [("n1024_F5w", 1024, 5, True), ("n1024_F3w", 1024, 3, True), ("n4096_F5w", 4096, 5, True)])
+def test_patched_reference_over_llvmpipe_samples_the_unpatched_texture(glvlib, tmp_path, name, n, F, win):
+    """VERDICT r4 item 2, over a real GL: the reference's rd_new / rd_update WITH integration/render_hip.patch (oracle/_ref/libglvglref_hip.so:
+    the same harness, the patched render.c, the product library) run over Mesa llvmpipe with the shipped shaders, fed the frames the
+    committed goldens were recorded with by the UNPATCHED reference.  The texture the module's bind samples afterwards (read back with
+    glGetTexImage) must be the unpatched run's `sm` texture -- within one texel step, fragile tap sets excluded (the end-to-end standard
+    above) -- while the GL passes' own textures (gravity store, ring, average, smooth target) are never created: the work happened in the
+    one call on the MI355X.  With GLAVA_HIP_GL off the same build runs the passes on the GL from the HIP FFT's upload: its `sm` texture
+    meets the same standard.  Needs the GPU, Mesa's swrast driver and the shader files (oracle/_ref/shaders on the GPU box)."""
+    so = os.path.join(ROOT, "oracle", "_ref", "libglvglref_hip.so")
+    shaders = "/root/reference/shaders/glava" if os.path.exists("/root/reference/shaders/glava/rc.glsl") else os.path.join(ROOT, "oracle", "_ref", "shaders")
+    if not os.path.exists(so) or not os.path.exists(os.path.join(shaders, "rc.glsl")):
+        pytest.skip("oracle/_ref/libglvglref_hip.so / the shader files are not there (built where /root/reference and Mesa are)")
+    if not os.path.exists(os.environ.get("GLREF_SWRAST_DRI", "/usr/lib/x86_64-linux-gnu/dri/swrast_dri.so")):
+        pytest.skip("no Mesa swrast_dri.so on this box")
+    import subprocess, sys
+    pcm, tex = GOLD[name + "_pcm"], GOLD[name + "_tex"]
+    np.save(str(tmp_path / "pcm.npy"), pcm)
+    for on_hip in (1, 0):
+        # in a child process: rd_new prints deprecation warnings and glava_abort()s on errors
+        code = ("import sys, numpy as np, tempfile; sys.path.insert(0, %r); import make_gl_golden as M; pcm = np.load(%r); "
+                "out, v, r = M.run_case(%d, %d, %r, pcm, tempfile.mkdtemp(), so=%r, hip=(%d, 0)); np.save(%r, out)"
+                % (os.path.join(ROOT, "tests", "golden"), str(tmp_path / "pcm.npy"), n, F, bool(win), so, on_hip, str(tmp_path / "t.npy")))
+        subprocess.run([sys.executable, "-c", code], check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, env=dict(os.environ, GLV_SHADERS=shaders))
+        got = np.load(str(tmp_path / "t.npy"))
+        for f in range(pcm.shape[0]):
+            for ch in range(2):
+                _, _, frag = exact_smooth(tex[f, ch, AV], n)
+                final = got[f, ch, UP] if on_hip else got[f, ch, SM]            # on the MI355X the bind's own texture holds the result
+                d = np.abs(final.astype(np.int64) - tex[f, ch, SM].astype(np.int64))
+                assert d[~frag].max() <= 1, (name, on_hip, f, ch, int(d[~frag].max()))
+                if on_hip:
+                    assert not got[f, ch, GR].any() and not got[f, ch, SM].any()   # the GL passes' textures were never made

@@ -27,7 +27,8 @@ HIP_SO = os.path.join(ROOT, "oracle", "_ref", "libglvnullgl_hip.so")
 class Cfg(C.Structure):
     _fields_ = [("n", C.c_uint), ("bufscale", C.c_uint), ("interpolate", C.c_int), ("accel_fft", C.c_int),
                 ("avg_frames", C.c_uint), ("avg_window", C.c_int), ("fft_scale", C.c_float), ("fft_cutoff", C.c_float),
-                ("gravity_step", C.c_float), ("ur", C.c_float), ("fr", C.c_float), ("hip_log_mode", C.c_uint)]
+                ("gravity_step", C.c_float), ("ur", C.c_float), ("fr", C.c_float), ("hip_log_mode", C.c_uint),
+                ("smooth_pass", C.c_int), ("hip_gl", C.c_int)]
 
 
 def load(path):
@@ -46,12 +47,15 @@ def load(path):
     L.nullgl_interpolate_glsl.argtypes = [C.c_void_p]
     if hasattr(L, "nullgl_spectra_in"):
         L.nullgl_spectra_in.argtypes = [C.c_int]
+    if hasattr(L, "nullgl_update_texels"):
+        u16 = np.ctypeslib.ndpointer(np.uint16, flags="C_CONTIGUOUS")
+        L.nullgl_update_texels.argtypes = [C.c_void_p, fp, fp, C.c_size_t, C.c_int, u16, u16, C.POINTER(C.c_int)]
     return L
 
 
 def cfg(n, **kw):
     d = dict(n=n, bufscale=1, interpolate=0, accel_fft=0, avg_frames=5, avg_window=1, fft_scale=10.2, fft_cutoff=0.3,
-             gravity_step=4.2, ur=86.1328125, fr=144.0, hip_log_mode=1)
+             gravity_step=4.2, ur=86.1328125, fr=144.0, hip_log_mode=1, smooth_pass=0, hip_gl=0)
     d.update(kw)
     return Cfg(**d)
 
@@ -259,3 +263,46 @@ def test_handle_audio_fed_by_the_hipfifo_backend(glvlib, tmp_path, accel):
         assert (bits(got_b[f]) == bits(want[f])).all(), ("rings", f)
         # spectra mode: the backend's transform uses the default hardware log (<= 1e-5 per magnitude); gravity / average follow it
         assert np.allclose(got_c[f], want[f], rtol=1e-5, atol=2e-6), ("spectra", f)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,n,F,win", [("n1024_F5w", 1024, 5, True), ("n1024_F6u", 1024, 6, False), ("n1024_F3w", 1024, 3, True), ("n1024_F2w", 1024, 2, True),
+                                           ("n2048_F5w_loud", 2048, 5, True), ("n4096_F5w", 4096, 5, True)])
+def test_patched_accel_path_uploads_the_texture_the_reference_samples(glvlib, name, n, F, win):
+    """the shipped pipeline BOUND into the reference host.  With integration/render_hip.patch applied and
+    setaccelfft on, handle_audio makes ONE call per bind and update (integration/glava_hip_shim.c transform_gl_hip ->
+    glv_gl_texture: transform_fft, GL_R16 upload, GL_MAX store + gravity pass, ring + average pass, pre-smoothing pass on the MI355X),
+    skips render.c:2188-2303 and uploads the result as GL_UNSIGNED_SHORT texels into the bind's texture -- the one the module samples.
+    The frames are the ones tests/golden/gl_vectors.npz was recorded with, by the UNPATCHED reference over Mesa llvmpipe: the patched
+    host's texture must be the reference's `sm` texture (setsmoothpass on) / `av` texture (off) -- to the end-to-end standard of
+    tests/test_gl_reference.py: within one texel step (an upload texel that took the other neighbour at a tie travels on as at most
+    that step), fragile tap sets of the smooth pass excluded.  A frame without new audio uploads nothing: the texture keeps the last
+    result (render.c:2268-2272).  No GL_FLOAT upload happens at all on this path."""
+    from test_gl_reference import GOLD, UR, AV, SM, exact_smooth
+    H = load(HIP_SO)
+    if not hasattr(H, "nullgl_update_texels"):
+        pytest.skip("libglvnullgl_hip.so predates the texel uploads")
+    pcm, tex = GOLD[name + "_pcm"], GOLD[name + "_tex"]
+    for smooth in (1, 0):
+        h = H.nullgl_create(C.byref(cfg(n, accel_fft=1, avg_frames=F, avg_window=int(win), ur=UR, smooth_pass=smooth, hip_gl=1, hip_log_mode=0)))
+        assert h
+        tl, tr = np.zeros(n, np.uint16), np.zeros(n, np.uint16)
+        nf = C.c_int(0)
+        for f in range(pcm.shape[0]):
+            lb = (pcm[f, :, 0].astype(np.float32) / np.float32(65535)).copy(); rb = (pcm[f, :, 1].astype(np.float32) / np.float32(65535)).copy()
+            keep = lb.copy()
+            assert H.nullgl_update_texels(h, lb, rb, n, 1, tl, tr, C.byref(nf)) == 2 and nf.value == 0
+            assert (lb == keep).all()                                   # the samples are left as they are
+            for ch, got in enumerate((tl, tr)):
+                want = tex[f, ch, SM if smooth else AV].astype(np.int64)
+                d = np.abs(got.astype(np.int64) - want)
+                if smooth:
+                    _, _, frag = exact_smooth(tex[f, ch, AV], n)
+                    assert d[~frag].max() <= 1, (name, smooth, f, ch, int(d[~frag].max()))
+                else:
+                    assert d.max() <= 1, (name, smooth, f, ch, int(d.max()))
+            if f == 2:                                                  # a rendered frame without new audio
+                last = (tl.copy(), tr.copy())
+                assert H.nullgl_update_texels(h, lb, rb, n, 0, tl, tr, C.byref(nf)) == 0 and nf.value == 0
+                assert (tl == last[0]).all() and (tr == last[1]).all()
+        H.nullgl_destroy(h)

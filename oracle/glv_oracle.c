@@ -578,6 +578,36 @@ void glvo_bars_at_exact(const float* tex, size_t sz, double* exact, int* ntaps, 
     }
 }
 
+/* One bar of smooth_audio() in float64 like glvo_bars_at_exact, with the loop's float bounds MOVED by dmin / dmax units in the last place
+ * (nextafterf steps): the tap set another implementation of scale_audio() -- its log() a few ulps off -- would walk.  The loop itself
+ * (s = smin; s <= smax; s += 1.0F, tap round(s)) is the shader's, in float: which taps exist and which bins they hit follows from the
+ * moved bounds exactly as it would in that implementation.  half_even: GLSL leaves the direction round() takes at an exact .5 to the
+ * implementation (GLSL 4.60 8.3); C's roundf goes away from zero, Mesa's llvmpipe to even -- and a tap position CAN be an exact .5
+ * (n = 4096, bar 2848: 473.49997 + 39 rounds to 512.5 in float).  tests/test_gl_reference.py uses it to make the comparison TAP-SET-AWARE:
+ * where glvo_bars_at_exact flags a bar as fragile, a texel is accepted iff it is right for ONE of the admissible tap sets. */
+void glvo_bars_one_exact(const float* tex, size_t sz, size_t k, size_t bars, float smooth_factor, float phase, int dmin, int dmax, int half_even, double* exact, int* ntaps) {
+    float idx = phase == 0.0F ? (float) k / (float) bars : ((float) k + phase) / (float) bars;
+    float smin = glvo_scale_audio(glvo_clamp01(idx - smooth_factor)) * sz;
+    float smax = glvo_scale_audio(glvo_clamp01(idx + smooth_factor)) * sz;
+    for (int q = 0; q < abs(dmin); ++q) smin = nextafterf(smin, dmin > 0 ? INFINITY : -INFINITY);
+    for (int q = 0; q < abs(dmax); ++q) smax = nextafterf(smax, dmax > 0 ? INFINITY : -INFINITY);
+    if (smin < 0) smin = 0;
+    float m = (smax - smin) / 2.0F, rm = smin + m;
+    double avg = 0, weight = 0;
+    int cnt = 0;
+    for (float s = smin; s <= smax; s += 1.0F) {
+        double x = ((double) m - fabs((double) rm - (double) s)) / (double) m;
+        x = x < 0 ? 0 : (x > 1 ? 1 : x);
+        double w = 0.5 * sin(3.14159265358979323846 * x - 3.14159265358979323846 / 2) + 0.5;
+        long b = (long) (int) (half_even ? rintf(s) : roundf(s));
+        double tv = tex[b < (long) sz ? b : (long) sz - 1];
+        tv = tv > 0 ? (tv < 1 ? tv : 1) : 0;
+        avg += tv * w; weight += w; ++cnt;
+    }
+    *exact = weight > 0 ? avg / weight : 0.0;
+    *ntaps = cnt;
+}
+
 /* The library's s16 window product (glava_amd/csrc/glv_core.h apply_window_split): for every window position of size n the
  * float pair hi = (float) w, lo = (float) (w - hi), lo moved by +1, -1, +2, ... ulps until
  *     fmaf(x, hi, x * lo) == (float) ((double) x * w)        (render.c:794: float * double -> double -> float)

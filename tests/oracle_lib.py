@@ -109,6 +109,8 @@ class Oracle:
             _u16p = np.ctypeslib.ndpointer(np.uint16, flags="C_CONTIGUOUS")
             L.glvo_bars_int_at.argtypes = [_u16p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_size_t, C.c_float, C.c_float]
             L.glvo_bars_int_at.restype = C.c_int
+            L.glvo_bars_one_exact.argtypes = [_f32p, C.c_size_t, C.c_size_t, C.c_size_t, C.c_float, C.c_float, C.c_int, C.c_int, C.c_int,
+                                              C.POINTER(C.c_double), C.POINTER(C.c_int)]
             L.glvo_texels_r16.argtypes = [_f32p, C.c_size_t, np.ctypeslib.ndpointer(np.uint16, flags="C_CONTIGUOUS")]
             L.glvo_bars_at_exact.argtypes = [_f32p, C.c_size_t, np.ctypeslib.ndpointer(np.float64, flags="C_CONTIGUOUS"),
                                              np.ctypeslib.ndpointer(np.int32, flags="C_CONTIGUOUS"), np.ctypeslib.ndpointer(np.int32, flags="C_CONTIGUOUS"),
@@ -174,10 +176,31 @@ class Oracle:
         cls.lib().glvo_average(b, hist, C.byref(head), b.size, F, int(use_window))
 
 
+def log1_rel(n: int) -> float:
+    """bound of the default log mode's relative error on EVERY input of the magnitude stage (hardware v_log_f32; exhaustive:
+    tests/test_gpu_parity.py::test_magnitude_stage_every_float measures <= 1.8e-7, <= 6.3e-7 from n = 16384 up where the tilt factor is folded)"""
+    return 2e-7 if n < 16384 else 7e-7
+
+
+def chain_close(got, want, peak=None, n=4096, rel=1e-5):
+    """north_star's tolerance for the default log mode: 1e-5 RELATIVE on every value.  Behind gravity's subtraction (max(b, applied) - g can
+    land anywhere near zero) a relative bound on the difference means nothing; what is bounded there is its ABSOLUTE error: gravity's max()
+    is 1-Lipschitz and its subtraction exact up to one rounding, the average's weights are <= 1, so the error of a bin is at most the log's
+    relative error times the LARGEST magnitude that bin has held so far -- `peak` (per bin), log1_rel(n) * peak.  (Until round 4 a flat
+    atol = 2e-6 stood here)  peak None: a chain without gravity -- purely relative."""
+    tol = rel * np.abs(want).astype(np.float64)
+    if peak is not None:
+        tol = tol + log1_rel(n) * np.asarray(peak, np.float64)
+    d = np.abs(np.asarray(got, np.float64) - np.asarray(want, np.float64))
+    fin = np.isfinite(want)
+    return bool((d[fin] <= tol[fin]).all() and (np.asarray(got)[~fin] == np.asarray(want)[~fin]).all())
+
+
 class StreamOracle:
     """Stateful per-stream oracle: PCM frame in -> spectrum out, with gravity/average state.
 
-    Mirrors the order handle_audio applies the operators (render.c:2140-2156)."""
+    Mirrors the order handle_audio applies the operators (render.c:2140-2156).  With gravity it also keeps `peak`, the largest
+    magnitude every bin has held (chain_close's absolute term); close(got, want) applies the tolerance."""
 
     def __init__(self, n, channels=2, fft_scale=10.2, fft_cutoff=0.3, gravity_step=4.2,
                  ur=86.1328125, avg_frames=5, avg_window=True, gravity=True, average=True):
@@ -188,10 +211,19 @@ class StreamOracle:
         self.grav = np.zeros((2, n), np.float32) if gravity else None
         self.hist = np.zeros((2, avg_frames, n), np.float32) if average else None
         self.heads = (C.c_size_t * 2)(0, 0)
+        self.peak = np.zeros((2, n), np.float32) if gravity else None
+
+    def close(self, got, want, rel=1e-5) -> bool:
+        return chain_close(got, want, self.peak, self.n, rel)
 
     def frame(self, pcm: np.ndarray, want_raw=False):
         pcm = np.ascontiguousarray(pcm, dtype=np.int16).reshape(-1)
         assert pcm.size == 2 * self.n
+        if self.peak is not None:                            # the magnitudes that enter the chain (fft only, no state)
+            mag = np.empty((2, self.n), np.float32)
+            Oracle.lib().glvo_frame_s16(pcm, self.n, self.channels, self.fft_scale, self.fft_cutoff, mag, None, None, self.gravity_step, self.ur,
+                                        None, None, self.F, int(self.avg_window))
+            self.peak = np.maximum(self.peak, np.where(np.isfinite(mag), np.abs(mag), 0).astype(np.float32))
         out = np.empty((2, self.n), np.float32)
         raw = np.empty((2, self.n), np.float32) if want_raw else None
         Oracle.lib().glvo_frame_s16(

@@ -104,7 +104,7 @@ def test_config4_mixed_sizes_on_concurrent_streams(G, log_mode):
                 if log_mode == 0:
                     assert (bits(got) == bits(want)).all(), (n, int(sidx), u)
                 else:
-                    assert np.allclose(got, want, rtol=1e-5, atol=2e-6), (n, int(sidx), u)
+                    assert so.close(got, want), (n, int(sidx), u)
         for k in ("b_raw", "b_mag", "b_chain"):
             c[k].close()
 
@@ -140,7 +140,7 @@ def _same_value(got, want, exact):
     if not (got[inf] == want[inf]).all():
         return False
     fin = ok & ~inf
-    return bool(np.allclose(got[fin], want[fin], rtol=1e-5, atol=2e-6))
+    return bool(np.allclose(got[fin], want[fin], rtol=1e-5, atol=0.0))      # magnitudes only (no gravity in front): purely relative
 
 
 @pytest.mark.parametrize("n", [1024, 4096, 16384])
@@ -244,7 +244,7 @@ def test_gravity_output_is_the_state(G, n):
         got = o_same.cpu().numpy(); raw = o_raw.cpu().numpy()
         for s in range(streams):
             want, wraw = sos[s].frame(pcm[s * 2 * n:(s + 1) * 2 * n], want_raw=True)
-            assert np.allclose(got[2 * s:2 * s + 2], want, rtol=1e-5, atol=2e-6), (u, s)
+            assert sos[s].close(got[2 * s:2 * s + 2], want), (u, s)
             for c in range(2):                                      # gravity on the raw values: bit-exact state machine
                 row = np.ascontiguousarray(wraw[c]); Oracle.gravity(row, grav_raw[2 * s + c])
                 assert (bits(raw[2 * s + c]) == bits(row)).all(), (u, s, c)

@@ -17,7 +17,7 @@ import os
 import numpy as np
 import pytest
 
-from oracle_lib import Oracle, StreamOracle, lcg_pcm_fast
+from oracle_lib import Oracle, StreamOracle, chain_close, lcg_pcm_fast
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 REF_SO = os.path.join(ROOT, "oracle", "_ref", "libglvnullgl_ref.so")
@@ -208,6 +208,12 @@ def test_patched_handle_audio_uploads_what_the_reference_uploads(glvlib, accel, 
     modified = [True, True, False, True, False, False, True, True]
     base = dict(accel_fft=accel, interpolate=interp, bufscale=k, ur=30.0 if interp else 86.1328125, fr=120.0)
     want, wbuf = run(R, cfg(n, **base), frames, modified)
+    # chain_close's absolute term: behind gravity (CPU path) the largest magnitude a bin holds in any of the frames (the interpolating and
+    # decimating preludes mix frames and shorten them: the bound is taken over all frames, at the size the transforms see); on the accel path
+    # nothing is subtracted, but frames without new audio upload RE-transformed buffers (render.c:2176-2180) -- an FFT of magnitudes, whose
+    # small bins inherit the absolute error of the large ones: the row's largest value stands in for the peak there
+    mags = np.stack([[Oracle.transform_fft(np.ascontiguousarray(fr_[c].reshape(-1, k).mean(axis=1), dtype=np.float32)) for c in range(2)] for fr_ in frames])
+    peaks = [np.broadcast_to(np.abs(want[f]).max(), want[f].shape) if accel else np.broadcast_to(mags.max(axis=0), want[f].shape) for f in range(len(frames))]
     for log_mode in (0, 1):
         got, gbuf = run(H, cfg(n, hip_log_mode=log_mode, **base), frames, modified)
         for f in range(len(frames)):
@@ -215,7 +221,7 @@ def test_patched_handle_audio_uploads_what_the_reference_uploads(glvlib, accel, 
                 assert (bits(got[f]) == bits(want[f])).all(), (f, log_mode)
                 assert (bits(gbuf[f]) == bits(wbuf[f])).all(), (f, log_mode)
             else:
-                assert np.allclose(got[f], want[f], rtol=1e-5, atol=2e-6), (f, log_mode)
+                assert chain_close(got[f], want[f], peaks[f], n), (f, log_mode)
 
 
 @pytest.mark.gpu
@@ -262,7 +268,7 @@ def test_handle_audio_fed_by_the_hipfifo_backend(glvlib, tmp_path, accel):
     for f in range(len(want)):
         assert (bits(got_b[f]) == bits(want[f])).all(), ("rings", f)
         # spectra mode: the backend's transform uses the default hardware log (<= 1e-5 per magnitude); gravity / average follow it
-        assert np.allclose(got_c[f], want[f], rtol=1e-5, atol=2e-6), ("spectra", f)
+        assert chain_close(got_c[f], want[f], np.full(want[f].shape, 40.0, np.float32), n), ("spectra", f)      # (peak: no magnitude of n = 1024 exceeds log(2^11) / 3 * 10.9)
 
 
 @pytest.mark.gpu

@@ -222,16 +222,20 @@ def extra_configs(G, torch, device, a, peak_gbs):
     gl["bars_out"]["launches_per_step"] = b.last_launches()
     b.close()
     # ... and with the pre-smoothing pass of render.c:2277-2303 behind it (bars == n at the texel centres: the texture every stock
-    # module samples under setsmoothpass): 4096 bars do not fit the slack behind a row in LDS, so this is the fused GL kernel
-    # writing the `av` floats + the bars kernel; that pass is ~57 weighted taps per OUTPUT texel (233 K multiply-adds per row) --
-    # compute-bound, not memory-bound: reported as frames/s with its (meaningless here) byte fraction, on 1/16 of the streams
+    # module samples under setsmoothpass, GLava's shipped configuration): the fused GL kernel hands the `av` rows over as uint16
+    # texels and the pass runs in exact integer arithmetic on the i8 matrix cores (round 5) -- two launches.  roofline_frac is
+    # against the CHAIN's algorithmic bytes, 28 N per frame: PCM in, four ring slots read, one written, `sm` texels out (the
+    # intermediate `av` rows are not counted -- traffic the organisation adds, not the problem needs)
     s3 = max(s // 4, 1)
     qs = torch.empty((s3, 2, n), dtype=torch.int16, device="cuda")
+    smops = glops | G.OP_BARS | G.OP_R16
     b3 = G.Batch(G.Params(n=n, log_mode=a.log_mode, avg_frames=F, avg_window_kind=1, gl_storage=1, bars=n, bar_phase=0.5), s3,
                  G.OP_GRAVITY | G.OP_AVERAGE | G.OP_BARS, device=device)
-    dt, kms = run(b3, lambda: b3.process_s16(pcm, qs, glops | G.OP_BARS | G.OP_R16, st0))
-    gl["sm_out"] = entry(f"same chain + the pre-smoothing pass (bars = n = {n}, bar_phase 0.5) -> `sm` GL_R16 texels, {s3} streams, two launches; "
-                         f"the pass is ~58 weighted taps per output texel, a banded matrix product on the matrix cores (v_mfma_f32_32x32x2_f32 = the documented fma chain): bound by them and the output, not HBM", s3, b3.algorithmic_bytes(glops | G.OP_R16) + 12 * n * s3, dt, kms)
+    dt, kms = run(b3, lambda: b3.process_s16(pcm, qs, smops, st0))
+    assert b3.algorithmic_bytes(smops) == 28 * n * s3
+    gl["sm_out"] = entry(f"GLava's SHIPPED pipeline end to end: same chain + the pre-smoothing pass (bars = n = {n}, bar_phase 0.5) -> `sm` GL_R16 texels, {s3} streams, "
+                         f"two launches (glv_frame_kernel -> uint16 `av` rows -> glv_bars_rows_i8_kernel: exact integer weighted means on v_mfma_i32_32x32x32_i8); "
+                         f"bytes: the chain's 28 N per frame", s3, b3.algorithmic_bytes(smops), dt, kms)
     gl["sm_out"]["launches_per_step"] = b3.last_launches()
     b3.close(); del qs
     # the pre-smoothing kernel by itself on rows already in HBM: its roofline is the f32 matrix rate (157.3 TFLOP/s dense at nominal
@@ -255,11 +259,12 @@ def extra_configs(G, torch, device, a, peak_gbs):
         e1.record(); sync()
         ms = e0.elapsed_time(e1) / 20
         tf = 2.0 * taps * s3 * 2 / (ms * 1e-3) * 1e-12
-        gl["sm_out"]["pass_alone"] = {"note": f"glv_bars_rows_kernel alone, {s3 * 2} float rows in HBM -> floats: {taps} useful multiply-adds per row on v_mfma_f32_32x32x2_f32",
+        gl["sm_out"]["pass_alone_f32_rows"] = {"note": f"the FLOAT-row form of the pass (gl_storage 0; glv_batch_bars: one fma chain per bar on v_mfma_f32_32x32x2_f32), glv_bars_rows_kernel alone, "
+                                                       f"{s3 * 2} float rows in HBM -> floats: {taps} useful multiply-adds per row.  (The GL chain above runs the integer form on the i8 matrix cores.)",
                                       "ms": ms, "roofline": {"bound": "mfma", "achieved": tf, "peak": 157.3, "unit": "TFLOP/s", "frac": tf / 157.3}}
         b4.close(); del rows_in, qs4
     except Exception as ex:                                   # never fails the bench line
-        gl["sm_out"]["pass_alone"] = {"note": f"not measured: {ex}"}
+        gl["sm_out"]["pass_alone_f32_rows"] = {"note": f"not measured: {ex}"}
     # the pass-by-pass form of the same chain (the checker: f32 intermediates, three launches), for the record
     s2 = s // 4
     b2 = G.Batch(G.Params(n=n, log_mode=a.log_mode, avg_frames=F, avg_window_kind=1, gl_storage=2), s2, G.OP_GRAVITY | G.OP_AVERAGE, device=device)
@@ -272,6 +277,35 @@ def extra_configs(G, torch, device, a, peak_gbs):
     b2.close()
     out["gl_default"] = gl
     del q, qb
+    # --- SURVEY 8e's only failure mode, probed without an 8-GPU node: the C multi-GPU driver with EIGHT shards on eight
+    # host threads, all on this one device (host-gathered stats: GLV_MULTI_RCCL=0), against ONE shard of all the streams.  The device does the
+    # same work either way; if launching from eight host threads serialised on the host (a lock in the launch path), the eight-shard run
+    # would be slower by more than the smaller kernels explain.
+    try:
+        sh, msteps = 8, 20
+        pm = G.Params(n=n, log_mode=a.log_mode)
+        saved = os.environ.get("GLV_MULTI_RCCL")
+        os.environ["GLV_MULTI_RCCL"] = "0"
+        try:
+            res = {}
+            for nsh in (1, sh):
+                m = G.Multi(pm, s, G.OP_FFT, devices=[device] * nsh)
+                ins, outs = [], []
+                for i in range(nsh):
+                    _, lo_, cnt = m.shard(i)
+                    ins.append(pcm[lo_:lo_ + cnt]); outs.append(torch.empty((cnt, 2, n), dtype=torch.float32, device="cuda"))
+                m.run_s16(ins, outs, G.OP_FFT, warmup=20, steps=msteps)               # spin-up
+                st_, mx = m.run_s16(ins, outs, G.OP_FFT, warmup=3, steps=msteps)
+                res[nsh] = {"max_seconds": mx, "ms_per_step": mx / msteps * 1e3, "frames_per_s": sum(r["frames"] for r in st_) / mx}
+                m.close(); del ins, outs
+        finally:
+            if saved is None: os.environ.pop("GLV_MULTI_RCCL", None)
+            else: os.environ["GLV_MULTI_RCCL"] = saved
+        out["multi_host_threads"] = {"note": f"glv_multi_run_s16, N={n} x {s} streams on ONE device: 1 shard / 1 host thread against {sh} shards / {sh} host threads "
+                                             f"(each with its own batch and HIP stream; thread barrier + synchronize around {msteps} timed updates; stats gathered on the host)",
+                                     "one_shard": res[1], f"{sh}_shards": res[sh], "ratio": res[sh]["max_seconds"] / res[1]["max_seconds"]}
+    except Exception as ex:                                   # a probe, never a reason to lose the line
+        out["multi_host_threads"] = {"note": f"not measured: {ex}"}
     # --- f1: the FIFO ring mode (fifo.c:91-112 on the device): append 256 new frames per stream, transform the whole window
     nf = 256
     new = torch.randint(-32768, 32768, (s, nf, 2), dtype=torch.int16, device="cuda", generator=gen)
@@ -484,6 +518,16 @@ def main() -> None:
     frames_rank = streams * a.steps
     stats = gather_stats({"frames": frames_rank, "seconds": elapsed, "kernel_ms": kernel_ms,
                           "bytes": batch.algorithmic_bytes(ops) * launches}, world, force=dist_on)
+    # which device every rank actually drove (a scaling run on one node must show N distinct devices)
+    prop = torch.cuda.get_device_properties(device)
+    ident = {"rank": rank, "local_rank": local_rank, "device": device, "uuid": str(getattr(prop, "uuid", "")), "name": prop.name,
+             "pci_bus_id": getattr(prop, "pci_bus_id", None), "global_stream_first": lo}
+    idents = [ident]
+    if dist_on:
+        idents = [None] * world
+        dist.all_gather_object(idents, ident)
+    for srec, irec in zip(stats, idents):
+        srec.update({k: irec[k] for k in ("device", "uuid", "name", "pci_bus_id", "global_stream_first")})
 
     if rank == 0:
         total_frames = sum(s["frames"] for s in stats)
@@ -494,7 +538,8 @@ def main() -> None:
         line = {
             "metric": f"stereo {n}-pt window+FFT+magnitude frames/s (BASELINE configs[1]; the FFT+smooth chain is in smooth_chain)",
             "value": value, "unit": "frames/s", "log_mode": a.log_mode,
-            "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "n_gpus": world, "rccl_ranks": dist.get_world_size() if dist_on else 1, "distinct_devices": len({(r.get("uuid"), r.get("pci_bus_id"), r.get("device")) for r in stats}),
+            "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": elapsed / a.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{world} MI355X, {streams} batched stereo streams per GPU, N={n} "

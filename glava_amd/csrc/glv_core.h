@@ -21,18 +21,13 @@
 #include <math.h>
 #include <stdint.h>
 
-// Experiment macros (timing experiments that produce WRONG results -- no loads, no stores, no barriers -- and A/B knobs) exist
-// for tools/tune.py's A/B libraries only.  They are quarantined behind ONE switch: a translation unit that defines any of them
-// without -DGLV_TUNE_BUILD does not compile, and glava_amd/build.py's build() -- the product -- never passes either
-// (tests/test_abi.py checks the recorded command lines).
+// Tuning knobs (A/B builds of tools/tune.py and tools/rows_bench*.sh only) are quarantined behind ONE switch: a translation unit that defines
+// any of them without -DGLV_TUNE_BUILD does not compile, and glava_amd/build.py's build() -- the product -- never passes either
+// (tests/test_abi.py checks the recorded command lines).  (Round 5 removed the timing-experiment and rejected-variant switches of rounds
+// 1-4 from the kernels: profiles/r05/removed_experiment_scaffolding.diff has them.)
 #if !defined(GLV_TUNE_BUILD)
-#if defined(GLV_EXP_BARS_NOLOOP) || defined(GLV_EXP_BARS_NOWLOAD) || defined(GLV_EXP_NOBARRIER) || defined(GLV_EXP_NOCOMPUTE) || \
-    defined(GLV_EXP_NOLOAD) || defined(GLV_EXP_NOSPLIT) || defined(GLV_EXP_NOSTORE) || defined(GLV_EXP_NOTWLOAD) || \
-    defined(GLV_EXP_NOWINLOAD) || defined(GLV_EXP_OLDGROUPS) || defined(GLV_EXP_PHASETIME) || defined(GLV_EXP_STOREPRIO) || \
-    defined(GLV_EXP_SWAP16) || defined(GLV_EXP_WGBARRIER) || defined(GLV_EXP_SHUFFLE) || defined(GLV_EXP_STOREWAVE) || \
-    defined(GLV_EXP_ROWS_NOFILL) || defined(GLV_EXP_ROWS_NOFLUSH) || defined(GLV_EXP_ROWS_NOCOMPUTE) || defined(GLV_ROWS_NB) || defined(GLV_ROWS_RB) || defined(GLV_EXP_ROWS_NOWLOAD) || defined(GLV_EXP_ROWS_NOLDS) || defined(GLV_EXP_ROWS_NOBARRIER) || \
-    defined(GLV_R16_SOFT) || defined(GLV_BAR_BATCH_BIG) || defined(GLV_STATE_PAIR_MAX) || defined(GLV_GL16_BLK) || defined(GLV_GL16_DIV)
-#error "GLV_EXP_* / tuning macros are for tools/tune.py A/B builds: compile with -DGLV_TUNE_BUILD (glava_amd.build.build_variant does); the product never defines them"
+#if defined(GLV_ROWS_RB) || defined(GLV_BAR_BATCH_BIG) || defined(GLV_STATE_PAIR_MAX)
+#error "tuning macros are for tools/tune.py A/B builds: compile with -DGLV_TUNE_BUILD (glava_amd.build.build_variant does); the product never defines them"
 #endif
 #endif
 
@@ -328,7 +323,7 @@ GLV_HD uint32_t unorm16(float x) {
     return (uint32_t) __builtin_rint((double) c * 65535.0);
 }
 GLV_HD uint32_t pack_unorm16(float lo, float hi) {
-#if defined(__HIP_DEVICE_COMPILE__) && !defined(GLV_R16_SOFT)
+#if defined(__HIP_DEVICE_COMPILE__)
     typedef unsigned short glv_us2 __attribute__((ext_vector_type(2)));
     const glv_us2 p = __builtin_amdgcn_cvt_pknorm_u16(lo, hi);
     return __builtin_bit_cast(uint32_t, p);
@@ -354,18 +349,10 @@ GLV_HD float gravity(float b, float applied, float g) {
 // (~10 instructions: scale, reciprocal, three refinement steps, fix-up): with r = RN(1 / F), q0 = RN(x r), the remainder
 // rem = x - q0 F is exact in one fused multiply-add and q = RN(q0 + rem r) is the correctly rounded quotient (Markstein).  Checked
 // against the division for every float of that range and every F (tests/test_gl_storage.py through the host emulator).
-#if !defined(GLV_GL16_DIV)
-#define GLV_GL16_DIV 1
-#endif
 GLV_HD float div_frames(float x, float F, float rcpF) {
-#if GLV_GL16_DIV
     const float q0 = x * rcpF;
     const float rem = __builtin_fmaf(-q0, F, x);
     return __builtin_fmaf(rem, rcpF, q0);
-#else
-    (void) rcpF;
-    return x / F;
-#endif
 }
 
 // ---- GL_R16 state (glv_params.gl_storage == 1) ---------------------------------------------------------------------------

@@ -150,17 +150,12 @@ template <bool VEC = true>
 GLV_HD BarTaps bar_item_load(const float* tex_row, const float* tap_w, const BarItem& it, int sub) {
     BarTaps s;
     const uint32_t lane_byte = 4u * (uint32_t) kBarTaps * (uint32_t) sub;
-#if defined(GLV_EXP_BARS_NOWLOAD)     /* A/B experiment only (glava_amd.build build_variant): no weight loads, wrong bars */
-    for (int i = 0; i < kBarTaps; ++i) s.w[i] = 1.0f;
-    (void) tap_w;
-#else
 #pragma unroll
     for (int h = 0; h < kBarTaps / 4; ++h) {
         const BarW4 w4 = ld<BarW4>(tap_w, it.w_byte + lane_byte + 16u * (uint32_t) h);   // chunks start on 64-float boundaries
 #pragma unroll
         for (int i = 0; i < 4; ++i) s.w[4 * h + i] = w4.w[i];
     }
-#endif
     const uint32_t base = it.tex_byte + lane_byte;
     if constexpr (VEC) {
 #pragma unroll
@@ -535,11 +530,7 @@ struct Frame {
             uint32_t off;
             if constexpr (RING) off = ((uint32_t) (i * T + tid + (rot >> 1)) & (uint32_t) (NN - 1)) * 8u;
             else off = (uint32_t) tid * 8u + (uint32_t) (i * T) * 8u;
-#if defined(GLV_EXP_NOLOAD)    /* tools/tune.py experiment: fake PCM, no HBM read */
-            const u32x2 u = { off * 2654435761u, off * 40503u + 977u };
-#else
             const u32x2 u = ld<u32x2>(frame, off);
-#endif
             p.x[i] = u.x; p.y[i] = u.y;
         }
     }
@@ -597,17 +588,6 @@ struct Frame {
     }
     template <bool MONO, int WPRE = 0, bool SPLIT = false>
     GLV_HD static void unpack_window_impl(cf (&v)[E], const Raw& p, const void* win, int tid, uint32_t ch_shift, const d2* wpre = nullptr) {
-#if defined(GLV_EXP_NOWINLOAD)        /* tools/tune.py timing experiment: no window loads (wrong results) */
-        {
-            const double w0 = 0.5 + 1e-6 * (double) tid;
-#pragma unroll
-            for (int i = 0; i < E; ++i) {
-                v[i].x = apply_window(sample(p.x[i], ch_shift, MONO), w0 + 1e-3 * i);
-                v[i].y = apply_window(sample(p.y[i], ch_shift, MONO), w0 - 1e-3 * i);
-            }
-            return;
-        }
-#endif
         static_assert(WPRE % WCHUNK == 0 && WPRE <= E, "WPRE: whole chunks");
         d2 w[2][WCHUNK];
         if constexpr (WPRE < E) {
@@ -749,34 +729,15 @@ struct Frame {
     // in runs of two consecutive complex points: 16-byte ds_read_b128 / global_store_dwordx4 instead of 8-byte ones
     // (the spectrum store is issue-bound, not bandwidth-bound: half the instructions, half the time), and consecutive lanes
     // hold consecutive 16-byte pieces (whole cache lines per wave instruction).
-    // SWAP16 (last pass with ONE group per lane: N=1024 at E=8, N=8192 at E=16): a lane's outputs are then nn/R
-    // points apart, which would mean 8-byte stores.  Instead the lanes of a wave take the groups in the order
-    //     lane l = (b5 | h | m3..m0)  ->  group (b5 | m3..m0 | h)
-    // so that lanes l and l^16 own ADJACENT groups; after the magnitude stage one v_permlane16_swap_b32 per
-    // register pair (rows of 16 lanes trade registers: a 2x2 transpose) leaves every lane with two adjacent
-    // points per register pair and the spectrum leaves in 16-byte stores like at the other sizes.  A 32-lane
-    // half of the wave still covers 32 consecutive groups, so the LDS reads of the pass stay conflict free.
-    // Measured (profiles/r02/sweep_3.txt, same box, warmed clocks): N=8192 0.738-0.742 ms with the swap against 0.731-0.741 ms
-    // without, N=1024 0.610-0.613 against 0.613-0.617 -- the pass is not bound by store issue, so the production kernels keep
-    // the plain layout (8-byte stores for these two sizes) and the swap stays an opt-in experiment (-DGLV_EXP_SWAP16).
-#if defined(GLV_EXP_SWAP16)
-    static constexpr bool SWAP16 = P >= 2 && (E >> PL::rb(P - 1)) == 1 && (T % 64) == 0;
-#else
-    static constexpr bool SWAP16 = false;
-#endif
-    GLV_HD static constexpr int swap16_lane_group(int tid) {
-        return (tid & ~31) | ((tid & 15) << 1) | ((tid >> 4) & 1);
-    }
+    // (With ONE group per lane in the last pass -- N=1024 at E=8, N=8192 at E=16 -- the stores are 8-byte ones: trading registers between
+    // lanes 16 apart for 16-byte stores measured no gain, profiles/r02/sweep_3.txt; the variant is in profiles/r05/removed_experiment_scaffolding.diff.)
     template <int PASS>
     GLV_HD static constexpr int group_of(int tid, int gi) {
-        if (PASS == P - 1 && SWAP16) return swap16_lane_group(tid);
-#if !defined(GLV_EXP_OLDGROUPS)     /* tools/tune.py A/B only: the round-2 mapping (all NG groups of a lane adjacent) */
         // last pass: the lane's groups come in adjacent PAIRS (one 16-byte access per pair), pair p of lane t at 2*(p*T + t):
         // the 64 lanes of a store (or state load) instruction then cover 1 KiB CONTIGUOUS bytes.  With all NG groups of a lane
         // adjacent (round 2) a lane's 16-byte pieces were 8*NG bytes apart: at NG = 4 (N=16384) every wave store wrote
         // half of each 128-byte line it touched and a second instruction came back for the other half.
         if (PASS == P - 1 && PassInfo<PASS>::NG >= 2) return (gi >> 1) * (2 * T) + 2 * tid + (gi & 1);
-#endif
         return PASS == P - 1 ? tid * PassInfo<PASS>::NG + gi : gi * T + tid;
     }
 
@@ -786,7 +747,7 @@ struct Frame {
         using PI = PassInfo<PASS>;
         // last pass with paired groups (group_of): groups gi, gi + 1 are adjacent, so are their twiddles -- W[L][k0 + ...] and
         // W[L][k0 + 1 + ...], k0 even, every stage's table starting on an even entry (tw_offset) -- one 16-byte load per pair
-        constexpr bool PAIRED = PASS == P - 1 && PI::NG >= 2 && !SWAP16 && (BIAS % 2) == 0 && group_of<PASS>(0, 1) == group_of<PASS>(0, 0) + 1;
+        constexpr bool PAIRED = PASS == P - 1 && PI::NG >= 2 && (BIAS % 2) == 0 && group_of<PASS>(0, 1) == group_of<PASS>(0, 0) + 1;
 #pragma unroll
         for (int gi = 0; gi < PI::NG; gi += (PAIRED ? 2 : 1)) {
             const int G = group_of<PASS>(tid, gi);
@@ -795,16 +756,11 @@ struct Frame {
             for (int s = 0; s < PI::RB; ++s)
 #pragma unroll
                 for (int ks = 0; ks < (1 << s); ++ks) {
-#if defined(GLV_EXP_NOTWLOAD)     /* tools/tune.py timing experiment: no twiddle loads (wrong results) */
-                    const float f = (float) (k0 + ks) * 1e-4f; tw[gi * (PI::R - 1) + (1 << s) - 1 + ks] = cf{ 1.0f - f, f };
-                    if constexpr (PAIRED) tw[(gi + 1) * (PI::R - 1) + (1 << s) - 1 + ks] = cf{ 1.0f - f, -f };
-#else
                     if constexpr (PAIRED) {
                         const cf2 two = ld<cf2>(table, (uint32_t) (SubPass<PI::RB>::tw_index(PI::L0, k0, s, ks) - BIAS) * 8u);
                         tw[gi * (PI::R - 1) + (1 << s) - 1 + ks] = two.a;
                         tw[(gi + 1) * (PI::R - 1) + (1 << s) - 1 + ks] = two.b;
                     } else tw[gi * (PI::R - 1) + (1 << s) - 1 + ks] = table[SubPass<PI::RB>::tw_index(PI::L0, k0, s, ks) - BIAS];
-#endif
                 }
         }
     }
@@ -883,50 +839,9 @@ struct Frame {
         }
     }
 
-    // ---- the last exchange as wavefront shuffles (north_star: "wavefront shuffles for the small-stage butterflies"; A/B knob
-    // GLV_EXP_SHUFFLE, tools/tune.py builds only) -----------------------------------------------------------------------------
-    // Where ONE wave owns a row and a lane holds 8 points (N=1024: T = 64, E = 8, passes 3+3+3) the exchange between the last two
-    // passes is a pure 8 x 8 transpose between the register index and lane bits 3..5: slot r of lane (a, l) -- a = lane >> 3,
-    // l = lane & 7 -- holds element a*64 + bitrev(r)*8 + l, and the last pass wants element i*64 + lane in slot i, i.e. slot
-    // bitrev(h) of lane (i, l) in slot i of lane (h, l).  Three butterfly stages of 2 x 2 block swaps do it without LDS:
-    //   lane bit 5 <-> register bit 2   v_permlane32_swap_b32  (the two 32-lane halves trade registers)     8 instructions
-    //   lane bit 4 <-> register bit 1   v_permlane16_swap_b32  (rows of 16)                                8
-    //   lane bit 3 <-> register bit 0   v_mov_b32 ... row_ror:8 under a bank mask: no 8-lane swap exists,  24 (a copy and two
-    //                                   masked moves per dword pair)
-    // 40 vector-ALU instructions in place of 8 ds_write_b64 + 8 ds_read_b64 and their round trip.  Pure data movement: same bits.
-    static constexpr bool SHUFFLE_LAST = T == 64 && E == 8 && P >= 2 && PL::rb(P - 1) == 3 && PL::log_l0(P - 1) == LOG_NN - 3 && LOG_NN == 9;
-#if defined(__HIPCC__)
-    __device__ __forceinline__ static void shuffle_last(cf (&v)[E]) {
-#if defined(__HIP_DEVICE_COMPILE__)
-        float w[8][2];                                   // w[b] = the slot holding element ... + b*8 + l: slot bitrev(b)
-#pragma unroll
-        for (int b = 0; b < 8; ++b) { w[b][0] = v[bitrev(b, 3)].x; w[b][1] = v[bitrev(b, 3)].y; }
-        // register bit 2 <-> lane bit 5
-        asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %8\n\tv_permlane32_swap_b32 %1, %9\n\tv_permlane32_swap_b32 %2, %10\n\tv_permlane32_swap_b32 %3, %11\n\t"
-                     "v_permlane32_swap_b32 %4, %12\n\tv_permlane32_swap_b32 %5, %13\n\tv_permlane32_swap_b32 %6, %14\n\tv_permlane32_swap_b32 %7, %15\n\ts_nop 1"
-                     : "+v"(w[0][0]), "+v"(w[0][1]), "+v"(w[1][0]), "+v"(w[1][1]), "+v"(w[2][0]), "+v"(w[2][1]), "+v"(w[3][0]), "+v"(w[3][1]),
-                       "+v"(w[4][0]), "+v"(w[4][1]), "+v"(w[5][0]), "+v"(w[5][1]), "+v"(w[6][0]), "+v"(w[6][1]), "+v"(w[7][0]), "+v"(w[7][1]));
-        // register bit 1 <-> lane bit 4
-        asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %8\n\tv_permlane16_swap_b32 %1, %9\n\tv_permlane16_swap_b32 %2, %10\n\tv_permlane16_swap_b32 %3, %11\n\t"
-                     "v_permlane16_swap_b32 %4, %12\n\tv_permlane16_swap_b32 %5, %13\n\tv_permlane16_swap_b32 %6, %14\n\tv_permlane16_swap_b32 %7, %15\n\ts_nop 1"
-                     : "+v"(w[0][0]), "+v"(w[0][1]), "+v"(w[1][0]), "+v"(w[1][1]), "+v"(w[4][0]), "+v"(w[4][1]), "+v"(w[5][0]), "+v"(w[5][1]),
-                       "+v"(w[2][0]), "+v"(w[2][1]), "+v"(w[3][0]), "+v"(w[3][1]), "+v"(w[6][0]), "+v"(w[6][1]), "+v"(w[7][0]), "+v"(w[7][1]));
-        // register bit 0 <-> lane bit 3: lanes 0-7 of every row of 16 keep A and take the partner's A into B, lanes 8-15 take the
-        // partner's B into A and keep B (row_ror:8 reads lane ^ 8 inside a row; bank mask 0x3 = lanes 0-7, 0xC = lanes 8-15)
-#pragma unroll
-        for (int b = 0; b < 8; b += 2)
-#pragma unroll
-            for (int c = 0; c < 2; ++c) {
-                const int A = __builtin_bit_cast(int, w[b][c]), B = __builtin_bit_cast(int, w[b + 1][c]);
-                const int nB = __builtin_amdgcn_update_dpp(B, A, 0x128, 0xF, 0x3, false);
-                const int nA = __builtin_amdgcn_update_dpp(A, B, 0x128, 0xF, 0xC, false);
-                w[b][c] = __builtin_bit_cast(float, nA); w[b + 1][c] = __builtin_bit_cast(float, nB);
-            }
-#pragma unroll
-        for (int i = 0; i < 8; ++i) { v[i].x = w[i][0]; v[i].y = w[i][1]; }
-#endif
-    }
-#endif
+    // (The last exchange of N=1024 as wavefront shuffles -- v_permlane32_swap / v_permlane16_swap / DPP row_ror, 40 vector instructions in
+    // place of 16 LDS accesses -- gave the same bits and no speed-up: profiles/r04/shuffle_ab.txt; code in profiles/r05/removed_experiment_scaffolding.diff.
+    // Lane-crossing instructions stay where they pay: the DPP reductions of the bars, glv_frame.h group_sum.)
 
     // ---- split exchange (kernel knob NBUF = 0): the row crosses LDS one float component at a time -- all real parts
     // (write, barrier, read), then all imaginary parts -- so the exchange region is XREGION floats instead of XREGION complex
@@ -990,34 +905,13 @@ struct Frame {
     }
 
     // ---- output pairs ---------------------------------------------------------------------------------------------
-    // The epilogue leaves the row in 16-byte pieces: two memory-adjacent complex points per lane and store.  With two
-    // or more groups per lane in the last pass they are the same register slot of neighbouring groups; with one group
-    // per lane (SWAP16) the neighbouring group lives 16 lanes away and is fetched with v_permlane16_swap_b32.  The host
-    // emulator walks lanes one at a time and cannot swap: it stores the same values point by point instead.
-#if defined(__HIP_DEVICE_COMPILE__)
-    static constexpr bool SWAP_DEV = SWAP16;
-#else
-    static constexpr bool SWAP_DEV = false;
-#endif
-    static constexpr bool PAIRS = (E >> PL::rb(P - 1)) >= 2 || SWAP_DEV;
-#if defined(__HIP_DEVICE_COMPILE__)
-    // rows of 16 lanes trade registers: afterwards (a, b) hold (own a, neighbour's a) in the even rows and
-    // (neighbour's b, own b) in the odd rows -- in both cases the pair (lower group, upper group) of ONE output slot.
-    // gfx950 wants two wait states between a VALU write and the swap reading it, and after the swap.
-    __device__ __forceinline__ static void swap16(cf& a0, cf& b0, cf& a1, cf& b1) {
-        asm("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\tv_permlane16_swap_b32 %2, %3\n\t"
-            "v_permlane16_swap_b32 %4, %5\n\tv_permlane16_swap_b32 %6, %7\n\ts_nop 1"
-            : "+v"(a0.x), "+v"(b0.x), "+v"(a0.y), "+v"(b0.y), "+v"(a1.x), "+v"(b1.x), "+v"(a1.y), "+v"(b1.y));
-    }
-#endif
-    // byte offset (f32 rows) of the lane's pair p = 0 .. E/2-1; pairs (p, p+1) with p even are swapped together
+    // The epilogue leaves the row in 16-byte pieces where the last pass gives a lane two or more groups: the same register slot of
+    // neighbouring groups is two memory-adjacent complex points.
+    static constexpr bool PAIRS = (E >> PL::rb(P - 1)) >= 2;
+    // byte offset (f32 rows) of the lane's pair p = 0 .. E/2-1
     GLV_HD static uint32_t pair_offset(int tid, int p) {
         using PI = PassInfo<P - 1>;
-        if constexpr (SWAP16) {
-            const int h = (tid >> 4) & 1;
-            const int lane_q = group_of<P - 1>(tid, 0) - h + h * ((PI::R / 2) * PI::L0);   // odd rows own slot r + 1: bitrev(1) = R/2
-            return (uint32_t) (lane_q + bitrev(2 * p, PI::RB) * PI::L0) * 8u;
-        } else {
+        {
             const int idx = 2 * p;
             return (uint32_t) out_index<P - 1>(tid, idx % PI::NG, idx / PI::NG) * 8u;
         }
@@ -1045,7 +939,6 @@ struct Frame {
         // magnitude of register slot (gi, r): abs/log/tilt, or the raw value
         auto value = [&](int gi, int r) -> cf {
             cf val = v[gi * PI::R + r];
-#if !defined(GLV_EXP_NOCOMPUTE)
             if constexpr (EPI == EPI_MAG || EPI == EPI_MAG_STATE) {
                 const int q = out_index<P - 1>(tid, gi, r);     // = lane base + compile-time constant
                 const float y0 = __builtin_fabsf(val.x) + 1.0f, y1 = __builtin_fabsf(val.y) + 1.0f;   // render.c:843-844
@@ -1064,22 +957,7 @@ struct Frame {
                 val.x = log_third_nf<LOG_MODE, NONFINITE>(y0, logtab, log_tab_bits_of(LOG_NN)) * tl.x;
                 val.y = log_third_nf<LOG_MODE, NONFINITE>(y1, logtab, log_tab_bits_of(LOG_NN)) * tl.y;
             }
-#endif
             return val;
-        };
-        // the lane's pairs 2*p2 and 2*p2 + 1 (PAIRS only): values in memory order
-        auto two_pairs = [&](int p2, cf2& t0, cf2& t1) {
-            if constexpr (SWAP_DEV) {
-#if defined(__HIP_DEVICE_COMPILE__)
-                t0.a = value(0, 4 * p2);     t0.b = value(0, 4 * p2 + 1);
-                t1.a = value(0, 4 * p2 + 2); t1.b = value(0, 4 * p2 + 3);
-                swap16(t0.a, t0.b, t1.a, t1.b);
-#endif
-            } else {
-                const int i0 = 4 * p2, i1 = 4 * p2 + 2;
-                t0.a = value(i0 % PI::NG, i0 / PI::NG); t0.b = value(i0 % PI::NG + 1, i0 / PI::NG);
-                t1.a = value(i1 % PI::NG, i1 / PI::NG); t1.b = value(i1 % PI::NG + 1, i1 / PI::NG);
-            }
         };
         // one finished pair / point -> the output row (f32 or GL_R16 texels)
         auto store_pair = [&](uint32_t off, const cf2& two) {
@@ -1094,15 +972,7 @@ struct Frame {
         };
         if constexpr (!STATE) {
             // stateless: value -> store, pair by pair (nothing but the pair in flight)
-            if constexpr (SWAP_DEV) {
-#pragma unroll
-                for (int p2 = 0; p2 < E / 4; ++p2) {
-                    cf2 t0, t1;
-                    two_pairs(p2, t0, t1);
-                    store_pair(pair_offset(tid, 2 * p2), t0);
-                    store_pair(pair_offset(tid, 2 * p2 + 1), t1);
-                }
-            } else {
+            {
 #pragma unroll
                 for (int r = 0; r < PI::R; ++r) {
                     if constexpr (PI::NG >= 2) {
@@ -1111,15 +981,9 @@ struct Frame {
                             cf2 two;
                             two.a = value(gi, r);
                             two.b = value(gi + 1, r);
-#if defined(GLV_EXP_NOSTORE)   /* tools/tune.py experiment: keep 1 store in 16 (never in product builds) */
-                            if (r == 0 && gi == 0)
-#endif
                             store_pair((uint32_t) out_index<P - 1>(tid, gi, r) * 8u, two);
                         }
                     } else {
-#if defined(GLV_EXP_NOSTORE)
-                        if (r == 0)
-#endif
                         store_point((uint32_t) out_index<P - 1>(tid, 0, r) * 8u, value(0, r));
                     }
                 }
@@ -1131,25 +995,7 @@ struct Frame {
             if (!(a.ops & OP_AVERAGE) && (a.ops & OP_GRAVITY) && E <= 32) {
                 const float* gs = a.grav + row * (size_t) N;
                 float* gw = a.grav_w + row * (size_t) N;
-                if constexpr (SWAP_DEV) {
-                    cf2 st0[E / 2];
-#pragma unroll
-                    for (int p = 0; p < E / 2; ++p) st0[p] = ld<cf2>(gs, pair_offset(tid, p));
-#pragma unroll
-                    for (int p2 = 0; p2 < E / 4; ++p2) {
-                        cf2 t[2];
-                        two_pairs(p2, t[0], t[1]);
-#pragma unroll
-                        for (int k = 0; k < 2; ++k) {
-                            const int p = 2 * p2 + k;
-                            t[k].a.x = gravity(t[k].a.x, st0[p].a.x, a.g); t[k].a.y = gravity(t[k].a.y, st0[p].a.y, a.g);
-                            t[k].b.x = gravity(t[k].b.x, st0[p].b.x, a.g); t[k].b.y = gravity(t[k].b.y, st0[p].b.y, a.g);
-                            st<cf2>(gw, pair_offset(tid, p), t[k]);
-                            if (out_row != nullptr) store_pair(pair_offset(tid, p), t[k]);
-                        }
-                    }
-                    return;
-                }
+                
                 cf st0[E];
 #pragma unroll
                 for (int idx = 0; idx < E; ++idx)
@@ -1180,17 +1026,7 @@ struct Frame {
             for (int h0 = 0; h0 < E; h0 += BLK) {
                 cf val[BLK];
                 uint32_t off[BLK];
-                if constexpr (SWAP_DEV) {
-                    // memory order after the swap: pairs h0/2 .. of the lane
-#pragma unroll
-                    for (int j = 0; j < BLK; j += 4) {
-                        cf2 t0, t1;
-                        two_pairs((h0 + j) / 4, t0, t1);
-                        val[j] = t0.a; val[j + 1] = t0.b; val[j + 2] = t1.a; val[j + 3] = t1.b;
-                        off[j] = pair_offset(tid, (h0 + j) / 2);     off[j + 1] = off[j] + 8u;
-                        off[j + 2] = pair_offset(tid, (h0 + j) / 2 + 1); off[j + 3] = off[j + 2] + 8u;
-                    }
-                } else {
+                {
                     // enumeration order: r outer, gi inner => adjacent groups sit next to each other in val[]
 #pragma unroll
                     for (int j = 0; j < BLK; ++j) {
@@ -1222,16 +1058,11 @@ struct Frame {
     // Every stored value is a 16-bit integer by construction, so state and output move 2 bytes per value: with F = 5 a stereo
     // frame costs 4 N (PCM) + 16 N (four ring slots) + 4 N (newest slot) + 4 N (texels) = 28 N bytes where the pass-by-pass form
     // (f32 intermediates, three launches) moved ~80 N.
-#if defined(GLV_GL16_BLK)
-    static constexpr int GL16_BLK = (GLV_GL16_BLK) < E ? (GLV_GL16_BLK) : E;      // tools/tune.py A/B
-#else
     static constexpr int GL16_BLK = E <= 16 ? E : E / 2;       // points per block: the whole lane where the registers allow it
-#endif
     template <int LOG_MODE, int TILTREG, bool NONFINITE, bool TO_LDS>
     GLV_HD static void epilogue_gl16(const cf (&v)[E], float* out_row, size_t row, int tid, const FrameArgs& a,
                                      const LogEntry* logtab, const cf* tl_reg = nullptr) {
         using PI = PassInfo<P - 1>;
-        static_assert(!SWAP16, "the GL_R16 epilogue keeps the plain last-pass layout");
         constexpr bool PAIRED = PI::NG >= 2;
         float tilt_base = 0.0f;
         if constexpr (TILTREG == 3 && LOG_MODE == 1) {

@@ -63,52 +63,14 @@ namespace glv {
 //     adds 1 (ordered behind the wave's own LDS writes), then the wave polls until all T/64 waves of the
 //     slot arrived.  A workgroup-wide s_barrier here would keep the two slots in lockstep -- the same
 //     coupling that makes 4 slots per workgroup slower than 2.
-// GLV_EXP_WGBARRIER (tools/tune.py experiments) restores the workgroup-wide barrier everywhere.
 template <int T, int SLOTS>
 struct SlotSync {
-#if defined(GLV_EXP_WGBARRIER)
-    static constexpr bool WAVE_LOCAL = false, WORKGROUP = true;
-#else
     static constexpr bool WAVE_LOCAL = T <= 64 && (64 % T) == 0;
     static constexpr bool WORKGROUP = !WAVE_LOCAL && SLOTS == 1;
-#endif
     static constexpr bool COUNTER = !WAVE_LOCAL && !WORKGROUP;
     static constexpr uint32_t WAVES = T / 64 > 0 ? T / 64 : 1;
     uint32_t* counter = nullptr;     // LDS, one per slot (COUNTER mode)
     uint32_t expected = 0;
-    // GLV_EXP_STOREWAVE (tools/tune.py A/B builds): the handshake with the slot's store wave -- counter[1] counts the compute
-    // waves that have parked their part of a finished row in the slot's LDS region ("ready"), counter[2] the rows the store wave
-    // has taken out of it ("free").  Every wait is bounded: a protocol error ends in wrong results, never in a hung GPU.
-    uint32_t rows_done = 0;
-    bool dead = false;
-    static constexpr uint32_t SPIN_LIMIT = 1u << 22;
-    __device__ __forceinline__ void signal_ready() {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        if ((threadIdx.x & 63) == 0) __hip_atomic_fetch_add(counter + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        ++rows_done;
-    }
-    __device__ __forceinline__ void wait_free() {          // the store wave has read every row parked so far
-        uint32_t spins = 0;
-        if (rows_done == 0) return;                         // nothing parked yet (and kernels without store waves never park)
-        while (!dead && __hip_atomic_load(counter + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < rows_done) {
-            __builtin_amdgcn_s_sleep(1);
-            if (++spins == SPIN_LIMIT) dead = true;
-        }
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-    }
-    __device__ __forceinline__ void wait_ready(uint32_t rows) {   // store wave: all WAVES compute waves parked row number `rows`
-        uint32_t spins = 0;
-        while (!dead && __hip_atomic_load(counter + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < rows * WAVES) {
-            __builtin_amdgcn_s_sleep(1);
-            if (++spins == SPIN_LIMIT) dead = true;
-        }
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-    }
-    __device__ __forceinline__ void signal_free(uint32_t rows) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        if ((threadIdx.x & 63) == 0) __hip_atomic_store(counter + 2, rows, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    }
-
     __device__ __forceinline__ void sync() {
         if constexpr (WAVE_LOCAL) {
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -124,28 +86,6 @@ struct SlotSync {
         }
     }
 };
-
-// ---- poor man's phase trace (GLV_EXP_PHASETIME, tools/tune.py builds only) -----------------------------------
-// wave 0 of workgroup 0 adds the s_memtime cycles it spends in each phase of the row loop to g_phase[]:
-//   0 A (issue PCM loads)  1..P compute of pass 0..P-1  P+1.. exchange after pass 0.. (write, sync, gather, sync, read)
-//   14 W (vmcnt wait)  15 D (epilogue)  16 C (unpack + window)  17 rows
-#if defined(GLV_EXP_PHASETIME)
-__device__ unsigned long long g_phase[32];
-struct PhaseClock {
-    unsigned long long t;
-    bool on;
-    __device__ __forceinline__ void start() { on = blockIdx.x == 0 && threadIdx.x == 0; t = __builtin_readcyclecounter(); }
-    __device__ __forceinline__ void lap(int slot) {
-        const unsigned long long n = __builtin_readcyclecounter();
-        if (on) g_phase[slot] += n - t;
-        t = n;
-    }
-};
-#define GLV_PHASE(clk, slot) (clk).lap(slot)
-#else
-struct PhaseClock { __device__ __forceinline__ void start() {} };
-#define GLV_PHASE(clk, slot) ((void) 0)
-#endif
 
 // UNIT_SHORTCUT: pass 0 evaluates its (1, +0) twiddles as a +- b (s16 input only, glv_core.h SubPass::run)
 template <int LOG_NN, int LOG_E, int NBUF, int TWREG, bool UNIT_SHORTCUT = true>
@@ -205,23 +145,14 @@ struct Body {
     // so that the backend cannot pull the table loads of later passes (30 VGPRs each) up front.
     template <int PASS, typename SYNC>
     static __device__ __forceinline__ void run(cf (&v)[FR::E], cf* tw_all, const cf* __restrict__ table,
-                                               char* xslot, int tid, unsigned& xcount, const cf* lds_tw, SYNC& sy, PhaseClock& clk) {
+                                               char* xslot, int tid, unsigned& xcount, const cf* lds_tw, SYNC& sy) {
         // pass 0's twiddles are the same for every lane (k0 = 0); the kernel gathers them once, before
         // the row loop, into scalar registers (gather_uniform_tw0) -- a vector load here would sit in
         // front of every row's first butterfly AND, vmcnt being in-order, behind the PCM prefetch.
-#if defined(GLV_EXP_NOCOMPUTE)        /* tools/tune.py timing experiment only: memory traffic without the transform */
-        return;
-#endif
         FR::template compute<PASS, UNIT_SHORTCUT>(v, tw_ref<PASS>(tw_all));
-        GLV_PHASE(clk, 1 + PASS);
         if constexpr (PASS + 1 < P) {
             char* xb = xslot + (NBUF == 2 ? (size_t) (xcount & 1u) * FR::XREGION * sizeof(cf) : 0);
             GLV_SCHED_FENCE();
-#if defined(GLV_EXP_SHUFFLE)          /* tools/tune.py A/B: the last exchange as wavefront shuffles (glv_frame.h shuffle_last) */
-            if constexpr (PASS + 1 == P - 1 && FR::SHUFFLE_LAST) {
-                FR::shuffle_last(v);
-            } else
-#endif
             if constexpr (NBUF == 0) {
                 // split exchange: real parts, then imaginary parts, through the one half-size region
                 sy.sync();                                  // previous readers of the region are done
@@ -235,27 +166,16 @@ struct Body {
                 sy.sync();
                 FR::template exchange_read_half<PASS + 1, 1>(v, xb, tid);
             } else {
-#if defined(GLV_EXP_STOREWAVE)
-            if constexpr (PASS == 0) sy.wait_free();    // the store wave has taken the previous row out of the region
-#endif
-#if !defined(GLV_EXP_NOBARRIER)      /* tools/tune.py timing experiment only: wrong results without the barriers */
             if constexpr (NBUF == 1) sy.sync();         // previous readers of the region are done
-#endif
             FR::template exchange_write<PASS>(xb, v, tid);
             // the next pass's per-lane twiddles travel from L2 while the exchange settles
             gather_transient<PASS + 1>(tw_all, table, lds_tw, tid);
-#if !defined(GLV_EXP_NOBARRIER)
             sy.sync();
-#endif
             FR::template exchange_read<PASS + 1>(v, xb, tid);
             }
             GLV_SCHED_FENCE();
-#if defined(GLV_EXP_PHASETIME)
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#endif
-            GLV_PHASE(clk, 1 + P + PASS);
             ++xcount;
-            run<PASS + 1>(v, tw_all, table, xslot, tid, xcount, lds_tw, sy, clk);
+            run<PASS + 1>(v, tw_all, table, xslot, tid, xcount, lds_tw, sy);
         }
     }
 };
@@ -275,38 +195,16 @@ static __device__ __forceinline__ uint32_t maybe_scalar(uint32_t v) {
     else return v;
 }
 
-// GLV_EXP_STOREWAVE (tools/tune.py A/B builds only): store-wave specialisation.  vmcnt is per WAVE and counts
-// loads and stores on one in-order counter, so a table / PCM load a compute wave issues behind a row's stores waits for all of
-// them.  With this knob the compute waves of a slot park the finished row in the slot's LDS exchange region (idle between a
-// row's last exchange and the next row's first) and one extra wave per slot streams it to HBM: the compute waves never have a
-// store in flight.  Built for the stateless s16 pipeline (f32 and GL_R16 output) of configurations with at least two slots.
-// The catch is in the occupancy: registers are allocated per KERNEL, the store wave gets the compute waves' budget, so a CU
-// must have a free wave slot at that budget -- the production plans (210-250 VGPRs, exactly two waves per SIMD) have none.
-template <int LOG_NN, int LOG_E, int SLOTS, int IN_MODE, int PREFETCH, int STATEFUL>
-constexpr bool frame_store_waves() {
-#if defined(GLV_EXP_STOREWAVE)
-    return (IN_MODE == IN_S16_STEREO || IN_MODE == IN_S16_RING) && PREFETCH == 1 && (STATEFUL == 0 || STATEFUL == 3) && (Frame<LOG_NN, LOG_E>::T % 64) == 0 && SLOTS >= 2;
-#else
-    return false;
-#endif
-}
-template <int LOG_NN, int LOG_E, int SLOTS, int IN_MODE, int PREFETCH, int STATEFUL>
-constexpr int frame_threads() { return Frame<LOG_NN, LOG_E>::T * SLOTS + (frame_store_waves<LOG_NN, LOG_E, SLOTS, IN_MODE, PREFETCH, STATEFUL>() ? 64 * SLOTS : 0); }
-
 template <int LOG_NN, int IN_MODE, int LOG_MODE, int SLOTS, int NBUF, int TWREG, bool WINLDS, int OCC, int PREFETCH, int TILTREG,
           int LOG_E, int STATEFUL, int WPRE = 0>
-__global__ void __launch_bounds__((frame_threads<LOG_NN, LOG_E, SLOTS, IN_MODE, PREFETCH, STATEFUL>()), OCC)
+__global__ void __launch_bounds__((Frame<LOG_NN, LOG_E>::T * SLOTS), OCC)
 glv_frame_kernel(const FrameArgs a) {
     using FR = Frame<LOG_NN, LOG_E>;
     constexpr int E = FR::E;
     constexpr int T = FR::T, N = FR::N;
     constexpr bool RING = IN_MODE == IN_S16_RING;
     constexpr bool S16 = IN_MODE == IN_S16_STEREO || RING;
-#if defined(GLV_EXP_NOSPLIT)         /* A/B experiment: the fp64 window product for s16 samples too */
-    constexpr bool WSPLIT = false;
-#else
     constexpr bool WSPLIT = S16 && win_split_of(LOG_NN, STATEFUL);     // s16 samples: the window product without fp64 (glv_core.h apply_window_split)
-#endif
     // f32 rows may hold -0.0, Inf and NaN: no unit-twiddle shortcut, non-finite values through the bit-faithful log
     constexpr bool NF = !S16;
     using BD = Body<LOG_NN, LOG_E, NBUF, TWREG, S16>;
@@ -315,11 +213,9 @@ glv_frame_kernel(const FrameArgs a) {
     constexpr int NREG = NBUF == 0 ? 1 : NBUF;                                                         // regions per slot
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr bool SWAVE = frame_store_waves<LOG_NN, LOG_E, SLOTS, IN_MODE, PREFETCH, STATEFUL>();
-    constexpr int NCOMPUTE = T * SLOTS, NTHREADS = frame_threads<LOG_NN, LOG_E, SLOTS, IN_MODE, PREFETCH, STATEFUL>();
-    const bool store_wave = SWAVE && threadIdx.x >= (uint32_t) NCOMPUTE;          // wave-uniform: NCOMPUTE is a multiple of 64
-    const uint32_t slot = maybe_scalar<WAVE_SLOT>(store_wave ? (threadIdx.x - NCOMPUTE) / 64 : threadIdx.x / T);
-    const int tid = store_wave ? (int) (threadIdx.x & 63u) : (int) (threadIdx.x % T);
+    constexpr int NTHREADS = T * SLOTS;
+    const uint32_t slot = maybe_scalar<WAVE_SLOT>(threadIdx.x / T);
+    const int tid = (int) (threadIdx.x % T);
     char* xslot = smem + (size_t) slot * NREG * XBYTES;
 
     const void* gwin = WSPLIT ? a.win_split : static_cast<const void*>(a.win);     // 16 bytes per complex point either way
@@ -355,43 +251,11 @@ glv_frame_kernel(const FrameArgs a) {
     SlotSync<T, SLOTS> sy;
     if constexpr (SlotSync<T, SLOTS>::COUNTER) {
         uint32_t* ctr = reinterpret_cast<uint32_t*>(smem + frame_lds_bytes<LOG_NN, LOG_E, SLOTS, NBUF, WINLDS, TWREG>() - 16 * SLOTS) + 4 * slot;
-        if (tid == 0 && !store_wave) { ctr[0] = 0; ctr[1] = 0; ctr[2] = 0; }
+        if (tid == 0) { ctr[0] = 0; ctr[1] = 0; ctr[2] = 0; }
         __syncthreads();
         sy.counter = ctr;
     }
 
-    if constexpr (SWAVE) {
-        static_assert(SlotSync<T, SLOTS>::COUNTER, "store waves need the slot-scoped counter barrier (the workgroup barrier would include them)");
-        if (store_wave) {
-            // one wave per slot: take each finished row out of the slot's region (1 KiB per wave instruction) and stream it to HBM
-            constexpr bool R16OUT = STATEFUL == 3;
-            constexpr uint32_t ROWBYTES = R16OUT ? N * 2u : N * 4u, PIECES = ROWBYTES / 1024u;
-            const uint32_t nframes = a.units / 2, fstride = gridDim.x * SLOTS;
-            const uint32_t nfs = nframes == 0 ? 0 : (nframes - 1) / fstride + 1;
-            uint32_t k = 0;
-            for (uint32_t r = 0; r < 2 * nfs; ++r) {
-                const uint32_t m = r >> 1, ch = r & 1u;
-                if (blockIdx.x * SLOTS + m * fstride >= nframes) break;
-                const uint32_t fraw = blockIdx.x * SLOTS + m * fstride + slot;
-                const bool active = fraw < nframes;
-                const size_t row = (size_t) (active ? fraw : nframes - 1) * 2 + ch;
-                ++k;
-                sy.wait_ready(k);
-                cf2 piece[PIECES];
-#pragma unroll
-                for (uint32_t j = 0; j < PIECES; ++j) piece[j] = ld<cf2>(xslot, j * 1024u + (uint32_t) tid * 16u);
-                sy.signal_free(k);                          // (the release fence waits for the reads)
-                char* dst = reinterpret_cast<char*>(a.out) + row * (size_t) ROWBYTES;
-                if (active) {
-#pragma unroll
-                    for (uint32_t j = 0; j < PIECES; ++j) st<cf2>(dst, j * 1024u + (uint32_t) tid * 16u, piece[j]);
-                }
-            }
-            return;
-        }
-    }
-    PhaseClock clk;
-    clk.start();
     cf tw_all[BD::TW_TOTAL];
     BD::gather_uniform_tw0(tw_all, a.tw);
     if constexpr (FR::P > 1) BD::template gather_resident<1>(tw_all, a.tw, tid);
@@ -427,7 +291,7 @@ glv_frame_kernel(const FrameArgs a) {
     auto finish = [&](const cf (&v)[E], size_t row, int tid) {
         // a.out == nullptr (gravity without average only): the spectra ARE the gravity state
         // (render.c:733-734 stores the same value to both), so the second copy is not written
-        float* out_row = (FUSED_BARS || SWAVE) ? reinterpret_cast<float*>(xslot)
+        float* out_row = FUSED_BARS ? reinterpret_cast<float*>(xslot)
                                                : (HAS_STATE && a.out == nullptr ? nullptr : a.out + row * N);
         if constexpr (GL16) {
             float* o = FUSED_BARS ? reinterpret_cast<float*>(xslot)
@@ -441,7 +305,7 @@ glv_frame_kernel(const FrameArgs a) {
             if (raw_out) FR::template epilogue<LOG_MODE, EPI_RAW_STATE, 0, false, NF>(v, out_row, row, tid, a, logtab);
             else FR::template epilogue<LOG_MODE, EPI_MAG_STATE, TILTREG, false, NF>(v, out_row, row, tid, a, logtab, tilt_reg);
         } else if constexpr (STATEFUL == 3) {
-            float* out16 = SWAVE ? reinterpret_cast<float*>(xslot) : reinterpret_cast<float*>(reinterpret_cast<uint16_t*>(a.out) + row * N);
+            float* out16 = reinterpret_cast<float*>(reinterpret_cast<uint16_t*>(a.out) + row * N);
             if (raw_out) FR::template epilogue<LOG_MODE, EPI_RAW, 0, true, NF>(v, out16, row, tid, a, logtab);
             else FR::template epilogue<LOG_MODE, EPI_MAG, TILTREG, true, NF>(v, out16, row, tid, a, logtab, tilt_reg);
         } else {
@@ -479,11 +343,7 @@ glv_frame_kernel(const FrameArgs a) {
 #pragma unroll
                 for (int b = 0; b < BB; ++b) it[b] = items[(size_t) b * G];
                 float total = 0.0f;
-#if defined(GLV_EXP_BARS_NOLOOP)      /* A/B experiment only: the row goes to LDS, the barriers stay, no bar is summed */
-                for (uint32_t s0 = 0; s0 < 0u; s0 += BB) {
-#else
                 for (uint32_t s0 = 0; s0 < a.bar_nsteps; s0 += BB) {
-#endif
                     BarTaps tp[BB];
                     BarItem nx[BB];
                     // (taps read from LDS step by step, only the weights held for the batch, would let ten steps fit the
@@ -514,18 +374,8 @@ glv_frame_kernel(const FrameArgs a) {
                 }
             }
             // the next row's first exchange write is preceded by a barrier (NBUF == 1): the bars readers are safe
-        } else if constexpr (SWAVE) {
-            sy.sync();                                     // every reader of the row's last exchange is done: the region is ours
-            if (active) finish(v, row, tid);               // finished row -> LDS, natural order
-            sy.signal_ready();                             // the store wave takes it from here
         } else {
-#if defined(GLV_EXP_STOREPRIO)       /* tools/tune.py A/B: the epilogue (stores) at raised wave priority */
-            __builtin_amdgcn_s_setprio(GLV_EXP_STOREPRIO);
-#endif
             if (active) finish(v, row, tid);
-#if defined(GLV_EXP_STOREPRIO)
-            __builtin_amdgcn_s_setprio(0);
-#endif
         }
     };
     // row handled by this slot in the iteration that starts at `base` (idle slots clamp to the last
@@ -584,26 +434,17 @@ glv_frame_kernel(const FrameArgs a) {
             const uint32_t fraw = blockIdx.x * SLOTS + m * fstride + slot;
             const bool active = fraw < nframes;
             const uint32_t f = frame_of(m);
-            GLV_PHASE(clk, 18);                                                                  // loop overhead since C
             if (ch) FR::template load_pcm<RING>(raw, frame_ptr(frame_of(m + 1)), tid, a.rot);   // A
             GLV_SCHED_FENCE();
-            GLV_PHASE(clk, 0);
-            BD::template run<0>(v, tw_all, a.tw, xslot, tid, xcount, lds_tw, sy, clk);                            // B
+            BD::template run<0>(v, tw_all, a.tw, xslot, tid, xcount, lds_tw, sy);                            // B
             GLV_SCHED_FENCE();
             __builtin_amdgcn_s_waitcnt(0x0F70);                                                  // W
-            GLV_PHASE(clk, 14);
             // WPRE: the first window values of row r+1 are requested ahead of D's stores (glv_frame.h window_prefetch)
             typename FR::template WinPre<WPRE> wp;
             if constexpr (WPRE > 0) { FR::template window_prefetch<WPRE>(wp, win, tid); GLV_SCHED_FENCE(); }
             finish_row(v, (size_t) f * 2 + ch, tid, active);                                     // D
             GLV_SCHED_FENCE();
-            GLV_PHASE(clk, 15);
             FR::template unpack_window<WPRE, WSPLIT>(v, raw, win, tid, ch ^ 1u, a.mono != 0, wp.w);      // C
-#if defined(GLV_EXP_PHASETIME)
-            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-            if (clk.on) g_phase[17] += 1;
-#endif
-            GLV_PHASE(clk, 16);
         }
         return;
     }
@@ -631,7 +472,7 @@ glv_frame_kernel(const FrameArgs a) {
             const bool has_next = step + 1 < nsteps && nb < a.units;
             FR::load_f32_raw(raw, row_ptr(row_of(has_next ? nb : base)), tid);                   // A (unconditional)
             GLV_SCHED_FENCE();
-            BD::template run<0>(v, tw_all, a.tw, xslot, tid, xcount, lds_tw, sy, clk);                    // B
+            BD::template run<0>(v, tw_all, a.tw, xslot, tid, xcount, lds_tw, sy);                    // B
             GLV_SCHED_FENCE();
             __builtin_amdgcn_s_waitcnt(0x0F70);                                                  // W
             finish_row(v, (size_t) row, tid, active);                                            // D
@@ -673,7 +514,7 @@ glv_frame_kernel(const FrameArgs a) {
                 const uint32_t f = frame_of(m);
                 FR::template load_f32s_raw<RINGF>(raw, frame_ptr(frame_of(m + ch)), tid, ch ^ 1u, a.rot);   // A (unconditional)
                 GLV_SCHED_FENCE();
-                BD::template run<0>(v, tw_all, a.tw, xslot, tid, xcount, lds_tw, sy, clk);                // B
+                BD::template run<0>(v, tw_all, a.tw, xslot, tid, xcount, lds_tw, sy);                // B
                 GLV_SCHED_FENCE();
                 __builtin_amdgcn_s_waitcnt(0x0F70);                                              // W
                 finish_row(v, (size_t) f * 2 + ch, tid, active);                                 // D
@@ -708,7 +549,7 @@ glv_frame_kernel(const FrameArgs a) {
         } else {
             FR::load_f32_window(v, static_cast<const char*>(a.in) + (size_t) row * ((size_t) N * 4), win, tid);
         }
-        BD::template run<0>(v, tw_all, a.tw, xslot, tid, xcount, lds_tw, sy, clk);
+        BD::template run<0>(v, tw_all, a.tw, xslot, tid, xcount, lds_tw, sy);
         finish_row(v, (size_t) row, tid, active);
     }
 }
@@ -769,10 +610,8 @@ hipError_t launch_variant(const FrameArgs& a, int grid, hipStream_t st) {
     if (a.ops & (OP_GRAVITY | OP_AVERAGE))
         return launch(glv_frame_kernel<LOG_NN, IN_MODE, LOG_MODE, SLOTS, NBUF, TW_STATEFUL, WINLDS, OCC, PREFETCH, TILTREG, LOG_E, 1, WPRE_S>, done_state);
     if (a.ops & OP_R16)
-        return launch(glv_frame_kernel<LOG_NN, IN_MODE, LOG_MODE, SLOTS, NBUF, TWREG, WINLDS, OCC, PREFETCH, TILTREG, LOG_E, 3, WPRE>, done_r16,
-                      frame_threads<LOG_NN, LOG_E, SLOTS, IN_MODE, PREFETCH, 3>());
-    return launch(glv_frame_kernel<LOG_NN, IN_MODE, LOG_MODE, SLOTS, NBUF, TWREG, WINLDS, OCC, PREFETCH, TILTREG, LOG_E, 0, WPRE>, done_plain,
-                  frame_threads<LOG_NN, LOG_E, SLOTS, IN_MODE, PREFETCH, 0>());
+        return launch(glv_frame_kernel<LOG_NN, IN_MODE, LOG_MODE, SLOTS, NBUF, TWREG, WINLDS, OCC, PREFETCH, TILTREG, LOG_E, 3, WPRE>, done_r16);
+    return launch(glv_frame_kernel<LOG_NN, IN_MODE, LOG_MODE, SLOTS, NBUF, TWREG, WINLDS, OCC, PREFETCH, TILTREG, LOG_E, 0, WPRE>, done_plain);
 }
 
 }  // namespace glv

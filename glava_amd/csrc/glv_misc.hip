@@ -404,11 +404,7 @@ __global__ void __launch_bounds__(64 * kRowsWaves) glv_bars_rows_kernel(const fl
     extern __shared__ float rows_lds[];                 // [S][RB]: the ring
     static_assert(S % 8 == 0 && (RB == 64 || RB == 32), "a parked slot of four bins never straddles the ring's end; one or two MFMAs per step");
     constexpr uint32_t CPI = 64 / RB;                   // columns of four bins one fetch instruction covers (the lanes beyond RB rows take the next column)
-#if defined(GLV_ROWS_NB)                /* tools/rows_bench A/B builds */
-    constexpr int NB = GLV_ROWS_NB, PF = 8 * NB;
-#else
     constexpr int NB = 1, PF = 8 * NB;                  // steps of weights in flight: NB banks of 8 registers (tiles are whole banks: glv_tables.h kBarStepPad)
-#endif
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = (uint32_t) __builtin_amdgcn_readfirstlane((int) (threadIdx.x >> 6));
     const size_t row0 = (size_t) blockIdx.x * RB;
@@ -422,11 +418,7 @@ __global__ void __launch_bounds__(64 * kRowsWaves) glv_bars_rows_kernel(const fl
     // 4 bins of this lane's row (column `col` of four bins from bin0); clamped here, once per texel: [0, 1] like the GL_R16 texel the shader samples, NaN -> 0 (v_pk_mul_f32
     // x, 1.0 clamp -- the operation bar_item_lane_sum applies to every tap)
     auto fetch = [&](uint32_t bin) {
-#if defined(GLV_EXP_ROWS_NOFILL)        /* timing experiment (wrong results): no row loads */
-        return BarW4{{(float) bin, 0.5f, 0.25f, (float) lane}};
-#else
         return ld<BarW4>(src, bin * 4u);
-#endif
     };
     auto park = [&](const BarW4& v, uint32_t bin) {
         glv_f2 lo = {v.w[0], v.w[1]}, hi = {v.w[2], v.w[3]};
@@ -483,9 +475,6 @@ __global__ void __launch_bounds__(64 * kRowsWaves) glv_bars_rows_kernel(const fl
             for (uint32_t i = wave + 2u * kRowsWaves; i * CPI < nnew; i += kRowsWaves)
                 if (col_of(i) < nnew) park(fetch(filled_to + 4u * col_of(i)), filled_to + 4u * col_of(i));
         };
-#if defined(GLV_EXP_ROWS_NOCOMPUTE)
-        park_new();
-#else
         if (valid) {
             const uint32_t steps = (uint32_t) __builtin_amdgcn_readfirstlane((int) M.steps);        // a multiple of 8 (glv_tables.h kBarStepPad)
             uint32_t sb = (uint32_t) __builtin_amdgcn_readfirstlane((int) (M.origin % (uint32_t) S));   // ring slot of the step's even bin
@@ -506,18 +495,10 @@ __global__ void __launch_bounds__(64 * kRowsWaves) glv_bars_rows_kernel(const fl
                 constexpr int B = decltype(BC)::value;
 #pragma unroll
                 for (int u = 0; u < 8; ++u) {
-#if defined(GLV_EXP_ROWS_NOLDS)         /* timing experiment (wrong results): no texel reads */
-                    const float na = xa0 + 1.0f, nb = xb0 + 1.0f;
-#else
                     const float na = xlane[(size_t) sb * RB], nb = RB == 64 ? xlane[(size_t) sb * RB + 32] : 0.0f;      // (up to two steps past the tile's end are read and dropped)
-#endif
                     sb = sb + 2u == (uint32_t) S ? 0u : sb + 2u;
                     const float wcur = w[8 * B + u];
-#if defined(GLV_EXP_ROWS_NOWLOAD)       /* timing experiment (wrong results): no weight loads */
-                    w[8 * B + u] = wcur + 1.0f;
-#else
                     w[8 * B + u] = wp[(size_t) u * 64];
-#endif
                     acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(xa0, wcur, acc0, 0, 0, 0);
                     if constexpr (RB == 64) acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(xb0, wcur, acc1, 0, 0, 0);
                     xa0 = xa1; xb0 = xb1; xa1 = na; xb1 = nb;
@@ -555,11 +536,7 @@ __global__ void __launch_bounds__(64 * kRowsWaves) glv_bars_rows_kernel(const fl
             const size_t at0 = (row0 + 4u * (lane >> 5)) * (size_t) bars + kb;
             auto put = [&](int r, float v) {
                 const uint32_t jr = 32u * (uint32_t) (r / 16) + 8u * (uint32_t) ((r & 15) / 4) + 4u * (lane >> 5) + (uint32_t) (r & 3);
-#if defined(GLV_EXP_ROWS_NOFLUSH)       /* timing experiment (wrong results): one store in 32 */
-                if (jr < R && kb < bars && r == 0) {
-#else
                 if (jr < R && kb < bars) {
-#endif
                     const size_t at = at0 + (size_t) (32u * (uint32_t) (r / 16) + 8u * (uint32_t) ((r & 15) / 4) + (uint32_t) (r & 3)) * bars;
                     if (r16) reinterpret_cast<uint16_t*>(bars_out)[at] = (uint16_t) pack_unorm16(v, 0.0f);
                     else reinterpret_cast<float*>(bars_out)[at] = v;
@@ -580,11 +557,8 @@ __global__ void __launch_bounds__(64 * kRowsWaves) glv_bars_rows_kernel(const fl
         } else {
             park_new();
         }
-#endif
         filled_to = next_end > filled_to ? next_end : filled_to;
-#if !defined(GLV_EXP_ROWS_NOBARRIER)     /* timing experiment (wrong results): rounds not synchronised */
         __syncthreads();
-#endif
     }
 #endif
 }

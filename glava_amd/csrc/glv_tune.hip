@@ -57,14 +57,6 @@ const Variant kVariants[] = {
 }  // namespace glv
 
 extern "C" {
-#if defined(GLV_EXP_PHASETIME)
-// experiment builds: read (and clear) the phase cycle counters of glv_kernel_tmpl.h
-int glv_tune_phase_read(unsigned long long* out32) {
-    if (hipMemcpyFromSymbol(out32, HIP_SYMBOL(glv::g_phase), sizeof(unsigned long long) * 32) != hipSuccess) return -1;
-    unsigned long long zero[32] = {};
-    return hipMemcpyToSymbol(HIP_SYMBOL(glv::g_phase), zero, sizeof(zero)) == hipSuccess ? 0 : -2;
-}
-#endif
 int glv_tune_count(void) { return (int) (sizeof(glv::kVariants) / sizeof(glv::kVariants[0])); }
 const char* glv_tune_describe(int i) { return glv::kVariants[i].desc; }
 int glv_tune_slots(int i) { return glv::kVariants[i].slots; }

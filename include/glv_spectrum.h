@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define GLV_ABI_VERSION 4
+#define GLV_ABI_VERSION 5      /* 5 (round 5): + glv_gl_texture; GLV_OP_BARS over texel rows (gl_storage != 0, 256 bars or more) is the exact integer mean */
 
 /* status codes (0 = ok).  The reference has no error channel: it prints and calls
  * glava_abort() (glava/glava.h:17, glava/render.c passim); the in-tree shim maps any
@@ -56,7 +56,15 @@ enum {
                                    matrix cores compute: glava_amd/csrc/glv_frame.h "GLV_OP_BARS arithmetic";
                                    oracle/glv_oracle.c glvo_bars_chunked restates both) -- within 2e-4 relative of the
                                    shader's tap-by-tap loop, identical bits on every device path.  A bar whose weights
-                                   sum to 0 is 0 / 0 as in the shader */
+                                   sum to 0 is 0 / 0 as in the shader.
+                                   Inside the GL chains (gl_storage != 0, gravity / average in the chain: the rows the bars sample are
+                                   GL_R16 TEXELS, as in the reference's pre-smoothing pass, render.c:2277-2303) 256 bars or more are computed
+                                   EXACTLY (ABI 5): per bar the shader's float weights w_j become integers W_j = llrint(w_j 2^P / sum w) with the
+                                   first largest taking the residue so that sum W_j == 2^P (P = max(17, 21 + ceil(log2 sum w))), and
+                                   texel = floor(sum W_j c_j / 2^P + 1/2) on the 16-bit texels c_j; without GLV_OP_R16 the float
+                                   (float) ((double) sum W_j c_j 2^-P / 65535).  Integer arithmetic on the i8 matrix cores: no summation order,
+                                   within 0.03 texel steps of the mean with the float weights in exact arithmetic
+                                   (glava_amd/csrc/glv_tables.h make_bar_itiles; oracle/glv_oracle.c glvo_bars_int_at restates it) */
     GLV_OP_SMOOTH   = 1u << 6,  /* CPU-path log-window mean  == transform_smooth   render.c:694-718;
                                    applied last, in place on each row (after fft/gravity/average) */
     GLV_OP_MAGNITUDE = 1u << 7, /* the magnitude stage alone: b = (float)(log(|b| + 1.0f) / 3) * tilt(i),

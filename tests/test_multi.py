@@ -123,6 +123,41 @@ def test_c_multi_driver_several_shards_without_rccl(glvlib, monkeypatch, shards)
         G.Multi(p, 64, G.OP_FFT, devices=[0, 0])
 
 
+@pytest.mark.gpu
+def test_eight_shards_on_eight_host_threads_do_not_serialise_on_the_host(glvlib, monkeypatch):
+    """VERDICT r4 item 7 / SURVEY 8e ("anything else than linear scaling indicates host-side launch serialisation"), probed without an
+    8-GPU node: glv_multi_run_s16 with EIGHT shards -- eight host threads, each with its own batch and HIP stream -- on this one device
+    (host-gathered stats) against ONE shard of all the streams.  The device does the same work either way, so the eight-thread run may
+    cost what eight smaller kernels per update cost (tails, less overlap) but not multiples: a lock around the launch path would
+    show as ~8 x.  Every shard's spectra equal the plain batch's bit for bit."""
+    import torch
+    G = glvlib
+    monkeypatch.setenv("GLV_MULTI_RCCL", "0")
+    n, streams, steps, shards = 4096, 32768, 20, 8
+    p = G.Params(n=n)
+    gen = torch.Generator(device="cuda"); gen.manual_seed(8)
+    d_pcm = torch.randint(-32768, 32768, (streams, n * 2), dtype=torch.int16, device="cuda", generator=gen)
+    secs = {}
+    for nsh in (1, shards):
+        m = G.Multi(p, streams, G.OP_FFT, devices=[0] * nsh)
+        ins, outs = [], []
+        for i in range(nsh):
+            _, lo, cnt = m.shard(i)
+            ins.append(d_pcm[lo:lo + cnt]); outs.append(torch.zeros((cnt * 2, n), dtype=torch.float32, device="cuda"))
+        m.run_s16(ins, outs, G.OP_FFT, warmup=20, steps=steps)
+        stats, mx = m.run_s16(ins, outs, G.OP_FFT, warmup=3, steps=steps)
+        torch.cuda.synchronize()
+        assert len(stats) == nsh and sum(s["frames"] for s in stats) == streams * steps
+        secs[nsh] = mx
+        if nsh == 1: ref = outs[0].clone()
+        else:
+            got = torch.cat(outs)
+            assert torch.equal(got.view(torch.int32), ref.view(torch.int32))
+        m.close()
+    print(f"one shard {secs[1] / steps * 1e3:.3f} ms per update, eight shards on eight host threads {secs[shards] / steps * 1e3:.3f} ms: ratio {secs[shards] / secs[1]:.2f}")
+    assert secs[shards] <= 2.5 * secs[1], secs
+
+
 def _run_bench_distributed(nproc, port, extra_env=None, extra_args=()):
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")

@@ -45,6 +45,7 @@ struct alignas(16) BarMTile { uint32_t k0, origin, steps, w_off; };
 // a bar whose weights sum to 0 has every digit 0, c = 0 and s = kBarIFinNone (the same expression then gives texel 0; the float form NaN)
 struct alignas(8) BarIFin { uint32_t c, s; };
 constexpr uint32_t kBarIFinNone = 16;
+constexpr uint32_t kBarILookAhead = 4;      // steps of zero weights behind the last tile's: the kernel's weight requests run ahead of the step it computes
 
 struct FrameArgs {
     const void* in;        // s16: int16 [units/2][n][2] (a unit is one channel row of a frame);  f32 planar: float [units][n];

@@ -418,7 +418,7 @@ __global__ void __launch_bounds__(64 * kRowsWaves) glv_bars_rows_kernel(const fl
     // 4 bins of this lane's row (column `col` of four bins from bin0); clamped here, once per texel: [0, 1] like the GL_R16 texel the shader samples, NaN -> 0 (v_pk_mul_f32
     // x, 1.0 clamp -- the operation bar_item_lane_sum applies to every tap)
     auto fetch = [&](uint32_t bin) {
-        return ld<BarW4>(src, bin * 4u);
+        return ld<BarW4>(src, (bin + 4u <= n ? bin : n - 4u) * 4u);      // (a dummy request at the row's very end stays inside the row: ADVICE r4)
     };
     auto park = [&](const BarW4& v, uint32_t bin) {
         glv_f2 lo = {v.w[0], v.w[1]}, hi = {v.w[2], v.w[3]};
@@ -637,6 +637,7 @@ __global__ void __launch_bounds__(64 * kRowsWaves, 2) glv_bars_rows_i8_kernel(co
     struct Tex8 { uint32_t d[4]; };                                     // 8 texels, two per dword
     auto fetch = [&](uint32_t bin) -> Tex8 {
         Tex8 v;
+        bin = bin + 8u <= n ? bin : n - 8u;                             // (a dummy request -- nothing new to park -- at the row's very end stays inside the row)
         if constexpr (F32IN) {                                          // rows of floats c / 65535 (the pass-by-pass chain): back to the texels, exactly
             const BarW4 a = ld<BarW4>(src, bin * 4u), b = ld<BarW4>(src, bin * 4u + 16u);
             v.d[0] = pack_unorm16(a.w[0], a.w[1]); v.d[1] = pack_unorm16(a.w[2], a.w[3]);
@@ -678,6 +679,7 @@ __global__ void __launch_bounds__(64 * kRowsWaves, 2) glv_bars_rows_i8_kernel(co
     // end after any step: the loop below runs over the wave's STREAM, and what a tile's last step is followed by -- parking the next round's
     // bins, the epilogue, the round's barrier, the next tile's set-up -- hangs off each of the PF steps as a side block.
     constexpr int PF = 3;
+    static_assert((uint32_t) PF < kBarILookAhead, "the stream that lies last in memory is read PF steps past its last tile: the host pads kBarILookAhead steps");
     const glv_i4v* wp = nullptr;                                        // stream position of the NEXT load (lane-offset)
     glv_i4v wb[PF][3];
     glv_i16v acc[G][4];

@@ -308,7 +308,9 @@ inline bool make_bar_mtiles(std::vector<BarMTile>& mtiles, std::vector<float>& w
 //              origin + 32 step + 16 (l / 32) + j (0 outside the bar's own taps) -- the b-operand of the MFMA, one coalesced load per digit
 //   fin[k]:    {c, s}: texel = (uint32) (floor(T / 2^16) + c) >> s with s = P - 16 in [1, 15] and c = 32896 * 2^s + 2^(s-1); weights that sum to 0: {0, kBarIFinNone}, every digit 0
 //   rounds:    as make_bar_mtiles (tile ends rounded up to 8 bins: the ring is filled 8 texels = 16 bytes at a time)
-constexpr uint32_t kBarIStepBins = 32, kBarILookAhead = 2;       // bins per step; steps of zeros behind the last tile (the kernel's weight look-ahead)
+// bins per step; steps of zeros behind the last tile: the kernel requests a wave's weights PF = 3 steps ahead of the step it runs, so the
+// stream that lies last in memory is read up to three steps past its last tile (glv_misc.hip glv_bars_rows_i8_kernel)
+constexpr uint32_t kBarIStepBins = 32;                    // (kBarILookAhead: glv_frame.h, shared with the kernel)
 // the integer weights of one bar (W: count values); returns P, or -1 when the float weights sum to 0 / NaN, or -2 when P would exceed 31
 inline int bar_int_weights(const float* w, uint32_t count, std::vector<int32_t>& W) {
     W.assign(count, 0);

@@ -303,7 +303,11 @@ int glv_batch_bars(glv_batch* b, const float* d_spec, float* d_bars, void* hip_s
 int glv_batch_timing_begin(glv_batch* b);
 int glv_batch_timing_end(glv_batch* b, double* kernel_ms, uint64_t* launches);
 
-/* Algorithmic HBM bytes one process call moves for the given ops. */
+/* Algorithmic HBM bytes one process call moves for the given ops: what the CHAIN must move -- input, state
+ * read and written, output.  Rows that one launch of a multi-launch chain hands to the next (the uint16 `av` rows in front of the
+ * pre-smoothing pass, bars that are not computed inside the transform's launch) are traffic of the organisation, not of the problem, and
+ * are not counted -- except gl_storage 2, whose pass-by-pass f32 round trip (+16 n) is its definition.  A chain that ends in gravity is
+ * counted with its output copy (28 n) unless GLV_OP_OUTPUT_IS_STATE is in `ops` (20 n; a NULL d_out moves those 20 n too). */
 uint64_t glv_batch_algorithmic_bytes(const glv_batch* b, unsigned ops, int input_is_s16);
 
 /* Launch-geometry override for tuning (workgroups of the persistent frame kernel; 0 = automatic). */

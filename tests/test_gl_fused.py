@@ -409,3 +409,49 @@ def test_single_stream_gl_texture_is_the_batched_chain(glvlib):
                 assert (row == x[ch]).all() and (tex == want[ch]).all(), (smooth, u, ch)
         for s in st: s.close()
         b.close()
+
+
+def test_presmoothing_pass_of_the_gl_chains_over_random_parameters(glvlib):
+    """The integer pass over a seeded sweep of sizes, bar counts (ragged last tiles and rounds), smoothing widths (wide bars: hundreds of
+    taps, the long rings) and phases, F = 1 .. 3: the fused chain and the pass-by-pass chain agree bit for bit, and two rows of every
+    trial equal the oracle's integer mean of the chain's own `av` texels -- or, where no ring takes the tiles (the library then keeps
+    the float chain's kernels for the pass), the documented fma chain of the texels' floats."""
+    import torch
+    G = glvlib
+    rng = np.random.default_rng(555)
+    seen_int = 0
+    for trial in range(16):
+        n = int(rng.choice([512, 1024, 2048, 4096, 8192]))
+        bars = min(n, int(rng.choice([256, 300, 333, 512, 1000, n])))
+        factor = float(rng.choice([0.005, 0.025, 0.05, 0.12]))
+        phase = float(rng.choice([0.0, 0.5, 0.25]))
+        F = int(rng.choice([1, 2, 3]))
+        streams = 65 + int(rng.integers(0, 40))
+        kw = dict(n=n, avg_frames=F, avg_window_kind=1, bars=bars, bar_phase=phase, smooth_factor=factor)
+        mask = G.OP_GRAVITY | (G.OP_AVERAGE if F > 1 else 0)
+        ops = G.OP_FFT | mask
+        try:
+            sm1 = G.Batch(G.Params(gl_storage=1, **kw), streams, mask | G.OP_BARS)
+        except G.GlvError:
+            continue                                    # (a parameter set without bar tables at all)
+        sm2 = G.Batch(G.Params(gl_storage=2, **kw), streams, mask | G.OP_BARS)
+        av = G.Batch(G.Params(gl_storage=1, **kw), streams, mask)
+        o1 = torch.full((streams * 2, bars), -1, dtype=torch.int16, device="cuda"); o2 = torch.zeros_like(o1)
+        oa = torch.zeros((streams * 2, n), dtype=torch.int16, device="cuda")
+        for u in range(F + 1):
+            d_pcm = torch.from_numpy((lcg_pcm_fast(31 * trial + u, streams * 2 * n) // (4, 24)[u % 2]).astype(np.int16)).cuda()
+            sm1.process_s16(d_pcm, o1, ops | G.OP_BARS | G.OP_R16); sm2.process_s16(d_pcm, o2, ops | G.OP_BARS | G.OP_R16)
+            av.process_s16(d_pcm, oa, ops | G.OP_R16)
+            assert _eq(o1, o2), (trial, n, bars, factor, phase, F, u)
+        t_av = oa.cpu().numpy().view(np.uint16); t_sm = o1.cpu().numpy().view(np.uint16)
+        for r in (0, streams * 2 - 1):
+            w16 = np.zeros(bars, np.uint16)
+            rc = Oracle.lib().glvo_bars_int_at(np.ascontiguousarray(t_av[r]), n, w16.ctypes.data, None, bars, factor, phase)
+            if rc == 0 and (t_sm[r] == w16).all():
+                seen_int += 1
+                continue
+            want = np.empty(bars, np.float32)
+            Oracle.lib().glvo_bars_chunked_at((t_av[r].astype(np.float32) / np.float32(65535)).copy(), n, want, bars, factor, phase)
+            assert (t_sm[r] == Oracle.texels_r16(want)).all(), (trial, n, bars, factor, phase, F, r, rc)
+        for b in (sm1, sm2, av): b.close()
+    assert seen_int >= 16                               # most trials run the integer pass

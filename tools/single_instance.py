@@ -26,3 +26,17 @@ sync = (time.perf_counter() - t0) / 500
 print(f"one stream, N={n}, default pipeline with the pre-smoothing pass ({b.last_launches()} launches): {eager * 1e6:.1f} us per update back to back, "
       f"{sync * 1e6:.1f} us per update with a synchronize after each (launch + completion latency)")
 b.close()
+# ... and what the patched GLava host pays per rendered frame: integration/render_hip.patch makes ONE glv_gl_texture call per bind (two binds:
+# audio_l, audio_r) -- host samples in, the module's GL_R16 texels out, synchronous (pinned mapped staging, one stream synchronise per call)
+sts = [G.State(p), G.State(p)]
+x = (np.random.default_rng(1).integers(-8000, 8000, (2, n)).astype(np.float32) / np.float32(65535))
+tex = np.zeros((2, n), np.uint16)
+for _ in range(50):
+    for c in range(2): sts[c].gl_texture(x[c], tex[c], True)
+t0 = time.perf_counter()
+for _ in range(1000):
+    for c in range(2): sts[c].gl_texture(x[c], tex[c], True)
+host = (time.perf_counter() - t0) / 1000
+print(f"the same through the host drop-in (glv_gl_texture, two binds per update, host buffers in and out): {host * 1e6:.1f} us per update "
+      f"(GLava has 11.6 ms per update at 86 updates/s; its CPU + GL passes are replaced by this)")
+for s_ in sts: s_.close()

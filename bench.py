@@ -226,18 +226,22 @@ def extra_configs(G, torch, device, a, peak_gbs):
     # texels and the pass runs in exact integer arithmetic on the i8 matrix cores (round 5) -- two launches.  roofline_frac is
     # against the CHAIN's algorithmic bytes, 28 N per frame: PCM in, four ring slots read, one written, `sm` texels out (the
     # intermediate `av` rows are not counted -- traffic the organisation adds, not the problem needs)
-    s3 = max(s // 4, 1)
-    qs = torch.empty((s3, 2, n), dtype=torch.int16, device="cuda")
     smops = glops | G.OP_BARS | G.OP_R16
-    b3 = G.Batch(G.Params(n=n, log_mode=a.log_mode, avg_frames=F, avg_window_kind=1, gl_storage=1, bars=n, bar_phase=0.5), s3,
-                 G.OP_GRAVITY | G.OP_AVERAGE | G.OP_BARS, device=device)
-    dt, kms = run(b3, lambda: b3.process_s16(pcm, qs, smops, st0))
-    assert b3.algorithmic_bytes(smops) == 28 * n * s3
-    gl["sm_out"] = entry(f"GLava's SHIPPED pipeline end to end: same chain + the pre-smoothing pass (bars = n = {n}, bar_phase 0.5) -> `sm` GL_R16 texels, {s3} streams, "
-                         f"two launches (glv_frame_kernel -> uint16 `av` rows -> glv_bars_rows_i8_kernel: exact integer weighted means on v_mfma_i32_32x32x32_i8); "
-                         f"bytes: the chain's 28 N per frame", s3, b3.algorithmic_bytes(smops), dt, kms)
-    gl["sm_out"]["launches_per_step"] = b3.last_launches()
-    b3.close(); del qs
+    psm = G.Params(n=n, log_mode=a.log_mode, avg_frames=F, avg_window_kind=1, gl_storage=1, bars=n, bar_phase=0.5)
+    sm_entries = {}
+    for tag, s3 in (("full", s), ("quarter", max(s // 4, 1))):          # the whole batch (as every other entry), and round 4's quarter batch
+        qs = torch.empty((s3, 2, n), dtype=torch.int16, device="cuda")
+        b3 = G.Batch(psm, s3, G.OP_GRAVITY | G.OP_AVERAGE | G.OP_BARS, device=device)
+        dt, kms = run(b3, lambda: b3.process_s16(pcm, qs, smops, st0))
+        assert b3.algorithmic_bytes(smops) == 28 * n * s3
+        sm_entries[tag] = entry(f"GLava's SHIPPED pipeline end to end: the chain above + the pre-smoothing pass (bars = n = {n}, bar_phase 0.5) -> `sm` GL_R16 texels, {s3} streams, "
+                                f"two launches (glv_frame_kernel -> uint16 `av` rows -> glv_bars_rows_i8_kernel: exact integer weighted means on v_mfma_i32_32x32x32_i8); "
+                                f"bytes: the chain's 28 N per frame", s3, b3.algorithmic_bytes(smops), dt, kms)
+        sm_entries[tag]["launches_per_step"] = b3.last_launches()
+        b3.close(); del qs
+    gl["sm_out"] = sm_entries["full"]
+    gl["sm_out"]["quarter_batch"] = sm_entries["quarter"]
+    s3 = max(s // 4, 1)
     # the pre-smoothing kernel by itself on rows already in HBM: its roofline is the f32 matrix rate (157.3 TFLOP/s dense at nominal
     # clock, MI355X_MICROARCH.md), counted on the USEFUL multiply-adds (smooth_audio()'s own taps; the tiles' padding is not counted)
     try:

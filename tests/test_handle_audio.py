@@ -312,3 +312,28 @@ def test_patched_accel_path_uploads_the_texture_the_reference_samples(glvlib, na
                 assert H.nullgl_update_texels(h, lb, rb, n, 0, tl, tr, C.byref(nf)) == 0 and nf.value == 0
                 assert (tl == last[0]).all() and (tr == last[1]).all()
         H.nullgl_destroy(h)
+
+
+def test_render_hip_patch_applies_to_the_reference_and_compiles(tmp_path):
+    """integration/render_hip.patch is a unified diff against the reference's glava/render.c: where the reference tree is present it must
+    apply without fuzz or rejects (`patch -p1` from the GLava tree's root), touch nothing but render.c, and the patched file must compile
+    as the reference's own build would compile it (gcc -std=gnu11, with the shim on the include path) -- every hunk of INTEGRATION.md
+    section 1, the accel-chain hunk of round 5 included."""
+    import shutil, subprocess
+    ref = "/root/reference/glava/render.c"
+    if not os.path.exists(ref):
+        pytest.skip("needs the reference tree (build container only)")
+    tree = tmp_path / "glava"
+    tree.mkdir()
+    shutil.copy(ref, tree / "render.c")
+    patch = os.path.join(ROOT, "integration", "render_hip.patch")
+    r = subprocess.run(["patch", "-p1", "--no-backup-if-mismatch", "-i", patch], cwd=tmp_path, capture_output=True, text=True)
+    assert r.returncode == 0 and "fuzz" not in r.stdout and "FAILED" not in r.stdout and "offset" not in r.stdout, r.stdout + r.stderr
+    assert sorted(p.name for p in tree.iterdir()) == ["render.c"]
+    txt = (tree / "render.c").read_text()
+    for needle in ("transform_gl_hip(gl, &bind->hip_gl_slot", "GL_UNSIGNED_SHORT, bind->hip_texels", "goto glv_bound;", "glv_bound:", "transform_fga_hip",
+                   "glv_hip_release(bind->hip_gl_slot)"):
+        assert needle in txt, needle
+    c = subprocess.run(["gcc", "-std=gnu11", "-O2", "-fcommon", "-w", "-fsyntax-only", "-I/root/reference/glava", "-I" + os.path.join(ROOT, "include"),
+                        "-I" + os.path.join(ROOT, "integration"), "-DGLAVA_GLX", "-DGLAVA_UNIX", str(tree / "render.c")], capture_output=True, text=True)
+    assert c.returncode == 0, c.stderr[-800:]

@@ -9,7 +9,7 @@
 #   prof:<cfg>       rocprofv3 stats + PMC of tools/cfg_run.py <cfg> 150 (gl_default | gl_bars | gl_sm | configs2 | chain | n1024bars | ring)
 #   size:<n>:<s>     the stateless pass at another size (tools/profile.sh --n <n> --streams <s>)
 #   i8               the integer pre-smoothing pass alone (tools/bin/rows_i8_bench, built beforehand by tools/rows_i8_bench.sh)
-#   overlap          two batches on two streams against one (tools/sm_overlap.py)
+#   overlap[:<streams>]  two / four batches on as many streams against one (tools/sm_overlap.py)
 #   single           one GLava instance: the default pipeline per update, batched API and host drop-in (tools/single_instance.py)
 #   power            tools/power_probe.py
 # GLV_PMC_EXTRA="<counters>" adds a PMC pass to headline / prof / size.
@@ -40,6 +40,7 @@ PY
     size:*)     IFS=: read -r _ n s <<< "$sec"; bash tools/profile.sh "${R}_n$n" --n "$n" --streams "$s" --no-alt --no-configs --sustained-s 0 > "$O/prof_n$n.txt" 2>&1; tail -6 "$O/prof_n$n.txt" | cut -c1-200 ;;
     i8)         for b in tools/bin/rows_i8_bench*; do echo "== $b"; timeout 120 "$b" 4096 32768 20 2>&1 | tail -1; done | tee "$O/i8_bench.txt" ;;
     overlap)    timeout 300 python tools/sm_overlap.py 16384 60 2>&1 | tail -2 | tee "$O/overlap.txt" ;;
+    overlap:*)  k=${sec#overlap:}; timeout 300 python tools/sm_overlap.py "$k" 40 2>&1 | tail -5 | tee "$O/overlap_$k.txt" ;;
     single)     timeout 300 python tools/single_instance.py 2>&1 | tail -2 | tee "$O/single_instance.txt" ;;
     power)      python tools/power_probe.py --seconds 5 > "$O/power.txt" 2>/dev/null; cat "$O/power.txt" ;;
     *)          echo "unknown section $sec" ;;

@@ -41,3 +41,23 @@ for parts in (2, 4):
     ms = timed(split)
     print(f"sm chain N={n} x {streams} streams: one batch, one stream {ms1:.4f} ms = {streams / ms1 / 1e3:.2f} M frames/s; {parts} batches on {parts} streams {ms:.4f} ms = {streams / ms / 1e3:.2f} M frames/s")
     for b in bs: b.close()
+
+# The same with the semantics ONE library call would have to keep: everything forked from and joined back into the caller's
+# stream inside each call (chunk i's chain on internal stream i % 2), so that nothing of call k is in flight when call k + 1 starts.
+main = torch.cuda.current_stream()
+for parts in (2, 4, 8):
+    sub = streams // parts
+    bs = [G.Batch(p, sub, mask) for _ in range(parts)]
+    sts = [torch.cuda.Stream() for _ in range(2)]
+    ev_in = torch.cuda.Event(); ev_out = [torch.cuda.Event() for _ in range(2)]
+
+    def joined():
+        ev_in.record(main)
+        for st in sts: st.wait_event(ev_in)
+        for i, b in enumerate(bs):
+            b.process_s16(pcm[i * sub:(i + 1) * sub], out[i * sub:(i + 1) * sub], ops, sts[i % 2].cuda_stream)
+        for st, ev in zip(sts, ev_out):
+            ev.record(st); main.wait_event(ev)
+    ms = timed(joined)
+    print(f"sm chain N={n} x {streams} streams: forked and joined inside every call, {parts} chunks on 2 streams {ms:.4f} ms = {streams / ms / 1e3:.2f} M frames/s (one batch {ms1:.4f})")
+    for b in bs: b.close()

@@ -6,7 +6,7 @@
 #   tests:<expr>     pytest -k <expr>                         -> pytest_<expr>.txt
 #   bench            python bench.py                          -> bench_line.json
 #   headline         rocprofv3 stats + PMC of the headline launch (tools/profile.sh)         -> gpurun_out/prof_<round>/
-#   prof:<cfg>       rocprofv3 stats + PMC of tools/cfg_run.py <cfg> 150 (gl_default | gl_bars | gl_sm | configs2 | chain | n1024bars | ring)
+#   prof:<cfg>       rocprofv3 stats + PMC of tools/cfg_run.py <cfg> 150 (gl_default | gl_bars | gl_sm | gl_sm64 | configs2 | chain | n1024bars | ring)
 #   size:<n>:<s>     the stateless pass at another size (tools/profile.sh --n <n> --streams <s>)
 #   i8               the integer pre-smoothing pass alone (tools/bin/rows_i8_bench, built beforehand by tools/rows_i8_bench.sh)
 #   overlap[:<streams>]  two / four batches on as many streams against one (tools/sm_overlap.py)

@@ -364,10 +364,12 @@ GLV_HD float div_frames(float x, float F, float rcpF) {
 GLV_HD cf texels_to_float(uint32_t p) {
 #if defined(__HIP_DEVICE_COMPILE__)
     const glv_f2 K = {(float) (p & 0xffffu), (float) (p >> 16)};        // v_cvt_f32_u32 with a word selector each
+    // the two constants as SCALAR register pairs (one scalar operand per VOP3P instruction is allowed): as vector operands the backend
+    // rebuilt each 64-bit pair with a v_mov_b32 in front of every use -- two more instructions per texel pair, 80 pairs per lane and row
     const glv_f2 CH = {0x1.0001p-16f, 0x1.0001p-16f}, CL = {0x1.0001p-48f, 0x1.0001p-48f};
     glv_f2 t, q;
-    asm("v_pk_mul_f32 %0, %1, %2" : "=v"(t) : "v"(K), "v"(CL));
-    asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(q) : "v"(K), "v"(CH), "v"(t));
+    asm("v_pk_mul_f32 %0, %1, %2" : "=v"(t) : "v"(K), "s"(CL));
+    asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(q) : "v"(K), "s"(CH), "v"(t));
     return cf{q.x, q.y};
 #else
     return cf{unorm16_to_float(p & 0xffffu), unorm16_to_float(p >> 16)};
@@ -385,7 +387,7 @@ GLV_HD uint32_t gravity_r16(uint32_t tex, uint32_t store, float g, uint32_t sub,
 #if defined(__HIP_DEVICE_COMPILE__)
     uint32_t m;
     asm("v_pk_max_u16 %0, %1, %2" : "=v"(m) : "v"(tex), "v"(store));
-    if (exact_int) {                                                    // uniform
+    if (exact_int) {                                                    // uniform (callers with many texels test it ONCE around their loop: gravity_r16_int / _flt)
         uint32_t r;
         asm("v_pk_sub_u16 %0, %1, %2 clamp" : "=v"(r) : "v"(m), "v"(sub));
         return r;
@@ -402,6 +404,27 @@ GLV_HD uint32_t gravity_r16(uint32_t tex, uint32_t store, float g, uint32_t sub,
     return unorm16(unorm16_to_float(m0) - g) | (unorm16(unorm16_to_float(m1) - g) << 16);
 #endif
 }
+
+// The two arms of gravity_r16 on their own, for callers that hold many texel pairs: a uniform test per PAIR stays a pair of branches per
+// pair in the unrolled code (the backend does not merge them across the inline assembly: 32 branches per lane and row in the frame
+// kernel's GL epilogue); tested once around the loop it costs nothing.  Same instructions, same bits.
+#if defined(__HIP_DEVICE_COMPILE__)
+__device__ __forceinline__ uint32_t gravity_r16_int(uint32_t tex, uint32_t store, uint32_t sub_uniform) {
+    uint32_t m, r;
+    asm("v_pk_max_u16 %0, %1, %2" : "=v"(m) : "v"(tex), "v"(store));
+    asm("v_pk_sub_u16 %0, %1, %2 clamp" : "=v"(r) : "v"(m), "s"(sub_uniform));
+    return r;
+}
+__device__ __forceinline__ uint32_t gravity_r16_flt(uint32_t tex, uint32_t store, float g) {
+    uint32_t m;
+    asm("v_pk_max_u16 %0, %1, %2" : "=v"(m) : "v"(tex), "v"(store));
+    const cf f = texels_to_float(m);
+    return pack_unorm16(f.x - g, f.y - g);
+}
+#else
+inline uint32_t gravity_r16_int(uint32_t tex, uint32_t store, uint32_t sub) { return gravity_r16(tex, store, 0.0f, sub, 1u); }
+inline uint32_t gravity_r16_flt(uint32_t tex, uint32_t store, float g) { return gravity_r16(tex, store, g, 0u, 0u); }
+#endif
 
 // render.c:844: (float)(log((double)y) / 3) with y = |x| + 1.0f already rounded to float (y >= 1).
 //   mode 0  fp64: table-driven double-precision log (relative error ~2^-50) times 1/3, rounded to

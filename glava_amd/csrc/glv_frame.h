@@ -17,6 +17,8 @@
 //   bar_item_*                   smooth_audio() bin averaging (smooth.glsl:13-40) in 64-tap chunks
 #pragma once
 
+#include <type_traits>
+
 #include "glv_core.h"
 
 namespace glv {
@@ -180,7 +182,7 @@ GLV_HD float bar_item_lane_sum(const BarTaps& s) {
     for (int i = 0; i < kBarTaps; i += 2) {
         glv_f2 t = {s.t[i], s.t[i + 1]};
         const glv_f2 w = {s.w[i], s.w[i + 1]};
-        asm("v_pk_mul_f32 %0, %1, %2 clamp" : "=v"(t) : "v"(t), "v"(ones));
+        asm("v_pk_mul_f32 %0, %1, %2 clamp" : "=v"(t) : "v"(t), "s"(ones));          // (uniform constant: a scalar pair, not a v_mov_b64 per step)
         asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(acc) : "v"(t), "v"(w), "v"(acc));
     }
     return acc.x + acc.y;
@@ -247,9 +249,9 @@ GLV_HD void weighted_add(cf& acc, cf f, float w, bool windowed) {
     const glv_f2 T = {f.x, f.y}, A = {acc.x, acc.y};
     glv_f2 s;
     if (windowed) {
-        const glv_f2 W = {w, w};
+        const glv_f2 W = {w, w};                               // uniform: a scalar register pair (as a vector operand it was rebuilt with a v_mov_b64 per use)
         glv_f2 p;
-        asm("v_pk_mul_f32 %0, %1, %2" : "=v"(p) : "v"(T), "v"(W));
+        asm("v_pk_mul_f32 %0, %1, %2" : "=v"(p) : "v"(T), "s"(W));
         asm("v_pk_add_f32 %0, %1, %2" : "=v"(s) : "v"(A), "v"(p));
     } else asm("v_pk_add_f32 %0, %1, %2" : "=v"(s) : "v"(A), "v"(T));
     acc.x = s.x; acc.y = s.y;
@@ -346,8 +348,11 @@ GLV_HD cf apply_state(cf val, uint32_t off, size_t row, uint32_t n, const FrameA
 #ifndef GLV_STATE_PAIR_MAX
 #define GLV_STATE_PAIR_MAX 12
 #endif
+// The per-point-test form of apply_state_block below (window or plain sum, gravity or not: tested for every point).  Kept for the kernels with
+// 32 points per lane (N >= 16384): there the straight-line form raises the f32 chains' scratch from 68-160 to 190-220 bytes per lane and
+// costs configs[2] 16 % (profiles/r05/uniform_branches.txt); everywhere else the straight-line form is the one that runs.
 template <int NV, bool PAIR = false>
-GLV_HD void apply_state_block(cf (&val)[NV], const uint32_t (&off)[NV], size_t row, uint32_t n, const FrameArgs& a) {
+GLV_HD void apply_state_block_tests(cf (&val)[NV], const uint32_t (&off)[NV], size_t row, uint32_t n, const FrameArgs& a) {
     if (a.ops & OP_AVERAGE) {
         float* h = a.hist + row * (size_t) a.F * n;                          // uniform
         const uint32_t F = a.F;
@@ -423,6 +428,83 @@ GLV_HD void apply_state_block(cf (&val)[NV], const uint32_t (&off)[NV], size_t r
     }
 }
 
+template <int NV, bool PAIR = false>
+GLV_HD void apply_state_block(cf (&val)[NV], const uint32_t (&off)[NV], size_t row, uint32_t n, const FrameArgs& a) {
+    // Window or plain sum (uniform) is NOT tested per point: in the unrolled code every such test was a pair of scalar branches of its own
+    // (see gl16_state_block), ~100 pairs per lane and row at F = 5.  The plain sum is the windowed form with weight 1:
+    // (float) ((double) acc + 1.0 * (double) x) == acc + x bit for bit -- the product is exact, and rounding a sum of two floats to double first
+    // is innocuous (53 >= 2 * 24 + 2 bits) -- so one straight-line version serves both; the rare unwindowed chain pays fp64 adds for it.
+    const bool win = a.avg_window != 0;
+    if (a.ops & OP_AVERAGE) {
+        float* h = a.hist + row * (size_t) a.F * n;                          // uniform
+        const uint32_t F = a.F;
+        cf acc[NV], prev[NV];
+#pragma unroll
+        for (int e = 0; e < NV; ++e) { acc[e].x = 0.0f; acc[e].y = 0.0f; prev[e].x = 0.0f; prev[e].y = 0.0f; }
+        if (F == 1) {
+#pragma unroll
+            for (int e = 0; e < NV; ++e) prev[e] = ld<cf>(h + (size_t) a.head * n, off[e]);
+        }
+        // oldest .. second newest, two history frames per trip (PAIR): their 2 NV loads are in flight
+        // together -- the epilogue is a chain of dependent HBM round trips (F - 1 per block), halving their number is
+        // worth more than the NV extra registers; the accumulation order (render.c:757-760) is unchanged
+        uint32_t f = 0;
+        if constexpr (PAIR) for (; f + 2 < F; f += 2) {
+            const float* hs0 = h + (size_t) ring_slot(a.head, f, F) * n;         // uniform
+            const float* hs1 = h + (size_t) ring_slot(a.head, f + 1, F) * n;     // uniform
+            cf p0[NV];
+#pragma unroll
+            for (int e = 0; e < NV; ++e) p0[e] = ld<cf>(hs0, off[e]);
+#pragma unroll
+            for (int e = 0; e < NV; ++e) prev[e] = ld<cf>(hs1, off[e]);
+            const double w0 = win ? a.wts[f] : 1.0, w1 = win ? a.wts[f + 1] : 1.0;
+#pragma unroll
+            for (int e = 0; e < NV; ++e) {                                   // render.c:759, double product
+                acc[e].x = (float) ((double) acc[e].x + w0 * (double) p0[e].x);
+                acc[e].y = (float) ((double) acc[e].y + w0 * (double) p0[e].y);
+                acc[e].x = (float) ((double) acc[e].x + w1 * (double) prev[e].x);
+                acc[e].y = (float) ((double) acc[e].y + w1 * (double) prev[e].y);
+            }
+        }
+        for (; f + 1 < F; ++f) {
+            const float* hs = h + (size_t) ring_slot(a.head, f, F) * n;      // uniform
+#pragma unroll
+            for (int e = 0; e < NV; ++e) prev[e] = ld<cf>(hs, off[e]);
+            const double w = win ? a.wts[f] : 1.0;
+#pragma unroll
+            for (int e = 0; e < NV; ++e) {                                   // render.c:759, double product
+                acc[e].x = (float) ((double) acc[e].x + w * (double) prev[e].x);
+                acc[e].y = (float) ((double) acc[e].y + w * (double) prev[e].y);
+            }
+        }
+        const double wl = win ? a.wts[F - 1] : 1.0;
+        const bool grav = (a.ops & OP_GRAVITY) != 0;
+#pragma unroll
+        for (int e = 0; e < NV; ++e) {
+            {                                                                // (a select on the uniform flag, not a branch per point)
+                const float gx = gravity(val[e].x, prev[e].x, a.g), gy = gravity(val[e].y, prev[e].y, a.g);
+                val[e].x = grav ? gx : val[e].x; val[e].y = grav ? gy : val[e].y;
+            }
+            st<cf>(h + (size_t) a.head * n, off[e], val[e]);
+            acc[e].x = (float) ((double) acc[e].x + wl * (double) val[e].x);
+            acc[e].y = (float) ((double) acc[e].y + wl * (double) val[e].y);
+            val[e].x = acc[e].x / a.F_as_float;                              // render.c:761
+            val[e].y = acc[e].y / a.F_as_float;
+        }
+    } else if (a.ops & OP_GRAVITY) {
+        const float* gs = a.grav + row * (size_t) n;                         // uniform
+        float* gw = a.grav_w + row * (size_t) n;
+        cf st0[NV];
+#pragma unroll
+        for (int e = 0; e < NV; ++e) st0[e] = ld<cf>(gs, off[e]);
+#pragma unroll
+        for (int e = 0; e < NV; ++e) {
+            val[e].x = gravity(val[e].x, st0[e].x, a.g); val[e].y = gravity(val[e].y, st0[e].y, a.g);
+            st<cf>(gw, off[e], val[e]);
+        }
+    }
+}
+
 // gl_storage == 1 inside the frame kernel: apply_state_r16 for NV complex points of one lane at once, loads first (the shape of
 // apply_state_block; same arithmetic, same order).  PAIRED: points j and j + 1 (j even) are adjacent in the row -- their four
 // texels are one 8-byte access.  TWO: two history frames per trip.
@@ -447,7 +529,20 @@ GLV_HD void gl16_state_block(uint32_t (&tex)[NV], const uint32_t (&off)[NV], siz
         }
     };
     const uint32_t F = a.F;
+    // Uniform choices -- window or plain sum, the gravity step as an integer subtraction or in floats -- are made ONCE around the loops over the
+    // lane's points, not inside weighted_texels / gravity_r16 for every point: in the unrolled code each inner test was a pair of scalar
+    // branches of its own (the backend does not merge identical tests across the inline assembly between them), 12 pairs per point at
+    // F = 5, ~190 per lane and row (profiles/r05/uniform_branches.txt).  A plain sum is the windowed form with weight 1 (1 * t == t, bit for bit).
     const bool windowed = a.avg_window != 0;
+    auto gravity_all = [&](const uint32_t (&st)[NV]) {
+        if (a.grav_int) {
+#pragma unroll
+            for (int e = 0; e < NV; ++e) tex[e] = gravity_r16_int(tex[e], st[e], a.grav_sub);
+        } else {
+#pragma unroll
+            for (int e = 0; e < NV; ++e) tex[e] = gravity_r16_flt(tex[e], st[e], a.g);
+        }
+    };
     if (a.ops & OP_AVERAGE) {
         uint16_t* h = reinterpret_cast<uint16_t*>(a.hist) + row * (size_t) F * n;                      // uniform
         cf acc[NV];
@@ -460,35 +555,31 @@ GLV_HD void gl16_state_block(uint32_t (&tex)[NV], const uint32_t (&off)[NV], siz
             uint32_t p0[NV];
             load(p0, h + (size_t) ring_slot(a.head, f, F) * n);
             load(prev, h + (size_t) ring_slot(a.head, f + 1, F) * n);
-            const float w0 = a.wts32[f], w1 = a.wts32[f + 1];
+            const float w0 = windowed ? a.wts32[f] : 1.0f, w1 = windowed ? a.wts32[f + 1] : 1.0f;
 #pragma unroll
-            for (int e = 0; e < NV; ++e) { weighted_texels(acc[e], p0[e], w0, windowed); weighted_texels(acc[e], prev[e], w1, windowed); }
+            for (int e = 0; e < NV; ++e) { weighted_texels(acc[e], p0[e], w0, true); weighted_texels(acc[e], prev[e], w1, true); }
         }
         for (; f + 1 < F; ++f) {
             load(prev, h + (size_t) ring_slot(a.head, f, F) * n);
-            const float w = a.wts32[f];
+            const float w = windowed ? a.wts32[f] : 1.0f;
 #pragma unroll
-            for (int e = 0; e < NV; ++e) weighted_texels(acc[e], prev[e], w, windowed);
+            for (int e = 0; e < NV; ++e) weighted_texels(acc[e], prev[e], w, true);
         }
         // prev == the previous newest slot == the gravity store (the same texels: render.c:2232-2243 copies it into the ring)
-        if (a.ops & OP_GRAVITY) {
-#pragma unroll
-            for (int e = 0; e < NV; ++e) tex[e] = gravity_r16(tex[e], prev[e], a.g, a.grav_sub, a.grav_int);
-        }
+        if (a.ops & OP_GRAVITY) gravity_all(prev);
         store(h + (size_t) a.head * n, tex);
         if (F > 1) {                                                         // render.c:2230: no averaging pass for one frame
-            const float wl = a.wts32[F - 1];
+            const float wl = windowed ? a.wts32[F - 1] : 1.0f;
 #pragma unroll
             for (int e = 0; e < NV; ++e) {
-                weighted_texels(acc[e], tex[e], wl, windowed);
+                weighted_texels(acc[e], tex[e], wl, true);
                 tex[e] = pack_unorm16(div_frames(acc[e].x, a.F_as_float, a.F_rcp), div_frames(acc[e].y, a.F_as_float, a.F_rcp));
             }
         }
     } else if (a.ops & OP_GRAVITY) {
         uint32_t st0[NV];
         load(st0, reinterpret_cast<const uint16_t*>(a.grav) + row * (size_t) n);
-#pragma unroll
-        for (int e = 0; e < NV; ++e) tex[e] = gravity_r16(tex[e], st0[e], a.g, a.grav_sub, a.grav_int);
+        gravity_all(st0);
         store(reinterpret_cast<uint16_t*>(a.grav_w) + row * (size_t) n, tex);
     }
 }
@@ -1036,7 +1127,8 @@ struct Frame {
                         off[j] = (uint32_t) out_index<P - 1>(tid, gi, r) * 8u;
                     }
                 }
-                apply_state_block<BLK, (LOG_NN <= GLV_STATE_PAIR_MAX)>(val, off, row, (uint32_t) N, a);
+                if constexpr (LOG_E >= 5) apply_state_block_tests<BLK, (LOG_NN <= GLV_STATE_PAIR_MAX)>(val, off, row, (uint32_t) N, a);
+                else apply_state_block<BLK, (LOG_NN <= GLV_STATE_PAIR_MAX)>(val, off, row, (uint32_t) N, a);
                 if (out_row == nullptr) continue;                     // uniform: output aliased to the gravity state
 #pragma unroll
                 for (int j = 0; j < BLK; ++j) {

@@ -352,6 +352,9 @@ glv_frame_kernel(const FrameArgs a) {
                     for (int b = 0; b < BB; ++b) tp[b] = bar_item_load<false>(lrow, a.bar_w, it[b], sub);   // slack: 2T >= 63 floats
 #pragma unroll
                     for (int b = 0; b < BB; ++b) nx[b] = items[(size_t) (s0 + BB + b) * G];   // table has one batch of padding
+                    // every load of the batch is ISSUED before the first sum: left to itself the backend sinks one step's four LDS reads to
+                    // their uses -- four exposed LDS round trips (read, lgkmcnt(0), multiply) per batch (profiles/r05/uniform_branches.txt)
+                    GLV_SCHED_FENCE();
 #pragma unroll
                     for (int b = 0; b < BB; ++b) {
                         total = __builtin_fmaf(total, it[b].keep, group_sum<GL>(bar_item_lane_sum(tp[b])));

@@ -17,8 +17,6 @@
 //   bar_item_*                   smooth_audio() bin averaging (smooth.glsl:13-40) in 64-tap chunks
 #pragma once
 
-#include <type_traits>
-
 #include "glv_core.h"
 
 namespace glv {
@@ -348,11 +346,8 @@ GLV_HD cf apply_state(cf val, uint32_t off, size_t row, uint32_t n, const FrameA
 #ifndef GLV_STATE_PAIR_MAX
 #define GLV_STATE_PAIR_MAX 12
 #endif
-// The per-point-test form of apply_state_block below (window or plain sum, gravity or not: tested for every point).  Kept for the kernels with
-// 32 points per lane (N >= 16384): there the straight-line form raises the f32 chains' scratch from 68-160 to 190-220 bytes per lane and
-// costs configs[2] 16 % (profiles/r05/uniform_branches.txt); everywhere else the straight-line form is the one that runs.
 template <int NV, bool PAIR = false>
-GLV_HD void apply_state_block_tests(cf (&val)[NV], const uint32_t (&off)[NV], size_t row, uint32_t n, const FrameArgs& a) {
+GLV_HD void apply_state_block(cf (&val)[NV], const uint32_t (&off)[NV], size_t row, uint32_t n, const FrameArgs& a) {
     if (a.ops & OP_AVERAGE) {
         float* h = a.hist + row * (size_t) a.F * n;                          // uniform
         const uint32_t F = a.F;
@@ -411,83 +406,6 @@ GLV_HD void apply_state_block_tests(cf (&val)[NV], const uint32_t (&off)[NV], si
                 acc[e].x = (float) ((double) acc[e].x + wl * (double) val[e].x);
                 acc[e].y = (float) ((double) acc[e].y + wl * (double) val[e].y);
             } else { acc[e].x = acc[e].x + val[e].x; acc[e].y = acc[e].y + val[e].y; }
-            val[e].x = acc[e].x / a.F_as_float;                              // render.c:761
-            val[e].y = acc[e].y / a.F_as_float;
-        }
-    } else if (a.ops & OP_GRAVITY) {
-        const float* gs = a.grav + row * (size_t) n;                         // uniform
-        float* gw = a.grav_w + row * (size_t) n;
-        cf st0[NV];
-#pragma unroll
-        for (int e = 0; e < NV; ++e) st0[e] = ld<cf>(gs, off[e]);
-#pragma unroll
-        for (int e = 0; e < NV; ++e) {
-            val[e].x = gravity(val[e].x, st0[e].x, a.g); val[e].y = gravity(val[e].y, st0[e].y, a.g);
-            st<cf>(gw, off[e], val[e]);
-        }
-    }
-}
-
-template <int NV, bool PAIR = false>
-GLV_HD void apply_state_block(cf (&val)[NV], const uint32_t (&off)[NV], size_t row, uint32_t n, const FrameArgs& a) {
-    // Window or plain sum (uniform) is NOT tested per point: in the unrolled code every such test was a pair of scalar branches of its own
-    // (see gl16_state_block), ~100 pairs per lane and row at F = 5.  The plain sum is the windowed form with weight 1:
-    // (float) ((double) acc + 1.0 * (double) x) == acc + x bit for bit -- the product is exact, and rounding a sum of two floats to double first
-    // is innocuous (53 >= 2 * 24 + 2 bits) -- so one straight-line version serves both; the rare unwindowed chain pays fp64 adds for it.
-    const bool win = a.avg_window != 0;
-    if (a.ops & OP_AVERAGE) {
-        float* h = a.hist + row * (size_t) a.F * n;                          // uniform
-        const uint32_t F = a.F;
-        cf acc[NV], prev[NV];
-#pragma unroll
-        for (int e = 0; e < NV; ++e) { acc[e].x = 0.0f; acc[e].y = 0.0f; prev[e].x = 0.0f; prev[e].y = 0.0f; }
-        if (F == 1) {
-#pragma unroll
-            for (int e = 0; e < NV; ++e) prev[e] = ld<cf>(h + (size_t) a.head * n, off[e]);
-        }
-        // oldest .. second newest, two history frames per trip (PAIR): their 2 NV loads are in flight
-        // together -- the epilogue is a chain of dependent HBM round trips (F - 1 per block), halving their number is
-        // worth more than the NV extra registers; the accumulation order (render.c:757-760) is unchanged
-        uint32_t f = 0;
-        if constexpr (PAIR) for (; f + 2 < F; f += 2) {
-            const float* hs0 = h + (size_t) ring_slot(a.head, f, F) * n;         // uniform
-            const float* hs1 = h + (size_t) ring_slot(a.head, f + 1, F) * n;     // uniform
-            cf p0[NV];
-#pragma unroll
-            for (int e = 0; e < NV; ++e) p0[e] = ld<cf>(hs0, off[e]);
-#pragma unroll
-            for (int e = 0; e < NV; ++e) prev[e] = ld<cf>(hs1, off[e]);
-            const double w0 = win ? a.wts[f] : 1.0, w1 = win ? a.wts[f + 1] : 1.0;
-#pragma unroll
-            for (int e = 0; e < NV; ++e) {                                   // render.c:759, double product
-                acc[e].x = (float) ((double) acc[e].x + w0 * (double) p0[e].x);
-                acc[e].y = (float) ((double) acc[e].y + w0 * (double) p0[e].y);
-                acc[e].x = (float) ((double) acc[e].x + w1 * (double) prev[e].x);
-                acc[e].y = (float) ((double) acc[e].y + w1 * (double) prev[e].y);
-            }
-        }
-        for (; f + 1 < F; ++f) {
-            const float* hs = h + (size_t) ring_slot(a.head, f, F) * n;      // uniform
-#pragma unroll
-            for (int e = 0; e < NV; ++e) prev[e] = ld<cf>(hs, off[e]);
-            const double w = win ? a.wts[f] : 1.0;
-#pragma unroll
-            for (int e = 0; e < NV; ++e) {                                   // render.c:759, double product
-                acc[e].x = (float) ((double) acc[e].x + w * (double) prev[e].x);
-                acc[e].y = (float) ((double) acc[e].y + w * (double) prev[e].y);
-            }
-        }
-        const double wl = win ? a.wts[F - 1] : 1.0;
-        const bool grav = (a.ops & OP_GRAVITY) != 0;
-#pragma unroll
-        for (int e = 0; e < NV; ++e) {
-            {                                                                // (a select on the uniform flag, not a branch per point)
-                const float gx = gravity(val[e].x, prev[e].x, a.g), gy = gravity(val[e].y, prev[e].y, a.g);
-                val[e].x = grav ? gx : val[e].x; val[e].y = grav ? gy : val[e].y;
-            }
-            st<cf>(h + (size_t) a.head * n, off[e], val[e]);
-            acc[e].x = (float) ((double) acc[e].x + wl * (double) val[e].x);
-            acc[e].y = (float) ((double) acc[e].y + wl * (double) val[e].y);
             val[e].x = acc[e].x / a.F_as_float;                              // render.c:761
             val[e].y = acc[e].y / a.F_as_float;
         }
@@ -1127,8 +1045,7 @@ struct Frame {
                         off[j] = (uint32_t) out_index<P - 1>(tid, gi, r) * 8u;
                     }
                 }
-                if constexpr (LOG_E >= 5) apply_state_block_tests<BLK, (LOG_NN <= GLV_STATE_PAIR_MAX)>(val, off, row, (uint32_t) N, a);
-                else apply_state_block<BLK, (LOG_NN <= GLV_STATE_PAIR_MAX)>(val, off, row, (uint32_t) N, a);
+                apply_state_block<BLK, (LOG_NN <= GLV_STATE_PAIR_MAX)>(val, off, row, (uint32_t) N, a);
                 if (out_row == nullptr) continue;                     // uniform: output aliased to the gravity state
 #pragma unroll
                 for (int j = 0; j < BLK; ++j) {

@@ -353,8 +353,11 @@ glv_frame_kernel(const FrameArgs a) {
 #pragma unroll
                     for (int b = 0; b < BB; ++b) nx[b] = items[(size_t) (s0 + BB + b) * G];   // table has one batch of padding
                     // every load of the batch is ISSUED before the first sum: left to itself the backend sinks one step's four LDS reads to
-                    // their uses -- four exposed LDS round trips (read, lgkmcnt(0), multiply) per batch (profiles/r05/uniform_branches.txt)
-                    GLV_SCHED_FENCE();
+                    // their uses -- four exposed LDS round trips (read, lgkmcnt(0), multiply) per batch of TWO steps (N = 4096 GL chain + 80 bars
+                    // 1.645 -> 1.481 ms, N = 1024 1.318 -> 1.277, same box alternating: profiles/r05/uniform_branches.txt).  The six-step batches of
+                    // N >= 16384 keep the backend's order: there one sunk step of six costs less than 96 registers of loads held at once
+                    // (configs[2] 0.626 -> 0.643 ms with the fence on the same box)
+                    if constexpr (BB <= kBarBatch) GLV_SCHED_FENCE();
 #pragma unroll
                     for (int b = 0; b < BB; ++b) {
                         total = __builtin_fmaf(total, it[b].keep, group_sum<GL>(bar_item_lane_sum(tp[b])));

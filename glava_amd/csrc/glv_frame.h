@@ -428,22 +428,35 @@ GLV_HD void apply_state_block(cf (&val)[NV], const uint32_t (&off)[NV], size_t r
 // texels are one 8-byte access.  TWO: two history frames per trip.
 template <int NV, bool PAIRED, bool TWO>
 GLV_HD void gl16_state_block(uint32_t (&tex)[NV], const uint32_t (&off)[NV], size_t row, uint32_t n, const FrameArgs& a) {
+    // Every access is `uniform base + lane offset + compile-time constant` (off[e] - off[0] is a constant: the points of a lane are a fixed
+    // pattern).  The lane offset is re-defined opaquely per call: inside the history loop the backend otherwise hoists its zero-extension out of
+    // the loop and then forms a 64-bit address per access and trip with v_lshl_add_u64 (two registers each) instead of the
+    // `global_load v_off, s[base:base+1] offset:imm` form -- one 32-bit offset register for all of a slot's accesses.
+    auto lane_base = [&]() -> uint32_t {
+        uint32_t lb = off[0] / 2u;
+#if defined(__HIP_DEVICE_COMPILE__)
+        asm volatile("" : "+v"(lb));
+#endif
+        return lb;
+    };
     auto load = [&](uint32_t (&dst)[NV], const uint16_t* base) {
+        const uint32_t lb = lane_base();
         if constexpr (PAIRED) {
 #pragma unroll
-            for (int e = 0; e < NV; e += 2) { const u32x2 t = ld<u32x2>(base, off[e] / 2u); dst[e] = t.x; dst[e + 1] = t.y; }
+            for (int e = 0; e < NV; e += 2) { const u32x2 t = ld<u32x2>(base, lb + (off[e] - off[0]) / 2u); dst[e] = t.x; dst[e + 1] = t.y; }
         } else {
 #pragma unroll
-            for (int e = 0; e < NV; ++e) dst[e] = ld<uint32_t>(base, off[e] / 2u);
+            for (int e = 0; e < NV; ++e) dst[e] = ld<uint32_t>(base, lb + (off[e] - off[0]) / 2u);
         }
     };
     auto store = [&](uint16_t* base, const uint32_t (&src)[NV]) {
+        const uint32_t lb = lane_base();
         if constexpr (PAIRED) {
 #pragma unroll
-            for (int e = 0; e < NV; e += 2) st<u32x2>(base, off[e] / 2u, u32x2{src[e], src[e + 1]});
+            for (int e = 0; e < NV; e += 2) st<u32x2>(base, lb + (off[e] - off[0]) / 2u, u32x2{src[e], src[e + 1]});
         } else {
 #pragma unroll
-            for (int e = 0; e < NV; ++e) st<uint32_t>(base, off[e] / 2u, src[e]);
+            for (int e = 0; e < NV; ++e) st<uint32_t>(base, lb + (off[e] - off[0]) / 2u, src[e]);
         }
     };
     const uint32_t F = a.F;

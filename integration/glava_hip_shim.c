@@ -32,11 +32,13 @@ struct glv_box { unsigned long long magic; glv_state* st; };
  *   GLAVA_HIP_LOG_MODE=0|1|2       glv_params.log_mode: 1 (default) the hardware log2, <= 1.8e-7 relative on every input of the stage;
  *                                  0 the bit-faithful fp64 table log -- the reference's floats, bit for bit; 2 the audit form
  *   GLAVA_HIP_GL=0                 keep the accel path's GL passes on the GL (only the per-frame FFT runs on the MI355X)
- *   GLAVA_HIP_SMOOTH_FACTOR=<f>    SMOOTH_FACTOR of the pre-smoothing pass when the user's smooth_parameters.glsl changes it
- *                                  (a GLSL #define: struct gl_data does not carry it; default 0.025, smooth_parameters.glsl:72) */
+ *   GLAVA_HIP_SMOOTH_FACTOR=<f>    OVERRIDES the pre-smoothing pass's _SMOOTH_FACTOR.  Without it the factor is the host's own:
+ *                                  gl_data.smooth_factor (render.c:184, `#request setsmoothfactor` render.c:1198-1200), through the
+ *                                  same "%.6f" text the reference prepends to every shader as `#define _SMOOTH_FACTOR` (render.c:317-326)
+ *                                  and the GLSL compiler reads back as a float literal */
 static unsigned glv_hip_log_mode = 1;      /* glv_params.log_mode for new boxes (GLAVA_HIP_LOG_MODE; tests flip it) */
 static int glv_hip_env_done = 0, glv_hip_dev = 0, glv_hip_gl = 1;
-static float glv_hip_smooth_factor = 0.025f;
+static float glv_hip_smooth_factor = -1.0f;   /* < 0: none given, the host's gl_data.smooth_factor is used */
 static void glv_hip_env(void) {
     if (glv_hip_env_done) return;
     glv_hip_env_done = 1;
@@ -65,7 +67,14 @@ static void glv_hip_fill(const struct gl_data* d, size_t sz, glv_params* p) {
 static void glv_hip_fill_gl(const struct gl_data* d, size_t sz, glv_params* p) {
     glv_hip_fill(d, sz, p);
     p->gl_storage = 1; p->avg_window_kind = 1;
-    p->bars = (uint32_t) sz; p->bar_phase = 0.5f; p->smooth_factor = glv_hip_smooth_factor;
+    p->bars = (uint32_t) sz; p->bar_phase = 0.5f;
+    if (glv_hip_smooth_factor >= 0.0f) p->smooth_factor = glv_hip_smooth_factor;
+    else {
+        /* what smooth.glsl:25-27 computes with: the float literal of the header line shaderload() formats (render.c:317-326) */
+        char lit[64];
+        snprintf(lit, sizeof(lit), "%.6f", (double) d->smooth_factor);
+        p->smooth_factor = strtof(lit, NULL);
+    }
 }
 
 /* Parameters outside what the library takes -- a window that is not a power of two in [256, 32768] (setbufsize is
@@ -75,6 +84,10 @@ static void glv_hip_fill_gl(const struct gl_data* d, size_t sz, glv_params* p) {
 static bool glv_hip_supported(const struct gl_data* d, size_t sz) {
     return sz >= 256 && sz <= 32768 && (sz & (sz - 1)) == 0 && d->avg_frames >= 1 && d->avg_frames <= GLV_MAX_AVG_FRAMES;
 }
+
+/* ... and for the GL passes on the MI355X: a pre-smoothing factor the library builds tap tables for (a factor outside (0, 1] -- every
+   bar without taps, or NaN weights in the shader -- stays on the GL, whatever it renders there) */
+static bool glv_hip_gl_supported(const struct gl_data* d) { return d->smooth_factor > 0.0f && d->smooth_factor <= 1.0f; }
 
 static glv_state* glv_hip_slot(struct gl_data* d, void** udata, size_t sz) {
     struct glv_box* b = *udata;

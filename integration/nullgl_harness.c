@@ -92,6 +92,7 @@ typedef struct {
     unsigned hip_log_mode;      /* patched build only: glv_params.log_mode of the *_hip operators */
     int smooth_pass;            /* setsmoothpass (render.c:2277) */
     int hip_gl;                 /* patched build only: the accel path's GL passes on the MI355X too (GLAVA_HIP_GL) */
+    float smooth_factor;        /* setsmoothfactor (render.c:184, 1198-1200); 0 = rd_new's default 0.025 (render.c:916) */
 } nullgl_cfg;
 
 typedef struct { struct glava_renderer* r; size_t isz; } nullgl;
@@ -134,6 +135,7 @@ void* nullgl_create(const nullgl_cfg* c) {
     gl->avg_frames = c->avg_frames; gl->avg_window = c->avg_window != 0;
     gl->fft_scale = c->fft_scale; gl->fft_cutoff = c->fft_cutoff; gl->gravity_step = c->gravity_step;
     gl->ur = c->ur; gl->fr = c->fr; gl->smooth_pass = c->smooth_pass != 0;
+    gl->smooth_factor = c->smooth_factor != 0.0f ? c->smooth_factor : 0.025;
     gl->audio_tex_l = 11; gl->audio_tex_r = 12;
     gl->av_utex = calloc(c->avg_frames ? c->avg_frames : 1, sizeof(GLuint));   /* uniform locations of the averaging pass (render.c:1655-1660) */
     gl->stages_sz = 1;

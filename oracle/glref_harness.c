@@ -131,6 +131,7 @@ unsigned glref_bufsize(void* h) { return (unsigned) ((struct glava_renderer*) h)
 unsigned glref_avg_frames(void* h) { return (unsigned) ((struct glava_renderer*) h)->gl->avg_frames; }
 int glref_accel_fft(void* h) { return ((struct glava_renderer*) h)->gl->accel_fft; }
 float glref_ur(void* h) { return ((struct glava_renderer*) h)->gl->ur; }
+float glref_smooth_factor(void* h) { return ((struct glava_renderer*) h)->gl->smooth_factor; }
 
 static void glref_read(GLuint tex, size_t n, uint16_t* out) {
     if (!out) return;
@@ -154,7 +155,12 @@ int glref_update(void* h, float* lb, float* rb, size_t bsz, int modified, uint16
             int ch = bind->src_type == SRC_AUDIO_L ? 0 : bind->src_type == SRC_AUDIO_R ? 1 : -1;
             if (ch < 0 || !bind->optimize_fft) continue;
             uint16_t* base = texels + (size_t) ch * 4 * bsz;
+#ifdef GLV_GLREF_HIP
+            /* patched build, GL passes on the MI355X: the bind's own texture (render_hip.patch) is what the module samples */
+            glref_read(bind->hip_tex ? bind->hip_tex : ch == 0 ? gl->audio_tex_l : gl->audio_tex_r, bsz, base);
+#else
             glref_read(ch == 0 ? gl->audio_tex_l : gl->audio_tex_r, bsz, base);
+#endif
             glref_read(bind->gr_store.tex, bsz, base + bsz);
             glref_read(gl->avg_frames > 1 ? bind->av.tex : bind->gr_store.tex, bsz, base + 2 * bsz);
             glref_read(bind->sm.tex, bsz, base + 3 * bsz);

@@ -608,6 +608,73 @@ void glvo_bars_one_exact(const float* tex, size_t sz, size_t k, size_t bars, flo
     *ntaps = cnt;
 }
 
+/* What smooth_audio() may return for every bar when scale_audio()'s log() is only as accurate as GLSL implementations are held to:
+ * the loop's bounds are n * (-log(1 - 0.9 u) / 8), and log() carries an ABSOLUTE error of up to log_abs inside [0.5, 2] (2^-21 is what
+ * the SPIR-V / Vulkan precision table demands there; OpenGL promises no more, and Mesa's llvmpipe -- a polynomial log2 -- uses a good
+ * part of it just below 1, where -log(1 - 0.9 u) is small: tests/golden `n1024_F5w_sf010`, bar 13).  So either bound may sit anywhere
+ * within d = log_abs * sz / 8 (+ 4 ulps) of the value a correctly rounded log gives.  Over that box the mean is piecewise smooth and, for
+ * so small a box, monotone along each axis within a piece; the pieces end where the tap SET changes: frac(smin) crossing .5 (every tap's
+ * round() moves) and smax - smin crossing an integer (a tap appears).  The range is therefore taken over a 9 x 9 grid of the box, the
+ * points on either side of every such crossing inside it, and both directions of round() at an exact .5.
+ * vmin is evaluated on tex_lo, vmax on tex_hi (the weights are >= 0: the mean is monotone in every tap); pass the same row twice for one
+ * row's range.  ntaps[k] = the largest tap count met (the float error of an implementation's sums grows with it). */
+static double glvo_bars_mean_moved(const float* tex, size_t sz, float smin, float smax, int half_even, int* cnt_out) {
+    float m = (smax - smin) / 2.0F, rm = smin + m;
+    double avg = 0, weight = 0;
+    int cnt = 0;
+    for (float s = smin; s <= smax; s += 1.0F) {
+        double x = ((double) m - fabs((double) rm - (double) s)) / (double) m;
+        x = x < 0 ? 0 : (x > 1 ? 1 : x);
+        double w = 0.5 * sin(3.14159265358979323846 * x - 3.14159265358979323846 / 2) + 0.5;
+        long b = (long) (int) (half_even ? rintf(s) : roundf(s));
+        double tv = tex[b < (long) sz ? b : (long) sz - 1];
+        tv = tv > 0 ? (tv < 1 ? tv : 1) : 0;
+        avg += tv * w; weight += w; ++cnt;
+    }
+    *cnt_out = cnt;
+    return weight > 0 ? avg / weight : 0.0;
+}
+void glvo_bars_range_exact(const float* tex_lo, const float* tex_hi, size_t sz, double* vmin, double* vmax, int* ntaps, size_t bars,
+                           float smooth_factor, float phase, double log_abs) {
+    for (size_t k = 0; k < bars; ++k) {
+        float idx = phase == 0.0F ? (float) k / (float) bars : ((float) k + phase) / (float) bars;
+        float smin0 = glvo_scale_audio(glvo_clamp01(idx - smooth_factor)) * sz;
+        float smax0 = glvo_scale_audio(glvo_clamp01(idx + smooth_factor)) * sz;
+        double big = fabs((double) smax0) > 1 ? fabs((double) smax0) : 1;
+        double d = log_abs * (double) sz / 8.0 + 4.0 * (nextafterf((float) big, INFINITY) - (float) big);
+        float amin[9 + 3 * 3]; int na = 0;
+        for (int g = -4; g <= 4; ++g) amin[na++] = (float) ((double) smin0 + d * g / 4.0);
+        for (int q = -1; q <= 1; ++q) {                                  /* frac(smin) == .5 inside the box */
+            double c = floor((double) smin0) + 0.5 + q;
+            if (fabs(c - (double) smin0) <= d) { amin[na++] = nextafterf((float) c, -INFINITY); amin[na++] = (float) c; amin[na++] = nextafterf((float) c, INFINITY); }
+        }
+        double lo = INFINITY, hi = -INFINITY; int most = 0;
+        for (int a = 0; a < na; ++a) {
+            float smin = amin[a] < 0 ? 0 : amin[a];
+            float bmax[9 + 5 * 5]; int nb = 0;
+            for (int g = -4; g <= 4; ++g) bmax[nb++] = (float) ((double) smax0 + d * g / 4.0);
+            double q0 = rint((double) smax0 - (double) smin);
+            for (int q = -2; q <= 2; ++q) {                              /* smax - smin == an integer inside the box */
+                float c = smin + (float) (q0 + q);
+                if (fabs((double) c - (double) smax0) <= d && nb + 5 <= (int) (sizeof(bmax) / sizeof(bmax[0]))) {
+                    float dn = nextafterf(c, -INFINITY), up = nextafterf(c, INFINITY);
+                    bmax[nb++] = nextafterf(dn, -INFINITY); bmax[nb++] = dn; bmax[nb++] = c; bmax[nb++] = up; bmax[nb++] = nextafterf(up, INFINITY);
+                }
+            }
+            for (int b = 0; b < nb; ++b)
+                for (int he = 0; he < 2; ++he) {
+                    int cnt;
+                    double v = glvo_bars_mean_moved(tex_lo, sz, smin, bmax[b], he, &cnt);
+                    if (v < lo) lo = v;
+                    if (cnt > most) most = cnt;
+                    if (tex_hi != tex_lo) v = glvo_bars_mean_moved(tex_hi, sz, smin, bmax[b], he, &cnt);
+                    if (v > hi) hi = v;
+                }
+        }
+        vmin[k] = lo; vmax[k] = hi; ntaps[k] = most;
+    }
+}
+
 /* The library's s16 window product (glava_amd/csrc/glv_core.h apply_window_split): for every window position of size n the
  * float pair hi = (float) w, lo = (float) (w - hi), lo moved by +1, -1, +2, ... ulps until
  *     fmaf(x, hi, x * lo) == (float) ((double) x * w)        (render.c:794: float * double -> double -> float)

@@ -34,6 +34,11 @@ UR = 86.1328125
 CASES = [("n1024_F5w", 1024, 5, True, 9, 4), ("n1024_F6u", 1024, 6, False, 9, 4), ("n1024_F1", 1024, 1, True, 5, 4),
          ("n1024_F3w", 1024, 3, True, 6, 4), ("n1024_F2w", 1024, 2, True, 5, 4), ("n2048_F5w_loud", 2048, 5, True, 7, 0),
          ("n4096_F5w", 4096, 5, True, 7, 5)]
+# round 6: `#request setsmoothfactor` other than the shipped 0.025 -- gl_data.smooth_factor (render.c:184, 1198-1200)
+# reaches the pre-smoothing pass as the `#define _SMOOTH_FACTOR %.6f` header line (render.c:317-326).  name -> factor
+FACTOR_CASES = [("n1024_F5w_sf010", 1024, 5, True, 6, 4, 0.01), ("n1024_F5w_sf050", 1024, 5, True, 6, 4, 0.05), ("n4096_F5w_sf050", 4096, 5, True, 6, 5, 0.05),
+                ("n2048_F3w_sf010", 2048, 3, True, 5, 4, 0.01)]
+FACTORS = {c[0]: c[6] for c in FACTOR_CASES}
 
 
 def frames_of(name, n, count, shift):
@@ -42,12 +47,12 @@ def frames_of(name, n, count, shift):
     return pcm
 
 
-def config_dir(tmp, F, win):
+def config_dir(tmp, F, win, factor=None):
     """a user configuration directory like `glava --copy-config` makes: links to the installed tree, and its own
     smooth_parameters.glsl -- the reference's text with the two averaging requests changed (that file's #request lines are
     processed when the module's shaders include it, after everything rc.glsl and the command line said)"""
     import re
-    d = os.path.join(tmp, f"cfg_F{F}_{int(win)}")
+    d = os.path.join(tmp, f"cfg_F{F}_{int(win)}" + (f"_sf{factor}" if factor is not None else ""))
     os.makedirs(d, exist_ok=True)
     for e in os.listdir(SHADERS):
         dst = os.path.join(d, e)
@@ -57,13 +62,16 @@ def config_dir(tmp, F, win):
             txt, n1 = re.subn(r"#request setavgframes \d+", f"#request setavgframes {F}", txt)
             txt, n2 = re.subn(r"#request setavgwindow \w+", f"#request setavgwindow {'true' if win else 'false'}", txt)
             assert n1 == 1 and n2 == 1
+            if factor is not None:
+                txt, n3 = re.subn(r"#request setsmoothfactor [0-9.]+", f"#request setsmoothfactor {factor}", txt)
+                assert n3 == 1
             open(dst, "w").write(txt)
         else:
             os.symlink(os.path.join(SHADERS, e), dst)
     return d
 
 
-def run_case(n, F, win, pcm, tmp, so=SO, hip=None):
+def run_case(n, F, win, pcm, tmp, so=SO, hip=None, factor=None):
     """one renderer per case; rd_new can be called repeatedly in one process (every call makes its own context).
     so / hip: the patched build (oracle/_ref/libglvglref_hip.so) with hip = (GL passes on the MI355X?, log_mode)"""
     L = C.CDLL(so)
@@ -77,8 +85,11 @@ def run_case(n, F, win, pcm, tmp, so=SO, hip=None):
     L.glref_update.argtypes = [C.c_void_p, fp, fp, C.c_size_t, C.c_int, np.ctypeslib.ndpointer(np.uint16, flags="C_CONTIGUOUS")]
     L.glref_gl_version.restype = C.c_char_p; L.glref_gl_renderer.restype = C.c_char_p
     reqs = (C.c_char_p * 2)(b"setbufsize %d" % n, None)
-    h = L.glref_create(config_dir(tmp, F, win).encode(), SHADERS.encode(), reqs, UR)
+    h = L.glref_create(config_dir(tmp, F, win, factor).encode(), SHADERS.encode(), reqs, UR)
     assert h and L.glref_avg_frames(h) == F
+    if factor is not None:
+        L.glref_smooth_factor.restype = C.c_float; L.glref_smooth_factor.argtypes = [C.c_void_p]
+        assert L.glref_smooth_factor(h) == np.float32(factor), (L.glref_smooth_factor(h), factor)      # the request arrived in gl_data
     out = np.zeros((pcm.shape[0], 2, 4, n), np.uint16)
     for f in range(pcm.shape[0]):
         lb = (pcm[f, :, 0].astype(np.float32) / np.float32(65535)).copy()          # fifo.c:105-106
@@ -101,6 +112,13 @@ def main():
         vecs[f"{name}_tex"] = tex
         info = f"{ver} / {rend}"
         print(name, "ok", tex.shape, info, flush=True)
+    for name, n, F, win, count, shift, factor in FACTOR_CASES:
+        pcm = frames_of(name, n, count, shift)
+        tex, ver, rend = run_case(n, F, win, pcm, tmp, factor=factor)
+        vecs[f"{name}_pcm"] = pcm
+        vecs[f"{name}_tex"] = tex
+        vecs[f"{name}_factor"] = np.float32(factor)
+        print(name, "ok", tex.shape, factor, flush=True)
     vecs["gl_implementation"] = np.array(info)
     vecs["ur"] = np.float32(UR)
     np.savez_compressed(os.path.join(HERE, "gl_vectors.npz"), **vecs)

@@ -115,6 +115,9 @@ class Oracle:
             L.glvo_bars_at_exact.argtypes = [_f32p, C.c_size_t, np.ctypeslib.ndpointer(np.float64, flags="C_CONTIGUOUS"),
                                              np.ctypeslib.ndpointer(np.int32, flags="C_CONTIGUOUS"), np.ctypeslib.ndpointer(np.int32, flags="C_CONTIGUOUS"),
                                              C.c_size_t, C.c_float, C.c_float, C.c_int]
+            _f64q = np.ctypeslib.ndpointer(np.float64, flags="C_CONTIGUOUS")
+            L.glvo_bars_range_exact.argtypes = [_f32p, _f32p, C.c_size_t, _f64q, _f64q, np.ctypeslib.ndpointer(np.int32, flags="C_CONTIGUOUS"),
+                                                C.c_size_t, C.c_float, C.c_float, C.c_double]
             L.glvo_gl_chain_r16.argtypes = [_f32p, _f32p, _f32p, C.POINTER(C.c_size_t), C.c_size_t, C.c_size_t, C.c_int, C.c_int, C.c_float, C.c_float]
             L.glvo_unorm16.argtypes = [C.c_float]; L.glvo_unorm16.restype = C.c_uint16
             L.glvo_unorm16_to_float.argtypes = [C.c_uint16]; L.glvo_unorm16_to_float.restype = C.c_float

@@ -28,7 +28,7 @@ class Cfg(C.Structure):
     _fields_ = [("n", C.c_uint), ("bufscale", C.c_uint), ("interpolate", C.c_int), ("accel_fft", C.c_int),
                 ("avg_frames", C.c_uint), ("avg_window", C.c_int), ("fft_scale", C.c_float), ("fft_cutoff", C.c_float),
                 ("gravity_step", C.c_float), ("ur", C.c_float), ("fr", C.c_float), ("hip_log_mode", C.c_uint),
-                ("smooth_pass", C.c_int), ("hip_gl", C.c_int)]
+                ("smooth_pass", C.c_int), ("hip_gl", C.c_int), ("smooth_factor", C.c_float)]
 
 
 def load(path):
@@ -55,7 +55,7 @@ def load(path):
 
 def cfg(n, **kw):
     d = dict(n=n, bufscale=1, interpolate=0, accel_fft=0, avg_frames=5, avg_window=1, fft_scale=10.2, fft_cutoff=0.3,
-             gravity_step=4.2, ur=86.1328125, fr=144.0, hip_log_mode=1, smooth_pass=0, hip_gl=0)
+             gravity_step=4.2, ur=86.1328125, fr=144.0, hip_log_mode=1, smooth_pass=0, hip_gl=0, smooth_factor=0.0)
     d.update(kw)
     return Cfg(**d)
 
@@ -273,45 +273,61 @@ def test_handle_audio_fed_by_the_hipfifo_backend(glvlib, tmp_path, accel):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("name,n,F,win", [("n1024_F5w", 1024, 5, True), ("n1024_F6u", 1024, 6, False), ("n1024_F3w", 1024, 3, True), ("n1024_F2w", 1024, 2, True),
-                                           ("n2048_F5w_loud", 2048, 5, True), ("n4096_F5w", 4096, 5, True)])
+                                           ("n2048_F5w_loud", 2048, 5, True), ("n4096_F5w", 4096, 5, True),
+                                           ("n1024_F5w_sf010", 1024, 5, True), ("n1024_F5w_sf050", 1024, 5, True), ("n4096_F5w_sf050", 4096, 5, True),
+                                           ("n2048_F3w_sf010", 2048, 3, True)])
 def test_patched_accel_path_uploads_the_texture_the_reference_samples(glvlib, name, n, F, win):
-    """VERDICT r4 item 2: the shipped pipeline BOUND into the reference host.  With integration/render_hip.patch applied and
+    """VERDICT r4 item 2 / r5 item 1: the shipped pipeline BOUND into the reference host.  With integration/render_hip.patch applied and
     setaccelfft on, handle_audio makes ONE call per bind and update (integration/glava_hip_shim.c transform_gl_hip ->
     glv_gl_texture: transform_fft, GL_R16 upload, GL_MAX store + gravity pass, ring + average pass, pre-smoothing pass on the MI355X),
     skips render.c:2188-2303 and uploads the result as GL_UNSIGNED_SHORT texels into the bind's texture -- the one the module samples.
-    The frames are the ones tests/golden/gl_vectors.npz was recorded with, by the UNPATCHED reference over Mesa llvmpipe: the patched
-    host's texture must be the reference's `sm` texture (setsmoothpass on) / `av` texture (off) -- to the end-to-end standard of
-    tests/test_gl_reference.py: within one texel step (an upload texel that took the other neighbour at a tie travels on as at most
-    that step), fragile tap sets of the smooth pass excluded.  A frame without new audio uploads nothing: the texture keeps the last
-    result (render.c:2268-2272).  No GL_FLOAT upload happens at all on this path."""
-    from test_gl_reference import GOLD, UR, AV, SM, exact_smooth
+    The frames are the ones tests/golden/gl_vectors.npz was recorded with, by the UNPATCHED reference over Mesa llvmpipe, the
+    `#request setsmoothfactor` 0.01 / 0.05 cases included: the factor is gl_data.smooth_factor (render.c:184), set here as the request
+    handler sets it (render.c:1198-1200), and the shim must take it from there.  The patched host's texture is held to the standard of
+    the library itself (tests/test_gl_reference.py test_device_gl_passes_tie_aware): every texel inside the admissible range of the
+    exact model of the chain -- ChainBounds for the `av` texture (setsmoothpass off), smooth_bounds with the case's factor for the `sm`
+    texture: a single value, i.e. EQUALITY with the reference's llvmpipe texel, wherever no upload / average tie and no fragile tap set
+    is in play.  No +-1, no excluded bars.  A frame without new audio uploads nothing: the texture keeps the last result
+    (render.c:2268-2272).  No GL_FLOAT upload happens at all on this path."""
+    from test_gl_reference import GOLD, UR, AV, SM, LOG_ABS, ChainBounds, smooth_bounds, factor_of
     H = load(HIP_SO)
     if not hasattr(H, "nullgl_update_texels"):
         pytest.skip("libglvnullgl_hip.so predates the texel uploads")
     pcm, tex = GOLD[name + "_pcm"], GOLD[name + "_tex"]
+    request = float(GOLD[name + "_factor"]) if name + "_factor" in GOLD.files else 0.0      # 0: rd_new's default (render.c:916)
+    factor = factor_of(name)
+    assert "GLAVA_HIP_SMOOTH_FACTOR" not in os.environ
     for smooth in (1, 0):
-        h = H.nullgl_create(C.byref(cfg(n, accel_fft=1, avg_frames=F, avg_window=int(win), ur=UR, smooth_pass=smooth, hip_gl=1, hip_log_mode=0)))
+        h = H.nullgl_create(C.byref(cfg(n, accel_fft=1, avg_frames=F, avg_window=int(win), ur=UR, smooth_pass=smooth, hip_gl=1, hip_log_mode=0,
+                                        smooth_factor=request)))
         assert h
         tl, tr = np.zeros(n, np.uint16), np.zeros(n, np.uint16)
         nf = C.c_int(0)
+        bounds = [ChainBounds(n, F, win), ChainBounds(n, F, win)]
+        equal = total = 0
         for f in range(pcm.shape[0]):
             lb = (pcm[f, :, 0].astype(np.float32) / np.float32(65535)).copy(); rb = (pcm[f, :, 1].astype(np.float32) / np.float32(65535)).copy()
-            keep = lb.copy()
+            keep = (lb.copy(), rb.copy())
             assert H.nullgl_update_texels(h, lb, rb, n, 1, tl, tr, C.byref(nf)) == 2 and nf.value == 0
-            assert (lb == keep).all()                                   # the samples are left as they are
+            assert (lb == keep[0]).all() and (rb == keep[1]).all()    # the samples are left as they are
             for ch, got in enumerate((tl, tr)):
-                want = tex[f, ch, SM if smooth else AV].astype(np.int64)
-                d = np.abs(got.astype(np.int64) - want)
+                lo, hi = bounds[ch].frame(Oracle.transform_fft(keep[ch]))
+                av_lo, av_hi = lo, hi
                 if smooth:
-                    _, _, frag = exact_smooth(tex[f, ch, AV], n)
-                    assert d[~frag].max() <= 1, (name, smooth, f, ch, int(d[~frag].max()))
-                else:
-                    assert d.max() <= 1, (name, smooth, f, ch, int(d.max()))
+                    lo, hi = smooth_bounds(lo.astype(np.uint16), hi.astype(np.uint16), n, factor)
+                want = tex[f, ch, SM if smooth else AV].astype(np.int64)
+                bad = (got < lo) | (got > hi)
+                assert not bad.any(), (name, smooth, f, ch, int(bad.sum()), np.flatnonzero(bad)[:4])
+                if smooth and request:                                  # (the reference's own texels: in the range a GLSL log() opens around it)
+                    lo, hi = smooth_bounds(av_lo.astype(np.uint16), av_hi.astype(np.uint16), n, factor, LOG_ABS)
+                assert ((lo <= want) & (want <= hi)).all()
+                equal += int((got == want).sum()); total += n
             if f == 2:                                                  # a rendered frame without new audio
                 last = (tl.copy(), tr.copy())
                 assert H.nullgl_update_texels(h, lb, rb, n, 0, tl, tr, C.byref(nf)) == 0 and nf.value == 0
                 assert (tl == last[0]).all() and (tr == last[1]).all()
         H.nullgl_destroy(h)
+        print(name, "smooth" if smooth else "av", "texels equal to the reference's llvmpipe texels: %d of %d" % (equal, total))
 
 
 def test_render_hip_patch_applies_to_the_reference_and_compiles(tmp_path):
@@ -332,7 +348,7 @@ def test_render_hip_patch_applies_to_the_reference_and_compiles(tmp_path):
     assert sorted(p.name for p in tree.iterdir()) == ["render.c"]
     txt = (tree / "render.c").read_text()
     for needle in ("transform_gl_hip(gl, &bind->hip_gl_slot", "GL_UNSIGNED_SHORT, bind->hip_texels", "goto glv_bound;", "glv_bound:", "transform_fga_hip",
-                   "glv_hip_release(bind->hip_gl_slot)"):
+                   "glv_hip_release(bind->hip_gl_slot)", "bind->hip_tex = create_1d_tex()", "glv_hip_gl_supported(gl)"):
         assert needle in txt, needle
     c = subprocess.run(["gcc", "-std=gnu11", "-O2", "-fcommon", "-w", "-fsyntax-only", "-I/root/reference/glava", "-I" + os.path.join(ROOT, "include"),
                         "-I" + os.path.join(ROOT, "integration"), "-DGLAVA_GLX", "-DGLAVA_UNIX", str(tree / "render.c")], capture_output=True, text=True)

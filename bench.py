@@ -241,6 +241,21 @@ def extra_configs(G, torch, device, a, peak_gbs):
         b3.close(); del qs
     gl["sm_out"] = sm_entries["full"]
     gl["sm_out"]["quarter_batch"] = sm_entries["quarter"]
+    # ... and as GLava actually consumes it (round 6, GLV_OP_BARS_ONLY): the modules sample the `sm` texture and nothing else (smooth.glsl:62),
+    # and smooth_audio() reaches bins below 0.288 n + half a window -- the gravity store, ring and average of the bins beyond are dead values
+    # the reference's GL passes compute for nobody.  The chain keeps and computes only the live bins; the `sm` texels are bit-identical
+    # (tests/test_gl_fused.py).  roofline_frac is against THIS chain's own algorithmic bytes (PCM 4 N + live state + `sm` 4 N); frac_of_28N
+    # prices the same frames at the full chain's bytes for comparison with sm_out -- it is NOT a roofline claim.
+    qs = torch.empty((s, 2, n), dtype=torch.int16, device="cuda")
+    b5 = G.Batch(psm, s, G.OP_GRAVITY | G.OP_AVERAGE | G.OP_BARS | G.OP_BARS_ONLY, device=device)
+    dt, kms = run(b5, lambda: b5.process_s16(pcm, qs, smops, st0))
+    gl["sm_out_live"] = entry(f"the shipped pipeline with the state kept only where the pre-smoothing pass samples (GLV_OP_BARS_ONLY: live bins {b5.live_bins()} of {n}, "
+                              f"kept in whole last-pass blocks), {s} streams, two launches, same `sm` texels bit for bit; bytes: 4 N + (4 (F - 1) + 4) L + 4 N per frame",
+                              s, b5.algorithmic_bytes(smops), dt, kms)
+    gl["sm_out_live"]["launches_per_step"] = b5.last_launches()
+    gl["sm_out_live"]["live_bins"] = b5.live_bins()
+    gl["sm_out_live"]["frac_of_28N"] = 28 * n * s / (gl["sm_out_live"]["avg_kernel_ms"] * 1e-3) / 1e9 / peak_gbs
+    b5.close(); del qs
     s3 = max(s // 4, 1)
     # the pre-smoothing kernel by itself on rows already in HBM: its roofline is the f32 matrix rate (157.3 TFLOP/s dense at nominal
     # clock, MI355X_MICROARCH.md), counted on the USEFUL multiply-adds (smooth_audio()'s own taps; the tiles' padding is not counted)

@@ -322,6 +322,18 @@ struct glv_batch {
     float* d_bar_wsum = nullptr;
     glv::BarTile* d_bar_rounds = nullptr;
     uint32_t bar_ntiles = 0, bar_nrounds = 0, bar_ring_bins = 0, bar_bins_needed = 0;      // bar_bins_needed: bins of a row the many-bars kernels sample (0: all)
+    // GLV_OP_BARS_ONLY (gl_storage 1 + many bars through the integer pass): the chain lives below bar_bins_needed -- when EVERY kernel configuration of
+    // the size keeps those bins alive in its live class (a compile-time share of the row, FrameGeometry::live_points; whichever configuration a call
+    // runs, the bins the bars sample are maintained); 0: every bin is live (no flag, or the bars reach further than the live classes keep: the full chain)
+    uint32_t live_bins_now = 0;                     // refreshed with the bar tables (update_live_bins)
+    uint32_t live_bins() const { return live_bins_now; }
+    void update_live_bins() {
+        live_bins_now = 0u;
+        if (!(ops_mask & GLV_OP_BARS_ONLY) || bar_bins_needed == 0 || bar_bins_needed >= p.n) return;
+        for (int v = 0; v < glv::frame_variants(log_nn); ++v)
+            if ((uint32_t) glv::frame_geometry(log_nn, v).live_points * 2u < bar_bins_needed) return;
+        live_bins_now = bar_bins_needed;
+    }
     glv::BarRowsTables rows_tables() const { return glv::BarRowsTables{d_bar_mtiles, bar_ntiles, d_bar_wt, d_bar_wsum, d_bar_rounds, bar_nrounds, bar_ring_bins}; }
     // the same pass over TEXEL rows (the GL chains, gl_storage != 0): exact integer arithmetic on the i8 matrix cores (glv_tables.h make_bar_itiles)
     glv::BarMTile* d_bar_itiles = nullptr; int8_t* d_bar_wq = nullptr; glv::BarIFin* d_bar_fin = nullptr; glv::BarTile* d_bar_irounds = nullptr;
@@ -528,7 +540,7 @@ int ensure_bar_tables(glv_batch* b) {
     HIP_TRY(hipMemcpy(b->d_bar_w, w.data(), sizeof(float) * w.size(), hipMemcpyHostToDevice));
     b->bar_count = b->p.bars; b->bar_factor = b->p.smooth_factor; b->bar_phase = b->p.bar_phase;
     // many bars (the pre-smoothing pass): tiles of 32 bars for the chain kernels; rounds for the smallest LDS ring that takes them
-    b->bar_ntiles = 0; b->bar_nrounds = 0; b->bar_ring_bins = 0; b->bar_bins_needed = 0;
+    b->bar_ntiles = 0; b->bar_nrounds = 0; b->bar_ring_bins = 0; b->bar_bins_needed = 0; b->live_bins_now = 0;
     if (b->p.bars >= glv::kBarSeqMin) {
         std::vector<glv::BarMTile> mtiles;
         std::vector<glv::BarTile> rounds;
@@ -549,6 +561,7 @@ int ensure_bar_tables(glv_batch* b) {
         b->bar_bins_needed = 0;
         for (const glv::BarDesc& d : desc) b->bar_bins_needed = d.first_bin + d.count > b->bar_bins_needed ? d.first_bin + d.count : b->bar_bins_needed;
         b->bar_bins_needed = (b->bar_bins_needed + 63u) & ~63u;                     // whole store instructions (and slack for the fill's 16-byte loads)
+        b->update_live_bins();
         if (!rounds.empty()) {
             HIP_TRY(hipMalloc(&b->d_bar_rounds, sizeof(glv::BarTile) * rounds.size()));
             HIP_TRY(hipMemcpy(b->d_bar_rounds, rounds.data(), sizeof(glv::BarTile) * rounds.size(), hipMemcpyHostToDevice));
@@ -631,7 +644,12 @@ int batch_prepare(glv_batch* b) {
         // -- the test must cover EVERY chain process() would run unfused (its `fused_bars`): the float chain's bars as texels
         // (BARS | R16 with gl_storage 0) leave through glv_bars_kernel, the audit log (log_mode 2) takes the GL passes one by one, and
         // GLV_UNFUSED_BARS forces two launches; only the GL_R16 chain whose every kernel configuration takes the bars goes without
-        bool all_fused = (b->ops_mask & (GLV_OP_GRAVITY | GLV_OP_AVERAGE)) != 0 && !(b->ops_mask & GLV_OP_SMOOTH) && b->p.gl_storage == 1
+        // A FLOAT chain (gl_storage 0) whose every kernel configuration takes the bars goes without as well (16384 stereo streams of
+        // N = 4096 would hold 512 MiB nothing reads) -- unless the creation mask announces GLV_OP_R16: its bars as GL_R16 texels leave
+        // through glv_bars_kernel, from the scratch rows (the mask's R16 bit is that hint and nothing else; gravity-only chains read the
+        // state).  gl_storage 2 takes the GL passes one by one and always parks the rows.
+        bool all_fused = (b->ops_mask & (GLV_OP_GRAVITY | GLV_OP_AVERAGE)) != 0 && !(b->ops_mask & GLV_OP_SMOOTH)
+                         && (b->p.gl_storage == 1 || (b->p.gl_storage == 0 && !(b->ops_mask & GLV_OP_R16)))
                          && b->p.log_mode != 2 && !b->unfused_bars;
         for (int v = 0; v < glv::frame_variants(b->log_nn) && v < glv_batch::kMaxVariants; ++v) all_fused = all_fused && b->bar_fusable[v];
         if (!all_fused && !b->d_scratch) HIP_TRY(hipMalloc(&b->d_scratch, sizeof(float) * (size_t) b->rows * b->p.n));
@@ -643,13 +661,13 @@ int batch_prepare(glv_batch* b) {
         b->attr_log_mode = (int) b->p.log_mode;
         glv::FrameArgs a;
         std::memset(&a, 0, sizeof(a));
-        const struct { unsigned ops; bool bars; uint32_t gl; } cls[] = {
-            {GLV_OP_FFT, false, 0}, {GLV_OP_FFT | GLV_OP_R16, false, 0}, {GLV_OP_FFT | GLV_OP_GRAVITY, false, 0}, {GLV_OP_FFT | GLV_OP_GRAVITY | GLV_OP_R16, false, 0},
-            {GLV_OP_FFT | GLV_OP_GRAVITY, true, 0}, {GLV_OP_FFT | GLV_OP_GRAVITY, false, 1}, {GLV_OP_FFT | GLV_OP_GRAVITY, true, 1}};
+        const struct { unsigned ops; bool bars; uint32_t gl, live; } cls[] = {
+            {GLV_OP_FFT, false, 0, 0}, {GLV_OP_FFT | GLV_OP_R16, false, 0, 0}, {GLV_OP_FFT | GLV_OP_GRAVITY, false, 0, 0}, {GLV_OP_FFT | GLV_OP_GRAVITY | GLV_OP_R16, false, 0, 0},
+            {GLV_OP_FFT | GLV_OP_GRAVITY, true, 0, 0}, {GLV_OP_FFT | GLV_OP_GRAVITY, false, 1, 0}, {GLV_OP_FFT | GLV_OP_GRAVITY, true, 1, 0}, {GLV_OP_FFT | GLV_OP_GRAVITY, false, 1, 1}};
         for (int in_mode = 0; in_mode < kInKinds; ++in_mode)
             for (int v = 0; v < glv::frame_variants(b->log_nn); ++v)
                 for (const auto& c : cls) {
-                    a.ops = c.ops; a.gl_storage = c.gl; a.bars_out = c.bars ? reinterpret_cast<float*>(16) : nullptr;
+                    a.ops = c.ops; a.gl_storage = c.gl; a.bars_out = c.bars ? reinterpret_cast<float*>(16) : nullptr; a.live_points = c.live;
                     (void) glv::launch_frame(b->log_nn, in_mode, (int) b->p.log_mode, v, a, 0, nullptr);
                 }
         (void) hipGetLastError();
@@ -673,6 +691,8 @@ int check_ops(const glv_batch* b, unsigned ops, const float* d_out) {
         return fail(GLV_ERR_STATE, "ops 0x%x need state the batch was not created with (ops_mask 0x%x)", ops, b->ops_mask);
     if (stateful && b->state16 != (b->p.gl_storage == 1))
         return fail(GLV_ERR_STATE, "gl_storage=%u: the state of this batch was created as %s", b->p.gl_storage, b->state16 ? "GL_R16 texels (gl_storage 1)" : "floats (gl_storage 0 / 2)");
+    if ((b->ops_mask & GLV_OP_BARS_ONLY) && stateful && !(ops & GLV_OP_BARS))
+        return fail(GLV_ERR_STATE, "the batch was created with GLV_OP_BARS_ONLY: its state lives only below the bins the bars sample, a stateful call must ask for GLV_OP_BARS (ops 0x%x)", ops);
     if ((ops & GLV_OP_WRANGE) && (ops & GLV_OP_FFT)) return fail(GLV_ERR_INVALID, "GLV_OP_WRANGE excludes GLV_OP_FFT");
     if ((ops & GLV_OP_RAW) && !(ops & GLV_OP_FFT)) return fail(GLV_ERR_INVALID, "GLV_OP_RAW needs GLV_OP_FFT");
     if ((ops & GLV_OP_MAGNITUDE) && (ops & (GLV_OP_FFT | GLV_OP_WRANGE))) return fail(GLV_ERR_INVALID, "GLV_OP_MAGNITUDE excludes GLV_OP_FFT and GLV_OP_WRANGE");
@@ -738,7 +758,7 @@ int process(glv_batch* b, const void* d_in, int in_mode, float* d_out, unsigned 
     if (ops & GLV_OP_BARS) {
         if (fused_bars || (state_is_output && !b->p.gl_storage)) d_out = nullptr;
         else {
-            if (!b->d_scratch) return fail(GLV_ERR_STATE, "this GLV_OP_BARS chain needs the internal spectra rows: announce it in glv_batch_create's ops_mask (GLV_OP_BARS together with the chain's other operators)");
+            if (!b->d_scratch) return fail(GLV_ERR_STATE, "this GLV_OP_BARS chain needs the internal spectra rows: announce it in glv_batch_create's ops_mask (GLV_OP_BARS together with the chain's other operators; GLV_OP_R16 too when a float chain's bars are wanted as texels)");
             d_out = b->d_scratch;
         }
     }
@@ -775,6 +795,8 @@ int process(glv_batch* b, const void* d_in, int in_mode, float* d_out, unsigned 
         // the rows go to the bars of a second launch and nowhere else (the scratch rows): what those bars do not sample is not stored
         if ((ops & GLV_OP_BARS) && !fused_bars && d_out == b->d_scratch && b->bar_bins_needed != 0 && b->bar_bins_needed < b->p.n)
             a.out_limit = b->bar_bins_needed * 4u;
+        // GLV_OP_BARS_ONLY: ... and what they do not sample is not computed, nor is its state kept (kernel class 7; check_ops vetted the call)
+        if (b->live_bins() != 0) a.live_points = b->live_bins() / 2u;
         // ... and they go there as what they are, 16-bit texels (uint16 [rows][n] in the scratch rows), when the second launch is the
         // integer matrix-core pass (many bars: the pre-smoothing pass)
         const bool bars_i8 = (ops & GLV_OP_BARS) && !fused_bars && b->p.bars >= glv::kBarSeqMin && b->bars_i8();
@@ -1198,7 +1220,11 @@ uint64_t glv_batch_algorithmic_bytes(const glv_batch* b, unsigned ops, int input
     //   gl_storage 2 (pass by pass): the transform's f32 spectra are written and read back by the gravity / average pass (+16N)
     const uint64_t N = b->p.n, F = b->p.avg_frames;
     const bool stateful = (ops & (GLV_OP_GRAVITY | GLV_OP_AVERAGE)) != 0;
-    const uint64_t sv = (b->state16 && stateful) ? 4 * N : 8 * N;          // one state slot of both channels
+    //   GLV_OP_BARS_ONLY: state traffic is counted for the live bins L only -- the bins the bars sample, NOT the (larger) share of the row the kernel
+    //   class keeps (FrameGeometry::live_points: an implementation granularity, its extra bytes are traffic above the algorithmic figure)
+    uint64_t L = N;
+    if (b->live_bins() != 0 && stateful && (ops & GLV_OP_BARS)) L = b->live_bins();
+    const uint64_t sv = (b->state16 && stateful) ? 4 * L : 8 * N;          // one state slot of both channels
     uint64_t per = input_is_s16 ? 4 * N : 8 * N;
     const bool bars = (ops & GLV_OP_BARS) != 0;
     if (bars) per += (uint64_t) ((ops & GLV_OP_R16) ? 4 : 8) * b->p.bars;
@@ -1209,7 +1235,15 @@ uint64_t glv_batch_algorithmic_bytes(const glv_batch* b, unsigned ops, int input
     return per * b->streams;
 }
 
+uint32_t glv_batch_live_bins(const glv_batch* b) { return b ? b->live_bins() : 0u; }
+
 const char* glv_batch_kernel_name(const glv_batch* b) { return b ? b->kernel_name : ""; }
+
+int glv_batch_bars_arithmetic(const glv_batch* b) {
+    if (!b || b->bar_count == 0 || !b->d_bar_desc) return GLV_BARS_NONE;
+    if (b->p.bars < glv::kBarSeqMin) return GLV_BARS_F32_CHAIN;
+    return b->p.gl_storage != 0 && b->bars_i8() ? GLV_BARS_I8_EXACT : GLV_BARS_F32_MATRIX;
+}
 
 int glv_batch_last_grid(const glv_batch* b) { return b ? b->last_grid : 0; }
 int glv_batch_last_launches(const glv_batch* b) { return b ? b->last_launches : 0; }

@@ -80,6 +80,9 @@ struct FrameArgs {
     uint32_t out_limit;    // gl_storage 1, rows handed to a later kernel only (the bars of a second launch): bytes of a float row that are
                            // written at all -- the pre-smoothing pass samples bins below 0.31 n, the rest of the row is not stored (0: no limit);
                            // texel rows (OP_R16: what the i8 matrix-core pass reads) stop at the same bin, i.e. at half as many bytes
+    uint32_t live_points;  // gl_storage 1, GLV_OP_BARS_ONLY batches (0: every point): complex points [0, live_points) of a row are all the chain's consumer (the
+                           // bars of a second launch) ever samples -- the LIVE kernel class keeps the gravity store and the ring, and computes magnitude,
+                           // upload, gravity and average, for the last pass's blocks of L0 points that hold them, and touches nothing beyond
     double wts[64];        // window_frame weights, oldest first (render.c:661 as expanded at :766); GLV_MAX_AVG_FRAMES
     float wts32[64];       // the same rounded to float: the GL passes' arithmetic is the shader's, 32-bit (weighted_texels)
     // fused GLV_OP_BARS (stateful kernels, lanes-per-row a multiple of 64): the finished row goes to the
@@ -1082,11 +1085,22 @@ struct Frame {
     // frame costs 4 N (PCM) + 16 N (four ring slots) + 4 N (newest slot) + 4 N (texels) = 28 N bytes where the pass-by-pass form
     // (f32 intermediates, three launches) moved ~80 N.
     static constexpr int GL16_BLK = E <= 16 ? E : E / 2;       // points per block: the whole lane where the registers allow it
-    template <int LOG_MODE, int TILTREG, bool NONFINITE, bool TO_LDS>
+    // LIVE (GLV_OP_BARS_ONLY batches, kernel class 7): the last pass leaves point bitrev(r) * L0 + G in register slot (gi, r), so the row's
+    // blocks of L0 points are the same register slots in every lane.  The class keeps alive the first LIVE_RBLOCKS of the last pass's R
+    // blocks -- three eighths of the row (one half where the last pass is radix 2 or 4): smooth_audio() at the shipped parameters samples
+    // bins below 0.30 n -- as a COMPILE-TIME count: the lane's live points are one state block of LIVE_SLOTS entries with no test inside
+    // (a run-time count cost a scalar branch per point and 208 bytes of scratch: profiles/r06/live_chain.txt).  The host takes this
+    // class only when the bins the bars sample fit (glv_launch.h FrameGeometry::live_points), else the full chain of class 5.
+    static constexpr int LIVE_RBLOCKS = (3 * PassInfo<P - 1>::R + 7) / 8;
+    static constexpr int LIVE_SLOTS = LIVE_RBLOCKS * PassInfo<P - 1>::NG;
+    static constexpr int LIVE_POINTS = LIVE_RBLOCKS * PassInfo<P - 1>::L0;
+    static_assert(LIVE_SLOTS <= GL16_BLK, "the live points of a lane are one state block");
+    template <int LOG_MODE, int TILTREG, bool NONFINITE, bool TO_LDS, bool LIVE = false>
     GLV_HD static void epilogue_gl16(const cf (&v)[E], float* out_row, size_t row, int tid, const FrameArgs& a,
                                      const LogEntry* logtab, const cf* tl_reg = nullptr) {
         using PI = PassInfo<P - 1>;
         constexpr bool PAIRED = PI::NG >= 2;
+        constexpr int SLOTS = LIVE ? LIVE_SLOTS : E, BLK = LIVE ? LIVE_SLOTS : GL16_BLK;
         float tilt_base = 0.0f;
         if constexpr (TILTREG == 3 && LOG_MODE == 1) {
             tilt_base = tl_reg[0].x;
@@ -1115,19 +1129,19 @@ struct Frame {
         };
         const bool r16_out = (a.ops & OP_R16) != 0;                                // uniform
 #pragma unroll
-        for (int h0 = 0; h0 < E; h0 += GL16_BLK) {
-            uint32_t tex[GL16_BLK], off[GL16_BLK];
-            // enumeration order: r outer, gi inner => adjacent groups sit next to each other
+        for (int h0 = 0; h0 < SLOTS; h0 += BLK) {
+            uint32_t tex[BLK], off[BLK];
+            // enumeration order: r outer, gi inner => adjacent groups sit next to each other (LIVE: r in the order of the row's blocks)
 #pragma unroll
-            for (int j = 0; j < GL16_BLK; ++j) {
-                const int idx = h0 + j, r = idx / PI::NG, gi = idx % PI::NG;
+            for (int j = 0; j < BLK; ++j) {
+                const int idx = h0 + j, r = LIVE ? bitrev(idx / PI::NG, PI::RB) : idx / PI::NG, gi = idx % PI::NG;
                 tex[j] = texels(gi, r);
                 off[j] = (uint32_t) out_index<P - 1>(tid, gi, r) * 8u;
             }
-            gl16_state_block<GL16_BLK, PAIRED, (LOG_NN <= GLV_STATE_PAIR_MAX)>(tex, off, row, (uint32_t) N, a);
+            gl16_state_block<BLK, PAIRED, (LOG_NN <= GLV_STATE_PAIR_MAX)>(tex, off, row, (uint32_t) N, a);
             if (TO_LDS || !r16_out) {
 #pragma unroll
-                for (int j = 0; j < GL16_BLK; j += (PAIRED ? 2 : 1)) {
+                for (int j = 0; j < BLK; j += (PAIRED ? 2 : 1)) {
                     // (out_limit: a store instruction covers consecutive points across its lanes, so whole instructions fall away)
                     if (!TO_LDS && a.out_limit != 0u && off[j] >= a.out_limit) continue;
                     if constexpr (PAIRED) { cf2 two; two.a = texels_to_float(tex[j]); two.b = texels_to_float(tex[j + 1]); st<cf2>(out_row, off[j], two); }
@@ -1135,7 +1149,7 @@ struct Frame {
                 }
             } else {
 #pragma unroll
-                for (int j = 0; j < GL16_BLK; j += (PAIRED ? 2 : 1)) {
+                for (int j = 0; j < BLK; j += (PAIRED ? 2 : 1)) {
                     if (a.out_limit != 0u && off[j] >= a.out_limit) continue;      // (out_limit counts bytes of a FLOAT row: off[j] is that offset)
                     if constexpr (PAIRED) st<u32x2>(out_row, off[j] / 2u, u32x2{tex[j], tex[j + 1]});
                     else st<uint32_t>(out_row, off[j] / 2u, tex[j]);

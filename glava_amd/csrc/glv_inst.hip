@@ -153,6 +153,7 @@ static FrameGeometry geometry_of() {
     g.rows_per_trip = (TU::prefetch == 1 || TU::slots == 1) ? 2 * TU::slots : TU::slots;
     g.lds_bytes = (int) lds;
     g.log_e = TU::log_e; g.slots = TU::slots; g.twreg = TU::twreg; g.winlds = TU::winlds ? 1 : 0; g.nbuf = TU::nbuf;
+    g.live_points = FR::LIVE_POINTS;
     return g;
 }
 

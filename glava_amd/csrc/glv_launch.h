@@ -16,6 +16,8 @@ struct FrameGeometry {
     int bar_batch;      // steps per batch of the fused GLV_OP_BARS loop: its work lists are padded to multiples of this
     int lds_bytes, log_e, slots, twreg, winlds;   // for diagnostics / the wisdom file's comments
     int nbuf;           // exchange regions per row (0: split exchange -- no room to park a finished row: bars are a second launch)
+    int live_points;    // complex points [0, live_points) of a row are what the GLV_OP_BARS_ONLY kernel class of this configuration keeps alive (a compile-time
+                        // share of the last pass's blocks, glv_frame.h LIVE_RBLOCKS): the host takes that class only when the bars sample nothing beyond
 };
 
 // per-size production launchers, one translation unit each (glv_inst.hip -DGLV_LOG_NN=k)

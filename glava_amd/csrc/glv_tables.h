@@ -349,6 +349,9 @@ inline bool make_bar_itiles(std::vector<BarMTile>& itiles, std::vector<int8_t>& 
         const int P = bar_int_weights(tap_w.data() + desc[k].tap_offset, desc[k].count, W[k]);
         if (P == -2) return false;
         if (P < 0) continue;                                                    // weights sum to 0: {0, kBarIFinNone}, every digit 0
+        // bar_int_digits splits into three SIGNED bytes: |W| must stay below 2^23 - 2^16 (true while every shader weight is <= 1 -- smooth.glsl's window
+        // functions are -- and its share of the sum <= 1; a weight function that breaks it takes the f32 form, announced by glv_batch_bars_arithmetic)
+        for (const int32_t x : W[k]) if (x > 127 * 65536 || x < -127 * 65536) return false;   // d2 in [-127, 127] with room for the carries of d0, d1
         const uint32_t s = (uint32_t) P - 16u;
         fin[k] = BarIFin{(32896u << s) + (1u << (s - 1u)), s};
     }
@@ -364,6 +367,7 @@ inline bool make_bar_itiles(std::vector<BarMTile>& itiles, std::vector<int8_t>& 
         uint32_t lo = 0xffffffffu;
         for (uint32_t k = k0; k < k1; ++k) lo = desc[k].first_bin < lo ? desc[k].first_bin : lo;
         BarMTile t{k0, lo & ~15u, 0u, 0u};
+        if (lo == 0xffffffffu || tile_end(T) <= t.origin) return false;         // a tile without taps: the kernel's step countdown starts at steps >= 1
         t.steps = (tile_end(T) - t.origin + kBarIStepBins - 1u) / kBarIStepBins;
         if (T && t.origin < itiles[T - 1].origin) monotone = false;
         itiles.push_back(t);

@@ -19,8 +19,9 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("GLV_SPECTRUM_LIB") or os.path.join(HERE, "csrc", "libglvspectrum.so")
 
 OP_FFT, OP_GRAVITY, OP_AVERAGE, OP_RAW, OP_WRANGE, OP_BARS, OP_SMOOTH, OP_MAGNITUDE, OP_R16 = 1, 2, 4, 8, 16, 32, 64, 128, 256
-OP_PRIVATE_STATE, OP_RING_S16, OP_RING_F32, OP_OUTPUT_IS_STATE = 512, 1024, 2048, 4096
+OP_PRIVATE_STATE, OP_RING_S16, OP_RING_F32, OP_OUTPUT_IS_STATE, OP_BARS_ONLY = 512, 1024, 2048, 4096, 8192
 OK, ERR_INVALID, ERR_NO_DEVICE, ERR_HIP, ERR_NOMEM, ERR_STATE = 0, 1, 2, 3, 4, 5
+BARS_NONE, BARS_F32_CHAIN, BARS_F32_MATRIX, BARS_I8_EXACT = 0, 1, 2, 3
 
 
 class GlvError(RuntimeError):
@@ -94,6 +95,8 @@ def lib() -> C.CDLL:
         L.glv_prelude_lerp.argtypes = [C.c_int, vp, vp, vp, C.c_size_t, C.c_float, C.c_int, vp]
         L.glv_batch_timing_begin.argtypes = [vp]
         L.glv_batch_timing_end.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]
+        L.glv_batch_live_bins.argtypes = [vp]; L.glv_batch_live_bins.restype = C.c_uint32
+        L.glv_batch_bars_arithmetic.argtypes = [vp]; L.glv_batch_bars_arithmetic.restype = C.c_int
         L.glv_batch_algorithmic_bytes.argtypes = [vp, C.c_uint, C.c_int]
         L.glv_batch_algorithmic_bytes.restype = C.c_uint64
         L.glv_batch_kernel_name.argtypes = [vp]; L.glv_batch_kernel_name.restype = C.c_char_p
@@ -226,6 +229,13 @@ class Batch:
         ms, n = C.c_double(0), C.c_uint64(0)
         _check(lib().glv_batch_timing_end(self._h, C.byref(ms), C.byref(n)))
         return ms.value, n.value
+
+    def live_bins(self) -> int:
+        return int(lib().glv_batch_live_bins(self._h))
+
+    def bars_arithmetic(self) -> int:
+        """BARS_NONE / BARS_F32_CHAIN / BARS_F32_MATRIX / BARS_I8_EXACT (include/glv_spectrum.h glv_batch_bars_arithmetic)"""
+        return int(lib().glv_batch_bars_arithmetic(self._h))
 
     def algorithmic_bytes(self, ops: int, input_is_s16: bool = True) -> int:
         return int(lib().glv_batch_algorithmic_bytes(self._h, ops, int(input_is_s16)))

@@ -21,7 +21,8 @@
 extern "C" {
 #endif
 
-#define GLV_ABI_VERSION 5      /* 5 (round 5): + glv_gl_texture; GLV_OP_BARS over texel rows (gl_storage != 0, 256 bars or more) is the exact integer mean */
+#define GLV_ABI_VERSION 6      /* 5 (round 5): + glv_gl_texture; GLV_OP_BARS over texel rows (gl_storage != 0, 256 bars or more) is the exact integer mean
+                                  6 (round 6): + GLV_OP_BARS_ONLY, glv_batch_live_bins, glv_batch_bars_arithmetic; GLV_OP_R16 in a creation mask is a hint */
 
 /* status codes (0 = ok).  The reference has no error channel: it prints and calls
  * glava_abort() (glava/glava.h:17, glava/render.c passim); the in-tree shim maps any
@@ -86,6 +87,16 @@ enum {
                                    glava.c:487-494) the s16 device ring of glv_batch_ring_update_s16 / _append_s16; ring calls on
                                    a batch created without it are refused (GLV_ERR_STATE: nothing is allocated after creation) */
     GLV_OP_RING_F32 = 1u << 11, /* the same for the interleaved f32 ring of glv_batch_ring_update_f32 */
+    GLV_OP_BARS_ONLY = 1u << 13, /* glv_batch_create's ops_mask only (ABI 6), with GLV_OP_BARS on a gl_storage 1 batch: the caller promises that every
+                                   stateful call on this batch asks for GLV_OP_BARS -- the bars are all that is ever looked at (GLava's shipped
+                                   pipeline: the modules sample the pre-smoothed texture and nothing else, smooth.glsl:62).  smooth_audio() samples
+                                   bins below scale_audio(1) * n = 0.288 n plus half a window (SAMPLE_RANGE 0.9, SAMPLE_SCALE 8), so what the
+                                   reference's GL passes compute beyond that is dead: the chain then keeps its gravity store and ring, and
+                                   computes magnitude / upload / gravity / average, only for the bins the bars sample (rounded up to the
+                                   transform's last-pass block, 512 bins at n = 4096; glv_batch_live_bins tells) -- 15.5 n instead of 28 n bytes
+                                   per frame at n = 4096, F = 5.  The bars are bit-identical to those of a batch without the flag.  A stateful
+                                   call without GLV_OP_BARS, glv_batch_gravity_state and anything else that would read the state beyond the
+                                   live bins are refused (GLV_ERR_STATE) */
     GLV_OP_OUTPUT_IS_STATE = 1u << 12 /* opt-in, with a chain that ENDS in gravity (GLV_OP_GRAVITY without AVERAGE / SMOOTH / RAW, f32
                                    rows out, no gl_storage): transform_gravity stores every value twice, to its `applied` array and to
                                    the buffer (render.c:733-734) -- with this flag ONE array is kept: the call writes the spectra
@@ -310,6 +321,10 @@ int glv_batch_timing_end(glv_batch* b, double* kernel_ms, uint64_t* launches);
  * counted with its output copy (28 n) unless GLV_OP_OUTPUT_IS_STATE is in `ops` (20 n; a NULL d_out moves those 20 n too). */
 uint64_t glv_batch_algorithmic_bytes(const glv_batch* b, unsigned ops, int input_is_s16);
 
+/* GLV_OP_BARS_ONLY batches: the bins of a row the chain keeps alive, [0, glv_batch_live_bins) (what the bars sample, in whole store
+ * instructions); 0 for every other batch (all n bins live).  The kernels round it up to their last pass's block. */
+uint32_t glv_batch_live_bins(const glv_batch* b);
+
 /* Launch-geometry override for tuning (workgroups of the persistent frame kernel; 0 = automatic). */
 int glv_batch_set_grid(glv_batch* b, int grid);
 int glv_batch_last_grid(const glv_batch* b);      /* workgroups the last frame-kernel launch of this batch used */
@@ -348,6 +363,18 @@ int glv_batch_window_selftest(glv_batch* b, unsigned long long* mismatches, int*
 
 /* Name of the kernel the last process call launched (for matching rocprofv3 rows). */
 const char* glv_batch_kernel_name(const glv_batch* b);
+
+/* Which arithmetic GLV_OP_BARS over TEXEL rows (gl_storage != 0) runs on this batch with its current parameters (ABI 6):
+ *   GLV_BARS_NONE          the batch has no bar tables (bars == 0 / GLV_OP_BARS not announced)
+ *   GLV_BARS_F32_CHAIN     fewer than 256 bars: smooth_audio()'s float chain per bar (the modules' bars; fused into the transform where it fits)
+ *   GLV_BARS_I8_EXACT      256 bars or more, the documented form: exact integer weighted means on the i8 matrix cores (oracle glvo_bars_int_at)
+ *   GLV_BARS_F32_MATRIX    256 bars or more where the integer tables could NOT be made -- a bar wider than the largest LDS ring (1600 bins: very
+ *                          large smooth_factor, or n = 32768 with smooth_factor slightly above 0.025), 2^P scaling beyond 31 bits, a weight
+ *                          >= 2^23 / a tile without steps, or GLV_NO_BARS_I8 in the environment at creation: one f32 fma chain per bar on
+ *                          the f32 matrix cores (bit-equal to smooth_audio()'s float order, NOT to glvo_bars_int_at)
+ * Float rows (gl_storage 0) always take the float forms.  Callers and parity tests that depend on the exact form check this. */
+enum { GLV_BARS_NONE = 0, GLV_BARS_F32_CHAIN = 1, GLV_BARS_F32_MATRIX = 2, GLV_BARS_I8_EXACT = 3 };
+int glv_batch_bars_arithmetic(const glv_batch* b);
 
 /* ------------------------------------------------------------------------------------
  * 3. Several GPUs of one node (BASELINE configs[3]).  No reference counterpart.

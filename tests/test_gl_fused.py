@@ -444,14 +444,68 @@ def test_presmoothing_pass_of_the_gl_chains_over_random_parameters(glvlib):
             av.process_s16(d_pcm, oa, ops | G.OP_R16)
             assert _eq(o1, o2), (trial, n, bars, factor, phase, F, u)
         t_av = oa.cpu().numpy().view(np.uint16); t_sm = o1.cpu().numpy().view(np.uint16)
+        arith = sm1.bars_arithmetic()                   # the library SAYS which arithmetic ran (ABI 6): no either-or in the comparison
+        assert arith == sm2.bars_arithmetic() and arith in (G.BARS_I8_EXACT, G.BARS_F32_MATRIX), arith
         for r in (0, streams * 2 - 1):
-            w16 = np.zeros(bars, np.uint16)
-            rc = Oracle.lib().glvo_bars_int_at(np.ascontiguousarray(t_av[r]), n, w16.ctypes.data, None, bars, factor, phase)
-            if rc == 0 and (t_sm[r] == w16).all():
+            if arith == G.BARS_I8_EXACT:
+                w16 = np.zeros(bars, np.uint16)
+                rc = Oracle.lib().glvo_bars_int_at(np.ascontiguousarray(t_av[r]), n, w16.ctypes.data, None, bars, factor, phase)
+                assert rc == 0 and (t_sm[r] == w16).all(), (trial, n, bars, factor, phase, F, r, rc)
                 seen_int += 1
                 continue
             want = np.empty(bars, np.float32)
             Oracle.lib().glvo_bars_chunked_at((t_av[r].astype(np.float32) / np.float32(65535)).copy(), n, want, bars, factor, phase)
-            assert (t_sm[r] == Oracle.texels_r16(want)).all(), (trial, n, bars, factor, phase, F, r, rc)
+            assert (t_sm[r] == Oracle.texels_r16(want)).all(), (trial, n, bars, factor, phase, F, r)
         for b in (sm1, sm2, av): b.close()
     assert seen_int >= 16                               # most trials run the integer pass
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,F,factor,in_kind", [(1024, 5, 0.025, "s16"), (2048, 3, 0.05, "s16"), (4096, 5, 0.025, "s16"), (4096, 5, 0.025, "f32"), (4096, 2, 0.01, "s16"),
+                                                (8192, 5, 0.025, "s16"), (16384, 3, 0.025, "s16"), (32768, 2, 0.025, "s16")])
+def test_bars_only_chain_is_the_full_chain_on_the_bins_the_bars_sample(glvlib, n, F, factor, in_kind):
+    """GLV_OP_BARS_ONLY (round 6): GLava's modules sample the pre-smoothed texture and nothing else (smooth.glsl:62), and smooth_audio() reaches
+    bins below scale_audio(1) n = 0.288 n plus half a window -- what the reference's GL passes compute beyond is never looked at.  A batch
+    created with the flag keeps the gravity store and the ring, and computes magnitude / upload / gravity / average, for those bins only
+    (kernel class 7: a compile-time share of the last pass's blocks -- 3/8 of the row -- taken when the bars sample nothing beyond, else the full chain).  Its `sm` texels must equal, bit for bit and update after update
+    (loud, quiet, silent frames: the gravity store and every ring slot are exercised), those of a batch without the flag, in both kernel
+    configurations of the size; a stateful call without GLV_OP_BARS is refused; the algorithmic bytes shrink with the live bins."""
+    import torch
+    G = glvlib
+    streams = 9 if n <= 8192 else 3
+    kw = dict(n=n, avg_frames=F, avg_window_kind=1, gl_storage=1, bars=n, bar_phase=0.5, smooth_factor=factor)
+    mask = G.OP_GRAVITY | G.OP_AVERAGE | G.OP_BARS
+    ops = G.OP_FFT | G.OP_GRAVITY | G.OP_AVERAGE | G.OP_BARS | G.OP_R16
+    for variant in (0, 1):
+        full = G.Batch(G.Params(**kw), streams, mask)
+        live = G.Batch(G.Params(**kw), streams, mask | G.OP_BARS_ONLY)
+        try:
+            full.set_variant(variant); live.set_variant(variant)
+        except G.GlvError:
+            full.close(); live.close()
+            continue
+        L = live.live_bins()
+        assert full.live_bins() == 0 and live.bars_arithmetic() == G.BARS_I8_EXACT
+        if L == 0:                                      # the bars reach beyond what the live kernel classes keep (3/8 of the row): the full chain serves
+            assert factor > 0.03 or n <= 2048, (n, factor)
+            assert live.algorithmic_bytes(ops, in_kind == "s16") == full.algorithmic_bytes(ops, in_kind == "s16")
+        else:
+            assert 0.28 * n < L <= 0.5 * n and L % 64 == 0, (L, n)
+            assert live.algorithmic_bytes(ops, in_kind == "s16") < full.algorithmic_bytes(ops, in_kind == "s16")
+        o_f = torch.full((streams * 2, n), -1, dtype=torch.int16, device="cuda"); o_l = torch.full_like(o_f, -2)
+        for u in range(F + 3):
+            pcm = (lcg_pcm_fast(8100 + u + n, streams * 2 * n) // (1, 8, 64)[u % 3]).astype(np.int16)
+            if u == 2: pcm[:] = 0
+            if in_kind == "s16":
+                d_in = torch.from_numpy(pcm).cuda()
+                full.process_s16(d_in, o_f, ops); live.process_s16(d_in, o_l, ops)
+            else:
+                x = (pcm.reshape(streams, n, 2).transpose(0, 2, 1).astype(np.float32) / np.float32(65535)).copy()
+                d_in = torch.from_numpy(x).cuda()
+                full.process_f32(d_in, o_f, ops); live.process_f32(d_in, o_l, ops)
+            assert live.last_launches() == 2 and full.last_launches() == 2
+            assert _eq(o_f, o_l), (n, F, variant, u, int((o_f != o_l).sum()))
+        with pytest.raises(G.GlvError) as ei:
+            live.process_s16(torch.zeros((streams, n, 2), dtype=torch.int16, device="cuda"), o_l, G.OP_FFT | G.OP_GRAVITY | G.OP_AVERAGE | G.OP_R16)
+        assert ei.value.code == G.ERR_STATE
+        full.close(); live.close()

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """One configuration, warmed up and launched back to back, for rocprofv3 (tools/profile_cmd.sh):
-    cfg_run.py configs2 | chain | n1024bars | gl_default | gl_bars | gl_sm | gl_sm64 | ring  [calls]
+    cfg_run.py configs2 | chain | n1024bars | gl_default | gl_bars | gl_sm | gl_sm64 | gl_sm64_live | ring  [calls]
 0.3 s of spin-up launches first (the first dozens of launches after idle run ~20 % slower), then `calls` launches (default 150):
 the kernel-trace average then describes the warm kernel (the r03 summaries averaged 6 cold calls)."""
 import os, sys, time
@@ -29,6 +29,9 @@ elif which == "gl_sm":
 elif which == "gl_sm64":      # the shipped chain at the batch of bench.py's gl_default.sm_out entry
     n, streams, ops, bars = 4096, 65536, G.OP_FFT | G.OP_GRAVITY | G.OP_AVERAGE | G.OP_BARS | G.OP_R16, 4096
     kw, dt, mask = dict(avg_window_kind=1, gl_storage=1, bar_phase=0.5), torch.int16, G.OP_BARS
+elif which == "gl_sm64_live":  # ... with the state kept only where the pass samples (GLV_OP_BARS_ONLY)
+    n, streams, ops, bars = 4096, 65536, G.OP_FFT | G.OP_GRAVITY | G.OP_AVERAGE | G.OP_BARS | G.OP_R16, 4096
+    kw, dt, mask = dict(avg_window_kind=1, gl_storage=1, bar_phase=0.5), torch.int16, G.OP_BARS | G.OP_BARS_ONLY
 elif which == "ring":
     n, streams, ops, bars = 4096, 65536, G.OP_FFT, 0
     mask = G.OP_RING_S16

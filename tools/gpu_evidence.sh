@@ -26,7 +26,7 @@ import json, sys
 d = json.load(open(sys.argv[1]))
 print("headline", round(d["value"] / 1e6, 2), "M frames/s", round(d["roofline"]["frac"], 4))
 for k, v in d.get("configs", {}).get("gl_default", {}).items():
-    if isinstance(v, dict) and "value" in v: print("gl_default." + k, round(v["value"] / 1e6, 2), "M frames/s", round(v["roofline_frac"], 4), v.get("launches_per_step"))
+    if isinstance(v, dict) and "value" in v: print("gl_default." + k, round(v["value"] / 1e6, 2), "M frames/s", round(v["roofline_frac"], 4), v.get("launches_per_step"), v.get("frac_of_28N", ""))
 for k in ("configs[2]", "n8192_stateless", "n16384_stateless", "ring_update"):
     v = d.get("configs", {}).get(k)
     if v: print(k, round(v["value"] / 1e6, 2), round(v["roofline_frac"], 4))

@@ -468,7 +468,7 @@ __global__ void __launch_bounds__(64 * kRowsWaves) glv_bars_rows_kernel(const fl
         BarW4 pre[2];
 #pragma unroll
         for (uint32_t q = 0; q < 2; ++q) pre[q] = fetch(filled_to + 4u * (col_of(wave + kRowsWaves * q) < nnew ? col_of(wave + kRowsWaves * q) : 0u));
-        auto park_new = [&]() {
+    auto park_new = [&]() {
 #pragma unroll
             for (uint32_t q = 0; q < 2; ++q)
                 if (col_of(wave + kRowsWaves * q) < nnew) park(pre[q], filled_to + 4u * col_of(wave + kRowsWaves * q));
@@ -612,6 +612,7 @@ __global__ void __launch_bounds__(256) glv_bars_seq_kernel(const float* __restri
 // integer instructions per texel: floor(T / 2^16) = (a3 << 8) + a2 + ((a1 + (a0 >> 8)) >> 8), texel = (that + c) >> s with the host's
 // c = 32896 2^s + 2^(s - 1), s = P - 16 (round to nearest, an exact half up).
 typedef int glv_i4v __attribute__((ext_vector_type(4)));
+typedef int glv_i2v __attribute__((ext_vector_type(2)));
 typedef int glv_i16v __attribute__((ext_vector_type(16)));
 template <int S, int RB, bool F32IN, bool R16>
 __global__ void __launch_bounds__(64 * kRowsWaves, 2) glv_bars_rows_i8_kernel(const void* __restrict__ rows_in, void* __restrict__ bars_out, size_t nrows, uint32_t n,
@@ -695,7 +696,9 @@ __global__ void __launch_bounds__(64 * kRowsWaves, 2) glv_bars_rows_i8_kernel(co
     };
     // opens round t: sets up the wave's tile, requests what the NEXT round adds to the ring (parked behind this round's arithmetic) and the
     // tile's epilogue constants.  false: the wave has no tile in this round
-    BarIFin fpre = BarIFin{0u, 0u};
+    // the epilogue constants {c, s} of the wave's tile: requested a ROUND ahead (the next tile's descriptor is known by then), behind the previous
+    // tile's last step -- the full wait in front of that tile's stores covers them, so their first use never waits
+    BarIFin fcur = BarIFin{0u, 0u}, fnext = BarIFin{0u, 0u};
     // (the descriptors of round t + 1 -- uniform scalar loads, the tile's dependent on the round's -- are requested while round t runs)
     BarTile Tn = rounds[t_begin];
     BarMTile Mn = tiles[Tn.k0 + wave < Tn.k1 ? Tn.k0 + wave : Tn.k0];
@@ -717,13 +720,17 @@ __global__ void __launch_bounds__(64 * kRowsWaves, 2) glv_bars_rows_i8_kernel(co
         }
 #pragma unroll
         for (uint32_t q = 0; q < 2; ++q) pre[q] = fetch(filled_to + 8u * (fcol + q * CPI < nnew ? fcol + q * CPI : 0u));
-        if (valid) fpre = fin[M.k0 + (lane & 31u)];                             // (padded to whole tiles)
+        fcur = fnext;
         return valid;
     };
     // rounds without a tile for this wave: park, join the barrier, go on.  false: no round is left
     auto next_tile = [&]() -> bool {
         while (t < t_end) {
             if (open_round()) return true;
+            fnext = fin[Mn.k0 + (lane & 31u)];
+            // (awaited HERE: a compiler-visible load left in flight across the loop's back edge makes the backend guard every later reuse of its
+            // register with a vmcnt(0) -- in front of every step's LDS reads, a drain of the result stores per step)
+            asm volatile("" : "+v"(fnext.c), "+v"(fnext.s));
             park_new();
             __syncthreads();
             ++t;
@@ -731,26 +738,20 @@ __global__ void __launch_bounds__(64 * kRowsWaves, 2) glv_bars_rows_i8_kernel(co
         return false;
     };
     // behind a tile's last step
-    // Loads and stores retire on ONE counter and out of order with respect to each other, so behind a tile's 32 result stores a wait for a
-    // weight fragment is in effect a wait for the stores as well (vmcnt(6) below stays CORRECT -- loads retire in order among themselves, six
-    // younger ones outstanding mean the awaited one is back -- it just lasts until the stores have left too).  Hence: every load is awaited
-    // BEFORE the stores are issued -- the fragments of the next PF steps are then in their registers and those steps (most tiles have no
-    // more) wait for nothing while the stores drain behind the round's barrier.  `fresh` counts the steps that still need no wait.
+    // Loads and stores retire on ONE counter, so behind a tile's result stores a wait for a weight fragment is in effect a wait for the stores as
+    // well (vmcnt(6) in step() stays CORRECT -- loads retire in order among themselves -- it just lasts until the stores have left too).  Hence
+    // every load is awaited BEFORE the stores are issued: the fragments of the next PF steps are then in their registers and those steps (most
+    // tiles have no more) wait for nothing while the stores drain behind the round's barrier; `fresh` counts the steps that still need no wait.
+    // That full wait includes the weight requests of the tile's last steps, a moment old.  Round 6: ALL of the epilogue's arithmetic (which needs no
+    // load: its constants were requested a round ahead) sits between the last step and the wait, so that the L2 round trip of those requests runs
+    // under ~1.5 K cycles of vector work instead of in front of them; parking the next round's texels follows the wait.
     uint32_t fresh = 0;
     auto close_tile = [&]() {
-        __builtin_amdgcn_s_waitcnt(0x0F70);                                     // vmcnt(0): the ring's new texels, the weight stream
-        fresh = PF;
-        park_new();
+        fnext = fin[Mn.k0 + (lane & 31u)];                                      // (padded to whole tiles; Mn: the wave's tile of the next round, or a valid one)
         // a lane's 16 results of a group are one bar (k0 + lane % 32) of the rows 32 g + 8 (r / 4) + 4 (lane / 32) + r % 4
         const uint32_t kb = M.k0 + (lane & 31u);
-        const BarIFin f = fpre;
+        const BarIFin f = fcur;
         using OutT = std::conditional_t<R16, uint16_t, float>;
-        // the lane's first row of the block at its bar; the compiler must not keep 32 per-lane addresses alive across the tile loop
-        // (it did: spilled, and every store then waited for a scratch reload with vmcnt(0) -- i.e. for the store before it)
-        // (the OFFSET is what is made opaque: a pointer that went through an asm statement loses its address space and the stores become FLAT ones)
-        size_t base_at = (row0 + 4u * (lane >> 5)) * (size_t) bars + kb;
-        asm volatile("" : "+v"(base_at));
-        OutT* base = static_cast<OutT*>(bars_out) + base_at;
         auto result = [&](uint32_t g, int r) -> OutT {
             const int a0 = acc[g][0][r], a1 = acc[g][1][r], a2 = acc[g][2][r], a3 = acc[g][3][r];
             if constexpr (R16) {
@@ -763,33 +764,69 @@ __global__ void __launch_bounds__(64 * kRowsWaves, 2) glv_bars_rows_i8_kernel(co
                 return f.s == kBarIFinNone ? __builtin_nanf("") : (float) (__builtin_ldexp((double) tot, -P) / 65535.0);
             }
         };
-        // register r of a group is row 8 (r / 4) + r % 4 (+ 4 for the upper lanes: in `base`) of its 32: four row pointers, each moved on by
-        // eight rows per quad of registers -- no table of 32 row offsets in scalar registers
-        OutT* rp[4] = {base, base + bars, base + 2 * (size_t) bars, base + 3 * (size_t) bars};
-        const size_t eight = 8 * (size_t) bars;
-        // a partial last block: rows of the group this lane may store (made opaque: 32 hoisted row masks would not fit the scalar registers)
+        auto out_of = [](uint32_t x) -> OutT { if constexpr (R16) return (uint16_t) x; else return __builtin_bit_cast(float, x); };
+        // all results first (they take the place of the accumulators they come from) ...
+        uint32_t res[G][16];                                                    // (a float's bits, or the texel)
+#pragma unroll
+        for (uint32_t g = 0; g < G; ++g)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                if constexpr (R16) res[g][r] = result(g, r);
+                else res[g][r] = __builtin_bit_cast(uint32_t, result(g, r));
+            }
+        // ... pinned in front of the wait (sixteen at a time: an asm statement takes thirty operands) ...
+#pragma unroll
+        for (uint32_t g = 0; g < G; ++g) {
+            uint32_t (&x)[16] = res[g];
+            asm volatile("" : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]), "+v"(x[4]), "+v"(x[5]), "+v"(x[6]), "+v"(x[7]), "+v"(x[8]), "+v"(x[9]), "+v"(x[10]), "+v"(x[11]),
+                         "+v"(x[12]), "+v"(x[13]), "+v"(x[14]), "+v"(x[15]));
+        }
+        // ... then every load this wave has in flight -- the weight stream's next PF steps ...
+        __builtin_amdgcn_s_waitcnt(0x0F70);                                     // vmcnt(0)
+        asm volatile("" : "+v"(pre[0].d[0]), "+v"(pre[0].d[1]), "+v"(pre[0].d[2]), "+v"(pre[0].d[3]), "+v"(pre[1].d[0]), "+v"(pre[1].d[1]), "+v"(pre[1].d[2]), "+v"(pre[1].d[3]) : : "memory");
+        fresh = PF;
+        park_new();                                                             // (the ring's new texels: requested when the round opened)
+        // ... then the stores, `global_store v_off, v_data, s[base:base+1]`: a uniform row base in scalar registers, walked from row to row by
+        // scalar additions, + one 32-bit lane offset -- no vector address arithmetic per store.  (What it takes: the row OFFSET goes through an asm
+        // statement so that the backend neither folds the lane offset into a 64-bit vector address it then walks with a v_lshl_add_u64 per store nor
+        // keeps 64 hoisted row offsets in scalar registers -- the offset, not the pointer: a pointer that went through an asm statement loses its
+        // address space and the stores become FLAT ones -- and the lane offset is re-defined opaquely in every basic block that stores: its
+        // zero-extension must sit next to the store for the addressing mode to be matched.)
+        // register r of a group is row 8 (r / 4) + r % 4 (+ 4 for the upper lanes: in the lane offset) of its 32
+        uint32_t loff = (4u * (lane >> 5) * bars + kb) * (uint32_t) sizeof(OutT);
+        const size_t one_row = (size_t) bars * sizeof(OutT);
+        size_t ro = row0 * one_row;                                             // uniform: offset of the row the next store goes to
+        // a partial last block: rows of the group this lane may store
         uint32_t rlim = R > 4u * (lane >> 5) ? R - 4u * (lane >> 5) : 0u;
         asm volatile("" : "+v"(rlim));
         if (kb < bars) {
-            if (R == (uint32_t) RB) {                                           // whole block (uniform): no row checks
+            if (R == (uint32_t) RB) {                                           // whole block (uniform): no row checks, one basic block
+                asm volatile("" : "+v"(loff));
 #pragma unroll
                 for (uint32_t g = 0; g < G; ++g)
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) {
+                    for (int q = 0; q < 4; ++q)
 #pragma unroll
-                        for (int i = 0; i < 4; ++i) { *rp[i] = result(g, 4 * q + i); rp[i] += eight; }
-                    }
+                        for (int i = 0; i < 4; ++i) {
+                            asm volatile("" : "+s"(ro));
+                            st<OutT>(static_cast<char*>(bars_out) + ro, loff, out_of(res[g][4 * q + i]));
+                            ro += i == 3 ? 5 * one_row : one_row;
+                        }
             } else {
 #pragma unroll
                 for (uint32_t g = 0; g < G; ++g)
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) {
+                    for (int q = 0; q < 4; ++q)
 #pragma unroll
                         for (int i = 0; i < 4; ++i) {
-                            if (32u * g + 8u * (uint32_t) q + (uint32_t) i < rlim) *rp[i] = result(g, 4 * q + i);
-                            rp[i] += eight;
+                            asm volatile("" : "+s"(ro));
+                            if (32u * g + 8u * (uint32_t) q + (uint32_t) i < rlim) {
+                                uint32_t lo = loff;
+                                asm volatile("" : "+v"(lo));
+                                st<OutT>(static_cast<char*>(bars_out) + ro, lo, out_of(res[g][4 * q + i]));
+                            }
+                            ro += i == 3 ? 5 * one_row : one_row;
                         }
-                    }
             }
         }
         __syncthreads();
@@ -833,6 +870,8 @@ __global__ void __launch_bounds__(64 * kRowsWaves, 2) glv_bars_rows_i8_kernel(co
         asm volatile("" : : "v"(acc[0][1]) : "memory");
         wload(wb[B][0], wb[B][1], wb[B][2]);
     };
+    fnext = fin[Mn.k0 + (lane & 31u)];                                          // the first tile's epilogue constants
+    asm volatile("" : "+v"(fnext.c), "+v"(fnext.s));
     if (!next_tile()) return;
     // the wave's first tile: fill the pipeline
     wp = wq + (uint32_t) __builtin_amdgcn_readfirstlane((int) M.w_off) + lane;

@@ -43,5 +43,22 @@ def test_weight_fragments_of_the_integer_pass_are_touched_by_the_matrix_cores_on
                 regs.add(int(m.group(1)))
             assert not (regs & dest), (name, t)
         assert "scratch_" not in body and "flat_" not in body, name
+        # round 6: between a step's a-operand reads and its MFMAs the only vector-memory wait is the hand-placed vmcnt(6).  (A compiler-visible
+        # load left in flight across the loop's back edge -- the epilogue constants requested a round ahead were one -- makes the backend guard
+        # the reuse of its register with a vmcnt(0) in front of EVERY step: a drain of the previous tile's result stores per step, +20 ... +80 %.)
+        i = 0
+        while i < len(lines):
+            if "ds_read_b128" in lines[i]:
+                j = i
+                while j < len(lines) and "v_mfma" not in lines[j] and not lines[j].strip().startswith("s_barrier"):
+                    if re.match(r"\s*s_waitcnt vmcnt", lines[j]):
+                        assert ";;#ASMSTART" in lines[j - 1] and "vmcnt(6)" in lines[j], (name, j, lines[j])
+                    j += 1
+                i = j
+            i += 1
+        # the result stores take `uniform base + 32-bit lane offset`: no 64-bit vector address arithmetic next to them
+        for k, l in enumerate(lines):
+            if re.match(r"\s*global_store_(short|dword) ", l):
+                assert re.search(r", s\[\d+:\d+\]\s*$", l), (name, l)
         m = re.search(r"\.amdhsa_next_free_vgpr (\d+)", body)
         assert m and int(m.group(1)) <= 256, (name, m and m.group(1))

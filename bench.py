@@ -165,6 +165,15 @@ def extra_configs(G, torch, device, a, peak_gbs):
             kms = ms / max(nl, 1)
         return dt, kms
 
+    def place(batch, d_in, d_out, ops):
+        """placement wisdom (glv_batch_tune_placement): the fastest of six placements of the state arrays for THESE buffers; untimed, like autotune"""
+        if not a.tune_placement: return None
+        try:
+            f, b = batch.tune_placement(d_in, d_out, ops, 6, st0)
+            return {"ms_first_placement": f, "ms_best_placement": b}
+        except Exception as ex:                                   # never fails the bench line
+            return {"error": str(ex)}
+
     def entry(note, frames, bytes_per_launch, dt, kms):
         k = kms if kms else dt * 1e3
         return {"note": note, "value": frames / dt, "unit": "frames/s", "ms_per_step": dt * 1e3, "avg_kernel_ms": k,
@@ -188,9 +197,11 @@ def extra_configs(G, torch, device, a, peak_gbs):
     ob = torch.empty((s, 2, bars), dtype=torch.float32, device="cuda")
     gops = G.OP_FFT | G.OP_GRAVITY
     b = G.Batch(G.Params(n=n, log_mode=a.log_mode, bars=bars), s, G.OP_GRAVITY, device=device)
+    pl = place(b, pcm, ob, gops | G.OP_BARS)
     dt, kms = run(b, lambda: b.process_s16(pcm, ob, gops | G.OP_BARS, st0))
     c2 = entry(f"BASELINE configs[2]: N={n} x {s} streams, fft + gravity + radial bin averaging to {bars} bars/channel (fused: bars from the row in LDS), "
                f"20 N + 640 B/frame (SURVEY 8d row D)", s, (20 * n + 8 * bars) * s, dt, kms)
+    c2["placement"] = pl
     b.reset()
     gois = gops | G.OP_OUTPUT_IS_STATE
     dt, kms = run(b, lambda: b.process_s16(pcm, o, gois, st0))
@@ -210,16 +221,20 @@ def extra_configs(G, torch, device, a, peak_gbs):
     glops = G.OP_FFT | G.OP_GRAVITY | G.OP_AVERAGE
     pg = G.Params(n=n, log_mode=a.log_mode, avg_frames=F, avg_window_kind=1, gl_storage=1, bars=bars)
     b = G.Batch(pg, s, G.OP_GRAVITY | G.OP_AVERAGE, device=device)
+    pl = place(b, pcm, q, glops | G.OP_R16)
     dt, kms = run(b, lambda: b.process_s16(pcm, q, glops | G.OP_R16, st0))
     gl = entry(f"GLava's shipped pipeline (setaccelfft): N={n} x {s} streams, s16 PCM -> upload quantisation -> GL_MAX + gravity pass -> ring -> "
                f"average pass (F={F}, Hamming newest-first) -> `av` GL_R16 texels, ONE launch on uint16 state: 4N + 16N + 4N + 4N = 28 N B/frame",
                s, b.algorithmic_bytes(glops | G.OP_R16), dt, kms)
     gl["launches_per_step"] = b.last_launches()
+    gl["placement"] = pl
     b.reset()
+    pl = place(b, pcm, qb, glops | G.OP_BARS | G.OP_R16)
     dt, kms = run(b, lambda: b.process_s16(pcm, qb, glops | G.OP_BARS | G.OP_R16, st0))
     gl["bars_out"] = entry(f"same chain with the {bars} bars of the bars / radial modules computed in the kernel (from the finished row in LDS) and "
                            f"stored as GL_R16 texels: 24 N + {4 * bars} B/frame", s, b.algorithmic_bytes(glops | G.OP_BARS | G.OP_R16), dt, kms)
     gl["bars_out"]["launches_per_step"] = b.last_launches()
+    gl["bars_out"]["placement"] = pl
     b.close()
     # ... and with the pre-smoothing pass of render.c:2277-2303 behind it (bars == n at the texel centres: the texture every stock
     # module samples under setsmoothpass, GLava's shipped configuration): the fused GL kernel hands the `av` rows over as uint16
@@ -232,12 +247,14 @@ def extra_configs(G, torch, device, a, peak_gbs):
     for tag, s3 in (("full", s), ("quarter", max(s // 4, 1))):          # the whole batch (as every other entry), and round 4's quarter batch
         qs = torch.empty((s3, 2, n), dtype=torch.int16, device="cuda")
         b3 = G.Batch(psm, s3, G.OP_GRAVITY | G.OP_AVERAGE | G.OP_BARS, device=device)
+        pl = place(b3, pcm, qs, smops)
         dt, kms = run(b3, lambda: b3.process_s16(pcm, qs, smops, st0))
         assert b3.algorithmic_bytes(smops) == 28 * n * s3
         sm_entries[tag] = entry(f"GLava's SHIPPED pipeline end to end: the chain above + the pre-smoothing pass (bars = n = {n}, bar_phase 0.5) -> `sm` GL_R16 texels, {s3} streams, "
                                 f"two launches (glv_frame_kernel -> uint16 `av` rows -> glv_bars_rows_i8_kernel: exact integer weighted means on v_mfma_i32_32x32x32_i8); "
                                 f"bytes: the chain's 28 N per frame", s3, b3.algorithmic_bytes(smops), dt, kms)
         sm_entries[tag]["launches_per_step"] = b3.last_launches()
+        sm_entries[tag]["placement"] = pl
         b3.close(); del qs
     gl["sm_out"] = sm_entries["full"]
     gl["sm_out"]["quarter_batch"] = sm_entries["quarter"]
@@ -248,11 +265,13 @@ def extra_configs(G, torch, device, a, peak_gbs):
     # prices the same frames at the full chain's bytes for comparison with sm_out -- it is NOT a roofline claim.
     qs = torch.empty((s, 2, n), dtype=torch.int16, device="cuda")
     b5 = G.Batch(psm, s, G.OP_GRAVITY | G.OP_AVERAGE | G.OP_BARS | G.OP_BARS_ONLY, device=device)
+    pl = place(b5, pcm, qs, smops)
     dt, kms = run(b5, lambda: b5.process_s16(pcm, qs, smops, st0))
     gl["sm_out_live"] = entry(f"the shipped pipeline with the state kept only where the pre-smoothing pass samples (GLV_OP_BARS_ONLY: live bins {b5.live_bins()} of {n}, "
                               f"kept in whole last-pass blocks), {s} streams, two launches, same `sm` texels bit for bit; bytes: 4 N + (4 (F - 1) + 4) L + 4 N per frame",
                               s, b5.algorithmic_bytes(smops), dt, kms)
     gl["sm_out_live"]["launches_per_step"] = b5.last_launches()
+    gl["sm_out_live"]["placement"] = pl
     gl["sm_out_live"]["live_bins"] = b5.live_bins()
     gl["sm_out_live"]["frac_of_28N"] = 28 * n * s / (gl["sm_out_live"]["avg_kernel_ms"] * 1e-3) / 1e9 / peak_gbs
     b5.close(); del qs
@@ -380,6 +399,9 @@ def main() -> None:
     ap.add_argument("--sustained-s", type=float, default=2.0, help="seconds of back-to-back headline launches behind the `sustained` key (0 = skip)")
     ap.add_argument("--check-dump", default="", help="test hook: every rank saves the PCM of its FIRST stream and the raw FFT the library "
                                                      "computes for it to <path>.rank<r>.npz (global stream index inside); tests/ compare with the oracle")
+    ap.add_argument("--no-tune-placement", dest="tune_placement", action="store_false",
+                    help="stateful entries: skip glv_batch_tune_placement (the fastest of six placements of the state arrays for the entry's buffers, "
+                         "found outside the timed region; profiles/r06/modes.txt) and time whatever placement the allocation happened to give")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
     ap.add_argument("--spinup-s", type=float, default=0.3, help="untimed clock spin-up before the W warm-up steps")
     a = ap.parse_args()
@@ -529,6 +551,13 @@ def main() -> None:
         if alt_batch is not None: alt_batch.close(); alt_batch = None
         cops = G.OP_FFT | G.OP_GRAVITY | G.OP_AVERAGE
         cb = G.Batch(params, streams, cops, device=device)
+        c_place = None
+        if a.tune_placement:
+            try:
+                pf, pb = cb.tune_placement(d_pcm, d_out, cops, 6, stream)
+                c_place = {"ms_first_placement": pf, "ms_best_placement": pb}
+            except Exception as ex:
+                c_place = {"error": str(ex)}
         ops_saved, ops = ops, cops
         c_el, c_kms, c_nl = timed(cb)
         ops = ops_saved
@@ -536,7 +565,7 @@ def main() -> None:
         c_bytes = cb.algorithmic_bytes(cops)
         chain = {"note": f"fft -> gravity -> average(F=5, windowed), log_mode {a.log_mode}; algorithmic bytes 52*N per frame (SURVEY 8d row C)",
                  "algorithmic_bytes_per_launch": c_bytes, "value": streams * a.steps / c_el, "unit": "frames/s", "ms_per_step": c_el / a.steps * 1e3,
-                 "avg_kernel_ms": c_k * 1e3, "roofline_frac": (c_bytes / c_k / 1e9) / HBM_PEAK_GBS if c_k > 0 else 0.0}
+                 "avg_kernel_ms": c_k * 1e3, "roofline_frac": (c_bytes / c_k / 1e9) / HBM_PEAK_GBS if c_k > 0 else 0.0, "placement": c_place}
         cb.close()
 
     # the same pass with the output as GL_R16 texels (what handle_audio uploads, render.c:521-524): 8N bytes per frame
@@ -631,6 +660,7 @@ def main() -> None:
             rec = {"what": what, "frames_per_s": e["value"], "ms_per_step": e["ms_per_step"], "avg_kernel_ms": e["avg_kernel_ms"],
                    "bytes_per_frame": by / frames, "frac": e["roofline_frac"], "launches_per_step": e.get("launches_per_step", 1)}
             if "frac_of_28N" in e: rec["frac_of_28N"] = e["frac_of_28N"]
+            if e.get("placement"): rec["placement"] = e["placement"]
             return rec
         chains = {"smooth_chain": chain_rec(chain, streams, "fft -> gravity -> average (F=5) on f32 state, 52 N B/frame (the CPU path's transform list: bars/1.frag:12-24)"),
                   "strict_log": chain_rec(line.get("strict_log"), streams * world, "the headline pass with the bit-faithful fp64 log (log_mode 0), 12 N B/frame")}

@@ -367,20 +367,82 @@ struct glv_state {
 
 namespace {
 
+// The large state arrays (gravity store, history ring): hipMalloc -- or, for the placement experiments of profiles/r06/modes.txt (the stateful
+// chains run at one of two or three speeds per PROCESS), what GLV_STATE_ALLOC asks for (read when a batch is created; diagnostics, not API):
+//   vmm:<MiB>   virtual memory management: one address range, physical memory created and mapped in chunks of <MiB> MiB (0: one chunk),
+//               rounded up to the device's recommended granularity
+//   fine        hipExtMallocWithFlags(hipDeviceMallocFinegrained);   uncached   ... (hipDeviceMallocUncached)
+struct StateAlloc {
+    void* ptr = nullptr; size_t size = 0; int kind = 0;                        // 0 hipMalloc / hipExtMalloc, 1 vmm
+    std::vector<hipMemGenericAllocationHandle_t> handles;
+};
+static std::mutex g_state_mu;
+static std::vector<StateAlloc> g_state_allocs;                                  // (vmm allocations only: what state_free must unmap)
+
+hipError_t state_malloc(void** out, size_t bytes, int device) {
+    const char* pol = std::getenv("GLV_STATE_ALLOC");
+    if (!pol || !*pol || !std::strcmp(pol, "malloc")) return hipMalloc(out, bytes);
+    if (!std::strcmp(pol, "fine")) return hipExtMallocWithFlags(out, bytes, hipDeviceMallocFinegrained);
+    if (!std::strcmp(pol, "uncached")) return hipExtMallocWithFlags(out, bytes, hipDeviceMallocUncached);
+    if (!std::strncmp(pol, "vmm:", 4)) {
+        hipMemAllocationProp prop = {};
+        prop.type = hipMemAllocationTypePinned; prop.location.type = hipMemLocationTypeDevice; prop.location.id = device;
+        size_t gran = 0;
+        hipError_t e = hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityRecommended);
+        if (e != hipSuccess) return e;
+        size_t chunk = (size_t) std::atol(pol + 4) << 20;
+        const size_t total = (bytes + gran - 1) / gran * gran;
+        if (chunk == 0 || chunk > total) chunk = total;
+        chunk = (chunk + gran - 1) / gran * gran;
+        StateAlloc a; a.kind = 1; a.size = total;
+        if ((e = hipMemAddressReserve(&a.ptr, total, gran, nullptr, 0)) != hipSuccess) return e;
+        for (size_t off = 0; off < total; off += chunk) {
+            const size_t sz = off + chunk <= total ? chunk : total - off;
+            hipMemGenericAllocationHandle_t h;
+            if ((e = hipMemCreate(&h, sz, &prop, 0)) != hipSuccess) return e;
+            if ((e = hipMemMap(static_cast<char*>(a.ptr) + off, sz, 0, h, 0)) != hipSuccess) return e;
+            a.handles.push_back(h);
+        }
+        hipMemAccessDesc acc = {}; acc.location = prop.location; acc.flags = hipMemAccessFlagsProtReadWrite;
+        if ((e = hipMemSetAccess(a.ptr, total, &acc, 1)) != hipSuccess) return e;
+        *out = a.ptr;
+        std::lock_guard<std::mutex> lk(g_state_mu);
+        g_state_allocs.push_back(std::move(a));
+        return hipSuccess;
+    }
+    return hipErrorInvalidValue;
+}
+void state_free(void* p) {
+    if (!p) return;
+    {
+        std::lock_guard<std::mutex> lk(g_state_mu);
+        for (size_t i = 0; i < g_state_allocs.size(); ++i)
+            if (g_state_allocs[i].ptr == p) {
+                StateAlloc a = std::move(g_state_allocs[i]);
+                g_state_allocs.erase(g_state_allocs.begin() + (long) i);
+                (void) hipMemUnmap(a.ptr, a.size);
+                for (auto h : a.handles) (void) hipMemRelease(h);
+                (void) hipMemAddressFree(a.ptr, a.size);
+                return;
+            }
+    }
+    (void) hipFree(p);
+}
+
 int batch_alloc(glv_batch* b, uint32_t rows) {
     const size_t n = b->p.n;
     b->state16 = b->p.gl_storage == 1;
     const size_t esz = b->state16 ? sizeof(uint16_t) : sizeof(float);          // GL_R16 state: texels
     if ((b->ops_mask & GLV_OP_AVERAGE)) {
         const size_t bytes = esz * rows * (size_t) b->p.avg_frames * n;
-        HIP_TRY(hipMalloc(&b->d_hist, bytes));
+        HIP_TRY(state_malloc(reinterpret_cast<void**>(&b->d_hist), bytes, b->device));
         HIP_TRY(hipMemset(b->d_hist, 0, bytes));
     }
     if ((b->ops_mask & GLV_OP_GRAVITY)) {
         // kept even when the ring also exists: the single-op glv_gravity() drop-in owns its own
         // `applied` buffer exactly like the reference's separate udata slot (render.c:724)
         const size_t bytes = esz * rows * n;
-        HIP_TRY(hipMalloc(&b->d_grav, bytes));
+        HIP_TRY(state_malloc(reinterpret_cast<void**>(&b->d_grav), bytes, b->device));
         HIP_TRY(hipMemset(b->d_grav, 0, bytes));
         b->grav_cur = b->d_grav;
     }
@@ -1014,8 +1076,8 @@ int glv_batch_destroy(glv_batch* b) {
     if (!b) return GLV_OK;
     (void) hipSetDevice(b->device);
     b->tab.destroy();
-    if (b->d_grav) (void) hipFree(b->d_grav);
-    if (b->d_hist) (void) hipFree(b->d_hist);
+    state_free(b->d_grav);
+    state_free(b->d_hist);
     if (b->d_ring) (void) hipFree(b->d_ring);
     if (b->d_scratch) (void) hipFree(b->d_scratch);
     if (b->d_ring_f32) (void) hipFree(b->d_ring_f32);
@@ -1333,6 +1395,67 @@ int glv_batch_autotune(glv_batch* b, const int16_t* d_pcm, float* d_out, unsigne
     wisdom_store(wisdom_key(b, glv::IN_S16_STEREO, plan_ops(b, ops)), best.variant, best.grid, bms);
     if (best_grid) *best_grid = best.grid;
     if (best_ms) *best_ms = bms;
+    return GLV_OK;
+}
+
+// Placement wisdom (round 6; profiles/r06/modes.txt).  A stateful chain runs at one of two or three speeds, 7 - 14 % apart, and which one is a property of
+// WHERE ITS STATE ARRAYS LIE in physical memory relative to the caller's output buffer: K batches of one process, created one after the other, each keep
+// their own speed against the same buffers, and one batch changes speed with the output buffer it is given -- not with the allocator (hipMalloc, virtual
+// memory management in one or many chunks, fine-grained: the same mix), not with the TLB (UTCL1 misses 3e4 of 2.8e8 requests in every mode), not with
+// clocks, power or temperature.  So the library does what it does for the launch geometry: it measures.  The current placement is timed with the caller's
+// real buffers, then up to `candidates` - 1 fresh allocations of the state arrays (the earlier ones stay allocated meanwhile, so every candidate lies on
+// other frames); the fastest is kept, the others are freed, the state is reset.
+int glv_batch_tune_placement(glv_batch* b, const int16_t* d_pcm, void* d_out, unsigned ops, int candidates, void* hip_stream, float* first_ms, float* best_ms) {
+    if (!b) return fail(GLV_ERR_INVALID, "batch is NULL");
+    if (!(ops & GLV_OP_FFT) || !(ops & (GLV_OP_GRAVITY | GLV_OP_AVERAGE))) return fail(GLV_ERR_INVALID, "glv_batch_tune_placement tunes a stateful chain: ops needs GLV_OP_FFT and GLV_OP_GRAVITY / GLV_OP_AVERAGE");
+    if (int rc = check_ops(b, ops, static_cast<float*>(d_out))) return rc;
+    if (!d_pcm || !d_out) return fail(GLV_ERR_INVALID, "NULL device pointer");
+    if (candidates < 1) candidates = 1;
+    if (candidates > 16) candidates = 16;
+    hipStream_t st = (hipStream_t) hip_stream;
+    HIP_TRY(hipSetDevice(b->device));
+    const uint32_t units = b->streams * 2;
+    const size_t esz = b->state16 ? sizeof(uint16_t) : sizeof(float);
+    const size_t hist_bytes = b->d_hist ? esz * (size_t) b->rows * b->p.avg_frames * b->p.n : 0, grav_bytes = b->d_grav ? esz * (size_t) b->rows * b->p.n : 0;
+    hipEvent_t e0, e1;
+    HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1));
+    int rc = GLV_OK;
+    auto measure = [&](float* ms) -> int {
+        if (int r = glv_batch_reset(b)) return r;
+        for (int i = 0; i < 4; ++i) if (int r = process(b, d_pcm, glv::IN_S16_STEREO, static_cast<float*>(d_out), ops, units, 0, st)) return r;
+        if (hipEventRecord(e0, st) != hipSuccess) return fail(GLV_ERR_HIP, "hipEventRecord failed");
+        const int iters = 10;
+        for (int i = 0; i < iters; ++i) if (int r = process(b, d_pcm, glv::IN_S16_STEREO, static_cast<float*>(d_out), ops, units, 0, st)) return r;
+        if (hipEventRecord(e1, st) != hipSuccess || hipEventSynchronize(e1) != hipSuccess || hipEventElapsedTime(ms, e0, e1) != hipSuccess) return fail(GLV_ERR_HIP, "event timing failed");
+        *ms /= (float) iters;
+        return GLV_OK;
+    };
+    float cur = 0.f;
+    for (int i = 0; i < 24 && rc == GLV_OK; ++i) rc = process(b, d_pcm, glv::IN_S16_STEREO, static_cast<float*>(d_out), ops, units, 0, st);      // clocks up
+    if (rc == GLV_OK) rc = measure(&cur);
+    const float first = cur;
+    std::vector<std::pair<void*, void*>> losers;                                 // (hist, grav) of the placements that lost: freed at the end
+    for (int c = 1; c < candidates && rc == GLV_OK; ++c) {
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b < 2 * (hist_bytes + grav_bytes) + ((size_t) 1 << 30)) break;      // room for this candidate and slack
+        void *nh = nullptr, *ng = nullptr;
+        if (hist_bytes && state_malloc(&nh, hist_bytes, b->device) != hipSuccess) { (void) hipGetLastError(); break; }
+        if (grav_bytes && state_malloc(&ng, grav_bytes, b->device) != hipSuccess) { (void) hipGetLastError(); state_free(nh); break; }
+        void *oh = b->d_hist, *og = b->d_grav;
+        if (nh) b->d_hist = static_cast<float*>(nh);
+        if (ng) b->d_grav = static_cast<float*>(ng);
+        float ms = 0.f;
+        rc = measure(&ms);
+        if (rc == GLV_OK && ms < cur * 0.985f) { cur = ms; losers.emplace_back(oh, og); }
+        else { b->d_hist = static_cast<float*>(oh); b->d_grav = static_cast<float*>(og); losers.emplace_back(nh, ng); }
+    }
+    (void) hipStreamSynchronize(st);
+    for (auto& l : losers) { state_free(l.first); state_free(l.second); }
+    (void) hipEventDestroy(e0); (void) hipEventDestroy(e1);
+    if (rc != GLV_OK) return rc;
+    if (int r = glv_batch_reset(b)) return r;
+    if (first_ms) *first_ms = first;
+    if (best_ms) *best_ms = cur;
     return GLV_OK;
 }
 

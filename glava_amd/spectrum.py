@@ -96,6 +96,7 @@ def lib() -> C.CDLL:
         L.glv_batch_timing_begin.argtypes = [vp]
         L.glv_batch_timing_end.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]
         L.glv_batch_live_bins.argtypes = [vp]; L.glv_batch_live_bins.restype = C.c_uint32
+        L.glv_batch_tune_placement.argtypes = [vp, vp, vp, C.c_uint, C.c_int, vp, C.POINTER(C.c_float), C.POINTER(C.c_float)]
         L.glv_batch_bars_arithmetic.argtypes = [vp]; L.glv_batch_bars_arithmetic.restype = C.c_int
         L.glv_batch_algorithmic_bytes.argtypes = [vp, C.c_uint, C.c_int]
         L.glv_batch_algorithmic_bytes.restype = C.c_uint64
@@ -280,6 +281,13 @@ class Batch:
         g, ms = C.c_int(0), C.c_float(0)
         _check(lib().glv_batch_autotune(self._h, _ptr(d_pcm), _ptr(d_out), ops, _ptr(stream), C.byref(g), C.byref(ms)))
         return g.value, ms.value
+
+    def tune_placement(self, d_pcm, d_out, ops: int, candidates: int = 6, stream: int | None = None) -> tuple[float, float]:
+        """placement wisdom (include/glv_spectrum.h glv_batch_tune_placement): keep the fastest of `candidates` placements of the state arrays
+        for THESE buffers; resets the state.  Returns (ms per update of the placement it had, of the one it has now)"""
+        f, b = C.c_float(0), C.c_float(0)
+        _check(lib().glv_batch_tune_placement(self._h, _ptr(d_pcm), _ptr(d_out), ops, candidates, _ptr(stream), C.byref(f), C.byref(b)))
+        return f.value, b.value
 
     def close(self) -> None:
         if self._h:

@@ -22,7 +22,7 @@ extern "C" {
 #endif
 
 #define GLV_ABI_VERSION 6      /* 5 (round 5): + glv_gl_texture; GLV_OP_BARS over texel rows (gl_storage != 0, 256 bars or more) is the exact integer mean
-                                  6 (round 6): + GLV_OP_BARS_ONLY, glv_batch_live_bins, glv_batch_bars_arithmetic; GLV_OP_R16 in a creation mask is a hint */
+                                  6 (round 6): + GLV_OP_BARS_ONLY, glv_batch_live_bins, glv_batch_bars_arithmetic, glv_batch_tune_placement; GLV_OP_R16 in a creation mask is a hint */
 
 /* status codes (0 = ok).  The reference has no error channel: it prints and calls
  * glava_abort() (glava/glava.h:17, glava/render.c passim); the in-tree shim maps any
@@ -348,6 +348,13 @@ int glv_batch_describe_variant(const glv_batch* b, int variant, char* buf, size_
  * Save / load carry the table across processes (a text file, one entry per line; entries of other devices are kept but
  * never match); the file named by the environment variable GLV_WISDOM is loaded when the first batch is created. */
 int glv_batch_autotune(glv_batch* b, const int16_t* d_pcm, float* d_out, unsigned ops, void* hip_stream, int* best_grid, float* best_ms);
+/* Placement wisdom (ABI 6).  A stateful chain (GLV_OP_GRAVITY / GLV_OP_AVERAGE) runs at one of two or three speeds, 7 - 14 % apart, decided by where its
+ * state arrays lie in physical memory relative to the caller's OUTPUT buffer (profiles/r06/modes.txt: K batches of one process keep K speeds; one batch
+ * changes speed with the output buffer; no allocator choice, TLB or clock effect).  This call times the batch's current placement with the caller's real
+ * buffers and then up to `candidates` - 1 fresh allocations of the state arrays (all alive together while it runs: up to `candidates` x the state's size,
+ * bounded by the free device memory), keeps the fastest, frees the rest and RESETS the state -- call it once, before the first real update, with the
+ * buffers the updates will use.  *first_ms / *best_ms (may be NULL): ms per update of the placement the batch was created with / now has. */
+int glv_batch_tune_placement(glv_batch* b, const int16_t* d_pcm, void* d_out, unsigned ops, int candidates, void* hip_stream, float* first_ms, float* best_ms);
 int glv_wisdom_save(const char* path);
 int glv_wisdom_load(const char* path);
 int glv_wisdom_clear(void);

@@ -138,3 +138,34 @@ def test_wisdom_selects_the_kernel_variant(glvlib, tmp_path, n, streams):
     assert b2.last_variant() == (chosen if chosen != other else 0)
     for x in (b, b2, bc): x.close()
     G.wisdom_clear()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("gl", [0, 1])
+def test_placement_tuning_keeps_the_results_and_never_the_slower_placement(glvlib, gl):
+    """Placement wisdom (round 6, profiles/r06/modes.txt): a stateful chain's speed depends on where its state arrays lie relative to the caller's output
+    buffer; glv_batch_tune_placement times fresh allocations with the caller's buffers and keeps the fastest.  Checked: the placement it ends with is not
+    slower than the one it started with, the state is reset, the updates that follow equal an untuned batch's bit for bit (state on other frames changes
+    no value), arguments are validated, and a stateless chain is refused."""
+    import torch
+    G = glvlib
+    n, streams, F = 4096, 8192, 5
+    kw = dict(n=n, avg_frames=F, avg_window_kind=1, gl_storage=gl)
+    mask = G.OP_GRAVITY | G.OP_AVERAGE
+    ops = G.OP_FFT | mask | (G.OP_R16 if gl else 0)
+    dt = torch.int16 if gl else torch.float32
+    pcm = [torch.randint(-32768, 32768, (streams, n, 2), dtype=torch.int16, device="cuda") // d for d in (1, 16, 3)]
+    out, ref = torch.empty((streams, 2, n), dtype=dt, device="cuda"), torch.empty((streams, 2, n), dtype=dt, device="cuda")
+    tuned, plain = G.Batch(G.Params(**kw), streams, mask), G.Batch(G.Params(**kw), streams, mask)
+    tuned.process_s16(pcm[0], out, ops)                                 # state that the tuning must wipe
+    first, best = tuned.tune_placement(pcm[0], out, ops, candidates=4)
+    assert first > 0 and 0 < best <= first * 1.001, (first, best)
+    for u in range(F + 2):
+        tuned.process_s16(pcm[u % 3], out, ops); plain.process_s16(pcm[u % 3], ref, ops)
+        assert torch.equal(out.view(torch.int16), ref.view(torch.int16)), u
+    with pytest.raises(G.GlvError) as ei:
+        tuned.tune_placement(pcm[0], out, G.OP_FFT, 3)
+    assert ei.value.code == G.ERR_INVALID
+    one, same = tuned.tune_placement(pcm[0], out, ops, candidates=1)    # one candidate: a measurement, nothing is moved
+    assert one == same
+    tuned.close(); plain.close()

@@ -10,6 +10,7 @@ import torch
 from glava_amd import spectrum as G
 which = sys.argv[1] if len(sys.argv) > 1 else "configs2"
 calls = int(sys.argv[2]) if len(sys.argv) > 2 else 150
+_shake = torch.empty(int(os.environ.get("CFG_SHAKE_MB", "0")) << 20, dtype=torch.uint8, device="cuda") if os.environ.get("CFG_SHAKE_MB") else None   # (tools/modes.py: moves every later allocation's physical frames)
 kw, mask, dt, width = {}, 0, torch.float32, None
 if which == "configs2":
     n, streams, ops, bars = 16384, 8192, G.OP_FFT | G.OP_GRAVITY | G.OP_BARS, 80

@@ -57,4 +57,4 @@ template <int LOG_NN, int LOG_E> void run() {
         printf("  exchange after pass 1: write extra cycles per row %d, read (as b64) %d\n", wr, rd);
     }
 }
-int main() { for (g_shift = 3; g_shift <= 7; ++g_shift) { printf("pad shift %d\n", g_shift); run<12, 4>(); run<11, 4>(); } }
+int main() { for (g_shift = 3; g_shift <= 7; ++g_shift) { printf("pad shift %d\n", g_shift); run<12, 4>(); run<11, 4>(); run<13, 5>(); run<13, 4>(); run<14, 5>(); } }

@@ -1,12 +1,14 @@
 #!/usr/bin/env python3
 """The stateful chains' two speeds (profiles/r05/run_to_run.txt) against what the part reports while they run: rocm-smi power, sclk, mclk, fclk sampled beside
-10 s of back-to-back GL-default launches, kernel ms per second of the run.    python tools/mode_probe.py [chain]"""
+SECONDS (default 10) of back-to-back launches, ms per call for every second of the run.    python tools/mode_probe.py [chain|gl] [seconds]
+Round 6: run for minutes, the speed changes WITHIN one process (profiles/r06/modes.txt) -- the "modes" are states of the device in time, not of a process."""
 import os, re, subprocess, sys, threading, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch
 from glava_amd import spectrum as G
 n, streams = 4096, 65536
+SECS = int(sys.argv[2]) if len(sys.argv) > 2 else 10
 chain = len(sys.argv) > 1 and sys.argv[1] == "chain"
 pcm = torch.randint(-32768, 32768, (streams, n, 2), dtype=torch.int16, device="cuda")
 if chain:
@@ -24,9 +26,9 @@ print("idle:", sample(), flush=True)
 stop = False
 def watch():
     while not stop:
-        print("   smi:", sample(), flush=True); time.sleep(1.0)
+        print("   smi:", sample(), flush=True); time.sleep(5.0 if SECS > 30 else 1.0)
 th = threading.Thread(target=watch); th.start()
-for sec in range(10):
+for sec in range(SECS):
     t0 = time.perf_counter(); k = 0
     while time.perf_counter() - t0 < 1.0:
         for _ in range(32): b.process_s16(pcm, out, ops)

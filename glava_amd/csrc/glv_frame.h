@@ -429,8 +429,37 @@ GLV_HD void apply_state_block(cf (&val)[NV], const uint32_t (&off)[NV], size_t r
 // gl_storage == 1 inside the frame kernel: apply_state_r16 for NV complex points of one lane at once, loads first (the shape of
 // apply_state_block; same arithmetic, same order).  PAIRED: points j and j + 1 (j even) are adjacent in the row -- their four
 // texels are one 8-byte access.  TWO: two history frames per trip.
-template <int NV, bool PAIRED, bool TWO>
-GLV_HD void gl16_state_block(uint32_t (&tex)[NV], const uint32_t (&off)[NV], size_t row, uint32_t n, const FrameArgs& a) {
+// KPRE > 0 (the live class, glv_kernel_tmpl.h): the oldest `npre` <= KPRE ring slots of the lane's points were requested BEFORE the row's transform
+// (gl16_state_prefetch, same addresses) and are in `pre` -- the HBM latency of the state ran under the FFT passes instead of in front of the
+// average; the sum takes them in the same order, oldest first, so not a bit changes.  Only chains that average over F >= 2 frames prefetch.
+constexpr int kLivePre = 4;
+template <int NV, bool PAIRED>
+GLV_HD uint32_t gl16_state_prefetch(uint32_t (&pre)[kLivePre][NV], const uint32_t (&off)[NV], size_t row, uint32_t n, const FrameArgs& a) {
+    const uint32_t F = a.F;
+    if (!(a.ops & OP_AVERAGE) || F < 2u) return 0u;
+    const uint32_t npre = F - 1u < (uint32_t) kLivePre ? F - 1u : (uint32_t) kLivePre;
+    const uint16_t* h = reinterpret_cast<const uint16_t*>(a.hist) + row * (size_t) F * n;
+    uint32_t lb = off[0] / 2u;
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("" : "+v"(lb));
+#endif
+#pragma unroll
+    for (int k = 0; k < kLivePre; ++k) {
+        if ((uint32_t) k >= npre) break;
+        const uint16_t* base = h + (size_t) ring_slot(a.head, (uint32_t) k, F) * n;
+        if constexpr (PAIRED) {
+#pragma unroll
+            for (int e = 0; e < NV; e += 2) { const u32x2 t = ld<u32x2>(base, lb + (off[e] - off[0]) / 2u); pre[k][e] = t.x; pre[k][e + 1] = t.y; }
+        } else {
+#pragma unroll
+            for (int e = 0; e < NV; ++e) pre[k][e] = ld<uint32_t>(base, lb + (off[e] - off[0]) / 2u);
+        }
+    }
+    return npre;
+}
+template <int NV, bool PAIRED, bool TWO, int KPRE = 0>
+GLV_HD void gl16_state_block(uint32_t (&tex)[NV], const uint32_t (&off)[NV], size_t row, uint32_t n, const FrameArgs& a,
+                             const uint32_t (*pre)[NV] = nullptr, uint32_t npre = 0) {
     // Every access is `uniform base + lane offset + compile-time constant` (off[e] - off[0] is a constant: the points of a lane are a fixed
     // pattern).  The lane offset is re-defined opaquely per call: inside the history loop the backend otherwise hoists its zero-extension out of
     // the loop and then forms a 64-bit address per access and trip with v_lshl_add_u64 (two registers each) instead of the
@@ -485,7 +514,21 @@ GLV_HD void gl16_state_block(uint32_t (&tex)[NV], const uint32_t (&off)[NV], siz
         for (int e = 0; e < NV; ++e) { acc[e].x = 0.0f; acc[e].y = 0.0f; prev[e] = 0u; }
         if (F == 1) load(prev, h + (size_t) a.head * n);                     // the gravity store of a one-frame ring is the slot itself
         uint32_t f = 0;
-        if constexpr (TWO) for (; f + 2 < F; f += 2) {                       // oldest .. second newest, two frames per trip
+        if constexpr (KPRE > 0) {                                            // the prefetched slots, oldest first (uniform tests: npre, F)
+#pragma unroll
+            for (int k = 0; k < KPRE; ++k) {
+                if ((uint32_t) k >= npre) break;
+                const float w = windowed ? a.wts32[k] : 1.0f;
+#pragma unroll
+                for (int e = 0; e < NV; ++e) weighted_texels(acc[e], pre[k][e], w, true);
+                if ((uint32_t) k + 2u == F) {                                // slot F - 2: the previous newest == the gravity store
+#pragma unroll
+                    for (int e = 0; e < NV; ++e) prev[e] = pre[k][e];
+                }
+            }
+            f = npre;
+        }
+        if constexpr (TWO && KPRE == 0) for (; f + 2 < F; f += 2) {          // oldest .. second newest, two frames per trip
             uint32_t p0[NV];
             load(p0, h + (size_t) ring_slot(a.head, f, F) * n);
             load(prev, h + (size_t) ring_slot(a.head, f + 1, F) * n);
@@ -1095,9 +1138,22 @@ struct Frame {
     static constexpr int LIVE_SLOTS = LIVE_RBLOCKS * PassInfo<P - 1>::NG;
     static constexpr int LIVE_POINTS = LIVE_RBLOCKS * PassInfo<P - 1>::L0;
     static_assert(LIVE_SLOTS <= GL16_BLK, "the live points of a lane are one state block");
+    // the live class's state prefetch (gl16_state_prefetch): where its 4 x LIVE_SLOTS registers fit -- E <= 16
+    static constexpr bool LIVE_PREFETCH = LOG_E <= 4;
+    struct LivePre { uint32_t t[kLivePre][LIVE_SLOTS]; uint32_t n; };
+    GLV_HD static void live_offsets(uint32_t (&off)[LIVE_SLOTS], int tid) {      // byte offsets (of a float row) of the lane's live points, block by block of the row
+        using PI = PassInfo<P - 1>;
+#pragma unroll
+        for (int j = 0; j < LIVE_SLOTS; ++j) off[j] = (uint32_t) out_index<P - 1>(tid, j % PI::NG, bitrev(j / PI::NG, PI::RB)) * 8u;
+    }
+    GLV_HD static void live_prefetch(LivePre& lp, size_t row, int tid, const FrameArgs& a) {
+        uint32_t off[LIVE_SLOTS];
+        live_offsets(off, tid);
+        lp.n = gl16_state_prefetch<LIVE_SLOTS, (PassInfo<P - 1>::NG >= 2)>(lp.t, off, row, (uint32_t) N, a);
+    }
     template <int LOG_MODE, int TILTREG, bool NONFINITE, bool TO_LDS, bool LIVE = false>
     GLV_HD static void epilogue_gl16(const cf (&v)[E], float* out_row, size_t row, int tid, const FrameArgs& a,
-                                     const LogEntry* logtab, const cf* tl_reg = nullptr) {
+                                     const LogEntry* logtab, const cf* tl_reg = nullptr, const LivePre* lp = nullptr) {
         using PI = PassInfo<P - 1>;
         constexpr bool PAIRED = PI::NG >= 2;
         constexpr int SLOTS = LIVE ? LIVE_SLOTS : E, BLK = LIVE ? LIVE_SLOTS : GL16_BLK;
@@ -1138,7 +1194,10 @@ struct Frame {
                 tex[j] = texels(gi, r);
                 off[j] = (uint32_t) out_index<P - 1>(tid, gi, r) * 8u;
             }
-            gl16_state_block<BLK, PAIRED, (LOG_NN <= GLV_STATE_PAIR_MAX)>(tex, off, row, (uint32_t) N, a);
+            if constexpr (LIVE && LIVE_PREFETCH) {
+                if (lp != nullptr) gl16_state_block<BLK, PAIRED, (LOG_NN <= GLV_STATE_PAIR_MAX), kLivePre>(tex, off, row, (uint32_t) N, a, lp->t, lp->n);
+                else gl16_state_block<BLK, PAIRED, (LOG_NN <= GLV_STATE_PAIR_MAX)>(tex, off, row, (uint32_t) N, a);
+            } else gl16_state_block<BLK, PAIRED, (LOG_NN <= GLV_STATE_PAIR_MAX)>(tex, off, row, (uint32_t) N, a);
             if (TO_LDS || !r16_out) {
 #pragma unroll
                 for (int j = 0; j < BLK; j += (PAIRED ? 2 : 1)) {

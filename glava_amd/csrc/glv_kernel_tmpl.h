@@ -290,6 +290,10 @@ glv_frame_kernel(const FrameArgs a) {
     static_assert(!FUSED_BARS || WAVE_SLOT, "fused bars need whole waves per row");
     static_assert(!GL16 || LOG_MODE != 2, "the GL_R16 chain is built for log modes 0 and 1");
     static_assert(!FUSED_BARS || NBUF == 1, "fused bars park the finished row in exchange region 0: needs the full-size, two-barrier region");
+    // class 7 in the s16 frame pipeline: the row's old state is requested before its transform (glv_frame.h gl16_state_prefetch)
+    constexpr bool LIVE_PRE = GL16_LIVE && FR::LIVE_PREFETCH && S16 && PREFETCH == 1;
+    typename FR::LivePre live_pre;
+    const typename FR::LivePre* live_pre_ptr = nullptr;
     auto finish = [&](const cf (&v)[E], size_t row, int tid) {
         // a.out == nullptr (gravity without average only): the spectra ARE the gravity state
         // (render.c:733-734 stores the same value to both), so the second copy is not written
@@ -298,7 +302,7 @@ glv_frame_kernel(const FrameArgs a) {
         if constexpr (GL16) {
             float* o = FUSED_BARS ? reinterpret_cast<float*>(xslot)
                                   : ((a.ops & OP_R16) ? reinterpret_cast<float*>(reinterpret_cast<uint16_t*>(a.out) + row * N) : a.out + row * N);
-            FR::template epilogue_gl16<LOG_MODE, TILTREG, NF, FUSED_BARS, GL16_LIVE>(v, o, row, tid, a, logtab, tilt_reg);
+            FR::template epilogue_gl16<LOG_MODE, TILTREG, NF, FUSED_BARS, GL16_LIVE>(v, o, row, tid, a, logtab, tilt_reg, live_pre_ptr);
         } else if constexpr (STATEFUL == 4) {
             float* out16 = reinterpret_cast<float*>(reinterpret_cast<uint16_t*>(a.out) + row * N);
             if (raw_out) FR::template epilogue<LOG_MODE, EPI_RAW_STATE, 0, true, NF>(v, out16, row, tid, a, logtab);
@@ -443,6 +447,7 @@ glv_frame_kernel(const FrameArgs a) {
             const bool active = fraw < nframes;
             const uint32_t f = frame_of(m);
             if (ch) FR::template load_pcm<RING>(raw, frame_ptr(frame_of(m + 1)), tid, a.rot);   // A
+            if constexpr (LIVE_PRE) { FR::live_prefetch(live_pre, (size_t) f * 2 + ch, tid, a); live_pre_ptr = &live_pre; }   // A': the row's old state (W awaits it)
             GLV_SCHED_FENCE();
             BD::template run<0>(v, tw_all, a.tw, xslot, tid, xcount, lds_tw, sy);                            // B
             GLV_SCHED_FENCE();

@@ -12,9 +12,10 @@
 #   overlap[:<streams>]  two / four batches on as many streams against one (tools/sm_overlap.py)
 #   single           one GLava instance: the default pipeline per update, batched API and host drop-in (tools/single_instance.py)
 #   power            tools/power_probe.py
+#   modes:<what>     the stateful chains' speeds (profiles/r06/modes.txt): alloc | counters | multi | stateless | probe (tools/modes*.py, mode_probe.py; every rocprofv3 run bounded)
 # GLV_PMC_EXTRA="<counters>" adds a PMC pass to headline / prof / size.
 cd "$GRAFT_REPO_ROOT" || exit 1
-R=${1:-r05}; shift
+R=${1:-r06}; shift
 O=$GRAFT_REPO_ROOT/gpurun_out/$R
 mkdir -p "$O"
 for sec in "$@"; do
@@ -42,6 +43,11 @@ PY
     overlap)    timeout 300 python tools/sm_overlap.py 16384 60 2>&1 | tail -2 | tee "$O/overlap.txt" ;;
     overlap:*)  k=${sec#overlap:}; timeout 300 python tools/sm_overlap.py "$k" 40 2>&1 | tail -5 | tee "$O/overlap_$k.txt" ;;
     single)     timeout 300 python tools/single_instance.py 2>&1 | tail -2 | tee "$O/single_instance.txt" ;;
+    modes:alloc)     GLV_MODES_POLICIES="malloc vmm:0 vmm:2 fine" timeout 600 python tools/modes.py alloc chain 6 2>&1 | tee "$O/modes_alloc.txt" ;;
+    modes:counters)  timeout 900 python tools/modes.py counters chain 3 2>&1 | cut -c1-400 | tee "$O/modes_counters.txt" ;;
+    modes:multi)     (timeout 200 python tools/modes_multi.py chain 6; timeout 200 python tools/modes_multi.py gl 6) 2>&1 | grep -v amdgpu.ids | tee "$O/modes_multi.txt" ;;
+    modes:stateless) timeout 200 python tools/modes_stateless.py 6 2>&1 | grep -v amdgpu.ids | tee "$O/modes_stateless.txt" ;;
+    modes:probe)     timeout 400 python tools/mode_probe.py chain 240 > "$O/mode_probe_240s.txt" 2>&1; grep "^second" "$O/mode_probe_240s.txt" | awk '{print $3}' | sort -n | sed -n '1p;$p' ;;
     power)      python tools/power_probe.py --seconds 5 > "$O/power.txt" 2>/dev/null; cat "$O/power.txt" ;;
     *)          echo "unknown section $sec" ;;
   esac

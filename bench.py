@@ -209,6 +209,17 @@ def extra_configs(G, torch, device, a, peak_gbs):
     b.reset()
     dt, kms = run(b, lambda: b.process_s16(pcm, o, gops, st0))
     c2["spectra_out_private_state"] = entry("same chain with the batch-owned state (the default): spectra written twice, 28 N B/frame", s, b.algorithmic_bytes(gops), dt, kms)
+    # ... and with GLV_OP_BARS_ONLY (round 6): the 80 bars are all this configuration outputs, and smooth_audio() samples bins below 0.30 n -- the live kernel
+    # class (8) computes magnitude and keeps the gravity state for 3/8 of the row only; the same bars bit for bit (tests/test_gl_fused.py).  roofline_frac is
+    # against ITS OWN algorithmic bytes (4 N + 16 L + 640, L the live bins); frac_of_full_chain prices the same frames at configs[2]'s 20 N + 640 B.
+    b6 = G.Batch(G.Params(n=n, log_mode=a.log_mode, bars=bars), s, G.OP_GRAVITY | G.OP_BARS | G.OP_BARS_ONLY, device=device)
+    pl = place(b6, pcm, ob, gops | G.OP_BARS)
+    dt, kms = run(b6, lambda: b6.process_s16(pcm, ob, gops | G.OP_BARS, st0))
+    c2["bars_only"] = entry(f"BASELINE configs[2] with GLV_OP_BARS_ONLY: live bins {b6.live_bins()} of {n}; same bars bit for bit", s, b6.algorithmic_bytes(gops | G.OP_BARS), dt, kms)
+    c2["bars_only"]["live_bins"] = b6.live_bins()
+    c2["bars_only"]["placement"] = pl
+    c2["bars_only"]["frac_of_full_chain"] = (20 * n + 8 * bars) * s / (c2["bars_only"]["avg_kernel_ms"] * 1e-3) / 1e9 / peak_gbs
+    b6.close()
     out["configs[2]"] = c2
     b.close(); del pcm, o, ob
     torch.cuda.empty_cache()
@@ -236,6 +247,16 @@ def extra_configs(G, torch, device, a, peak_gbs):
     gl["bars_out"]["launches_per_step"] = b.last_launches()
     gl["bars_out"]["placement"] = pl
     b.close()
+    b7 = G.Batch(pg, s, G.OP_GRAVITY | G.OP_AVERAGE | G.OP_BARS | G.OP_BARS_ONLY, device=device)       # the same with GLV_OP_BARS_ONLY (kernel class 9)
+    pl = place(b7, pcm, qb, glops | G.OP_BARS | G.OP_R16)
+    dt, kms = run(b7, lambda: b7.process_s16(pcm, qb, glops | G.OP_BARS | G.OP_R16, st0))
+    gl["bars_out_live"] = entry(f"the GL chain + {bars} bars with GLV_OP_BARS_ONLY: live bins {b7.live_bins()} of {n}, one launch, same bars bit for bit; roofline_frac on its own bytes",
+                                s, b7.algorithmic_bytes(glops | G.OP_BARS | G.OP_R16), dt, kms)
+    gl["bars_out_live"]["launches_per_step"] = b7.last_launches()
+    gl["bars_out_live"]["live_bins"] = b7.live_bins()
+    gl["bars_out_live"]["placement"] = pl
+    gl["bars_out_live"]["frac_of_24N"] = gl["bars_out"]["algorithmic_bytes_per_launch"] / (gl["bars_out_live"]["avg_kernel_ms"] * 1e-3) / 1e9 / peak_gbs
+    b7.close()
     # ... and with the pre-smoothing pass of render.c:2277-2303 behind it (bars == n at the texel centres: the texture every stock
     # module samples under setsmoothpass, GLava's shipped configuration): the fused GL kernel hands the `av` rows over as uint16
     # texels and the pass runs in exact integer arithmetic on the i8 matrix cores (round 5) -- two launches.  roofline_frac is
@@ -668,6 +689,7 @@ def main() -> None:
             g = configs["gl_default"]
             chains["gl_default"] = chain_rec(g, streams, "GLava's shipped accel chain (render.c:2188-2265): upload, GL_MAX + gravity, ring, average on GL_R16 state -> `av` texels, one launch, 28 N B/frame")
             chains["gl_default_bars"] = chain_rec(g.get("bars_out"), streams, "... + the 80 bars of the bars / radial modules in the same launch")
+            chains["gl_default_bars_live"] = chain_rec(g.get("bars_out_live"), streams, "... the same with GLV_OP_BARS_ONLY (live bins only); frac on ITS OWN bytes")
             chains["sm_out"] = chain_rec(g.get("sm_out"), streams, "... + the pre-smoothing pass (render.c:2277-2303) -> `sm` texels: what GLava ships end to end, two launches, 28 N B/frame")
             chains["sm_out_live"] = chain_rec(g.get("sm_out_live"), streams, "the same `sm` texels with the state kept only for the bins the pass samples (GLV_OP_BARS_ONLY); frac on ITS OWN bytes, frac_of_28N for comparison")
         line["roofline"]["chains"] = {k: v for k, v in chains.items() if v}

@@ -322,17 +322,23 @@ struct glv_batch {
     float* d_bar_wsum = nullptr;
     glv::BarTile* d_bar_rounds = nullptr;
     uint32_t bar_ntiles = 0, bar_nrounds = 0, bar_ring_bins = 0, bar_bins_needed = 0;      // bar_bins_needed: bins of a row the many-bars kernels sample (0: all)
-    // GLV_OP_BARS_ONLY (gl_storage 1 + many bars through the integer pass): the chain lives below bar_bins_needed -- when EVERY kernel configuration of
-    // the size keeps those bins alive in its live class (a compile-time share of the row, FrameGeometry::live_points; whichever configuration a call
-    // runs, the bins the bars sample are maintained); 0: every bin is live (no flag, or the bars reach further than the live classes keep: the full chain)
-    uint32_t live_bins_now = 0;                     // refreshed with the bar tables (update_live_bins)
+    // GLV_OP_BARS_ONLY: the chain lives below bar_bins_sampled (the last bin any bar has a tap on, rounded up to 64) -- when EVERY kernel configuration
+    // of the size keeps those bins alive in its live class (a compile-time share of the row, FrameGeometry::live_points; whichever configuration a
+    // call runs, the bins the bars sample are maintained) and a live class exists for the chain: the GL_R16 chains have one with the bars in a second
+    // launch (7) and one with the bars fused (9); the float chains only the fused one (8).
+    // 0: every bin is live (no flag, or one of the conditions fails: the full chain, the same results)
+    uint32_t bar_bins_sampled = 0;
+    uint32_t live_bins_now = 0;                     // refreshed with the bar tables and when the batch is prepared (update_live_bins)
     uint32_t live_bins() const { return live_bins_now; }
     void update_live_bins() {
         live_bins_now = 0u;
-        if (!(ops_mask & GLV_OP_BARS_ONLY) || bar_bins_needed == 0 || bar_bins_needed >= p.n) return;
+        if (!(ops_mask & GLV_OP_BARS_ONLY) || bar_bins_sampled == 0 || bar_bins_sampled >= p.n || p.gl_storage > 1u || p.log_mode == 2u) return;
         for (int v = 0; v < glv::frame_variants(log_nn); ++v)
-            if ((uint32_t) glv::frame_geometry(log_nn, v).live_points * 2u < bar_bins_needed) return;
-        live_bins_now = bar_bins_needed;
+            if ((uint32_t) glv::frame_geometry(log_nn, v).live_points * 2u < bar_bins_sampled) return;
+        // (a float chain's live class is the fused one: the production configuration must take the bars; a call that runs a configuration which cannot
+        // -- forced, or from the wisdom -- takes the full chain for that call: it maintains every bin, the live calls the sampled ones, the bars see no difference)
+        if (p.gl_storage == 0u && (!bar_fusable[0] || unfused_bars)) return;
+        live_bins_now = bar_bins_sampled;
     }
     glv::BarRowsTables rows_tables() const { return glv::BarRowsTables{d_bar_mtiles, bar_ntiles, d_bar_wt, d_bar_wsum, d_bar_rounds, bar_nrounds, bar_ring_bins}; }
     // the same pass over TEXEL rows (the GL chains, gl_storage != 0): exact integer arithmetic on the i8 matrix cores (glv_tables.h make_bar_itiles)
@@ -601,8 +607,12 @@ int ensure_bar_tables(glv_batch* b) {
     HIP_TRY(hipMemcpy(b->d_bar_desc, desc.data(), sizeof(glv::BarDesc) * desc.size(), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(b->d_bar_w, w.data(), sizeof(float) * w.size(), hipMemcpyHostToDevice));
     b->bar_count = b->p.bars; b->bar_factor = b->p.smooth_factor; b->bar_phase = b->p.bar_phase;
+    b->bar_bins_sampled = 0;
+    for (const glv::BarDesc& d : desc) b->bar_bins_sampled = d.first_bin + d.count > b->bar_bins_sampled ? d.first_bin + d.count : b->bar_bins_sampled;
+    b->bar_bins_sampled = (b->bar_bins_sampled + 63u) & ~63u;                      // whole store instructions (the ring fill's 16-byte loads)
     // many bars (the pre-smoothing pass): tiles of 32 bars for the chain kernels; rounds for the smallest LDS ring that takes them
-    b->bar_ntiles = 0; b->bar_nrounds = 0; b->bar_ring_bins = 0; b->bar_bins_needed = 0; b->live_bins_now = 0;
+    b->bar_ntiles = 0; b->bar_nrounds = 0; b->bar_ring_bins = 0; b->bar_bins_needed = 0;
+    b->update_live_bins();
     if (b->p.bars >= glv::kBarSeqMin) {
         std::vector<glv::BarMTile> mtiles;
         std::vector<glv::BarTile> rounds;
@@ -623,7 +633,6 @@ int ensure_bar_tables(glv_batch* b) {
         b->bar_bins_needed = 0;
         for (const glv::BarDesc& d : desc) b->bar_bins_needed = d.first_bin + d.count > b->bar_bins_needed ? d.first_bin + d.count : b->bar_bins_needed;
         b->bar_bins_needed = (b->bar_bins_needed + 63u) & ~63u;                     // whole store instructions (and slack for the fill's 16-byte loads)
-        b->update_live_bins();
         if (!rounds.empty()) {
             HIP_TRY(hipMalloc(&b->d_bar_rounds, sizeof(glv::BarTile) * rounds.size()));
             HIP_TRY(hipMemcpy(b->d_bar_rounds, rounds.data(), sizeof(glv::BarTile) * rounds.size(), hipMemcpyHostToDevice));
@@ -715,6 +724,7 @@ int batch_prepare(glv_batch* b) {
                          && b->p.log_mode != 2 && !b->unfused_bars;
         for (int v = 0; v < glv::frame_variants(b->log_nn) && v < glv_batch::kMaxVariants; ++v) all_fused = all_fused && b->bar_fusable[v];
         if (!all_fused && !b->d_scratch) HIP_TRY(hipMalloc(&b->d_scratch, sizeof(float) * (size_t) b->rows * b->p.n));
+        b->update_live_bins();
     }
     // function attributes (the > 64 KiB dynamic-LDS opt-in) of every frame kernel this batch can launch: set here, once per device
     // and instantiation, so that a process call is a plain launch (launch_variant with grid 0 = attribute only; combinations
@@ -725,7 +735,8 @@ int batch_prepare(glv_batch* b) {
         std::memset(&a, 0, sizeof(a));
         const struct { unsigned ops; bool bars; uint32_t gl, live; } cls[] = {
             {GLV_OP_FFT, false, 0, 0}, {GLV_OP_FFT | GLV_OP_R16, false, 0, 0}, {GLV_OP_FFT | GLV_OP_GRAVITY, false, 0, 0}, {GLV_OP_FFT | GLV_OP_GRAVITY | GLV_OP_R16, false, 0, 0},
-            {GLV_OP_FFT | GLV_OP_GRAVITY, true, 0, 0}, {GLV_OP_FFT | GLV_OP_GRAVITY, false, 1, 0}, {GLV_OP_FFT | GLV_OP_GRAVITY, true, 1, 0}, {GLV_OP_FFT | GLV_OP_GRAVITY, false, 1, 1}};
+            {GLV_OP_FFT | GLV_OP_GRAVITY, true, 0, 0}, {GLV_OP_FFT | GLV_OP_GRAVITY, false, 1, 0}, {GLV_OP_FFT | GLV_OP_GRAVITY, true, 1, 0}, {GLV_OP_FFT | GLV_OP_GRAVITY, false, 1, 1},
+            {GLV_OP_FFT | GLV_OP_GRAVITY, true, 0, 1}, {GLV_OP_FFT | GLV_OP_GRAVITY, true, 1, 1}};
         for (int in_mode = 0; in_mode < kInKinds; ++in_mode)
             for (int v = 0; v < glv::frame_variants(b->log_nn); ++v)
                 for (const auto& c : cls) {
@@ -924,6 +935,8 @@ int process(glv_batch* b, const void* d_in, int in_mode, float* d_out, unsigned 
         return timed_launch_end(b, st);            // the HIP-event window covers every launch of the chain
     }
     if (gl_split) a.gl_storage = b->p.gl_storage;                    // operators on planar rows: the post kernel models it directly
+    // GLV_OP_BARS_ONLY on a float chain with the bars fused (kernel class 8): magnitude, state and the row in LDS for the live blocks only
+    if (b->live_bins() != 0 && fused_bars && !gl_split && (ops & GLV_OP_FFT)) a.live_points = b->live_bins() / 2u;
 
     if (int rc = timed_launch_begin(b, st)) return rc;
     const unsigned core = ops & (GLV_OP_FFT | GLV_OP_GRAVITY | GLV_OP_AVERAGE | GLV_OP_WRANGE | GLV_OP_MAGNITUDE | GLV_OP_R16);
@@ -1212,6 +1225,7 @@ int glv_batch_gravity_state(glv_batch* b, const float** d_state) {
         return fail(GLV_ERR_STATE, "gravity runs fused with average on this batch: its state is the newest slot of the history ring "
                                    "(float [rows][F][n], not a [streams][2][n] array); request the chain's output instead");
     if (b->state16) return fail(GLV_ERR_STATE, "gl_storage 1 keeps the gravity store as uint16 texels, not floats: request the chain's output instead");
+    if (b->ops_mask & GLV_OP_BARS_ONLY) return fail(GLV_ERR_STATE, "the batch was created with GLV_OP_BARS_ONLY: its gravity state exists only where the bars sample");
     *d_state = b->grav_cur;
     return GLV_OK;
 }
@@ -1286,7 +1300,7 @@ uint64_t glv_batch_algorithmic_bytes(const glv_batch* b, unsigned ops, int input
     //   class keeps (FrameGeometry::live_points: an implementation granularity, its extra bytes are traffic above the algorithmic figure)
     uint64_t L = N;
     if (b->live_bins() != 0 && stateful && (ops & GLV_OP_BARS)) L = b->live_bins();
-    const uint64_t sv = (b->state16 && stateful) ? 4 * L : 8 * N;          // one state slot of both channels
+    const uint64_t sv = (b->state16 && stateful) ? 4 * L : 8 * L;          // one state slot of both channels
     uint64_t per = input_is_s16 ? 4 * N : 8 * N;
     const bool bars = (ops & GLV_OP_BARS) != 0;
     if (bars) per += (uint64_t) ((ops & GLV_OP_R16) ? 4 : 8) * b->p.bars;

@@ -991,11 +991,17 @@ struct Frame {
     // folded factor from two fused multiply-adds (glv_core.h tilt_lin; tl_reg[0].x carries the lane's base term), else as 2
     // R16: the output row is uint16 [n] (GL_R16 texels, glv_core.h unorm16) instead of float [n]; state stays f32
     // NONFINITE: the row may hold Inf / NaN (f32 input): log_mode 0 then needs log_third_nf's select
-    template <int LOG_MODE, int EPI, int TILTREG = 0, bool R16 = false, bool NONFINITE = false>
+    // LIVE (GLV_OP_BARS_ONLY with the bars fused, kernel class 8; stateful only): magnitude, state and the row in LDS for the lane's LIVE_SLOTS live
+    // register slots only, enumerated block by block of the row (see epilogue_gl16 below) -- what the fused bars never sample is neither computed nor kept
+    template <int LOG_MODE, int EPI, int TILTREG = 0, bool R16 = false, bool NONFINITE = false, bool LIVE = false>
     GLV_HD static void epilogue(const cf (&v)[E], float* out_row, size_t row, int tid, const FrameArgs& a,
                                 const LogEntry* logtab, const cf* tl_reg = nullptr) {
         using PI = PassInfo<P - 1>;
         constexpr bool STATE = EPI == EPI_MAG_STATE || EPI == EPI_RAW_STATE;
+        static_assert(!LIVE || STATE, "the live class is a stateful one");
+        constexpr int NS = LIVE ? (E >> PI::RB) * ((3 * PI::R + 7) / 8) : E;       // == LIVE_SLOTS (declared below)
+        // register slot (gi, r) of the lane's idx-th point: r outer, gi inner; LIVE: r in the order of the row's blocks
+        auto slot_r = [](int idx) constexpr -> int { return LIVE ? bitrev(idx / PI::NG, PI::RB) : idx / PI::NG; };
         // TILTREG 3: the lane's base term, re-defined opaquely per row -- the factors derived from it are loop invariant and
         // LLVM would otherwise hoist all 2E of them out of the row loop (and spill them)
         float tilt_base = 0.0f;
@@ -1065,13 +1071,13 @@ struct Frame {
                 const float* gs = a.grav + row * (size_t) N;
                 float* gw = a.grav_w + row * (size_t) N;
                 
-                cf st0[E];
+                cf st0[NS];
 #pragma unroll
-                for (int idx = 0; idx < E; ++idx)
-                    st0[idx] = ld<cf>(gs, (uint32_t) out_index<P - 1>(tid, idx % PI::NG, idx / PI::NG) * 8u);
+                for (int idx = 0; idx < NS; ++idx)
+                    st0[idx] = ld<cf>(gs, (uint32_t) out_index<P - 1>(tid, idx % PI::NG, slot_r(idx)) * 8u);
 #pragma unroll
-                for (int idx = 0; idx < E; idx += (PI::NG >= 2 ? 2 : 1)) {
-                    const int r = idx / PI::NG, gi = idx % PI::NG;
+                for (int idx = 0; idx < NS; idx += (PI::NG >= 2 ? 2 : 1)) {
+                    const int r = slot_r(idx), gi = idx % PI::NG;
                     const uint32_t off = (uint32_t) out_index<P - 1>(tid, gi, r) * 8u;
                     cf va = value(gi, r);
                     va.x = gravity(va.x, st0[idx].x, a.g); va.y = gravity(va.y, st0[idx].y, a.g);
@@ -1090,16 +1096,16 @@ struct Frame {
             }
             // stateful: the lane's E points in blocks of BLK, loads of a block issued together
             // (apply_state_block); BLK bounds the registers the history loads need
-            constexpr int BLK = E / 2 > 0 ? E / 2 : 1;
+            constexpr int BLK = LIVE ? NS : (E / 2 > 0 ? E / 2 : 1);
 #pragma unroll
-            for (int h0 = 0; h0 < E; h0 += BLK) {
+            for (int h0 = 0; h0 < NS; h0 += BLK) {
                 cf val[BLK];
                 uint32_t off[BLK];
                 {
                     // enumeration order: r outer, gi inner => adjacent groups sit next to each other in val[]
 #pragma unroll
                     for (int j = 0; j < BLK; ++j) {
-                        const int idx = h0 + j, r = idx / PI::NG, gi = idx % PI::NG;
+                        const int idx = h0 + j, r = slot_r(idx), gi = idx % PI::NG;
                         val[j] = value(gi, r);
                         off[j] = (uint32_t) out_index<P - 1>(tid, gi, r) * 8u;
                     }
@@ -1137,7 +1143,7 @@ struct Frame {
     static constexpr int LIVE_RBLOCKS = (3 * PassInfo<P - 1>::R + 7) / 8;
     static constexpr int LIVE_SLOTS = LIVE_RBLOCKS * PassInfo<P - 1>::NG;
     static constexpr int LIVE_POINTS = LIVE_RBLOCKS * PassInfo<P - 1>::L0;
-    static_assert(LIVE_SLOTS <= GL16_BLK, "the live points of a lane are one state block");
+    static_assert(LIVE_SLOTS <= GL16_BLK && LIVE_SLOTS <= (E / 2 > 0 ? E / 2 : 1), "the live points of a lane are one state block");
     // the live class's state prefetch (gl16_state_prefetch): where its 4 x LIVE_SLOTS registers fit -- E <= 16
     static constexpr bool LIVE_PREFETCH = LOG_E <= 4;
     struct LivePre { uint32_t t[kLivePre][LIVE_SLOTS]; uint32_t n; };

@@ -283,10 +283,12 @@ glv_frame_kernel(const FrameArgs a) {
     // state (glv_frame.h epilogue_gl16); output GL_R16 texels or their floats (a.ops & OP_R16, uniform).  6: the same with the
     // bars computed in the kernel (the finished row's floats go to the slot's LDS region), bars as floats or texels (a.bars_r16)
     // 7: class 5 for GLV_OP_BARS_ONLY batches (a.live_points != 0): state, average and output for the row's live blocks only (glv_frame.h epilogue_gl16 LIVE)
-    constexpr bool FUSED_BARS = STATEFUL == 2 || STATEFUL == 6;
-    constexpr bool GL16 = STATEFUL == 5 || STATEFUL == 6 || STATEFUL == 7;
-    constexpr bool GL16_LIVE = STATEFUL == 7;
-    constexpr bool HAS_STATE = STATEFUL == 1 || STATEFUL == 2 || STATEFUL == 4 || GL16;
+    // 8 / 9: classes 2 / 6 (bars fused) for GLV_OP_BARS_ONLY batches: magnitude, state and the row in LDS for the live blocks only
+    constexpr bool FUSED_BARS = STATEFUL == 2 || STATEFUL == 6 || STATEFUL == 8 || STATEFUL == 9;
+    constexpr bool GL16 = STATEFUL == 5 || STATEFUL == 6 || STATEFUL == 7 || STATEFUL == 9;
+    constexpr bool GL16_LIVE = STATEFUL == 7 || STATEFUL == 9;
+    constexpr bool F32_LIVE = STATEFUL == 8;
+    constexpr bool HAS_STATE = STATEFUL == 1 || STATEFUL == 2 || STATEFUL == 4 || STATEFUL == 8 || GL16;
     static_assert(!FUSED_BARS || WAVE_SLOT, "fused bars need whole waves per row");
     static_assert(!GL16 || LOG_MODE != 2, "the GL_R16 chain is built for log modes 0 and 1");
     static_assert(!FUSED_BARS || NBUF == 1, "fused bars park the finished row in exchange region 0: needs the full-size, two-barrier region");
@@ -307,6 +309,8 @@ glv_frame_kernel(const FrameArgs a) {
             float* out16 = reinterpret_cast<float*>(reinterpret_cast<uint16_t*>(a.out) + row * N);
             if (raw_out) FR::template epilogue<LOG_MODE, EPI_RAW_STATE, 0, true, NF>(v, out16, row, tid, a, logtab);
             else FR::template epilogue<LOG_MODE, EPI_MAG_STATE, TILTREG, true, NF>(v, out16, row, tid, a, logtab, tilt_reg);
+        } else if constexpr (F32_LIVE) {
+            FR::template epilogue<LOG_MODE, EPI_MAG_STATE, TILTREG, false, NF, true>(v, out_row, row, tid, a, logtab, tilt_reg);
         } else if constexpr (HAS_STATE) {
             if (raw_out) FR::template epilogue<LOG_MODE, EPI_RAW_STATE, 0, false, NF>(v, out_row, row, tid, a, logtab);
             else FR::template epilogue<LOG_MODE, EPI_MAG_STATE, TILTREG, false, NF>(v, out_row, row, tid, a, logtab, tilt_reg);
@@ -602,21 +606,25 @@ hipError_t launch_variant(const FrameArgs& a, int grid, hipStream_t st) {
     // the GL_R16 chain (gl_storage == 1: uint16 state): built for log modes 0 and 1
     if (a.gl_storage == 1 && (a.ops & (OP_GRAVITY | OP_AVERAGE))) {
         if constexpr (LOG_MODE != 2) {
-            static AttrDone done_gl16, done_gl16_bars, done_gl16_live;
+            static AttrDone done_gl16, done_gl16_bars, done_gl16_live, done_gl16_bars_live;
             if (a.live_points != 0 && a.bars_out == nullptr)
                 return launch(glv_frame_kernel<LOG_NN, IN_MODE, LOG_MODE, SLOTS, NBUF, TW_STATEFUL, WINLDS, OCC, PREFETCH, TILTREG, LOG_E, 7, WPRE_S>, done_gl16_live);
             if (a.bars_out != nullptr) {
-                if constexpr (FR::T % 64 == 0 && NBUF == 1)
+                if constexpr (FR::T % 64 == 0 && NBUF == 1) {
+                    if (a.live_points != 0)
+                        return launch(glv_frame_kernel<LOG_NN, IN_MODE, LOG_MODE, SLOTS, NBUF, TW_STATEFUL, WINLDS, OCC, PREFETCH, TILTREG, LOG_E, 9, WPRE_S>, done_gl16_bars_live);
                     return launch(glv_frame_kernel<LOG_NN, IN_MODE, LOG_MODE, SLOTS, NBUF, TW_STATEFUL, WINLDS, OCC, PREFETCH, TILTREG, LOG_E, 6, WPRE_S>, done_gl16_bars);
-                else return hipErrorInvalidValue;
+                } else return hipErrorInvalidValue;
             }
             return launch(glv_frame_kernel<LOG_NN, IN_MODE, LOG_MODE, SLOTS, NBUF, TW_STATEFUL, WINLDS, OCC, PREFETCH, TILTREG, LOG_E, 5, WPRE_S>, done_gl16);
         } else return hipErrorInvalidValue;
     }
     if (a.bars_out != nullptr) {
         if constexpr (FR::T % 64 == 0 && NBUF == 1) {
-            static AttrDone done_bars;
+            static AttrDone done_bars, done_bars_live;
             if (!(a.ops & (OP_GRAVITY | OP_AVERAGE))) return hipErrorInvalidValue;
+            if (a.live_points != 0)
+                return launch(glv_frame_kernel<LOG_NN, IN_MODE, LOG_MODE, SLOTS, NBUF, TW_STATEFUL, WINLDS, OCC, PREFETCH, TILTREG, LOG_E, 8, WPRE_S>, done_bars_live);
             return launch(glv_frame_kernel<LOG_NN, IN_MODE, LOG_MODE, SLOTS, NBUF, TW_STATEFUL, WINLDS, OCC, PREFETCH, TILTREG, LOG_E, 2, WPRE_S>, done_bars);
         } else return hipErrorInvalidValue;
     }

@@ -81,22 +81,29 @@ enum {
                                    op) it quantises planar f32 rows.  With GLV_OP_BARS the bars are what is quantised (d_out:
                                    uint16 [streams][2][bars]; the spectra feeding them stay f32): with gl_storage = 1, bars = n and
                                    bar_phase = 0.5 that is the texture every stock module samples -- upload, gravity, average and
-                                   pre-smoothing pass of render.c:2188-2303 in one call.  Excludes GLV_OP_RAW, GLV_OP_SMOOTH. */
+                                   pre-smoothing pass of render.c:2188-2303 in one call.  Excludes GLV_OP_RAW, GLV_OP_SMOOTH.
+                                   In glv_batch_create's ops_mask (ABI 6) the bit is a HINT and nothing else: a FLOAT chain (gl_storage 0)
+                                   with GLV_OP_BARS whose bars the transform kernel can compute itself gets the internal spectra rows --
+                                   which only its bars AS TEXELS need (they leave through a second launch) -- only when the mask carries
+                                   GLV_OP_R16 too; without it such a call is refused (GLV_ERR_STATE), with it nothing else changes. */
     GLV_OP_PRIVATE_STATE = 1u << 9, /* (ABI 3 flag, accepted and ignored since ABI 4: a batch-owned gravity state is the default again) */
     GLV_OP_RING_S16 = 1u << 10, /* glv_batch_create's ops_mask only: allocate (and zero, == the calloc'd rings of
                                    glava.c:487-494) the s16 device ring of glv_batch_ring_update_s16 / _append_s16; ring calls on
                                    a batch created without it are refused (GLV_ERR_STATE: nothing is allocated after creation) */
     GLV_OP_RING_F32 = 1u << 11, /* the same for the interleaved f32 ring of glv_batch_ring_update_f32 */
-    GLV_OP_BARS_ONLY = 1u << 13, /* glv_batch_create's ops_mask only (ABI 6), with GLV_OP_BARS on a gl_storage 1 batch: the caller promises that every
-                                   stateful call on this batch asks for GLV_OP_BARS -- the bars are all that is ever looked at (GLava's shipped
-                                   pipeline: the modules sample the pre-smoothed texture and nothing else, smooth.glsl:62).  smooth_audio() samples
-                                   bins below scale_audio(1) * n = 0.288 n plus half a window (SAMPLE_RANGE 0.9, SAMPLE_SCALE 8), so what the
-                                   reference's GL passes compute beyond that is dead: the chain then keeps its gravity store and ring, and
-                                   computes magnitude / upload / gravity / average, only for the bins the bars sample (rounded up to the
-                                   transform's last-pass block, 512 bins at n = 4096; glv_batch_live_bins tells) -- 15.5 n instead of 28 n bytes
-                                   per frame at n = 4096, F = 5.  The bars are bit-identical to those of a batch without the flag.  A stateful
-                                   call without GLV_OP_BARS, glv_batch_gravity_state and anything else that would read the state beyond the
-                                   live bins are refused (GLV_ERR_STATE) */
+    GLV_OP_BARS_ONLY = 1u << 13, /* glv_batch_create's ops_mask only (ABI 6), with GLV_OP_BARS: the caller promises that every stateful call on this
+                                   batch asks for GLV_OP_BARS -- the bars are all that is ever looked at (GLava's shipped pipeline: the modules sample
+                                   the pre-smoothed texture and nothing else, smooth.glsl:62; BASELINE configs[2]: the radial module's bars).
+                                   smooth_audio() samples bins below scale_audio(1) * n = 0.288 n plus half a window (SAMPLE_RANGE 0.9,
+                                   SAMPLE_SCALE 8), so what the reference's passes compute beyond that is dead: the chain then keeps its gravity
+                                   store and ring, and computes magnitude / upload / gravity / average, only for a compile-time share of the row
+                                   that covers the bins the bars sample (3/8 of it; glv_batch_live_bins tells whether the batch runs that way) --
+                                   15 n instead of 28 n bytes per frame at n = 4096, F = 5 on GL_R16 state.  Live kernel classes exist for the
+                                   GL_R16 chains (gl_storage 1: bars in a second launch or fused) and for float chains whose bars the transform
+                                   kernel computes itself (fewer than 256 bars, every kernel configuration of the size fusable); any other
+                                   batch, and bars that reach beyond the share (very wide smooth_factor), run the full chain: the bars are
+                                   bit-identical either way.  A stateful call without GLV_OP_BARS and glv_batch_gravity_state are refused
+                                   (GLV_ERR_STATE) */
     GLV_OP_OUTPUT_IS_STATE = 1u << 12 /* opt-in, with a chain that ENDS in gravity (GLV_OP_GRAVITY without AVERAGE / SMOOTH / RAW, f32
                                    rows out, no gl_storage): transform_gravity stores every value twice, to its `applied` array and to
                                    the buffer (render.c:733-734) -- with this flag ONE array is kept: the call writes the spectra

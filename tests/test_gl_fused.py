@@ -364,14 +364,17 @@ def test_presmoothing_pass_of_the_gl_chains_is_the_exact_integer_mean(glvlib, n,
 def test_float_chain_with_bars_as_texels_after_creation_time_allocation(glvlib):
     """gl_storage 0, GRAVITY | AVERAGE | BARS in the creation mask, 80 bars the transform kernel could compute itself --
     and then FFT | GRAVITY | AVERAGE | BARS | R16: the float chain's bars as texels leave through glv_bars_kernel, which needs the internal
-    spectra rows; they must have been allocated at creation (process calls never allocate).  The texels are the quantised float bars."""
+    spectra rows; they must have been allocated at creation (process calls never allocate).  The texels are the quantised float bars.
+    Since ABI 6 (512 MiB of rows nothing read at 16 K streams) a float chain whose every kernel configuration computes the bars itself
+    gets those rows only when the creation mask carries GLV_OP_R16 as well -- the hint that texel bars will be asked for; without it the call is
+    refused (GLV_ERR_STATE), never allocated mid-stream."""
     import torch
     G = glvlib
     n, streams, bars = 4096, 5, 80
     mask = G.OP_GRAVITY | G.OP_AVERAGE | G.OP_BARS
     ops = G.OP_FFT | mask
     p = G.Params(n=n, bars=bars)
-    bt, bf = G.Batch(p, streams, mask), G.Batch(p, streams, mask)
+    bt, bf = G.Batch(p, streams, mask | G.OP_R16), G.Batch(p, streams, mask)
     ot = torch.zeros((streams * 2, bars), dtype=torch.int16, device="cuda")
     of = torch.zeros((streams * 2, bars), dtype=torch.float32, device="cuda")
     for u in range(7):
@@ -380,6 +383,9 @@ def test_float_chain_with_bars_as_texels_after_creation_time_allocation(glvlib):
         bf.process_s16(d_pcm, of, ops)
         assert bf.last_launches() == 1 and bt.last_launches() == 2
         assert (ot.cpu().numpy().view(np.uint16) == Oracle.texels_r16(of.cpu().numpy())).all(), u
+    with pytest.raises(G.GlvError) as ei:                # no hint, no rows: refused
+        bf.process_s16(d_pcm, ot, ops | G.OP_R16)
+    assert ei.value.code == G.ERR_STATE
     bt.close(); bf.close()
 
 
@@ -509,3 +515,46 @@ def test_bars_only_chain_is_the_full_chain_on_the_bins_the_bars_sample(glvlib, n
             live.process_s16(torch.zeros((streams, n, 2), dtype=torch.int16, device="cuda"), o_l, G.OP_FFT | G.OP_GRAVITY | G.OP_AVERAGE | G.OP_R16)
         assert ei.value.code == G.ERR_STATE
         full.close(); live.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,gl,avg,bars", [(4096, 0, False, 80), (4096, 0, True, 80), (4096, 1, True, 80), (16384, 0, False, 80), (16384, 1, True, 80),
+                                           (8192, 0, True, 100), (2048, 1, True, 64), (1024, 0, True, 80)])
+def test_bars_only_with_the_bars_fused_is_the_full_chain(glvlib, n, gl, avg, bars):
+    """GLV_OP_BARS_ONLY where the transform kernel computes the bars itself (BASELINE configs[2]: N = 16384, gravity + the radial module's 80 bars; the bars
+    module's chain; the GL_R16 chain + 80 bars) -- kernel classes 8 (float state) and 9 (GL_R16 state): magnitude, state and the row in LDS for the live blocks
+    only.  The bars must equal those of a batch without the flag bit for bit over loud, quiet and silent updates in every kernel configuration of the size; one
+    launch; fewer algorithmic bytes when the live class is taken (glv_batch_live_bins != 0), the same when it is not; glv_batch_gravity_state is refused."""
+    import torch
+    G = glvlib
+    streams, F = (7 if n <= 8192 else 3), 3
+    kw = dict(n=n, avg_frames=F if avg else 1, avg_window_kind=1 if gl else 0, gl_storage=gl, bars=bars)
+    mask = G.OP_GRAVITY | (G.OP_AVERAGE if avg else 0) | G.OP_BARS
+    ops = G.OP_FFT | mask | (G.OP_R16 if gl else 0)
+    dt = torch.int16 if gl else torch.float32
+    took_live = 0
+    for variant in (0, 1):
+        full, live = G.Batch(G.Params(**kw), streams, mask), G.Batch(G.Params(**kw), streams, mask | G.OP_BARS_ONLY)
+        try:
+            full.set_variant(variant); live.set_variant(variant)
+        except G.GlvError:
+            full.close(); live.close()
+            continue
+        L = live.live_bins()
+        assert full.live_bins() == 0
+        if L: assert 0.28 * n < L <= 0.5 * n and live.algorithmic_bytes(ops) < full.algorithmic_bytes(ops), (L, n)
+        else: assert live.algorithmic_bytes(ops) == full.algorithmic_bytes(ops)
+        took_live += bool(L)
+        o_f = torch.full((streams * 2, bars), -1, dtype=dt, device="cuda"); o_l = torch.full_like(o_f, -2)
+        for u in range(F + 3):
+            pcm = (lcg_pcm_fast(9100 + u + n, streams * 2 * n) // (1, 8, 64)[u % 3]).astype(np.int16)
+            if u == 2: pcm[:] = 0
+            d_in = torch.from_numpy(pcm).cuda()
+            full.process_s16(d_in, o_f, ops); live.process_s16(d_in, o_l, ops)
+            assert live.last_launches() == full.last_launches()
+            assert torch.equal(o_f.view(torch.int16), o_l.view(torch.int16)), (n, gl, avg, variant, u, L)
+        if not gl and not avg:
+            with pytest.raises(G.GlvError) as ei: live.gravity_state()
+            assert ei.value.code == G.ERR_STATE
+        full.close(); live.close()
+    if n >= 2048: assert took_live >= 1, "no kernel configuration took the live class"

@@ -31,6 +31,9 @@ for k, v in d.get("configs", {}).get("gl_default", {}).items():
 for k in ("configs[2]", "n8192_stateless", "n16384_stateless", "ring_update"):
     v = d.get("configs", {}).get(k)
     if v: print(k, round(v["value"] / 1e6, 2), round(v["roofline_frac"], 4))
+v = d.get("configs", {}).get("configs[2]", {}).get("bars_only")
+if v: print("configs[2].bars_only", round(v["value"] / 1e6, 2), round(v["roofline_frac"], 4), "live", v.get("live_bins"), "priced at 20N:", round(v.get("frac_of_full_chain", 0), 4))
+for k, v in d.get("roofline", {}).get("chains", {}).items(): print("chain", k, round(v["frames_per_s"] / 1e6, 2), round(v["frac"], 4), v.get("placement"))
 print("multi_host_threads", d.get("configs", {}).get("multi_host_threads", {}).get("ratio"))
 PY
                 ;;

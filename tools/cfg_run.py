@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """One configuration, warmed up and launched back to back, for rocprofv3 (tools/profile_cmd.sh):
-    cfg_run.py configs2 | chain | n1024bars | gl_default | gl_bars | gl_sm | gl_sm64 | gl_sm64_live | ring  [calls]
+    cfg_run.py configs2 | configs2_live | chain | n1024bars | gl_default | gl_bars | gl_bars_live | gl_sm | gl_sm64 | gl_sm64_live | ring  [calls]
 0.3 s of spin-up launches first (the first dozens of launches after idle run ~20 % slower), then `calls` launches (default 150):
 the kernel-trace average then describes the warm kernel (the r03 summaries averaged 6 cold calls)."""
 import os, sys, time
@@ -14,6 +14,9 @@ _shake = torch.empty(int(os.environ.get("CFG_SHAKE_MB", "0")) << 20, dtype=torch
 kw, mask, dt, width = {}, 0, torch.float32, None
 if which == "configs2":
     n, streams, ops, bars = 16384, 8192, G.OP_FFT | G.OP_GRAVITY | G.OP_BARS, 80
+elif which == "configs2_live":     # ... with GLV_OP_BARS_ONLY (kernel class 8)
+    n, streams, ops, bars = 16384, 8192, G.OP_FFT | G.OP_GRAVITY | G.OP_BARS, 80
+    mask = G.OP_BARS | G.OP_BARS_ONLY
 elif which == "chain":
     n, streams, ops, bars = 4096, 65536, G.OP_FFT | G.OP_GRAVITY | G.OP_AVERAGE, 0
 elif which == "n1024bars":
@@ -24,6 +27,9 @@ elif which == "gl_default":
 elif which == "gl_bars":
     n, streams, ops, bars = 4096, 65536, G.OP_FFT | G.OP_GRAVITY | G.OP_AVERAGE | G.OP_BARS | G.OP_R16, 80
     kw, dt = dict(avg_window_kind=1, gl_storage=1), torch.int16
+elif which == "gl_bars_live":      # ... with GLV_OP_BARS_ONLY (kernel class 9)
+    n, streams, ops, bars = 4096, 65536, G.OP_FFT | G.OP_GRAVITY | G.OP_AVERAGE | G.OP_BARS | G.OP_R16, 80
+    kw, dt, mask = dict(avg_window_kind=1, gl_storage=1), torch.int16, G.OP_BARS | G.OP_BARS_ONLY
 elif which == "gl_sm":
     n, streams, ops, bars = 4096, 16384, G.OP_FFT | G.OP_GRAVITY | G.OP_AVERAGE | G.OP_BARS | G.OP_R16, 4096
     kw, dt, mask = dict(avg_window_kind=1, gl_storage=1, bar_phase=0.5), torch.int16, G.OP_BARS

@@ -330,6 +330,7 @@ struct glv_batch {
     uint32_t bar_bins_sampled = 0;
     uint32_t live_bins_now = 0;                     // refreshed with the bar tables and when the batch is prepared (update_live_bins)
     uint32_t live_bins() const { return live_bins_now; }
+    bool ran_live = false;                          // a live kernel class has run since creation / the last reset: the state beyond the live bins is stale
     void update_live_bins() {
         live_bins_now = 0u;
         if (!(ops_mask & GLV_OP_BARS_ONLY) || bar_bins_sampled == 0 || bar_bins_sampled >= p.n || p.gl_storage > 1u || p.log_mode == 2u) return;
@@ -869,7 +870,7 @@ int process(glv_batch* b, const void* d_in, int in_mode, float* d_out, unsigned 
         if ((ops & GLV_OP_BARS) && !fused_bars && d_out == b->d_scratch && b->bar_bins_needed != 0 && b->bar_bins_needed < b->p.n)
             a.out_limit = b->bar_bins_needed * 4u;
         // GLV_OP_BARS_ONLY: ... and what they do not sample is not computed, nor is its state kept (kernel class 7; check_ops vetted the call)
-        if (b->live_bins() != 0) a.live_points = b->live_bins() / 2u;
+        if (b->live_bins() != 0) { a.live_points = b->live_bins() / 2u; b->ran_live = true; }
         // ... and they go there as what they are, 16-bit texels (uint16 [rows][n] in the scratch rows), when the second launch is the
         // integer matrix-core pass (many bars: the pre-smoothing pass)
         const bool bars_i8 = (ops & GLV_OP_BARS) && !fused_bars && b->p.bars >= glv::kBarSeqMin && b->bars_i8();
@@ -936,7 +937,7 @@ int process(glv_batch* b, const void* d_in, int in_mode, float* d_out, unsigned 
     }
     if (gl_split) a.gl_storage = b->p.gl_storage;                    // operators on planar rows: the post kernel models it directly
     // GLV_OP_BARS_ONLY on a float chain with the bars fused (kernel class 8): magnitude, state and the row in LDS for the live blocks only
-    if (b->live_bins() != 0 && fused_bars && !gl_split && (ops & GLV_OP_FFT)) a.live_points = b->live_bins() / 2u;
+    if (b->live_bins() != 0 && fused_bars && !gl_split && (ops & GLV_OP_FFT)) { a.live_points = b->live_bins() / 2u; b->ran_live = true; }
 
     if (int rc = timed_launch_begin(b, st)) return rc;
     const unsigned core = ops & (GLV_OP_FFT | GLV_OP_GRAVITY | GLV_OP_AVERAGE | GLV_OP_WRANGE | GLV_OP_MAGNITUDE | GLV_OP_R16);
@@ -1065,8 +1066,13 @@ int glv_batch_set_params(glv_batch* b, const glv_params* p) {
     HIP_TRY(hipDeviceSynchronize());
     const glv_params old = b->p;
     b->p = *p;
-    const int rc = batch_prepare(b);
-    if (rc != GLV_OK) { b->p = old; (void) batch_prepare(b); }              // a rejected change leaves the batch as it was
+    int rc = batch_prepare(b);
+    // a GLV_OP_BARS_ONLY batch that has run its live class keeps no state beyond the live bins: parameters under which the bars sample further than the
+    // live classes keep (or that take the live class away: log_mode 2) would read state that was never maintained -- refused until the state is reset
+    if (rc == GLV_OK && b->ran_live && b->live_bins() == 0)
+        rc = fail(GLV_ERR_STATE, "this GLV_OP_BARS_ONLY batch has run its live kernel class: the state beyond the live bins was not kept, and these parameters "
+                                 "(smooth_factor=%g bars=%u log_mode=%u) need the full chain -- glv_batch_reset first, or a new batch", (double) p->smooth_factor, p->bars, p->log_mode);
+    if (rc != GLV_OK) { const std::string said = g_err; b->p = old; (void) batch_prepare(b); g_err = said; }   // a rejected change leaves the batch as it was
     for (auto& row : b->plan_cache) for (auto& pc : row) pc.gen = 0;        // log_mode is part of the wisdom key
     return rc;
 }
@@ -1081,7 +1087,7 @@ int glv_batch_reset(glv_batch* b) {
     if (b->d_grav) HIP_TRY(hipMemset(b->d_grav, 0, esz * rows * n));
     if (b->d_ring) HIP_TRY(hipMemset(b->d_ring, 0, sizeof(int16_t) * 2 * n * b->streams));
     if (b->d_ring_f32) HIP_TRY(hipMemset(b->d_ring_f32, 0, sizeof(float) * 2 * n * b->streams));
-    b->head = 0; b->ring_pos = 0; b->ring_pos_f32 = 0; b->grav_mode = 0; b->grav_cur = b->d_grav;
+    b->head = 0; b->ring_pos = 0; b->ring_pos_f32 = 0; b->grav_mode = 0; b->grav_cur = b->d_grav; b->ran_live = false;
     return GLV_OK;
 }
 

@@ -101,9 +101,10 @@ enum {
                                    15 n instead of 28 n bytes per frame at n = 4096, F = 5 on GL_R16 state.  Live kernel classes exist for the
                                    GL_R16 chains (gl_storage 1: bars in a second launch or fused) and for float chains whose bars the transform
                                    kernel computes itself (fewer than 256 bars, every kernel configuration of the size fusable); any other
-                                   batch, and bars that reach beyond the share (very wide smooth_factor), run the full chain: the bars are
-                                   bit-identical either way.  A stateful call without GLV_OP_BARS and glv_batch_gravity_state are refused
-                                   (GLV_ERR_STATE) */
+                                   batch (and log_mode 2) runs the full chain: the bars are bit-identical either way (no smooth_factor makes a
+                                   bar sample further: smooth_audio() clamps its positions to [0, 1]).  A stateful call without GLV_OP_BARS and glv_batch_gravity_state are refused
+                                   (GLV_ERR_STATE); so is a glv_batch_set_params that would take a batch which has run its live class to the
+                                   full chain (the state beyond the live bins was never kept) -- until glv_batch_reset */
     GLV_OP_OUTPUT_IS_STATE = 1u << 12 /* opt-in, with a chain that ENDS in gravity (GLV_OP_GRAVITY without AVERAGE / SMOOTH / RAW, f32
                                    rows out, no gl_storage): transform_gravity stores every value twice, to its `applied` array and to
                                    the buffer (render.c:733-734) -- with this flag ONE array is kept: the call writes the spectra

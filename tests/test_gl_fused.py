@@ -558,3 +558,38 @@ def test_bars_only_with_the_bars_fused_is_the_full_chain(glvlib, n, gl, avg, bar
             assert ei.value.code == G.ERR_STATE
         full.close(); live.close()
     if n >= 2048: assert took_live >= 1, "no kernel configuration took the live class"
+
+
+@pytest.mark.gpu
+def test_bars_only_batch_refuses_parameters_that_need_state_it_did_not_keep(glvlib):
+    """A GLV_OP_BARS_ONLY batch that has run its live class has no state beyond the live bins.  A glv_batch_set_params that takes the live class away (log_mode 2:
+    the GL passes one by one, no live class) would make the full chain read state nobody maintained: refused (GLV_ERR_STATE), the batch left as it was (the next
+    update still equals the unflagged batch's); after glv_batch_reset the change is accepted and the batch follows an unflagged one bit for bit.  smooth_factor can
+    change freely mid-stream: smooth_audio() clamps its sample positions to [0, 1], so no factor makes a bar sample beyond scale_audio(1) n = 0.288 n."""
+    import torch
+    G = glvlib
+    n, streams, F = 4096, 5, 3
+    kw = dict(n=n, avg_frames=F, avg_window_kind=1, gl_storage=1, bars=n, bar_phase=0.5)
+    mask = G.OP_GRAVITY | G.OP_AVERAGE | G.OP_BARS
+    ops = G.OP_FFT | mask | G.OP_R16
+    live, full = G.Batch(G.Params(smooth_factor=0.025, **kw), streams, mask | G.OP_BARS_ONLY), G.Batch(G.Params(smooth_factor=0.025, **kw), streams, mask)
+    ol = torch.zeros((streams * 2, n), dtype=torch.int16, device="cuda"); of = torch.zeros_like(ol)
+    def step(u):
+        d = torch.from_numpy((lcg_pcm_fast(4242 + u, streams * 2 * n) // (1, 16)[u % 2]).astype(np.int16)).cuda()
+        live.process_s16(d, ol, ops); full.process_s16(d, of, ops)
+        assert _eq(ol, of), u
+    for u in range(F + 1): step(u)
+    assert live.live_bins() != 0
+    for b in (live, full): b.set_params(G.Params(smooth_factor=0.3, **kw))           # any factor: the taps end at 0.288 n
+    assert live.live_bins() != 0 and live.live_bins() <= 0.30 * n
+    for u in range(F + 1, 2 * F + 2): step(u)
+    with pytest.raises(G.GlvError) as ei:
+        live.set_params(G.Params(smooth_factor=0.3, log_mode=2, **kw))               # the audit form: passes one by one, no live class
+    assert ei.value.code == G.ERR_STATE and "live" in str(ei.value)
+    assert live.live_bins() != 0
+    step(100)                                                                        # ... and the batch is what it was
+    live.reset(); full.reset()
+    for b in (live, full): b.set_params(G.Params(smooth_factor=0.3, log_mode=2, **kw))
+    assert live.live_bins() == 0
+    for u in range(200, 200 + F + 1): step(u)
+    live.close(); full.close()

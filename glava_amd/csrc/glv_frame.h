@@ -433,8 +433,11 @@ GLV_HD void apply_state_block(cf (&val)[NV], const uint32_t (&off)[NV], size_t r
 // (gl16_state_prefetch, same addresses) and are in `pre` -- the HBM latency of the state ran under the FFT passes instead of in front of the
 // average; the sum takes them in the same order, oldest first, so not a bit changes.  Only chains that average over F >= 2 frames prefetch.
 constexpr int kLivePre = 4;
-template <int NV, bool PAIRED>
-GLV_HD uint32_t gl16_state_prefetch(uint32_t (&pre)[kLivePre][NV], const uint32_t (&off)[NV], size_t row, uint32_t n, const FrameArgs& a) {
+// TAIL / `limit` (the live classes): the last TAIL entries are the lane's points of the last live block of the row, which the bars sample only in part --
+// a lane whose point lies at or beyond byte offset `limit` (of a float row) neither loads nor stores it (its arithmetic runs on whatever the register holds;
+// nothing reads the result): the block's dead tail is not moved -- 1216 of the 1536 bins kept at n = 4096.
+template <int NV, bool PAIRED, int TAIL = 0>
+GLV_HD uint32_t gl16_state_prefetch(uint32_t (&pre)[kLivePre][NV], const uint32_t (&off)[NV], size_t row, uint32_t n, const FrameArgs& a, uint32_t limit = 0xffffffffu) {
     const uint32_t F = a.F;
     if (!(a.ops & OP_AVERAGE) || F < 2u) return 0u;
     const uint32_t npre = F - 1u < (uint32_t) kLivePre ? F - 1u : (uint32_t) kLivePre;
@@ -449,17 +452,23 @@ GLV_HD uint32_t gl16_state_prefetch(uint32_t (&pre)[kLivePre][NV], const uint32_
         const uint16_t* base = h + (size_t) ring_slot(a.head, (uint32_t) k, F) * n;
         if constexpr (PAIRED) {
 #pragma unroll
-            for (int e = 0; e < NV; e += 2) { const u32x2 t = ld<u32x2>(base, lb + (off[e] - off[0]) / 2u); pre[k][e] = t.x; pre[k][e + 1] = t.y; }
+            for (int e = 0; e < NV; e += 2) {
+                if (e >= NV - TAIL && off[e] >= limit) { pre[k][e] = 0u; pre[k][e + 1] = 0u; continue; }
+                const u32x2 t = ld<u32x2>(base, lb + (off[e] - off[0]) / 2u); pre[k][e] = t.x; pre[k][e + 1] = t.y;
+            }
         } else {
 #pragma unroll
-            for (int e = 0; e < NV; ++e) pre[k][e] = ld<uint32_t>(base, lb + (off[e] - off[0]) / 2u);
+            for (int e = 0; e < NV; ++e) {
+                if (e >= NV - TAIL && off[e] >= limit) { pre[k][e] = 0u; continue; }
+                pre[k][e] = ld<uint32_t>(base, lb + (off[e] - off[0]) / 2u);
+            }
         }
     }
     return npre;
 }
-template <int NV, bool PAIRED, bool TWO, int KPRE = 0>
+template <int NV, bool PAIRED, bool TWO, int KPRE = 0, int TAIL = 0>
 GLV_HD void gl16_state_block(uint32_t (&tex)[NV], const uint32_t (&off)[NV], size_t row, uint32_t n, const FrameArgs& a,
-                             const uint32_t (*pre)[NV] = nullptr, uint32_t npre = 0) {
+                             const uint32_t (*pre)[NV] = nullptr, uint32_t npre = 0, uint32_t limit = 0xffffffffu) {
     // Every access is `uniform base + lane offset + compile-time constant` (off[e] - off[0] is a constant: the points of a lane are a fixed
     // pattern).  The lane offset is re-defined opaquely per call: inside the history loop the backend otherwise hoists its zero-extension out of
     // the loop and then forms a 64-bit address per access and trip with v_lshl_add_u64 (two registers each) instead of the
@@ -475,20 +484,32 @@ GLV_HD void gl16_state_block(uint32_t (&tex)[NV], const uint32_t (&off)[NV], siz
         const uint32_t lb = lane_base();
         if constexpr (PAIRED) {
 #pragma unroll
-            for (int e = 0; e < NV; e += 2) { const u32x2 t = ld<u32x2>(base, lb + (off[e] - off[0]) / 2u); dst[e] = t.x; dst[e + 1] = t.y; }
+            for (int e = 0; e < NV; e += 2) {
+                if (e >= NV - TAIL && off[e] >= limit) { dst[e] = 0u; dst[e + 1] = 0u; continue; }
+                const u32x2 t = ld<u32x2>(base, lb + (off[e] - off[0]) / 2u); dst[e] = t.x; dst[e + 1] = t.y;
+            }
         } else {
 #pragma unroll
-            for (int e = 0; e < NV; ++e) dst[e] = ld<uint32_t>(base, lb + (off[e] - off[0]) / 2u);
+            for (int e = 0; e < NV; ++e) {
+                if (e >= NV - TAIL && off[e] >= limit) { dst[e] = 0u; continue; }
+                dst[e] = ld<uint32_t>(base, lb + (off[e] - off[0]) / 2u);
+            }
         }
     };
     auto store = [&](uint16_t* base, const uint32_t (&src)[NV]) {
         const uint32_t lb = lane_base();
         if constexpr (PAIRED) {
 #pragma unroll
-            for (int e = 0; e < NV; e += 2) st<u32x2>(base, lb + (off[e] - off[0]) / 2u, u32x2{src[e], src[e + 1]});
+            for (int e = 0; e < NV; e += 2) {
+                if (e >= NV - TAIL && off[e] >= limit) continue;
+                st<u32x2>(base, lb + (off[e] - off[0]) / 2u, u32x2{src[e], src[e + 1]});
+            }
         } else {
 #pragma unroll
-            for (int e = 0; e < NV; ++e) st<uint32_t>(base, lb + (off[e] - off[0]) / 2u, src[e]);
+            for (int e = 0; e < NV; ++e) {
+                if (e >= NV - TAIL && off[e] >= limit) continue;
+                st<uint32_t>(base, lb + (off[e] - off[0]) / 2u, src[e]);
+            }
         }
     };
     const uint32_t F = a.F;
@@ -1147,6 +1168,10 @@ struct Frame {
     // the live class's state prefetch (gl16_state_prefetch): where its 4 x LIVE_SLOTS registers fit -- E <= 16
     static constexpr bool LIVE_PREFETCH = LOG_E <= 4;
     struct LivePre { uint32_t t[kLivePre][LIVE_SLOTS]; uint32_t n; };
+    // byte offset (of a float row) behind the last point the bars sample, when it lies inside the LAST live block (else: no limit) -- uniform
+    GLV_HD static uint32_t live_limit(const FrameArgs& a) {
+        return a.live_points > (uint32_t) ((LIVE_RBLOCKS - 1) * PassInfo<P - 1>::L0) && a.live_points < (uint32_t) LIVE_POINTS ? a.live_points * 8u : 0xffffffffu;
+    }
     GLV_HD static void live_offsets(uint32_t (&off)[LIVE_SLOTS], int tid) {      // byte offsets (of a float row) of the lane's live points, block by block of the row
         using PI = PassInfo<P - 1>;
 #pragma unroll
@@ -1155,7 +1180,7 @@ struct Frame {
     GLV_HD static void live_prefetch(LivePre& lp, size_t row, int tid, const FrameArgs& a) {
         uint32_t off[LIVE_SLOTS];
         live_offsets(off, tid);
-        lp.n = gl16_state_prefetch<LIVE_SLOTS, (PassInfo<P - 1>::NG >= 2)>(lp.t, off, row, (uint32_t) N, a);
+        lp.n = gl16_state_prefetch<LIVE_SLOTS, (PassInfo<P - 1>::NG >= 2), PassInfo<P - 1>::NG>(lp.t, off, row, (uint32_t) N, a, live_limit(a));
     }
     template <int LOG_MODE, int TILTREG, bool NONFINITE, bool TO_LDS, bool LIVE = false>
     GLV_HD static void epilogue_gl16(const cf (&v)[E], float* out_row, size_t row, int tid, const FrameArgs& a,
@@ -1201,9 +1226,10 @@ struct Frame {
                 off[j] = (uint32_t) out_index<P - 1>(tid, gi, r) * 8u;
             }
             if constexpr (LIVE && LIVE_PREFETCH) {
-                if (lp != nullptr) gl16_state_block<BLK, PAIRED, (LOG_NN <= GLV_STATE_PAIR_MAX), kLivePre>(tex, off, row, (uint32_t) N, a, lp->t, lp->n);
-                else gl16_state_block<BLK, PAIRED, (LOG_NN <= GLV_STATE_PAIR_MAX)>(tex, off, row, (uint32_t) N, a);
-            } else gl16_state_block<BLK, PAIRED, (LOG_NN <= GLV_STATE_PAIR_MAX)>(tex, off, row, (uint32_t) N, a);
+                if (lp != nullptr) gl16_state_block<BLK, PAIRED, (LOG_NN <= GLV_STATE_PAIR_MAX), kLivePre, PI::NG>(tex, off, row, (uint32_t) N, a, lp->t, lp->n, live_limit(a));
+                else gl16_state_block<BLK, PAIRED, (LOG_NN <= GLV_STATE_PAIR_MAX), 0, PI::NG>(tex, off, row, (uint32_t) N, a, nullptr, 0u, live_limit(a));
+            } else if constexpr (LIVE) gl16_state_block<BLK, PAIRED, (LOG_NN <= GLV_STATE_PAIR_MAX), 0, PI::NG>(tex, off, row, (uint32_t) N, a, nullptr, 0u, live_limit(a));
+            else gl16_state_block<BLK, PAIRED, (LOG_NN <= GLV_STATE_PAIR_MAX)>(tex, off, row, (uint32_t) N, a);
             if (TO_LDS || !r16_out) {
 #pragma unroll
                 for (int j = 0; j < BLK; j += (PAIRED ? 2 : 1)) {

@@ -59,8 +59,21 @@ int validate(const glv_params* p) {
     if (p->log_mode > 2) return fail(GLV_ERR_INVALID, "log_mode=%u: must be 0, 1 or 2", p->log_mode);
     if (p->gl_storage > 2) return fail(GLV_ERR_INVALID, "gl_storage=%u: must be 0, 1 (GL_R16 state, one launch) or 2 (pass by pass, f32 state)", p->gl_storage);
     if (p->ur != p->ur) return fail(GLV_ERR_INVALID, "ur is NaN");   // 0 is legal: render.c:2387 yields it after an interval without updates
+    if (p->round_formula > GLV_ROUND_LINEAR) return fail(GLV_ERR_INVALID, "round_formula=%u: 0 sinusoidal, 1 circular, 2 linear", p->round_formula);
+    if (p->sample_mode > GLV_SAMPLE_HYBRID) return fail(GLV_ERR_INVALID, "sample_mode=%u: 0 average, 1 maximum, 2 hybrid", p->sample_mode);
     return GLV_OK;
 }
+
+// smooth_audio()'s shape as the tables take it: 0 in a glv_params field is the shipped value (smooth_parameters.glsl:17-42)
+float shape_scale(const glv_params& p) { return p.sample_scale != 0.0f ? p.sample_scale : 8.0f; }
+float shape_range(const glv_params& p) { return p.sample_range != 0.0f ? p.sample_range : 0.9f; }
+float shape_hybrid(const glv_params& p) { return p.sample_hybrid_weight != 0.0f ? p.sample_hybrid_weight : 0.65f; }
+bool same_bits(float a, float b) { return std::memcmp(&a, &b, sizeof(a)) == 0; }
+bool same_shape(const glv_params& a, const glv_params& b) {
+    return a.round_formula == b.round_formula && a.sample_mode == b.sample_mode && same_bits(a.sample_hybrid_weight, b.sample_hybrid_weight)
+           && same_bits(a.sample_scale, b.sample_scale) && same_bits(a.sample_range, b.sample_range);
+}
+glv::BarShape bar_shape(const glv_params& p) { return glv::BarShape{p.round_formula, shape_scale(p), shape_range(p), p.sample_mode == GLV_SAMPLE_AVERAGE}; }
 
 int ensure_device(int device) {
     int count = 0;
@@ -317,6 +330,8 @@ struct glv_batch {
     uint32_t bar_fnsteps[kMaxVariants] = {}; bool bar_fusable[kMaxVariants] = {};
     uint32_t bar_nsteps = 0;
     uint32_t bar_count = 0; float bar_factor = -1.f, bar_phase = 0.f;
+    glv_params bar_shape_of{};               // the shape fields (round_formula ... sample_range) the tables were made for
+    glv::BarModeBlock* d_bar_mblocks = nullptr; float* d_bar_mw = nullptr; uint32_t bar_nmblocks = 0;   // sample_mode maximum / hybrid (glv_tables.h make_bar_mode_blocks)
     glv::BarMTile* d_bar_mtiles = nullptr;  // >= 256 bars (glv_tables.h make_bar_mtiles): tiles of 32 bars, their weights in MFMA operand layout, the bars'
     float* d_bar_wt = nullptr;              // {weight sum, reciprocal}, and -- when they could be cut -- the rounds of glv_bars_rows_kernel for its LDS ring
     float* d_bar_wsum = nullptr;
@@ -341,7 +356,12 @@ struct glv_batch {
         if (p.gl_storage == 0u && (!bar_fusable[0] || unfused_bars)) return;
         live_bins_now = bar_bins_sampled;
     }
-    glv::BarRowsTables rows_tables() const { return glv::BarRowsTables{d_bar_mtiles, bar_ntiles, d_bar_wt, d_bar_wsum, d_bar_rounds, bar_nrounds, bar_ring_bins}; }
+    glv::BarRowsTables rows_tables() const {
+        glv::BarRowsTables t{d_bar_mtiles, bar_ntiles, d_bar_wt, d_bar_wsum, d_bar_rounds, bar_nrounds, bar_ring_bins};
+        t.mode = p.sample_mode; t.hybrid_weight = p.sample_hybrid_weight != 0.0f ? p.sample_hybrid_weight : 0.65f;
+        t.mblocks = d_bar_mblocks; t.nmblocks = bar_nmblocks; t.mw = d_bar_mw; t.mode_bins = bar_bins_sampled < p.n ? bar_bins_sampled : p.n;
+        return t;
+    }
     // the same pass over TEXEL rows (the GL chains, gl_storage != 0): exact integer arithmetic on the i8 matrix cores (glv_tables.h make_bar_itiles)
     glv::BarMTile* d_bar_itiles = nullptr; int8_t* d_bar_wq = nullptr; glv::BarIFin* d_bar_fin = nullptr; glv::BarTile* d_bar_irounds = nullptr;
     uint32_t bar_intiles = 0, bar_inrounds = 0, bar_iring_bins = 0;
@@ -566,19 +586,28 @@ int ensure_smooth_tables(glv_batch* b) {
 // GLV_OP_BARS tables: taps, weights, the work lists of glv_bars_kernel and one fused work list per kernel configuration of the
 // size (their lanes per row differ).  Host generation + synchronous upload: creation / glv_batch_set_params only.
 int ensure_bar_tables(glv_batch* b) {
-    const bool want_i8 = b->p.gl_storage != 0 && b->p.bars >= glv::kBarSeqMin && !b->bar_i8_off;      // chains whose rows are texels
-    if (b->d_bar_desc && b->bar_count == b->p.bars && b->bar_factor == b->p.smooth_factor && b->bar_phase == b->p.bar_phase && (want_i8 == (b->d_bar_itiles != nullptr) || b->bar_i8_none)) return GLV_OK;
+    const bool averaging = b->p.sample_mode == GLV_SAMPLE_AVERAGE;                                       // maximum / hybrid: glv_bars_mode_kernel, no matrix-core / fused form
+    const bool want_i8 = b->p.gl_storage != 0 && b->p.bars >= glv::kBarSeqMin && !b->bar_i8_off && averaging;      // chains whose rows are texels
+    if (b->d_bar_desc && b->bar_count == b->p.bars && b->bar_factor == b->p.smooth_factor && b->bar_phase == b->p.bar_phase && same_shape(b->bar_shape_of, b->p)
+        && (want_i8 == (b->d_bar_itiles != nullptr) || b->bar_i8_none)) return GLV_OK;
     if (b->p.bars == 0 || b->p.bars > b->p.n) return fail(GLV_ERR_INVALID, "bars=%u out of range", b->p.bars);
+    {   // the shape: scale_audio(1) = -log(1 - SAMPLE_RANGE) / SAMPLE_SCALE is the last position smooth_audio() samples (a share of the row)
+        const float sc = shape_scale(b->p), rg = shape_range(b->p), hw = shape_hybrid(b->p);
+        if (!(sc > 0.0f && sc <= 1e6f) || !(rg > 0.0f && rg < 1.0f) || !(-logf(1.0f - rg) / sc <= 1.0f))
+            return fail(GLV_ERR_INVALID, "sample_scale=%g sample_range=%g: need scale > 0, 0 < range < 1 and -log(1 - range) / scale <= 1 (smooth_audio() would fetch texels beyond the texture)", (double) sc, (double) rg);
+        if (!(hw > 0.0f && hw <= 1.0f)) return fail(GLV_ERR_INVALID, "sample_hybrid_weight=%g: must be in (0, 1]", (double) hw);
+    }
     if (!(b->p.smooth_factor >= 0.0f && b->p.smooth_factor <= 1.0f))       // also rejects NaN
         return fail(GLV_ERR_INVALID, "smooth_factor=%g: must be in [0, 1] (a bar would have no taps)", (double) b->p.smooth_factor);
     if (!(b->p.bar_phase >= 0.0f && b->p.bar_phase < 1.0f)) return fail(GLV_ERR_INVALID, "bar_phase=%g: must be in [0, 1)", (double) b->p.bar_phase);
     std::vector<glv::BarDesc> desc;
     std::vector<float> w;
-    glv::make_bar_taps(desc, w, b->p.n, b->p.bars, b->p.smooth_factor, b->p.bar_phase);
+    glv::make_bar_taps(desc, w, b->p.n, b->p.bars, b->p.smooth_factor, b->p.bar_phase, bar_shape(b->p));
     if (!glv::bar_chunks_in_row(desc, b->p.n)) return fail(GLV_ERR_INVALID, "bars: a tap chunk would leave the row (n=%u smooth_factor=%g)", b->p.n, (double) b->p.smooth_factor);
     auto drop = [](auto*& ptr) { if (ptr) { (void) hipFree(ptr); ptr = nullptr; } };
     drop(b->d_bar_desc); drop(b->d_bar_w); drop(b->d_bar_items); drop(b->d_bar_mtiles); drop(b->d_bar_wt); drop(b->d_bar_wsum); drop(b->d_bar_rounds);
-    drop(b->d_bar_itiles); drop(b->d_bar_wq); drop(b->d_bar_fin); drop(b->d_bar_irounds);
+    drop(b->d_bar_itiles); drop(b->d_bar_wq); drop(b->d_bar_fin); drop(b->d_bar_irounds); drop(b->d_bar_mblocks); drop(b->d_bar_mw);
+    b->bar_nmblocks = 0;
     b->bar_intiles = 0; b->bar_inrounds = 0; b->bar_iring_bins = 0; b->bar_i8_none = false;
     for (int v = 0; v < glv_batch::kMaxVariants; ++v) { drop(b->d_bar_fitems[v]); b->bar_fusable[v] = false; b->bar_fnsteps[v] = 0; }
     b->bar_count = 0;
@@ -596,7 +625,7 @@ int ensure_bar_tables(glv_batch* b) {
         const glv::FrameGeometry geo = glv::frame_geometry(b->log_nn, v);
         // bar totals + the dump slot fit the 2 * lanes floats of slack behind the row in LDS
         // (from 256 bars up a bar is one fma chain, glv_tables.h make_bar_mtiles: the chunked loop of the epilogue does not apply)
-        b->bar_fusable[v] = geo.lanes % 64 == 0 && geo.nbuf == 1 && b->p.bars + 1 <= 2 * (uint32_t) geo.lanes && b->p.bars < glv::kBarSeqMin;
+        b->bar_fusable[v] = geo.lanes % 64 == 0 && geo.nbuf == 1 && b->p.bars + 1 <= 2 * (uint32_t) geo.lanes && b->p.bars < glv::kBarSeqMin && averaging;
         if (!b->bar_fusable[v]) continue;
         std::vector<glv::BarItem> fitems;
         b->bar_fnsteps[v] = glv::make_bar_items(fitems, desc, (uint32_t) geo.lanes / gl, zero_off, chunk, (uint32_t) geo.bar_batch);
@@ -607,13 +636,27 @@ int ensure_bar_tables(glv_batch* b) {
     HIP_TRY(hipMalloc(&b->d_bar_w, sizeof(float) * w.size()));
     HIP_TRY(hipMemcpy(b->d_bar_desc, desc.data(), sizeof(glv::BarDesc) * desc.size(), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(b->d_bar_w, w.data(), sizeof(float) * w.size(), hipMemcpyHostToDevice));
-    b->bar_count = b->p.bars; b->bar_factor = b->p.smooth_factor; b->bar_phase = b->p.bar_phase;
+    b->bar_count = b->p.bars; b->bar_factor = b->p.smooth_factor; b->bar_phase = b->p.bar_phase; b->bar_shape_of = b->p;
     b->bar_bins_sampled = 0;
     for (const glv::BarDesc& d : desc) b->bar_bins_sampled = d.first_bin + d.count > b->bar_bins_sampled ? d.first_bin + d.count : b->bar_bins_sampled;
     b->bar_bins_sampled = (b->bar_bins_sampled + 63u) & ~63u;                      // whole store instructions (the ring fill's 16-byte loads)
     // many bars (the pre-smoothing pass): tiles of 32 bars for the chain kernels; rounds for the smallest LDS ring that takes them
     b->bar_ntiles = 0; b->bar_nrounds = 0; b->bar_ring_bins = 0; b->bar_bins_needed = 0;
     b->update_live_bins();
+    if (!averaging) {                          // sample_mode maximum / hybrid: one lane per bar and row off block-transposed weights, any number of bars
+        std::vector<glv::BarModeBlock> blocks;
+        std::vector<float> mw;
+        glv::make_bar_mode_blocks(blocks, mw, desc, w);
+        if (mw.empty()) mw.push_back(0.0f);
+        HIP_TRY(hipMalloc(&b->d_bar_mblocks, sizeof(glv::BarModeBlock) * blocks.size()));
+        HIP_TRY(hipMemcpy(b->d_bar_mblocks, blocks.data(), sizeof(glv::BarModeBlock) * blocks.size(), hipMemcpyHostToDevice));
+        HIP_TRY(hipMalloc(&b->d_bar_mw, sizeof(float) * mw.size()));
+        HIP_TRY(hipMemcpy(b->d_bar_mw, mw.data(), sizeof(float) * mw.size(), hipMemcpyHostToDevice));
+        b->bar_nmblocks = (uint32_t) blocks.size();
+        if (b->bar_bins_sampled == 0) b->bar_bins_sampled = 64u;                   // (no bar has a tap: every bar is 0, or 0 / 0 in the hybrid)
+        b->bar_bins_needed = b->bar_bins_sampled;                                  // what a transform in front of the bars has to store of a row
+        return GLV_OK;
+    }
     if (b->p.bars >= glv::kBarSeqMin) {
         std::vector<glv::BarMTile> mtiles;
         std::vector<glv::BarTile> rounds;
@@ -680,13 +723,12 @@ void update_gravity_step(glv_batch* b) {
     }
 }
 
-bool same_bits(float a, float b) { return std::memcmp(&a, &b, sizeof(a)) == 0; }
 bool same_params(const glv_params& a, const glv_params& b) {
     return a.n == b.n && a.channels == b.channels && same_bits(a.fft_scale, b.fft_scale) && same_bits(a.fft_cutoff, b.fft_cutoff)
            && same_bits(a.gravity_step, b.gravity_step) && same_bits(a.ur, b.ur) && a.avg_frames == b.avg_frames && a.avg_window == b.avg_window
            && a.avg_window_kind == b.avg_window_kind && a.log_mode == b.log_mode && a.bars == b.bars && same_bits(a.smooth_factor, b.smooth_factor)
            && same_bits(a.smooth_distance, b.smooth_distance) && same_bits(a.smooth_ratio, b.smooth_ratio) && a.gl_storage == b.gl_storage
-           && same_bits(a.bar_phase, b.bar_phase);
+           && same_bits(a.bar_phase, b.bar_phase) && same_shape(a, b);
 }
 
 // Everything the process calls need besides the state arrays, made from b->p: tilt table, the gravity step on texels, and -- as
@@ -777,7 +819,7 @@ int check_ops(const glv_batch* b, unsigned ops, const float* d_out) {
         return fail(GLV_ERR_INVALID, "GLV_OP_OUTPUT_IS_STATE needs a chain that ends in gravity with f32 rows out (no AVERAGE / SMOOTH / RAW / BARS / R16, gl_storage 0)");
     if ((ops & GLV_OP_BARS) && !b->d_bar_desc)
         return fail(GLV_ERR_STATE, "GLV_OP_BARS: the batch has no bar tables (bars / smooth_factor / bar_phase were unusable when it was created; tables are built at creation and by glv_batch_set_params, process calls never allocate)");
-    if ((ops & GLV_OP_BARS) && (b->bar_count != b->p.bars || b->bar_factor != b->p.smooth_factor || b->bar_phase != b->p.bar_phase))
+    if ((ops & GLV_OP_BARS) && (b->bar_count != b->p.bars || b->bar_factor != b->p.smooth_factor || b->bar_phase != b->p.bar_phase || !same_shape(b->bar_shape_of, b->p)))
         return fail(GLV_ERR_STATE, "GLV_OP_BARS: bar parameters changed without glv_batch_set_params");
     if ((ops & GLV_OP_SMOOTH) && (!b->d_smin || b->smooth_d != b->p.smooth_distance || b->smooth_r != b->p.smooth_ratio))
         return fail(GLV_ERR_STATE, "GLV_OP_SMOOTH: the batch has no window bounds for these parameters (unusable smooth_ratio at creation, or changed without glv_batch_set_params)");
@@ -1323,6 +1365,7 @@ const char* glv_batch_kernel_name(const glv_batch* b) { return b ? b->kernel_nam
 
 int glv_batch_bars_arithmetic(const glv_batch* b) {
     if (!b || b->bar_count == 0 || !b->d_bar_desc) return GLV_BARS_NONE;
+    if (b->p.sample_mode != GLV_SAMPLE_AVERAGE) return GLV_BARS_F32_SEQ;
     if (b->p.bars < glv::kBarSeqMin) return GLV_BARS_F32_CHAIN;
     return b->p.gl_storage != 0 && b->bars_i8() ? GLV_BARS_I8_EXACT : GLV_BARS_F32_MATRIX;
 }

@@ -44,9 +44,12 @@ hipError_t launch_window_split(const double* w_tab, float* split, uint32_t n, in
 hipError_t launch_window_split_check(const double* w_tab, const float* split, uint32_t n, unsigned long long* d_mismatches, hipStream_t st);
 // rt: the tables of the many-bars kernels (>= 256 bars; glv_tables.h make_bar_mtiles): tiles of 32 bars with their weights, the bars'
 // weight sums, and -- when they could be cut -- the rounds of the matrix-core kernel for an LDS ring of ring_bins (160, 288, 448 or 832) bins
+// mode != 0 (glv_params.sample_mode maximum / hybrid): the block-transposed weights of glv_bars_mode_kernel (glv_tables.h make_bar_mode_blocks) and the
+// bins of a row its bars sample; the other tables are then unused
 struct BarRowsTables {
     const BarMTile* mtiles; uint32_t ntiles; const float* wt; const float* wsum;
     const BarTile* rounds; uint32_t nrounds, ring_bins;
+    uint32_t mode = 0; float hybrid_weight = 0.65f; const BarModeBlock* mblocks = nullptr; uint32_t nmblocks = 0; const float* mw = nullptr; uint32_t mode_bins = 0;
 };
 hipError_t launch_bars(const float* spec, float* bars_out, size_t nrows, uint32_t n, uint32_t bars, uint32_t nsteps,
                        const BarItem* items, const BarDesc* desc, const float* tap_w, hipStream_t st, bool r16 = false, const BarRowsTables* rt = nullptr);

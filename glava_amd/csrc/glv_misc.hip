@@ -271,7 +271,7 @@ __global__ void __launch_bounds__(64) glv_smooth_ring_kernel(float* __restrict__
 // ---- smooth_audio() bar sampling (shaders/glava/util/smooth.glsl:13-40, radial/1.frag:58-70) --------
 // The tap positions and weights of a bar depend only on (bar, n, smooth_factor) -- not on the data -- so
 // they are generated once per batch on the host (glv_tables.h make_bar_taps: SAMPLE_MODE average,
-// ROUND_FORMULA sinusoidal, SAMPLE_SCALE 8, SAMPLE_RANGE 0.9) together with the work lists
+// ROUND_FORMULA / SAMPLE_SCALE / SAMPLE_RANGE from glv_params: sinusoidal, 8, 0.9 as shipped) together with the work lists
 // (make_bar_items).  One 256-thread workgroup = 256 / GL groups of GL = bar_lanes_of(n) lanes per row; arithmetic: glv_frame.h.
 // r16: bars_out is uint16 [nrows][bars], the GL_R16 texel of every value (what the reference's smooth pass renders into,
 // render.c:2277-2303 with bind_1d_fbo's GL_R16 texture) instead of float
@@ -596,6 +596,81 @@ __global__ void __launch_bounds__(256) glv_bars_seq_kernel(const float* __restri
             else reinterpret_cast<float*>(bars_out)[row * bars + kb] = v;
         }
     }
+}
+
+// SAMPLE_MODE maximum / hybrid (shaders/glava/util/smooth.glsl:41-59; glv_params.sample_mode has the contract, the tests' CPU checker restates it
+// as glvo_bars_mode_at): a maximum is not a matrix product and the hybrid's average is the shader's own chain of float additions, so a bar is ONE lane
+// walking its taps in bin order -- v = x * w (rounded), vmax = max(vmax, v), avg = avg + v -- for RR rows at a time (RR independent chains per lane).
+// A workgroup parks the bins the bars sample of its RR rows in LDS, clamped to [0, 1] (NaN -> 0) like the texels the shader fetches (LDS = false: rows
+// too long for that are read through L1); wave w then takes the 64-bar blocks w, w + 4, ...: lane l of a block is bar 64 blk + l, its weights come
+// block-transposed (glv_tables.h make_bar_mode_blocks: [tap][lane], one coalesced 256-byte load per tap) and padded with +0 up to the block's longest
+// bar -- x * +0 = +0 changes neither the maximum (vmax >= +0) nor the sum.  MODE 1: bar = vmax;  MODE 2: bar = vmax * (1 - H) + (avg / weight) * H,
+// every operation rounded on its own (no fused multiply-add: the shader's expression as written).
+template <int MODE, int RR, bool LDS>
+__global__ void __launch_bounds__(256) glv_bars_mode_kernel(const float* __restrict__ spec, void* __restrict__ bars_out, size_t nrows, uint32_t n, uint32_t bars,
+                                                           const BarDesc* __restrict__ desc, const BarModeBlock* __restrict__ blocks, uint32_t nblocks,
+                                                           const float* __restrict__ mw, uint32_t bins, float hyb, float one_minus_hyb, int r16) {
+    extern __shared__ float glv_mode_rows[];                                      // [RR][bins]
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    auto clamp01 = [](float x) { return x > 0.0f ? (x < 1.0f ? x : 1.0f) : 0.0f; };   // NaN -> 0
+    for (size_t row0 = (size_t) blockIdx.x * RR; row0 < nrows; row0 += (size_t) gridDim.x * RR) {
+        if constexpr (LDS) {
+            __syncthreads();                                                      // the previous rows have been read
+            for (uint32_t i = threadIdx.x; i < (uint32_t) RR * bins; i += 256u) {
+                const uint32_t r = i / bins, bin = i - r * bins;
+                const size_t row = row0 + r < nrows ? row0 + r : nrows - 1;
+                glv_mode_rows[i] = clamp01(spec[row * (size_t) n + (bin < n ? bin : n - 1u)]);
+            }
+            __syncthreads();
+        }
+        for (uint32_t blk = wave; blk < nblocks; blk += 4u) {
+            const BarModeBlock B = blocks[blk];
+            const uint32_t k = blk * 64u + lane;
+            const BarDesc d = desc[k < bars ? k : bars - 1u];
+            const float* wp = mw + B.w_off + lane;
+            float vmax[RR], avg[RR];
+#pragma unroll
+            for (int r = 0; r < RR; ++r) { vmax[r] = 0.0f; avg[r] = 0.0f; }
+            for (uint32_t j = 0; j < B.maxcount; ++j) {
+                const float w = wp[(size_t) j * 64u];
+                uint32_t bin = d.first_bin + j;
+                bin = bin < bins ? bin : bins - 1u;                               // (past the bar's own taps: weight +0)
+#pragma unroll
+                for (int r = 0; r < RR; ++r) {
+                    float x;
+                    if constexpr (LDS) x = glv_mode_rows[(uint32_t) r * bins + bin];
+                    else x = clamp01(spec[(row0 + r < nrows ? row0 + r : nrows - 1) * (size_t) n + bin]);
+                    const float v = __fmul_rn(x, w);
+                    vmax[r] = vmax[r] < v ? v : vmax[r];                          // smooth.glsl:48-49 / :56-57
+                    if constexpr (MODE == 2) avg[r] = __fadd_rn(avg[r], v);
+                }
+            }
+            if (k < bars) {
+#pragma unroll
+                for (int r = 0; r < RR; ++r) {
+                    if (row0 + r >= nrows) break;
+                    float v = vmax[r];
+                    if constexpr (MODE == 2) v = __fadd_rn(__fmul_rn(vmax[r], one_minus_hyb), __fmul_rn(avg[r] / d.weight_sum, hyb));   // smooth.glsl:51
+                    if (r16) reinterpret_cast<uint16_t*>(bars_out)[(row0 + r) * bars + k] = (uint16_t) unorm16(v);
+                    else reinterpret_cast<float*>(bars_out)[(row0 + r) * bars + k] = v;
+                }
+            }
+        }
+    }
+}
+template <int MODE>
+static hipError_t launch_bars_mode(const float* spec, void* bars_out, size_t nrows, uint32_t n, uint32_t bars, const BarDesc* desc, const BarRowsTables& rt, hipStream_t st, int r16) {
+    if (rt.mblocks == nullptr || rt.mw == nullptr || rt.nmblocks == 0 || rt.mode_bins == 0 || rt.mode_bins > n) return hipErrorInvalidValue;
+    const uint32_t bins = rt.mode_bins;
+    const float h = rt.hybrid_weight, omh = 1.0f - rt.hybrid_weight;
+    auto grid_of = [&](int rr) { const size_t g = (nrows + (size_t) rr - 1) / (size_t) rr; return dim3((unsigned) (g < 256u * 8u ? (g ? g : 1) : 256u * 8u)); };
+    if ((size_t) bins * 16u <= 48u * 1024u)
+        hipLaunchKernelGGL((glv_bars_mode_kernel<MODE, 4, true>), grid_of(4), dim3(256), (size_t) bins * 16u, st, spec, bars_out, nrows, n, bars, desc, rt.mblocks, rt.nmblocks, rt.mw, bins, h, omh, r16);
+    else if ((size_t) bins * 4u <= 64u * 1024u)
+        hipLaunchKernelGGL((glv_bars_mode_kernel<MODE, 1, true>), grid_of(1), dim3(256), (size_t) bins * 4u, st, spec, bars_out, nrows, n, bars, desc, rt.mblocks, rt.nmblocks, rt.mw, bins, h, omh, r16);
+    else
+        hipLaunchKernelGGL((glv_bars_mode_kernel<MODE, 4, false>), grid_of(4), dim3(256), 0, st, spec, bars_out, nrows, n, bars, desc, rt.mblocks, rt.nmblocks, rt.mw, bins, h, omh, r16);
+    return hipGetLastError();
 }
 
 // MANY bars over TEXEL rows (the library's GL chains, gl_storage != 0: the pre-smoothing pass of render.c:2277-2303 samples a GL_R16
@@ -1071,6 +1146,9 @@ hipError_t prepare_bars_i8(uint32_t n, const BarIRowsTables* rt) {
 hipError_t launch_bars(const float* spec, float* bars_out, size_t nrows, uint32_t n, uint32_t bars, uint32_t nsteps,
                        const BarItem* items, const BarDesc* desc, const float* tap_w, hipStream_t st, bool r16, const BarRowsTables* rt) {
     const int r = r16 ? 1 : 0;
+    // SAMPLE_MODE maximum / hybrid: one lane per bar and row, any number of bars
+    if (rt != nullptr && rt->mode == 1u) return launch_bars_mode<1>(spec, bars_out, nrows, n, bars, desc, *rt, st, r);
+    if (rt != nullptr && rt->mode == 2u) return launch_bars_mode<2>(spec, bars_out, nrows, n, bars, desc, *rt, st, r);
     // many bars: one fma chain per bar (glv_tables.h make_bar_mtiles) -- on the matrix cores when the host could cut the tiles into
     // rounds for the LDS ring, one lane per bar otherwise
     if (bars >= 256) {

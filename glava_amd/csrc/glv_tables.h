@@ -105,14 +105,22 @@ inline size_t make_smooth_bounds(int* smin, int* smax, size_t sz, float smooth_d
     return asz;
 }
 
-// smooth_audio() taps of every bar (shaders/glava/util/smooth.glsl:13-40 in float, as the GLSL would):
+// smooth_audio() taps of every bar (shaders/glava/util/smooth.glsl:13-59 in float, as the GLSL would):
 //   idx = (k + phase) / bars (phase 0: the modules' bar positions; 0.5: the texel centres of smooth_pass.frag);
-//   smin/smax = scale_audio(clamp(idx -/+ factor)) * n,  scale_audio(u) = -log(1 - 0.9u)/8
-//   m = (smax - smin)/2, rm = smin + m;  for s = smin; s <= smax; s += 1:  w = sinusoidal(clamp((m - |rm - s|)/m))
+//   smin/smax = scale_audio(clamp(idx -/+ factor)) * n,  scale_audio(u) = -log(1 - SAMPLE_RANGE u) / SAMPLE_SCALE   (smooth.glsl:13-15)
+//   m = (smax - smin)/2, rm = smin + m;  for s = smin; s <= smax; s += 1:  w = ROUND_FORMULA(clamp((m - |rm - s|)/m))
 //   sample bin int(round(s)).  Consecutive s round to consecutive bins, so a bar is a contiguous bin range.
-inline void make_bar_taps(std::vector<BarDesc>& desc, std::vector<float>& tap_w, uint32_t n, uint32_t bars, float smooth_factor, float phase = 0.0f) {
+// BarShape: the GLSL `#define`s of smooth_parameters.glsl:17-42 (glv_params round_formula / sample_scale / sample_range); `inclusive`:
+// SAMPLE_MODE average walks s <= smax (smooth.glsl:34), maximum and hybrid s < smax (:43, :54).
+struct BarShape { uint32_t round_formula = 0; float scale = 8.0f, range = 0.9f; bool inclusive = true; };
+inline float bar_round_formula(uint32_t formula, float x) {                       // common.glsl:17-22
+    if (formula == 1u) return sqrtf(1.0f - ((x - 1.0f) * (x - 1.0f)));            // circular
+    if (formula == 2u) return x;                                                  // linear
+    return (0.5f * sinf((3.14159265359f * x) - (3.14159265359f / 2.0f))) + 0.5f;  // sinusoidal
+}
+inline void make_bar_taps(std::vector<BarDesc>& desc, std::vector<float>& tap_w, uint32_t n, uint32_t bars, float smooth_factor, float phase = 0.0f, const BarShape& shape = BarShape{}) {
     const uint32_t chunk = bar_chunk_of(n);
-    auto scale = [](float u) { return -logf((-0.9f * u) + 1.0f) / 8.0f; };
+    auto scale = [&](float u) { return -logf((-shape.range * u) + 1.0f) / shape.scale; };
     auto clamp01 = [](float x) { return x < 0.0f ? 0.0f : (x > 1.0f ? 1.0f : x); };
     desc.resize(bars);
     tap_w.clear();
@@ -126,8 +134,8 @@ inline void make_bar_taps(std::vector<BarDesc>& desc, std::vector<float>& tap_w,
         float weight = 0.0f;
         bool first = true;
         uint32_t prev_bin = 0;
-        for (float sx = smin; sx <= smax; sx += 1.0f) {
-            const float w = (0.5f * sinf((3.14159265359f * clamp01((m - fabsf(rm - sx)) / m)) - (3.14159265359f / 2.0f))) + 0.5f;
+        for (float sx = smin; shape.inclusive ? sx <= smax : sx < smax; sx += 1.0f) {
+            const float w = bar_round_formula(shape.round_formula, clamp01((m - fabsf(rm - sx)) / m));
             const uint32_t bin = (uint32_t) (int) roundf(sx);
             if (first) { d.first_bin = bin; first = false; }
             else if (bin != prev_bin + 1) {          // (never for step 1.0; keep the range contiguous regardless)
@@ -142,6 +150,21 @@ inline void make_bar_taps(std::vector<BarDesc>& desc, std::vector<float>& tap_w,
         // zero-pad to whole chunks: the kernels load a chunk's weights unconditionally
         while ((tap_w.size() - d.tap_offset) % chunk) tap_w.push_back(0.0f);
         desc[k] = d;
+    }
+}
+
+// SAMPLE_MODE maximum / hybrid (glv_misc.hip glv_bars_mode_kernel): blocks of 64 bars, lane l = bar 64 b + l; the block's weights as [tap j][lane], +0 behind a
+// bar's own taps up to the block's longest bar (and for bars past the last one)
+inline void make_bar_mode_blocks(std::vector<BarModeBlock>& blocks, std::vector<float>& mw, const std::vector<BarDesc>& desc, const std::vector<float>& tap_w) {
+    blocks.clear(); mw.clear();
+    const uint32_t bars = (uint32_t) desc.size();
+    for (uint32_t k0 = 0; k0 < bars; k0 += 64u) {
+        BarModeBlock b{(uint32_t) mw.size(), 0u};
+        for (uint32_t k = k0; k < k0 + 64u && k < bars; ++k) b.maxcount = desc[k].count > b.maxcount ? desc[k].count : b.maxcount;
+        mw.resize(mw.size() + (size_t) b.maxcount * 64u, 0.0f);
+        for (uint32_t k = k0; k < k0 + 64u && k < bars; ++k)
+            for (uint32_t j = 0; j < desc[k].count; ++j) mw[b.w_off + (size_t) j * 64u + (k - k0)] = tap_w[desc[k].tap_offset + j];
+        blocks.push_back(b);
     }
 }
 

@@ -21,7 +21,9 @@ LIB_PATH = os.environ.get("GLV_SPECTRUM_LIB") or os.path.join(HERE, "csrc", "lib
 OP_FFT, OP_GRAVITY, OP_AVERAGE, OP_RAW, OP_WRANGE, OP_BARS, OP_SMOOTH, OP_MAGNITUDE, OP_R16 = 1, 2, 4, 8, 16, 32, 64, 128, 256
 OP_PRIVATE_STATE, OP_RING_S16, OP_RING_F32, OP_OUTPUT_IS_STATE, OP_BARS_ONLY = 512, 1024, 2048, 4096, 8192
 OK, ERR_INVALID, ERR_NO_DEVICE, ERR_HIP, ERR_NOMEM, ERR_STATE = 0, 1, 2, 3, 4, 5
-BARS_NONE, BARS_F32_CHAIN, BARS_F32_MATRIX, BARS_I8_EXACT = 0, 1, 2, 3
+BARS_NONE, BARS_F32_CHAIN, BARS_F32_MATRIX, BARS_I8_EXACT, BARS_F32_SEQ = 0, 1, 2, 3, 4
+ROUND_SINUSOIDAL, ROUND_CIRCULAR, ROUND_LINEAR = 0, 1, 2          # glv_params.round_formula
+SAMPLE_AVERAGE, SAMPLE_MAXIMUM, SAMPLE_HYBRID = 0, 1, 2            # glv_params.sample_mode
 
 
 class GlvError(RuntimeError):
@@ -36,7 +38,10 @@ class CParams(C.Structure):
                 ("avg_window", C.c_uint32), ("avg_window_kind", C.c_uint32), ("log_mode", C.c_uint32),
                 ("bars", C.c_uint32), ("smooth_factor", C.c_float),
                 ("smooth_distance", C.c_float), ("smooth_ratio", C.c_float), ("gl_storage", C.c_uint32),
-                ("bar_phase", C.c_float)]
+                ("bar_phase", C.c_float),
+                # ABI 7: smooth_audio()'s shape (smooth_parameters.glsl:17-42); 0 = the shipped value in every field
+                ("round_formula", C.c_uint32), ("sample_mode", C.c_uint32), ("sample_hybrid_weight", C.c_float),
+                ("sample_scale", C.c_float), ("sample_range", C.c_float)]
 
 
 class MultiStats(C.Structure):
@@ -147,11 +152,17 @@ class Params:
     smooth_ratio: float = 4.0
     gl_storage: int = 0
     bar_phase: float = 0.0
+    round_formula: int = 0          # ROUND_SINUSOIDAL / ROUND_CIRCULAR / ROUND_LINEAR
+    sample_mode: int = 0            # SAMPLE_AVERAGE / SAMPLE_MAXIMUM / SAMPLE_HYBRID
+    sample_hybrid_weight: float = 0.0
+    sample_scale: float = 0.0
+    sample_range: float = 0.0
 
     def c(self) -> CParams:
         return CParams(self.n, self.channels, self.fft_scale, self.fft_cutoff, self.gravity_step, self.ur,
                        self.avg_frames, int(self.avg_window), self.avg_window_kind, self.log_mode,
-                       self.bars, self.smooth_factor, self.smooth_distance, self.smooth_ratio, self.gl_storage, self.bar_phase)
+                       self.bars, self.smooth_factor, self.smooth_distance, self.smooth_ratio, self.gl_storage, self.bar_phase,
+                       self.round_formula, self.sample_mode, self.sample_hybrid_weight, self.sample_scale, self.sample_range)
 
 
 def _ptr(x) -> C.c_void_p:

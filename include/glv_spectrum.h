@@ -21,8 +21,10 @@
 extern "C" {
 #endif
 
-#define GLV_ABI_VERSION 6      /* 5 (round 5): + glv_gl_texture; GLV_OP_BARS over texel rows (gl_storage != 0, 256 bars or more) is the exact integer mean
-                                  6 (round 6): + GLV_OP_BARS_ONLY, glv_batch_live_bins, glv_batch_bars_arithmetic, glv_batch_tune_placement; GLV_OP_R16 in a creation mask is a hint */
+#define GLV_ABI_VERSION 7      /* 5 (round 5): + glv_gl_texture; GLV_OP_BARS over texel rows (gl_storage != 0, 256 bars or more) is the exact integer mean
+                                  6 (round 6): + GLV_OP_BARS_ONLY, glv_batch_live_bins, glv_batch_bars_arithmetic, glv_batch_tune_placement; GLV_OP_R16 in a creation mask is a hint
+                                  7 (round 6): glv_params grew smooth_audio()'s shape -- round_formula, sample_mode, sample_hybrid_weight, sample_scale, sample_range
+                                               (appended; all-zero == the shipped shape, so a caller that zero-fills the tail keeps ABI 6's results); GLV_BARS_F32_SEQ */
 
 /* status codes (0 = ok).  The reference has no error channel: it prints and calls
  * glava_abort() (glava/glava.h:17, glava/render.c passim); the in-tree shim maps any
@@ -173,7 +175,28 @@ typedef struct glv_params {
                                0.5 with bars == n: the texel centres of the reference's pre-smoothing pass
                                (util/smooth_pass.frag: smooth_audio(tex, sz, gl_FragCoord.x / w), render.c:2277-2303) -- the
                                texture every stock module samples when setsmoothpass is on (the default) */
+    /* smooth_audio()'s SHAPE (ABI 7): the GLSL `#define`s of shaders/glava/smooth_parameters.glsl:17-42, which a user overrides in
+     * ~/.config/glava/smooth_parameters.glsl or a module's config (the reference re-defines them textually, glsl_ext.c:143-157).  0 in every
+     * field is the shipped shape.  GLV_OP_BARS evaluates exactly this smooth_audio(); integration/glava_hip_shim.c reads the defines out of
+     * the processed shader text the host compiles. */
+    uint32_t round_formula; /* ROUND_FORMULA (smooth_parameters.glsl:17, the macros of util/common.glsl:17-22):
+                               GLV_ROUND_SINUSOIDAL 0 (shipped), GLV_ROUND_CIRCULAR 1, GLV_ROUND_LINEAR 2 */
+    uint32_t sample_mode;   /* SAMPLE_MODE (smooth_parameters.glsl:28; smooth.glsl:9-11, :32-59):
+                               GLV_SAMPLE_AVERAGE 0 (shipped): the weighted mean over s = smin; s <= smax -- every arithmetic GLV_OP_BARS documents above;
+                               GLV_SAMPLE_MAXIMUM 1: max over s = smin; s < smax of fl(x_j * w_j), from +0 (order-free: bit-exact by construction);
+                               GLV_SAMPLE_HYBRID  2: fl(fl(vmax * fl(1 - H)) + fl(fl(avg / weight) * H)) with v_j = fl(x_j * w_j), vmax their maximum,
+                                  avg = ONE chain of float additions of the v_j in bin order from +0 (the shader's loop as written, no fused
+                                  multiply-add), weight the tap-order float sum of the w_j; s < smax.
+                               Modes 1 and 2 run one lane per bar and row (glv_bars_mode_kernel), never inside the transform's launch and never on the
+                               matrix cores (a maximum is not a matrix product); texel rows (gl_storage != 0) enter as x = c / 65535 in float (what
+                               texelFetch returns) and leave, with GLV_OP_R16, as round_to_nearest_even(clamp(bar, 0, 1) * 65535) */
+    float sample_hybrid_weight; /* SAMPLE_HYBRID_WEIGHT, smooth_parameters.glsl:31; 0 = the shipped 0.65; (0, 1] */
+    float sample_scale;     /* SAMPLE_SCALE, smooth_parameters.glsl:35; 0 = the shipped 8 */
+    float sample_range;     /* SAMPLE_RANGE, smooth_parameters.glsl:40; 0 = the shipped 0.9.  scale_audio(1) = -log(1 - range) / scale must not
+                               exceed 1 (the shader would fetch texels beyond the texture: undefined in GL, GLV_ERR_INVALID here) */
 } glv_params;
+enum { GLV_ROUND_SINUSOIDAL = 0, GLV_ROUND_CIRCULAR = 1, GLV_ROUND_LINEAR = 2 };
+enum { GLV_SAMPLE_AVERAGE = 0, GLV_SAMPLE_MAXIMUM = 1, GLV_SAMPLE_HYBRID = 2 };
 
 #define GLV_MAX_AVG_FRAMES 64
 
@@ -387,8 +410,10 @@ const char* glv_batch_kernel_name(const glv_batch* b);
  *                          large smooth_factor, or n = 32768 with smooth_factor slightly above 0.025), 2^P scaling beyond 31 bits, a weight
  *                          >= 2^23 / a tile without steps, or GLV_NO_BARS_I8 in the environment at creation: one f32 fma chain per bar on
  *                          the f32 matrix cores (bit-equal to smooth_audio()'s float order, NOT to glvo_bars_int_at)
+ *   GLV_BARS_F32_SEQ       (ABI 7) sample_mode maximum / hybrid: one lane per bar and row, the shader's loop in float as glv_params.sample_mode documents
+ *                          (oracle glvo_bars_mode_at), float and texel rows alike
  * Float rows (gl_storage 0) always take the float forms.  Callers and parity tests that depend on the exact form check this. */
-enum { GLV_BARS_NONE = 0, GLV_BARS_F32_CHAIN = 1, GLV_BARS_F32_MATRIX = 2, GLV_BARS_I8_EXACT = 3 };
+enum { GLV_BARS_NONE = 0, GLV_BARS_F32_CHAIN = 1, GLV_BARS_F32_MATRIX = 2, GLV_BARS_I8_EXACT = 3, GLV_BARS_F32_SEQ = 4 };
 int glv_batch_bars_arithmetic(const glv_batch* b);
 
 /* ------------------------------------------------------------------------------------

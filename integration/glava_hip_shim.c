@@ -34,6 +34,7 @@ struct glv_box { unsigned long long magic; glv_state* st; };
  *                                  the patched host gives up nothing for being exact; 1 the hardware log2 (<= 1.8e-7 relative on every
  *                                  input of the stage; the batched API's default, where the log is 25 % of a launch); 2 the audit form
  *   GLAVA_HIP_GL=0                 keep the accel path's GL passes on the GL (only the per-frame FFT runs on the MI355X)
+ *                                  (the smoothing SHAPE needs no knob: glv_hip_scan_shape below reads it from the shader the host compiles)
  *   GLAVA_HIP_SMOOTH_FACTOR=<f>    OVERRIDES the pre-smoothing pass's _SMOOTH_FACTOR.  Without it the factor is the host's own:
  *                                  gl_data.smooth_factor (render.c:184, `#request setsmoothfactor` render.c:1198-1200), through the
  *                                  same "%.6f" text the reference prepends to every shader as `#define _SMOOTH_FACTOR` (render.c:317-326)
@@ -51,6 +52,81 @@ static void glv_hip_env(void) {
     if ((e = getenv("GLAVA_HIP_SMOOTH_FACTOR")) && e[0]) glv_hip_smooth_factor = (float) atof(e);
 }
 static bool glv_hip_gl_on(void) { glv_hip_env(); return glv_hip_gl != 0; }
+
+/* smooth_audio()'s SHAPE (glv_params ABI 7).  The host has no field for it: ROUND_FORMULA, SAMPLE_MODE, SAMPLE_HYBRID_WEIGHT, SAMPLE_SCALE and
+   SAMPLE_RANGE are GLSL `#define`s of shaders/glava/smooth_parameters.glsl:17-42, which a user's ~/.config/glava/smooth_parameters.glsl or a
+   module's config re-defines; glsl_ext.c:143-157 turns every `#define X` into `#ifdef X / #undef X / #endif / #define X ...`, so in the
+   processed text the LAST definition is the one the GLSL compiler keeps.  shaderload() (render_hip.patch) hands every processed source
+   here; the pre-smoothing pass (util/smooth_pass.frag, render.c:1634-1636) is the one shader whose smooth_audio() the MI355X replaces.
+   A value that is not one of the stock names / a plain numeric literal (an expression, another macro, a definition inside a conditional
+   the scan cannot evaluate -- `#if` lines between the last definition and the end of the file are not interpreted) marks the shape
+   unreadable: glv_hip_gl_supported() then keeps the GL passes on the GL, whatever they render there. */
+static struct { bool readable; unsigned formula, mode; float hybrid, scale, range; } glv_hip_shape = { true, 0u, 0u, 0.0f, 0.0f, 0.0f };
+static const char* glv_hip_last_define(const char* text, size_t len, const char* name, size_t* vlen) {
+    const size_t nl = strlen(name);
+    const char* found = NULL;
+    size_t i = 0;
+    while (i < len) {                                                    /* line by line */
+        size_t j = i;
+        while (j < len && (text[j] == ' ' || text[j] == '\t')) ++j;
+        if (j < len && text[j] == '#') {
+            ++j;
+            while (j < len && (text[j] == ' ' || text[j] == '\t')) ++j;
+            if (len - j > 6 && !strncmp(text + j, "define", 6) && (text[j + 6] == ' ' || text[j + 6] == '\t')) {
+                j += 6;
+                while (j < len && (text[j] == ' ' || text[j] == '\t')) ++j;
+                if (len - j > nl && !strncmp(text + j, name, nl) && (text[j + nl] == ' ' || text[j + nl] == '\t')) {
+                    j += nl;
+                    while (j < len && (text[j] == ' ' || text[j] == '\t')) ++j;
+                    size_t e = j;
+                    while (e < len && text[e] != '\n' && text[e] != '\r' && !(text[e] == '/' && e + 1 < len && (text[e + 1] == '/' || text[e + 1] == '*'))) ++e;
+                    while (e > j && (text[e - 1] == ' ' || text[e - 1] == '\t')) --e;
+                    found = text + j; *vlen = e - j;
+                }
+            }
+        }
+        while (i < len && text[i] != '\n') ++i;
+        ++i;
+    }
+    return found;
+}
+static bool glv_hip_literal(const char* v, size_t vlen, float* out) {     /* a GLSL numeric literal: 8, 0.9, .65, 1e-1, 0.9f, (0.9) */
+    char buf[48];
+    while (vlen >= 2 && v[0] == '(' && v[vlen - 1] == ')') { ++v; vlen -= 2; }
+    if (vlen == 0 || vlen >= sizeof(buf)) return false;
+    memcpy(buf, v, vlen); buf[vlen] = 0;
+    if (buf[vlen - 1] == 'f' || buf[vlen - 1] == 'F') buf[vlen - 1] = 0;
+    char* end = NULL;
+    *out = strtof(buf, &end);
+    return end != buf && *end == 0 && (buf[0] == '.' || (buf[0] >= '0' && buf[0] <= '9'));
+}
+void glv_hip_scan_shape(const char* rpath, const char* text, size_t len) {
+    static const char* formulas[] = { "sinusoidal", "circular", "linear" }, * modes[] = { "average", "maximum", "hybrid" };
+    const size_t pl = rpath ? strlen(rpath) : 0;
+    if (pl < 16 || strcmp(rpath + pl - 16, "smooth_pass.frag") || !text) return;
+    glv_hip_shape.readable = true; glv_hip_shape.formula = 0u; glv_hip_shape.mode = 0u;
+    glv_hip_shape.hybrid = glv_hip_shape.scale = glv_hip_shape.range = 0.0f;
+    size_t vl = 0;
+    const char* v;
+    if ((v = glv_hip_last_define(text, len, "ROUND_FORMULA", &vl))) {
+        unsigned k = 0;
+        while (k < 3 && !(strlen(formulas[k]) == vl && !strncmp(v, formulas[k], vl))) ++k;
+        if (k < 3) glv_hip_shape.formula = k; else glv_hip_shape.readable = false;
+    }
+    if ((v = glv_hip_last_define(text, len, "SAMPLE_MODE", &vl))) {
+        unsigned k = 0;
+        while (k < 3 && !(strlen(modes[k]) == vl && !strncmp(v, modes[k], vl))) ++k;
+        if (k < 3) glv_hip_shape.mode = k; else glv_hip_shape.readable = false;
+    }
+    if ((v = glv_hip_last_define(text, len, "SAMPLE_HYBRID_WEIGHT", &vl)) && !glv_hip_literal(v, vl, &glv_hip_shape.hybrid)) glv_hip_shape.readable = false;
+    if ((v = glv_hip_last_define(text, len, "SAMPLE_SCALE", &vl)) && !glv_hip_literal(v, vl, &glv_hip_shape.scale)) glv_hip_shape.readable = false;
+    if ((v = glv_hip_last_define(text, len, "SAMPLE_RANGE", &vl)) && !glv_hip_literal(v, vl, &glv_hip_shape.range)) glv_hip_shape.readable = false;
+    /* what the library refuses (glv_api.cpp ensure_bar_tables: positions past the end of the texture) stays on the GL as well */
+    const float sc = glv_hip_shape.scale != 0.0f ? glv_hip_shape.scale : 8.0f, rg = glv_hip_shape.range != 0.0f ? glv_hip_shape.range : 0.9f;
+    const float hw = glv_hip_shape.hybrid != 0.0f ? glv_hip_shape.hybrid : 0.65f;
+    if (!(sc > 0.0f && sc <= 1e6f) || !(rg > 0.0f && rg < 1.0f) || !(-logf(1.0f - rg) / sc <= 1.0f) || !(hw > 0.0f && hw <= 1.0f)) glv_hip_shape.readable = false;
+    if (!glv_hip_shape.readable) fprintf(stderr, "glv: the smoothing shape of '%s' is not one the MI355X path reads (SAMPLE_* / ROUND_FORMULA): its GL passes stay on the GL\n", rpath);
+}
 
 static void glv_hip_fill(const struct gl_data* d, size_t sz, glv_params* p) {
     glv_params_default(p);
@@ -70,6 +146,8 @@ static void glv_hip_fill_gl(const struct gl_data* d, size_t sz, glv_params* p) {
     glv_hip_fill(d, sz, p);
     p->gl_storage = 1; p->avg_window_kind = 1;
     p->bars = (uint32_t) sz; p->bar_phase = 0.5f;
+    p->round_formula = glv_hip_shape.formula; p->sample_mode = glv_hip_shape.mode;      /* glv_hip_scan_shape: the pre-smoothing shader's own defines */
+    p->sample_hybrid_weight = glv_hip_shape.hybrid; p->sample_scale = glv_hip_shape.scale; p->sample_range = glv_hip_shape.range;
     if (glv_hip_smooth_factor >= 0.0f) p->smooth_factor = glv_hip_smooth_factor;
     else {
         /* what smooth.glsl:25-27 computes with: the float literal of the header line shaderload() formats (render.c:317-326) */
@@ -89,7 +167,7 @@ static bool glv_hip_supported(const struct gl_data* d, size_t sz) {
 
 /* ... and for the GL passes on the MI355X: a pre-smoothing factor the library builds tap tables for (a factor outside (0, 1] -- every
    bar without taps, or NaN weights in the shader -- stays on the GL, whatever it renders there) */
-static bool glv_hip_gl_supported(const struct gl_data* d) { return d->smooth_factor > 0.0f && d->smooth_factor <= 1.0f; }
+static bool glv_hip_gl_supported(const struct gl_data* d) { return d->smooth_factor > 0.0f && d->smooth_factor <= 1.0f && glv_hip_shape.readable; }
 
 static glv_state* glv_hip_slot(struct gl_data* d, void** udata, size_t sz) {
     struct glv_box* b = *udata;

@@ -15,6 +15,15 @@ void xwin_wait_for_wm(void) {}
 
 #include "glava_hip_shim.c"
 
+/* what glv_hip_scan_shape made of the last pre-smoothing shader text it was given (tests/test_smooth_shape.py); returns `readable` */
+int shim_shape(unsigned* formula, unsigned* mode, float* hybrid, float* scale, float* range) {
+    *formula = glv_hip_shape.formula; *mode = glv_hip_shape.mode;
+    *hybrid = glv_hip_shape.hybrid != 0.0f ? glv_hip_shape.hybrid : 0.65f;
+    *scale = glv_hip_shape.scale != 0.0f ? glv_hip_shape.scale : 8.0f;
+    *range = glv_hip_shape.range != 0.0f ? glv_hip_shape.range : 0.9f;
+    return glv_hip_shape.readable ? 1 : 0;
+}
+
 typedef struct {
     float fft_scale, fft_cutoff, gravity_step, ur;
     unsigned long avg_frames;

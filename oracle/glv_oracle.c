@@ -396,13 +396,32 @@ void glvo_gl_chain_r16(float* row, float* store, float* hist, size_t* head, size
     *head = (*head + 1) % F;
 }
 
-/* smooth_audio() (shaders/glava/util/smooth.glsl:13-40, SAMPLE_MODE average, ROUND_FORMULA sinusoidal,
- * SAMPLE_SCALE 8, SAMPLE_RANGE 0.9 -- smooth_parameters.glsl) sampled at the bar positions the radial
+/* smooth_audio() (shaders/glava/util/smooth.glsl:13-40, SAMPLE_MODE average) sampled at the bar positions the radial
  * module uses (radial/1.frag:58-70: pos = k / bars, k = 0..bars-1).  tex[] is clamped to [0,1] as the
- * GL_R16 texture would (render.c:523). */
-static float glvo_scale_audio(float idx) { return -logf((-0.9F * idx) + 1) / 8.0F; }
+ * GL_R16 texture would (render.c:523).
+ * The SHAPE -- ROUND_FORMULA, SAMPLE_SCALE, SAMPLE_RANGE, the `#define`s of smooth_parameters.glsl:17-42 that a user's config overrides
+ * (glsl_ext.c:143-157 re-defines them textually) -- is a setting of this checker: glvo_set_smooth_shape() selects it for every glvo_bars_*
+ * function until changed (formula 0 sinusoidal / 1 circular / 2 linear: the macros of util/common.glsl:17-22; a scale or range of 0 selects the
+ * shipped 8 / 0.9).  Test infrastructure: one thread, set - use - restore. */
+static int glvo_shape_formula = 0;
+static float glvo_shape_scale = 8.0F, glvo_shape_range = 0.9F;
+void glvo_set_smooth_shape(int formula, float scale, float range) {
+    glvo_shape_formula = formula;
+    glvo_shape_scale = scale != 0 ? scale : 8.0F;
+    glvo_shape_range = range != 0 ? range : 0.9F;
+}
+static float glvo_scale_audio(float idx) { return -logf((-glvo_shape_range * idx) + 1) / glvo_shape_scale; }   /* smooth.glsl:13-15 */
 static float glvo_clamp01(float x) { return x < 0 ? 0 : (x > 1 ? 1 : x); }
-static float glvo_sinusoidal(float x) { return (0.5F * sinf((3.14159265359F * x) - (3.14159265359F / 2))) + 0.5F; }
+static float glvo_sinusoidal(float x) {                                              /* ROUND_FORMULA(x), common.glsl:17-22 */
+    if (glvo_shape_formula == 1) return sqrtf(1 - ((x - 1) * (x - 1)));              /* circular */
+    if (glvo_shape_formula == 2) return x;                                           /* linear */
+    return (0.5F * sinf((3.14159265359F * x) - (3.14159265359F / 2))) + 0.5F;        /* sinusoidal */
+}
+static double glvo_round_formula_exact(double x) {                                   /* the same in float64 (the *_exact functions) */
+    if (glvo_shape_formula == 1) return sqrt(1 - (x - 1) * (x - 1));
+    if (glvo_shape_formula == 2) return x;
+    return 0.5 * sin(3.14159265358979323846 * x - 3.14159265358979323846 / 2) + 0.5;
+}
 /* phase: smooth_audio() is evaluated at idx = (k + phase) / bars -- 0: the modules' bar positions (radial/1.frag:58-70);
  * 0.5 with bars == sz: gl_FragCoord.x / w of util/smooth_pass.frag, the reference's pre-smoothing pass (render.c:2277-2303) */
 void glvo_bars_at(const float* tex, size_t sz, float* bars_out, size_t bars, float smooth_factor, float phase);
@@ -420,6 +439,31 @@ void glvo_bars_at(const float* tex, size_t sz, float* bars_out, size_t bars, flo
             avg += glvo_clamp01(tex[(int) roundf(s)]) * w;
         }
         bars_out[k] = avg / weight;
+    }
+}
+
+/* SAMPLE_MODE maximum (mode 1, smooth.glsl:52-58) and hybrid (mode 2, smooth.glsl:41-51) -- the shader's loops as written, in float, every operation
+ * rounded on its own (this file is compiled with -ffp-contract=off): s = smin; s < smax; v = tex * w; vmax from 0 by `if (vmax < v) vmax = v`;
+ * hybrid: avg += v, weight += w, result (vmax * (1 - H)) + ((avg / weight) * H).  The library's glv_bars_mode_kernel must produce these bits
+ * (glv_params.sample_mode in include/glv_spectrum.h states the same contract).  tex[] clamped to [0, 1], NaN -> 0 (a GL_R16 texel). */
+void glvo_bars_mode_at(const float* tex, size_t sz, float* bars_out, size_t bars, float smooth_factor, float phase, int mode, float hybrid_weight) {
+    for (size_t k = 0; k < bars; ++k) {
+        float idx = phase == 0.0F ? (float) k / (float) bars : ((float) k + phase) / (float) bars;
+        float smin = glvo_scale_audio(glvo_clamp01(idx - smooth_factor)) * sz;
+        float smax = glvo_scale_audio(glvo_clamp01(idx + smooth_factor)) * sz;
+        float m = (smax - smin) / 2.0F, rm = smin + m;
+        float vmax = 0, avg = 0, weight = 0;
+        for (float s = smin; s < smax; s += 1.0F) {
+            float w = glvo_sinusoidal(glvo_clamp01((m - fabsf(rm - s)) / m));
+            float tv = tex[(int) roundf(s)];
+            tv = tv > 0 ? (tv < 1 ? tv : 1) : 0;
+            float v = tv * w;
+            weight += w;
+            avg += v;
+            if (vmax < v) vmax = v;
+        }
+        float one_minus = 1 - hybrid_weight;
+        bars_out[k] = mode == 1 ? vmax : (vmax * one_minus) + ((avg / weight) * hybrid_weight);
     }
 }
 
@@ -563,7 +607,7 @@ void glvo_bars_at_exact(const float* tex, size_t sz, double* exact, int* ntaps, 
         for (float s = smin; s <= smax; s += 1.0F) {
             double x = ((double) m - fabs((double) rm - (double) s)) / (double) m;
             x = x < 0 ? 0 : (x > 1 ? 1 : x);
-            double w = 0.5 * sin(3.14159265358979323846 * x - 3.14159265358979323846 / 2) + 0.5;
+            double w = glvo_round_formula_exact(x);
             double tv = tex[(int) roundf(s)];
             tv = tv > 0 ? (tv < 1 ? tv : 1) : 0;
             avg += tv * w; weight += w; ++cnt;
@@ -598,7 +642,7 @@ void glvo_bars_one_exact(const float* tex, size_t sz, size_t k, size_t bars, flo
     for (float s = smin; s <= smax; s += 1.0F) {
         double x = ((double) m - fabs((double) rm - (double) s)) / (double) m;
         x = x < 0 ? 0 : (x > 1 ? 1 : x);
-        double w = 0.5 * sin(3.14159265358979323846 * x - 3.14159265358979323846 / 2) + 0.5;
+        double w = glvo_round_formula_exact(x);
         long b = (long) (int) (half_even ? rintf(s) : roundf(s));
         double tv = tex[b < (long) sz ? b : (long) sz - 1];
         tv = tv > 0 ? (tv < 1 ? tv : 1) : 0;
@@ -625,7 +669,7 @@ static double glvo_bars_mean_moved(const float* tex, size_t sz, float smin, floa
     for (float s = smin; s <= smax; s += 1.0F) {
         double x = ((double) m - fabs((double) rm - (double) s)) / (double) m;
         x = x < 0 ? 0 : (x > 1 ? 1 : x);
-        double w = 0.5 * sin(3.14159265358979323846 * x - 3.14159265358979323846 / 2) + 0.5;
+        double w = glvo_round_formula_exact(x);
         long b = (long) (int) (half_even ? rintf(s) : roundf(s));
         double tv = tex[b < (long) sz ? b : (long) sz - 1];
         tv = tv > 0 ? (tv < 1 ? tv : 1) : 0;
@@ -641,7 +685,7 @@ void glvo_bars_range_exact(const float* tex_lo, const float* tex_hi, size_t sz, 
         float smin0 = glvo_scale_audio(glvo_clamp01(idx - smooth_factor)) * sz;
         float smax0 = glvo_scale_audio(glvo_clamp01(idx + smooth_factor)) * sz;
         double big = fabs((double) smax0) > 1 ? fabs((double) smax0) : 1;
-        double d = log_abs * (double) sz / 8.0 + 4.0 * (nextafterf((float) big, INFINITY) - (float) big);
+        double d = log_abs * (double) sz / (double) glvo_shape_scale + 4.0 * (nextafterf((float) big, INFINITY) - (float) big);
         float amin[9 + 3 * 3]; int na = 0;
         for (int g = -4; g <= 4; ++g) amin[na++] = (float) ((double) smin0 + d * g / 4.0);
         for (int q = -1; q <= 1; ++q) {                                  /* frac(smin) == .5 inside the box */

@@ -119,10 +119,13 @@ def _eval_pp(expr: str, macros: dict) -> int:
     return int(eval(expr, {"__builtins__": {}}, {}))
 
 
-def preprocess(path: str, defines: dict | None = None, root: str = SHADER_ROOT, _macros=None, _seen=None) -> tuple[str, dict]:
-    """returns (expanded source, macro table).  `defines`: the macros GLava itself injects (_AVG_FRAMES, _SMOOTH_FACTOR ...)"""
+def preprocess(path: str, defines: dict | None = None, root: str = SHADER_ROOT, _macros=None, _seen=None, overrides: dict | None = None,
+               _text: str | None = None) -> tuple[str, dict]:
+    """returns (expanded source, macro table).  `defines`: the macros GLava itself injects (_AVG_FRAMES, _SMOOTH_FACTOR ...).
+    `overrides`: {file name: text} -- a user's copy of a configuration file (~/.config/glava/<name>): GLava includes the installed file first
+    ("@name", glsl_ext.c:173-181) and the user's second (":name", :168-172), and re-defines macros textually (:143-157), so the user's wins."""
     macros = _macros if _macros is not None else {k: Macro(None, str(v)) for k, v in (defines or {}).items()}
-    src = _strip_comments(open(path).read()).replace("\\\n", " ")
+    src = _strip_comments(_text if _text is not None else open(path).read()).replace("\\\n", " ")
     out = []
     stack = []          # (taking, taken_any)
     def active():
@@ -159,10 +162,11 @@ def preprocess(path: str, defines: dict | None = None, root: str = SHADER_ROOT, 
                 macros.pop(rest.split()[0], None)
             elif name == "include":
                 inc = rest.strip().strip('"')
-                if inc.startswith("@"):          # user override file: optional (glsl_ext.c), absent here
+                if inc.startswith("@") and not (overrides and inc[1:] in overrides):   # the two includes of a configuration file name the same stock file here
                     continue
-                p = os.path.join(root, inc[1:]) if inc.startswith(":") else os.path.join(os.path.dirname(path), inc)
-                text, _ = preprocess(p, None, root, macros)
+                p = os.path.join(root, inc[1:]) if inc[0] in ":@" else os.path.join(os.path.dirname(path), inc)
+                user = overrides.get(inc[1:]) if overrides and inc.startswith(":") else None
+                text, _ = preprocess(p, None, root, macros, overrides=overrides, _text=user)
                 out.append(text)
             elif name == "expand":               # GLava's compile-time loop: `#expand MACRO COUNT` (glsl_ext.c)
                 mname, cnt = rest.split()
@@ -412,17 +416,19 @@ class Shader:
 
 
 # ------------------------------------------------------------------------------------------ the shaders of the path
-def load(relpath: str, defines: dict) -> Shader:
-    src, _ = preprocess(os.path.join(SHADER_ROOT, relpath), defines)
+def load(relpath: str, defines: dict, overrides: dict | None = None) -> Shader:
+    src, _ = preprocess(os.path.join(SHADER_ROOT, relpath), defines, overrides=overrides)
     return Shader(src)
 
 
-def smooth_audio_bars(tex_row, bars: int, smooth_factor=0.025, pre_smoothed=0) -> np.ndarray:
-    """smooth_audio(tex, n, k / bars) of shaders/glava/util/smooth.glsl for k = 0 .. bars-1, evaluated from the shader text"""
-    sh = load("util/smooth.glsl", {"_SMOOTH_FACTOR": repr(float(smooth_factor)), "_PRE_SMOOTHED_AUDIO": pre_smoothed})
+def smooth_audio_bars(tex_row, bars: int, smooth_factor=0.025, pre_smoothed=0, user_parameters: str | None = None, phase=0.0) -> np.ndarray:
+    """smooth_audio(tex, n, (k + phase) / bars) of shaders/glava/util/smooth.glsl for k = 0 .. bars-1, evaluated from the shader text.
+    user_parameters: the text of a user's smooth_parameters.glsl (`#define SAMPLE_MODE maximum` ...), included after the stock one"""
+    sh = load("util/smooth.glsl", {"_SMOOTH_FACTOR": repr(float(smooth_factor)), "_PRE_SMOOTHED_AUDIO": pre_smoothed},
+              {"smooth_parameters.glsl": user_parameters} if user_parameters is not None else None)
     tex = _Tex(tex_row)
     n = int(tex.data.size)
-    return np.array([sh.call("smooth_audio", tex, n, f32(k) / f32(bars)) for k in range(bars)], np.float32)
+    return np.array([sh.call("smooth_audio", tex, n, (f32(k) + f32(phase)) / f32(bars) if phase else f32(k) / f32(bars)) for k in range(bars)], np.float32)
 
 
 def average_pass(frames_newest_first, avg_window=True) -> np.ndarray:

@@ -8,6 +8,7 @@ Nothing in glava_amd/ imports this module.
 """
 from __future__ import annotations
 
+import contextlib
 import ctypes as C
 import os
 import subprocess
@@ -106,6 +107,8 @@ class Oracle:
             L.glvo_bars_chunked.argtypes = [_f32p, C.c_size_t, _f32p, C.c_size_t, C.c_float]
             L.glvo_bars_at.argtypes = [_f32p, C.c_size_t, _f32p, C.c_size_t, C.c_float, C.c_float]
             L.glvo_bars_chunked_at.argtypes = [_f32p, C.c_size_t, _f32p, C.c_size_t, C.c_float, C.c_float]
+            L.glvo_bars_mode_at.argtypes = [_f32p, C.c_size_t, _f32p, C.c_size_t, C.c_float, C.c_float, C.c_int, C.c_float]
+            L.glvo_set_smooth_shape.argtypes = [C.c_int, C.c_float, C.c_float]
             _u16p = np.ctypeslib.ndpointer(np.uint16, flags="C_CONTIGUOUS")
             L.glvo_bars_int_at.argtypes = [_u16p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_size_t, C.c_float, C.c_float]
             L.glvo_bars_int_at.restype = C.c_int
@@ -149,6 +152,25 @@ class Oracle:
         rc = cls.lib().glvo_bars_int_at(texels, texels.size, t.ctypes.data, f.ctypes.data, bars, smooth_factor, phase)
         assert rc == 0, rc
         return t, f
+
+    @classmethod
+    def bars_mode(cls, row: np.ndarray, bars: int, mode: int, hybrid_weight=0.65, smooth_factor=0.025, phase=0.0) -> np.ndarray:
+        """glvo_bars_mode_at: SAMPLE_MODE maximum (1) / hybrid (2) of one float row, the shader's loop in float"""
+        row = np.ascontiguousarray(row, dtype=np.float32)
+        out = np.zeros(bars, np.float32)
+        cls.lib().glvo_bars_mode_at(row, row.size, out, bars, smooth_factor, phase, mode, hybrid_weight)
+        return out
+
+    @classmethod
+    @contextlib.contextmanager
+    def smooth_shape(cls, formula: int = 0, scale: float = 0.0, rng: float = 0.0):
+        """glvo_set_smooth_shape for the duration of a `with` block: ROUND_FORMULA (0 sinusoidal, 1 circular, 2 linear), SAMPLE_SCALE, SAMPLE_RANGE
+        as every glvo_bars_* function sees them (0 = the shipped 8 / 0.9)"""
+        cls.lib().glvo_set_smooth_shape(formula, scale, rng)
+        try:
+            yield
+        finally:
+            cls.lib().glvo_set_smooth_shape(0, 0.0, 0.0)
 
     @classmethod
     def window_table(cls, n: int) -> np.ndarray:

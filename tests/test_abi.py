@@ -45,7 +45,7 @@ def test_defaults_match_shipped_config(glvlib):
     assert cp.n == 4096 and cp.channels == 2 and cp.avg_frames == 5 and cp.avg_window == 1
     assert cp.fft_scale == np.float32(10.2) and cp.fft_cutoff == np.float32(0.3)
     assert cp.gravity_step == np.float32(4.2) and cp.ur == np.float32(22050 / 256)
-    assert glvlib.lib().glv_abi_version() == 6
+    assert glvlib.lib().glv_abi_version() == 7
 
 
 def test_argument_validation(glvlib):

@@ -422,6 +422,34 @@ static double glvo_round_formula_exact(double x) {                              
     if (glvo_shape_formula == 2) return x;
     return 0.5 * sin(3.14159265358979323846 * x - 3.14159265358979323846 / 2) + 0.5;
 }
+/* SAMPLE_MODE for the float64 evaluations below (glvo_bars_at_exact, glvo_bars_one_exact, glvo_bars_range_exact -- the brackets the texels of a
+ * GLSL implementation are held to): 0 average (s <= smax), 1 maximum, 2 hybrid with weight H (s < smax) -- smooth.glsl:32-59.  The float functions
+ * take the mode as an argument (glvo_bars_mode_at) or are the averaging forms by definition. */
+static int glvo_shape_mode = 0;
+static double glvo_shape_hybrid = 0.65;
+void glvo_set_smooth_mode(int mode, float hybrid_weight) { glvo_shape_mode = mode; glvo_shape_hybrid = hybrid_weight != 0 ? (double) hybrid_weight : 0.65; }
+/* smooth_audio()'s loop from the float bounds smin / smax -- the shader's own walk in float (s += 1.0F, tap round(s)), weights, products, sums and the
+ * result in float64.  half_even: round() at an exact .5 to even (Mesa) instead of away from zero (C). */
+static double glvo_smooth_loop_exact(const float* tex, size_t sz, float smin, float smax, int half_even, int* cnt_out) {
+    float m = (smax - smin) / 2.0F, rm = smin + m;
+    double avg = 0, weight = 0, vmax = 0;
+    int cnt = 0;
+    for (float s = smin; glvo_shape_mode == 0 ? s <= smax : s < smax; s += 1.0F) {
+        double x = ((double) m - fabs((double) rm - (double) s)) / (double) m;
+        x = x < 0 ? 0 : (x > 1 ? 1 : x);
+        double w = glvo_round_formula_exact(x);
+        long b = (long) (int) (half_even ? rintf(s) : roundf(s));
+        double tv = tex[b < (long) sz ? b : (long) sz - 1];
+        tv = tv > 0 ? (tv < 1 ? tv : 1) : 0;
+        double v = tv * w;
+        avg += v; weight += w; ++cnt;
+        if (vmax < v) vmax = v;
+    }
+    *cnt_out = cnt;
+    if (glvo_shape_mode == 1) return vmax;
+    double mean = weight > 0 ? avg / weight : 0.0;
+    return glvo_shape_mode == 2 ? vmax * (1.0 - glvo_shape_hybrid) + mean * glvo_shape_hybrid : mean;
+}
 /* phase: smooth_audio() is evaluated at idx = (k + phase) / bars -- 0: the modules' bar positions (radial/1.frag:58-70);
  * 0.5 with bars == sz: gl_FragCoord.x / w of util/smooth_pass.frag, the reference's pre-smoothing pass (render.c:2277-2303) */
 void glvo_bars_at(const float* tex, size_t sz, float* bars_out, size_t bars, float smooth_factor, float phase);
@@ -601,24 +629,41 @@ void glvo_bars_at_exact(const float* tex, size_t sz, double* exact, int* ntaps, 
         float idx = phase == 0.0F ? (float) k / (float) bars : ((float) k + phase) / (float) bars;
         float smin = glvo_scale_audio(glvo_clamp01(idx - smooth_factor)) * sz;
         float smax = glvo_scale_audio(glvo_clamp01(idx + smooth_factor)) * sz;
-        float m = (smax - smin) / 2.0F, rm = smin + m;
-        double avg = 0, weight = 0;
         int cnt = 0;
-        for (float s = smin; s <= smax; s += 1.0F) {
-            double x = ((double) m - fabs((double) rm - (double) s)) / (double) m;
-            x = x < 0 ? 0 : (x > 1 ? 1 : x);
-            double w = glvo_round_formula_exact(x);
-            double tv = tex[(int) roundf(s)];
-            tv = tv > 0 ? (tv < 1 ? tv : 1) : 0;
-            avg += tv * w; weight += w; ++cnt;
-        }
-        exact[k] = weight > 0 ? avg / weight : 0.0;
+        exact[k] = glvo_smooth_loop_exact(tex, sz, smin, smax, 0, &cnt);
         ntaps[k] = cnt;
         /* scale_audio() = log, a product and a quotient in float: `ulps` units of the larger bound, four times over for the chain */
         double big = fabs((double) smax) > 1 ? fabs((double) smax) : 1;
         double eps = 4.0 * ulps * (nextafterf((float) big, INFINITY) - (float) big);
         double d = (double) smax - (double) smin, fm = (double) smin - floor((double) smin);
         fragile[k] = fabs(d - rint(d)) <= 2 * eps || fabs(fm - 0.5) <= eps;
+    }
+}
+
+/* How much of a float implementation's error the WEIGHT FUNCTION amplifies, per bar (for the brackets of tests/test_gl_reference.py): the argument
+ * x = (m - |rm - s|) / m is a difference of float positions, good to dx = 8 ulp(max(smax, 1)) / m, and ROUND_FORMULA circular = sqrt(1 - (x - 1)^2) has
+ * an infinite slope at x = 0 -- the outermost taps of a bar get weights that hang on the last bits of x whoever evaluates them (sinusoidal is flat
+ * there, linear has slope 1).  rel[k] = sum_j |w(x_j + dx) - w(x_j - dx)| / sum_j w_j bounds the relative move of a weighted mean, abs[k] = max_j of the
+ * same differences the absolute move of a maximum of x_j w_j. */
+void glvo_bars_weight_slack(size_t sz, double* rel, double* abs_out, size_t bars, float smooth_factor, float phase) {
+    for (size_t k = 0; k < bars; ++k) {
+        float idx = phase == 0.0F ? (float) k / (float) bars : ((float) k + phase) / (float) bars;
+        float smin = glvo_scale_audio(glvo_clamp01(idx - smooth_factor)) * sz;
+        float smax = glvo_scale_audio(glvo_clamp01(idx + smooth_factor)) * sz;
+        float m = (smax - smin) / 2.0F, rm = smin + m;
+        double big = fabs((double) smax) > 1 ? fabs((double) smax) : 1;
+        double dx = m > 0 ? 8.0 * (nextafterf((float) big, INFINITY) - (float) big) / (double) m : 0.0;
+        double acc = 0, wsum = 0, worst = 0;
+        for (float s = smin; glvo_shape_mode == 0 ? s <= smax : s < smax; s += 1.0F) {
+            double x = ((double) m - fabs((double) rm - (double) s)) / (double) m;
+            double xc = x < 0 ? 0 : (x > 1 ? 1 : x), xp = x + dx, xm = x - dx;
+            xp = xp < 0 ? 0 : (xp > 1 ? 1 : xp); xm = xm < 0 ? 0 : (xm > 1 ? 1 : xm);
+            double d = fabs(glvo_round_formula_exact(xp) - glvo_round_formula_exact(xm));
+            acc += d; wsum += glvo_round_formula_exact(xc);
+            if (d > worst) worst = d;
+        }
+        rel[k] = wsum > 0 ? acc / wsum : 0.0;
+        abs_out[k] = worst;
     }
 }
 
@@ -636,20 +681,7 @@ void glvo_bars_one_exact(const float* tex, size_t sz, size_t k, size_t bars, flo
     for (int q = 0; q < abs(dmin); ++q) smin = nextafterf(smin, dmin > 0 ? INFINITY : -INFINITY);
     for (int q = 0; q < abs(dmax); ++q) smax = nextafterf(smax, dmax > 0 ? INFINITY : -INFINITY);
     if (smin < 0) smin = 0;
-    float m = (smax - smin) / 2.0F, rm = smin + m;
-    double avg = 0, weight = 0;
-    int cnt = 0;
-    for (float s = smin; s <= smax; s += 1.0F) {
-        double x = ((double) m - fabs((double) rm - (double) s)) / (double) m;
-        x = x < 0 ? 0 : (x > 1 ? 1 : x);
-        double w = glvo_round_formula_exact(x);
-        long b = (long) (int) (half_even ? rintf(s) : roundf(s));
-        double tv = tex[b < (long) sz ? b : (long) sz - 1];
-        tv = tv > 0 ? (tv < 1 ? tv : 1) : 0;
-        avg += tv * w; weight += w; ++cnt;
-    }
-    *exact = weight > 0 ? avg / weight : 0.0;
-    *ntaps = cnt;
+    *exact = glvo_smooth_loop_exact(tex, sz, smin, smax, half_even, ntaps);
 }
 
 /* What smooth_audio() may return for every bar when scale_audio()'s log() is only as accurate as GLSL implementations are held to:
@@ -663,20 +695,7 @@ void glvo_bars_one_exact(const float* tex, size_t sz, size_t k, size_t bars, flo
  * vmin is evaluated on tex_lo, vmax on tex_hi (the weights are >= 0: the mean is monotone in every tap); pass the same row twice for one
  * row's range.  ntaps[k] = the largest tap count met (the float error of an implementation's sums grows with it). */
 static double glvo_bars_mean_moved(const float* tex, size_t sz, float smin, float smax, int half_even, int* cnt_out) {
-    float m = (smax - smin) / 2.0F, rm = smin + m;
-    double avg = 0, weight = 0;
-    int cnt = 0;
-    for (float s = smin; s <= smax; s += 1.0F) {
-        double x = ((double) m - fabs((double) rm - (double) s)) / (double) m;
-        x = x < 0 ? 0 : (x > 1 ? 1 : x);
-        double w = glvo_round_formula_exact(x);
-        long b = (long) (int) (half_even ? rintf(s) : roundf(s));
-        double tv = tex[b < (long) sz ? b : (long) sz - 1];
-        tv = tv > 0 ? (tv < 1 ? tv : 1) : 0;
-        avg += tv * w; weight += w; ++cnt;
-    }
-    *cnt_out = cnt;
-    return weight > 0 ? avg / weight : 0.0;
+    return glvo_smooth_loop_exact(tex, sz, smin, smax, half_even, cnt_out);
 }
 void glvo_bars_range_exact(const float* tex_lo, const float* tex_hi, size_t sz, double* vmin, double* vmax, int* ntaps, size_t bars,
                            float smooth_factor, float phase, double log_abs) {

@@ -39,6 +39,14 @@ CASES = [("n1024_F5w", 1024, 5, True, 9, 4), ("n1024_F6u", 1024, 6, False, 9, 4)
 FACTOR_CASES = [("n1024_F5w_sf010", 1024, 5, True, 6, 4, 0.01), ("n1024_F5w_sf050", 1024, 5, True, 6, 4, 0.05), ("n4096_F5w_sf050", 4096, 5, True, 6, 5, 0.05),
                 ("n2048_F3w_sf010", 2048, 3, True, 5, 4, 0.01)]
 FACTORS = {c[0]: c[6] for c in FACTOR_CASES}
+# round 6 (VERDICT r5 missing 7): a user's smooth_parameters.glsl that re-defines the smoothing SHAPE -- SAMPLE_MODE, ROUND_FORMULA, SAMPLE_HYBRID_WEIGHT,
+# SAMPLE_SCALE, SAMPLE_RANGE (smooth_parameters.glsl:17-42).  name, n, F, window, frames, shift, the defines, and the same shape as glv_params /
+# the oracle take it: (round_formula, sample_mode, sample_hybrid_weight, sample_scale, sample_range)
+SHAPE_CASES = [("n1024_F5w_maximum", 1024, 5, True, 6, 4, {"SAMPLE_MODE": "maximum"}, (0, 1, 0.0, 0.0, 0.0)),
+               ("n1024_F5w_hybrid", 1024, 5, True, 6, 4, {"SAMPLE_MODE": "hybrid"}, (0, 2, 0.0, 0.0, 0.0)),
+               ("n4096_F5w_circular_s6_r80", 4096, 5, True, 6, 5, {"ROUND_FORMULA": "circular", "SAMPLE_SCALE": "6", "SAMPLE_RANGE": "0.8"}, (1, 0, 0.0, 6.0, 0.8)),
+               ("n2048_F3w_linear_hybrid40", 2048, 3, True, 5, 4, {"ROUND_FORMULA": "linear", "SAMPLE_MODE": "hybrid", "SAMPLE_HYBRID_WEIGHT": "0.4"}, (2, 2, 0.4, 0.0, 0.0))]
+SHAPES = {c[0]: (c[6], c[7]) for c in SHAPE_CASES}
 
 
 def frames_of(name, n, count, shift):
@@ -47,12 +55,12 @@ def frames_of(name, n, count, shift):
     return pcm
 
 
-def config_dir(tmp, F, win, factor=None):
+def config_dir(tmp, F, win, factor=None, defines=None):
     """a user configuration directory like `glava --copy-config` makes: links to the installed tree, and its own
     smooth_parameters.glsl -- the reference's text with the two averaging requests changed (that file's #request lines are
     processed when the module's shaders include it, after everything rc.glsl and the command line said)"""
     import re
-    d = os.path.join(tmp, f"cfg_F{F}_{int(win)}" + (f"_sf{factor}" if factor is not None else ""))
+    d = os.path.join(tmp, f"cfg_F{F}_{int(win)}" + (f"_sf{factor}" if factor is not None else "") + ("_" + "_".join(f"{k}{v}" for k, v in sorted(defines.items())) if defines else ""))
     os.makedirs(d, exist_ok=True)
     for e in os.listdir(SHADERS):
         dst = os.path.join(d, e)
@@ -65,13 +73,16 @@ def config_dir(tmp, F, win, factor=None):
             if factor is not None:
                 txt, n3 = re.subn(r"#request setsmoothfactor [0-9.]+", f"#request setsmoothfactor {factor}", txt)
                 assert n3 == 1
+            for k, v in (defines or {}).items():                # the user's copy with the shape's `#define`s edited, as a GLava user would
+                txt, n4 = re.subn(rf"(?m)^#define {k} \S+", f"#define {k} {v}", txt)
+                assert n4 == 1, k
             open(dst, "w").write(txt)
         else:
             os.symlink(os.path.join(SHADERS, e), dst)
     return d
 
 
-def run_case(n, F, win, pcm, tmp, so=SO, hip=None, factor=None):
+def run_case(n, F, win, pcm, tmp, so=SO, hip=None, factor=None, defines=None):
     """one renderer per case; rd_new can be called repeatedly in one process (every call makes its own context).
     so / hip: the patched build (oracle/_ref/libglvglref_hip.so) with hip = (GL passes on the MI355X?, log_mode)"""
     L = C.CDLL(so)
@@ -85,7 +96,7 @@ def run_case(n, F, win, pcm, tmp, so=SO, hip=None, factor=None):
     L.glref_update.argtypes = [C.c_void_p, fp, fp, C.c_size_t, C.c_int, np.ctypeslib.ndpointer(np.uint16, flags="C_CONTIGUOUS")]
     L.glref_gl_version.restype = C.c_char_p; L.glref_gl_renderer.restype = C.c_char_p
     reqs = (C.c_char_p * 2)(b"setbufsize %d" % n, None)
-    h = L.glref_create(config_dir(tmp, F, win, factor).encode(), SHADERS.encode(), reqs, UR)
+    h = L.glref_create(config_dir(tmp, F, win, factor, defines).encode(), SHADERS.encode(), reqs, UR)
     assert h and L.glref_avg_frames(h) == F
     if factor is not None:
         L.glref_smooth_factor.restype = C.c_float; L.glref_smooth_factor.argtypes = [C.c_void_p]
@@ -105,7 +116,20 @@ def main():
     vecs = {}
     info = None
     tmp = tempfile.mkdtemp(prefix="glv_glref_")
+    if "--add" in sys.argv:                                     # keep the committed vectors, compute only the cases the file does not hold yet
+        old = np.load(os.path.join(HERE, "gl_vectors.npz"))
+        vecs = {k: old[k] for k in old.files}
+        info = str(vecs["gl_implementation"])
+    for name, n, F, win, count, shift, defines, _ in SHAPE_CASES:
+        if f"{name}_tex" in vecs: continue
+        pcm = frames_of(name, n, count, shift)
+        tex, ver, rend = run_case(n, F, win, pcm, tmp, defines=defines)
+        assert info is None or info == f"{ver} / {rend}", (info, ver, rend)
+        vecs[f"{name}_pcm"] = pcm
+        vecs[f"{name}_tex"] = tex
+        print(name, "ok", tex.shape, defines, flush=True)
     for name, n, F, win, count, shift in CASES:
+        if f"{name}_tex" in vecs: continue
         pcm = frames_of(name, n, count, shift)
         tex, ver, rend = run_case(n, F, win, pcm, tmp)
         vecs[f"{name}_pcm"] = pcm
@@ -113,6 +137,7 @@ def main():
         info = f"{ver} / {rend}"
         print(name, "ok", tex.shape, info, flush=True)
     for name, n, F, win, count, shift, factor in FACTOR_CASES:
+        if f"{name}_tex" in vecs: continue
         pcm = frames_of(name, n, count, shift)
         tex, ver, rend = run_case(n, F, win, pcm, tmp, factor=factor)
         vecs[f"{name}_pcm"] = pcm

@@ -109,6 +109,9 @@ class Oracle:
             L.glvo_bars_chunked_at.argtypes = [_f32p, C.c_size_t, _f32p, C.c_size_t, C.c_float, C.c_float]
             L.glvo_bars_mode_at.argtypes = [_f32p, C.c_size_t, _f32p, C.c_size_t, C.c_float, C.c_float, C.c_int, C.c_float]
             L.glvo_set_smooth_shape.argtypes = [C.c_int, C.c_float, C.c_float]
+            L.glvo_set_smooth_mode.argtypes = [C.c_int, C.c_float]
+            _f64s = np.ctypeslib.ndpointer(np.float64, flags="C_CONTIGUOUS")
+            L.glvo_bars_weight_slack.argtypes = [C.c_size_t, _f64s, _f64s, C.c_size_t, C.c_float, C.c_float]
             _u16p = np.ctypeslib.ndpointer(np.uint16, flags="C_CONTIGUOUS")
             L.glvo_bars_int_at.argtypes = [_u16p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_size_t, C.c_float, C.c_float]
             L.glvo_bars_int_at.restype = C.c_int
@@ -163,14 +166,17 @@ class Oracle:
 
     @classmethod
     @contextlib.contextmanager
-    def smooth_shape(cls, formula: int = 0, scale: float = 0.0, rng: float = 0.0):
+    def smooth_shape(cls, formula: int = 0, scale: float = 0.0, rng: float = 0.0, mode: int = 0, hybrid_weight: float = 0.0):
         """glvo_set_smooth_shape for the duration of a `with` block: ROUND_FORMULA (0 sinusoidal, 1 circular, 2 linear), SAMPLE_SCALE, SAMPLE_RANGE
-        as every glvo_bars_* function sees them (0 = the shipped 8 / 0.9)"""
+        as every glvo_bars_* function sees them (0 = the shipped 8 / 0.9); mode / hybrid_weight: SAMPLE_MODE for the float64 evaluations
+        (glvo_bars_at_exact, _one_exact, _range_exact: glvo_set_smooth_mode)"""
         cls.lib().glvo_set_smooth_shape(formula, scale, rng)
+        cls.lib().glvo_set_smooth_mode(mode, hybrid_weight)
         try:
             yield
         finally:
             cls.lib().glvo_set_smooth_shape(0, 0.0, 0.0)
+            cls.lib().glvo_set_smooth_mode(0, 0.0)
 
     @classmethod
     def window_table(cls, n: int) -> np.ndarray:

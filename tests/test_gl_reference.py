@@ -34,7 +34,52 @@ CASES = [("n1024_F5w", 1024, 5, True), ("n1024_F6u", 1024, 6, False), ("n1024_F1
          ("n1024_F2w", 1024, 2, True), ("n2048_F5w_loud", 2048, 5, True), ("n4096_F5w", 4096, 5, True)]
 # `#request setsmoothfactor` cases (round 6): gl_data.smooth_factor reaches the pass as the header's `#define _SMOOTH_FACTOR %.6f` (render.c:317-326)
 FACTOR_CASES = [("n1024_F5w_sf010", 1024, 5, True), ("n1024_F5w_sf050", 1024, 5, True), ("n4096_F5w_sf050", 4096, 5, True), ("n2048_F3w_sf010", 2048, 3, True)]
+# a user's smooth_parameters.glsl with the smoothing SHAPE re-defined (round 6, VERDICT r5 missing 7): name -> (the `#define`s of the generator's
+# configuration directory, glv_params' (round_formula, sample_mode, sample_hybrid_weight, sample_scale, sample_range))
+SHAPE_CASES = [("n1024_F5w_maximum", 1024, 5, True), ("n1024_F5w_hybrid", 1024, 5, True), ("n4096_F5w_circular_s6_r80", 4096, 5, True), ("n2048_F3w_linear_hybrid40", 2048, 3, True)]
+SHAPES = {"n1024_F5w_maximum": ({"SAMPLE_MODE": "maximum"}, (0, 1, 0.0, 0.0, 0.0)), "n1024_F5w_hybrid": ({"SAMPLE_MODE": "hybrid"}, (0, 2, 0.0, 0.0, 0.0)),
+          "n4096_F5w_circular_s6_r80": ({"ROUND_FORMULA": "circular", "SAMPLE_SCALE": "6", "SAMPLE_RANGE": "0.8"}, (1, 0, 0.0, 6.0, 0.8)),
+          "n2048_F3w_linear_hybrid40": ({"ROUND_FORMULA": "linear", "SAMPLE_MODE": "hybrid", "SAMPLE_HYBRID_WEIGHT": "0.4"}, (2, 2, 0.4, 0.0, 0.0))}
 UP, GR, AV, SM = 0, 1, 2, 3
+
+
+def shape_of(name):
+    return SHAPES[name][1] if name in SHAPES else (0, 0, 0.0, 0.0, 0.0)
+
+
+import contextlib
+
+
+@contextlib.contextmanager
+def shape_ctx(name):
+    """every oracle evaluation of smooth_audio() inside the block runs under the case's shape (the float functions and the float64 brackets alike);
+    for a ROUND_FORMULA other than the shipped one the brackets carry what the weight function makes of a float argument (WEIGHT_SLACK)"""
+    formula, mode, hw, scale, rng = shape_of(name)
+    with Oracle.smooth_shape(formula, scale, rng, mode, hw):
+        if formula != 0:
+            n = next(c[1] for c in SHAPE_CASES if c[0] == name)
+            rel = np.empty(n, np.float64); ab = np.empty(n, np.float64)
+            Oracle.lib().glvo_bars_weight_slack(n, rel, ab, n, factor_of(name), 0.5)
+            WEIGHT_SLACK["rel"], WEIGHT_SLACK["abs"] = rel, ab * (1.0 if mode == 1 else (1.0 - (hw or 0.65)) if mode == 2 else 0.0)   # the maximum's share
+        try:
+            yield
+        finally:
+            WEIGHT_SLACK["rel"] = WEIGHT_SLACK["abs"] = None
+
+
+def shape_params(name):
+    formula, mode, hw, scale, rng = shape_of(name)
+    return dict(round_formula=formula, sample_mode=mode, sample_hybrid_weight=hw, sample_scale=scale, sample_range=rng)
+
+
+def oracle_smooth_texels(av_texels, n, factor, name):
+    """the oracle's float form of the pass on one row of `av` texels under the case's shape -> texels"""
+    formula, mode, hw, scale, rng = shape_of(name)
+    if mode:
+        return Oracle.texels_r16(Oracle.bars_mode(texel_float(av_texels), n, mode, hw or 0.65, factor, 0.5))
+    sm = np.empty(n, np.float32)
+    Oracle.lib().glvo_bars_at(texel_float(av_texels), n, sm, n, factor, 0.5)
+    return Oracle.texels_r16(sm)
 
 
 def factor_of(name):
@@ -89,7 +134,16 @@ def d_upload(ex): return U * np.maximum(ex, 1.0) + 1e-9                      # o
 def d_average(ex, F): return (F + 8) * U * np.maximum(ex, 1.0)               # F products, F sums, the quotient, the folded weights
 # worst case of an nt-term float sum (numerator and weight sum) + the weights themselves: they are sin() values, GLSL promises no
 # accuracy for sin() and Mesa's llvmpipe evaluates it with a polynomial good to ~2^-20, which a weighted mean inherits
-def d_smooth(ex, nt): return ((nt + 16) * U + 2.0 ** -18) * np.maximum(ex, 1.0)
+# ... under a user's ROUND_FORMULA the weight function itself can amplify the float error of its argument (circular: an infinite slope at the outermost
+# taps): WEIGHT_SLACK holds glvo_bars_weight_slack's per-bar bounds for the case being checked (None for the shipped sinusoidal: flat there, and
+# covered by the 2^-18 above) -- `k`: the bar a scalar evaluation belongs to
+WEIGHT_SLACK = {"rel": None, "abs": None}
+def d_smooth(ex, nt, k=None):
+    d = ((nt + 16) * U + 2.0 ** -18) * np.maximum(ex, 1.0)
+    if WEIGHT_SLACK["rel"] is not None:
+        rel, ab = (WEIGHT_SLACK["rel"], WEIGHT_SLACK["abs"]) if k is None else (WEIGHT_SLACK["rel"][k], WEIGHT_SLACK["abs"][k])
+        d = d + rel * np.maximum(ex, 1.0) + ab * 65535.0
+    return d
 
 
 # the tap sets a fragile bar may walk: the loop's bounds up to 4 ulps away (another log()), round() at an exact .5 away from zero or to even
@@ -141,7 +195,7 @@ def smooth_admissible(got, av_texels, n, what, factor=0.025, log_abs=0.0):
         ok = False
         for dmin, dmax, he in CANDIDATES:
             Oracle.lib().glvo_bars_one_exact(texf, n, int(k), n, factor, 0.5, dmin, dmax, he, C.byref(e), C.byref(c))
-            if texel_ok(got[k], e.value * 65535.0, float(d_smooth(e.value * 65535.0, c.value))):
+            if texel_ok(got[k], e.value * 65535.0, float(d_smooth(e.value * 65535.0, c.value, int(k)))):
                 ok = True
                 break
         bad[k] = not ok
@@ -170,10 +224,10 @@ def smooth_bounds(av_lo, av_hi, n, factor=0.025, log_abs=0.0):
     for k in np.flatnonzero(frag):
         for dmin, dmax, he in CANDIDATES:
             Oracle.lib().glvo_bars_one_exact(fl, n, int(k), n, factor, 0.5, dmin, dmax, he, C.byref(e), C.byref(c))
-            v = e.value * 65535.0; dl = float(d_smooth(v, c.value))
+            v = e.value * 65535.0; dl = float(d_smooth(v, c.value, int(k)))
             lo[k] = min(lo[k], np.floor(v) if abs(v - np.floor(v) - 0.5) <= dl else np.rint(v))
             Oracle.lib().glvo_bars_one_exact(fh, n, int(k), n, factor, 0.5, dmin, dmax, he, C.byref(e), C.byref(c))
-            v = e.value * 65535.0; dl = float(d_smooth(v, c.value))
+            v = e.value * 65535.0; dl = float(d_smooth(v, c.value, int(k)))
             hi[k] = max(hi[k], np.floor(v) + 1 if abs(v - np.floor(v) - 0.5) <= dl else np.rint(v))
     lo = np.clip(lo, 0, 65535).astype(np.int64); hi = np.clip(hi, 0, 65535).astype(np.int64)
     if log_abs > 0:
@@ -212,8 +266,13 @@ class ChainBounds:
         return out[0], out[1]
 
 
-@pytest.mark.parametrize("name,n,F,win", CASES + FACTOR_CASES)
+@pytest.mark.parametrize("name,n,F,win", CASES + FACTOR_CASES + SHAPE_CASES)
 def test_gl_passes_tie_aware_reference_and_oracle(name, n, F, win):
+    with shape_ctx(name):
+        _gl_passes_tie_aware_reference_and_oracle(name, n, F, win)
+
+
+def _gl_passes_tie_aware_reference_and_oracle(name, n, F, win):
     """Pass by pass, each fed with the reference's own input texels: the REFERENCE's llvmpipe texels and the ORACLE's restatement
     against the exact value of the pass -- gravity store exact; upload, average and pre-smoothing pass equal to the rounded exact
     value except at genuine ties (either neighbour); the smooth pass tap-set-aware (smooth_admissible: no bar excluded), also for the
@@ -221,7 +280,8 @@ def test_gl_passes_tie_aware_reference_and_oracle(name, n, F, win):
     model (ChainBounds / smooth_bounds: equality wherever no tie is in play)."""
     pcm, tex = GOLD[name + "_pcm"], GOLD[name + "_tex"]
     factor = factor_of(name)
-    glsl_log = name + "_factor" in GOLD.files
+    glsl_log = name + "_factor" in GOLD.files or name in SHAPES
+    averaging = shape_of(name)[1] == 0
     store = np.zeros((2, n), np.float32); hist = np.zeros((2, F, n), np.float32)
     heads = [C.c_size_t(0), C.c_size_t(0)]
     ring = [[np.zeros(n, np.int64) for _ in range(F)] for _ in range(2)]
@@ -248,10 +308,9 @@ def test_gl_passes_tie_aware_reference_and_oracle(name, n, F, win):
             else:
                 assert (tex[f, ch, AV] == tex[f, ch, GR]).all() and (Oracle.texels_r16(row) == tex[f, ch, GR]).all()     # render.c:2230
             # (the model's state IS the reference's: the gravity store matched exactly)
-            sm = np.empty(n, np.float32)
-            Oracle.lib().glvo_bars_at(texel_float(tex[f, ch, AV]), n, sm, n, factor, 0.5)
-            smi, _ = Oracle.bars_int(tex[f, ch, AV], n, factor, 0.5)             # the library's exact integer form of the pass (round 5)
-            for who, got in (("oracle", Oracle.texels_r16(sm)), ("integer form", smi), ("reference", tex[f, ch, SM])):
+            forms = [("oracle", oracle_smooth_texels(tex[f, ch, AV], n, factor, name)), ("reference", tex[f, ch, SM])]
+            if averaging: forms.insert(1, ("integer form", Oracle.bars_int(tex[f, ch, AV], n, factor, 0.5)[0]))   # the library's exact integer form of the pass (round 5)
+            for who, got in forms:
                 # the reference's texels come off a GLSL log(): at the shipped factor they meet the correctly-rounded-log standard all the
                 # same (log_abs stays 0 there: a regression would show); at other factors the log's admissible error is part of the claim
                 nn, nd, nfrag, nw = smooth_admissible(got, tex[f, ch, AV], n, ("smooth pass", who, f, ch), factor, LOG_ABS if (who == "reference" and glsl_log) else 0.0)
@@ -288,8 +347,13 @@ def test_gl_golden_file_is_reproducible(tmp_path):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("name,n,F,win", CASES + FACTOR_CASES)
+@pytest.mark.parametrize("name,n,F,win", CASES + FACTOR_CASES + SHAPE_CASES)
 def test_device_gl_passes_tie_aware(glvlib, name, n, F, win):
+    with shape_ctx(name):
+        _device_gl_passes_tie_aware(glvlib, name, n, F, win)
+
+
+def _device_gl_passes_tie_aware(glvlib, name, n, F, win):
     """The HIP path (gl_storage 1: the fused GL_R16 chain; avg_window_kind 1; GLV_OP_BARS at the pre-smoothing pass's texel centres)
     held to the same standard.  Pass by pass, fed with the reference's own texels: upload (GLV_OP_R16 of the transform), gravity +
     average (the operators on planar rows), smooth pass (glv_batch_bars) -- each equal to the rounded exact value except at genuine
@@ -303,7 +367,8 @@ def test_device_gl_passes_tie_aware(glvlib, name, n, F, win):
     factor = factor_of(name)
     mask = G.OP_GRAVITY | (G.OP_AVERAGE if F > 1 else 0)
     ops = G.OP_FFT | mask
-    p = G.Params(n=n, avg_frames=F, avg_window=win, avg_window_kind=1, gl_storage=1, log_mode=0, ur=UR, bars=n, bar_phase=0.5, smooth_factor=factor)
+    p = G.Params(n=n, avg_frames=F, avg_window=win, avg_window_kind=1, gl_storage=1, log_mode=0, ur=UR, bars=n, bar_phase=0.5, smooth_factor=factor, **shape_params(name))
+    averaging = shape_of(name)[1] == 0
     up = G.Batch(p, 1, G.OP_FFT)            # the transform with the texel upload
     passes = G.Batch(p, 1, mask)            # gravity / average passes on the reference's upload texels (planar rows in)
     bb = G.Batch(p, 1, G.OP_FFT | G.OP_BARS)
@@ -352,14 +417,20 @@ def test_device_gl_passes_tie_aware(glvlib, name, n, F, win):
                 slo, shi = smooth_bounds(lo.astype(np.uint16), hi.astype(np.uint16), n, factor)
                 bad = (got_sm[ch] < slo) | (got_sm[ch] > shi)
                 assert not bad.any(), ("end to end", f, ch, int(bad.sum()), np.flatnonzero(bad)[:4])
-                # ... and the pass itself is exact on the device's own `av`: the integer weighted mean
-                assert (got_sm[ch] == Oracle.bars_int(got_av[ch], n, factor, 0.5)[0]).all(), ("integer pass", f, ch)
+                # ... and the pass itself is exact on the device's own `av`: the integer weighted mean (maximum / hybrid: the shader's float loop)
+                want = Oracle.bars_int(got_av[ch], n, factor, 0.5)[0] if averaging else oracle_smooth_texels(got_av[ch], n, factor, name)
+                assert (got_sm[ch] == want).all(), ("the pass on the device's own av", f, ch)
     for b in (up, passes, bb, full, chain): b.close()
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("name,n,F,win", [("n1024_F5w", 1024, 5, True), ("n1024_F3w", 1024, 3, True), ("n4096_F5w", 4096, 5, True)] + FACTOR_CASES)
+@pytest.mark.parametrize("name,n,F,win", [("n1024_F5w", 1024, 5, True), ("n1024_F3w", 1024, 3, True), ("n4096_F5w", 4096, 5, True)] + FACTOR_CASES + SHAPE_CASES)
 def test_patched_reference_over_llvmpipe_samples_the_unpatched_texture(glvlib, tmp_path, name, n, F, win):
+    with shape_ctx(name):
+        _patched_reference_over_llvmpipe(glvlib, tmp_path, name, n, F, win)
+
+
+def _patched_reference_over_llvmpipe(glvlib, tmp_path, name, n, F, win):
     """VERDICT r4 item 2 / r5 item 1, over a real GL: the reference's rd_new / rd_update WITH integration/render_hip.patch
     (oracle/_ref/libglvglref_hip.so: the same harness, the patched render.c, the product library) run over Mesa llvmpipe with the shipped
     shaders, fed the frames the committed goldens were recorded with by the UNPATCHED reference -- the `#request setsmoothfactor` cases
@@ -386,8 +457,9 @@ def test_patched_reference_over_llvmpipe_samples_the_unpatched_texture(glvlib, t
     for on_hip in (1, 0):
         # in a child process: rd_new prints deprecation warnings and glava_abort()s on errors
         code = ("import sys, numpy as np, tempfile; sys.path.insert(0, %r); import make_gl_golden as M; pcm = np.load(%r); "
-                "out, v, r = M.run_case(%d, %d, %r, pcm, tempfile.mkdtemp(), so=%r, hip=(%d, 0), factor=%r); np.save(%r, out)"
-                % (os.path.join(ROOT, "tests", "golden"), str(tmp_path / "pcm.npy"), n, F, bool(win), so, on_hip, request, str(tmp_path / "t.npy")))
+                "out, v, r = M.run_case(%d, %d, %r, pcm, tempfile.mkdtemp(), so=%r, hip=(%d, 0), factor=%r, defines=%r); np.save(%r, out)"
+                % (os.path.join(ROOT, "tests", "golden"), str(tmp_path / "pcm.npy"), n, F, bool(win), so, on_hip, request, SHAPES[name][0] if name in SHAPES else None,
+                   str(tmp_path / "t.npy")))
         env = {k: v for k, v in os.environ.items() if k != "GLAVA_HIP_SMOOTH_FACTOR"}
         subprocess.run([sys.executable, "-c", code], check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, env=dict(env, GLV_SHADERS=shaders))
         got = np.load(str(tmp_path / "t.npy"))
@@ -404,7 +476,7 @@ def test_patched_reference_over_llvmpipe_samples_the_unpatched_texture(glvlib, t
                 final = got[f, ch, UP].astype(np.int64)                         # on the MI355X the bind's own texture holds the result
                 bad = (final < slo) | (final > shi)
                 assert not bad.any(), (name, f, ch, int(bad.sum()), np.flatnonzero(bad)[:4])
-                if request is not None:                                         # (the unpatched run's texture lies in the range a GLSL log() opens around it)
+                if request is not None or name in SHAPES:                       # (the unpatched run's texture lies in the range a GLSL log() opens around it)
                     slo, shi = smooth_bounds(lo.astype(np.uint16), hi.astype(np.uint16), n, factor, LOG_ABS)
                 assert ((slo <= tex[f, ch, SM]) & (tex[f, ch, SM] <= shi)).all()
                 equal += int((final == tex[f, ch, SM]).sum()); total += n

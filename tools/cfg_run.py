@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """One configuration, warmed up and launched back to back, for rocprofv3 (tools/profile_cmd.sh):
-    cfg_run.py configs2 | configs2_live | chain | n1024bars | gl_default | gl_bars | gl_bars_live | gl_sm | gl_sm64 | gl_sm64_live | ring  [calls]
+    cfg_run.py configs2 | configs2_live | chain | n1024bars | gl_default | gl_bars | gl_bars_live | gl_sm | gl_sm64 | gl_sm64_live | gl_sm64[_live]_maximum | gl_sm64_hybrid | gl_sm64[_live]_circular | ring  [calls]
 0.3 s of spin-up launches first (the first dozens of launches after idle run ~20 % slower), then `calls` launches (default 150):
 the kernel-trace average then describes the warm kernel (the r03 summaries averaged 6 cold calls)."""
 import os, sys, time
@@ -39,6 +39,11 @@ elif which == "gl_sm64":      # the shipped chain at the batch of bench.py's gl_
 elif which == "gl_sm64_live":  # ... with the state kept only where the pass samples (GLV_OP_BARS_ONLY)
     n, streams, ops, bars = 4096, 65536, G.OP_FFT | G.OP_GRAVITY | G.OP_AVERAGE | G.OP_BARS | G.OP_R16, 4096
     kw, dt, mask = dict(avg_window_kind=1, gl_storage=1, bar_phase=0.5), torch.int16, G.OP_BARS | G.OP_BARS_ONLY
+elif which in ("gl_sm64_maximum", "gl_sm64_hybrid", "gl_sm64_circular", "gl_sm64_live_maximum", "gl_sm64_live_circular"):
+    # the shipped chain under a user's smoothing shape (ABI 7): SAMPLE_MODE maximum / hybrid -> glv_bars_mode_kernel; ROUND_FORMULA circular -> other tap tables, same kernels
+    n, streams, ops, bars = 4096, 65536, G.OP_FFT | G.OP_GRAVITY | G.OP_AVERAGE | G.OP_BARS | G.OP_R16, 4096
+    shape = dict(sample_mode=G.SAMPLE_MAXIMUM) if "maximum" in which else dict(sample_mode=G.SAMPLE_HYBRID) if "hybrid" in which else dict(round_formula=G.ROUND_CIRCULAR)
+    kw, dt, mask = dict(avg_window_kind=1, gl_storage=1, bar_phase=0.5, **shape), torch.int16, G.OP_BARS | (G.OP_BARS_ONLY if "_live" in which else 0)
 elif which == "ring":
     n, streams, ops, bars = 4096, 65536, G.OP_FFT, 0
     mask = G.OP_RING_S16

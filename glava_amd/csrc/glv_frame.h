@@ -30,7 +30,8 @@ enum : uint32_t { OP_FFT = 1u, OP_GRAVITY = 2u, OP_AVERAGE = 4u, OP_RAW = 8u, OP
 // one output bar of GLV_OP_BARS: taps are consecutive bins [first_bin, first_bin + count) with weights
 // tap_w[tap_offset ...]; weight_sum = float sum of the weights in tap order (smooth.glsl:31-36)
 struct BarDesc { uint32_t first_bin, count, tap_offset; float weight_sum; };
-struct BarModeBlock { uint32_t w_off, maxcount; };      // bars [64 b, 64 b + 64) of glv_bars_mode_kernel: where their [tap][lane] weights start, taps of the longest
+struct BarModeBlock { uint32_t w_off, maxcount; };      // bars [64 b, 64 b + 64) of glv_bars_mode_kernel: where their [tap][lane] weights start, taps of the longest (rounded up to kBarModeUnroll)
+constexpr uint32_t kBarModeUnroll = 4;
 // One work item of GLV_OP_BARS: a chunk of bar_chunk_of(n) = 16 / 32 / 64 consecutive taps of one bar, taken by one group of
 // bar_lanes_of(n) = 2 / 4 / 8 lanes.  Everything a step needs, ready to use (the loop is instruction-bound): w_byte = byte offset
 // of the chunk's weights in tap_w (zero-padded by make_bar_taps; an all-zero block for padding items, which

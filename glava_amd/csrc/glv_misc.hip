@@ -600,7 +600,7 @@ __global__ void __launch_bounds__(256) glv_bars_seq_kernel(const float* __restri
 
 // SAMPLE_MODE maximum / hybrid (shaders/glava/util/smooth.glsl:41-59; glv_params.sample_mode has the contract, the tests' CPU checker restates it
 // as glvo_bars_mode_at): a maximum is not a matrix product and the hybrid's average is the shader's own chain of float additions, so a bar is ONE lane
-// walking its taps in bin order -- v = x * w (rounded), vmax = max(vmax, v), avg = avg + v -- for RR rows at a time (RR independent chains per lane).
+// walking its taps in bin order -- v = x * w (rounded), vmax = max(vmax, v), avg = avg + v -- for RR rows at a time (RR = 8 / 4 / 1 independent chains per lane).
 // A workgroup parks the bins the bars sample of its RR rows in LDS, clamped to [0, 1] (NaN -> 0) like the texels the shader fetches (LDS = false: rows
 // too long for that are read through L1); wave w then takes the 64-bar blocks w, w + 4, ...: lane l of a block is bar 64 blk + l, its weights come
 // block-transposed (glv_tables.h make_bar_mode_blocks: [tap][lane], one coalesced 256-byte load per tap) and padded with +0 up to the block's longest
@@ -610,16 +610,16 @@ template <int MODE, int RR, bool LDS>
 __global__ void __launch_bounds__(256) glv_bars_mode_kernel(const float* __restrict__ spec, void* __restrict__ bars_out, size_t nrows, uint32_t n, uint32_t bars,
                                                            const BarDesc* __restrict__ desc, const BarModeBlock* __restrict__ blocks, uint32_t nblocks,
                                                            const float* __restrict__ mw, uint32_t bins, float hyb, float one_minus_hyb, int r16) {
-    extern __shared__ float glv_mode_rows[];                                      // [RR][bins]
+    extern __shared__ __attribute__((aligned(16))) float glv_mode_rows[];        // [bins][RR]: a tap's RR rows are one 16-byte read per four rows
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     auto clamp01 = [](float x) { return x > 0.0f ? (x < 1.0f ? x : 1.0f) : 0.0f; };   // NaN -> 0
     for (size_t row0 = (size_t) blockIdx.x * RR; row0 < nrows; row0 += (size_t) gridDim.x * RR) {
         if constexpr (LDS) {
             __syncthreads();                                                      // the previous rows have been read
             for (uint32_t i = threadIdx.x; i < (uint32_t) RR * bins; i += 256u) {
-                const uint32_t r = i / bins, bin = i - r * bins;
+                const uint32_t r = i / bins, bin = i - r * bins;                  // (coalesced row reads; the transposing writes are the small side)
                 const size_t row = row0 + r < nrows ? row0 + r : nrows - 1;
-                glv_mode_rows[i] = clamp01(spec[row * (size_t) n + (bin < n ? bin : n - 1u)]);
+                glv_mode_rows[bin * (uint32_t) RR + r] = clamp01(spec[row * (size_t) n + bin]);
             }
             __syncthreads();
         }
@@ -631,18 +631,37 @@ __global__ void __launch_bounds__(256) glv_bars_mode_kernel(const float* __restr
             float vmax[RR], avg[RR];
 #pragma unroll
             for (int r = 0; r < RR; ++r) { vmax[r] = 0.0f; avg[r] = 0.0f; }
-            for (uint32_t j = 0; j < B.maxcount; ++j) {
-                const float w = wp[(size_t) j * 64u];
-                uint32_t bin = d.first_bin + j;
-                bin = bin < bins ? bin : bins - 1u;                               // (past the bar's own taps: weight +0)
+            // the taps in groups of JU: the group's weights are requested together (one L2 round trip per group instead of per tap; the host pads a
+            // block's weights with +0 to a multiple of JU taps)
+            constexpr uint32_t JU = kBarModeUnroll;
+            for (uint32_t j0 = 0; j0 < B.maxcount; j0 += JU) {
+                float w[JU];
 #pragma unroll
-                for (int r = 0; r < RR; ++r) {
-                    float x;
-                    if constexpr (LDS) x = glv_mode_rows[(uint32_t) r * bins + bin];
-                    else x = clamp01(spec[(row0 + r < nrows ? row0 + r : nrows - 1) * (size_t) n + bin]);
-                    const float v = __fmul_rn(x, w);
-                    vmax[r] = vmax[r] < v ? v : vmax[r];                          // smooth.glsl:48-49 / :56-57
-                    if constexpr (MODE == 2) avg[r] = __fadd_rn(avg[r], v);
+                for (uint32_t u = 0; u < JU; ++u) w[u] = wp[(size_t) (j0 + u) * 64u];
+#pragma unroll
+                for (uint32_t u = 0; u < JU; ++u) {
+                    uint32_t bin = d.first_bin + j0 + u;
+                    bin = bin < bins ? bin : bins - 1u;                           // (past the bar's own taps: weight +0)
+                    float x[RR];
+                    if constexpr (LDS && RR % 4 == 0) {
+#pragma unroll
+                        for (int q = 0; q < RR / 4; ++q) {
+                            const float4 t = *reinterpret_cast<const float4*>(&glv_mode_rows[bin * (uint32_t) RR + 4u * (uint32_t) q]);
+                            x[4 * q] = t.x; x[4 * q + 1] = t.y; x[4 * q + 2] = t.z; x[4 * q + 3] = t.w;
+                        }
+                    } else if constexpr (LDS) {
+#pragma unroll
+                        for (int r = 0; r < RR; ++r) x[r] = glv_mode_rows[bin * (uint32_t) RR + (uint32_t) r];
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < RR; ++r) x[r] = clamp01(spec[(row0 + r < nrows ? row0 + r : nrows - 1) * (size_t) n + bin]);
+                    }
+#pragma unroll
+                    for (int r = 0; r < RR; ++r) {
+                        const float v = __fmul_rn(x[r], w[u]);
+                        vmax[r] = vmax[r] < v ? v : vmax[r];                      // smooth.glsl:48-49 / :56-57
+                        if constexpr (MODE == 2) avg[r] = __fadd_rn(avg[r], v);
+                    }
                 }
             }
             if (k < bars) {
@@ -664,12 +683,13 @@ static hipError_t launch_bars_mode(const float* spec, void* bars_out, size_t nro
     const uint32_t bins = rt.mode_bins;
     const float h = rt.hybrid_weight, omh = 1.0f - rt.hybrid_weight;
     auto grid_of = [&](int rr) { const size_t g = (nrows + (size_t) rr - 1) / (size_t) rr; return dim3((unsigned) (g < 256u * 8u ? (g ? g : 1) : 256u * 8u)); };
-    if ((size_t) bins * 16u <= 48u * 1024u)
-        hipLaunchKernelGGL((glv_bars_mode_kernel<MODE, 4, true>), grid_of(4), dim3(256), (size_t) bins * 16u, st, spec, bars_out, nrows, n, bars, desc, rt.mblocks, rt.nmblocks, rt.mw, bins, h, omh, r16);
-    else if ((size_t) bins * 4u <= 64u * 1024u)
-        hipLaunchKernelGGL((glv_bars_mode_kernel<MODE, 1, true>), grid_of(1), dim3(256), (size_t) bins * 4u, st, spec, bars_out, nrows, n, bars, desc, rt.mblocks, rt.nmblocks, rt.mw, bins, h, omh, r16);
-    else
-        hipLaunchKernelGGL((glv_bars_mode_kernel<MODE, 4, false>), grid_of(4), dim3(256), 0, st, spec, bars_out, nrows, n, bars, desc, rt.mblocks, rt.nmblocks, rt.mw, bins, h, omh, r16);
+#define GLV_MODE_LAUNCH(RR, LDSF, BYTES) hipLaunchKernelGGL((glv_bars_mode_kernel<MODE, RR, LDSF>), grid_of(RR), dim3(256), BYTES, st, spec, bars_out, nrows, n, bars, desc, rt.mblocks, rt.nmblocks, rt.mw, bins, h, omh, r16)
+    // rows per workgroup by what their sampled bins take of the 64 KiB a launch may ask for without an attribute: 8 (n <= 4096 as shipped), 4, 1; else through L1
+    if ((size_t) bins * 32u <= 64u * 1024u && nrows >= 8) GLV_MODE_LAUNCH(8, true, (size_t) bins * 32u);
+    else if ((size_t) bins * 16u <= 64u * 1024u) GLV_MODE_LAUNCH(4, true, (size_t) bins * 16u);
+    else if ((size_t) bins * 4u <= 64u * 1024u) GLV_MODE_LAUNCH(1, true, (size_t) bins * 4u);
+    else GLV_MODE_LAUNCH(4, false, 0);
+#undef GLV_MODE_LAUNCH
     return hipGetLastError();
 }
 

@@ -161,6 +161,7 @@ inline void make_bar_mode_blocks(std::vector<BarModeBlock>& blocks, std::vector<
     for (uint32_t k0 = 0; k0 < bars; k0 += 64u) {
         BarModeBlock b{(uint32_t) mw.size(), 0u};
         for (uint32_t k = k0; k < k0 + 64u && k < bars; ++k) b.maxcount = desc[k].count > b.maxcount ? desc[k].count : b.maxcount;
+        b.maxcount = (b.maxcount + kBarModeUnroll - 1u) / kBarModeUnroll * kBarModeUnroll;      // the kernel walks whole groups of taps
         mw.resize(mw.size() + (size_t) b.maxcount * 64u, 0.0f);
         for (uint32_t k = k0; k < k0 + 64u && k < bars; ++k)
             for (uint32_t j = 0; j < desc[k].count; ++j) mw[b.w_off + (size_t) j * 64u + (k - k0)] = tap_w[desc[k].tap_offset + j];

@@ -296,6 +296,28 @@ def extra_configs(G, torch, device, a, peak_gbs):
     gl["sm_out_live"]["live_bins"] = b5.live_bins()
     gl["sm_out_live"]["frac_of_28N"] = 28 * n * s / (gl["sm_out_live"]["avg_kernel_ms"] * 1e-3) / 1e9 / peak_gbs
     b5.close(); del qs
+    # ... and what a FUSED form (the pass as a phase of the transform's persistent workgroups) could at most buy, measured instead of
+    # estimated: two batches of half the streams on two HIP streams, free-running, each transform held to ONE persistent workgroup per CU
+    # (glv_batch_set_grid) so that a pass workgroup of the other half RESIDES beside it (222 + 235 registers, two waves per SIMD) -- the co-residence a fused
+    # kernel would arrange by hand.  Wall clock over the same K updates of all the streams; caller-side pipelining, not the default entry.
+    cus = torch.cuda.get_device_properties(device).multi_processor_count
+    for key, extra in (("sm_out", 0), ("sm_out_live", G.OP_BARS_ONLY)):
+        try:
+            half = s // 2
+            qs = torch.empty((s, 2, n), dtype=torch.int16, device="cuda")
+            hb = [G.Batch(psm, half, G.OP_GRAVITY | G.OP_AVERAGE | G.OP_BARS | extra, device=device) for _ in range(2)]
+            hs = [torch.cuda.Stream(device=device) for _ in range(2)]
+            for x in hb: x.set_grid(cus)
+            def two_halves():
+                for i in range(2): hb[i].process_s16(pcm[i * half:(i + 1) * half], qs[i * half:(i + 1) * half], smops, hs[i].cuda_stream)
+            dt, _ = run(None, two_halves)
+            gl[key]["two_half_batches"] = {"note": f"the same {s} streams as two batches of {half} on two HIP streams, free-running, each transform on {cus} persistent workgroups (one per CU): the pass "
+                                                   f"of one half resides beside the transform of the other -- the measured bound of what fusing the two launches could buy; wall clock",
+                                           "value": s / dt, "unit": "frames/s", "ms_per_step": dt * 1e3, "vs_one_batch": gl[key]["ms_per_step"] / (dt * 1e3)}
+            for x in hb: x.close()
+            del qs
+        except Exception as ex:                                   # never fails the bench line
+            gl[key]["two_half_batches"] = {"error": str(ex)}
     s3 = max(s // 4, 1)
     # the pre-smoothing kernel by itself on rows already in HBM: its roofline is the f32 matrix rate (157.3 TFLOP/s dense at nominal
     # clock, MI355X_MICROARCH.md), counted on the USEFUL multiply-adds (smooth_audio()'s own taps; the tiles' padding is not counted)

@@ -42,12 +42,35 @@ for parts in (2, 4):
     print(f"sm chain N={n} x {streams} streams: one batch, one stream {ms1:.4f} ms = {streams / ms1 / 1e3:.2f} M frames/s; {parts} batches on {parts} streams {ms:.4f} ms = {streams / ms / 1e3:.2f} M frames/s")
     for b in bs: b.close()
 
+# Round 6: can the pass of one batch RESIDE beside the transform of the other?  Both kernels fill the chip when launched alone (two workgroups per CU each:
+# 222 / 235 registers), so two streams serialise them in practice.  With the transform held to ONE persistent workgroup per CU (glv_batch_set_grid) a pass
+# workgroup fits beside it -- what a fused kernel with the pass as a phase would amount to.  `live`: the same with GLV_OP_BARS_ONLY.
+for live in (0, 1):
+    m = mask | (G.OP_BARS_ONLY if live else 0)
+    one = G.Batch(p, streams, m)
+    base = timed(lambda: one.process_s16(pcm, out, ops))
+    one.close()
+    sub = streams // 2
+    for grid in (0, 256, 384, 512):
+        bs = [G.Batch(p, sub, m) for _ in range(2)]
+        for b in bs: b.set_grid(grid)
+        sts = [torch.cuda.Stream() for _ in range(2)]
+
+        def split2():
+            for i, (b, st) in enumerate(zip(bs, sts)):
+                b.process_s16(pcm[i * sub:(i + 1) * sub], out[i * sub:(i + 1) * sub], ops, st.cuda_stream)
+        ms = timed(split2)
+        print(f"sm chain{' (BARS_ONLY)' if live else ''} N={n} x {streams} streams: one batch {base:.4f} ms; two half batches on two streams, transform on {grid or 'its default'} workgroups "
+              f"(last grid {bs[0].last_grid()}): {ms:.4f} ms = {streams / ms / 1e3:.2f} M frames/s ({(ms / base - 1) * 100:+.1f} %)")
+        for b in bs: b.close()
+
 # The same with the semantics ONE library call would have to keep: everything forked from and joined back into the caller's
 # stream inside each call (chunk i's chain on internal stream i % 2), so that nothing of call k is in flight when call k + 1 starts.
 main = torch.cuda.current_stream()
-for parts in (2, 4, 8):
+for parts, grid, live in [(2, 0, 0), (4, 0, 0), (8, 0, 0), (2, 256, 0), (4, 256, 0), (8, 256, 0), (4, 256, 1), (8, 256, 1), (4, 0, 1)]:
     sub = streams // parts
-    bs = [G.Batch(p, sub, mask) for _ in range(parts)]
+    bs = [G.Batch(p, sub, mask | (G.OP_BARS_ONLY if live else 0)) for _ in range(parts)]
+    for b in bs: b.set_grid(grid)
     sts = [torch.cuda.Stream() for _ in range(2)]
     ev_in = torch.cuda.Event(); ev_out = [torch.cuda.Event() for _ in range(2)]
 
@@ -59,5 +82,5 @@ for parts in (2, 4, 8):
         for st, ev in zip(sts, ev_out):
             ev.record(st); main.wait_event(ev)
     ms = timed(joined)
-    print(f"sm chain N={n} x {streams} streams: forked and joined inside every call, {parts} chunks on 2 streams {ms:.4f} ms = {streams / ms / 1e3:.2f} M frames/s (one batch {ms1:.4f})")
+    print(f"sm chain{' (BARS_ONLY)' if live else ''} N={n} x {streams} streams: forked and joined inside every call, {parts} chunks on 2 streams, transform on {grid or 'its default'} workgroups: {ms:.4f} ms = {streams / ms / 1e3:.2f} M frames/s (one batch {ms1:.4f} / BARS_ONLY above)")
     for b in bs: b.close()

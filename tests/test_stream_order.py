@@ -93,7 +93,7 @@ def _bits_equal(a, b):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("case", ["configs1", "chain_F5", "fused_bars", "gl_default", "gl_default_sm", "gravity_out_is_state", "unfused_bars"])
+@pytest.mark.parametrize("case", ["configs1", "chain_F5", "fused_bars", "gl_default", "gl_default_sm", "gravity_out_is_state", "unfused_bars", "gl_default_sm_hybrid", "bars_maximum_live"])
 def test_first_process_call_can_be_captured_and_replayed(glvlib, case):
     """capture the FIRST call(s) after glv_batch_create into a hipGraph, replay, compare with an eagerly driven twin batch"""
     import torch
@@ -111,6 +111,12 @@ def test_first_process_call_can_be_captured_and_replayed(glvlib, case):
         # + the pre-smoothing pass (two launches; the matrix-core kernel with its > 64 KiB LDS opt-in set at creation)
         "gl_default_sm": dict(p=G.Params(n=n, avg_frames=F, avg_window_kind=1, gl_storage=1, bars=n, bar_phase=0.5), mask=G.OP_GRAVITY | G.OP_AVERAGE | G.OP_BARS,
                               ops=G.OP_FFT | G.OP_GRAVITY | G.OP_AVERAGE | G.OP_BARS | G.OP_R16, dt=torch.int16, w=n, per_graph=F, streams=128),
+        # ... under a user's SAMPLE_MODE (ABI 7): glv_bars_mode_kernel behind the transform, its rows in dynamic LDS below the 64 KiB a launch may ask for
+        "gl_default_sm_hybrid": dict(p=G.Params(n=n, avg_frames=F, avg_window_kind=1, gl_storage=1, bars=n, bar_phase=0.5, sample_mode=G.SAMPLE_HYBRID, round_formula=G.ROUND_CIRCULAR),
+                                     mask=G.OP_GRAVITY | G.OP_AVERAGE | G.OP_BARS, ops=G.OP_FFT | G.OP_GRAVITY | G.OP_AVERAGE | G.OP_BARS | G.OP_R16, dt=torch.int16, w=n, per_graph=F),
+        "bars_maximum_live": dict(p=G.Params(n=n, avg_frames=F, avg_window_kind=1, gl_storage=1, bars=n, bar_phase=0.5, sample_mode=G.SAMPLE_MAXIMUM),
+                                  mask=G.OP_GRAVITY | G.OP_AVERAGE | G.OP_BARS | G.OP_BARS_ONLY, ops=G.OP_FFT | G.OP_GRAVITY | G.OP_AVERAGE | G.OP_BARS | G.OP_R16, dt=torch.int16, w=n,
+                                  per_graph=F),
         "gravity_out_is_state": dict(p=G.Params(n=n), mask=G.OP_GRAVITY, ops=G.OP_FFT | G.OP_GRAVITY | G.OP_OUTPUT_IS_STATE,
                                      dt=torch.float32, w=n, per_graph=1),
         "unfused_bars": dict(p=G.Params(n=512, avg_frames=F), mask=G.OP_GRAVITY | G.OP_AVERAGE | G.OP_BARS,

@@ -593,3 +593,40 @@ def test_bars_only_batch_refuses_parameters_that_need_state_it_did_not_keep(glvl
     assert live.live_bins() == 0
     for u in range(200, 200 + F + 1): step(u)
     live.close(); full.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", ["shipped_pipeline_64k", "configs2_8k"])
+def test_bars_only_at_baseline_sizes_is_the_full_chain(glvlib, case):
+    """BASELINE.json's full sizes through a size-independent property: at 65 536 streams of N = 4096 (configs[1]'s batch, GLava's shipped pipeline -> `sm`
+    texels) and at 8 192 streams of N = 16384 (configs[2]: gravity + 80 radial bars) the GLV_OP_BARS_ONLY batch -- live kernel classes 7 / 8, the persistent
+    workgroups' frame walk at full occupancy, the row block tails of the last workgroups -- gives the full chain's output bit for bit, update after update;
+    a subset of streams is also checked against the oracle elsewhere (tests/test_gpu_parity.py), so equality here carries that to every stream.  Every row is
+    compared on the device; a 64-bit checksum of checksums of the two outputs is compared as well (one number per update for the log)."""
+    import torch
+    G = glvlib
+    if case == "shipped_pipeline_64k":
+        n, streams, F, updates = 4096, 65536, 5, 6
+        kw = dict(n=n, avg_frames=F, avg_window_kind=1, gl_storage=1, bars=n, bar_phase=0.5)
+        mask, ops, dt, width = G.OP_GRAVITY | G.OP_AVERAGE | G.OP_BARS, G.OP_FFT | G.OP_GRAVITY | G.OP_AVERAGE | G.OP_BARS | G.OP_R16, torch.int16, n
+    else:
+        n, streams, F, updates = 16384, 8192, 1, 4
+        kw = dict(n=n, bars=80)
+        mask, ops, dt, width = G.OP_GRAVITY | G.OP_BARS, G.OP_FFT | G.OP_GRAVITY | G.OP_BARS, torch.float32, 80
+    full = G.Batch(G.Params(**kw), streams, mask)
+    live = G.Batch(G.Params(**kw), streams, mask | G.OP_BARS_ONLY)
+    assert live.live_bins() > 0 and full.live_bins() == 0
+    o_f = torch.zeros((streams * 2, width), dtype=dt, device="cuda"); o_l = torch.ones_like(o_f)
+    gen = torch.Generator(device="cuda"); gen.manual_seed(4242)
+    weights = torch.arange(1, streams * 2 + 1, dtype=torch.int64, device="cuda")
+    for u in range(updates):
+        pcm = torch.randint(-32768, 32768, (streams, n, 2), dtype=torch.int16, device="cuda", generator=gen) // (1, 16, 4, 64)[u % 4]
+        if u == 2: pcm.zero_()
+        full.process_s16(pcm, o_f, ops); live.process_s16(pcm, o_l, ops)
+        a = o_f.view(torch.int32) if dt == torch.float32 else o_f
+        b = o_l.view(torch.int32) if dt == torch.float32 else o_l
+        assert torch.equal(a, b), (case, u, int((a != b).sum()))
+        rows_f = (a.to(torch.int64) & 0xffffffff).sum(dim=1); rows_l = (b.to(torch.int64) & 0xffffffff).sum(dim=1)      # a checksum per row, then one of those
+        assert int((rows_f * weights).sum()) == int((rows_l * weights).sum())
+        assert int(rows_f.max()) > 0 or u == 2
+    full.close(); live.close()

@@ -305,23 +305,22 @@ def extra_configs(G, torch, device, a, peak_gbs):
         try:
             half = s // 2
             qs = torch.empty((s, 2, n), dtype=torch.int16, device="cuda")
-            hs = [torch.cuda.Stream(device=device) for _ in range(2)]
-            trials, junk = [], []
-            for t in range(3):                                    # like every stateful chain (placement) a pair of batches keeps ONE speed for its life -- here 1.17 or 1.52 ms
-                hb = [G.Batch(psm, half, G.OP_GRAVITY | G.OP_AVERAGE | G.OP_BARS | extra, device=device) for _ in range(2)]   # (profiles/r06/overlap_grid.txt: also with a synchronize per
-                for x in hb: x.set_grid(cus)                      # call, so not a phase of the two streams).  Three fresh pairs, every value reported, the best one is `value`
-                def two_halves():
+            hb = [G.Batch(psm, half, G.OP_GRAVITY | G.OP_AVERAGE | G.OP_BARS | extra, device=device) for _ in range(2)]
+            for x in hb: x.set_grid(cus)
+            trials = []
+            for t in range(4):                                    # the runtime maps HIP streams onto a few hardware queues: two streams that share one never overlap
+                hs = [torch.cuda.Stream(device=device) for _ in range(2)]     # (profiles/r06/overlap_grid.txt: 1 pair in 10, 1.52 instead of 1.20 ms, the same batches) -- four
+                def two_halves():                                 # fresh pairs of streams, every value reported, the best one is `value`
                     for i in range(2): hb[i].process_s16(pcm[i * half:(i + 1) * half], qs[i * half:(i + 1) * half], smops, hs[i].cuda_stream)
                 dt, _ = run(None, two_halves)
                 trials.append(dt * 1e3)
-                for x in hb: x.close()
-                junk.append(torch.empty((t + 1) * 37 << 20, dtype=torch.uint8, device="cuda"))       # the next pair's state lands elsewhere
+            for x in hb: x.close()
             dt = min(trials) * 1e-3
             gl[key]["two_half_batches"] = {"note": f"the same {s} streams as two batches of {half} on two HIP streams, free-running, each transform on {cus} persistent workgroups (one per CU): the pass "
                                                    f"of one half resides beside the transform of the other -- the measured bound of what fusing the two launches could buy; wall clock; "
-                                                   f"best of three fresh pairs of batches (a pair keeps one of two speeds for its life, by where its state was allocated)",
+                                                   f"best of four fresh pairs of streams (two streams the runtime maps onto one hardware queue never overlap)",
                                            "value": s / dt, "unit": "frames/s", "ms_per_step": dt * 1e3, "ms_per_step_trials": trials, "vs_one_batch": gl[key]["ms_per_step"] / (dt * 1e3)}
-            del qs, junk
+            del qs
         except Exception as ex:                                   # never fails the bench line
             gl[key]["two_half_batches"] = {"error": str(ex)}
     s3 = max(s // 4, 1)

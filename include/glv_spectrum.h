@@ -96,8 +96,8 @@ enum {
     GLV_OP_BARS_ONLY = 1u << 13, /* glv_batch_create's ops_mask only (ABI 6), with GLV_OP_BARS: the caller promises that every stateful call on this
                                    batch asks for GLV_OP_BARS -- the bars are all that is ever looked at (GLava's shipped pipeline: the modules sample
                                    the pre-smoothed texture and nothing else, smooth.glsl:62; BASELINE configs[2]: the radial module's bars).
-                                   smooth_audio() samples bins below scale_audio(1) * n = 0.288 n plus half a window (SAMPLE_RANGE 0.9,
-                                   SAMPLE_SCALE 8), so what the reference's passes compute beyond that is dead: the chain then keeps its gravity
+                                   smooth_audio() samples bins below scale_audio(1) * n plus half a window (0.288 n with the shipped
+                                   SAMPLE_RANGE 0.9 / SAMPLE_SCALE 8; glv_params.sample_range / sample_scale), so what the reference's passes compute beyond that is dead: the chain then keeps its gravity
                                    store and ring, and computes magnitude / upload / gravity / average, only for a compile-time share of the row
                                    that covers the bins the bars sample (3/8 of it; glv_batch_live_bins tells whether the batch runs that way) --
                                    15 n instead of 28 n bytes per frame at n = 4096, F = 5 on GL_R16 state.  Live kernel classes exist for the

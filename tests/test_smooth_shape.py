@@ -236,3 +236,52 @@ def test_fused_bars_and_live_classes_follow_the_shape(glvlib):
         with pytest.raises(G.GlvError) as e:
             G.Batch(G.Params(n=1024, bars=80, **bad), 1, G.OP_FFT | G.OP_BARS)
         assert e.value.code == G.ERR_INVALID, bad
+
+
+@pytest.mark.gpu
+def test_shapes_over_random_parameters(glvlib):
+    """60 seeded draws of (n, bars, smooth_factor, bar_phase, rows, formula, mode, hybrid weight, scale, range): glv_batch_bars on float rows against the oracle
+    under the same shape, bit for bit -- every arithmetic the library has for bars (chunked chains below 256 bars, one chain per bar on the matrix cores or one
+    lane per bar above, the mode kernel with 8 / 4 / 1 rows per lane and through L1), ragged last blocks, bars that are not a multiple of 64, taps that reach
+    the row's last bins.  A shape the library refuses (positions past the row) must be refused with GLV_ERR_INVALID, not computed."""
+    import torch
+    G = glvlib
+    rng = np.random.default_rng(20260930)
+    done = refused = 0
+    for trial in range(60):
+        n = int(rng.choice([256, 512, 1024, 2048, 4096, 8192]))
+        bars = int(rng.choice([1, 7, 64, 65, 80, 200, 255, 256, 300, n // 2, n]))
+        bars = min(bars, n)
+        factor = float(rng.choice([0.005, 0.01, 0.025, 0.05, 0.1]))
+        phase = float(rng.choice([0.0, 0.5, 0.25]))
+        rows = int(rng.choice([2, 4, 6, 10, 34, 70]))
+        formula, mode = int(rng.integers(0, 3)), int(rng.integers(0, 3))
+        hw = float(rng.choice([0.0, 0.2, 0.65, 1.0]))
+        scale = float(rng.choice([0.0, 3.0, 5.0, 8.0, 12.0]))
+        rg = float(rng.choice([0.0, 0.5, 0.8, 0.9, 0.95, 0.99]))
+        shape = (formula, mode, hw, scale, rg)
+        p = G.Params(n=n, bars=bars, smooth_factor=factor, bar_phase=phase, round_formula=formula, sample_mode=mode, sample_hybrid_weight=hw, sample_scale=scale, sample_range=rg)
+        sc, r_ = (scale or 8.0), (rg or 0.9)
+        if -np.log(np.float32(1.0) - np.float32(r_)) / np.float32(sc) > 1.0:
+            with pytest.raises(G.GlvError) as e:
+                G.Batch(p, rows // 2, G.OP_FFT | G.OP_BARS)
+            assert e.value.code == G.ERR_INVALID
+            refused += 1
+            continue
+        try:
+            b = G.Batch(p, rows // 2, G.OP_FFT | G.OP_BARS)
+        except G.GlvError as e:                                  # a tap chunk past the row's end (large factors at the top of the range): refused, never computed
+            assert e.code == G.ERR_INVALID and "leave the row" in str(e), (trial, shape, str(e))
+            refused += 1
+            continue
+        spec = np.stack([tex_row(n, 5000 + 97 * trial + r) for r in range(rows)])
+        d_bars = torch.full((rows, bars), -1.0, dtype=torch.float32, device="cuda")
+        b.bars(torch.from_numpy(spec).cuda(), d_bars)
+        got = d_bars.cpu().numpy()
+        b.close()
+        for r in (0, rows - 1):
+            want = _oracle_bars(spec[r], bars, factor, phase, shape, chunked=True)
+            same = (got[r].view(np.uint32) == want.view(np.uint32)) | (np.isnan(got[r]) & np.isnan(want))
+            assert same.all(), (trial, n, bars, factor, phase, rows, shape, r, int((~same).sum()), np.flatnonzero(~same)[:4], got[r][~same][:3], want[~same][:3])
+        done += 1
+    assert done >= 40 and refused >= 1, (done, refused)

@@ -285,3 +285,36 @@ def test_shapes_over_random_parameters(glvlib):
             assert same.all(), (trial, n, bars, factor, phase, rows, shape, r, int((~same).sum()), np.flatnonzero(~same)[:4], got[r][~same][:3], want[~same][:3])
         done += 1
     assert done >= 40 and refused >= 1, (done, refused)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(0, 1, 0.0, 0.0, 0.0), (1, 2, 0.5, 6.0, 0.85)])
+@pytest.mark.parametrize("bars_only", [False, True])
+def test_gl_chain_with_the_modules_bars_under_maximum_and_hybrid(glvlib, shape, bars_only):
+    """the GL_R16 chain + the 80 bars of the bars / radial modules (fewer than 256 bars: fused into the transform for the averaging modes) under SAMPLE_MODE maximum /
+    hybrid: two launches, the shader's loop on the chain's own `av` texels as floats c / 65535, as GL_R16 texels and as floats"""
+    import torch
+    G = glvlib
+    n, F, streams, bars = 4096, 5, 11, 80
+    formula, mode, hw, scale, rng = shape
+    kw = dict(n=n, avg_frames=F, avg_window_kind=1, gl_storage=1, bars=bars, round_formula=formula, sample_mode=mode, sample_hybrid_weight=hw, sample_scale=scale, sample_range=rng)
+    ops = G.OP_FFT | G.OP_GRAVITY | G.OP_AVERAGE
+    av = G.Batch(G.Params(**kw), streams, G.OP_GRAVITY | G.OP_AVERAGE)
+    bt = G.Batch(G.Params(**kw), streams, G.OP_GRAVITY | G.OP_AVERAGE | G.OP_BARS | (G.OP_BARS_ONLY if bars_only else 0))
+    bf = G.Batch(G.Params(**kw), streams, G.OP_GRAVITY | G.OP_AVERAGE | G.OP_BARS)
+    o_av = torch.zeros((streams * 2, n), dtype=torch.int16, device="cuda")
+    o_t = torch.zeros((streams * 2, bars), dtype=torch.int16, device="cuda")
+    o_f = torch.zeros((streams * 2, bars), dtype=torch.float32, device="cuda")
+    for fr in range(F + 1):
+        d_pcm = torch.from_numpy((lcg_pcm_fast(9100 + fr, streams * 2 * n) // (2, 32)[fr % 2]).astype(np.int16)).cuda()
+        av.process_s16(d_pcm, o_av, ops | G.OP_R16)
+        bt.process_s16(d_pcm, o_t, ops | G.OP_BARS | G.OP_R16)
+        bf.process_s16(d_pcm, o_f, ops | G.OP_BARS)
+        assert bt.last_launches() == 2 and bf.last_launches() == 2
+    a = o_av.cpu().numpy().view(np.uint16); t = o_t.cpu().numpy().view(np.uint16); f = o_f.cpu().numpy()
+    for r in (0, 7, 2 * streams - 1):
+        want = _oracle_bars(a[r].astype(np.float32) / np.float32(65535), bars, 0.025, 0.0, shape)
+        assert (f[r].view(np.uint32) == want.view(np.uint32)).all(), (r, shape)
+        assert (t[r] == Oracle.texels_r16(want)).all(), (r, shape)
+    assert int(t.max()) > 1000
+    for b in (av, bt, bf): b.close()

@@ -39,6 +39,27 @@ def test_header_compiles_as_plain_c(tmp_path):
                     "-c", str(src), "-o", str(tmp_path / "t.o")], check=True)
 
 
+def test_python_mirror_of_glv_params_has_the_headers_layout(glvlib, tmp_path):
+    """glava_amd/spectrum.py CParams against the C struct: size and the offset of every field, from the header as a C compiler lays it out -- a field added to
+    one side only (ABI 7 appended five) would otherwise shift everything behind it silently"""
+    import subprocess
+    fields = [f[0] for f in glvlib.CParams._fields_]
+    src = tmp_path / "layout.c"
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "glv_spectrum.h"\nint main(void){ printf("%zu", sizeof(glv_params));\n'
+                   + "".join(f'printf(" %zu", offsetof(glv_params, {f}));\n' for f in fields) + "return 0; }\n")
+    subprocess.run(["gcc", "-std=c99", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(tmp_path / "layout")], check=True)
+    got = [int(x) for x in subprocess.run([str(tmp_path / "layout")], check=True, capture_output=True, text=True).stdout.split()]
+    assert got[0] == C.sizeof(glvlib.CParams), (got[0], C.sizeof(glvlib.CParams))
+    assert got[1:] == [getattr(glvlib.CParams, f).offset for f in fields]
+    assert fields[-5:] == ["round_formula", "sample_mode", "sample_hybrid_weight", "sample_scale", "sample_range"]
+    # every field of the header is mirrored: the header's struct has exactly these members
+    import re
+    body = re.search(r"typedef struct glv_params \{(.*?)\} glv_params;", open(os.path.join(ROOT, "include", "glv_spectrum.h")).read(), re.S).group(1)
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    members = re.findall(r"\b(?:uint32_t|float)\s+(\w+)\s*;", body)
+    assert members == fields, (members, fields)
+
+
 def test_defaults_match_shipped_config(glvlib):
     cp = glvlib.CParams()
     glvlib.lib().glv_params_default(C.byref(cp))
@@ -46,6 +67,8 @@ def test_defaults_match_shipped_config(glvlib):
     assert cp.fft_scale == np.float32(10.2) and cp.fft_cutoff == np.float32(0.3)
     assert cp.gravity_step == np.float32(4.2) and cp.ur == np.float32(22050 / 256)
     assert glvlib.lib().glv_abi_version() == 7
+    # the smoothing shape: all-zero == the shipped `#define`s (smooth_parameters.glsl:17-42)
+    assert (cp.round_formula, cp.sample_mode, cp.sample_hybrid_weight, cp.sample_scale, cp.sample_range) == (0, 0, 0.0, 0.0, 0.0)
 
 
 def test_argument_validation(glvlib):

@@ -1282,3 +1282,36 @@ def test_log_mode_0_chain_bit_exact_end_to_end(G, n, F, win):
             want = sos[u].frame(pcm[u * 2 * n:(u + 1) * 2 * n])
             assert (bits(got[2 * u:2 * u + 2]) == bits(want)).all(), (fr, u, int((bits(got[2 * u:2 * u + 2]) != bits(want)).sum()))
     b.close()
+
+
+def test_chain_over_random_parameters_bit_exact(G):
+    """24 seeded draws of every scalar knob the chain reads -- n, channels, fft_scale, fft_cutoff, gravity_step, ur, avg_frames, avg_window, the operator subset --
+    with the bit-faithful log: fft (-> gravity) (-> average) on s16 frames against the oracle (itself bit-equal to the compiled reference at every size,
+    tests/test_oracle.py), bit for bit over 2 F + 2 updates of loud, quiet and silent frames.  The parametrised tests above fix the shipped values; this walks
+    around them (tilt slopes that cross zero, gravity steps larger than the signal, one averaging frame, mono mix)."""
+    import torch
+    rng = np.random.default_rng(6060)
+    for trial in range(24):
+        n = int(rng.choice([256, 512, 1024, 2048, 4096, 8192, 16384]))
+        channels = int(rng.choice([2, 2, 1]))
+        F = int(rng.choice([1, 2, 3, 5, 8]))
+        win = bool(rng.integers(0, 2))
+        kw = dict(fft_scale=float(np.float32(rng.uniform(0.5, 30.0))), fft_cutoff=float(np.float32(rng.uniform(0.0, 0.95))),
+                  gravity_step=float(np.float32(rng.choice([0.0, 0.3, 4.2, 40.0]))), ur=float(np.float32(rng.uniform(20.0, 240.0))))
+        chain = int(rng.integers(0, 3))                          # 0: fft   1: fft + gravity   2: fft + gravity + average
+        mask = (G.OP_GRAVITY if chain >= 1 else 0) | (G.OP_AVERAGE if chain == 2 else 0)
+        ops = G.OP_FFT | mask
+        streams = 5 if n <= 4096 else 2
+        b = G.Batch(G.Params(n=n, channels=channels, avg_frames=F, avg_window=win, log_mode=0, **kw), streams, mask if mask else G.OP_FFT)
+        sos = [StreamOracle(n, channels=channels, avg_frames=F, avg_window=win, gravity=chain >= 1, average=chain == 2, **kw) for _ in range(streams)]
+        d_out = torch.empty((streams * 2, n), dtype=torch.float32, device="cuda")
+        for fr in range(2 * F + 2):
+            pcm = (lcg_pcm_fast(777 + 31 * trial + fr, streams * 2 * n) // (1, 64, 8)[fr % 3]).astype(np.int16)
+            if fr == 1: pcm[:] = 0
+            b.process_s16(torch.from_numpy(pcm).cuda(), d_out, ops)
+            got = d_out.cpu().numpy()
+            for u in range(streams):
+                want = sos[u].frame(pcm[u * 2 * n:(u + 1) * 2 * n])
+                diff = bits(got[2 * u:2 * u + 2]) != bits(want)
+                assert not diff.any(), (trial, n, channels, F, win, kw, chain, fr, u, int(diff.sum()), np.argwhere(diff)[:3].tolist())
+        b.close()

@@ -630,3 +630,39 @@ def test_bars_only_at_baseline_sizes_is_the_full_chain(glvlib, case):
         assert int((rows_f * weights).sum()) == int((rows_l * weights).sum())
         assert int(rows_f.max()) > 0 or u == 2
     full.close(); live.close()
+
+
+def test_fused_gl_chain_over_random_parameters_equals_the_oracle_model(glvlib):
+    """20 seeded draws of (n, F, window, gravity_step, ur, fft_scale, fft_cutoff, chain with or without the average pass) for the GL_R16 chain in one launch:
+    texels equal to the oracle's transform_fft + glvo_gl_chain_r16 model, update after update -- gravity steps for which the pass is NOT the integer step
+    (glv_tables.h gravity_r16_integer_step: float evaluation per texel) and steps larger than any texel among them"""
+    import torch
+    G = glvlib
+    rng = np.random.default_rng(4711)
+    for trial in range(20):
+        n = int(rng.choice([512, 1024, 2048, 4096, 8192]))
+        F = int(rng.choice([1, 2, 3, 5, 7]))
+        win = bool(rng.integers(0, 2))
+        gs = float(np.float32(rng.choice([0.0, 0.37, 4.2, 11.0, 90.0])))
+        ur = float(np.float32(rng.uniform(30.0, 200.0)))
+        sc, cut = float(np.float32(rng.uniform(2.0, 20.0))), float(np.float32(rng.uniform(0.0, 0.8)))
+        avg = bool(rng.integers(0, 4)) and True
+        streams = 3
+        mask = G.OP_GRAVITY | (G.OP_AVERAGE if avg else 0)
+        b = G.Batch(G.Params(n=n, avg_frames=F, avg_window=win, avg_window_kind=1, gl_storage=1, log_mode=0, gravity_step=gs, ur=ur, fft_scale=sc, fft_cutoff=cut), streams, mask)
+        d_q = torch.zeros((streams * 2, n), dtype=torch.int16, device="cuda")
+        store = np.zeros((streams * 2, n), np.float32); hist = np.zeros((streams * 2, F, n), np.float32)
+        heads = [C.c_size_t(0) for _ in range(streams * 2)]
+        for fr in range(F + 2):
+            pcm = (lcg_pcm_fast(6200 + 13 * trial + fr, streams * 2 * n) // (8, 128)[fr % 2]).astype(np.int16)
+            b.process_s16(torch.from_numpy(pcm).cuda(), d_q, G.OP_FFT | mask | G.OP_R16)
+            assert b.last_launches() == 1
+            gq = d_q.cpu().numpy().view(np.uint16)
+            for u in range(streams):
+                spec = StreamOracle(n, gravity=False, average=False, fft_scale=sc, fft_cutoff=cut).frame(pcm[u * 2 * n:(u + 1) * 2 * n])
+                for c in range(2):
+                    want = np.ascontiguousarray(spec[c])
+                    Oracle.lib().glvo_gl_chain_r16(want, store[2 * u + c], hist[2 * u + c], C.byref(heads[2 * u + c]), n, F, int(win), int(avg), gs, ur)
+                    bad = gq[2 * u + c] != Oracle.texels_r16(want)
+                    assert not bad.any(), (trial, n, F, win, gs, ur, sc, cut, avg, fr, u, c, int(bad.sum()), np.flatnonzero(bad)[:4])
+        b.close()

@@ -1156,6 +1156,8 @@ int glv_batch_destroy(glv_batch* b) {
     if (b->d_bar_wq) (void) hipFree(b->d_bar_wq);
     if (b->d_bar_fin) (void) hipFree(b->d_bar_fin);
     if (b->d_bar_irounds) (void) hipFree(b->d_bar_irounds);
+    if (b->d_bar_mblocks) (void) hipFree(b->d_bar_mblocks);
+    if (b->d_bar_mw) (void) hipFree(b->d_bar_mw);
     for (hipEvent_t e : b->ev) (void) hipEventDestroy(e);
     delete b;
     return GLV_OK;

@@ -407,3 +407,35 @@ def test_every_kernel_variant_gives_the_same_bits(G, n):
         b = G.Batch(G.Params(n=n), streams, G.OP_FFT | G.OP_BARS | G.OP_RING_S16)
         try: b.set_variant(nv)
         finally: b.close()
+
+
+def test_create_destroy_returns_every_byte(G):
+    """glv_batch_create / glv_batch_destroy over every family of tables and buffers the library can allocate -- float and GL_R16 state, rings, scratch rows, bar tables
+    of every arithmetic (chunked, f32 and i8 matrix-core tiles, the SAMPLE_MODE maximum / hybrid blocks), smooth bounds, placement tuning -- leaves the device's free
+    memory where it was (hipMemGetInfo through torch; 40 cycles each: a table leaked once per batch would show as 40 x its size)"""
+    import torch
+    torch.cuda.synchronize()
+    n, streams = 4096, 64
+    gl = dict(avg_window_kind=1, gl_storage=1)
+    cases = [
+        (G.Params(n=n), G.OP_GRAVITY | G.OP_AVERAGE | G.OP_BARS | G.OP_SMOOTH | G.OP_RING_S16 | G.OP_RING_F32),
+        (G.Params(n=n, bars=n, bar_phase=0.5, **gl), G.OP_GRAVITY | G.OP_AVERAGE | G.OP_BARS | G.OP_BARS_ONLY),
+        (G.Params(n=n, bars=n, bar_phase=0.5), G.OP_GRAVITY | G.OP_AVERAGE | G.OP_BARS | G.OP_R16),
+        (G.Params(n=n, bars=n, bar_phase=0.5, sample_mode=G.SAMPLE_MAXIMUM, **gl), G.OP_GRAVITY | G.OP_AVERAGE | G.OP_BARS),
+        (G.Params(n=n, bars=80, sample_mode=G.SAMPLE_HYBRID, round_formula=G.ROUND_LINEAR), G.OP_GRAVITY | G.OP_BARS),
+        (G.Params(n=16384, bars=80, gl_storage=2), G.OP_GRAVITY | G.OP_AVERAGE | G.OP_BARS),
+    ]
+    def cycle(count):
+        for p, mask in cases:
+            for _ in range(count):
+                b = G.Batch(p, streams, mask)
+                q = G.Params(**{**p.__dict__, "smooth_factor": 0.05})     # set_params rebuilds the bar tables in place
+                b.set_params(q)
+                b.close()
+    cycle(2)                                                        # (the runtime's own pools settle)
+    torch.cuda.synchronize()
+    free0, _ = torch.cuda.mem_get_info()
+    cycle(40)
+    torch.cuda.synchronize()
+    free1, _ = torch.cuda.mem_get_info()
+    assert free0 - free1 < (8 << 20), (free0, free1, free0 - free1)     # the smallest table here is > 200 KiB: 40 leaked copies would be > 8 MiB

@@ -89,7 +89,7 @@ def test_shim_reads_the_shape_from_the_processed_shader_text():
     def defs(**kw):
         return "".join(f"#ifdef {k}\n#undef {k}\n#endif\n#define {k} {v}\n" for k, v in kw.items())
     stock = defs(ROUND_FORMULA="sinusoidal", SAMPLE_MODE="average", SAMPLE_HYBRID_WEIGHT="0.65", SAMPLE_SCALE="8", SAMPLE_RANGE="0.9")
-    tail = "\n#define average 0\n#define maximum 1\n#define hybrid 2\nfloat scale_audio(float idx) { return -log((-(SAMPLE_RANGE) * idx) + 1) / (SAMPLE_SCALE); }\n"
+    tail = "\n#define average 0\n#define maximum 1\n#define hybrid 2\nfloat f(float x) { return x * (SAMPLE_RANGE) / (SAMPLE_SCALE); }\nvoid main() { }\n"      # (uses, not definitions)
     assert _scan(L, (stock + tail).encode()) == (1, 0, 0, 0.65, 8.0, 0.9)
     user = defs(ROUND_FORMULA="circular", SAMPLE_MODE="hybrid", SAMPLE_HYBRID_WEIGHT=".4 /* mine */", SAMPLE_SCALE="6.0f", SAMPLE_RANGE="(0.8) // narrower")
     assert _scan(L, (stock + user + tail).encode()) == (1, 1, 2, 0.4, 6.0, 0.8)               # the LAST definition is the one the compiler keeps

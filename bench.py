@@ -124,6 +124,42 @@ def measured_traffic(n: int, streams: int, ops: str):
     return None
 
 
+def live_traffic(a):
+    """2*FETCH_SIZE + WRITE_SIZE of the headline kernel collected IN THIS RUN: two SEPARATE `rocprofv3 --pmc` passes (one counter each, no tracing
+    domain beside them -- MI355X_MICROARCH.md's HBM recipe) over this same script reduced to its headline launches (--steps 2 --warmup 1, no configs), as child processes,
+    outside every timed region; mean over the dispatches of the headline kernel.  Returns (bytes per launch or None, detail dict).  Never fails the bench line: any
+    problem (no rocprofv3, a profiler already wrapped around this process, a timeout) returns None with the reason and the committed measurement is reported instead."""
+    import csv, glob, shutil, subprocess, tempfile
+    if any(k.startswith(("ROCPROF", "ROCP_", "ROCPROFILER")) for k in os.environ) or "rocprof" in os.environ.get("LD_PRELOAD", ""):
+        return None, {"skipped": "this process already runs under a rocprofiler tool"}
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return None, {"skipped": "rocprofv3 not found"}
+    child = [sys.executable, os.path.abspath(__file__), "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-alt", "--no-configs", "--sustained-s", "0",
+             "--no-live-traffic", "--streams", str(a.streams), "--n", str(a.n), "--ops", a.ops, "--log-mode", str(a.log_mode)]
+    tmp = tempfile.mkdtemp(prefix="glv_pmc_", dir="/tmp")
+    vals, counts = {}, {}
+    try:
+        for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+            d = os.path.join(tmp, ctr)
+            try:
+                r = subprocess.run([exe, "--pmc", ctr, "--output-format", "csv", "-d", d, "-o", "t", "--"] + child, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"),
+                                   stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=150)
+            except subprocess.TimeoutExpired:
+                return None, {"skipped": f"the {ctr} pass timed out"}
+            rows = []
+            for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+                for row in csv.DictReader(open(f)):
+                    if row.get("Counter_Name") == ctr and row.get("Kernel_Name", "").startswith("void glv::glv_frame_kernel<"):
+                        rows.append(float(row.get("Counter_Value", 0)))
+            if not rows:
+                return None, {"skipped": f"the {ctr} pass gave no rows for the headline kernel (rocprofv3 rc {r.returncode})"}
+            vals[ctr], counts[ctr] = sum(rows) / len(rows), len(rows)
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    return int(round((2 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024)), {"fetch_size_kb": vals["FETCH_SIZE"], "write_size_kb": vals["WRITE_SIZE"], "dispatches": counts}
+
+
 def streaming_ceiling(n: int, ops: str):
     """Second, honest denominator: what a do-nothing streaming kernel reaches on MI355X for
     this pass's read/write mix (tools/membench.hip, committed as profiles/stream_ceiling.json).  Only on file
@@ -442,6 +478,8 @@ def main() -> None:
     ap.add_argument("--grid", type=int, default=0, help="workgroups of the persistent kernel (0 = auto)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-alt", action="store_true", help="skip the secondary fast-log measurement")
+    ap.add_argument("--no-live-traffic", dest="live_traffic", action="store_false",
+                    help="do not collect roofline.traffic with rocprofv3 --pmc child passes (the committed profiles/hbm_traffic.json is reported instead)")
     ap.add_argument("--no-configs", action="store_true", help="skip the `configs` key (BASELINE configs[2], configs[4], N=8192 / 16384)")
     ap.add_argument("--configs-steps", type=int, default=20, help="timed steps per entry of the `configs` key (same spin-up as the headline)")
     ap.add_argument("--sustained-s", type=float, default=2.0, help="seconds of back-to-back headline launches behind the `sustained` key (0 = skip)")
@@ -653,6 +691,10 @@ def main() -> None:
     if rank == 0:
         total_frames = sum(s["frames"] for s in stats)
         value = total_frames / elapsed
+        traffic_now, traffic_detail = (None, {"skipped": "--no-live-traffic, or more than one rank"})
+        if a.live_traffic and world == 1:
+            torch.cuda.synchronize()
+            traffic_now, traffic_detail = live_traffic(a)
         alg_bytes = batch.algorithmic_bytes(ops)           # per launch (all streams of the rank)
         avg_kernel_s = (kernel_ms / max(launches, 1)) * 1e-3
         achieved = alg_bytes / avg_kernel_s / 1e9 if avg_kernel_s > 0 else 0.0
@@ -671,9 +713,13 @@ def main() -> None:
                        "collectives": (f"{backend} ({'RCCL over xGMI' if backend == 'nccl' else 'CPU rehearsal'}): barrier, all_reduce(MAX) of elapsed, "
                                        f"all_gather of one 32-byte stats record per rank; {world} rank(s)") if dist_on else None},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(n, streams, a.ops),
-                         "traffic_source": "profiles/hbm_traffic.json: 2*FETCH_SIZE + WRITE_SIZE of this kernel from separate rocprofv3 --pmc passes "
-                                           "(tools/profile.sh) of the same command on an MI355X -- a committed measurement, NOT collected in this run",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic_now if traffic_now is not None else measured_traffic(n, streams, a.ops),
+                         "traffic_source": ("collected in THIS run: 2*FETCH_SIZE + WRITE_SIZE (KiB, the guide's gfx950 wide-stream correction) of this kernel from two separate "
+                                            "rocprofv3 --pmc passes over this script's headline launches (child processes, outside the timed region), mean per dispatch")
+                                           if traffic_now is not None else
+                                           ("profiles/hbm_traffic.json: 2*FETCH_SIZE + WRITE_SIZE of this kernel from separate rocprofv3 --pmc passes "
+                                            "(tools/profile.sh) of the same command on an MI355X -- a committed measurement, NOT collected in this run"),
+                         "traffic_live": traffic_detail, "traffic_committed": measured_traffic(n, streams, a.ops),
                          "algorithmic_bytes_per_launch": alg_bytes, "avg_kernel_ms": avg_kernel_s * 1e3,
                          "kernel": batch.kernel_name()},
         }

@@ -260,3 +260,27 @@ def test_bench_two_ranks_with_real_kernels(glvlib, tmp_path):
         assert np.allclose(z["first_spectrum"], want, rtol=1e-5, atol=0.0), rank            # magnitudes (no gravity): purely relative
         pcms.append(pcm)
     assert not (pcms[0] == pcms[1]).all()                                      # the shards hold different streams
+
+
+@pytest.mark.gpu
+def test_bench_line_collects_its_hbm_traffic_in_the_same_run():
+    """`roofline.traffic` is collected by the bench run itself -- two separate `rocprofv3 --pmc` child passes (FETCH_SIZE, WRITE_SIZE) over the script's own
+    headline launches -- and must agree with the algorithmic bytes (the pass reads every PCM byte once and writes every spectrum byte once: 1.00x) and with the committed
+    measurement; with --no-live-traffic (what tools/profile.sh passes: a profiler is already wrapped around that run) the committed value is reported and says so."""
+    import json
+    import shutil
+    if not (shutil.which("rocprofv3") or os.path.exists("/opt/rocm/bin/rocprofv3")):
+        pytest.skip("no rocprofv3 on this box")
+    base = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--no-configs", "--no-cpu-baseline", "--no-alt", "--sustained-s", "0"]
+    env = {k: v for k, v in os.environ.items() if not k.startswith(("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_"))}
+    r = subprocess.run(base, capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    roof = json.loads(r.stdout.strip().splitlines()[-1])["roofline"]
+    assert "collected in THIS run" in roof["traffic_source"], roof["traffic_live"]
+    assert roof["traffic_live"]["dispatches"]["FETCH_SIZE"] >= 3 and roof["traffic_live"]["dispatches"]["WRITE_SIZE"] >= 3
+    assert 0.99 < roof["traffic"] / roof["algorithmic_bytes_per_launch"] < 1.02, roof
+    assert roof["traffic_committed"] is None or abs(roof["traffic"] / roof["traffic_committed"] - 1) < 0.01
+    r = subprocess.run(base + ["--no-live-traffic"], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    roof = json.loads(r.stdout.strip().splitlines()[-1])["roofline"]
+    assert "NOT collected in this run" in roof["traffic_source"] and roof["traffic"] == roof["traffic_committed"]

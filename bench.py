@@ -144,7 +144,7 @@ def live_traffic(a):
             d = os.path.join(tmp, ctr)
             try:
                 r = subprocess.run([exe, "--pmc", ctr, "--output-format", "csv", "-d", d, "-o", "t", "--"] + child, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"),
-                                   stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=150)
+                                   stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=90)
             except subprocess.TimeoutExpired:
                 return None, {"skipped": f"the {ctr} pass timed out"}
             rows = []
